@@ -1,0 +1,479 @@
+"""CPU oracle for the PPO / DAgger learner hot path.  TEST INFRASTRUCTURE ONLY.
+
+This is a from-scratch restatement (plain PyTorch on CPU, fp32) of the
+algorithm the reference implements on the path BASELINE.json names.  It is the
+checker for `tests/`, `__graft_entry__.smoke()` and `bench.py`'s
+`cpu_baseline` leg, and nothing else: the product package `partmanip_amd`
+never imports it (tests/test_no_oracle_in_product.py enforces that).
+
+Parity status: PINNED for GAE, PPO update (MLP and PointNet backbones), the
+actor-critic heads, the mini-batch sampler and the DAgger update -- each is
+checked in tests/test_oracle_golden.py against fixtures produced by running
+the reference itself (tests/golden/make_golden.py).  The point-set operators
+at the bottom (farthest point sampling, ball query, grouping, PointNet++ set
+abstraction) have NO implementation in the reference tree (SURVEY.md §8a A15,
+A16: the only FPS is a call into un-vendored, unpinned pytorch3d) -- for those
+this file is "parity unpinned": it restates the published algorithms
+(pytorch3d `sample_farthest_points` defaults; Qi et al. PointNet++ ball query).
+
+Each function cites the reference lines it follows (paths relative to
+/root/reference).
+"""
+import math
+
+import numpy as np
+import torch
+
+LN2PI = math.log(2.0 * math.pi)
+
+
+# =============================================================================
+# storage.py
+# =============================================================================
+def gae_returns(rewards, values, dones, succs, last_values, gamma, lam, succ_value=None,
+                whole_adv_norm=False):
+    """algorithms/algo_utils/storage.py:96-114 (`RolloutStorage.compute_returns`).
+
+    rewards/values (T,N,1) f32, dones/succs (T,N,1) bool, last_values (N,1).
+    Returns (returns, advantages), both (T,N,1) f32.
+    """
+    T = rewards.shape[0]
+    returns = torch.zeros_like(rewards)
+    advantage = 0
+    for step in reversed(range(T)):
+        next_values = last_values if step == T - 1 else values[step + 1]
+        not_terminal = ~dones[step]
+        delta = rewards[step] + gamma * next_values - values[step]
+        advantage = not_terminal * (delta + gamma * lam * advantage)
+        if succ_value is not None:
+            returns[step] = (~succs[step]) * (advantage + values[step]) + succs[step] * succ_value
+        else:
+            returns[step] = advantage + values[step]
+    advantages = returns - values
+    if whole_adv_norm:
+        advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+    return returns, advantages
+
+
+def minibatch_size(cur_buf_size, num_mini_batches):
+    """storage.py:126-127: the 2048 cap."""
+    return min(int(cur_buf_size // num_mini_batches), 2048)
+
+
+def minibatch_index_lists(cur_buf_size, num_mini_batches, sampler):
+    """One pass over storage.py:125-138's BatchSampler (drop_last=True).
+
+    'random' draws `torch.randperm(n)` from the GLOBAL torch RNG exactly like
+    SubsetRandomSampler.__iter__ does.
+    """
+    mb = minibatch_size(cur_buf_size, num_mini_batches)
+    if sampler == "sequential":
+        order = list(range(cur_buf_size))
+    elif sampler == "random":
+        order = torch.randperm(cur_buf_size).tolist()
+    else:
+        raise ValueError(sampler)
+    return [order[i * mb:(i + 1) * mb] for i in range(cur_buf_size // mb)] if mb > 0 else []
+
+
+def dagger_ring_insert(ring_obs, ring_tea, mix_buf_ind, cur_buf_size, stu_obs, tea_obs):
+    """storage.py:84-91 (`add_transitions_dagger`); returns new (mix_buf_ind, cur_buf_size)."""
+    n = stu_obs.shape[0]
+    ring_obs[mix_buf_ind:mix_buf_ind + n].copy_(stu_obs)
+    ring_tea[mix_buf_ind:mix_buf_ind + n].copy_(tea_obs)
+    cap = ring_obs.shape[0]
+    mix_buf_ind = (mix_buf_ind + n) % cap
+    if cur_buf_size < cap:
+        cur_buf_size += n
+    return mix_buf_ind, cur_buf_size
+
+
+# =============================================================================
+# network.py
+# =============================================================================
+def _act(name, x):
+    if name == "tanh":
+        return torch.tanh(x)
+    if name in ("relu", "crelu"):
+        return torch.relu(x)
+    if name == "elu":
+        return torch.nn.functional.elu(x)
+    if name == "selu":
+        return torch.selu(x)
+    if name == "lrelu":
+        return torch.nn.functional.leaky_relu(x)
+    if name == "sigmoid":
+        return torch.sigmoid(x)
+    raise ValueError(name)
+
+
+def _lin(p, prefix, x):
+    return torch.nn.functional.linear(x, p[prefix + ".weight"], p[prefix + ".bias"])
+
+
+def mlp_forward(p, prefix, net_cfg, x):
+    """network.py:27-54: Linear-act-...-Linear (no act after the last)."""
+    n = len(net_cfg["hid_dim"]) + 1
+    for i in range(n):
+        x = _lin(p, f"{prefix}.model.{2 * i}", x)
+        if i < n - 1:
+            x = _act(net_cfg["activation"], x)
+    return x
+
+
+def pointnet_forward(p, prefix, net_cfg, x, proprio_shape=0, point_num=1024):
+    """network.py:165-198.  `sub_mean` re-centres xyz per cloud (out of place here;
+    the reference does it in place on its input view, network.py:172-173)."""
+    B = x.shape[0]
+    if proprio_shape != 0:
+        proprio = x[:, -proprio_shape:]
+        pc = x[:, :-proprio_shape].reshape(B, point_num, -1)
+    else:
+        pc = x.reshape(B, point_num, -1)
+    if net_cfg.get("sub_mean", False):
+        pc = torch.cat([pc[..., :3] - pc[..., :3].mean(dim=1, keepdim=True), pc[..., 3:]], dim=-1)
+    a = net_cfg["activation"]
+    h = _act(a, _lin(p, f"{prefix}.mlp.0", pc))
+    h = _act(a, _lin(p, f"{prefix}.mlp.2", h))
+    h = _lin(p, f"{prefix}.mlp.4", h)
+    if net_cfg["max_mean"]:
+        f = torch.cat((h.max(dim=1)[0], h.mean(dim=1)), dim=-1)
+    else:
+        f = h.max(dim=1)[0]
+    if proprio_shape != 0:
+        f = torch.cat((f, proprio), dim=-1)
+    f = _act(a, _lin(p, f"{prefix}.final_mlp.0", f))
+    f = _act(a, _lin(p, f"{prefix}.final_mlp.2", f))
+    return _lin(p, f"{prefix}.final_mlp.4", f)
+
+
+def net_forward(p, prefix, net_cfg, x, proprio_shape=0):
+    """actor_critic.py:16,19: backbone chosen by `net_cfg['name']`."""
+    if net_cfg["name"] == "MLP":
+        return mlp_forward(p, prefix, net_cfg, x)
+    if net_cfg["name"] == "PointNet":
+        return pointnet_forward(p, prefix, net_cfg, x, proprio_shape)
+    raise ValueError(net_cfg["name"])
+
+
+# =============================================================================
+# actor_critic.py
+# =============================================================================
+def action_activation(a, activate, max_action):
+    """actor_critic.py:84-91."""
+    return torch.tanh(a) * max_action if activate == "tanh" else a
+
+
+def action_deactivation(a, activate, max_action):
+    """actor_critic.py:93-100."""
+    if activate == "tanh":
+        return torch.atanh(torch.clamp(a / max_action, max=1 - 1e-5, min=-1 + 1e-5))
+    return a
+
+
+def gaussian_logp_entropy(mu, log_std, x):
+    """actor_critic.py:74-78: MultivariateNormal(mu, scale_tril=diag(exp(log_std)^2)).
+
+    The Cholesky factor handed over is sigma^2, so the effective per-dim std is
+    sigma^2 = exp(2*log_std) (verified against the reference
+    in tests/test_oracle_golden.py via the fwd_logp/fwd_entropy fixtures).
+    """
+    s = torch.exp(log_std) * torch.exp(log_std)
+    z = (x - mu) / s
+    A = mu.shape[-1]
+    logp = -0.5 * (z * z).sum(-1) - torch.log(s).sum() - 0.5 * A * LN2PI
+    ent = 0.5 * A * (1.0 + LN2PI) + torch.log(s).sum()
+    return logp, ent.expand(mu.shape[0])
+
+
+def update_act_cri(p, model_cfg, obs, actions, proprio_shape=0):
+    """actor_critic.py:71-82 -> (log_prob (B,), entropy (B,), value (B,1), mu (B,A), log_std rows (B,A))."""
+    net = model_cfg["network"]
+    mu = net_forward(p, "actor", net, obs, proprio_shape)
+    x = action_deactivation(actions, model_cfg["action_activate"], model_cfg["clipAction"])
+    logp, ent = gaussian_logp_entropy(mu, p["log_std"], x)
+    value = net_forward(p, "critic", net, obs, proprio_shape)
+    return logp, ent, value, mu, p["log_std"].repeat(mu.shape[0], 1)
+
+
+def act(p, model_cfg, obs, proprio_shape=0):
+    """actor_critic.py:58-60 (deterministic, tanh-squashed)."""
+    mu = net_forward(p, "actor", model_cfg["network"], obs, proprio_shape)
+    return action_activation(mu.detach(), model_cfg["action_activate"], model_cfg["clipAction"])
+
+
+# =============================================================================
+# optimiser pieces the reference takes from torch (restated explicitly)
+# =============================================================================
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ as called at ppo.py:351,381 (L2, eps 1e-6)."""
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads]))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return total
+
+
+class Adam:
+    """torch.optim.Adam defaults (betas .9/.999, eps 1e-8, no weight decay), single-tensor
+    CPU path: lerp for m, addcmul for v, `denom = sqrt(v)/sqrt(bc2) + eps`, step lr/bc1."""
+
+    def __init__(self, params, lr, b1=0.9, b2=0.999, eps=1e-8):
+        self.params, self.lr, self.b1, self.b2, self.eps = list(params), lr, b1, b2, eps
+        self.m = [torch.zeros_like(q) for q in self.params]
+        self.v = [torch.zeros_like(q) for q in self.params]
+        self.t = [0 for _ in self.params]
+        self.lrs = [lr for _ in self.params]      # per-param lr (param groups)
+
+    def step(self, grads):
+        with torch.no_grad():
+            for i, (q, g) in enumerate(zip(self.params, grads)):
+                if g is None:
+                    continue
+                self.t[i] += 1
+                t = self.t[i]
+                self.m[i].lerp_(g, 1 - self.b1)
+                self.v[i].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+                bc1 = 1 - self.b1 ** t
+                bc2 = 1 - self.b2 ** t
+                denom = (self.v[i].sqrt() / math.sqrt(bc2)).add_(self.eps)
+                q.addcdiv_(self.m[i], denom, value=-(self.lrs[i] / bc1))
+
+
+# =============================================================================
+# ppo.py
+# =============================================================================
+def actor_loss_terms(logp, mu, log_std_rows, old_logp, adv, old_mu, old_sigma, eps_clip, mini_adv_norm):
+    """ppo.py:327-344: (kl_mean, surrogate_loss) on one mini-batch."""
+    if mini_adv_norm:
+        adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+    kl = torch.sum(log_std_rows - old_sigma + (torch.square(old_sigma.exp()) + torch.square(old_mu - mu))
+                   / (2.0 * torch.square(log_std_rows.exp())) - 0.5, axis=-1)
+    kl_mean = torch.mean(kl)
+    ratio = torch.exp(logp - torch.squeeze(old_logp))
+    s1 = -torch.squeeze(adv) * ratio
+    s2 = -torch.squeeze(adv) * torch.clamp(ratio, 1.0 - eps_clip, 1.0 + eps_clip)
+    return kl_mean, torch.max(s1, s2).mean()
+
+
+def value_loss_fn(value, returns, old_values, eps_clip, clipped):
+    """ppo.py:368-374."""
+    if clipped:
+        with torch.no_grad():
+            d = (eps_clip * old_values).abs().mean()
+            tgt = old_values + (returns - old_values).clamp(-d, d)
+        return (value - tgt).pow(2).mean()
+    return (returns - value).pow(2).mean()
+
+
+def split_params(p):
+    actor = [k for k in p if k.startswith("actor.")]
+    critic = [k for k in p if k.startswith("critic.")]
+    return actor, critic
+
+
+def ppo_update(p, st, cfg, it, opt=None, grad_sync=None):
+    """ppo.py:307-411 on explicit tensors.
+
+    p   : dict name -> leaf tensor (ActorCritic.state_dict() layout), updated in place.
+    st  : dict with flat-able rollout tensors (observations, actions, values, returns,
+          actions_log_prob, advantages, mu, sigma), shapes (T,N,.).
+    cfg : ppo.yaml-style dict (n_updates, n_minibatches, sampler, desired_kl, epsilon_clip,
+          tricks, lr, lr_schedule, max_iterations, model).
+    opt : optional (adam_actor, adam_critic) to continue from; created if None.
+    grad_sync : optional callable(list_of_grads, list_of_scalars)->None used by the
+          multi-process parity tests to average grads/scalars across ranks.
+    Returns dict(log=..., loss_trace=[...], opt=(adam_actor, adam_critic)).
+    """
+    tricks, model_cfg = cfg["tricks"], cfg["model"]
+    ak, ck = split_params(p)
+    for k in p:
+        p[k].requires_grad_(True)
+    if opt is None:
+        opt = (Adam([p[k] for k in ak] + [p["log_std"]], cfg["lr"]), Adam([p[k] for k in ck], cfg["lr"]))
+    adam_a, adam_c = opt
+    flat = {k: v.reshape(-1, v.shape[-1]) for k, v in st.items()}
+    n = flat["observations"].shape[0]
+    sampler = cfg["sampler"]
+    seq_lists = minibatch_index_lists(n, cfg["n_minibatches"], "sequential") if sampler == "sequential" else None
+    trace, sum_surr, sum_kl, kl_max, count, sum_v, n_v = [], 0.0, 0.0, 0.0, 0, 0.0, 0
+
+    for _ in range(cfg["n_updates"]):
+        lists = seq_lists if seq_lists is not None else minibatch_index_lists(n, cfg["n_minibatches"], sampler)
+        for idx in lists:
+            logp, _, _, mu, ls = update_act_cri(p, model_cfg, flat["observations"][idx], flat["actions"][idx],
+                                                cfg.get("proprio_shape", 0))
+            kl_mean, loss = actor_loss_terms(logp, mu, ls, flat["actions_log_prob"][idx], flat["advantages"][idx],
+                                             flat["mu"][idx], flat["sigma"][idx], cfg["epsilon_clip"],
+                                             tricks["mini_adv_norm"])
+            kl_mean = kl_mean.detach()
+            if grad_sync is not None:
+                kl_mean = grad_sync.mean_scalar(kl_mean)
+            if float(kl_mean) > kl_max:
+                kl_max = float(kl_mean)
+            if float(kl_mean) > cfg["desired_kl"]:
+                continue
+            gp = [p[k] for k in ak] + [p["log_std"]]
+            grads = list(torch.autograd.grad(loss, gp))
+            if grad_sync is not None:
+                grad_sync.mean_grads(grads)
+            if tricks["use_grad_clip"]:
+                clip_grad_norm(grads[:-1], tricks["max_grad_norm"])     # log_std is NOT clipped (ppo.py:351)
+            adam_a.step(grads)
+            trace.append(float(loss))
+            sum_surr += float(loss)
+            sum_kl += float(kl_mean)
+            count += 1
+
+    for _ in range(cfg["n_updates"]):
+        lists = seq_lists if seq_lists is not None else minibatch_index_lists(n, cfg["n_minibatches"], sampler)
+        for idx in lists:
+            value = net_forward(p, "critic", model_cfg["network"], flat["observations"][idx],
+                                cfg.get("proprio_shape", 0))
+            loss = value_loss_fn(value, flat["returns"][idx], flat["values"][idx], cfg["epsilon_clip"],
+                                 tricks["use_clipped_value_loss"])
+            grads = list(torch.autograd.grad(loss, [p[k] for k in ck]))
+            if grad_sync is not None:
+                grad_sync.mean_grads(grads)
+            if tricks["use_grad_clip"]:
+                clip_grad_norm(grads, tricks["max_grad_norm"])
+            adam_c.step(grads)
+            trace.append(float(loss))
+            sum_v += float(loss)
+            n_v += 1
+
+    lr_now = adam_a.lrs[0]
+    if cfg["lr_schedule"] == "linear_decay":
+        lr_now = max(cfg["lr"] * (1 - it / cfg["max_iterations"]), 1e-5)
+    elif cfg["lr_schedule"] == "step_decay":
+        lr_now = 1e-5 if it > cfg["max_iterations"] // 2 else cfg["lr"]
+    adam_a.lrs = [lr_now for _ in adam_a.lrs]                     # actor optimiser only (ppo.py:392,399)
+    log = {
+        "Train/value_gt_return_mean": float(st["returns"].mean()),
+        "Train/value_gt_return_max": float(st["returns"].max()),
+        "Train/learning_rate": lr_now,
+        "Train/value_function_loss": sum_v / n_v,
+        "Train/surrogate_loss": sum_surr / count,        # ZeroDivisionError if every mb was skipped, as ppo.py:387
+        "Train/kl": sum_kl / count,
+        "Train/kl_max": kl_max,
+        "Train/kl_update_count": count,
+    }
+    for k in p:
+        p[k].requires_grad_(False)
+    return dict(log=log, loss_trace=trace, opt=opt)
+
+
+# =============================================================================
+# dagger.py
+# =============================================================================
+def dagger_update(stu, tea, ring_obs, ring_tea, cur_buf_size, cfg, it, opt=None):
+    """dagger.py:299-337.  `stu`/`tea`: state dicts; cfg has model (student), tea_model,
+    n_updates, n_minibatches, sampler, lr, lr_schedule, max_iterations, proprio_shape."""
+    if cur_buf_size < 16:
+        return None
+    for k in stu:
+        stu[k].requires_grad_(True)
+    names = list(stu.keys())
+    # dagger.py:56: Adam over student.parameters() = log_std, actor.*, critic.* (module order)
+    if opt is None:
+        opt = Adam([stu[k] for k in names], cfg["lr"])
+    trace = []
+    for _ in range(cfg["n_updates"]):
+        for idx in minibatch_index_lists(cur_buf_size, cfg["n_minibatches"], cfg["sampler"]):
+            with torch.no_grad():
+                tea_act = act(tea, cfg["tea_model"], ring_tea[idx])
+            mu = net_forward(stu, "actor", cfg["model"]["network"], ring_obs[idx], cfg.get("proprio_shape", 0))
+            stu_act = action_activation(mu, cfg["model"]["action_activate"], cfg["model"]["clipAction"])
+            loss = (tea_act - stu_act).pow(2).mean()
+            grads = torch.autograd.grad(loss, [stu[k] for k in names], allow_unused=True)
+            opt.step(list(grads))
+            trace.append(float(loss))
+    lr_now = opt.lrs[0]
+    if cfg["lr_schedule"] == "linear_decay":
+        lr_now = cfg["lr"] * max(1 - it / cfg["max_iterations"] * 1.8, 0.1)
+    elif cfg["lr_schedule"] != "fixed":
+        raise NotImplementedError
+    opt.lrs = [lr_now for _ in opt.lrs]
+    for k in stu:
+        stu[k].requires_grad_(False)
+    return dict(log={"Train/learning_rate": lr_now, "Train/dagger_loss": sum(trace) / len(trace)},
+                loss_trace=trace, opt=opt)
+
+
+# =============================================================================
+# RMS.py (rollout side, "next" row)
+# =============================================================================
+class RunningMeanStd:
+    """RMS.py:3-34."""
+
+    def __init__(self, shape):
+        self.n = 0
+        self.mean = torch.zeros((1, shape))
+        self.S = torch.ones((1, shape)) * 1e-4
+        self.std = torch.sqrt(self.S)
+
+    def update(self, x):
+        self.n += 1
+        old = self.mean.clone()
+        new = x.mean(dim=0, keepdim=True)
+        self.mean = old + (new - old) / self.n
+        self.S = self.S + (x - new).pow(2).mean(dim=0, keepdim=True) + (old - new).pow(2) * (self.n - 1) / self.n
+        self.std = torch.sqrt(self.S / self.n)
+
+
+# =============================================================================
+# Point-set operators -- PARITY UNPINNED (no implementation in the reference tree)
+# =============================================================================
+def fps(points, K, lengths=None):
+    """Farthest point sampling, pytorch3d `sample_farthest_points` defaults as called at
+    utils/depth2tsdf.py:113,160: start index 0, squared-L2 running-min distance, next =
+    argmax with lowest-index tie-break.  points (B,P,D) float32 -> idx (B,K) int64.
+    If K > length the tail is padded with -1 (pytorch3d semantics)."""
+    pts = np.asarray(points, dtype=np.float32)
+    B, P, _ = pts.shape
+    out = np.full((B, K), -1, dtype=np.int64)
+    for b in range(B):
+        n = P if lengths is None else int(lengths[b])
+        if n == 0:
+            continue
+        mind = np.full((n,), np.inf, dtype=np.float32)
+        sel = 0
+        for j in range(min(K, n)):
+            out[b, j] = sel
+            d = pts[b, :n] - pts[b, sel]
+            d2 = np.zeros((n,), dtype=np.float32)
+            for c in range(d.shape[1]):              # fixed left-to-right fp32 accumulation order
+                d2 = d2 + d[:, c] * d[:, c]
+            mind = np.minimum(mind, d2)
+            sel = int(np.argmax(mind))
+    return out
+
+
+def ball_query(xyz, centers, radius, nsample):
+    """PointNet++ ball query: for each centre the first `nsample` point indices (ascending
+    index order) with squared distance < radius^2, padded with the first hit; if no point
+    qualifies the row is all 0.  xyz (B,P,3), centers (B,S,3) -> idx (B,S,nsample) int32."""
+    xyz = np.asarray(xyz, dtype=np.float32)
+    ctr = np.asarray(centers, dtype=np.float32)
+    B, P, _ = xyz.shape
+    S = ctr.shape[1]
+    r2 = np.float32(radius) * np.float32(radius)
+    out = np.zeros((B, S, nsample), dtype=np.int32)
+    for b in range(B):
+        for s in range(S):
+            d = xyz[b] - ctr[b, s]
+            d2 = d[:, 0] * d[:, 0]
+            d2 = d2 + d[:, 1] * d[:, 1]
+            d2 = d2 + d[:, 2] * d[:, 2]
+            hit = np.nonzero(d2 < r2)[0][:nsample]
+            if len(hit):
+                out[b, s, :] = hit[0]
+                out[b, s, :len(hit)] = hit
+    return out
+
+
+def group_points(feat, idx):
+    """Gather: feat (B,P,C), idx (B,S,ns) -> (B,S,ns,C)."""
+    feat = np.asarray(feat)
+    B = feat.shape[0]
+    return np.stack([feat[b][idx[b]] for b in range(B)], axis=0)

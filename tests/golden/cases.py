@@ -1,0 +1,145 @@
+"""Golden-case definitions shared by `make_golden.py` (runs the reference in the
+dev container) and the parity tests (which run the oracle / the HIP path).
+
+Pure data + deterministic input builders; nothing here imports the reference.
+Hyper-parameter names follow the reference's yaml (cfg/algos/ppo.yaml:1-48,
+cfg/algos/dagger_tsdf.yaml:1-38).
+"""
+import copy
+import numpy as np
+
+from .detgen import det_uniform, det_normal, det_bernoulli, linear_init
+
+TRICKS_DEFAULT = dict(mini_adv_norm=False, whole_adv_norm=False, use_state_norm=False,
+                      use_clipped_value_loss=False, use_grad_clip=True, max_grad_norm=0.5)
+TRICKS_ALLON = dict(mini_adv_norm=True, whole_adv_norm=True, use_state_norm=False,
+                    use_clipped_value_loss=True, use_grad_clip=True, max_grad_norm=0.5)
+TRICKS_NOCLIP = dict(mini_adv_norm=False, whole_adv_norm=False, use_state_norm=False,
+                     use_clipped_value_loss=False, use_grad_clip=False, max_grad_norm=0.5)
+
+GAE_CASES = {
+    "gae_none":      dict(T=16, N=8, succ_value=None, whole_adv_norm=False, seed=11),
+    "gae_500":       dict(T=16, N=8, succ_value=500, whole_adv_norm=False, seed=12),
+    "gae_none_norm": dict(T=16, N=8, succ_value=None, whole_adv_norm=True, seed=13),
+    "gae_500_norm":  dict(T=16, N=8, succ_value=500, whole_adv_norm=True, seed=14),
+    "gae_T1":        dict(T=1, N=5, succ_value=0, whole_adv_norm=False, seed=15),
+    "gae_ragged":    dict(T=37, N=131, succ_value=None, whole_adv_norm=True, seed=16),
+}
+
+_MLP_NET = dict(name="MLP", hid_dim=[64, 64, 64], activation="tanh")
+_PN_NET = dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False)
+_PN_NET_MAX = dict(name="PointNet", activation="tanh", max_mean=False, sub_mean=False)
+
+
+def _ppo(net, N, T, O, n_mb, n_up, tricks, sampler="sequential", succ_value=None,
+         lr=3e-3, desired_kl=0.1, lr_schedule="fixed", seed=100, old_noise=0.05, A=10, noise_ramp=False):
+    return dict(net=net, N=N, T=T, O=O, A=A, n_minibatches=n_mb, n_updates=n_up, tricks=tricks,
+                sampler=sampler, succ_value=succ_value, lr=lr, desired_kl=desired_kl,
+                lr_schedule=lr_schedule, seed=seed, old_noise=old_noise, noise_ramp=noise_ramp,
+                gamma=0.99, lam=0.95, epsilon_clip=0.2, action_std=0.5, max_iterations=1000, it=7)
+
+
+PPO_CASES = {
+    "ppo_mlp_default": _ppo(_MLP_NET, 8, 16, 32, 4, 2, TRICKS_DEFAULT, seed=101),
+    "ppo_mlp_allon":   _ppo(_MLP_NET, 8, 16, 32, 4, 2, TRICKS_ALLON, succ_value=500, seed=102,
+                            lr_schedule="linear_decay"),
+    "ppo_mlp_noclip":  _ppo(_MLP_NET, 8, 16, 32, 4, 2, TRICKS_NOCLIP, seed=103, lr_schedule="step_decay"),
+    "ppo_mlp_random":  _ppo(_MLP_NET, 8, 16, 32, 4, 2, TRICKS_DEFAULT, sampler="random", seed=104),
+    # some mini-batches exceed desired_kl and must be skipped (ppo.py:337-338)
+    "ppo_mlp_klskip":  _ppo(_MLP_NET, 8, 16, 32, 4, 2, TRICKS_DEFAULT, seed=105, old_noise=0.2, noise_ramp=True, lr=1e-3),
+    # drop_last with a ragged tail: 7*9=63 samples, 4 mini-batches of 15, 3 samples dropped
+    "ppo_mlp_ragged":  _ppo(_MLP_NET, 7, 9, 19, 4, 3, TRICKS_ALLON, seed=106, A=7),
+    "ppo_pn_maxmean":  _ppo(_PN_NET, 4, 4, 3072, 2, 2, TRICKS_DEFAULT, seed=107, lr=2e-4, old_noise=0.02),
+    "ppo_pn_max":      _ppo(_PN_NET_MAX, 4, 4, 3072, 2, 2, TRICKS_ALLON, seed=108, lr=2e-4, old_noise=0.02),
+}
+
+DAGGER_CASES = {
+    # student MLP on a 40-d obs, teacher MLP on a 32-d state
+    "dagger_mlp": dict(stu_net=_MLP_NET, tea_net=_MLP_NET, N=8, buf_size=6, n_fill=8, O_s=40, O_t=32,
+                       proprio=0, A=10, n_minibatches=3, n_updates=2, lr=3e-3, lr_schedule="linear_decay",
+                       sampler="random", seed=201, action_std=0.1, max_iterations=1000, it=5, torch_seed=77),
+    # student PointNet (+7-d proprio appended), teacher MLP
+    "dagger_pn":  dict(stu_net=_PN_NET, tea_net=_MLP_NET, N=4, buf_size=5, n_fill=4, O_s=3072 + 7, O_t=32,
+                       proprio=7, A=10, n_minibatches=2, n_updates=2, lr=1e-3, lr_schedule="fixed",
+                       sampler="sequential", seed=202, action_std=0.1, max_iterations=1000, it=5, torch_seed=78),
+}
+
+
+# --------------------------------------------------------------------------- inputs
+def gae_inputs(c):
+    T, N, s = c["T"], c["N"], c["seed"] * 1000
+    rewards = det_normal((T, N, 1), s + 1)
+    values = det_normal((T, N, 1), s + 2)
+    last_values = det_normal((N, 1), s + 3)
+    dones = det_bernoulli((T, N, 1), s + 4, 0.15)
+    succs = dones & det_bernoulli((T, N, 1), s + 5, 0.5)
+    return dict(rewards=rewards, values=values, last_values=last_values, dones=dones, succs=succs)
+
+
+def net_param_shapes(net, in_dim, out_dim, proprio=0):
+    """[(state_dict key suffix, (out,in))] in module order (network.py:31-41,147-160)."""
+    if net["name"] == "MLP":
+        dims = [in_dim] + list(net["hid_dim"]) + [out_dim]
+        return [(f"model.{2 * i}", (dims[i + 1], dims[i])) for i in range(len(dims) - 1)]
+    if net["name"] == "PointNet":
+        c = (in_dim - proprio) // 1024
+        feat = 512 * (2 if net["max_mean"] else 1) + proprio
+        return [("mlp.0", (128, c)), ("mlp.2", (256, 128)), ("mlp.4", (512, 256)),
+                ("final_mlp.0", (128, feat)), ("final_mlp.2", (32, 128)), ("final_mlp.4", (out_dim, 32))]
+    raise KeyError(net["name"])
+
+
+def actor_critic_state(net, in_dim, A, action_std, seed, proprio=0):
+    """Deterministic initial `ActorCritic.state_dict()` (numpy float32), keys as actor_critic.py:16-22."""
+    sd = {"log_std": np.full((A,), np.log(action_std), dtype=np.float32)}
+    for which, out_dim, s0 in (("actor", A, seed * 100), ("critic", 1, seed * 100 + 50)):
+        shapes = net_param_shapes(net, in_dim, out_dim, proprio)
+        for li, (key, (o, i)) in enumerate(shapes):
+            gain = 1.0
+            if li == len(shapes) - 1 and which == "actor":
+                gain = 0.3   # small policy head, like the reference's 0.01-gain orthogonal init
+            w, b = linear_init(o, i, s0 + li, gain)
+            sd[f"{which}.{key}.weight"] = w
+            sd[f"{which}.{key}.bias"] = b
+    return sd
+
+
+def ppo_raw_inputs(c):
+    """Rollout tensors that do not depend on the policy (obs, actions, rewards, masks)."""
+    T, N, O, A, s = c["T"], c["N"], c["O"], c["A"], c["seed"] * 1000
+    if c["net"]["name"] == "PointNet":
+        pts = det_uniform((T, N, 1024, O // 1024), s + 1, -1.0, 1.0)
+        shift = det_uniform((T, N, 1, O // 1024), s + 9, -0.5, 0.5)
+        obs = (pts + shift).reshape(T, N, O).astype(np.float32)
+    else:
+        obs = det_normal((T, N, O), s + 1)
+    actions = det_uniform((T, N, A), s + 2, -0.999, 0.999)
+    actions.reshape(-1)[::17] = 1.0      # saturated actions exercise the atanh clamp (actor_critic.py:95)
+    actions.reshape(-1)[5::23] = -1.0
+    rewards = det_normal((T, N, 1), s + 3)
+    dones = det_bernoulli((T, N, 1), s + 4, 0.1)
+    succs = dones & det_bernoulli((T, N, 1), s + 5, 0.5)
+    noise = dict(values=det_normal((T, N, 1), s + 6), logp=det_normal((T, N, 1), s + 7),
+                 mu=det_normal((T, N, A), s + 8), sigma=det_normal((T, N, A), s + 10),
+                 last_values=det_normal((N, 1), s + 11))
+    return dict(observations=obs, actions=actions, rewards=rewards, dones=dones, succs=succs, noise=noise)
+
+
+def dagger_raw_inputs(c):
+    s = c["seed"] * 1000
+    N, nf = c["N"], c["n_fill"]
+    stu, tea = [], []
+    for k in range(nf):
+        if c["stu_net"]["name"] == "PointNet":
+            npc = c["O_s"] - c["proprio"]
+            pts = det_uniform((N, 1024, npc // 1024), s + 10 * k + 1, -1.0, 1.0).reshape(N, npc)
+            pro = det_normal((N, c["proprio"]), s + 10 * k + 2)
+            stu.append(np.concatenate([pts, pro], axis=1).astype(np.float32))
+        else:
+            stu.append(det_normal((N, c["O_s"]), s + 10 * k + 1))
+        tea.append(det_normal((N, c["O_t"]), s + 10 * k + 3))
+    return dict(stu=stu, tea=tea)
+
+
+def case_copy(c):
+    return copy.deepcopy(c)

@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Dev-container only: imports `/root/reference` (read-only mount) with three
+`sys.modules` stubs and drives the reference's own
+`RolloutStorage.compute_returns`, `ppo.update`, `dagger.update`,
+`ActorCritic.update_act_cri` and `mini_batch_generator` on the deterministic
+inputs of `cases.py`.  Only inputs/outputs (data) are written; no reference
+source travels.  Run:  python -m tests.golden.make_golden   (from the repo root)
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    utils = types.ModuleType("utils")
+    utils.__path__ = []
+    utils.path2video = lambda *a, **k: None
+    sys.modules["utils"] = utils
+    sys.modules["utils.torch_jit_utils"] = types.ModuleType("utils.torch_jit_utils")
+    sys.modules["torchvision"] = types.ModuleType("torchvision")
+    # our own top-level `algorithms` shim must not shadow the reference's package
+    sys.path = [p for p in sys.path if os.path.abspath(p or ".") != os.path.abspath(os.path.join(HERE, "..", ".."))]
+    sys.path.insert(0, REF)
+    for m in [m for m in sys.modules if m == "algorithms" or m.startswith("algorithms.")]:
+        del sys.modules[m]
+    import algorithms  # noqa
+    assert algorithms.__file__.startswith(REF), algorithms.__file__
+    return algorithms
+
+
+class FakeEnv:
+    def __init__(self, num_envs, num_obs, num_actions):
+        self.num_envs, self.num_obs, self.num_actions = num_envs, num_obs, num_actions
+        self.max_episode_length = 200
+
+
+class FakeLogger:
+    def __init__(self, d):
+        self.save_ckpt_dir = d
+
+
+def ppo_cfg(c, num_envs, obs_mode="normal_state"):
+    return dict(num_envs=num_envs, obs_mode=obs_mode, succ_value=c.get("succ_value"),
+                model=dict(action_std=c["action_std"], action_activate="tanh", clipAction=1.0,
+                           network=dict(c["net"])),
+                max_iterations=c["max_iterations"], n_steps=c["T"], n_updates=c["n_updates"],
+                n_minibatches=c["n_minibatches"], device="cpu", eval_round=1, eval_frequence=10 ** 9,
+                save_frequence=10 ** 9, test_only=False, save_pose=False, save_video=False,
+                lr_schedule=c["lr_schedule"], lr=c["lr"], desired_kl=c["desired_kl"],
+                epsilon_clip=c["epsilon_clip"], gamma=c["gamma"], lam=c["lam"], tricks=dict(c["tricks"]),
+                sampler=c["sampler"], resume=None)
+
+
+def load_sd(module, sd_np):
+    module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+
+
+def flat_params(sd):
+    return np.concatenate([v.detach().cpu().numpy().reshape(-1).astype(np.float32) for v in sd.values()])
+
+
+class Trace:
+    """Records every `loss.backward()` value and a float64 checksum after every optimiser step."""
+
+    def __init__(self, params_fn):
+        self.losses, self.sums = [], []
+        self.params_fn = params_fn
+
+    def __enter__(self):
+        self._bw = torch.Tensor.backward
+        tr = self
+
+        def bw(t, *a, **k):
+            tr.losses.append(float(t.detach()))
+            return tr._bw(t, *a, **k)
+        torch.Tensor.backward = bw
+        self._step = torch.optim.Adam.step
+
+        def step(opt, *a, **k):
+            r = tr._step(opt, *a, **k)
+            ps = tr.params_fn()
+            tr.sums.append([float(sum(p.detach().double().sum() for p in ps)),
+                            float(sum((p.detach().double() ** 2).sum() for p in ps))])
+            return r
+        torch.optim.Adam.step = step
+        return self
+
+    def __exit__(self, *a):
+        torch.Tensor.backward = self._bw
+        torch.optim.Adam.step = self._step
+
+
+def gen_gae(ref_algos, cases):
+    from algorithms.algo_utils import RolloutStorage
+    for name, c in cases.GAE_CASES.items():
+        inp = cases.gae_inputs(c)
+        T, N = c["T"], c["N"]
+        st = RolloutStorage(N, T, 3, 2, "cpu", c["succ_value"], c["whole_adv_norm"])
+        st.rewards.copy_(torch.from_numpy(inp["rewards"]))
+        st.values.copy_(torch.from_numpy(inp["values"]))
+        st.dones.copy_(torch.from_numpy(inp["dones"]))
+        st.succs.copy_(torch.from_numpy(inp["succs"]))
+        st.compute_returns(torch.from_numpy(inp["last_values"]), 0.99, 0.95)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), returns=st.returns.numpy(),
+                            advantages=st.advantages.numpy())
+        print("wrote", name)
+
+
+def gen_ppo(ref_algos, cases):
+    from algorithms import ppo
+    for name, c in cases.PPO_CASES.items():
+        T, N, O, A = c["T"], c["N"], c["O"], c["A"]
+        env = FakeEnv(N, {"normal_state": O}, A)
+        with tempfile.TemporaryDirectory() as d:
+            run = ppo(env, ppo_cfg(c, N), FakeLogger(d))
+        sd0 = cases.actor_critic_state(c["net"], O, A, c["action_std"], c["seed"])
+        load_sd(run.actor_critic, sd0)
+        raw = cases.ppo_raw_inputs(c)
+        obs = torch.from_numpy(raw["observations"])
+        act = torch.from_numpy(raw["actions"])
+        with torch.no_grad():
+            logp, ent, val, mu, sig = run.actor_critic.update_act_cri(obs.view(-1, O).clone(), act.view(-1, A))
+        nz = raw["noise"]
+        on = c["old_noise"] * (torch.arange(1, T + 1).view(T, 1, 1) / T if c["noise_ramp"] else torch.ones(T, 1, 1))
+        values = val.view(T, N, 1) + 0.5 * torch.from_numpy(nz["values"])
+        old_logp = logp.view(T, N, 1) + on * torch.from_numpy(nz["logp"])
+        old_mu = mu.view(T, N, A) + on * torch.from_numpy(nz["mu"])
+        old_sigma = sig.view(T, N, A) + 0.02 * torch.from_numpy(nz["sigma"])
+        with torch.no_grad():
+            last_values = run.actor_critic.cri(obs[-1].clone()) + 0.5 * torch.from_numpy(nz["last_values"])
+        for t in range(T):
+            run.storage.add_transitions(obs[t], act[t], torch.from_numpy(raw["rewards"][t, :, 0]),
+                                        torch.from_numpy(raw["dones"][t, :, 0]),
+                                        torch.from_numpy(raw["succs"][t, :, 0]),
+                                        values[t], old_logp[t, :, 0], old_mu[t], old_sigma[t])
+        run.storage.compute_returns(last_values, c["gamma"], c["lam"])
+        out = dict(values=values.numpy(), actions_log_prob=old_logp.numpy(), mu=old_mu.numpy(),
+                   sigma=old_sigma.numpy(), last_values=last_values.numpy(),
+                   fwd_logp=logp.numpy(), fwd_entropy=ent.numpy(), fwd_value=val.numpy(), fwd_mu=mu.numpy(),
+                   returns=run.storage.returns.numpy().copy(),
+                   advantages=run.storage.advantages.numpy().copy())
+        if c["sampler"] == "random":
+            torch.manual_seed(c["seed"])
+            gen = run.storage.mini_batch_generator(c["n_minibatches"])
+            out["index_lists"] = np.array([[list(b) for b in gen] for _ in range(2 * c["n_updates"])], dtype=np.int64)
+            torch.manual_seed(c["seed"])
+        else:
+            gen = run.storage.mini_batch_generator(c["n_minibatches"])
+            out["index_lists"] = np.array([[list(b) for b in gen]], dtype=np.int64)
+        run.log_dict = {}
+        with Trace(lambda: list(run.actor_critic.parameters())) as tr:
+            run.update(c["it"])
+        out["loss_trace"] = np.array(tr.losses, dtype=np.float64)
+        out["sum_trace"] = np.array(tr.sums, dtype=np.float64)
+        for k in ("value_function_loss", "surrogate_loss", "kl", "kl_max", "kl_update_count", "learning_rate",
+                  "value_gt_return_mean", "value_gt_return_max"):
+            out["log_" + k] = np.float64(float(run.log_dict["Train/" + k]))
+        out["lr_actor_groups"] = np.array([g["lr"] for g in run.optimizer_actor.param_groups])
+        out["lr_critic_groups"] = np.array([g["lr"] for g in run.optimizer_critic.param_groups])
+        fin = flat_params(run.actor_critic.state_dict())
+        stride = 3 if c["net"]["name"] == "PointNet" else 1
+        out["final_flat"] = fin[::stride]
+        out["final_stride"] = np.int64(stride)
+        out["final_sum"] = np.float64(fin.astype(np.float64).sum())
+        out["final_sq"] = np.float64((fin.astype(np.float64) ** 2).sum())
+        # Adam moments of the policy head (small) pin the optimiser state too
+        st_a = run.optimizer_actor.state_dict()["state"]
+        last = max(k for k in st_a.keys() if st_a[k]["exp_avg"].numel() > 0)
+        out["adam_logstd_m"] = st_a[last]["exp_avg"].numpy()
+        out["adam_logstd_v"] = st_a[last]["exp_avg_sq"].numpy()
+        out["adam_step"] = np.float64(float(st_a[last]["step"]))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print("wrote", name, "losses", len(tr.losses), "count", out["log_kl_update_count"])
+
+
+def gen_dagger(ref_algos, cases):
+    from algorithms import ppo, dagger
+    for name, c in cases.DAGGER_CASES.items():
+        N, A = c["N"], c["A"]
+        with tempfile.TemporaryDirectory() as d:
+            cwd = os.getcwd()
+            os.chdir(d)
+            try:
+                np.save("teacher_reward.npy", np.linspace(0, 1, 200).astype(np.float32))
+                tc = dict(net=c["tea_net"], T=1, n_updates=1, n_minibatches=1, tricks=dict(cases.TRICKS_DEFAULT),
+                          sampler="sequential", succ_value=None, lr=1e-3, desired_kl=0.1, lr_schedule="fixed",
+                          gamma=0.99, lam=0.95, epsilon_clip=0.2, action_std=0.5, max_iterations=10)
+                env_t = FakeEnv(N, {"normal_state": c["O_t"]}, A)
+                tea_run = ppo(env_t, ppo_cfg(tc, N), FakeLogger(d))
+                load_sd(tea_run.actor_critic, cases.actor_critic_state(c["tea_net"], c["O_t"], A, 0.5, c["seed"] + 1))
+                tea_run.save(1)
+                env = FakeEnv(N, {"stu_mode": c["O_s"], "normal_state": c["O_t"], "proprio_state": c["proprio"]}, A)
+                cfg = dict(num_envs=N, obs_mode="stu_mode",
+                           model=dict(action_std=c["action_std"], action_activate="tanh", clipAction=1.0,
+                                      network=dict(c["stu_net"])),
+                           max_iterations=c["max_iterations"], n_steps=1, n_updates=c["n_updates"],
+                           n_minibatches=c["n_minibatches"], device="cpu", buf_size=c["buf_size"],
+                           reward_reset=True, add_proprio_obs=c["proprio"] > 0, offline_data_pth=None,
+                           eval_round=1, eval_frequence=10 ** 9, save_frequence=10 ** 9, test_only=False,
+                           save_pose=False, save_video=False, lr_schedule=c["lr_schedule"], lr=c["lr"],
+                           teacher=os.path.join(d, "model_1.pth"), resume=None, pretrain=None,
+                           sampler=c["sampler"])
+                run = dagger(env, cfg, FakeLogger(d))
+            finally:
+                os.chdir(cwd)
+        load_sd(run.student, cases.actor_critic_state(c["stu_net"], c["O_s"], A, c["action_std"], c["seed"],
+                                                      c["proprio"]))
+        raw = cases.dagger_raw_inputs(c)
+        for k in range(c["n_fill"]):
+            run.storage.add_transitions_dagger(torch.from_numpy(raw["stu"][k]), torch.from_numpy(raw["tea"][k]))
+        out = dict(ring_obs_sum=np.float64(run.storage.observations.double().sum()),
+                   ring_tea=run.storage.tea_obs.numpy().copy(), mix_buf_ind=np.int64(run.storage.mix_buf_ind),
+                   cur_buf_size=np.int64(run.storage.cur_buf_size))
+        with torch.no_grad():
+            out["tea_act"] = run.teacher.act(run.storage.tea_obs).numpy()
+            out["stu_act0"] = run.student.act(run.storage.observations.clone()).numpy()
+        torch.manual_seed(c["torch_seed"])
+        lists = []
+        for _ in range(c["n_updates"]):
+            lists.append([list(b) for b in run.storage.mini_batch_generator(c["n_minibatches"])])
+        out["index_lists"] = np.array(lists, dtype=np.int64)
+        torch.manual_seed(c["torch_seed"])
+        run.log_dict = {}
+        with Trace(lambda: list(run.student.parameters())) as tr:
+            run.update(c["it"])
+        out["loss_trace"] = np.array(tr.losses, dtype=np.float64)
+        out["sum_trace"] = np.array(tr.sums, dtype=np.float64)
+        out["log_dagger_loss"] = np.float64(float(run.log_dict["Train/dagger_loss"]))
+        out["log_learning_rate"] = np.float64(float(run.log_dict["Train/learning_rate"]))
+        fin = flat_params(run.student.state_dict())
+        stride = 3 if c["stu_net"]["name"] == "PointNet" else 1
+        out["final_flat"] = fin[::stride]
+        out["final_stride"] = np.int64(stride)
+        out["final_sum"] = np.float64(fin.astype(np.float64).sum())
+        out["final_sq"] = np.float64((fin.astype(np.float64) ** 2).sum())
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print("wrote", name, "losses", out["loss_trace"])
+
+
+def main():
+    torch.set_num_threads(8)
+    sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+    from tests.golden import cases
+    ref = _import_reference()
+    which = sys.argv[1:] or ["gae", "ppo", "dagger"]
+    if "gae" in which:
+        gen_gae(ref, cases)
+    if "ppo" in which:
+        gen_ppo(ref, cases)
+    if "dagger" in which:
+        gen_dagger(ref, cases)
+
+
+if __name__ == "__main__":
+    main()

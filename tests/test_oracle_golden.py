@@ -1,0 +1,127 @@
+"""Pin the CPU oracle (oracle/ref_cpu.py) to the reference: every golden vector
+captured by running the reference itself (tests/golden/make_golden.py) must be
+reproduced.  CPU-only; no GPU, no /root/reference at run time."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from tests.golden import cases
+from tests.helpers import load_fixture, t, state_dict_t, ppo_cfg, ppo_rollout, flat_state
+
+
+@pytest.mark.parametrize("name", list(cases.GAE_CASES))
+def test_gae_bit_exact(name):
+    c, fx = cases.GAE_CASES[name], load_fixture(name)
+    inp = cases.gae_inputs(c)
+    ret, adv = R.gae_returns(t(inp["rewards"]), t(inp["values"]), t(inp["dones"]), t(inp["succs"]),
+                             t(inp["last_values"]), 0.99, 0.95, c["succ_value"], c["whole_adv_norm"])
+    assert np.array_equal(ret.numpy(), fx["returns"])
+    assert np.array_equal(adv.numpy(), fx["advantages"])
+
+
+@pytest.mark.parametrize("name", list(cases.PPO_CASES))
+def test_actor_critic_forward(name):
+    c, fx = cases.PPO_CASES[name], load_fixture(name)
+    p = state_dict_t(cases.actor_critic_state(c["net"], c["O"], c["A"], c["action_std"], c["seed"]))
+    st = ppo_rollout(c, fx)
+    cfg = ppo_cfg(c)
+    with torch.no_grad():
+        logp, ent, val, mu, ls = R.update_act_cri(p, cfg["model"], st["observations"].view(-1, c["O"]),
+                                                  st["actions"].view(-1, c["A"]))
+    np.testing.assert_allclose(mu.numpy(), fx["fwd_mu"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(val.numpy(), fx["fwd_value"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(logp.numpy(), fx["fwd_logp"], rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(ent.numpy(), fx["fwd_entropy"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", list(cases.PPO_CASES))
+def test_gae_inside_ppo_cases(name):
+    c, fx = cases.PPO_CASES[name], load_fixture(name)
+    st = ppo_rollout(c, fx)
+    ret, adv = R.gae_returns(st["rewards"], st["values"], st["dones"], st["succs"], st["last_values"],
+                             c["gamma"], c["lam"], c["succ_value"], c["tricks"]["whole_adv_norm"])
+    assert np.array_equal(ret.numpy(), fx["returns"])
+    assert np.array_equal(adv.numpy(), fx["advantages"])
+
+
+@pytest.mark.parametrize("name", list(cases.PPO_CASES))
+def test_sampler_lists(name):
+    c, fx = cases.PPO_CASES[name], load_fixture(name)
+    n = c["T"] * c["N"]
+    if c["sampler"] == "random":
+        torch.manual_seed(c["seed"])
+        got = [R.minibatch_index_lists(n, c["n_minibatches"], "random") for _ in range(2 * c["n_updates"])]
+    else:
+        got = [R.minibatch_index_lists(n, c["n_minibatches"], "sequential")]
+    assert np.array_equal(np.array(got, dtype=np.int64), fx["index_lists"])
+
+
+@pytest.mark.parametrize("name", list(cases.PPO_CASES))
+def test_ppo_update(name):
+    c, fx = cases.PPO_CASES[name], load_fixture(name)
+    p = state_dict_t(cases.actor_critic_state(c["net"], c["O"], c["A"], c["action_std"], c["seed"]))
+    st = ppo_rollout(c, fx)
+    st["returns"], st["advantages"] = t(fx["returns"]), t(fx["advantages"])
+    cfg = ppo_cfg(c)
+    if c["sampler"] == "random":
+        torch.manual_seed(c["seed"])
+    out = R.ppo_update(p, {k: st[k] for k in ("observations", "actions", "values", "returns", "actions_log_prob",
+                                             "advantages", "mu", "sigma")}, cfg, c["it"])
+    np.testing.assert_allclose(out["loss_trace"], fx["loss_trace"], rtol=2e-4, atol=2e-6)
+    log = out["log"]
+    assert log["Train/kl_update_count"] == int(fx["log_kl_update_count"])
+    for k in ("value_function_loss", "surrogate_loss", "kl", "kl_max", "learning_rate",
+              "value_gt_return_mean", "value_gt_return_max"):
+        np.testing.assert_allclose(log["Train/" + k], float(fx["log_" + k]), rtol=2e-4, atol=2e-6, err_msg=k)
+    fin = flat_state(p)
+    s = int(fx["final_stride"])
+    np.testing.assert_allclose(fin[::s], fx["final_flat"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(fin.astype(np.float64).sum(), float(fx["final_sum"]), rtol=1e-6, atol=1e-4)
+    adam_a = out["opt"][0]
+    np.testing.assert_allclose(adam_a.m[-1].numpy(), fx["adam_logstd_m"], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(adam_a.v[-1].numpy(), fx["adam_logstd_v"], rtol=1e-3, atol=1e-9)
+    assert adam_a.t[-1] == int(fx["adam_step"])
+    np.testing.assert_allclose([adam_a.lrs[0], adam_a.lrs[-1]], fx["lr_actor_groups"])
+    np.testing.assert_allclose([out["opt"][1].lrs[0]], fx["lr_critic_groups"])
+
+
+@pytest.mark.parametrize("name", list(cases.DAGGER_CASES))
+def test_dagger(name):
+    c, fx = cases.DAGGER_CASES[name], load_fixture(name)
+    A = c["A"]
+    stu = state_dict_t(cases.actor_critic_state(c["stu_net"], c["O_s"], A, c["action_std"], c["seed"], c["proprio"]))
+    tea = state_dict_t(cases.actor_critic_state(c["tea_net"], c["O_t"], A, 0.5, c["seed"] + 1))
+    raw = cases.dagger_raw_inputs(c)
+    cap = c["buf_size"] * c["N"]
+    ring_obs, ring_tea = torch.zeros(cap, c["O_s"]), torch.zeros(cap, c["O_t"])
+    ind, size = 0, 0
+    for k in range(c["n_fill"]):
+        ind, size = R.dagger_ring_insert(ring_obs, ring_tea, ind, size, t(raw["stu"][k]), t(raw["tea"][k]))
+    assert (ind, size) == (int(fx["mix_buf_ind"]), int(fx["cur_buf_size"]))
+    assert np.array_equal(ring_tea.numpy(), fx["ring_tea"])
+    np.testing.assert_allclose(float(ring_obs.double().sum()), float(fx["ring_obs_sum"]), rtol=1e-12)
+    stu_model = dict(action_std=c["action_std"], action_activate="tanh", clipAction=1.0, network=dict(c["stu_net"]))
+    tea_model = dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=dict(c["tea_net"]))
+    with torch.no_grad():
+        np.testing.assert_allclose(R.act(tea, tea_model, ring_tea).numpy(), fx["tea_act"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(R.act(stu, stu_model, ring_obs, c["proprio"]).numpy(), fx["stu_act0"],
+                                   rtol=1e-5, atol=2e-6)
+    torch.manual_seed(c["torch_seed"])
+    lists = [R.minibatch_index_lists(size, c["n_minibatches"], c["sampler"]) for _ in range(c["n_updates"])]
+    assert np.array_equal(np.array(lists, dtype=np.int64), fx["index_lists"])
+    torch.manual_seed(c["torch_seed"])
+    cfg = dict(model=stu_model, tea_model=tea_model, n_updates=c["n_updates"], n_minibatches=c["n_minibatches"],
+               sampler=c["sampler"], lr=c["lr"], lr_schedule=c["lr_schedule"], max_iterations=c["max_iterations"],
+               proprio_shape=c["proprio"])
+    out = R.dagger_update(stu, tea, ring_obs, ring_tea, size, cfg, c["it"])
+    np.testing.assert_allclose(out["loss_trace"], fx["loss_trace"], rtol=2e-4, atol=1e-8)
+    np.testing.assert_allclose(out["log"]["Train/dagger_loss"], float(fx["log_dagger_loss"]), rtol=2e-4)
+    np.testing.assert_allclose(out["log"]["Train/learning_rate"], float(fx["log_learning_rate"]), rtol=1e-12)
+    fin = flat_state(stu)
+    s = int(fx["final_stride"])
+    np.testing.assert_allclose(fin[::s], fx["final_flat"], rtol=0, atol=2e-5)
+
+
+def test_dagger_small_buffer_returns_early():
+    assert R.dagger_update({}, {}, None, None, 15, {}, 1) is None
