@@ -1,0 +1,195 @@
+/*
+ * partmanip_hip.h -- C ABI of libpartmanip_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (PKU-EPIC/PartManip) is 100 % Python on PyTorch and has no FFI
+ * of its own; the boundary it offers is the Python API of
+ * algorithms/ppo.py, algorithms/dagger.py and the algorithms/algo_utils package.
+ * This header is the NEW native boundary underneath that API: every entry
+ * point replaces the ATen work one reference call site dispatches (cited per
+ * function as file:line under /root/reference).  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless
+ *     the name ends in _host; no torch types; no hidden allocations.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*,
+ *     NULL = the null stream), never synchronises, keeps no global state and
+ *     is re-entrant.  Scratch memory is supplied by the caller
+ *     (pm_*_workspace_bytes tells how much).
+ *   - return value: PM_OK (0) or a negative PM_E* code; a HIP launch error is
+ *     returned as -(1000 + hipError_t).
+ *   - matrices are row-major fp32 with an explicit row stride in ELEMENTS
+ *     (ld*), weights use torch.nn.Linear layout (out_features, in_features).
+ */
+#ifndef PARTMANIP_HIP_H
+#define PARTMANIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_OK 0
+#define PM_EINVAL (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
+#define PM_EWORKSPACE (-2) /* workspace too small                                                */
+#define PM_EALIGN (-3)     /* pointer / stride not aligned as required                           */
+
+#define PM_ACT_NONE 0
+#define PM_ACT_TANH 1
+
+/* ABI version: major*10000 + minor*100 + patch */
+int pm_version(void);
+
+/* ------------------------------------------------------------------ K1  GAE return scan
+ * Replaces RolloutStorage.compute_returns, algorithms/algo_utils/storage.py:96-112.
+ * rewards/values/returns/advantages: (T,N) fp32, N contiguous; dones/succs: (T,N) bytes
+ * (torch.bool storage); last_values: (N).  gamma_lam = (float)(gamma*lam) computed in
+ * double by the caller exactly as Python does.  use_succ==0 reproduces
+ * `default_succ_value is None`.  Bit-exact with the reference (no FMA contraction).
+ * Algorithmic HBM traffic: 18 B per env-step (8 B r,V + 2 B masks in, 8 B ret,adv out). */
+int pm_gae_scan_f32(const float* rewards, const float* values, const uint8_t* dones, const uint8_t* succs,
+                    const float* last_values, float* returns, float* advantages, int T, int N, float gamma,
+                    float gamma_lam, int use_succ, float succ_value, void* stream);
+
+/* ------------------------------------------------------------------ K2  advantage normalisation
+ * storage.py:113-114 (whole batch) and ppo.py:329 (mini-batch): (x-mean)/(std_unbiased+eps).
+ * pm_moments_f64 writes {sum, sum of squares} (fp64, deterministic two-stage reduction) to
+ * moments[0..1]; data-parallel callers all-reduce those two doubles (and the count) before
+ * pm_normalize_apply_f32.  Workspace: pm_moments_workspace_bytes(n). */
+size_t pm_moments_workspace_bytes(long n);
+int pm_moments_f64(const float* x, long n, double* moments, void* workspace, size_t workspace_bytes, void* stream);
+int pm_normalize_apply_f32(float* x, long n, const double* moments, double count, float eps, void* stream);
+
+/* ------------------------------------------------------------------ K3  mini-batch gather
+ * ppo.py:317-324,361-364 / dagger.py:307-308: dst[i,:] = src[idx[i],:] for `sampler: random`
+ * (sequential mini-batches are contiguous slices and need no copy). idx: int64 device. */
+int pm_gather_rows_f32(const float* src, const int64_t* idx, float* dst, long n_rows, long row_elems,
+                       long src_ld, long dst_ld, void* stream);
+
+/* ------------------------------------------------------------------ K4/K5  Linear layers (fp32 MFMA)
+ * network.py:53-54 (MLP) and network.py:154-160,196 (PointNet.final_mlp) forward, and the
+ * autograd backward ppo.py:348,378 / dagger.py:318 triggers for them.
+ *   fwd : Y[M,N]  = act(X[M,K] * W[N,K]^T + b[N])
+ *   bwd_data  : dX[M,K] = (dY[M,N] * W[N,K]) .* act'(H[M,K])   (H = the layer input, i.e. the previous
+ *               layer's activation OUTPUT; act' for tanh is 1-H^2; H may be NULL with PM_ACT_NONE)
+ *   bwd_weight: dW[N,K] = dY^T * X ; db[N] = column sums of dY (db may be NULL)
+ * v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate. */
+int pm_linear_fwd_f32(const float* X, long ldx, const float* W, long ldw, const float* b, float* Y, long ldy,
+                      int M, int N, int K, int act, void* stream);
+int pm_linear_bwd_data_f32(const float* dY, long lddy, const float* W, long ldw, const float* H, long ldh,
+                           float* dX, long lddx, int M, int N, int K, int act, void* stream);
+size_t pm_linear_bwd_weight_workspace_bytes(int M, int N, int K);
+int pm_linear_bwd_weight_f32(const float* dY, long lddy, const float* X, long ldx, float* dW, long lddw,
+                             float* db, int M, int N, int K, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+/* ------------------------------------------------------------------ K6/K7  PointNet encoder
+ * network.py:147-153,172-181: per-point shared MLP C->128->256->512 (tanh,tanh,none) over
+ * (B, P, C) clouds fused with the symmetric max(/mean) pooling; the (B,P,512) activation
+ * is never materialised.  feat (B, ldf) receives [max(512) | mean(512) if max_mean];
+ * argmax (B,512) int32 is the pooling index (lowest index on ties, as torch.max).
+ * x points are read at x + b*ldx + p*C (the reference's flat (B, P*C [+proprio]) rows).
+ * Weights in torch layout: W1 (128,C), W2 (256,128), W3 (512,256).
+ * pm_pointnet_pack_weights_f32 re-lays W2/W3 into the MFMA-operand order the kernels
+ * stream (call after every optimiser step); packed size = pm_pointnet_packed_elems(). */
+size_t pm_pointnet_packed_elems(void);
+int pm_pointnet_pack_weights_f32(const float* W2, const float* W3, float* packed, void* stream);
+int pm_pointnet_enc_fwd_f32(const float* x, long ldx, int B, int P, int C, int sub_mean, const float* W1,
+                            const float* b1, const float* b2, const float* b3, const float* packed,
+                            int max_mean, float* feat, long ldf, int32_t* argmax, void* stream);
+/* Backward of the above w.r.t. the six encoder parameters given dfeat (B, ldf) =
+ * [d max(512) | d mean(512)].  Uses the pooling structure: the gradient of the 512-wide
+ * layer-3 output is (d mean)/P on every point plus (d max) on the argmax point only, so
+ * layers 1-2 are recomputed per tile and only the 256->128 GEMMs run dense.
+ * Workspace: pm_pointnet_enc_bwd_workspace_bytes(B). Gradients are WRITTEN (not accumulated). */
+size_t pm_pointnet_enc_bwd_workspace_bytes(int B, int P, int C);
+int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, int C, int sub_mean, const float* W1,
+                            const float* b1, const float* b2, const float* W3, const float* packed,
+                            int max_mean, const float* dfeat, long ldf, const int32_t* argmax, float* dW1,
+                            float* db1, float* dW2, float* db2, float* dW3, float* db3, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ K8  PPO actor loss
+ * actor_critic.py:74-78,93-100 + ppo.py:327-344 in one pass over a mini-batch of B rows:
+ * atanh(clamp(a/max_a)), Gaussian log-prob with std = exp(log_std)^2, analytic KL to the
+ * stored (mu_old, log_std_old), ratio, clipped surrogate; and its backward.
+ * scal_out[0]=surrogate loss, [1]=kl mean, [2]=skip flag (kl_mean > desired_kl, as 0/1 float),
+ * [3]=entropy (identical for every row; unused by the loss, ppo.py:326).  dmu (B,A) and
+ * dlog_std (A) are d(loss)/d(.) and are ALWAYS written: the reference's `continue`
+ * (ppo.py:337-338) is realised by handing &scal_out[2] to pm_clip_adam_step_f32 as its
+ * skip flag, so no host sync sits between loss and optimiser.  adv_moments: NULL, or
+ * {sum,sumsq} of the mini-batch advantages (count adv_count) for ppo.py:329's
+ * mini_adv_norm (data-parallel callers all-reduce them first).  Single work-group kernel. */
+int pm_ppo_actor_loss_fwd_bwd_f32(const float* mu, long ldmu, const float* log_std, const float* actions,
+                                  long lda, const float* old_logp, const float* adv, const float* old_mu,
+                                  long ldom, const float* old_sigma, long ldos, int B, int A, float max_action,
+                                  int act_tanh, float eps_clip, float desired_kl, const double* adv_moments,
+                                  double adv_count, float* scal_out, float* dmu, long lddmu, float* dlog_std,
+                                  void* stream);
+/* forward-only: log-prob/entropy rows, actor_critic.py:71-82 (used by rollout + tests). */
+int pm_gaussian_logp_f32(const float* mu, long ldmu, const float* log_std, const float* actions, long lda,
+                         int B, int A, float max_action, int act_tanh, float* logp, float* entropy,
+                         void* stream);
+
+/* ------------------------------------------------------------------ K9  value loss
+ * ppo.py:368-374: mean((ret-V)^2), or the clipped variant with the batch-mean clip width.
+ * clip_mean_extern: NULL or device float = all-reduced mean(|eps*V_old|) (data parallel).
+ * scal_out[0] = loss.  dV (B) = d loss / dV * grad_scale. */
+int pm_value_loss_fwd_bwd_f32(const float* V, const float* returns, const float* old_values, int B,
+                              int clipped, float eps_clip, const float* clip_mean_extern, float grad_scale,
+                              float* scal_out, float* dV, void* stream);
+
+/* ------------------------------------------------------------------ K11 DAgger loss
+ * dagger.py:310-314: mean((tanh(tea_mu)*max_a - tanh(stu_mu)*max_a)^2) over B*A and
+ * d/d stu_mu.  act_tanh==0 -> identity squashing (actor_critic.py:87-88). */
+int pm_mse_tanh_loss_fwd_bwd_f32(const float* stu_mu, long lds, const float* tea_mu, long ldt, int B, int A,
+                                 float max_action, int act_tanh, float grad_scale, float* scal_out,
+                                 float* dstu_mu, long ldd, void* stream);
+/* actor_critic.py:84-91 */
+int pm_action_activation_f32(const float* mu, float* out, long n, float max_action, int act_tanh, void* stream);
+
+/* ------------------------------------------------------------------ K10 clip + Adam
+ * nn.utils.clip_grad_norm_ (ppo.py:351,381) fused with torch.optim.Adam.step (ppo.py:353,382,
+ * dagger.py:319) over ONE flat fp32 parameter buffer: the L2 norm / clip coefficient
+ * min(1, max_norm/(norm+1e-6)) covers the first n_clip elements only (the actor optimiser
+ * also owns log_std, which the reference does not clip); max_norm<=0 disables clipping.
+ * state (device, 4 x int32): [0]=step count t (incremented here unless skipped).
+ * skip_flag: NULL or device float; non-zero -> the whole step is a no-op (ppo.py:337-338).
+ * Adam: betas (b1,b2), eps, bias-corrected exactly as torch (denom = sqrt(v)/sqrt(1-b2^t)+eps,
+ * step = lr/(1-b1^t)).  Workspace: pm_clip_adam_workspace_bytes(n). */
+size_t pm_clip_adam_workspace_bytes(long n);
+int pm_clip_adam_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                          long n_clip, float max_norm, double lr, double b1, double b2, double eps,
+                          int32_t* state, const float* skip_flag, float* gnorm_out, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ scalar bookkeeping of ppo.update
+ * ppo.py:335-336,355-357,384: device-side running sums so the host never syncs per
+ * mini-batch. acc (device, 8 floats): [0]=sum surrogate,[1]=sum kl,[2]=kl max,[3]=count,
+ * [4]=sum value loss,[5]=n value steps.  which: 0 = actor step (reads scal[0..2]), 1 = critic. */
+int pm_ppo_accumulate_stats_f32(float* acc, const float* scal, int which, void* stream);
+
+/* ------------------------------------------------------------------ K12-K14 point-set operators
+ * K12: utils/depth2tsdf.py:113,160 call pytorch3d.ops.sample_farthest_points(points, K)
+ * (un-vendored; defaults: start index 0, no lengths).  idx_out (B,K) int32; squared-L2
+ * running-min distance; next = argmax, lowest index on ties.  PARITY UNPINNED (no reference
+ * implementation in tree) -- checked against oracle/pointops_ref.c.
+ * K13/K14: PointNet++ ball query / grouping -- absent from the reference (README.md:23,30),
+ * mandated by BASELINE.json.north_star; first `nsample` in-radius indices in ascending
+ * order, padded with the first hit, all-zero row when the ball is empty. */
+size_t pm_fps_workspace_bytes(int B, int P);   /* 0 when the cloud fits in registers (P <= 8192) */
+int pm_fps_f32(const float* xyz, int B, int P, int D, int K, int32_t* idx_out, void* workspace,
+               size_t workspace_bytes, void* stream);
+int pm_ball_query_f32(const float* xyz, const float* centers, int B, int P, int S, float radius, int nsample,
+                      int32_t* idx_out, void* stream);
+int pm_group_points_f32(const float* feat, const int32_t* idx, int B, int P, int C, int S, int nsample,
+                        float* out, void* stream);
+int pm_group_points_bwd_f32(const float* dout, const int32_t* idx, int B, int P, int C, int S, int nsample,
+                            float* dfeat, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARTMANIP_HIP_H */

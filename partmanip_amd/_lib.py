@@ -1,0 +1,65 @@
+"""ctypes loader for libpartmanip_hip.so -- the only way compute enters this package.
+
+There is NO fallback: if the shared library is missing or a symbol cannot be bound the
+import raises, and every op refuses non-GPU tensors (see ops.py).  Build the library with
+`python -m partmanip_amd.build` (or `__graft_entry__.build()`).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libpartmanip_hip.so")
+
+P, I, L, F, D, Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/partmanip_hip.h one to one
+# (tests/test_capi_symbols.py parses the header and checks this table and the .so against it)
+SIGNATURES = {
+    "pm_version": (I, []),
+    "pm_gae_scan_f32": (I, [P, P, P, P, P, P, P, I, I, F, F, I, F, P]),
+    "pm_moments_workspace_bytes": (Z, [L]),
+    "pm_moments_f64": (I, [P, L, P, P, Z, P]),
+    "pm_normalize_apply_f32": (I, [P, L, P, D, F, P]),
+    "pm_gather_rows_f32": (I, [P, P, P, L, L, L, L, P]),
+    "pm_linear_fwd_f32": (I, [P, L, P, L, P, P, L, I, I, I, I, P]),
+    "pm_linear_bwd_data_f32": (I, [P, L, P, L, P, L, P, L, I, I, I, I, P]),
+    "pm_linear_bwd_weight_workspace_bytes": (Z, [I, I, I]),
+    "pm_linear_bwd_weight_f32": (I, [P, L, P, L, P, L, P, I, I, I, P, Z, P]),
+    "pm_pointnet_packed_elems": (Z, []),
+    "pm_pointnet_pack_weights_f32": (I, [P, P, P, P]),
+    "pm_pointnet_enc_fwd_f32": (I, [P, L, I, I, I, I, P, P, P, P, P, I, P, L, P, P]),
+    "pm_pointnet_enc_bwd_workspace_bytes": (Z, [I, I, I]),
+    "pm_pointnet_enc_bwd_f32": (I, [P, L, I, I, I, I, P, P, P, P, P, I, P, L, P, P, P, P, P, P, P, P, Z, P]),
+    "pm_ppo_actor_loss_fwd_bwd_f32": (I, [P, L, P, P, L, P, P, P, L, P, L, I, I, F, I, F, F, P, D, P, P, L, P, P]),
+    "pm_gaussian_logp_f32": (I, [P, L, P, P, L, I, I, F, I, P, P, P]),
+    "pm_value_loss_fwd_bwd_f32": (I, [P, P, P, I, I, F, P, F, P, P, P]),
+    "pm_mse_tanh_loss_fwd_bwd_f32": (I, [P, L, P, L, I, I, F, I, F, P, P, L, P]),
+    "pm_action_activation_f32": (I, [P, P, L, F, I, P]),
+    "pm_clip_adam_workspace_bytes": (Z, [L]),
+    "pm_clip_adam_step_f32": (I, [P, P, P, P, L, L, F, D, D, D, D, P, P, P, P, Z, P]),
+    "pm_ppo_accumulate_stats_f32": (I, [P, P, I, P]),
+    "pm_fps_workspace_bytes": (Z, [I, I]),
+    "pm_fps_f32": (I, [P, I, I, I, I, P, P, Z, P]),
+    "pm_ball_query_f32": (I, [P, P, I, I, I, F, I, P, P]),
+    "pm_group_points_f32": (I, [P, P, I, I, I, I, I, P, P]),
+    "pm_group_points_bwd_f32": (I, [P, P, I, I, I, I, I, P, P]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -m partmanip_amd.build` "
+        "(needs hipcc; cross-compiles gfx950 without a GPU). partmanip_amd has no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = symbol missing from the .so: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+ERRORS = {-1: "PM_EINVAL (bad argument)", -2: "PM_EWORKSPACE (workspace too small)", -3: "PM_EALIGN (misaligned pointer)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = ERRORS.get(rc, f"HIP error {-rc - 1000}" if rc <= -1000 else f"code {rc}")
+        raise RuntimeError(f"{what} failed: {msg}")

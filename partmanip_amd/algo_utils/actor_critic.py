@@ -1,0 +1,152 @@
+"""ActorCritic with the reference's interface (algorithms/algo_utils/actor_critic.py:8-100):
+two separate backbones + a `log_std` parameter, a Gaussian policy whose covariance factor is
+diag(exp(log_std)^2) (so the effective std is sigma^2 -- kept deliberately),
+tanh action squashing.  Same method names, argument meaning and return tuples.
+
+Added for the MI355X path: `flatten()` re-homes all parameters into two contiguous fp32
+buffers -- [actor params | log_std] and [critic params] -- matching the reference's two
+optimisers (ppo.py:73-74), with same-layout gradient buffers the HIP backward writes into.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .network import MLP, Conv3DNet, PoolConv3DNet, PointNet, ResNet, depthResNet  # noqa: F401 (eval() namespace)
+from .. import ops
+
+
+class ActorCritic(nn.Module):
+    SCAL_TAIL = 8
+
+    def __init__(self, obs_shape, actions_shape, model_cfg, proprio_shape=0):
+        super(ActorCritic, self).__init__()
+        net_cfg = model_cfg['network']
+        self.actor = eval(net_cfg['name'])(obs_shape, actions_shape, net_cfg, proprio_shape=proprio_shape)
+        self.critic = eval(net_cfg['name'])(obs_shape, 1, net_cfg, proprio_shape=proprio_shape)
+        self.log_std = nn.Parameter(np.log(model_cfg['action_std']) * torch.ones(actions_shape))
+        self.max_action = model_cfg['clipAction']
+        assert self.max_action > 0
+        self.action_activate = model_cfg['action_activate']
+        if self.action_activate not in ('tanh', None):
+            raise NotImplementedError
+        self.actions_shape = actions_shape
+        self._flat = None
+
+    # ------------------------------------------------------------------ flat buffers
+    def flatten(self):
+        """(Re)build the flat parameter / gradient buffers on the parameters' current device."""
+        dev = self.log_std.device
+        a_params = list(self.actor.named_parameters())
+        c_params = list(self.critic.named_parameters())
+        n_a = sum(p.numel() for _, p in a_params)
+        n_c = sum(p.numel() for _, p in c_params)
+        A = self.log_std.numel()
+        flat_a = torch.empty(n_a + A, device=dev)
+        flat_c = torch.empty(n_c, device=dev)
+        # gradient buffers carry an 8-float tail for the step's scalars (loss, kl, skip flag, ...):
+        # a data-parallel step all-reduces gradient and scalars as ONE message (dist.py)
+        grad_a = torch.zeros(n_a + A + self.SCAL_TAIL, device=dev)
+        grad_c = torch.zeros(n_c + self.SCAL_TAIL, device=dev)
+
+        def rehome(params, flat, grad):
+            views, off = {}, 0
+            for name, p in params:
+                n = p.numel()
+                flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = flat[off:off + n].view(p.shape)
+                views[name] = grad[off:off + n].view(p.shape)
+                off += n
+            return views, off
+        va, off = rehome(a_params, flat_a, grad_a)
+        flat_a[off:off + A].copy_(self.log_std.data)
+        self.log_std.data = flat_a[off:off + A]
+        vc, _ = rehome(c_params, flat_c, grad_c)
+        self.actor.set_grad_views(va)
+        self.critic.set_grad_views(vc)
+        self._flat = dict(actor=flat_a, critic=flat_c, grad_actor=grad_a, grad_critic=grad_c, n_actor=n_a,
+                          n_critic=n_c, grad_log_std=grad_a[n_a:n_a + A], scal_actor=grad_a[n_a + A:],
+                          scal_critic=grad_c[n_c:])
+        return self._flat
+
+    def flat(self):
+        f = self._flat
+        if f is None or f["actor"].device != self.log_std.device or \
+                self.log_std.data_ptr() != f["actor"].data_ptr() + 4 * f["n_actor"] or \
+                next(self.critic.parameters()).data_ptr() != f["critic"].data_ptr():
+            f = self.flatten()      # first use, or .to(device)/load re-created the parameter tensors
+        return f
+
+    def forward(self):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ reference API
+    def _sigma2(self):
+        return self.log_std.data.exp() * self.log_std.data.exp()
+
+    def _logp_entropy(self, mu, actions_raw_or_squashed, squashed):
+        B = mu.shape[0]
+        logp = torch.empty(B, device=mu.device)
+        ent = torch.empty(B, device=mu.device)
+        ops.gaussian_logp(mu, self.log_std.data, actions_raw_or_squashed.contiguous(), self.max_action,
+                          squashed and self.action_activate == 'tanh', logp, ent)
+        return logp, ent
+
+    def cri(self, observations):
+        self.flat()
+        return self.critic(observations).detach()
+
+    def random_act_cri(self, observations):
+        """actor_critic.py:36-47."""
+        self.flat()
+        mu = self.actor(observations)
+        # MultivariateNormal(loc, scale_tril=diag(sigma^2)).sample(): loc + sigma^2 * eps
+        eps = torch.normal(torch.zeros_like(mu), torch.ones_like(mu))
+        actions = mu + self._sigma2() * eps
+        logp, _ = self._logp_entropy(mu, actions, squashed=False)
+        value = self.critic(observations)
+        return (self.action_activation(actions), logp, value, mu,
+                self.log_std.data.repeat(mu.shape[0], 1))
+
+    def random_act(self, observations):
+        self.flat()
+        mu = self.actor(observations)
+        eps = torch.normal(torch.zeros_like(mu), torch.ones_like(mu))
+        return self.action_activation(mu + self._sigma2() * eps)
+
+    def act(self, observations):
+        self.flat()
+        return self.action_activation(self.actor(observations))
+
+    def act_cri(self, observations):
+        self.flat()
+        return self.action_activation(self.actor(observations)), self.critic(observations)
+
+    def update_act(self, observations):
+        self.flat()
+        return self.action_activation(self.actor(observations))
+
+    def update_act_cri(self, observations, actions):
+        """actor_critic.py:71-82 -> (log_prob (B,), entropy (B,), value (B,1), mu (B,A), log_std rows (B,A)).
+        Values only (no autograd graph): the training step differentiates through the explicit
+        HIP backward in `algorithms/ppo.py`, not through this method."""
+        self.flat()
+        mu = self.actor(observations)
+        logp, ent = self._logp_entropy(mu, actions, squashed=True)
+        value = self.critic(observations)
+        return logp, ent, value, mu, self.log_std.data.repeat(mu.shape[0], 1)
+
+    def action_activation(self, action):
+        if self.action_activate == 'tanh':
+            out = torch.empty_like(action)
+            ops.action_activation(action.contiguous(), out, self.max_action, True)
+            return out
+        elif self.action_activate is None:
+            return action
+        raise NotImplementedError
+
+    def action_deactivation(self, action):
+        if self.action_activate == 'tanh':
+            return torch.atanh(torch.clamp(action / self.max_action, max=1 - 1e-5, min=-1 + 1e-5))
+        elif self.action_activate is None:
+            return action
+        raise NotImplementedError

@@ -1,0 +1,361 @@
+"""PPO runner with the reference's interface (algorithms/ppo.py: `ppo(vec_env, cfg, logger)`,
+`run()`, `update(it)`, `eval()`, `save(it)`, `resume(path)`; same cfg keys, same public
+attributes, same checkpoint dict) whose learner is the MI355X path:
+
+  compute_returns  -> HIP GAE scan                                   (storage.py:96-114)
+  update           -> per mini-batch: HIP forward, fused loss fwd+bwd, HIP backward,
+                      [one RCCL all-reduce], fused clip+Adam          (ppo.py:307-411)
+
+Differences that are deliberate and semantics-preserving:
+  * no host sync inside `update`: the KL early-stop `continue` (ppo.py:337-338) is a device
+    predicate consumed by the optimiser kernel; the running sums behind the `Train/*` scalars
+    are accumulated on the device and read back once at the end;
+  * each pass runs only the network it updates (the reference's `update_act_cri` also runs the
+    other one and discards the result, actor_critic.py:72,80);
+  * sequential mini-batches are zero-copy slices of the (T*N, D) views.
+"""
+import os
+import time
+from copy import deepcopy
+from os.path import join as pjoin
+
+import numpy as np
+import torch
+
+from ..algo_utils import RolloutStorage, ActorCritic, Normalization, FusedAdam
+from .. import ops, dist as pdist
+
+try:                                        # simulator-side helper of the reference (utils/img2video.py)
+    from utils import path2video            # noqa: F401
+except Exception:                           # not present when running against the feeder
+    def path2video(*a, **k):
+        return None
+
+
+class ppo:
+    def __init__(self, vec_env, cfg, logger):
+        self.vec_env = vec_env
+        self.num_envs = cfg['num_envs']
+        self.obs_mode = cfg['obs_mode']
+        self.num_obs = vec_env.num_obs[self.obs_mode]
+        self.num_actions = vec_env.num_actions
+        self.max_episode_length = vec_env.max_episode_length
+        self.default_succ_value = cfg['succ_value']
+
+        self.model_cfg = cfg['model']
+        self.max_iter = cfg['max_iterations']
+        self.n_steps = cfg['n_steps']
+        self.n_updates = cfg['n_updates']
+        self.num_mini_batches = cfg['n_minibatches']
+        self.device = cfg['device']
+
+        self.eval_round = cfg['eval_round']
+        self.eval_freq = cfg['eval_frequence']
+        self.save_freq = cfg['save_frequence']
+        self.test_only = cfg['test_only']
+        self.save_pose = cfg['save_pose']
+        self.save_video = cfg['save_video']
+        self.save_ckpt_dir = logger.save_ckpt_dir
+
+        self.lr_schedule = cfg['lr_schedule']
+        self.lr = cfg['lr']
+        self.desired_kl = cfg['desired_kl']
+        assert self.desired_kl > 0
+        if self.lr_schedule not in ('fixed', 'linear_decay', 'step_decay'):
+            raise NotImplementedError
+
+        self.epsilon_clip = cfg['epsilon_clip']
+        self.gamma = cfg['gamma']
+        self.lam = cfg['lam']
+
+        self.tricks_keys = ['mini_adv_norm', 'whole_adv_norm', 'use_state_norm', 'use_clipped_value_loss',
+                            'use_grad_clip']
+        self.tricks = {k: cfg['tricks'][k] for k in self.tricks_keys}
+        if self.tricks['use_grad_clip']:
+            self.max_grad_norm = cfg['tricks']['max_grad_norm']
+        if self.tricks['use_state_norm']:
+            self.state_norm = Normalization(shape=self.num_obs, device=self.device)
+            self.update_RMS = True
+
+        self.actor_critic = ActorCritic(self.num_obs, self.num_actions, self.model_cfg).to(self.device)
+        self.storage = RolloutStorage(self.num_envs, self.n_steps, self.num_obs, self.num_actions, self.device,
+                                      self.default_succ_value, self.tricks['whole_adv_norm'], cfg['sampler'])
+        ac = self.actor_critic
+        f = ac.flat()
+        n_a, n_c = f['n_actor'], f['n_critic']
+        # two optimisers over the two flat buffers, param groups as ppo.py:73-74
+        self.optimizer_actor = FusedAdam(f['actor'], f['grad_actor'][:n_a + self.num_actions],
+                                         [list(ac.actor.parameters()), [ac.log_std]], lr=self.lr)
+        self.optimizer_critic = FusedAdam(f['critic'], f['grad_critic'][:n_c], [list(ac.critic.parameters())],
+                                          lr=self.lr)
+        self.sync = pdist.maybe_sync()              # None on a single GPU
+        dev = f['actor'].device
+        self._acc = torch.zeros(8, device=dev)       # device-side running sums of `update`
+        self._mom = torch.zeros(2, dtype=torch.float64, device=dev)
+        self._ws = ops.Workspace(dev)
+        self._stage = {}
+
+        self.logger = logger
+        self.total_envsteps = 0
+        self.total_time = 0
+        self.curr_iter = 0
+        self.resume(cfg['resume'])
+
+    # ------------------------------------------------------------------ checkpoints (ppo.py:83-137)
+    def save(self, it):
+        os.makedirs(self.save_ckpt_dir, exist_ok=True)
+        save_path = pjoin(self.save_ckpt_dir, f'model_{it}.pth')
+        save_dict = {
+            'iteration': it,
+            'model_state_dict': {k: v.clone() for k, v in self.actor_critic.state_dict().items()},
+            'optimizer_actor': self.optimizer_actor.state_dict(),
+            'optimizer_critic': self.optimizer_critic.state_dict(),
+            'total_steps': self.total_envsteps,
+            'tricks': self.tricks,
+            'obs_mode': self.obs_mode,
+            'model_cfg': self.model_cfg,
+        }
+        if self.tricks['use_state_norm']:
+            save_dict['state_running_ms'] = self.state_norm.running_ms.save()
+        torch.save(save_dict, save_path)
+        print(f'save ckpt to {save_path}!')
+
+    def resume(self, ckpt_path):
+        self.ckpt_path = ckpt_path
+        if ckpt_path is None:
+            return
+        print(f'load ckpt from {ckpt_path}!')
+        assert os.path.exists(ckpt_path)
+        ckpt = torch.load(ckpt_path, map_location=self.device, weights_only=False)
+        self.actor_critic.load_state_dict(ckpt["model_state_dict"])
+        self.optimizer_actor.load_state_dict(ckpt["optimizer_actor"])
+        self.optimizer_critic.load_state_dict(ckpt["optimizer_critic"])
+        self.curr_iter = ckpt["iteration"]
+        self.total_envsteps = ckpt["total_steps"]
+        for k in self.tricks_keys:
+            if self.tricks[k] != ckpt['tricks'][k]:
+                print(f"WARNING: trick {k} is not consistent with ckpt! saved: {ckpt['tricks'][k]}, now: {self.tricks[k]}")
+                if k == 'use_state_norm':
+                    print('this is not allowed')
+                    exit(1)
+        if self.tricks['use_state_norm']:
+            self.state_norm.running_ms.load(ckpt['state_running_ms'])
+        assert self.obs_mode == ckpt['obs_mode']
+
+    # ------------------------------------------------------------------ learner
+    def _views(self):
+        st = self.storage
+        v = lambda t: t.view(-1, t.size(-1))
+        return dict(obs=v(st.observations), actions=v(st.actions), values=v(st.values), returns=v(st.returns),
+                    old_logp=v(st.actions_log_prob), adv=v(st.advantages), old_mu=v(st.mu), old_sigma=v(st.sigma))
+
+    def _minibatch(self, views, indices, keys):
+        """Sequential sampler -> contiguous slices (zero copy); random -> HIP row gather (K3)."""
+        n = len(indices)
+        if self.storage.sampler == "sequential":
+            lo = indices[0]
+            return {k: views[k][lo:lo + n] for k in keys}
+        dev = views['obs'].device
+        idx = torch.tensor(indices, dtype=torch.int64).to(dev, non_blocking=True)
+        out = {}
+        for k in keys:
+            src = views[k]
+            buf = self._stage.get(k)
+            if buf is None or buf.shape[0] != n:
+                buf = self._stage[k] = torch.empty(n, src.shape[1], device=dev)
+            ops.gather_rows(src, idx, buf)
+            out[k] = buf
+        return out
+
+    def update(self, it):
+        """ppo.py:307-411."""
+        ac, tricks = self.actor_critic, self.tricks
+        f = ac.flat()
+        n_a, n_c, A = f['n_actor'], f['n_critic'], self.num_actions
+        scal_a, scal_c = f['scal_actor'], f['scal_critic']
+        clip = tricks['use_grad_clip']
+        max_norm = self.max_grad_norm if clip else 0.0
+        act_tanh = ac.action_activate == 'tanh'
+        views = self._views()
+        self._acc.zero_()
+        sync = self.sync
+
+        batch = self.storage.mini_batch_generator(self.num_mini_batches)
+        a_keys = ('obs', 'actions', 'old_logp', 'adv', 'old_mu', 'old_sigma')
+        for _ in range(self.n_updates):                      # actor loop, ppo.py:315-357
+            for indices in batch:
+                mb = self._minibatch(views, indices, a_keys)
+                B = len(indices)
+                mu = ac.actor.hip_forward(mb['obs'])
+                mom, cnt = None, 0.0
+                if tricks['mini_adv_norm']:                  # ppo.py:329
+                    ops.moments(mb['adv'].reshape(-1), self._mom, self._ws)
+                    cnt = sync.moments_sync(self._mom, B) if sync else B
+                    mom = self._mom
+                dmu = torch.empty(B, A, device=mu.device)
+                ops.ppo_actor_loss(mu, ac.log_std.data, mb['actions'], mb['old_logp'], mb['adv'], mb['old_mu'],
+                                   mb['old_sigma'], ac.max_action, act_tanh, self.epsilon_clip, self.desired_kl,
+                                   mom, cnt, scal_a, dmu, f['grad_log_std'])
+                ac.actor.hip_backward(dmu)
+                if sync:                                      # ONE all-reduce: grads + loss/kl in the tail
+                    sync.mean_(f['grad_actor'])
+                    scal_a[2:3].copy_((scal_a[1:2] > self.desired_kl).float())
+                ops.ppo_accumulate_stats(self._acc, scal_a, 0)
+                # log_std belongs to this optimiser but is outside the clipped norm (ppo.py:351)
+                self.optimizer_actor.step(n=n_a + A, n_clip=n_a if clip else 0, max_norm=max_norm,
+                                          skip_flag=scal_a[2:3])
+
+        c_keys = ('obs', 'returns', 'values')
+        for _ in range(self.n_updates):                      # critic loop, ppo.py:359-384
+            for indices in batch:
+                mb = self._minibatch(views, indices, c_keys)
+                B = len(indices)
+                value = ac.critic.hip_forward(mb['obs'])
+                clip_mean = None
+                if tricks['use_clipped_value_loss'] and sync:
+                    clip_mean = sync.mean_((self.epsilon_clip * mb['values']).abs().mean().reshape(1))
+                dv = torch.empty(B, 1, device=value.device)
+                ops.value_loss(value, mb['returns'], mb['values'], tricks['use_clipped_value_loss'],
+                               self.epsilon_clip, clip_mean, 1.0, scal_c, dv)
+                ac.critic.hip_backward(dv)
+                if sync:
+                    sync.mean_(f['grad_critic'])
+                ops.ppo_accumulate_stats(self._acc, scal_c, 1)
+                self.optimizer_critic.step(n=n_c, n_clip=n_c if clip else 0, max_norm=max_norm)
+
+        acc = self._acc.tolist()                              # the only host sync of the update
+        sum_surr, sum_kl, kl_max, count, sum_v, n_v = acc[:6]
+        mean_value_loss = sum_v / (self.n_updates * len(batch))
+        mean_surrogate_loss = sum_surr / count                # ZeroDivisionError if every mb was skipped, as ppo.py:387
+        mean_kl_mean = sum_kl / count
+
+        if self.lr_schedule == 'linear_decay':
+            lr_now = max(self.lr * (1 - it / self.max_iter), 1e-5)
+        elif self.lr_schedule == 'step_decay':
+            lr_now = 1e-5 if it > self.max_iter // 2 else self.lr
+        else:
+            lr_now = None
+        if lr_now is not None:                                # actor optimiser only (ppo.py:392,399)
+            for g in self.optimizer_actor.param_groups:
+                g['lr'] = lr_now
+
+        self.log_dict['Train/value_gt_return_mean'] = self.storage.returns.mean()
+        self.log_dict['Train/value_gt_return_max'] = self.storage.returns.max()
+        self.log_dict['Train/learning_rate'] = self.optimizer_actor.param_groups[0]['lr']
+        self.log_dict['Train/value_function_loss'] = mean_value_loss
+        self.log_dict['Train/surrogate_loss'] = mean_surrogate_loss
+        self.log_dict['Train/kl'] = mean_kl_mean
+        self.log_dict['Train/kl_max'] = kl_max
+        self.log_dict['Train/kl_update_count'] = int(count)
+
+    def learn(self, last_values):
+        """The `learn_time` window of ppo.py:256-262: returns + update + clear."""
+        ms = self.sync.moments_sync if self.sync else None
+        self.storage.compute_returns(last_values, self.gamma, self.lam, moments_sync=ms)
+        self.update(self.curr_iter)
+        self.storage.clear()
+
+    # ------------------------------------------------------------------ rollout / eval (simulator-bound)
+    def _norm(self, obs, update):
+        return self.state_norm(obs, update=update) if self.tricks['use_state_norm'] else obs
+
+    def use_info_update_logdict(self, info_lst, mode):
+        """ppo.py:295-305: per-key mean and mean-of-per-env-max over the collected steps."""
+        for key in info_lst[0]:
+            assert len(info_lst[0][key].shape) == 1, f"{key}: {info_lst[0][key].shape}"
+            allv = torch.stack([info[key].float() for info in info_lst], dim=-1)
+            self.log_dict[f'{mode}/{key}_mean'] = torch.mean(allv)
+            self.log_dict[f'{mode}/{key}_max'] = torch.mean(allv.max(dim=-1)[0])
+
+    def eval(self):
+        """ppo.py:139-203."""
+        self.actor_critic.eval()
+        self.vec_env.train_test_flag = 'test'
+        if self.test_only:
+            self.log_dict = {}
+        ep_infos = []
+        with torch.no_grad():
+            for _ in range(self.eval_round):
+                poses = []
+                curr_obs = self.vec_env.reset()[self.obs_mode]
+                for i in range(self.max_episode_length):
+                    curr_obs = self._norm(curr_obs, False)
+                    actions, _ = self.actor_critic.act_cri(curr_obs)
+                    img = pjoin(self.logger.save_video_dir, f"Iter{self.curr_iter}", f"{i}.png") if self.save_video else None
+                    next_obs, rews, _, infos = self.vec_env.step(actions, save_image_path=img)
+                    infos['action_t'] = actions[:, :3].mean(dim=-1)
+                    infos['action_r'] = actions[:, 3:6].mean(dim=-1)
+                    infos['action_gripper'] = actions[:, -1]
+                    infos['succ_rate'] = self.vec_env.success
+                    ep_infos.append(deepcopy(infos))
+                    if self.save_pose:
+                        d = self.vec_env.save_scene_pose(pjoin(self.logger.save_pose_dir, f"Iter{self.curr_iter}", f"{i}.npy"))
+                        d['state'], d['action'] = curr_obs.cpu().numpy(), actions.cpu().numpy()
+                        poses.append(deepcopy(d))
+                    curr_obs = next_obs[self.obs_mode]
+                if self.save_pose:
+                    for i, d in enumerate(poses):
+                        d['success'] = ep_infos[-1]['obj_up_flag'].cpu().numpy()
+                        np.save(pjoin(self.logger.save_pose_dir, f"Iter{self.curr_iter}", f"{i}.npy"), d)
+                if self.save_video:
+                    path2video(pjoin(self.logger.save_video_dir, f"Iter{self.curr_iter}"))
+        mode = 'Test' if self.test_only else 'Val'
+        self.use_info_update_logdict(ep_infos, mode)
+        if self.tricks['use_state_norm'] and self.log_dict[f'{mode}/succ_rate_max'] > 0.5 and self.update_RMS:
+            self.update_RMS = False
+
+    def run(self):
+        """ppo.py:205-293: collect n_steps transitions per env, learn, log."""
+        if self.test_only:
+            self.eval()
+            self.logger.info(self.log_dict, self.curr_iter)
+            return
+        upd = lambda: getattr(self, 'update_RMS', False)
+        curr_obs = self._norm(self.vec_env.reset()[self.obs_mode], upd())
+        while self.curr_iter < self.max_iter:
+            self.curr_iter += 1
+            self.actor_critic.train()
+            self.vec_env.train_test_flag = 'train'
+            self.log_dict = {}
+            ep_infos = []
+            t0 = time.time()
+            for _ in range(self.n_steps):
+                actions, logp, values, mu, sigma = self.actor_critic.random_act_cri(curr_obs)
+                next_obs, rews, dones, infos = self.vec_env.step(actions)
+                self.storage.add_transitions(curr_obs, actions, rews, dones, self.vec_env.reset_succ, values, logp,
+                                             mu, sigma)
+                infos['action_t'] = actions[:, :3].abs().mean(dim=-1)
+                infos['action_r'] = actions[:, 3:6].abs().mean(dim=-1)
+                infos['action_gripper'] = actions[:, -1].abs()
+                infos['value_pred'] = values.squeeze(-1)
+                curr_obs = self._norm(next_obs[self.obs_mode], upd())
+                ep_infos.append(deepcopy(infos))
+            last_values = self.actor_critic.cri(curr_obs)
+            torch.cuda.synchronize()
+            collection_time = time.time() - t0
+
+            t0 = time.time()
+            self.learn(last_values)
+            torch.cuda.synchronize()
+            learn_time = time.time() - t0
+
+            self.total_envsteps += self.n_steps * self.vec_env.num_envs
+            self.total_time += collection_time + learn_time
+            action_std = self.actor_critic.log_std.exp()
+            self.log_dict['Progress/total_steps'] = self.curr_iter
+            self.log_dict['Progress/collection_time'] = collection_time
+            self.log_dict['Progress/learn_time'] = learn_time
+            self.log_dict['Progress/FPS'] = int(self.n_steps * self.vec_env.num_envs / (collection_time + learn_time))
+            self.log_dict['Progress/learner_env_steps_per_s'] = self.n_steps * self.vec_env.num_envs / learn_time
+            self.log_dict['Train/mean_action_noise_std'] = action_std.mean().item()
+            self.log_dict['Train/mean_t_noise_std'] = action_std[:3].mean()
+            self.log_dict['Train/mean_r_noise_std'] = action_std[3:-1].mean()
+            self.log_dict['Train/mean_gripper_noise_std'] = action_std[-1]
+            self.use_info_update_logdict(ep_infos, 'Train')
+
+            if self.curr_iter % self.eval_freq == 0:
+                self.eval()
+                curr_obs = self._norm(self.vec_env.reset()[self.obs_mode], upd())
+            if self.curr_iter % self.save_freq == 0:
+                self.save(self.curr_iter)
+            self.logger.info(self.log_dict, self.curr_iter)

@@ -1,0 +1,296 @@
+// K4/K5: Linear forward / backward as LDS-tiled fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32:
+// exact fp32 products, fp32 accumulate -- bitwise an fmaf chain per output, so results are
+// fp32-roundoff-class against the reference's CPU sgemm).
+//
+// One work-group = 4 waves (2x2), tile 64x64, K-step 32.  Operand tiles are staged in LDS in
+// their natural global orientation:
+//   "k-contiguous" operand (row r, k fastest):   LDS [64][36]  -> fragments by ds_read_b128;
+//        row stride 36 floats: (36*r) mod 64 hits 16 distinct 4-bank slots -> conflict-free.
+//   "k-major" operand (k slowest, r fastest):    LDS [32][64]  -> fragments by ds_read_b32,
+//        lanes read consecutive floats -> conflict-free.
+// Lane l of a wave feeds MFMA row/col (l&31); lanes 0-31 own k in [0,16) of the K-step and
+// lanes 32-63 own k in [16,32), so a k-contiguous lane reads its 16 k-values as 4 x 16 B.
+#include "common.h"
+
+#define GB_M 64
+#define GB_N 64
+#define GB_K 32
+#define LDK (GB_K + 4)   // k-contiguous LDS row stride (floats)
+#define LDR 64           // k-major LDS row stride (floats)
+
+enum { EPI_BIAS_ACT = 0, EPI_MUL_DACT = 1, EPI_PLAIN = 2 };
+
+struct GemmArgs {
+    const float* A; long lda;     // k-contig: A[row*lda + k] ; k-major: A[k*lda + row]
+    const float* B; long ldb;     // k-contig: B[col*ldb + k] ; k-major: B[k*ldb + col]
+    float* C; long ldc;           // C[row*ldc + col]
+    const float* bias;            // EPI_BIAS_ACT: per col (may be null)
+    const float* H; long ldh;     // EPI_MUL_DACT: C *= 1 - H[row][col]^2
+    int M, N, K;                  // GEMM dims (rows, cols, reduction)
+    int act;
+    int kchunk;                   // split-K: reduction range per blockIdx.z
+    long slab;                    // split-K: C offset per blockIdx.z (elements)
+    int vecA, vecB;               // 16 B global loads allowed
+};
+
+// ---- global -> register tile loads ------------------------------------------------------
+// k-contiguous tile: 64 rows x 32 k.  vec: 2 float4 per thread; scalar: 8 floats per thread.
+__device__ __forceinline__ void load_kcontig(const float* __restrict__ P, long ld, int row0, int nrows, int k0,
+                                             int kend, int vec, float (&r)[8]) {
+    const int tid = threadIdx.x;
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 3, k = k0 + ((idx & 7) << 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + row < nrows && k < kend) v = *(const float4*)(P + (long)(row0 + row) * ld + k);
+            r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 5, k = k0 + (idx & 31);
+            r[j] = (row0 + row < nrows && k < kend) ? P[(long)(row0 + row) * ld + k] : 0.f;
+        }
+    }
+}
+__device__ __forceinline__ void store_kcontig(float* __restrict__ S, int vec, const float (&r)[8]) {
+    const int tid = threadIdx.x;
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 3, k = (idx & 7) << 2;
+            *(float4*)(S + row * LDK + k) = make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j;
+            S[(idx >> 5) * LDK + (idx & 31)] = r[j];
+        }
+    }
+}
+// k-major tile: 32 k x 64 rows(cols).
+__device__ __forceinline__ void load_kmajor(const float* __restrict__ P, long ld, int row0, int nrows, int k0,
+                                            int kend, int vec, float (&r)[8]) {
+    const int tid = threadIdx.x;
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 256 * j, k = k0 + (idx >> 4), row = row0 + ((idx & 15) << 2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kend && row < nrows) v = *(const float4*)(P + (long)k * ld + row);
+            r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, k = k0 + (idx >> 6), row = row0 + (idx & 63);
+            r[j] = (k < kend && row < nrows) ? P[(long)k * ld + row] : 0.f;
+        }
+    }
+}
+__device__ __forceinline__ void store_kmajor(float* __restrict__ S, int vec, const float (&r)[8]) {
+    const int tid = threadIdx.x;
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 256 * j;
+            *(float4*)(S + (idx >> 4) * LDR + ((idx & 15) << 2)) =
+                make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j;
+            S[(idx >> 6) * LDR + (idx & 63)] = r[j];
+        }
+    }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[GB_M * LDK];   // 64*36 >= 32*64
+    __shared__ __attribute__((aligned(16))) float Bs[GB_N * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    float ra[8], rb[8];
+    if (kbeg < kend) {
+        if (A_KMAJOR) load_kmajor(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
+        else load_kcontig(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
+        if (B_KMAJOR) load_kmajor(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
+        else load_kcontig(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += GB_K) {
+        __syncthreads();                       // previous tile's fragment reads done
+        if (A_KMAJOR) store_kmajor(As, g.vecA, ra); else store_kcontig(As, g.vecA, ra);
+        if (B_KMAJOR) store_kmajor(Bs, g.vecB, rb); else store_kcontig(Bs, g.vecB, rb);
+        __syncthreads();
+        if (k0 + GB_K < kend) {                // prefetch next tile while this one is multiplied
+            if (A_KMAJOR) load_kmajor(g.A, g.lda, m0, g.M, k0 + GB_K, kend, g.vecA, ra);
+            else load_kcontig(g.A, g.lda, m0, g.M, k0 + GB_K, kend, g.vecA, ra);
+            if (B_KMAJOR) load_kmajor(g.B, g.ldb, n0, g.N, k0 + GB_K, kend, g.vecB, rb);
+            else load_kcontig(g.B, g.ldb, n0, g.N, k0 + GB_K, kend, g.vecB, rb);
+        }
+        float fa[16], fb[16];
+        if (A_KMAJOR) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) fa[s] = As[(lh * 16 + s) * LDR + wm + li];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *(const float4*)(As + (wm + li) * LDK + lh * 16 + 4 * q);
+                fa[4 * q] = v.x; fa[4 * q + 1] = v.y; fa[4 * q + 2] = v.z; fa[4 * q + 3] = v.w;
+            }
+        }
+        if (B_KMAJOR) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) fb[s] = Bs[(lh * 16 + s) * LDR + wn + li];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *(const float4*)(Bs + (wn + li) * LDK + lh * 16 + 4 * q);
+                fb[4 * q] = v.x; fb[4 * q + 1] = v.y; fb[4 * q + 2] = v.z; fb[4 * q + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
+    }
+
+    // epilogue: acc[r] is C[row = wm + (r&3) + 8*(r>>2) + 4*lh][col = wn + li]
+    float* C = g.C + (long)blockIdx.z * g.slab;
+    const int col = n0 + wn + li;
+    if (col >= g.N) return;
+    float bias = 0.f;
+    if (EPI == EPI_BIAS_ACT && g.bias) bias = g.bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < g.M) {
+            float v = acc[r];
+            if (EPI == EPI_BIAS_ACT) {
+                v += bias;
+                if (g.act == PM_ACT_TANH) v = tanhf(v);
+            } else if (EPI == EPI_MUL_DACT) {
+                if (g.act == PM_ACT_TANH) {
+                    const float h = g.H[(long)row * g.ldh + col];
+                    v *= (1.0f - h * h);
+                }
+            }
+            C[(long)row * g.ldc + col] = v;
+        }
+    }
+}
+
+static inline int aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int pm_linear_fwd_f32(const float* X, long ldx, const float* W, long ldw, const float* b, float* Y,
+                                 long ldy, int M, int N, int K, int act, void* stream) {
+    PM_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N);
+    PM_REQUIRE(act == PM_ACT_NONE || act == PM_ACT_TANH);
+    GemmArgs g{};
+    g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.bias = b;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.kchunk = K; g.slab = 0;
+    g.vecA = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
+    g.vecB = (K % 4 == 0) && (ldw % 4 == 0) && aligned16(W);
+    dim3 grid((N + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, 1);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_BIAS_ACT>), grid, dim3(256), 0, pm_stream(stream), g);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_linear_bwd_data_f32(const float* dY, long lddy, const float* W, long ldw, const float* H,
+                                      long ldh, float* dX, long lddx, int M, int N, int K, int act,
+                                      void* stream) {
+    PM_REQUIRE(dY && W && dX && M > 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K);
+    PM_REQUIRE(act == PM_ACT_NONE || (act == PM_ACT_TANH && H && ldh >= K));
+    GemmArgs g{};
+    // C[M x K] = dY[M x N] * W[N x K]: reduction over N; A = dY (k-contiguous), B = W (k-major)
+    g.A = dY; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = lddx; g.H = H; g.ldh = ldh;
+    g.M = M; g.N = K; g.K = N; g.act = act; g.kchunk = N; g.slab = 0;
+    g.vecA = (N % 4 == 0) && (lddy % 4 == 0) && aligned16(dY);
+    g.vecB = (K % 4 == 0) && (ldw % 4 == 0) && aligned16(W);
+    dim3 grid((K + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, 1);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, true, EPI_MUL_DACT>), grid, dim3(256), 0, pm_stream(stream), g);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// ---- weight gradient: split-K over the batch, slab reduction, bias column sums -----------
+static inline int bww_splits(int M, int N, int K) {
+    const long tiles = (long)((N + GB_M - 1) / GB_M) * ((K + GB_N - 1) / GB_N);
+    long s = 512 / tiles;
+    const long maxs = (M + GB_K - 1) / GB_K;
+    if (s > maxs) s = maxs;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" size_t pm_linear_bwd_weight_workspace_bytes(int M, int N, int K) {
+    const int s = bww_splits(M, N, K);
+    return s > 1 ? (size_t)s * N * K * sizeof(float) : 16;
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int S, long slab,
+                                                           float* __restrict__ dW, long lddw, int N, int K) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)N * K) return;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slabs[z * slab + e];
+    dW[(e / K) * lddw + (e % K)] = s;
+}
+
+// db[c] = sum_m dY[m][c]; one work-group per 64 columns, 4 row groups, fixed order.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dY, long ld, int M, int N,
+                                                      float* __restrict__ db) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < N)
+        for (int m = rg; m < M; m += 4) s += dY[(long)m * ld + c];
+    part[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < N) db[c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+extern "C" int pm_linear_bwd_weight_f32(const float* dY, long lddy, const float* X, long ldx, float* dW,
+                                        long lddw, float* db, int M, int N, int K, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K);
+    const int S = bww_splits(M, N, K);
+    if (S > 1 && (!workspace || workspace_bytes < (size_t)S * N * K * sizeof(float))) return PM_EWORKSPACE;
+    GemmArgs g{};
+    // C[N x K] = dY^T[N x M] * X[M x K]: reduction over M; both operands k-major
+    g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx;
+    g.M = N; g.N = K; g.K = M; g.act = 0;
+    g.vecA = (N % 4 == 0) && (lddy % 4 == 0) && aligned16(dY);
+    g.vecB = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
+    if (S > 1) {
+        int kchunk = (M + S - 1) / S;
+        kchunk = ((kchunk + GB_K - 1) / GB_K) * GB_K;
+        g.C = (float*)workspace; g.ldc = K; g.kchunk = kchunk; g.slab = (long)N * K;
+    } else {
+        g.C = dW; g.ldc = lddw; g.kchunk = M; g.slab = 0;
+    }
+    dim3 grid((K + GB_N - 1) / GB_N, (N + GB_M - 1) / GB_M, S);
+    hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI_PLAIN>), grid, dim3(256), 0, pm_stream(stream), g);
+    if (S > 1) {
+        const long ne = (long)N * K;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, pm_stream(stream),
+                           (const float*)workspace, S, (long)N * K, dW, lddw, N, K);
+    }
+    if (db)
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, pm_stream(stream), dY, lddy, M, N, db);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}

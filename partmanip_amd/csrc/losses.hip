@@ -1,0 +1,292 @@
+// K8 PPO actor loss, K9 value loss, K11 DAgger loss: one pass over a (B, A<=64) mini-batch,
+// forward value + backward gradient in the same launch.  These are a few hundred KB of
+// traffic per call; the point of fusing is to remove ~40 tiny ATen launches and two host
+// syncs per mini-batch (ppo.py:326-357), not bandwidth.
+#include "common.h"
+
+#define LOSS_THREADS 1024
+#define LOSS_WAVES (LOSS_THREADS / 64)
+#define MAX_A 64
+
+__device__ __forceinline__ float deactivate(float a, float max_action, int act_tanh) {
+    // actor_critic.py:93-100
+    if (!act_tanh) return a;
+    float u = a / max_action;
+    u = fminf(fmaxf(u, -1.0f + 1e-5f), 1.0f - 1e-5f);
+    return atanhf(u);
+}
+
+// ---------------------------------------------------------------------------------- K8
+__global__ __launch_bounds__(LOSS_THREADS) void ppo_actor_loss_kernel(
+    const float* __restrict__ mu, long ldmu, const float* __restrict__ log_std, const float* __restrict__ actions,
+    long lda, const float* __restrict__ old_logp, const float* __restrict__ adv, const float* __restrict__ old_mu,
+    long ldom, const float* __restrict__ old_sigma, long ldos, int B, int A, float max_action, int act_tanh,
+    float eps_clip, float desired_kl, const double* __restrict__ adv_moments, double adv_count,
+    float* __restrict__ scal_out, float* __restrict__ dmu, long lddmu, float* __restrict__ dlog_std) {
+    __shared__ float s_ls[MAX_A], s_s[MAX_A], s_en2[MAX_A];
+    __shared__ double red[LOSS_WAVES];
+    __shared__ float red_a[LOSS_WAVES][MAX_A];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < A) {
+        const float ls = log_std[tid];
+        const float e = expf(ls);
+        s_ls[tid] = ls;
+        s_s[tid] = e * e;                 // effective std: scale_tril = diag(exp(ls)*exp(ls)), actor_critic.py:74
+        s_en2[tid] = e * e;               // square(sigma.exp()) of the KL term, ppo.py:333
+    }
+    for (int a = lane; a < A; a += 64) red_a[w][a] = 0.f;
+    __syncthreads();
+    float sum_logs = 0.f;
+    for (int a = 0; a < A; ++a) sum_logs += logf(s_s[a]);
+    const float k_log2pi = (float)A * 1.8378770664093453f;
+
+    float a_mean = 0.f, a_den = 1.f;
+    if (adv_moments) {                    // ppo.py:329 mini_adv_norm
+        const double m = adv_moments[0] / adv_count;
+        double var = (adv_moments[1] - adv_moments[0] * m) / (adv_count - 1.0);
+        if (var < 0.0) var = 0.0;
+        a_mean = (float)m;
+        a_den = (float)sqrt(var) + 1e-8f;
+    }
+    const float invB = 1.0f / (float)B;
+    double loss_acc = 0.0, kl_acc = 0.0;
+    for (int base = 0; base < B; base += LOSS_THREADS) {     // uniform trip count: wave shuffles inside
+        const int i = base + tid;
+        const bool on = i < B;
+        float M = 0.f, kl = 0.f;
+        if (on) {
+            for (int a = 0; a < A; ++a) {
+                const float m = mu[i * ldmu + a];
+                const float x = deactivate(actions[i * lda + a], max_action, act_tanh);
+                const float z = (x - m) / s_s[a];
+                M += z * z;
+                const float eo = expf(old_sigma[i * ldos + a]);
+                const float dm = old_mu[i * ldom + a] - m;
+                kl += s_ls[a] - old_sigma[i * ldos + a] + (eo * eo + dm * dm) / (2.0f * s_en2[a]) - 0.5f;
+            }
+        }
+        float g = 0.f;
+        if (on) {
+            const float logp = -0.5f * (k_log2pi + M) - sum_logs;
+            const float ratio = expf(logp - old_logp[i]);
+            float ad = adv[i];
+            if (adv_moments) ad = (ad - a_mean) / a_den;
+            const float s1 = -ad * ratio;
+            const float s2 = -ad * fminf(fmaxf(ratio, 1.0f - eps_clip), 1.0f + eps_clip);
+            loss_acc += (double)fmaxf(s1, s2);
+            kl_acc += (double)kl;
+            // d max(s1,s2)/d ratio: -ad through the unclipped branch (incl. the tie inside the clip
+            // range, where torch splits the gradient in two halves that re-add); 0 when clipped.
+            g = (s1 >= s2 ? -ad : 0.0f) * ratio * invB;       // d loss / d logp_i
+        }
+        for (int a = 0; a < A; ++a) {
+            float c = 0.f;
+            if (on) {
+                const float x = deactivate(actions[i * lda + a], max_action, act_tanh);
+                const float z = (x - mu[i * ldmu + a]) / s_s[a];
+                dmu[i * lddmu + a] = g * z / s_s[a];          // d logp / d mu = z / s
+                c = g * (2.0f * z * z - 2.0f);                 // d logp / d log_std (s = exp(2 ls))
+            }
+            c = wave_sum(c);
+            if (lane == 0) red_a[w][a] += c;
+        }
+    }
+    const double loss_sum = block_sum<double, LOSS_THREADS>(loss_acc, red);
+    const double kl_sum = block_sum<double, LOSS_THREADS>(kl_acc, red);
+    __syncthreads();
+    if (tid < A) {
+        float t = 0.f;
+        for (int k = 0; k < LOSS_WAVES; ++k) t += red_a[k][tid];
+        dlog_std[tid] = t;
+    }
+    if (tid == 0) {
+        const float klm = (float)(kl_sum / (double)B);
+        scal_out[0] = (float)(loss_sum / (double)B);
+        scal_out[1] = klm;
+        scal_out[2] = (klm > desired_kl) ? 1.0f : 0.0f;
+        scal_out[3] = 0.5f * (float)A * (1.0f + 1.8378770664093453f) + sum_logs;   // entropy (same every row)
+    }
+}
+
+extern "C" int pm_ppo_actor_loss_fwd_bwd_f32(const float* mu, long ldmu, const float* log_std,
+                                             const float* actions, long lda, const float* old_logp,
+                                             const float* adv, const float* old_mu, long ldom,
+                                             const float* old_sigma, long ldos, int B, int A, float max_action,
+                                             int act_tanh, float eps_clip, float desired_kl,
+                                             const double* adv_moments, double adv_count, float* scal_out,
+                                             float* dmu, long lddmu, float* dlog_std, void* stream) {
+    PM_REQUIRE(mu && log_std && actions && old_logp && adv && old_mu && old_sigma && scal_out && dmu && dlog_std);
+    PM_REQUIRE(B > 0 && A > 0 && A <= MAX_A && max_action > 0.f);
+    PM_REQUIRE(!adv_moments || adv_count > 1.0);
+    hipLaunchKernelGGL(ppo_actor_loss_kernel, dim3(1), dim3(LOSS_THREADS), 0, pm_stream(stream), mu, ldmu, log_std,
+                       actions, lda, old_logp, adv, old_mu, ldom, old_sigma, ldos, B, A, max_action, act_tanh,
+                       eps_clip, desired_kl, adv_moments, adv_count, scal_out, dmu, lddmu, dlog_std);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// log-prob / entropy rows only (actor_critic.py:71-82, 36-47)
+__global__ __launch_bounds__(256) void gaussian_logp_kernel(const float* __restrict__ mu, long ldmu,
+                                                             const float* __restrict__ log_std,
+                                                             const float* __restrict__ actions, long lda, int B,
+                                                             int A, float max_action, int act_tanh,
+                                                             float* __restrict__ logp, float* __restrict__ entropy) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    float M = 0.f, sum_logs = 0.f;
+    for (int a = 0; a < A; ++a) {
+        const float e = expf(log_std[a]);
+        const float s = e * e;
+        sum_logs += logf(s);
+        const float x = deactivate(actions[i * lda + a], max_action, act_tanh);
+        const float z = (x - mu[i * ldmu + a]) / s;
+        M += z * z;
+    }
+    if (logp) logp[i] = -0.5f * ((float)A * 1.8378770664093453f + M) - sum_logs;
+    if (entropy) entropy[i] = 0.5f * (float)A * (1.0f + 1.8378770664093453f) + sum_logs;
+}
+
+extern "C" int pm_gaussian_logp_f32(const float* mu, long ldmu, const float* log_std, const float* actions,
+                                    long lda, int B, int A, float max_action, int act_tanh, float* logp,
+                                    float* entropy, void* stream) {
+    PM_REQUIRE(mu && log_std && actions && B > 0 && A > 0 && (logp || entropy) && max_action > 0.f);
+    hipLaunchKernelGGL(gaussian_logp_kernel, dim3((B + 255) / 256), dim3(256), 0, pm_stream(stream), mu, ldmu,
+                       log_std, actions, lda, B, A, max_action, act_tanh, logp, entropy);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// ---------------------------------------------------------------------------------- K9
+__global__ __launch_bounds__(LOSS_THREADS) void value_loss_kernel(const float* __restrict__ V,
+                                                                   const float* __restrict__ returns,
+                                                                   const float* __restrict__ old_values, int B,
+                                                                   int clipped, float eps_clip,
+                                                                   const float* __restrict__ clip_mean_extern,
+                                                                   float grad_scale, float* __restrict__ scal_out,
+                                                                   float* __restrict__ dV) {
+    __shared__ double red[LOSS_WAVES];
+    const int tid = threadIdx.x;
+    float d = 0.f;
+    if (clipped) {                       // ppo.py:370: delta = mean(|eps * V_old|) over the mini-batch
+        if (clip_mean_extern) {
+            d = clip_mean_extern[0];
+        } else {
+            double acc = 0.0;
+            for (int i = tid; i < B; i += LOSS_THREADS) acc += (double)fabsf(eps_clip * old_values[i]);
+            acc = block_sum<double, LOSS_THREADS>(acc, red);
+            d = (float)(acc / (double)B);
+        }
+    }
+    double acc = 0.0;
+    const float k = 2.0f / (float)B * grad_scale;
+    for (int i = tid; i < B; i += LOSS_THREADS) {
+        float tgt = returns[i];
+        if (clipped) {
+            const float ov = old_values[i];
+            tgt = ov + fminf(fmaxf(returns[i] - ov, -d), d);
+        }
+        const float e = V[i] - tgt;
+        acc += (double)(e * e);
+        dV[i] = k * e;
+    }
+    acc = block_sum<double, LOSS_THREADS>(acc, red);
+    if (tid == 0) {
+        scal_out[0] = (float)(acc / (double)B);
+        scal_out[1] = d;
+    }
+}
+
+extern "C" int pm_value_loss_fwd_bwd_f32(const float* V, const float* returns, const float* old_values, int B,
+                                         int clipped, float eps_clip, const float* clip_mean_extern,
+                                         float grad_scale, float* scal_out, float* dV, void* stream) {
+    PM_REQUIRE(V && returns && scal_out && dV && B > 0);
+    PM_REQUIRE(!clipped || old_values);
+    hipLaunchKernelGGL(value_loss_kernel, dim3(1), dim3(LOSS_THREADS), 0, pm_stream(stream), V, returns, old_values,
+                       B, clipped, eps_clip, clip_mean_extern, grad_scale, scal_out, dV);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// ---------------------------------------------------------------------------------- K11
+__global__ __launch_bounds__(LOSS_THREADS) void mse_tanh_loss_kernel(const float* __restrict__ stu_mu, long lds,
+                                                                      const float* __restrict__ tea_mu, long ldt,
+                                                                      int B, int A, float max_action, int act_tanh,
+                                                                      float grad_scale, float* __restrict__ scal_out,
+                                                                      float* __restrict__ dstu, long ldd) {
+    __shared__ double red[LOSS_WAVES];
+    const long n = (long)B * A;
+    const float k = 2.0f / (float)n * grad_scale;
+    double acc = 0.0;
+    for (long e = threadIdx.x; e < n; e += LOSS_THREADS) {
+        const long i = e / A, a = e % A;
+        const float sm = stu_mu[i * lds + a], tm = tea_mu[i * ldt + a];
+        float sa, ta, ds;
+        if (act_tanh) {
+            const float th = tanhf(sm);
+            sa = th * max_action;
+            ta = tanhf(tm) * max_action;
+            ds = max_action * (1.0f - th * th);
+        } else {
+            sa = sm;
+            ta = tm;
+            ds = 1.0f;
+        }
+        const float diff = ta - sa;
+        acc += (double)(diff * diff);
+        dstu[i * ldd + a] = -k * diff * ds;
+    }
+    acc = block_sum<double, LOSS_THREADS>(acc, red);
+    if (threadIdx.x == 0) scal_out[0] = (float)(acc / (double)n);
+}
+
+extern "C" int pm_mse_tanh_loss_fwd_bwd_f32(const float* stu_mu, long lds, const float* tea_mu, long ldt, int B,
+                                            int A, float max_action, int act_tanh, float grad_scale,
+                                            float* scal_out, float* dstu_mu, long ldd, void* stream) {
+    PM_REQUIRE(stu_mu && tea_mu && scal_out && dstu_mu && B > 0 && A > 0 && max_action > 0.f);
+    hipLaunchKernelGGL(mse_tanh_loss_kernel, dim3(1), dim3(LOSS_THREADS), 0, pm_stream(stream), stu_mu, lds, tea_mu,
+                       ldt, B, A, max_action, act_tanh, grad_scale, scal_out, dstu_mu, ldd);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+__global__ __launch_bounds__(256) void action_activation_kernel(const float* __restrict__ mu, float* __restrict__ out,
+                                                                 long n, float max_action, int act_tanh) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = act_tanh ? tanhf(mu[i]) * max_action : mu[i];
+}
+
+extern "C" int pm_action_activation_f32(const float* mu, float* out, long n, float max_action, int act_tanh,
+                                        void* stream) {
+    PM_REQUIRE(mu && out && n > 0);
+    long b = (n + 255) / 256;
+    if (b > 1024) b = 1024;
+    hipLaunchKernelGGL(action_activation_kernel, dim3((int)b), dim3(256), 0, pm_stream(stream), mu, out, n,
+                       max_action, act_tanh);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// ---------------------------------------------------------------------------------- stats
+// ppo.py:335-336 (kl_max), :355-357 (sums over non-skipped actor steps), :384 (value loss).
+__global__ void ppo_accumulate_stats_kernel(float* __restrict__ acc, const float* __restrict__ scal, int which) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (which == 0) {
+        const float loss = scal[0], kl = scal[1], skip = scal[2];
+        if (kl > acc[2]) acc[2] = kl;
+        if (skip == 0.0f) {
+            acc[0] += loss;
+            acc[1] += kl;
+            acc[3] += 1.0f;
+        }
+    } else {
+        acc[4] += scal[0];
+        acc[5] += 1.0f;
+    }
+}
+
+extern "C" int pm_ppo_accumulate_stats_f32(float* acc, const float* scal, int which, void* stream) {
+    PM_REQUIRE(acc && scal && (which == 0 || which == 1));
+    hipLaunchKernelGGL(ppo_accumulate_stats_kernel, dim3(1), dim3(64), 0, pm_stream(stream), acc, scal, which);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}

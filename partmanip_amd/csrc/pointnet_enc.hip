@@ -1,0 +1,662 @@
+// K6/K7: PointNet per-point shared MLP (C->128->256->512, tanh,tanh,none) fused with the
+// symmetric max(/mean) pooling -- network.py:147-153,172-181 -- forward and backward.
+//
+// Data layout in HBM
+//   x       (B, ldx)      one row per env-step: P points x C floats (+ optional proprio tail)
+//   packed  768 KB        W2 / W3 / W2-for-backward re-laid in MFMA B-operand order so that a
+//                         wave's 16 B-per-lane load is one contiguous 1 KB (L2-resident)
+//   feat    (B, ldf)      [max(512) | mean(512)]   argmax (B,512) int32
+//   never materialised: the (B,P,128/256/512) activations (4.3 GB per net at B=2048).
+//
+// One work-group (4 waves) owns one cloud and walks it in tiles of 64 points:
+//   layer 1 (K=C<=8)  VALU          -> H1 tile in LDS  [64][132]
+//   layer 2 (K=128)   fp32 MFMA     -> H2 tile in LDS  [64][260]   (aliases H1 after a barrier)
+//   layer 3 (K=256)   fp32 MFMA     -> running max / argmax / sum per channel in registers
+// A operands (activations) come from LDS by ds_read_b128 (row stride = K+4 floats: bank-
+// conflict free for the 16-lane b128 groups); B operands (weights) stream from L2 straight
+// into registers, one N-slice per wave, so the only LDS traffic is the activation tile.
+// MFMA = v_mfma_f32_32x32x2_f32 with the k-split convention: lanes 0-31 own k in [0,K/2),
+// lanes 32-63 own k in [K/2,K); points are MFMA rows, channels MFMA columns, so pooling over
+// points is an in-lane reduction over the 16 accumulator registers + one lane^32 exchange.
+#include "common.h"
+
+#define PN_C1 128
+#define PN_C2 256
+#define PN_C3 512
+#define PN_TM 64
+#define PN_LD1 (PN_C1 + 4)
+#define PN_LD2 (PN_C2 + 4)
+#define PN_MAXC 8
+
+#define PN_P2_OFF 0                      // [8][16][64][4]  W2 as fwd B operand
+#define PN_P3_OFF 32768                  // [16][32][64][4] W3 as fwd B operand
+#define PN_P2T_OFF (32768 + 131072)      // [4][32][64][4]  W2 as bwd (dh1 = dz2 * W2) B operand
+#define PN_PACKED_ELEMS (32768 + 131072 + 32768)
+
+extern "C" size_t pm_pointnet_packed_elems(void) { return PN_PACKED_ELEMS; }
+
+__global__ __launch_bounds__(256) void pn_pack_kernel(const float* __restrict__ W2, const float* __restrict__ W3,
+                                                       float* __restrict__ packed) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= PN_PACKED_ELEMS) return;
+    const int e = i & 3, lane = (i >> 2) & 63, li = lane & 31, lh = lane >> 5;
+    if (i < PN_P3_OFF) {                                   // W2 fwd: half = 64 k, 16 groups of 4
+        const int s4 = (i >> 8) & 15, nb = i >> 12;
+        packed[i] = W2[(nb * 32 + li) * PN_C1 + lh * 64 + s4 * 4 + e];
+    } else if (i < PN_P2T_OFF) {                           // W3 fwd: half = 128 k, 32 groups
+        const int j = i - PN_P3_OFF, s4 = (j >> 8) & 31, nb = j >> 13;
+        packed[i] = W3[(nb * 32 + li) * PN_C2 + lh * 128 + s4 * 4 + e];
+    } else {                                               // W2 bwd: B[k=out][j=in], half = 128 k
+        const int j = i - PN_P2T_OFF, s4 = (j >> 8) & 31, nb = j >> 13;
+        packed[i] = W2[(lh * 128 + s4 * 4 + e) * PN_C1 + nb * 32 + li];
+    }
+}
+
+extern "C" int pm_pointnet_pack_weights_f32(const float* W2, const float* W3, float* packed, void* stream) {
+    PM_REQUIRE(W2 && W3 && packed);
+    hipLaunchKernelGGL(pn_pack_kernel, dim3((PN_PACKED_ELEMS + 255) / 256), dim3(256), 0, pm_stream(stream), W2, W3,
+                       packed);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// ---- shared device pieces -----------------------------------------------------------------
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// centroid of the first 3 coordinates of a cloud (network.py:172-173 `sub_mean`)
+__device__ __forceinline__ void cloud_centroid(const float* __restrict__ xb, int P, int C, double* red, float (&cen)[3]) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        s0 += (double)xb[p * C];
+        s1 += (double)xb[p * C + 1];
+        s2 += (double)xb[p * C + 2];
+    }
+    s0 = block_sum<double, 256>(s0, red);
+    s1 = block_sum<double, 256>(s1, red);
+    s2 = block_sum<double, 256>(s2, red);
+    cen[0] = (float)(s0 / P);
+    cen[1] = (float)(s1 / P);
+    cen[2] = (float)(s2 / P);
+}
+
+// stage one tile of 64 points (C floats each) into Xs[64][PN_MAXC], optionally re-centred
+__device__ __forceinline__ void stage_points(const float* __restrict__ xb, int tile, int C, int sub_mean,
+                                             const float (&cen)[3], float* __restrict__ Xs) {
+    for (int i = threadIdx.x; i < PN_TM * C; i += 256) {
+        const int p = i / C, d = i - p * C;
+        float v = xb[(tile * PN_TM) * C + i];
+        if (sub_mean && d < 3) v -= cen[d];
+        Xs[p * PN_MAXC + d] = v;
+    }
+}
+
+// layer 1: thread (c = tid&127, half = tid>>7) computes tanh(b1[c] + W1[c,:] . x[p,:]) for its 32 points
+__device__ __forceinline__ void layer1_tile(const float* __restrict__ Xs, const float* __restrict__ W1,
+                                            const float* __restrict__ b1, int C, float* __restrict__ H1) {
+    const int c = threadIdx.x & 127, p0 = (threadIdx.x >> 7) * 32;
+    float w1[PN_MAXC];                         // re-read per tile (L1/L2 hit) instead of pinning 9 VGPRs
+#pragma unroll
+    for (int d = 0; d < PN_MAXC; ++d) w1[d] = (d < C) ? W1[c * C + d] : 0.f;
+    const float b1c = b1[c];
+#pragma unroll 4
+    for (int p = p0; p < p0 + 32; ++p) {
+        float s = b1c;
+#pragma unroll
+        for (int d = 0; d < PN_MAXC; ++d)
+            if (d < C) s += w1[d] * Xs[p * PN_MAXC + d];
+        H1[p * PN_LD1 + c] = tanhf(s);
+    }
+}
+
+// layer 2 MFMA part: acc[mb][nb] (64 points x this wave's 64 channels) = H1 * W2^T
+__device__ __forceinline__ void layer2_mfma(const float* __restrict__ H1, const float4* __restrict__ P2v, int wave,
+                                            int lane, f32x16 (&acc)[2][2]) {
+    const int li = lane & 31, lh = lane >> 5;
+    const float4* Bp = P2v + (size_t)(wave * 2) * 16 * 64 + lane;
+    const float* A0 = H1 + li * PN_LD1 + lh * 64;
+    const float* A1 = H1 + (32 + li) * PN_LD1 + lh * 64;
+    float4 bn0 = Bp[0], bn1 = Bp[16 * 64];
+    float4 an0 = *(const float4*)A0, an1 = *(const float4*)A1;
+#pragma unroll 2
+    for (int s4 = 0; s4 < 16; ++s4) {
+        const float4 b0 = bn0, b1 = bn1, a0 = an0, a1 = an1;
+        if (s4 + 1 < 16) {
+            bn0 = Bp[(s4 + 1) * 64];
+            bn1 = Bp[(16 + s4 + 1) * 64];
+            an0 = *(const float4*)(A0 + (s4 + 1) * 4);
+            an1 = *(const float4*)(A1 + (s4 + 1) * 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[0][0] = MFMA(a0[e], b0[e], acc[0][0]);
+            acc[0][1] = MFMA(a0[e], b1[e], acc[0][1]);
+            acc[1][0] = MFMA(a1[e], b0[e], acc[1][0]);
+            acc[1][1] = MFMA(a1[e], b1[e], acc[1][1]);
+        }
+    }
+}
+
+// layer 2 epilogue: H2[row][ch] = tanh(acc + b2[ch])
+__device__ __forceinline__ void layer2_store(const f32x16 (&acc)[2][2], const float* __restrict__ b2, int wave, int lane,
+                                             float* __restrict__ H2) {
+    const int li = lane & 31, lh = lane >> 5;
+    float b2v[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) b2v[nb] = b2[wave * 64 + nb * 32 + li];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                H2[row * PN_LD2 + wave * 64 + nb * 32 + li] = tanhf(acc[mb][nb][r] + b2v[nb]);
+            }
+}
+
+// =================================================================================== forward
+__global__ __launch_bounds__(256, 2) void pn_fwd_kernel(const float* __restrict__ x, long ldx, int P, int C,
+                                                         int sub_mean, const float* __restrict__ W1,
+                                                         const float* __restrict__ b1, const float* __restrict__ b2,
+                                                         const float* __restrict__ b3,
+                                                         const float* __restrict__ packed, int max_mean,
+                                                         float* __restrict__ feat, long ldf,
+                                                         int32_t* __restrict__ argmax) {
+    __shared__ __attribute__((aligned(16))) float smem[PN_TM * PN_LD2 + PN_TM * PN_MAXC + 16];
+    float* H = smem;                             // H1 [64][132] then H2 [64][260] (aliased)
+    float* Xs = smem + PN_TM * PN_LD2;
+    double* red = (double*)(Xs + PN_TM * PN_MAXC);
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const float* xb = x + (long)b * ldx;
+    const float4* P2v = (const float4*)(packed + PN_P2_OFF);
+    const float4* P3v = (const float4*)(packed + PN_P3_OFF);
+
+    float cen[3] = {0.f, 0.f, 0.f};
+    if (sub_mean) cloud_centroid(xb, P, C, red, cen);
+
+    float vmax[4], vsum[4];
+    int imax[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        vmax[nb] = -INFINITY;
+        vsum[nb] = 0.f;
+        imax[nb] = 0;
+    }
+
+    const int ntiles = P / PN_TM;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        __syncthreads();                          // previous tile's layer-3 reads of H are done
+        stage_points(xb, tile, C, sub_mean, cen, Xs);
+        __syncthreads();
+        layer1_tile(Xs, W1, b1, C, H);
+        __syncthreads();
+        {
+            f32x16 acc2[2][2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[mb][nb][r] = 0.f;
+            layer2_mfma(H, P2v, wave, lane, acc2);
+            __syncthreads();                      // every wave has finished reading H1
+            layer2_store(acc2, b2, wave, lane, H);
+        }
+        __syncthreads();
+
+        // ---- layer 3: 64 points x this wave's 128 channels, K = 256 -------------------------
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const float b3c = b3[wave * 128 + nb * 32 + li];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][nb][r] = acc[1][nb][r] = b3c;
+        }
+        {
+            const float4* Bp = P3v + (size_t)(wave * 4) * 32 * 64 + lane;
+            const float* A0 = H + li * PN_LD2 + lh * 128;
+            const float* A1 = H + (32 + li) * PN_LD2 + lh * 128;
+            float4 bn[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) bn[nb] = Bp[(nb * 32) * 64];
+            float4 an0 = *(const float4*)A0, an1 = *(const float4*)A1;
+#pragma unroll 2
+            for (int s4 = 0; s4 < 32; ++s4) {
+                float4 bc[4];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) bc[nb] = bn[nb];
+                const float4 a0 = an0, a1 = an1;
+                if (s4 + 1 < 32) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) bn[nb] = Bp[(nb * 32 + s4 + 1) * 64];
+                    an0 = *(const float4*)(A0 + (s4 + 1) * 4);
+                    an1 = *(const float4*)(A1 + (s4 + 1) * 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        acc[0][nb] = MFMA(a0[e], bc[nb][e], acc[0][nb]);
+                        acc[1][nb] = MFMA(a1[e], bc[nb][e], acc[1][nb]);
+                    }
+                }
+            }
+        }
+        // ---- pooling over this tile's 64 points (rows), in increasing point order ------------
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[mb][nb][r];
+                    const int p = tile * PN_TM + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (v > vmax[nb]) {
+                        vmax[nb] = v;
+                        imax[nb] = p;
+                    }
+                    vsum[nb] += v;
+                }
+    }
+    // lanes l and l^32 hold the two interleaved row sets of the same channel
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const float ov = __shfl_xor(vmax[nb], 32, 64);
+        const int oi = __shfl_xor(imax[nb], 32, 64);
+        const float os = __shfl_xor(vsum[nb], 32, 64);
+        float v = vmax[nb];
+        int i = imax[nb];
+        if (ov > v || (ov == v && oi < i)) {
+            v = ov;
+            i = oi;
+        }
+        if (lh == 0) {
+            const int ch = wave * 128 + nb * 32 + li;
+            feat[(long)b * ldf + ch] = v;
+            if (max_mean) feat[(long)b * ldf + PN_C3 + ch] = (vsum[nb] + os) / (float)P;
+            argmax[(long)b * PN_C3 + ch] = i;
+        }
+    }
+}
+
+extern "C" int pm_pointnet_enc_fwd_f32(const float* x, long ldx, int B, int P, int C, int sub_mean,
+                                       const float* W1, const float* b1, const float* b2, const float* b3,
+                                       const float* packed, int max_mean, float* feat, long ldf, int32_t* argmax,
+                                       void* stream) {
+    PM_REQUIRE(x && W1 && b1 && b2 && b3 && packed && feat && argmax);
+    PM_REQUIRE(B > 0 && P > 0 && P % PN_TM == 0 && C >= 1 && C <= PN_MAXC && ldx >= (long)P * C);
+    PM_REQUIRE(ldf >= PN_C3 * (max_mean ? 2 : 1));
+    PM_REQUIRE(!sub_mean || C >= 3);
+    if (((uintptr_t)packed & 15) != 0) return PM_EALIGN;
+    hipLaunchKernelGGL(pn_fwd_kernel, dim3(B), dim3(256), 0, pm_stream(stream), x, ldx, P, C, sub_mean, W1, b1, b2, b3,
+                       packed, max_mean, feat, ldf, argmax);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// ================================================================================== backward
+// Gradient of the pooled features w.r.t. the layer-3 output is structured:
+//   G[b,p,c] = dmean[b,c]/P  (every point)  +  dmax[b,c] * [p == argmax[b,c]]
+// so with  u[b,:] = dmean[b,:] * W3  (B x 256, a small GEMM done before this kernel)
+//   d h2[b,p,:] = u[b,:]/P + sum_{c: argmax[b,c]=p} dmax[b,c] * W3[c,:]
+//   d W3        = (dmean/P)^T * (sum_p h2[b,p,:])  +  sum_{b,c} dmax[b,c] e_c (x) h2[b,argmax[b,c],:]
+// and only layers 1-2 need a dense backward.  Per cloud the kernel recomputes h1,h2 tile by
+// tile (same code as the forward), turns the H2 tile into dz2 in place, and runs
+//   dW2 += dz2^T * h1     (MFMA, both operands from LDS, accumulator lives in registers for
+//                          the whole kernel: 256x128 over 4 waves x 128 VGPRs)
+//   dh1  = dz2 * W2       (MFMA, B operand streamed from L2)  ->  dz1 = dh1 .* (1-h1^2)
+//   dW1/db1 += dz1^T [x 1] (VALU, K = C+1)
+// It also emits, per cloud, sum_p h2 (scaled 1/P) and the h2 rows at the argmax points
+// (Hg[b,c,:]) from which two small follow-up kernels build dW3/db3.
+// Work-groups are persistent over clouds (grid <= 256) so the dW2 partials stay small.
+
+#define PN_BWD_MAXG 256
+
+struct PnBwdPart {          // per-work-group partial sums (floats)
+    float dW2[PN_C2 * PN_C1];
+    float db2[PN_C2];
+    float dW1[PN_C1 * PN_MAXC];
+    float db1[PN_C1];
+};
+
+// in-LDS bitonic sort of 512 int keys by 256 threads (ascending)
+__device__ __forceinline__ void bitonic_sort_512(int* keys) {
+    for (int k = 2; k <= 512; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            const int t = threadIdx.x;
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // lower index of the pair
+            const int ixj = i | j;
+            const int a = keys[i], c = keys[ixj];
+            const bool up = ((i & k) == 0);
+            if ((a > c) == up) {
+                keys[i] = c;
+                keys[ixj] = a;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
+    const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
+    const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ W3,
+    const float* __restrict__ packed, int max_mean, const float* __restrict__ dfeat, long ldf,
+    const int32_t* __restrict__ argmax, const float* __restrict__ U, float* __restrict__ H2sum,
+    float* __restrict__ Hg, PnBwdPart* __restrict__ parts) {
+    __shared__ __attribute__((aligned(16))) float smem[PN_TM * PN_LD1 * 2 + PN_TM * PN_LD2 + PN_TM * PN_MAXC +
+                                                        PN_C2 + PN_C3 + PN_C3 + 1040 + 4 * PN_C2 + 16];
+    float* H1 = smem;                                   // [64][132]
+    float* DZ1 = H1 + PN_TM * PN_LD1;                   // [64][132]
+    float* H2 = DZ1 + PN_TM * PN_LD1;                   // [64][260]  h2, then dz2 in place
+    float* Xs = H2 + PN_TM * PN_LD2;                    // [64][8]
+    float* Us = Xs + PN_TM * PN_MAXC;                   // [256]  u[b,:]/P
+    float* Gm = Us + PN_C2;                             // [512]  dmax[b,:]
+    int* keys = (int*)(Gm + PN_C3);                     // [512]  sorted (point<<9 | channel)
+    int* offs = keys + PN_C3;                           // [P+1 <= 1025(+pad)] first key index of each point
+    float* wred = (float*)(offs + 1040);                // [4][256] cross-wave reductions
+    double* red = (double*)(wred + 4 * PN_C2);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const float4* P2v = (const float4*)(packed + PN_P2_OFF);
+    const float4* P2Tv = (const float4*)(packed + PN_P2T_OFF);
+    const float invP = 1.0f / (float)P;
+
+    // accumulators that live for the whole kernel
+    f32x16 accW2[2][4];                                  // dW2[out = wave*64+mb*32+row][in = nb*32+li]
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accW2[mb][nb][r] = 0.f;
+    float4 db2acc = make_float4(0.f, 0.f, 0.f, 0.f);   // columns 4*lane..+3 over this wave's rows
+    float dW1acc[PN_MAXC], db1acc = 0.f;                 // channel tid&127, point half tid>>7
+#pragma unroll
+    for (int d = 0; d < PN_MAXC; ++d) dW1acc[d] = 0.f;
+
+    const int ntiles = P / PN_TM;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const float* xb = x + (long)b * ldx;
+        float cen[3] = {0.f, 0.f, 0.f};
+        __syncthreads();
+        if (sub_mean) cloud_centroid(xb, P, C, red, cen);
+        // ---- per-cloud setup: u/P, dmax, CSR of argmax by point ---------------------------
+        Us[tid] = max_mean ? U[(long)b * PN_C2 + tid] * invP : 0.f;
+        for (int c = tid; c < PN_C3; c += 256) {
+            Gm[c] = dfeat[(long)b * ldf + c];
+            keys[c] = (argmax[(long)b * PN_C3 + c] << 9) | c;
+        }
+        bitonic_sort_512(keys);                           // by point, then channel: deterministic order
+        for (int p = tid; p <= P; p += 256) {            // offs[p] = #keys with point < p (binary search)
+            int lo = 0, hi = PN_C3;
+            const int target = p << 9;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (keys[mid] < target) lo = mid + 1; else hi = mid;
+            }
+            offs[p] = lo;
+        }
+        float4 h2s = make_float4(0.f, 0.f, 0.f, 0.f);    // sum_p h2[p][4*lane..] over this wave's rows
+
+        for (int tile = 0; tile < ntiles; ++tile) {
+            __syncthreads();
+            stage_points(xb, tile, C, sub_mean, cen, Xs);
+            __syncthreads();
+            layer1_tile(Xs, W1, b1, C, H1);
+            __syncthreads();
+            {
+                f32x16 acc2[2][2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc2[mb][nb][r] = 0.f;
+                layer2_mfma(H1, P2v, wave, lane, acc2);
+                layer2_store(acc2, b2, wave, lane, H2);
+            }
+            __syncthreads();
+            // ---- row-owner pass: wave w owns rows w*16..w*16+15; h2 -> dz2 in place ----------
+            {
+                const int p0 = tile * PN_TM + wave * 16;
+                const float4 u4 = *(const float4*)(Us + 4 * lane);
+                const int e_end = offs[p0 + 16];
+                int e = offs[p0];
+                int c_next = 0;
+                float4 w_next = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < e_end) {
+                    c_next = keys[e] & 511;
+                    w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
+                }
+                for (int rr = 0; rr < 16; ++rr) {
+                    float* hrow = H2 + (wave * 16 + rr) * PN_LD2 + 4 * lane;
+                    const float4 h = *(const float4*)hrow;
+                    h2s.x += h.x; h2s.y += h.y; h2s.z += h.z; h2s.w += h.w;
+                    float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int row_end = offs[p0 + rr + 1];
+                    for (; e < row_end; ++e) {
+                        const int c = c_next;
+                        const float4 w3 = w_next;
+                        if (e + 1 < e_end) {
+                            c_next = keys[e + 1] & 511;
+                            w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
+                        }
+                        const float g = Gm[c];
+                        *(float4*)(Hg + ((long)b * PN_C3 + c) * PN_C2 + 4 * lane) = h;
+                        S.x += g * w3.x; S.y += g * w3.y; S.z += g * w3.z; S.w += g * w3.w;
+                    }
+                    float4 dz;
+                    dz.x = (u4.x + S.x) * (1.0f - h.x * h.x);
+                    dz.y = (u4.y + S.y) * (1.0f - h.y * h.y);
+                    dz.z = (u4.z + S.z) * (1.0f - h.z * h.z);
+                    dz.w = (u4.w + S.w) * (1.0f - h.w * h.w);
+                    *(float4*)hrow = dz;
+                    db2acc.x += dz.x; db2acc.y += dz.y; db2acc.z += dz.z; db2acc.w += dz.w;
+                }
+            }
+            __syncthreads();
+            // ---- dW2 += dz2^T * h1 : K = 64 points (lanes<32: point s, lanes>=32: point 32+s) ----
+            {
+                const float* Ap = H2 + (lh * 32) * PN_LD2 + wave * 64 + li;     // A[i=out][k=pt] = dz2[pt][out]
+                const float* Bp = H1 + (lh * 32) * PN_LD1 + li;                 // B[k=pt][j=in] = h1[pt][in]
+#pragma unroll 4
+                for (int s = 0; s < 32; ++s) {
+                    const float a0 = Ap[s * PN_LD2], a1 = Ap[s * PN_LD2 + 32];
+                    float bv[4];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) bv[nb] = Bp[s * PN_LD1 + nb * 32];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        accW2[0][nb] = MFMA(a0, bv[nb], accW2[0][nb]);
+                        accW2[1][nb] = MFMA(a1, bv[nb], accW2[1][nb]);
+                    }
+                }
+            }
+            // ---- dh1 = dz2 * W2 : this wave's 32 input channels, K = 256 --------------------
+            {
+                f32x16 accH[2];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accH[0][r] = accH[1][r] = 0.f;
+                const float4* Bp = P2Tv + (size_t)wave * 32 * 64 + lane;
+                const float* A0 = H2 + li * PN_LD2 + lh * 128;
+                const float* A1 = H2 + (32 + li) * PN_LD2 + lh * 128;
+                float4 bn = Bp[0], an0 = *(const float4*)A0, an1 = *(const float4*)A1;
+#pragma unroll 2
+                for (int s4 = 0; s4 < 32; ++s4) {
+                    const float4 bc = bn, a0 = an0, a1 = an1;
+                    if (s4 + 1 < 32) {
+                        bn = Bp[(s4 + 1) * 64];
+                        an0 = *(const float4*)(A0 + (s4 + 1) * 4);
+                        an1 = *(const float4*)(A1 + (s4 + 1) * 4);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        accH[0] = MFMA(a0[e], bc[e], accH[0]);
+                        accH[1] = MFMA(a1[e], bc[e], accH[1]);
+                    }
+                }
+                // dz1 = dh1 .* (1 - h1^2)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = wave * 32 + li;
+                        const float h = H1[row * PN_LD1 + col];
+                        DZ1[row * PN_LD1 + col] = accH[mb][r] * (1.0f - h * h);
+                    }
+            }
+            __syncthreads();
+            // ---- dW1 / db1 (K = C): thread (c, half) over its 32 points ---------------------
+            {
+                const int c = tid & 127, p0 = (tid >> 7) * 32;
+                for (int p = p0; p < p0 + 32; ++p) {
+                    const float dz = DZ1[p * PN_LD1 + c];
+                    db1acc += dz;
+#pragma unroll
+                    for (int d = 0; d < PN_MAXC; ++d)
+                        if (d < C) dW1acc[d] += dz * Xs[p * PN_MAXC + d];
+                }
+            }
+        }
+        // ---- per-cloud output: sum_p h2 / P (for dW3's mean term) ---------------------------
+        __syncthreads();
+        *(float4*)(wred + wave * PN_C2 + 4 * lane) = h2s;
+        __syncthreads();
+        H2sum[(long)b * PN_C2 + tid] = (wred[tid] + wred[PN_C2 + tid] + wred[2 * PN_C2 + tid] + wred[3 * PN_C2 + tid]) * invP;
+    }
+
+    // ---- write this work-group's partial sums ------------------------------------------------
+    PnBwdPart* part = parts + blockIdx.x;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int out = wave * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                part->dW2[out * PN_C1 + nb * 32 + li] = accW2[mb][nb][r];
+            }
+    __syncthreads();
+    *(float4*)(wred + wave * PN_C2 + 4 * lane) = db2acc;
+    __syncthreads();
+    part->db2[tid] = wred[tid] + wred[PN_C2 + tid] + wred[2 * PN_C2 + tid] + wred[3 * PN_C2 + tid];
+    __syncthreads();
+    {   // combine the two point-halves of dW1/db1 through LDS
+        float* t = wred;                                  // [2][128][PN_MAXC+1] = 2304 floats > 1024: use H1 region
+        t = H1;
+        const int c = tid & 127, half = tid >> 7;
+#pragma unroll
+        for (int d = 0; d < PN_MAXC; ++d) t[(half * 128 + c) * (PN_MAXC + 1) + d] = dW1acc[d];
+        t[(half * 128 + c) * (PN_MAXC + 1) + PN_MAXC] = db1acc;
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int d = 0; d < PN_MAXC; ++d)
+                part->dW1[c * PN_MAXC + d] = t[c * (PN_MAXC + 1) + d] + t[(128 + c) * (PN_MAXC + 1) + d];
+            part->db1[c] = t[c * (PN_MAXC + 1) + PN_MAXC] + t[(128 + c) * (PN_MAXC + 1) + PN_MAXC];
+        }
+    }
+}
+
+// sum the per-work-group partials in fixed order
+__global__ __launch_bounds__(256) void pn_bwd_reduce_kernel(const PnBwdPart* __restrict__ parts, int G, int C,
+                                                             float* __restrict__ dW1, float* __restrict__ db1,
+                                                             float* __restrict__ dW2, float* __restrict__ db2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = (int)(sizeof(PnBwdPart) / sizeof(float));
+    if (i >= n) return;
+    const float* base = (const float*)parts;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += base[(size_t)g * n + i];
+    const int o_db2 = PN_C2 * PN_C1, o_dW1 = o_db2 + PN_C2, o_db1 = o_dW1 + PN_C1 * PN_MAXC;
+    if (i < o_db2) dW2[i] = s;
+    else if (i < o_dW1) db2[i - o_db2] = s;
+    else if (i < o_db1) {
+        const int j = i - o_dW1, c = j / PN_MAXC, d = j % PN_MAXC;
+        if (d < C) dW1[c * C + d] = s;
+    } else db1[i - o_db1] = s;
+}
+
+// dW3[c,:] (+)= sum_b dmax[b,c] * Hg[b,c,:] ;  db3[c] = sum_b (dmax[b,c] + dmean[b,c])
+__global__ __launch_bounds__(256) void pn_dw3_gather_kernel(const float* __restrict__ dfeat, long ldf, int B,
+                                                             int max_mean, const float* __restrict__ Hg,
+                                                             float* __restrict__ dW3, float* __restrict__ db3) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, k = threadIdx.x;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < B; ++b) acc += dfeat[(long)b * ldf + c] * Hg[((long)b * PN_C3 + c) * PN_C2 + k];
+    dW3[c * PN_C2 + k] = (max_mean ? dW3[c * PN_C2 + k] : 0.f) + acc;
+    float s = 0.f;
+    for (int b = k; b < B; b += 256) s += dfeat[(long)b * ldf + c] + (max_mean ? dfeat[(long)b * ldf + PN_C3 + c] : 0.f);
+    s = block_sum<float, 256>(s, red);
+    if (k == 0) db3[c] = s;
+}
+
+static inline int pn_bwd_grid(int B) { return B < PN_BWD_MAXG ? B : PN_BWD_MAXG; }
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct PnBwdWs {
+    size_t off_U, off_H2sum, off_Hg, off_parts, off_gemm, total;
+};
+static PnBwdWs pn_bwd_layout(int B) {
+    PnBwdWs w;
+    size_t o = 0;
+    w.off_U = o;      o += align256((size_t)B * PN_C2 * 4);
+    w.off_H2sum = o;  o += align256((size_t)B * PN_C2 * 4);
+    w.off_Hg = o;     o += align256((size_t)B * PN_C3 * PN_C2 * 4);
+    w.off_parts = o;  o += align256((size_t)pn_bwd_grid(B) * sizeof(PnBwdPart));
+    w.off_gemm = o;   o += align256(pm_linear_bwd_weight_workspace_bytes(B, PN_C3, PN_C2));
+    w.total = o;
+    return w;
+}
+
+extern "C" size_t pm_pointnet_enc_bwd_workspace_bytes(int B, int P, int C) {
+    (void)P; (void)C;
+    return B > 0 ? pn_bwd_layout(B).total : 0;
+}
+
+extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, int C, int sub_mean,
+                                       const float* W1, const float* b1, const float* b2, const float* W3,
+                                       const float* packed, int max_mean, const float* dfeat, long ldf,
+                                       const int32_t* argmax, float* dW1, float* db1, float* dW2, float* db2,
+                                       float* dW3, float* db3, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    PM_REQUIRE(x && W1 && b1 && b2 && W3 && packed && dfeat && argmax && dW1 && db1 && dW2 && db2 && dW3 && db3);
+    PM_REQUIRE(B > 0 && P > 0 && P % PN_TM == 0 && P <= 1024 && C >= 1 && C <= PN_MAXC && ldx >= (long)P * C);
+    PM_REQUIRE(ldf >= PN_C3 * (max_mean ? 2 : 1));
+    PM_REQUIRE(!sub_mean || C >= 3);
+    if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)W3 & 15) != 0 || ((uintptr_t)workspace & 255) != 0) return PM_EALIGN;
+    const PnBwdWs w = pn_bwd_layout(B);
+    if (!workspace || workspace_bytes < w.total) return PM_EWORKSPACE;
+    char* ws = (char*)workspace;
+    float* U = (float*)(ws + w.off_U);
+    float* H2sum = (float*)(ws + w.off_H2sum);
+    float* Hg = (float*)(ws + w.off_Hg);
+    PnBwdPart* parts = (PnBwdPart*)(ws + w.off_parts);
+    int rc;
+    if (max_mean) {   // U[B,256] = dmean[B,512] * W3[512,256]
+        rc = pm_linear_bwd_data_f32(dfeat + PN_C3, ldf, W3, PN_C2, nullptr, 0, U, PN_C2, B, PN_C3, PN_C2, PM_ACT_NONE,
+                                    stream);
+        if (rc != PM_OK) return rc;
+    }
+    const int G = pn_bwd_grid(B);
+    hipLaunchKernelGGL(pn_bwd_kernel, dim3(G), dim3(256), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, b2, W3,
+                       packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, parts);
+    const int n = (int)(sizeof(PnBwdPart) / sizeof(float));
+    hipLaunchKernelGGL(pn_bwd_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, pm_stream(stream), parts, G, C, dW1,
+                       db1, dW2, db2);
+    if (max_mean) {   // dW3 = dmean^T * (sum_p h2 / P)
+        rc = pm_linear_bwd_weight_f32(dfeat + PN_C3, ldf, H2sum, PN_C2, dW3, PN_C2, nullptr, B, PN_C3, PN_C2,
+                                      ws + w.off_gemm, w.total - w.off_gemm, stream);
+        if (rc != PM_OK) return rc;
+    }
+    hipLaunchKernelGGL(pn_dw3_gather_kernel, dim3(PN_C3), dim3(256), 0, pm_stream(stream), dfeat, ldf, B, max_mean, Hg,
+                       dW3, db3);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}

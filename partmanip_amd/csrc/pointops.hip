@@ -1,0 +1,237 @@
+// K12 farthest point sampling, K13 ball query, K14 grouping (+ backward).
+// Integer-index outputs: bit-exact against the CPU restatement used by the tests (same fp32 distance
+// expression ((dx*dx)+dy*dy)+dz*dz with no FMA contraction, same tie-breaks).
+// The reference tree holds no implementation of these: parity unpinned.
+#include "common.h"
+
+#define FPS_NT 1024
+#define FPS_MAXD 4
+#define FPS_RPT 8            // register-resident points per thread (P <= 8192)
+
+__device__ __forceinline__ float dist2_rn(const float* a, const float* b, int D) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < FPS_MAXD; ++d)
+        if (d < D) {
+            const float t = sub_rn(a[d], b[d]);
+            s = (d == 0) ? mul_rn(t, t) : add_rn(s, mul_rn(t, t));
+        }
+    return s;
+}
+
+// (value, index) arg-max with lowest index on ties, across the work-group.
+__device__ __forceinline__ int block_argmax(float v, int i, float* sv, int* si) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(i, o, 64);
+        if (ov > v || (ov == v && oi < i)) {
+            v = ov;
+            i = oi;
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+        sv[w] = v;
+        si[w] = i;
+    }
+    __syncthreads();
+    float bv = sv[0];
+    int bi = si[0];
+    for (int k = 1; k < FPS_NT / 64; ++k) {
+        const float ov = sv[k];
+        const int oi = si[k];
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    return bi;
+}
+
+// One work-group per cloud.  REG variant keeps the cloud and the running min-distance in
+// registers (P <= 8192); the streaming variant re-reads points from L2/HBM and keeps the
+// min-distance in a caller-supplied fp32 workspace (depth2pc-sized clouds: P = 442 368).
+template <bool REG>
+__global__ __launch_bounds__(FPS_NT) void fps_kernel(const float* __restrict__ xyz, int P, int D, int K,
+                                                      int32_t* __restrict__ idx_out, float* __restrict__ mind_ws) {
+    __shared__ float sv[FPS_NT / 64];
+    __shared__ int si[FPS_NT / 64];
+    __shared__ float sel[FPS_MAXD];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* pts = xyz + (long)b * P * D;
+    float* mind_g = REG ? nullptr : mind_ws + (long)b * P;
+    float px[FPS_RPT][FPS_MAXD];
+    float mind[FPS_RPT];
+    if (REG) {
+#pragma unroll
+        for (int r = 0; r < FPS_RPT; ++r) {
+            const int p = tid + r * FPS_NT;
+            mind[r] = INFINITY;
+#pragma unroll
+            for (int d = 0; d < FPS_MAXD; ++d) px[r][d] = (p < P && d < D) ? pts[(long)p * D + d] : 0.f;
+        }
+    } else {
+        for (int p = tid; p < P; p += FPS_NT) mind_g[p] = INFINITY;
+    }
+    int cur = 0;
+    for (int j = 0; j < K; ++j) {
+        if (j >= P) {                       // more samples than points: pytorch3d pads with -1
+            if (tid == 0) idx_out[(long)b * K + j] = -1;
+            continue;
+        }
+        if (tid == 0) idx_out[(long)b * K + j] = cur;
+        if (tid < D) sel[tid] = pts[(long)cur * D + tid];
+        __syncthreads();
+        float s[FPS_MAXD];
+#pragma unroll
+        for (int d = 0; d < FPS_MAXD; ++d) s[d] = (d < D) ? sel[d] : 0.f;
+        float bv = -1.0f;
+        int bi = 0x7fffffff;
+        if (REG) {
+#pragma unroll
+            for (int r = 0; r < FPS_RPT; ++r) {
+                const int p = tid + r * FPS_NT;
+                if (p < P) {
+                    const float d2 = dist2_rn(px[r], s, D);
+                    mind[r] = fminf(mind[r], d2);
+                    if (mind[r] > bv) {     // strict: keeps the lowest index within the thread
+                        bv = mind[r];
+                        bi = p;
+                    }
+                }
+            }
+        } else {
+            for (int p = tid; p < P; p += FPS_NT) {
+                float q[FPS_MAXD];
+#pragma unroll
+                for (int d = 0; d < FPS_MAXD; ++d) q[d] = (d < D) ? pts[(long)p * D + d] : 0.f;
+                const float m = fminf(mind_g[p], dist2_rn(q, s, D));
+                mind_g[p] = m;
+                if (m > bv) {
+                    bv = m;
+                    bi = p;
+                }
+            }
+        }
+        cur = block_argmax(bv, bi, sv, si);
+    }
+}
+
+extern "C" size_t pm_fps_workspace_bytes(int B, int P) {
+    return (P > FPS_NT * FPS_RPT) ? (size_t)B * P * sizeof(float) : 0;
+}
+
+extern "C" int pm_fps_f32(const float* xyz, int B, int P, int D, int K, int32_t* idx_out, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(xyz && idx_out && B > 0 && P > 0 && D >= 1 && D <= FPS_MAXD && K > 0);
+    if (P <= FPS_NT * FPS_RPT) {
+        hipLaunchKernelGGL(fps_kernel<true>, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, P, D, K, idx_out,
+                           (float*)nullptr);
+    } else {
+        if (!workspace || workspace_bytes < (size_t)B * P * sizeof(float)) return PM_EWORKSPACE;
+        hipLaunchKernelGGL(fps_kernel<false>, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, P, D, K, idx_out,
+                           (float*)workspace);
+    }
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// ---------------------------------------------------------------------------------- K13
+// One wave per centre: 64 points tested per step, __ballot gives the in-radius mask and
+// the popcount of the lower lanes is each hit's output slot (ascending index order).
+__global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz,
+                                                          const float* __restrict__ centers, int B, int P, int S,
+                                                          float r2, int nsample, int32_t* __restrict__ idx_out) {
+    const int lane = threadIdx.x & 63;
+    const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);      // centre id in [0, B*S)
+    if (q >= (long)B * S) return;
+    const int b = (int)(q / S);
+    const float* pts = xyz + (long)b * P * 3;
+    const float c[3] = {centers[q * 3], centers[q * 3 + 1], centers[q * 3 + 2]};
+    int32_t* out = idx_out + q * nsample;
+    int cnt = 0, first = 0;
+    for (int base = 0; base < P && cnt < nsample; base += 64) {
+        const int p = base + lane;
+        bool hit = false;
+        if (p < P) {
+            const float a[3] = {pts[(long)p * 3], pts[(long)p * 3 + 1], pts[(long)p * 3 + 2]};
+            hit = dist2_rn(a, c, 3) < r2;
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            if (cnt == 0) first = base + __builtin_ctzll(mask);
+            const int slot = cnt + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (hit && slot < nsample) out[slot] = p;
+            cnt += __builtin_popcountll(mask);
+        }
+    }
+    if (cnt > nsample) cnt = nsample;
+    for (int j = cnt + lane; j < nsample; j += 64) out[j] = first;   // pad with the first hit (0 if none)
+}
+
+extern "C" int pm_ball_query_f32(const float* xyz, const float* centers, int B, int P, int S, float radius,
+                                 int nsample, int32_t* idx_out, void* stream) {
+    PM_REQUIRE(xyz && centers && idx_out && B > 0 && P > 0 && S > 0 && nsample > 0 && radius > 0.f);
+    const long nq = (long)B * S;
+    const float r2 = radius * radius;
+    hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, pm_stream(stream), xyz, centers,
+                       B, P, S, r2, nsample, idx_out);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// ---------------------------------------------------------------------------------- K14
+// out[b,s,j,:] = feat[b, idx[b,s,j], :]
+__global__ __launch_bounds__(256) void group_points_kernel(const float* __restrict__ feat,
+                                                            const int32_t* __restrict__ idx, int B, int P, int C,
+                                                            long n_rows, int rows_per_b, float* __restrict__ out) {
+    const long total = n_rows * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / C;
+        const int c = (int)(e - row * C);
+        const int b = (int)(row / rows_per_b);
+        out[e] = feat[((long)b * P + idx[row]) * C + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void group_points_bwd_kernel(const float* __restrict__ dout,
+                                                                const int32_t* __restrict__ idx, int B, int P, int C,
+                                                                long n_rows, int rows_per_b,
+                                                                float* __restrict__ dfeat) {
+    const long total = n_rows * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / C;
+        const int c = (int)(e - row * C);
+        const int b = (int)(row / rows_per_b);
+        atomicAdd(&dfeat[((long)b * P + idx[row]) * C + c], dout[e]);
+    }
+}
+
+extern "C" int pm_group_points_f32(const float* feat, const int32_t* idx, int B, int P, int C, int S, int nsample,
+                                   float* out, void* stream) {
+    PM_REQUIRE(feat && idx && out && B > 0 && P > 0 && C > 0 && S > 0 && nsample > 0);
+    const long n_rows = (long)B * S * nsample;
+    long nb = (n_rows * C + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(group_points_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), feat, idx, B, P, C,
+                       n_rows, S * nsample, out);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// dfeat must be zero-filled by the caller; fp32 atomics (summation order is not fixed).
+extern "C" int pm_group_points_bwd_f32(const float* dout, const int32_t* idx, int B, int P, int C, int S,
+                                       int nsample, float* dfeat, void* stream) {
+    PM_REQUIRE(dout && idx && dfeat && B > 0 && P > 0 && C > 0 && S > 0 && nsample > 0);
+    const long n_rows = (long)B * S * nsample;
+    long nb = (n_rows * C + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(group_points_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), dout, idx, B, P, C,
+                       n_rows, S * nsample, dfeat);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_version(void) { return 100; }

@@ -1,0 +1,70 @@
+"""Data-parallel glue: one process per GPU, `torch.distributed` ("nccl" = RCCL over xGMI on
+ROCm; "gloo" for the CPU tests).  The reference has no distributed path; the
+learner shards by env -- rank r owns envs [r*N/W, (r+1)*N/W) and its own (T, N/W, .) storage,
+no rollout data ever moves -- and the only exchange is ONE all-reduce per optimiser step of
+the flat gradient buffer with the step's scalars (loss, kl) riding in its tail.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU); the message here is 1.2-2.2 MB fp32, i.e.
+latency-bound, so everything that must be reduced for a step is packed into that single call.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun-style env vars; returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_envs(num_envs, rank, world):
+    """Contiguous env range owned by `rank`."""
+    if num_envs % world != 0:
+        raise ValueError(f"num_envs={num_envs} is not divisible by world_size={world}")
+    per = num_envs // world
+    return rank * per, (rank + 1) * per
+
+
+class GradSync:
+    """Mean-reduction of flat buffers across the data-parallel group."""
+
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("GradSync needs an initialised process group (see init_from_env)")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def mean_(self, flat):
+        """In-place average of a flat tensor over ranks (sum + scale: gloo has no AVG op)."""
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / self.world)
+        return flat
+
+    def sum_(self, flat):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+    def moments_sync(self, mom2, count):
+        """All-reduce {sum, sumsq} (fp64) of an advantage batch; returns the global count."""
+        self.sum_(mom2)
+        return count * self.world
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+
+def maybe_sync():
+    return GradSync() if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None

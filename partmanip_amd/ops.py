@@ -1,0 +1,254 @@
+"""Tensor-level wrappers over the C ABI (include/partmanip_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every op below passes
+raw device pointers to libpartmanip_hip.so.  Ops refuse CPU tensors -- there is no CPU path.
+"""
+import torch
+
+from ._lib import lib, check
+
+ACT_NONE, ACT_TANH = 0, 1
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("partmanip_amd ops run on MI355X only: got a CPU tensor (no CPU fallback exists)")
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+def _rows(t, name):
+    """(ptr-able 2-D view, row stride in elements); last dim must be contiguous."""
+    if t.dim() != 2 or t.dtype != torch.float32 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D float32 tensor with unit inner stride, got {tuple(t.shape)} {t.stride()}")
+    return t.stride(0)
+
+
+class Workspace:
+    """Grow-only device scratch buffer handed to the C ABI (the library never allocates)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        nbytes = max(int(nbytes), 256)
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+# ----------------------------------------------------------------------------- K1-K3
+def gae_scan(rewards, values, dones, succs, last_values, returns, advantages, gamma, lam, succ_value):
+    _req(rewards, values, dones, succs, last_values, returns, advantages)
+    T, N = rewards.shape[0], rewards.shape[1]
+    for t, n in ((rewards, "rewards"), (values, "values"), (returns, "returns"), (advantages, "advantages"),
+                 (last_values, "last_values")):
+        _f32c(t, n)
+    d8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones
+    s8 = succs.view(torch.uint8) if succs.dtype == torch.bool else succs
+    use = succ_value is not None
+    check(lib.pm_gae_scan_f32(_ptr(rewards), _ptr(values), _ptr(d8), _ptr(s8), _ptr(last_values), _ptr(returns),
+                              _ptr(advantages), T, N, float(gamma), float(gamma * lam), int(use),
+                              float(succ_value) if use else 0.0, _stream()), "pm_gae_scan_f32")
+
+
+def moments(x, out2, ws):
+    _req(x, out2)
+    _f32c(x, "x")
+    n = x.numel()
+    w = ws.get(lib.pm_moments_workspace_bytes(n))
+    check(lib.pm_moments_f64(_ptr(x), n, _ptr(out2), _ptr(w), w.numel(), _stream()), "pm_moments_f64")
+
+
+def normalize_apply(x, mom2, count, eps=1e-8):
+    _req(x, mom2)
+    _f32c(x, "x")
+    check(lib.pm_normalize_apply_f32(_ptr(x), x.numel(), _ptr(mom2), float(count), float(eps), _stream()),
+          "pm_normalize_apply_f32")
+
+
+def gather_rows(src2d, idx, dst2d):
+    _req(src2d, idx, dst2d)
+    ls, ld = _rows(src2d, "src"), _rows(dst2d, "dst")
+    if idx.dtype != torch.int64:
+        raise ValueError("idx must be int64")
+    check(lib.pm_gather_rows_f32(_ptr(src2d), _ptr(idx), _ptr(dst2d), idx.numel(), src2d.shape[1], ls, ld, _stream()),
+          "pm_gather_rows_f32")
+
+
+# ----------------------------------------------------------------------------- K4/K5
+def linear_fwd(x, w, b, y, act):
+    _req(x, w, b, y)
+    M, K = x.shape
+    N = w.shape[0]
+    check(lib.pm_linear_fwd_f32(_ptr(x), _rows(x, "x"), _ptr(w), _rows(w, "w"), _ptr(b), _ptr(y), _rows(y, "y"),
+                                M, N, K, act, _stream()), "pm_linear_fwd_f32")
+
+
+def linear_bwd_data(dy, w, h, dx, act):
+    _req(dy, w, h, dx)
+    M, N = dy.shape
+    K = w.shape[1]
+    check(lib.pm_linear_bwd_data_f32(_ptr(dy), _rows(dy, "dy"), _ptr(w), _rows(w, "w"), _ptr(h),
+                                     _rows(h, "h") if h is not None else 0, _ptr(dx), _rows(dx, "dx"), M, N, K, act,
+                                     _stream()), "pm_linear_bwd_data_f32")
+
+
+def linear_bwd_weight(dy, x, dw, db, ws):
+    _req(dy, x, dw, db)
+    M, N = dy.shape
+    K = x.shape[1]
+    w = ws.get(lib.pm_linear_bwd_weight_workspace_bytes(M, N, K))
+    check(lib.pm_linear_bwd_weight_f32(_ptr(dy), _rows(dy, "dy"), _ptr(x), _rows(x, "x"), _ptr(dw), _rows(dw, "dw"),
+                                       _ptr(db), M, N, K, _ptr(w), w.numel(), _stream()), "pm_linear_bwd_weight_f32")
+
+
+# ----------------------------------------------------------------------------- K6/K7
+def pointnet_packed_elems():
+    return int(lib.pm_pointnet_packed_elems())
+
+
+def pointnet_pack(w2, w3, packed):
+    _req(w2, w3, packed)
+    check(lib.pm_pointnet_pack_weights_f32(_ptr(w2), _ptr(w3), _ptr(packed), _stream()), "pm_pointnet_pack_weights_f32")
+
+
+def pointnet_enc_fwd(x, P, Cc, sub_mean, w1, b1, b2, b3, packed, max_mean, feat, argmax):
+    _req(x, w1, b1, b2, b3, packed, feat, argmax)
+    B = x.shape[0]
+    check(lib.pm_pointnet_enc_fwd_f32(_ptr(x), _rows(x, "x"), B, P, Cc, int(sub_mean), _ptr(w1), _ptr(b1), _ptr(b2),
+                                      _ptr(b3), _ptr(packed), int(max_mean), _ptr(feat), _rows(feat, "feat"),
+                                      _ptr(argmax), _stream()), "pm_pointnet_enc_fwd_f32")
+
+
+def pointnet_enc_bwd(x, P, Cc, sub_mean, w1, b1, b2, w3, packed, max_mean, dfeat, argmax, dw1, db1, dw2, db2, dw3, db3,
+                     ws):
+    _req(x, w1, b1, b2, w3, packed, dfeat, argmax, dw1, db1, dw2, db2, dw3, db3)
+    B = x.shape[0]
+    w = ws.get(lib.pm_pointnet_enc_bwd_workspace_bytes(B, P, Cc) + 256)
+    base = w.data_ptr()
+    al = (-base) % 256
+    check(lib.pm_pointnet_enc_bwd_f32(_ptr(x), _rows(x, "x"), B, P, Cc, int(sub_mean), _ptr(w1), _ptr(b1), _ptr(b2),
+                                      _ptr(w3), _ptr(packed), int(max_mean), _ptr(dfeat), _rows(dfeat, "dfeat"),
+                                      _ptr(argmax), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(dw3), _ptr(db3),
+                                      base + al, w.numel() - al, _stream()), "pm_pointnet_enc_bwd_f32")
+
+
+# ----------------------------------------------------------------------------- K8-K11
+def ppo_actor_loss(mu, log_std, actions, old_logp, adv, old_mu, old_sigma, max_action, act_tanh, eps_clip, desired_kl,
+                   adv_moments, adv_count, scal, dmu, dlog_std):
+    _req(mu, log_std, actions, old_logp, adv, old_mu, old_sigma, scal, dmu, dlog_std)
+    B, A = mu.shape
+    check(lib.pm_ppo_actor_loss_fwd_bwd_f32(_ptr(mu), _rows(mu, "mu"), _ptr(log_std), _ptr(actions),
+                                            _rows(actions, "actions"), _ptr(old_logp), _ptr(adv), _ptr(old_mu),
+                                            _rows(old_mu, "old_mu"), _ptr(old_sigma), _rows(old_sigma, "old_sigma"),
+                                            B, A, float(max_action), int(act_tanh), float(eps_clip), float(desired_kl),
+                                            _ptr(adv_moments), float(adv_count), _ptr(scal), _ptr(dmu),
+                                            _rows(dmu, "dmu"), _ptr(dlog_std), _stream()),
+          "pm_ppo_actor_loss_fwd_bwd_f32")
+
+
+def gaussian_logp(mu, log_std, actions, max_action, act_tanh, logp, entropy):
+    _req(mu, log_std, actions, logp, entropy)
+    B, A = mu.shape
+    check(lib.pm_gaussian_logp_f32(_ptr(mu), _rows(mu, "mu"), _ptr(log_std), _ptr(actions), _rows(actions, "actions"),
+                                   B, A, float(max_action), int(act_tanh), _ptr(logp), _ptr(entropy), _stream()),
+          "pm_gaussian_logp_f32")
+
+
+def value_loss(v, returns, old_values, clipped, eps_clip, clip_mean_extern, grad_scale, scal, dv):
+    _req(v, returns, old_values, clip_mean_extern, scal, dv)
+    check(lib.pm_value_loss_fwd_bwd_f32(_ptr(v), _ptr(returns), _ptr(old_values), v.numel(), int(clipped),
+                                        float(eps_clip), _ptr(clip_mean_extern), float(grad_scale), _ptr(scal), _ptr(dv),
+                                        _stream()), "pm_value_loss_fwd_bwd_f32")
+
+
+def mse_tanh_loss(stu_mu, tea_mu, max_action, act_tanh, grad_scale, scal, dstu):
+    _req(stu_mu, tea_mu, scal, dstu)
+    B, A = stu_mu.shape
+    check(lib.pm_mse_tanh_loss_fwd_bwd_f32(_ptr(stu_mu), _rows(stu_mu, "stu_mu"), _ptr(tea_mu), _rows(tea_mu, "tea_mu"),
+                                           B, A, float(max_action), int(act_tanh), float(grad_scale), _ptr(scal),
+                                           _ptr(dstu), _rows(dstu, "dstu"), _stream()), "pm_mse_tanh_loss_fwd_bwd_f32")
+
+
+def action_activation(mu, out, max_action, act_tanh):
+    _req(mu, out)
+    _f32c(mu, "mu")
+    _f32c(out, "out")
+    check(lib.pm_action_activation_f32(_ptr(mu), _ptr(out), mu.numel(), float(max_action), int(act_tanh), _stream()),
+          "pm_action_activation_f32")
+
+
+def clip_adam_step(p, g, m, v, n_clip, max_norm, lr, b1, b2, eps, state, skip_flag, gnorm_out, ws):
+    _req(p, g, m, v, state, skip_flag, gnorm_out)
+    n = p.numel()
+    w = ws.get(lib.pm_clip_adam_workspace_bytes(n))
+    check(lib.pm_clip_adam_step_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, int(n_clip), float(max_norm), float(lr),
+                                    float(b1), float(b2), float(eps), _ptr(state), _ptr(skip_flag), _ptr(gnorm_out),
+                                    _ptr(w), w.numel(), _stream()), "pm_clip_adam_step_f32")
+
+
+def ppo_accumulate_stats(acc, scal, which):
+    _req(acc, scal)
+    check(lib.pm_ppo_accumulate_stats_f32(_ptr(acc), _ptr(scal), int(which), _stream()), "pm_ppo_accumulate_stats_f32")
+
+
+# ----------------------------------------------------------------------------- K12-K14
+def fps(xyz, K, ws):
+    """xyz (B,P,D) -> idx (B,K) int32 (pytorch3d sample_farthest_points defaults)."""
+    _req(xyz)
+    _f32c(xyz, "xyz")
+    B, P, Dd = xyz.shape
+    idx = torch.empty(B, K, dtype=torch.int32, device=xyz.device)
+    nb = lib.pm_fps_workspace_bytes(B, P)
+    w = ws.get(nb) if nb else None
+    check(lib.pm_fps_f32(_ptr(xyz), B, P, Dd, K, _ptr(idx), _ptr(w), w.numel() if w is not None else 0, _stream()),
+          "pm_fps_f32")
+    return idx
+
+
+def ball_query(xyz, centers, radius, nsample):
+    _req(xyz, centers)
+    _f32c(xyz, "xyz")
+    _f32c(centers, "centers")
+    B, P, _ = xyz.shape
+    S = centers.shape[1]
+    idx = torch.empty(B, S, nsample, dtype=torch.int32, device=xyz.device)
+    check(lib.pm_ball_query_f32(_ptr(xyz), _ptr(centers), B, P, S, float(radius), nsample, _ptr(idx), _stream()),
+          "pm_ball_query_f32")
+    return idx
+
+
+def group_points(feat, idx):
+    _req(feat, idx)
+    _f32c(feat, "feat")
+    B, P, Cc = feat.shape
+    S, ns = idx.shape[1], idx.shape[2]
+    out = torch.empty(B, S, ns, Cc, dtype=torch.float32, device=feat.device)
+    check(lib.pm_group_points_f32(_ptr(feat), _ptr(idx), B, P, Cc, S, ns, _ptr(out), _stream()), "pm_group_points_f32")
+    return out
+
+
+def group_points_bwd(dout, idx, P):
+    _req(dout, idx)
+    _f32c(dout, "dout")
+    B, S, ns, Cc = dout.shape
+    dfeat = torch.zeros(B, P, Cc, dtype=torch.float32, device=dout.device)
+    check(lib.pm_group_points_bwd_f32(_ptr(dout), _ptr(idx), B, P, Cc, S, ns, _ptr(dfeat), _stream()),
+          "pm_group_points_bwd_f32")
+    return dfeat

@@ -1,0 +1,65 @@
+"""The C-ABI library loads (no GPU needed) and exports exactly what include/partmanip_hip.h
+declares; the ctypes table in partmanip_amd/_lib.py matches the header's parameter counts."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "partmanip_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int|size_t)\s+(pm_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(3).strip()
+        n = 0 if args in ("", "void") else len(args.split(","))
+        out[m.group(2)] = (m.group(1), n)
+    return out
+
+
+def test_header_declares_the_survey_minimum_symbol_set():
+    fns = header_functions()
+    for need in ("pm_gae_scan_f32", "pm_gather_rows_f32", "pm_linear_fwd_f32", "pm_linear_bwd_data_f32",
+                 "pm_linear_bwd_weight_f32", "pm_pointnet_enc_fwd_f32", "pm_pointnet_enc_bwd_f32",
+                 "pm_ppo_actor_loss_fwd_bwd_f32", "pm_value_loss_fwd_bwd_f32", "pm_mse_tanh_loss_fwd_bwd_f32",
+                 "pm_clip_adam_step_f32", "pm_fps_f32", "pm_ball_query_f32", "pm_group_points_f32",
+                 "pm_group_points_bwd_f32", "pm_version"):
+        assert need in fns, need
+
+
+def test_library_exports_every_declared_symbol_and_ctypes_table_matches():
+    from partmanip_amd import _lib
+    fns = header_functions()
+    assert len(fns) >= 25
+    so = ctypes.CDLL(_lib.LIB_PATH)
+    for name, (ret, nargs) in fns.items():
+        assert hasattr(so, name), f"{name} declared in the header but missing from the .so"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes binding"
+        res, args = _lib.SIGNATURES[name]
+        assert len(args) == nargs, f"{name}: header has {nargs} parameters, ctypes table {len(args)}"
+        assert (res is ctypes.c_size_t) == (ret == "size_t"), name
+    assert set(_lib.SIGNATURES) == set(fns)
+    assert so.pm_version() == 100
+
+
+def test_argument_validation_without_gpu():
+    """Null pointers / bad sizes are rejected before any launch (safe on a GPU-less host)."""
+    from partmanip_amd._lib import lib
+    assert lib.pm_gae_scan_f32(None, None, None, None, None, None, None, 4, 4, 0.99, 0.94, 0, 0.0, None) == -1
+    assert lib.pm_linear_fwd_f32(None, 0, None, 0, None, None, 0, 1, 1, 1, 0, None) == -1
+    assert lib.pm_pointnet_enc_fwd_f32(None, 0, 1, 1000, 3, 0, None, None, None, None, None, 1, None, 0, None, None) == -1
+    assert lib.pm_pointnet_packed_elems() == 196608
+    assert lib.pm_moments_workspace_bytes(10) >= 16
+    assert lib.pm_fps_workspace_bytes(2, 1024) == 0 and lib.pm_fps_workspace_bytes(2, 20000) == 160000
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from partmanip_amd import ops
+    x = torch.zeros(4, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear_fwd(x, x, x[0], x, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gae_scan(x, x, x, x, x, x, x, 0.9, 0.9, None)

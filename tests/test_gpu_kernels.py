@@ -1,0 +1,262 @@
+"""Parity of each HIP kernel (called through the C ABI via partmanip_amd.ops) against the CPU
+oracle on identical seeded inputs.  GPU box only (`-m gpu`).
+
+Tolerances (fp32 path; the oracle runs torch CPU fp32, kernels use exact-fp32 MFMA with a
+different summation order):
+  GAE returns/advantages ............ bit-exact
+  whole-batch normalised advantages . rtol 2e-6 (mean/std reduced in fp64 on both sides)
+  Linear / encoder outputs .......... atol 2e-5 + rtol 2e-5 of the output scale
+  gradients ......................... 1e-4 relative to the gradient tensor's max-abs
+  integer outputs (argmax on well-separated inputs, FPS, ball query) bit-exact
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from tests.golden import cases
+from tests.helpers import load_fixture, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def ops():
+    from partmanip_amd import ops as _ops
+    return _ops
+
+
+def rel_err(got, ref):
+    ref = ref.double()
+    return float((got.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+# ------------------------------------------------------------------------------- GAE
+@pytest.mark.parametrize("name", list(cases.GAE_CASES))
+def test_gae_golden_bit_exact(name):
+    c, fx = cases.GAE_CASES[name], load_fixture(name)
+    inp = cases.gae_inputs(c)
+    from partmanip_amd.algo_utils import RolloutStorage
+    st = RolloutStorage(c["N"], c["T"], 3, 2, DEV, c["succ_value"], c["whole_adv_norm"])
+    st.rewards.copy_(t(inp["rewards"]))
+    st.values.copy_(t(inp["values"]))
+    st.dones.copy_(t(inp["dones"]))
+    st.succs.copy_(t(inp["succs"]))
+    st.compute_returns(t(inp["last_values"]).to(DEV), 0.99, 0.95)
+    assert np.array_equal(st.returns.cpu().numpy(), fx["returns"])
+    if c["whole_adv_norm"]:
+        np.testing.assert_allclose(st.advantages.cpu().numpy(), fx["advantages"], rtol=2e-6, atol=1e-6)
+    else:
+        assert np.array_equal(st.advantages.cpu().numpy(), fx["advantages"])
+
+
+@pytest.mark.parametrize("T,N,succ", [(128, 4096, None), (8, 4096, 500.0), (64, 256, 0), (3, 1, None), (5, 67, 2.5)])
+def test_gae_full_size_vs_oracle(T, N, succ):
+    g = torch.Generator().manual_seed(T * 1000 + N)
+    rewards, values = torch.randn(T, N, 1, generator=g), torch.randn(T, N, 1, generator=g)
+    dones = torch.rand(T, N, 1, generator=g) < 0.02
+    succs = dones & (torch.rand(T, N, 1, generator=g) < 0.5)
+    last = torch.randn(N, 1, generator=g)
+    ret_ref, adv_ref = R.gae_returns(rewards, values, dones, succs, last, 0.99, 0.95, succ, False)
+    ret, adv = torch.empty(T, N, 1, device=DEV), torch.empty(T, N, 1, device=DEV)
+    ops().gae_scan(rewards.to(DEV), values.to(DEV), dones.to(DEV), succs.to(DEV), last.to(DEV), ret, adv, 0.99, 0.95, succ)
+    assert torch.equal(ret.cpu(), ret_ref)
+    assert torch.equal(adv.cpu(), adv_ref)
+
+
+def test_moments_normalize_and_gather():
+    o = ops()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(524288, generator=g) * 3 + 1.5
+    xd = x.to(DEV)
+    mom = torch.zeros(2, dtype=torch.float64, device=DEV)
+    ws = o.Workspace(torch.device(DEV))
+    o.moments(xd, mom, ws)
+    np.testing.assert_allclose(mom.cpu().numpy(), [x.double().sum(), (x.double() ** 2).sum()], rtol=1e-12)
+    o.normalize_apply(xd, mom, x.numel())
+    ref = (x - x.mean()) / (x.std() + 1e-8)
+    np.testing.assert_allclose(xd.cpu().numpy(), ref.numpy(), rtol=2e-6, atol=2e-6)
+    for cols in (53, 64, 3072):
+        src = torch.randn(1000, cols, generator=g)
+        idx = torch.randperm(1000, generator=g)[:257]
+        dst = torch.empty(257, cols, device=DEV)
+        o.gather_rows(src.to(DEV), idx.to(DEV), dst)
+        assert torch.equal(dst.cpu(), src[idx])
+
+
+# ------------------------------------------------------------------------------- Linear
+@pytest.mark.parametrize("M,N,K,act", [(2048, 512, 53, 1), (2048, 512, 512, 1), (2048, 10, 512, 0), (2048, 1, 512, 0),
+                                       (63, 33, 19, 1), (15, 64, 64, 1), (2048, 128, 1031, 1), (300, 32, 128, 0)])
+def test_linear_fwd_bwd(M, N, K, act):
+    o = ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    h_in = torch.tanh(torch.randn(M, K, generator=g))         # stands for "x is a tanh output" in bwd_data
+    xd, wd, bd, dyd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
+    y = torch.empty(M, N, device=DEV)
+    o.linear_fwd(xd, wd, bd, y, act)
+    z = x.double() @ w.double().T + b.double()
+    ref = torch.tanh(z) if act else z
+    assert rel_err(y, ref) < 2e-6
+    dx = torch.empty(M, K, device=DEV)
+    o.linear_bwd_data(dyd, wd, h_in.to(DEV) if act else None, dx, act)
+    dref = dy.double() @ w.double()
+    if act:
+        dref = dref * (1 - h_in.double() ** 2)
+    assert rel_err(dx, dref) < 2e-6
+    dw, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+    o.linear_bwd_weight(dyd, xd, dw, db, o.Workspace(torch.device(DEV)))
+    assert rel_err(dw, dy.double().T @ x.double()) < 2e-6
+    assert rel_err(db, dy.double().sum(0)) < 2e-6
+
+
+def test_linear_strided_views():
+    """Operands that are column slices of wider buffers (row stride > width), as the PointNet head uses."""
+    o = ops()
+    g = torch.Generator().manual_seed(9)
+    big = torch.randn(100, 1031, generator=g)
+    w, b = torch.randn(128, 1031, generator=g) / 32, torch.randn(128, generator=g)
+    x = big.to(DEV)
+    y = torch.empty(100, 200, device=DEV)
+    o.linear_fwd(x, w.to(DEV), b.to(DEV), y[:, 8:136], 1)
+    ref = torch.tanh(big.double() @ w.double().T + b.double())
+    assert rel_err(y[:, 8:136], ref) < 2e-6
+
+
+# ------------------------------------------------------------------------------- losses
+@pytest.mark.parametrize("B,A,mini_norm", [(2048, 10, False), (2048, 10, True), (37, 7, True), (1500, 3, False)])
+def test_ppo_actor_loss(B, A, mini_norm):
+    o = ops()
+    g = torch.Generator().manual_seed(B + A)
+    mu = (torch.randn(B, A, generator=g) * 0.3).requires_grad_(True)
+    log_std = (torch.full((A,), math.log(0.5)) + 0.1 * torch.randn(A, generator=g)).requires_grad_(True)
+    actions = torch.rand(B, A, generator=g) * 1.998 - 0.999
+    actions.view(-1)[::13] = 1.0
+    adv = torch.randn(B, 1, generator=g)
+    old_mu = mu.detach() + 0.05 * torch.randn(B, A, generator=g)
+    old_sigma = log_std.detach().repeat(B, 1) + 0.02 * torch.randn(B, A, generator=g)
+    x = R.action_deactivation(actions, "tanh", 1.0)
+    logp, ent = R.gaussian_logp_entropy(mu, log_std, x)
+    old_logp = (logp.detach() + 0.3 * torch.randn(B, generator=g)).view(B, 1)     # wide ratios: clip branches hit
+    kl_ref, loss_ref = R.actor_loss_terms(logp, mu, log_std.repeat(B, 1), old_logp, adv, old_mu, old_sigma, 0.2, mini_norm)
+    gmu, gls = torch.autograd.grad(loss_ref, [mu, log_std])
+
+    d = lambda v: v.detach().to(DEV).contiguous()
+    scal, dmu, dls = torch.zeros(8, device=DEV), torch.empty(B, A, device=DEV), torch.empty(A, device=DEV)
+    mom, cnt = None, 0
+    if mini_norm:
+        mom = torch.zeros(2, dtype=torch.float64, device=DEV)
+        o.moments(d(adv).view(-1), mom, o.Workspace(torch.device(DEV)))
+        cnt = B
+    o.ppo_actor_loss(d(mu), d(log_std), d(actions), d(old_logp), d(adv), d(old_mu), d(old_sigma), 1.0, True, 0.2, 0.1,
+                     mom, cnt, scal, dmu, dls)
+    s = scal.cpu()
+    np.testing.assert_allclose(float(s[0]), float(loss_ref), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(float(s[1]), float(kl_ref), rtol=2e-5, atol=1e-7)
+    assert float(s[2]) == float(float(kl_ref) > 0.1)
+    np.testing.assert_allclose(float(s[3]), float(ent[0]), rtol=1e-6)
+    assert rel_err(dmu, gmu) < 5e-5
+    assert rel_err(dls, gls) < 5e-5
+    lp, en = torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+    o.gaussian_logp(d(mu), d(log_std), d(actions), 1.0, True, lp, en)
+    np.testing.assert_allclose(lp.cpu().numpy(), logp.detach().numpy(), rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("B,clipped", [(2048, False), (2048, True), (15, True)])
+def test_value_loss(B, clipped):
+    o = ops()
+    g = torch.Generator().manual_seed(B)
+    v = torch.randn(B, 1, generator=g).requires_grad_(True)
+    ret, old = torch.randn(B, 1, generator=g) * 2, torch.randn(B, 1, generator=g)
+    loss = R.value_loss_fn(v, ret, old, 0.2, clipped)
+    gv, = torch.autograd.grad(loss, [v])
+    scal, dv = torch.zeros(8, device=DEV), torch.empty(B, 1, device=DEV)
+    o.value_loss(v.detach().to(DEV), ret.to(DEV), old.to(DEV), clipped, 0.2, None, 1.0, scal, dv)
+    np.testing.assert_allclose(float(scal[0]), float(loss), rtol=1e-5)
+    assert rel_err(dv, gv) < 1e-5
+
+
+@pytest.mark.parametrize("B,A", [(2048, 10), (33, 7)])
+def test_mse_tanh_loss(B, A):
+    o = ops()
+    g = torch.Generator().manual_seed(B)
+    sm = torch.randn(B, A, generator=g).requires_grad_(True)
+    tm = torch.randn(B, A, generator=g)
+    loss = (torch.tanh(tm) * 1.0 - torch.tanh(sm) * 1.0).pow(2).mean()
+    gs, = torch.autograd.grad(loss, [sm])
+    scal, ds = torch.zeros(8, device=DEV), torch.empty(B, A, device=DEV)
+    o.mse_tanh_loss(sm.detach().to(DEV), tm.to(DEV), 1.0, True, 1.0, scal, ds)
+    np.testing.assert_allclose(float(scal[0]), float(loss), rtol=1e-5)
+    assert rel_err(ds, gs) < 1e-5
+    out = torch.empty(B, A, device=DEV)
+    o.action_activation(tm.to(DEV), out, 1.0, True)
+    np.testing.assert_allclose(out.cpu().numpy(), torch.tanh(tm).numpy(), rtol=2e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------- clip + Adam
+@pytest.mark.parametrize("n,n_clip,max_norm", [(558100, 558090, 0.5), (1000, 1000, 0.5), (300789, 300779, 0.0), (77, 70, 1e-3)])
+def test_clip_adam_steps(n, n_clip, max_norm):
+    o = ops()
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g)
+    pd = p0.clone().to(DEV)
+    gd = torch.empty(n, device=DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    state = torch.zeros(4, dtype=torch.int32, device=DEV)
+    skip = torch.zeros(1, device=DEV)
+    gn = torch.zeros(1, device=DEV)
+    ws = o.Workspace(torch.device(DEV))
+    pr = p0.clone()
+    adam = R.Adam([pr], 3e-3)
+    for step in range(6):
+        grad = torch.randn(n, generator=g) * (0.02 if step % 2 else 2.0)
+        gd.copy_(grad)
+        is_skip = step == 3
+        skip.fill_(1.0 if is_skip else 0.0)
+        o.clip_adam_step(pd, gd, m, v, n_clip, max_norm, 3e-3, 0.9, 0.999, 1e-8, state, skip, gn, ws)
+        if not is_skip:
+            gr = grad.clone()
+            if max_norm > 0:
+                total = R.clip_grad_norm([gr[:n_clip]], max_norm)
+                np.testing.assert_allclose(float(gn), float(total), rtol=1e-5)
+            adam.step([gr])
+    assert int(state[0]) == 5
+    np.testing.assert_allclose(pd.cpu().numpy(), pr.numpy(), rtol=0, atol=3e-6)
+    assert rel_err(m, adam.m[0]) < 1e-5 and rel_err(v, adam.v[0]) < 1e-5
+
+
+# ------------------------------------------------------------------------------- point-set ops
+@pytest.mark.parametrize("B,P,D,K", [(3, 1024, 3, 128), (2, 777, 3, 64), (2, 5000, 3, 256), (1, 20000, 3, 64), (2, 50, 4, 80)])
+def test_fps_bit_exact(B, P, D, K):
+    o = ops()
+    g = torch.Generator().manual_seed(P)
+    xyz = torch.rand(B, P, D, generator=g) * 2 - 1
+    xyz[:, P // 3] = xyz[:, P // 5]                       # duplicated points -> exact ties
+    idx = o.fps(xyz.to(DEV), K, o.Workspace(torch.device(DEV))).cpu().numpy()
+    ref = R.fps(xyz.numpy(), K)
+    assert np.array_equal(idx, ref.astype(np.int32))
+
+
+@pytest.mark.parametrize("B,P,S,r,ns", [(2, 1024, 128, 0.3, 32), (1, 333, 50, 0.05, 16), (2, 1024, 64, 5.0, 64)])
+def test_ball_query_and_group_bit_exact(B, P, S, r, ns):
+    o = ops()
+    g = torch.Generator().manual_seed(P + S)
+    xyz = torch.rand(B, P, 3, generator=g) * 2 - 1
+    ctr = xyz[:, torch.randperm(P, generator=g)[:S]].contiguous()
+    if r < 0.1:
+        ctr[:, 0] += 10.0                                   # an empty ball
+    idx = o.ball_query(xyz.to(DEV), ctr.to(DEV), r, ns)
+    ref = R.ball_query(xyz.numpy(), ctr.numpy(), r, ns)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    feat = torch.randn(B, P, 7, generator=g)
+    out = o.group_points(feat.to(DEV), idx)
+    assert np.array_equal(out.cpu().numpy(), R.group_points(feat.numpy(), ref))
+    dout = torch.randn(B, S, ns, 7, generator=g)
+    dfeat = o.group_points_bwd(dout.to(DEV), idx, P)
+    dref = torch.zeros(B, P, 7, dtype=torch.float64)
+    for b in range(B):
+        dref[b].index_add_(0, torch.from_numpy(ref[b].reshape(-1).astype(np.int64)), dout[b].reshape(-1, 7).double())
+    assert rel_err(dfeat, dref) < 1e-5
