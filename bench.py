@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- PPO learner throughput on MI355X (BASELINE.json metric: PPO env-steps/sec,
+4096 envs x 1024-pt clouds).
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload vision|state]
+
+A "step" is one learner iteration = the reference's `learn_time` window (ppo.py:256-262:
+compute_returns + update + storage.clear) over one synthetic rollout batch that is already
+resident in HBM.  env-steps/s = N_env * T * world / (time per step).  One process per GPU;
+for N > 1 launch under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from the env):
+each rank owns its own 4096 envs (weak scaling) and gradients are all-reduced over RCCL once
+per optimiser step.
+
+Rank 0 prints ONE JSON line including
+  roofline     : live HIP-event timing of the dominant kernel (fused PointNet encoder forward)
+                 against the fp32-MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
+  cpu_baseline : the CPU oracle (oracle/ref_cpu.py, pinned to the reference) timed on this
+                 box's host cores on a bounded sample of the same workload (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3
+ENC_MAC_PER_POINT = 3 * 128 + 128 * 256 + 256 * 512          # 164 224
+
+WORKLOADS = {
+    # cfg3: open_drawer vision PPO, ppo.yaml hyper-parameters, PointNet(tanh, max_mean, no sub_mean)
+    "vision": dict(name="ppo_vision_pointnet_4096env_x_8step_x_1024pt", N=4096, T=8, O=3072, A=10,
+                   net=dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False)),
+    # cfg2: open_drawer state PPO, MLP 53-512-512-512
+    "state": dict(name="ppo_state_mlp_4096env_x_128step", N=4096, T=128, O=53, A=10,
+                  net=dict(name="MLP", hid_dim=[512, 512, 512], activation="tanh")),
+}
+
+
+def make_cfg(w, device):
+    return dict(num_envs=w["N"], obs_mode="obs", succ_value=None,
+                model=dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=dict(w["net"])),
+                max_iterations=200000, n_steps=w["T"], n_updates=5, n_minibatches=8, device=device, eval_round=1,
+                eval_frequence=10 ** 9, save_frequence=10 ** 9, test_only=False, save_pose=False, save_video=False,
+                lr_schedule="fixed", lr=5e-5, desired_kl=0.1, epsilon_clip=0.2, gamma=0.99, lam=0.95,
+                tricks=dict(mini_adv_norm=False, whole_adv_norm=False, use_state_norm=False,
+                            use_clipped_value_loss=False, use_grad_clip=True, max_grad_norm=0.5),
+                sampler="sequential", resume=None)
+
+
+def cpu_baseline(w, rollout_cpu, sd_cpu, cfg):
+    """Time the oracle's actor + critic mini-batch passes on a bounded sample and extrapolate to a
+    full iteration: per-sample cost x (n_updates * T*N samples) for each of the two loops."""
+    from oracle import ref_cpu as R
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    vision = w["net"]["name"] == "PointNet"
+    mb = 128 if vision else 2048                     # CPU PointNet pass: ~6 s per 128 samples
+    n_mb = 1 if vision else 4
+    T, N = w["T"], w["N"]
+    keys = ("observations", "actions", "values", "returns", "actions_log_prob", "advantages", "mu", "sigma")
+    sub = {k: rollout_cpu[k].reshape(-1, rollout_cpu[k].shape[-1])[: mb * n_mb].reshape(n_mb, mb, -1).clone() for k in keys}
+    p = {k: v.clone() for k, v in sd_cpu.items()}
+    c = dict(cfg)
+    c.update(n_updates=1, n_minibatches=n_mb, sampler="sequential", device="cpu")
+    t0 = time.perf_counter()
+    R.gae_returns(rollout_cpu["rewards_full"], rollout_cpu["values_full"], rollout_cpu["dones_full"],
+                  rollout_cpu["succs_full"], rollout_cpu["last_values"], 0.99, 0.95, None, False)
+    t_gae = time.perf_counter() - t0
+    st = {k: sub[k] for k in keys}
+    t0 = time.perf_counter()
+    R.ppo_update(p, st, c, 1)                         # n_mb actor steps + n_mb critic steps
+    t_upd = time.perf_counter() - t0
+    per_sample = t_upd / (mb * n_mb)                  # one actor pass + one critic pass of one sample
+    t_iter = t_gae + per_sample * cfg["n_updates"] * T * N
+    return dict(value=T * N / t_iter, unit="env-steps/s", cores=ncores, kind="port",
+                sample=f"oracle/ref_cpu.py ppo_update on {n_mb} actor + {n_mb} critic mini-batches of {mb} samples "
+                       f"({t_upd:.1f} s) + full GAE ({t_gae * 1e3:.1f} ms), extrapolated to "
+                       f"{cfg['n_updates']} epochs x {T * N} samples; {ncores} torch threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="vision", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from partmanip_amd import dist as pdist, ops
+    rank, world, local = pdist.init_from_env("nccl")
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    w = WORKLOADS[args.workload]
+    cfg = make_cfg(w, device)
+
+    from partmanip_amd.algorithms import ppo
+    from partmanip_amd.feeder import FeederEnv, ScreenLogger
+    torch.manual_seed(1234)                            # identical initial weights on every rank
+    env = FeederEnv(w["N"], {"obs": w["O"]}, w["A"], device, seed=1234 + rank)
+    run = ppo(env, cfg, ScreenLogger(quiet=True))
+    ac, st = run.actor_critic, run.storage
+
+    # ---- one synthetic rollout, produced by the freshly initialised policy (ratio ~ 1, KL ~ 0) ----
+    obs = env.reset()["obs"]
+    for _ in range(w["T"]):
+        actions, logp, values, mu, sigma = ac.random_act_cri(obs)
+        nxt, rew, done, _ = env.step(actions)
+        st.add_transitions(obs, actions, rew, done, env.reset_succ, values, logp, mu, sigma)
+        obs = nxt["obs"]
+    last_values = ac.cri(obs)
+    f = ac.flat()
+    snap = dict(a=f["actor"].clone(), c=f["critic"].clone())
+
+    def restore():                                     # every timed step starts from the same policy
+        f["actor"].copy_(snap["a"])
+        f["critic"].copy_(snap["c"])
+        for opt in (run.optimizer_actor, run.optimizer_critic):
+            opt.m.zero_()
+            opt.v.zero_()
+            opt.state_dev.zero_()
+
+    def step():
+        restore()
+        st.step = w["T"]
+        run.log_dict = {}
+        run.learn(last_values)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    dominant = "pointnet_enc_fwd" if args.workload == "vision" else None
+    if dominant:
+        ops.TIMER.enable(dominant, "pointnet_enc_bwd")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.TIMER.disable()
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = w["N"] * w["T"] * world / (dt / args.steps)
+
+    out = dict(metric="PPO env-steps/sec (whole node), 4096 envs x 1024-pt clouds", value=value, unit="env-steps/s",
+               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload=w["name"], envs_per_gpu=w["N"], n_steps=w["T"], points=1024 if args.workload == "vision" else 0,
+                           minibatch=2048, n_updates=5, backbone=w["net"]["name"], parallelism=f"dp{world}",
+                           train_scalars={k: float(v) for k, v in run.log_dict.items() if k.startswith("Train/")}))
+    if dominant:
+        mean_ms, n_launch = ops.TIMER.mean_ms(dominant)
+        flops = 2.0 * ENC_MAC_PER_POINT * 1024 * 2048           # one launch = 2048 clouds x 1024 points
+        achieved = flops / (mean_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("pn_fwd_kernel_bytes_per_launch")
+        out["roofline"] = dict(bound="mfma", kernel="pn_fwd_kernel", achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS,
+                               unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=traffic,
+                               launches=n_launch, mean_launch_ms=mean_ms, flops_per_launch=flops)
+        bwd = ops.TIMER.mean_ms("pointnet_enc_bwd")
+        if bwd:
+            out["roofline"]["enc_bwd_mean_ms"] = bwd[0]
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = lambda t: t.detach().cpu()
+        roll = dict(observations=cpu(st.observations), actions=cpu(st.actions), values=cpu(st.values),
+                    returns=cpu(st.returns), actions_log_prob=cpu(st.actions_log_prob), advantages=cpu(st.advantages),
+                    mu=cpu(st.mu), sigma=cpu(st.sigma), rewards_full=cpu(st.rewards), values_full=cpu(st.values),
+                    dones_full=cpu(st.dones), succs_full=cpu(st.succs), last_values=cpu(last_values))
+        sd_cpu = {k: cpu(v).clone() for k, v in ac.state_dict().items()}
+        out["cpu_baseline"] = cpu_baseline(w, roll, sd_cpu, cfg)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

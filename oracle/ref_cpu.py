@@ -121,9 +121,14 @@ def mlp_forward(p, prefix, net_cfg, x):
     return x
 
 
-def pointnet_forward(p, prefix, net_cfg, x, proprio_shape=0, point_num=1024):
+def pointnet_forward(p, prefix, net_cfg, x, proprio_shape=0, point_num=1024, argmax_override=None):
     """network.py:165-198.  `sub_mean` re-centres xyz per cloud (out of place here;
-    the reference does it in place on its input view, network.py:172-173)."""
+    the reference does it in place on its input view, network.py:172-173).
+
+    `argmax_override` (B,512) int64 is a TEST HOOK: the max-pool then gathers those point
+    indices instead of taking torch.max's.  Max-pooling is only piecewise differentiable; two
+    fp32 implementations with different summation orders legitimately pick different points for
+    near-tied channels, so gradient-parity tests pin the pooling index and compare the rest."""
     B = x.shape[0]
     if proprio_shape != 0:
         proprio = x[:, -proprio_shape:]
@@ -136,10 +141,11 @@ def pointnet_forward(p, prefix, net_cfg, x, proprio_shape=0, point_num=1024):
     h = _act(a, _lin(p, f"{prefix}.mlp.0", pc))
     h = _act(a, _lin(p, f"{prefix}.mlp.2", h))
     h = _lin(p, f"{prefix}.mlp.4", h)
+    hmax = h.max(dim=1)[0] if argmax_override is None else torch.gather(h, 1, argmax_override.unsqueeze(1)).squeeze(1)
     if net_cfg["max_mean"]:
-        f = torch.cat((h.max(dim=1)[0], h.mean(dim=1)), dim=-1)
+        f = torch.cat((hmax, h.mean(dim=1)), dim=-1)
     else:
-        f = h.max(dim=1)[0]
+        f = hmax
     if proprio_shape != 0:
         f = torch.cat((f, proprio), dim=-1)
     f = _act(a, _lin(p, f"{prefix}.final_mlp.0", f))
@@ -328,8 +334,9 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None):
     for _ in range(cfg["n_updates"]):
         lists = seq_lists if seq_lists is not None else minibatch_index_lists(n, cfg["n_minibatches"], sampler)
         for idx in lists:
-            value = net_forward(p, "critic", model_cfg["network"], flat["observations"][idx],
-                                cfg.get("proprio_shape", 0))
+            # ppo.py:366: the critic loop also calls update_act_cri, i.e. runs BOTH networks forward
+            _, _, value, _, _ = update_act_cri(p, model_cfg, flat["observations"][idx], flat["actions"][idx],
+                                               cfg.get("proprio_shape", 0))
             loss = value_loss_fn(value, flat["returns"][idx], flat["values"][idx], cfg["epsilon_clip"],
                                  tricks["use_clipped_value_loss"])
             grads = list(torch.autograd.grad(loss, [p[k] for k in ck]))

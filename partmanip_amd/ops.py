@@ -14,6 +14,58 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+class KernelTimer:
+    """HIP-event bracket around named launches (bench.py's live roofline measurement).
+    Events are recorded on torch's current stream, which is the stream every op launches on."""
+
+    def __init__(self):
+        self.enabled = set()
+        self.events = {}
+
+    def enable(self, *names):
+        self.enabled = set(names)
+        self.events = {n: [] for n in names}
+
+    def disable(self):
+        self.enabled = set()
+
+    def bracket(self, name):
+        return _Bracket(self, name) if name in self.enabled else _NULL
+
+    def mean_ms(self, name):
+        ev = self.events.get(name, [])
+        if not ev:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)
+
+
+class _Bracket:
+    def __init__(self, timer, name):
+        self.t, self.n = timer, name
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.t.events[self.n].append((self.a, self.b))
+
+
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _Null()
+TIMER = KernelTimer()
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -131,9 +183,10 @@ def pointnet_pack(w2, w3, packed):
 def pointnet_enc_fwd(x, P, Cc, sub_mean, w1, b1, b2, b3, packed, max_mean, feat, argmax):
     _req(x, w1, b1, b2, b3, packed, feat, argmax)
     B = x.shape[0]
-    check(lib.pm_pointnet_enc_fwd_f32(_ptr(x), _rows(x, "x"), B, P, Cc, int(sub_mean), _ptr(w1), _ptr(b1), _ptr(b2),
-                                      _ptr(b3), _ptr(packed), int(max_mean), _ptr(feat), _rows(feat, "feat"),
-                                      _ptr(argmax), _stream()), "pm_pointnet_enc_fwd_f32")
+    with TIMER.bracket("pointnet_enc_fwd"):
+        check(lib.pm_pointnet_enc_fwd_f32(_ptr(x), _rows(x, "x"), B, P, Cc, int(sub_mean), _ptr(w1), _ptr(b1), _ptr(b2),
+                                          _ptr(b3), _ptr(packed), int(max_mean), _ptr(feat), _rows(feat, "feat"),
+                                          _ptr(argmax), _stream()), "pm_pointnet_enc_fwd_f32")
 
 
 def pointnet_enc_bwd(x, P, Cc, sub_mean, w1, b1, b2, w3, packed, max_mean, dfeat, argmax, dw1, db1, dw2, db2, dw3, db3,
@@ -143,10 +196,11 @@ def pointnet_enc_bwd(x, P, Cc, sub_mean, w1, b1, b2, w3, packed, max_mean, dfeat
     w = ws.get(lib.pm_pointnet_enc_bwd_workspace_bytes(B, P, Cc) + 256)
     base = w.data_ptr()
     al = (-base) % 256
-    check(lib.pm_pointnet_enc_bwd_f32(_ptr(x), _rows(x, "x"), B, P, Cc, int(sub_mean), _ptr(w1), _ptr(b1), _ptr(b2),
-                                      _ptr(w3), _ptr(packed), int(max_mean), _ptr(dfeat), _rows(dfeat, "dfeat"),
-                                      _ptr(argmax), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(dw3), _ptr(db3),
-                                      base + al, w.numel() - al, _stream()), "pm_pointnet_enc_bwd_f32")
+    with TIMER.bracket("pointnet_enc_bwd"):
+        check(lib.pm_pointnet_enc_bwd_f32(_ptr(x), _rows(x, "x"), B, P, Cc, int(sub_mean), _ptr(w1), _ptr(b1), _ptr(b2),
+                                          _ptr(w3), _ptr(packed), int(max_mean), _ptr(dfeat), _rows(dfeat, "dfeat"),
+                                          _ptr(argmax), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(dw3),
+                                          _ptr(db3), base + al, w.numel() - al, _stream()), "pm_pointnet_enc_bwd_f32")
 
 
 # ----------------------------------------------------------------------------- K8-K11

