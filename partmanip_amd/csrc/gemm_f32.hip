@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             float v = acc[r];
             if (EPI == EPI_BIAS_ACT) {
                 v += bias;
-                if (g.act == PM_ACT_TANH) v = tanhf(v);
+                if (g.act == PM_ACT_TANH) v = pm_tanh(v);
             } else if (EPI == EPI_MUL_DACT) {
                 if (g.act == PM_ACT_TANH) {
                     const float h = g.H[(long)row * g.ldh + col];

@@ -222,9 +222,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void mse_tanh_loss_kernel(const float
         const float sm = stu_mu[i * lds + a], tm = tea_mu[i * ldt + a];
         float sa, ta, ds;
         if (act_tanh) {
-            const float th = tanhf(sm);
+            const float th = pm_tanh(sm);
             sa = th * max_action;
-            ta = tanhf(tm) * max_action;
+            ta = pm_tanh(tm) * max_action;
             ds = max_action * (1.0f - th * th);
         } else {
             sa = sm;
@@ -252,7 +252,7 @@ extern "C" int pm_mse_tanh_loss_fwd_bwd_f32(const float* stu_mu, long lds, const
 __global__ __launch_bounds__(256) void action_activation_kernel(const float* __restrict__ mu, float* __restrict__ out,
                                                                  long n, float max_action, int act_tanh) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-        out[i] = act_tanh ? tanhf(mu[i]) * max_action : mu[i];
+        out[i] = act_tanh ? pm_tanh(mu[i]) * max_action : mu[i];
 }
 
 extern "C" int pm_action_activation_f32(const float* mu, float* out, long n, float max_action, int act_tanh,

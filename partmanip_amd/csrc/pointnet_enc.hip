@@ -82,29 +82,91 @@ __device__ __forceinline__ void cloud_centroid(const float* __restrict__ xb, int
 // stage one tile of 64 points (C floats each) into Xs[64][PN_MAXC], optionally re-centred
 __device__ __forceinline__ void stage_points(const float* __restrict__ xb, int tile, int C, int sub_mean,
                                              const float (&cen)[3], float* __restrict__ Xs) {
-    for (int i = threadIdx.x; i < PN_TM * C; i += 256) {
-        const int p = i / C, d = i - p * C;
-        float v = xb[(tile * PN_TM) * C + i];
-        if (sub_mean && d < 3) v -= cen[d];
-        Xs[p * PN_MAXC + d] = v;
+    for (int i = threadIdx.x; i < PN_TM * PN_MAXC; i += 256) {
+        const int p = i >> 3, d = i & 7;
+        float v = 0.f;                                   // slots d >= C stay zero (layer1_tile reads float4s)
+        if (d < C) {
+            v = xb[(tile * PN_TM + p) * C + d];
+            if (sub_mean && d < 3) v -= cen[d];
+        }
+        Xs[i] = v;
     }
 }
 
-// layer 1: thread (c = tid&127, half = tid>>7) computes tanh(b1[c] + W1[c,:] . x[p,:]) for its 32 points
+// layer 1: thread (c = tid&127, half = tid>>7) computes tanh(b1[c] + W1[c,:] . x[p,:]) for its 32 points.
+// CT = compile-time channel count (3: xyz clouds, 4: depth_sparse); 0 = generic runtime C <= 8.
+template <int CT>
 __device__ __forceinline__ void layer1_tile(const float* __restrict__ Xs, const float* __restrict__ W1,
                                             const float* __restrict__ b1, int C, float* __restrict__ H1) {
     const int c = threadIdx.x & 127, p0 = (threadIdx.x >> 7) * 32;
-    float w1[PN_MAXC];                         // re-read per tile (L1/L2 hit) instead of pinning 9 VGPRs
-#pragma unroll
-    for (int d = 0; d < PN_MAXC; ++d) w1[d] = (d < C) ? W1[c * C + d] : 0.f;
     const float b1c = b1[c];
-#pragma unroll 4
-    for (int p = p0; p < p0 + 32; ++p) {
-        float s = b1c;
+    if (CT == 3 || CT == 4) {                  // one broadcast ds_read_b128 per point, no branches
+        float w[4];
 #pragma unroll
-        for (int d = 0; d < PN_MAXC; ++d)
-            if (d < C) s += w1[d] * Xs[p * PN_MAXC + d];
-        H1[p * PN_LD1 + c] = tanhf(s);
+        for (int d = 0; d < 4; ++d) w[d] = (d < CT) ? W1[c * CT + d] : 0.f;
+#pragma unroll 8
+        for (int p = p0; p < p0 + 32; ++p) {
+            const float4 xv = *(const float4*)(Xs + p * PN_MAXC);
+            float s = fmaf(w[0], xv.x, b1c);
+            s = fmaf(w[1], xv.y, s);
+            s = fmaf(w[2], xv.z, s);
+            if (CT == 4) s = fmaf(w[3], xv.w, s);
+            H1[p * PN_LD1 + c] = pm_tanh(s);
+        }
+    } else {
+        float w1[PN_MAXC];
+#pragma unroll
+        for (int d = 0; d < PN_MAXC; ++d) w1[d] = (d < C) ? W1[c * C + d] : 0.f;
+        for (int p = p0; p < p0 + 32; ++p) {
+            const float4 x0 = *(const float4*)(Xs + p * PN_MAXC), x1 = *(const float4*)(Xs + p * PN_MAXC + 4);
+            float s = b1c;                     // Xs slots d >= C are zero-filled by stage_points
+            s = fmaf(w1[0], x0.x, s); s = fmaf(w1[1], x0.y, s); s = fmaf(w1[2], x0.z, s); s = fmaf(w1[3], x0.w, s);
+            s = fmaf(w1[4], x1.x, s); s = fmaf(w1[5], x1.y, s); s = fmaf(w1[6], x1.z, s); s = fmaf(w1[7], x1.w, s);
+            H1[p * PN_LD1 + c] = pm_tanh(s);
+        }
+    }
+}
+
+// ---- MFMA operand streaming without register copies ------------------------------------------
+// acc[mb][nb] += A(64 x K, LDS) * B(K x NB*32, packed weights in L2).  Two named operand sets
+// (ping / pong): the loads of k-group g+1 are issued before the 8*NB MFMAs of group g and are first
+// waited for a full group (>= 1000 cycles) later.  (A "next -> current" register copy at the loop
+// top makes hipcc wait for the just-issued loads in the same iteration, exposing the whole L2 round
+// trip every 32 MFMAs: measured -27 % on the layer-3 loop.)
+template <int NB>
+struct OperandSet {
+    float4 a0, a1, b[NB];
+};
+template <int NB>
+__device__ __forceinline__ void load_set(OperandSet<NB>& o, const float* __restrict__ A0, const float* __restrict__ A1,
+                                         const float4* __restrict__ Bp, int bstride, int g) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) o.b[nb] = Bp[(size_t)(nb * bstride + g) * 64];
+    o.a0 = *(const float4*)(A0 + g * 4);
+    o.a1 = *(const float4*)(A1 + g * 4);
+}
+template <int NB>
+__device__ __forceinline__ void mfma_set(const OperandSet<NB>& o, f32x16 (&acc)[2][NB]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            acc[0][nb] = MFMA(o.a0[e], o.b[nb][e], acc[0][nb]);
+            acc[1][nb] = MFMA(o.a1[e], o.b[nb][e], acc[1][nb]);
+        }
+}
+// NG = number of 4-step k-groups per lane half (K/8); bstride = NG (packed layout [nb][g][lane][4]).
+template <int NB, int NG>
+__device__ __forceinline__ void mfma_stream(const float* __restrict__ A0, const float* __restrict__ A1,
+                                            const float4* __restrict__ Bp, f32x16 (&acc)[2][NB]) {
+    OperandSet<NB> ping, pong;
+    load_set<NB>(ping, A0, A1, Bp, NG, 0);
+#pragma unroll 1
+    for (int g = 0; g < NG; g += 2) {
+        load_set<NB>(pong, A0, A1, Bp, NG, g + 1);
+        mfma_set<NB>(ping, acc);
+        if (g + 2 < NG) load_set<NB>(ping, A0, A1, Bp, NG, g + 2);
+        mfma_set<NB>(pong, acc);
     }
 }
 
@@ -112,28 +174,8 @@ __device__ __forceinline__ void layer1_tile(const float* __restrict__ Xs, const 
 __device__ __forceinline__ void layer2_mfma(const float* __restrict__ H1, const float4* __restrict__ P2v, int wave,
                                             int lane, f32x16 (&acc)[2][2]) {
     const int li = lane & 31, lh = lane >> 5;
-    const float4* Bp = P2v + (size_t)(wave * 2) * 16 * 64 + lane;
-    const float* A0 = H1 + li * PN_LD1 + lh * 64;
-    const float* A1 = H1 + (32 + li) * PN_LD1 + lh * 64;
-    float4 bn0 = Bp[0], bn1 = Bp[16 * 64];
-    float4 an0 = *(const float4*)A0, an1 = *(const float4*)A1;
-#pragma unroll 2
-    for (int s4 = 0; s4 < 16; ++s4) {
-        const float4 b0 = bn0, b1 = bn1, a0 = an0, a1 = an1;
-        if (s4 + 1 < 16) {
-            bn0 = Bp[(s4 + 1) * 64];
-            bn1 = Bp[(16 + s4 + 1) * 64];
-            an0 = *(const float4*)(A0 + (s4 + 1) * 4);
-            an1 = *(const float4*)(A1 + (s4 + 1) * 4);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[0][0] = MFMA(a0[e], b0[e], acc[0][0]);
-            acc[0][1] = MFMA(a0[e], b1[e], acc[0][1]);
-            acc[1][0] = MFMA(a1[e], b0[e], acc[1][0]);
-            acc[1][1] = MFMA(a1[e], b1[e], acc[1][1]);
-        }
-    }
+    mfma_stream<2, 16>(H1 + li * PN_LD1 + lh * 64, H1 + (32 + li) * PN_LD1 + lh * 64,
+                       P2v + (size_t)(wave * 2) * 16 * 64 + lane, acc);
 }
 
 // layer 2 epilogue: H2[row][ch] = tanh(acc + b2[ch])
@@ -150,11 +192,12 @@ __device__ __forceinline__ void layer2_store(const f32x16 (&acc)[2][2], const fl
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                H2[row * PN_LD2 + wave * 64 + nb * 32 + li] = tanhf(acc[mb][nb][r] + b2v[nb]);
+                H2[row * PN_LD2 + wave * 64 + nb * 32 + li] = pm_tanh(acc[mb][nb][r] + b2v[nb]);
             }
 }
 
 // =================================================================================== forward
+template <int CT>
 __global__ __launch_bounds__(256, 2) void pn_fwd_kernel(const float* __restrict__ x, long ldx, int P, int C,
                                                          int sub_mean, const float* __restrict__ W1,
                                                          const float* __restrict__ b1, const float* __restrict__ b2,
@@ -190,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void pn_fwd_kernel(const float* __restrict_
         __syncthreads();                          // previous tile's layer-3 reads of H are done
         stage_points(xb, tile, C, sub_mean, cen, Xs);
         __syncthreads();
-        layer1_tile(Xs, W1, b1, C, H);
+        layer1_tile<CT>(Xs, W1, b1, C, H);
         __syncthreads();
         {
             f32x16 acc2[2][2];
@@ -214,36 +257,8 @@ __global__ __launch_bounds__(256, 2) void pn_fwd_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][nb][r] = acc[1][nb][r] = b3c;
         }
-        {
-            const float4* Bp = P3v + (size_t)(wave * 4) * 32 * 64 + lane;
-            const float* A0 = H + li * PN_LD2 + lh * 128;
-            const float* A1 = H + (32 + li) * PN_LD2 + lh * 128;
-            float4 bn[4];
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) bn[nb] = Bp[(nb * 32) * 64];
-            float4 an0 = *(const float4*)A0, an1 = *(const float4*)A1;
-#pragma unroll 2
-            for (int s4 = 0; s4 < 32; ++s4) {
-                float4 bc[4];
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) bc[nb] = bn[nb];
-                const float4 a0 = an0, a1 = an1;
-                if (s4 + 1 < 32) {
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) bn[nb] = Bp[(nb * 32 + s4 + 1) * 64];
-                    an0 = *(const float4*)(A0 + (s4 + 1) * 4);
-                    an1 = *(const float4*)(A1 + (s4 + 1) * 4);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) {
-                        acc[0][nb] = MFMA(a0[e], bc[nb][e], acc[0][nb]);
-                        acc[1][nb] = MFMA(a1[e], bc[nb][e], acc[1][nb]);
-                    }
-                }
-            }
-        }
+        mfma_stream<4, 32>(H + li * PN_LD2 + lh * 128, H + (32 + li) * PN_LD2 + lh * 128,
+                           P3v + (size_t)(wave * 4) * 32 * 64 + lane, acc);
         // ---- pooling over this tile's 64 points (rows), in increasing point order ------------
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
@@ -290,8 +305,13 @@ extern "C" int pm_pointnet_enc_fwd_f32(const float* x, long ldx, int B, int P, i
     PM_REQUIRE(ldf >= PN_C3 * (max_mean ? 2 : 1));
     PM_REQUIRE(!sub_mean || C >= 3);
     if (((uintptr_t)packed & 15) != 0) return PM_EALIGN;
-    hipLaunchKernelGGL(pn_fwd_kernel, dim3(B), dim3(256), 0, pm_stream(stream), x, ldx, P, C, sub_mean, W1, b1, b2, b3,
-                       packed, max_mean, feat, ldf, argmax);
+#define PN_FWD_LAUNCH(CT)                                                                                        \
+    hipLaunchKernelGGL(pn_fwd_kernel<CT>, dim3(B), dim3(256), 0, pm_stream(stream), x, ldx, P, C, sub_mean, W1, b1, b2, \
+                       b3, packed, max_mean, feat, ldf, argmax)
+    if (C == 3) PN_FWD_LAUNCH(3);
+    else if (C == 4) PN_FWD_LAUNCH(4);
+    else PN_FWD_LAUNCH(0);
+#undef PN_FWD_LAUNCH
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
@@ -340,6 +360,7 @@ __device__ __forceinline__ void bitonic_sort_512(int* keys) {
     __syncthreads();
 }
 
+template <int CT>
 __global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
     const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
     const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ W3,
@@ -406,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
             __syncthreads();
             stage_points(xb, tile, C, sub_mean, cen, Xs);
             __syncthreads();
-            layer1_tile(Xs, W1, b1, C, H1);
+            layer1_tile<CT>(Xs, W1, b1, C, H1);
             __syncthreads();
             {
                 f32x16 acc2[2][2];
@@ -463,42 +484,33 @@ __global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
             {
                 const float* Ap = H2 + (lh * 32) * PN_LD2 + wave * 64 + li;     // A[i=out][k=pt] = dz2[pt][out]
                 const float* Bp = H1 + (lh * 32) * PN_LD1 + li;                 // B[k=pt][j=in] = h1[pt][in]
-#pragma unroll 4
-                for (int s = 0; s < 32; ++s) {
-                    const float a0 = Ap[s * PN_LD2], a1 = Ap[s * PN_LD2 + 32];
-                    float bv[4];
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) bv[nb] = Bp[s * PN_LD1 + nb * 32];
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) {
-                        accW2[0][nb] = MFMA(a0, bv[nb], accW2[0][nb]);
-                        accW2[1][nb] = MFMA(a1, bv[nb], accW2[1][nb]);
-                    }
+                float a0p, a1p, bvp[4], a0q, a1q, bvq[4];
+#define DW2_LOAD(a0, a1, bv, s_)                                   \
+    a0 = Ap[(s_) * PN_LD2]; a1 = Ap[(s_) * PN_LD2 + 32];           \
+    _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) bv[nb] = Bp[(s_) * PN_LD1 + nb * 32];
+#define DW2_MMA(a0, a1, bv)                                         \
+    _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) {              \
+        accW2[0][nb] = MFMA(a0, bv[nb], accW2[0][nb]);              \
+        accW2[1][nb] = MFMA(a1, bv[nb], accW2[1][nb]);              \
+    }
+                DW2_LOAD(a0p, a1p, bvp, 0)
+#pragma unroll 1
+                for (int s = 0; s < 32; s += 2) {
+                    DW2_LOAD(a0q, a1q, bvq, s + 1)
+                    DW2_MMA(a0p, a1p, bvp)
+                    if (s + 2 < 32) { DW2_LOAD(a0p, a1p, bvp, s + 2) }
+                    DW2_MMA(a0q, a1q, bvq)
                 }
+#undef DW2_LOAD
+#undef DW2_MMA
             }
             // ---- dh1 = dz2 * W2 : this wave's 32 input channels, K = 256 --------------------
             {
-                f32x16 accH[2];
+                f32x16 accH[2][1];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) accH[0][r] = accH[1][r] = 0.f;
-                const float4* Bp = P2Tv + (size_t)wave * 32 * 64 + lane;
-                const float* A0 = H2 + li * PN_LD2 + lh * 128;
-                const float* A1 = H2 + (32 + li) * PN_LD2 + lh * 128;
-                float4 bn = Bp[0], an0 = *(const float4*)A0, an1 = *(const float4*)A1;
-#pragma unroll 2
-                for (int s4 = 0; s4 < 32; ++s4) {
-                    const float4 bc = bn, a0 = an0, a1 = an1;
-                    if (s4 + 1 < 32) {
-                        bn = Bp[(s4 + 1) * 64];
-                        an0 = *(const float4*)(A0 + (s4 + 1) * 4);
-                        an1 = *(const float4*)(A1 + (s4 + 1) * 4);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        accH[0] = MFMA(a0[e], bc[e], accH[0]);
-                        accH[1] = MFMA(a1[e], bc[e], accH[1]);
-                    }
-                }
+                for (int r = 0; r < 16; ++r) accH[0][0][r] = accH[1][0][r] = 0.f;
+                mfma_stream<1, 32>(H2 + li * PN_LD2 + lh * 128, H2 + (32 + li) * PN_LD2 + lh * 128,
+                                   P2Tv + (size_t)wave * 32 * 64 + lane, accH);
                 // dz1 = dh1 .* (1 - h1^2)
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
                     for (int r = 0; r < 16; ++r) {
                         const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = wave * 32 + li;
                         const float h = H1[row * PN_LD1 + col];
-                        DZ1[row * PN_LD1 + col] = accH[mb][r] * (1.0f - h * h);
+                        DZ1[row * PN_LD1 + col] = accH[mb][0][r] * (1.0f - h * h);
                     }
             }
             __syncthreads();
@@ -645,8 +657,13 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
         if (rc != PM_OK) return rc;
     }
     const int G = pn_bwd_grid(B);
-    hipLaunchKernelGGL(pn_bwd_kernel, dim3(G), dim3(256), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, b2, W3,
-                       packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, parts);
+#define PN_BWD_LAUNCH(CT)                                                                                          \
+    hipLaunchKernelGGL(pn_bwd_kernel<CT>, dim3(G), dim3(256), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, b2, \
+                       W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, parts)
+    if (C == 3) PN_BWD_LAUNCH(3);
+    else if (C == 4) PN_BWD_LAUNCH(4);
+    else PN_BWD_LAUNCH(0);
+#undef PN_BWD_LAUNCH
     const int n = (int)(sizeof(PnBwdPart) / sizeof(float));
     hipLaunchKernelGGL(pn_bwd_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, pm_stream(stream), parts, G, C, dW1,
                        db1, dW2, db2);

@@ -261,3 +261,19 @@ def test_ball_query_and_group_bit_exact(B, P, S, r, ns):
     for b in range(B):
         dref[b].index_add_(0, torch.from_numpy(ref[b].reshape(-1).astype(np.int64)), dout[b].reshape(-1, 7).double())
     assert rel_err(dfeat, dref) < 1e-5
+
+
+def test_fast_tanh_accuracy():
+    """pm_tanh (branch-free polynomial / exp2+rcp) against fp64 tanh on a dense grid incl. the 0.35 seam."""
+    o = ops()
+    x = torch.cat([torch.linspace(-12, 12, 400001), torch.linspace(0.3, 0.4, 100001), torch.logspace(-30, -1, 5000),
+                   torch.tensor([0.0, -0.0, 1e-38, 88.0, -88.0, 1e30, float("inf"), -float("inf")])]).float()
+    out = torch.empty_like(x).to(DEV)
+    o.action_activation(x.to(DEV), out, 1.0, True)
+    ref = torch.tanh(x.double())
+    got = out.cpu().double()
+    err = (got - ref).abs()
+    ulp = torch.maximum(ref.abs(), torch.tensor(1e-30, dtype=torch.float64)) * 2.0 ** -23
+    assert float((err / ulp).max()) < 6.0, float((err / ulp).max())
+    assert float(err.max()) < 2.5e-7
+    assert got[-2] == 1.0 and got[-1] == -1.0 and got[-8] == 0.0

@@ -149,7 +149,7 @@ def test_ppo_checkpoint_roundtrip():
 
 # ------------------------------------------------------------------------------- PointNet encoder
 @pytest.mark.parametrize("B,C,max_mean,sub_mean,proprio", [(6, 3, True, False, 0), (5, 3, False, False, 0),
-                                                           (4, 4, True, True, 0), (3, 3, True, True, 7),
+                                                           (4, 4, True, True, 0), (3, 3, True, True, 7), (2, 6, True, False, 0),
                                                            (300, 3, True, False, 0)])
 def test_pointnet_forward_backward(B, C, max_mean, sub_mean, proprio):
     from partmanip_amd.algo_utils import ActorCritic
