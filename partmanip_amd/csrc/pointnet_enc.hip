@@ -8,7 +8,8 @@
 //   feat    (B, ldf)      [max(512) | mean(512)]   argmax (B,512) int32
 //   never materialised: the (B,P,128/256/512) activations (4.3 GB per net at B=2048).
 //
-// One work-group (4 waves) owns one cloud and walks it in tiles of 64 points:
+// Forward: one work-group (4 waves) owns one cloud and walks it in tiles of 64 points
+// (the backward uses 32-point tiles so that two work-groups fit one CU, see below):
 //   layer 1 (K=C<=8)  VALU          -> H1 tile in LDS  [64][132]
 //   layer 2 (K=128)   fp32 MFMA     -> H2 tile in LDS  [64][260]   (aliases H1 after a barrier)
 //   layer 3 (K=256)   fp32 MFMA     -> running max / argmax / sum per channel in registers
@@ -79,33 +80,34 @@ __device__ __forceinline__ void cloud_centroid(const float* __restrict__ xb, int
     cen[2] = (float)(s2 / P);
 }
 
-// stage one tile of 64 points (C floats each) into Xs[64][PN_MAXC], optionally re-centred
+// stage one tile of TM points (C floats each) into Xs[TM][PN_MAXC], optionally re-centred
+template <int TM>
 __device__ __forceinline__ void stage_points(const float* __restrict__ xb, int tile, int C, int sub_mean,
                                              const float (&cen)[3], float* __restrict__ Xs) {
-    for (int i = threadIdx.x; i < PN_TM * PN_MAXC; i += 256) {
+    for (int i = threadIdx.x; i < TM * PN_MAXC; i += 256) {
         const int p = i >> 3, d = i & 7;
         float v = 0.f;                                   // slots d >= C stay zero (layer1_tile reads float4s)
         if (d < C) {
-            v = xb[(tile * PN_TM + p) * C + d];
+            v = xb[(tile * TM + p) * C + d];
             if (sub_mean && d < 3) v -= cen[d];
         }
         Xs[i] = v;
     }
 }
 
-// layer 1: thread (c = tid&127, half = tid>>7) computes tanh(b1[c] + W1[c,:] . x[p,:]) for its 32 points.
+// layer 1: thread (c = tid&127, half = tid>>7) computes tanh(b1[c] + W1[c,:] . x[p,:]) for its TM/2 points.
 // CT = compile-time channel count (3: xyz clouds, 4: depth_sparse); 0 = generic runtime C <= 8.
-template <int CT>
+template <int CT, int TM>
 __device__ __forceinline__ void layer1_tile(const float* __restrict__ Xs, const float* __restrict__ W1,
                                             const float* __restrict__ b1, int C, float* __restrict__ H1) {
-    const int c = threadIdx.x & 127, p0 = (threadIdx.x >> 7) * 32;
+    const int c = threadIdx.x & 127, p0 = (threadIdx.x >> 7) * (TM / 2);
     const float b1c = b1[c];
     if (CT == 3 || CT == 4) {                  // one broadcast ds_read_b128 per point, no branches
         float w[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) w[d] = (d < CT) ? W1[c * CT + d] : 0.f;
 #pragma unroll 8
-        for (int p = p0; p < p0 + 32; ++p) {
+        for (int p = p0; p < p0 + TM / 2; ++p) {
             const float4 xv = *(const float4*)(Xs + p * PN_MAXC);
             float s = fmaf(w[0], xv.x, b1c);
             s = fmaf(w[1], xv.y, s);
@@ -117,7 +119,7 @@ __device__ __forceinline__ void layer1_tile(const float* __restrict__ Xs, const 
         float w1[PN_MAXC];
 #pragma unroll
         for (int d = 0; d < PN_MAXC; ++d) w1[d] = (d < C) ? W1[c * C + d] : 0.f;
-        for (int p = p0; p < p0 + 32; ++p) {
+        for (int p = p0; p < p0 + TM / 2; ++p) {
             const float4 x0 = *(const float4*)(Xs + p * PN_MAXC), x1 = *(const float4*)(Xs + p * PN_MAXC + 4);
             float s = b1c;                     // Xs slots d >= C are zero-filled by stage_points
             s = fmaf(w1[0], x0.x, s); s = fmaf(w1[1], x0.y, s); s = fmaf(w1[2], x0.z, s); s = fmaf(w1[3], x0.w, s);
@@ -128,65 +130,76 @@ __device__ __forceinline__ void layer1_tile(const float* __restrict__ Xs, const 
 }
 
 // ---- MFMA operand streaming without register copies ------------------------------------------
-// acc[mb][nb] += A(64 x K, LDS) * B(K x NB*32, packed weights in L2).  Two named operand sets
-// (ping / pong): the loads of k-group g+1 are issued before the 8*NB MFMAs of group g and are first
-// waited for a full group (>= 1000 cycles) later.  (A "next -> current" register copy at the loop
-// top makes hipcc wait for the just-issued loads in the same iteration, exposing the whole L2 round
-// trip every 32 MFMAs: measured -27 % on the layer-3 loop.)
-template <int NB>
+// acc[mb][nb] += A(MB*32 x K, LDS, row stride lda) * B(K x NB*32, packed weights in L2).  Two named
+// operand sets (ping / pong): the loads of k-group g+1 are issued before the 4*MB*NB MFMAs of group g
+// and are first waited for a full group (>= 500 cycles) later.  (A "next -> current" register copy at
+// the loop top makes hipcc wait for the just-issued loads in the same iteration, exposing the whole
+// L2 round trip every group: measured -27 % on the forward's layer-3 loop.)
+template <int MB, int NB>
 struct OperandSet {
-    float4 a0, a1, b[NB];
+    float4 a[MB], b[NB];
 };
-template <int NB>
-__device__ __forceinline__ void load_set(OperandSet<NB>& o, const float* __restrict__ A0, const float* __restrict__ A1,
+template <int MB, int NB>
+__device__ __forceinline__ void load_set(OperandSet<MB, NB>& o, const float* __restrict__ A, int lda,
                                          const float4* __restrict__ Bp, int bstride, int g) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) o.b[nb] = Bp[(size_t)(nb * bstride + g) * 64];
-    o.a0 = *(const float4*)(A0 + g * 4);
-    o.a1 = *(const float4*)(A1 + g * 4);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) o.a[mb] = *(const float4*)(A + mb * 32 * lda + g * 4);
 }
-template <int NB>
-__device__ __forceinline__ void mfma_set(const OperandSet<NB>& o, f32x16 (&acc)[2][NB]) {
+template <int MB, int NB>
+__device__ __forceinline__ void mfma_set(const OperandSet<MB, NB>& o, f32x16 (&acc)[MB][NB]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            acc[0][nb] = MFMA(o.a0[e], o.b[nb][e], acc[0][nb]);
-            acc[1][nb] = MFMA(o.a1[e], o.b[nb][e], acc[1][nb]);
-        }
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb][nb] = MFMA(o.a[mb][e], o.b[nb][e], acc[mb][nb]);
 }
-// NG = number of 4-step k-groups per lane half (K/8); bstride = NG (packed layout [nb][g][lane][4]).
-template <int NB, int NG>
-__device__ __forceinline__ void mfma_stream(const float* __restrict__ A0, const float* __restrict__ A1,
-                                            const float4* __restrict__ Bp, f32x16 (&acc)[2][NB]) {
-    OperandSet<NB> ping, pong;
-    load_set<NB>(ping, A0, A1, Bp, NG, 0);
+// A points at this lane's first row/k (row li, k = lh*K/2); NG = 4-step k-groups per lane half (K/8);
+// packed B layout [nb][NG][lane][4] (Bp already offset to this wave's first N-block and this lane).
+template <int MB, int NB, int NG>
+__device__ __forceinline__ void mfma_stream(const float* __restrict__ A, int lda, const float4* __restrict__ Bp,
+                                            f32x16 (&acc)[MB][NB]) {
+    OperandSet<MB, NB> ping, pong;
+    load_set<MB, NB>(ping, A, lda, Bp, NG, 0);
 #pragma unroll 1
     for (int g = 0; g < NG; g += 2) {
-        load_set<NB>(pong, A0, A1, Bp, NG, g + 1);
-        mfma_set<NB>(ping, acc);
-        if (g + 2 < NG) load_set<NB>(ping, A0, A1, Bp, NG, g + 2);
-        mfma_set<NB>(pong, acc);
+        load_set<MB, NB>(pong, A, lda, Bp, NG, g + 1);
+        mfma_set<MB, NB>(ping, acc);
+        if (g + 2 < NG) load_set<MB, NB>(ping, A, lda, Bp, NG, g + 2);
+        mfma_set<MB, NB>(pong, acc);
     }
 }
 
-// layer 2 MFMA part: acc[mb][nb] (64 points x this wave's 64 channels) = H1 * W2^T
+template <int MB, int NB>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MB][NB]) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+}
+
+// layer 2 MFMA part: acc[mb][nb] (MB*32 points x this wave's 64 channels) = H1 * W2^T, K = 128
+template <int MB>
 __device__ __forceinline__ void layer2_mfma(const float* __restrict__ H1, const float4* __restrict__ P2v, int wave,
-                                            int lane, f32x16 (&acc)[2][2]) {
+                                            int lane, f32x16 (&acc)[MB][2]) {
     const int li = lane & 31, lh = lane >> 5;
-    mfma_stream<2, 16>(H1 + li * PN_LD1 + lh * 64, H1 + (32 + li) * PN_LD1 + lh * 64,
-                       P2v + (size_t)(wave * 2) * 16 * 64 + lane, acc);
+    mfma_stream<MB, 2, 16>(H1 + li * PN_LD1 + lh * 64, PN_LD1, P2v + (size_t)(wave * 2) * 16 * 64 + lane, acc);
 }
 
 // layer 2 epilogue: H2[row][ch] = tanh(acc + b2[ch])
-__device__ __forceinline__ void layer2_store(const f32x16 (&acc)[2][2], const float* __restrict__ b2, int wave, int lane,
+template <int MB>
+__device__ __forceinline__ void layer2_store(const f32x16 (&acc)[MB][2], const float* __restrict__ b2, int wave, int lane,
                                              float* __restrict__ H2) {
     const int li = lane & 31, lh = lane >> 5;
     float b2v[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) b2v[nb] = b2[wave * 64 + nb * 32 + li];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -231,21 +244,16 @@ __global__ __launch_bounds__(256, 2) void pn_fwd_kernel(const float* __restrict_
     const int ntiles = P / PN_TM;
     for (int tile = 0; tile < ntiles; ++tile) {
         __syncthreads();                          // previous tile's layer-3 reads of H are done
-        stage_points(xb, tile, C, sub_mean, cen, Xs);
+        stage_points<PN_TM>(xb, tile, C, sub_mean, cen, Xs);
         __syncthreads();
-        layer1_tile<CT>(Xs, W1, b1, C, H);
+        layer1_tile<CT, PN_TM>(Xs, W1, b1, C, H);
         __syncthreads();
         {
             f32x16 acc2[2][2];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc2[mb][nb][r] = 0.f;
-            layer2_mfma(H, P2v, wave, lane, acc2);
+            zero_acc<2, 2>(acc2);
+            layer2_mfma<2>(H, P2v, wave, lane, acc2);
             __syncthreads();                      // every wave has finished reading H1
-            layer2_store(acc2, b2, wave, lane, H);
+            layer2_store<2>(acc2, b2, wave, lane, H);
         }
         __syncthreads();
 
@@ -257,8 +265,7 @@ __global__ __launch_bounds__(256, 2) void pn_fwd_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][nb][r] = acc[1][nb][r] = b3c;
         }
-        mfma_stream<4, 32>(H + li * PN_LD2 + lh * 128, H + (32 + li) * PN_LD2 + lh * 128,
-                           P3v + (size_t)(wave * 4) * 32 * 64 + lane, acc);
+        mfma_stream<2, 4, 32>(H + li * PN_LD2 + lh * 128, PN_LD2, P3v + (size_t)(wave * 4) * 32 * 64 + lane, acc);
         // ---- pooling over this tile's 64 points (rows), in increasing point order ------------
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
@@ -330,9 +337,13 @@ extern "C" int pm_pointnet_enc_fwd_f32(const float* x, long ldx, int B, int P, i
 //   dW1/db1 += dz1^T [x 1] (VALU, K = C+1)
 // It also emits, per cloud, sum_p h2 (scaled 1/P) and the h2 rows at the argmax points
 // (Hg[b,c,:]) from which two small follow-up kernels build dW3/db3.
-// Work-groups are persistent over clouds (grid <= 256) so the dW2 partials stay small.
+// Tiles are 32 points: 79.5 KB of LDS per work-group => TWO work-groups per CU (two waves per
+// SIMD from independent work-groups), so one group's VALU / LDS / barrier phases hide under the
+// other's MFMA phases (the 64-point, one-group-per-CU version ran the MFMA pipe at 38 %).
+// Work-groups are persistent over clouds (grid <= 512) so the dW2 partials stay small.
 
-#define PN_BWD_MAXG 256
+#define PN_BT 32                 // backward tile (points)
+#define PN_BWD_MAXG 512
 
 struct PnBwdPart {          // per-work-group partial sums (floats)
     float dW2[PN_C2 * PN_C1];
@@ -343,7 +354,9 @@ struct PnBwdPart {          // per-work-group partial sums (floats)
 
 // in-LDS bitonic sort of 512 int keys by 256 threads (ascending)
 __device__ __forceinline__ void bitonic_sort_512(int* keys) {
-    for (int k = 2; k <= 512; k <<= 1) {
+#pragma unroll 1                                  // rolled: unrolling hoists 45 lane-constant address pairs
+    for (int k = 2; k <= 512; k <<= 1) {          // to kernel entry and spills them (rule: recompute, don't hoist)
+#pragma unroll 1
         for (int j = k >> 1; j > 0; j >>= 1) {
             __syncthreads();
             const int t = threadIdx.x;
@@ -361,23 +374,24 @@ __device__ __forceinline__ void bitonic_sort_512(int* keys) {
 }
 
 template <int CT>
-__global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
+__global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
     const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
     const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ W3,
     const float* __restrict__ packed, int max_mean, const float* __restrict__ dfeat, long ldf,
     const int32_t* __restrict__ argmax, const float* __restrict__ U, float* __restrict__ H2sum,
     float* __restrict__ Hg, PnBwdPart* __restrict__ parts) {
-    __shared__ __attribute__((aligned(16))) float smem[PN_TM * PN_LD1 * 2 + PN_TM * PN_LD2 + PN_TM * PN_MAXC +
-                                                        PN_C2 + PN_C3 + PN_C3 + 1040 + 4 * PN_C2 + 16];
-    float* H1 = smem;                                   // [64][132]
-    float* DZ1 = H1 + PN_TM * PN_LD1;                   // [64][132]
-    float* H2 = DZ1 + PN_TM * PN_LD1;                   // [64][260]  h2, then dz2 in place
-    float* Xs = H2 + PN_TM * PN_LD2;                    // [64][8]
-    float* Us = Xs + PN_TM * PN_MAXC;                   // [256]  u[b,:]/P
+    constexpr int BT = PN_BT;
+    __shared__ __attribute__((aligned(16))) float smem[BT * PN_LD1 * 2 + BT * PN_LD2 + BT * PN_MAXC + PN_C2 + PN_C3 +
+                                                        PN_C3 + 520 + 4 * PN_C2 + 16];
+    float* H1 = smem;                                   // [32][132]
+    float* DZ1 = H1 + BT * PN_LD1;                      // [32][132]
+    float* H2 = DZ1 + BT * PN_LD1;                      // [32][260]  h2, then dz2 in place
+    float* Xs = H2 + BT * PN_LD2;                       // [32][8]
+    float* Us = Xs + BT * PN_MAXC;                      // [256]  u[b,:]/P
     float* Gm = Us + PN_C2;                             // [512]  dmax[b,:]
     int* keys = (int*)(Gm + PN_C3);                     // [512]  sorted (point<<9 | channel)
-    int* offs = keys + PN_C3;                           // [P+1 <= 1025(+pad)] first key index of each point
-    float* wred = (float*)(offs + 1040);                // [4][256] cross-wave reductions
+    unsigned short* offs = (unsigned short*)(keys + PN_C3);   // [P+1 <= 1025] first key index of each point
+    float* wred = (float*)(keys + PN_C3) + 520;         // [4][256] cross-wave reductions
     double* red = (double*)(wred + 4 * PN_C2);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -388,18 +402,13 @@ __global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
 
     // accumulators that live for the whole kernel
     f32x16 accW2[2][4];                                  // dW2[out = wave*64+mb*32+row][in = nb*32+li]
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accW2[mb][nb][r] = 0.f;
+    zero_acc<2, 4>(accW2);
     float4 db2acc = make_float4(0.f, 0.f, 0.f, 0.f);   // columns 4*lane..+3 over this wave's rows
     float dW1acc[PN_MAXC], db1acc = 0.f;                 // channel tid&127, point half tid>>7
 #pragma unroll
     for (int d = 0; d < PN_MAXC; ++d) dW1acc[d] = 0.f;
 
-    const int ntiles = P / PN_TM;
+    const int ntiles = P / BT;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const float* xb = x + (long)b * ldx;
         float cen[3] = {0.f, 0.f, 0.f};
@@ -419,33 +428,29 @@ __global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
                 const int mid = (lo + hi) >> 1;
                 if (keys[mid] < target) lo = mid + 1; else hi = mid;
             }
-            offs[p] = lo;
+            offs[p] = (unsigned short)lo;
         }
         float4 h2s = make_float4(0.f, 0.f, 0.f, 0.f);    // sum_p h2[p][4*lane..] over this wave's rows
 
         for (int tile = 0; tile < ntiles; ++tile) {
             __syncthreads();
-            stage_points(xb, tile, C, sub_mean, cen, Xs);
+            stage_points<BT>(xb, tile, C, sub_mean, cen, Xs);
             __syncthreads();
-            layer1_tile<CT>(Xs, W1, b1, C, H1);
+            layer1_tile<CT, BT>(Xs, W1, b1, C, H1);
             __syncthreads();
             {
-                f32x16 acc2[2][2];
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc2[mb][nb][r] = 0.f;
-                layer2_mfma(H1, P2v, wave, lane, acc2);
-                layer2_store(acc2, b2, wave, lane, H2);
+                f32x16 acc2[1][2];
+                zero_acc<1, 2>(acc2);
+                layer2_mfma<1>(H1, P2v, wave, lane, acc2);
+                layer2_store<1>(acc2, b2, wave, lane, H2);
             }
             __syncthreads();
-            // ---- row-owner pass: wave w owns rows w*16..w*16+15; h2 -> dz2 in place ----------
+            // ---- row-owner pass: wave w owns rows w*8..w*8+7; h2 -> dz2 in place -------------
             {
-                const int p0 = tile * PN_TM + wave * 16;
+                constexpr int RPW = BT / 4;
+                const int p0 = tile * BT + wave * RPW;
                 const float4 u4 = *(const float4*)(Us + 4 * lane);
-                const int e_end = offs[p0 + 16];
+                const int e_end = offs[p0 + RPW];
                 int e = offs[p0];
                 int c_next = 0;
                 float4 w_next = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -453,8 +458,8 @@ __global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
                     c_next = keys[e] & 511;
                     w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
                 }
-                for (int rr = 0; rr < 16; ++rr) {
-                    float* hrow = H2 + (wave * 16 + rr) * PN_LD2 + 4 * lane;
+                for (int rr = 0; rr < RPW; ++rr) {
+                    float* hrow = H2 + (wave * RPW + rr) * PN_LD2 + 4 * lane;
                     const float4 h = *(const float4*)hrow;
                     h2s.x += h.x; h2s.y += h.y; h2s.z += h.z; h2s.w += h.w;
                     float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -480,10 +485,10 @@ __global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
                 }
             }
             __syncthreads();
-            // ---- dW2 += dz2^T * h1 : K = 64 points (lanes<32: point s, lanes>=32: point 32+s) ----
+            // ---- dW2 += dz2^T * h1 : K = 32 points (lanes<32: point s, lanes>=32: point 16+s) ----
             {
-                const float* Ap = H2 + (lh * 32) * PN_LD2 + wave * 64 + li;     // A[i=out][k=pt] = dz2[pt][out]
-                const float* Bp = H1 + (lh * 32) * PN_LD1 + li;                 // B[k=pt][j=in] = h1[pt][in]
+                const float* Ap = H2 + (lh * (BT / 2)) * PN_LD2 + wave * 64 + li;     // A[i=out][k=pt] = dz2[pt][out]
+                const float* Bp = H1 + (lh * (BT / 2)) * PN_LD1 + li;                 // B[k=pt][j=in] = h1[pt][in]
                 float a0p, a1p, bvp[4], a0q, a1q, bvq[4];
 #define DW2_LOAD(a0, a1, bv, s_)                                   \
     a0 = Ap[(s_) * PN_LD2]; a1 = Ap[(s_) * PN_LD2 + 32];           \
@@ -495,42 +500,48 @@ __global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
     }
                 DW2_LOAD(a0p, a1p, bvp, 0)
 #pragma unroll 1
-                for (int s = 0; s < 32; s += 2) {
+                for (int s = 0; s < BT / 2; s += 2) {
                     DW2_LOAD(a0q, a1q, bvq, s + 1)
                     DW2_MMA(a0p, a1p, bvp)
-                    if (s + 2 < 32) { DW2_LOAD(a0p, a1p, bvp, s + 2) }
+                    if (s + 2 < BT / 2) { DW2_LOAD(a0p, a1p, bvp, s + 2) }
                     DW2_MMA(a0q, a1q, bvq)
                 }
 #undef DW2_LOAD
 #undef DW2_MMA
             }
-            // ---- dh1 = dz2 * W2 : this wave's 32 input channels, K = 256 --------------------
+            // ---- dh1 = dz2 * W2 : 32 points x this wave's 32 input channels, K = 256 ----------
             {
-                f32x16 accH[2][1];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accH[0][0][r] = accH[1][0][r] = 0.f;
-                mfma_stream<1, 32>(H2 + li * PN_LD2 + lh * 128, H2 + (32 + li) * PN_LD2 + lh * 128,
-                                   P2Tv + (size_t)wave * 32 * 64 + lane, accH);
+                f32x16 accH[1][1];
+                zero_acc<1, 1>(accH);
+                mfma_stream<1, 1, 32>(H2 + li * PN_LD2 + lh * 128, PN_LD2, P2Tv + (size_t)wave * 32 * 64 + lane, accH);
                 // dz1 = dh1 .* (1 - h1^2)
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = wave * 32 + li;
-                        const float h = H1[row * PN_LD1 + col];
-                        DZ1[row * PN_LD1 + col] = accH[mb][0][r] * (1.0f - h * h);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh, col = wave * 32 + li;
+                    const float h = H1[row * PN_LD1 + col];
+                    DZ1[row * PN_LD1 + col] = accH[0][0][r] * (1.0f - h * h);
+                }
             }
             __syncthreads();
-            // ---- dW1 / db1 (K = C): thread (c, half) over its 32 points ---------------------
+            // ---- dW1 / db1 (K = C): thread (c, half) over its 16 points ---------------------
             {
-                const int c = tid & 127, p0 = (tid >> 7) * 32;
-                for (int p = p0; p < p0 + 32; ++p) {
+                const int c = tid & 127, p0 = (tid >> 7) * (BT / 2);
+#pragma unroll 4
+                for (int p = p0; p < p0 + BT / 2; ++p) {
                     const float dz = DZ1[p * PN_LD1 + c];
+                    const float4 x0 = *(const float4*)(Xs + p * PN_MAXC);
                     db1acc += dz;
-#pragma unroll
-                    for (int d = 0; d < PN_MAXC; ++d)
-                        if (d < C) dW1acc[d] += dz * Xs[p * PN_MAXC + d];
+                    dW1acc[0] = fmaf(dz, x0.x, dW1acc[0]);
+                    dW1acc[1] = fmaf(dz, x0.y, dW1acc[1]);
+                    dW1acc[2] = fmaf(dz, x0.z, dW1acc[2]);
+                    dW1acc[3] = fmaf(dz, x0.w, dW1acc[3]);
+                    if (CT != 3 && CT != 4) {
+                        const float4 x1 = *(const float4*)(Xs + p * PN_MAXC + 4);
+                        dW1acc[4] = fmaf(dz, x1.x, dW1acc[4]);
+                        dW1acc[5] = fmaf(dz, x1.y, dW1acc[5]);
+                        dW1acc[6] = fmaf(dz, x1.z, dW1acc[6]);
+                        dW1acc[7] = fmaf(dz, x1.w, dW1acc[7]);
+                    }
                 }
             }
         }
@@ -557,9 +568,8 @@ __global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
     __syncthreads();
     part->db2[tid] = wred[tid] + wred[PN_C2 + tid] + wred[2 * PN_C2 + tid] + wred[3 * PN_C2 + tid];
     __syncthreads();
-    {   // combine the two point-halves of dW1/db1 through LDS
-        float* t = wred;                                  // [2][128][PN_MAXC+1] = 2304 floats > 1024: use H1 region
-        t = H1;
+    {   // combine the two point-halves of dW1/db1 through LDS (H1 region: 2*128*9 floats <= 32*132)
+        float* t = H1;
         const int c = tid & 127, half = tid >> 7;
 #pragma unroll
         for (int d = 0; d < PN_MAXC; ++d) t[(half * 128 + c) * (PN_MAXC + 1) + d] = dW1acc[d];
@@ -573,7 +583,6 @@ __global__ __launch_bounds__(256, 1) void pn_bwd_kernel(
         }
     }
 }
-
 // sum the per-work-group partials in fixed order
 __global__ __launch_bounds__(256) void pn_bwd_reduce_kernel(const PnBwdPart* __restrict__ parts, int G, int C,
                                                              float* __restrict__ dW1, float* __restrict__ db1,
