@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libpartmanip_hip.so")
+LIB_PATH = os.environ.get("PARTMANIP_HIP_LIB") or os.path.join(HERE, "lib", "libpartmanip_hip.so")   # env: A/B kernel builds
 
 P, I, L, F, D, Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
 

@@ -28,11 +28,18 @@
 #define PN_LD1 (PN_C1 + 4)
 #define PN_LD2 (PN_C2 + 4)
 #define PN_MAXC 8
+#ifndef PN_ABLATE
+#define PN_ABLATE 0          // profiling only: bit0 = skip layer-3 MFMAs, bit1 = skip layer-2 MFMAs (wrong results)
+#endif
+#ifndef PN_FWD_NW
+#define PN_FWD_NW 8          // waves per forward work-group (4 or 8)
+#endif
 
 #define PN_P2_OFF 0                      // [8][16][64][4]  W2 as fwd B operand
 #define PN_P3_OFF 32768                  // [16][32][64][4] W3 as fwd B operand
 #define PN_P2T_OFF (32768 + 131072)      // [4][32][64][4]  W2 as bwd (dh1 = dz2 * W2) B operand
-#define PN_PACKED_ELEMS (32768 + 131072 + 32768)
+#define PN_PACKED_DATA (32768 + 131072 + 32768)
+#define PN_PACKED_ELEMS (PN_PACKED_DATA + 1024)   // + 4 KB tail pad: the operand stream prefetches one group past the end
 
 extern "C" size_t pm_pointnet_packed_elems(void) { return PN_PACKED_ELEMS; }
 
@@ -40,6 +47,10 @@ __global__ __launch_bounds__(256) void pn_pack_kernel(const float* __restrict__ 
                                                        float* __restrict__ packed) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= PN_PACKED_ELEMS) return;
+    if (i >= PN_PACKED_DATA) {
+        packed[i] = 0.f;
+        return;
+    }
     const int e = i & 3, lane = (i >> 2) & 63, li = lane & 31, lh = lane >> 5;
     if (i < PN_P3_OFF) {                                   // W2 fwd: half = 64 k, 16 groups of 4
         const int s4 = (i >> 8) & 15, nb = i >> 12;
@@ -65,26 +76,27 @@ extern "C" int pm_pointnet_pack_weights_f32(const float* W2, const float* W3, fl
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // centroid of the first 3 coordinates of a cloud (network.py:172-173 `sub_mean`)
+template <int NT>
 __device__ __forceinline__ void cloud_centroid(const float* __restrict__ xb, int P, int C, double* red, float (&cen)[3]) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int p = threadIdx.x; p < P; p += 256) {
+    for (int p = threadIdx.x; p < P; p += NT) {
         s0 += (double)xb[p * C];
         s1 += (double)xb[p * C + 1];
         s2 += (double)xb[p * C + 2];
     }
-    s0 = block_sum<double, 256>(s0, red);
-    s1 = block_sum<double, 256>(s1, red);
-    s2 = block_sum<double, 256>(s2, red);
+    s0 = block_sum<double, NT>(s0, red);
+    s1 = block_sum<double, NT>(s1, red);
+    s2 = block_sum<double, NT>(s2, red);
     cen[0] = (float)(s0 / P);
     cen[1] = (float)(s1 / P);
     cen[2] = (float)(s2 / P);
 }
 
 // stage one tile of TM points (C floats each) into Xs[TM][PN_MAXC], optionally re-centred
-template <int TM>
+template <int TM, int NT>
 __device__ __forceinline__ void stage_points(const float* __restrict__ xb, int tile, int C, int sub_mean,
                                              const float (&cen)[3], float* __restrict__ Xs) {
-    for (int i = threadIdx.x; i < TM * PN_MAXC; i += 256) {
+    for (int i = threadIdx.x; i < TM * PN_MAXC; i += NT) {
         const int p = i >> 3, d = i & 7;
         float v = 0.f;                                   // slots d >= C stay zero (layer1_tile reads float4s)
         if (d < C) {
@@ -95,19 +107,20 @@ __device__ __forceinline__ void stage_points(const float* __restrict__ xb, int t
     }
 }
 
-// layer 1: thread (c = tid&127, half = tid>>7) computes tanh(b1[c] + W1[c,:] . x[p,:]) for its TM/2 points.
+// layer 1: thread (c = tid&127, part = tid>>7) computes tanh(b1[c] + W1[c,:] . x[p,:]) for its PPT points.
 // CT = compile-time channel count (3: xyz clouds, 4: depth_sparse); 0 = generic runtime C <= 8.
-template <int CT, int TM>
+template <int CT, int TM, int NT>
 __device__ __forceinline__ void layer1_tile(const float* __restrict__ Xs, const float* __restrict__ W1,
                                             const float* __restrict__ b1, int C, float* __restrict__ H1) {
-    const int c = threadIdx.x & 127, p0 = (threadIdx.x >> 7) * (TM / 2);
+    constexpr int PPT = TM * 128 / NT;           // points per thread
+    const int c = threadIdx.x & 127, p0 = (threadIdx.x >> 7) * PPT;
     const float b1c = b1[c];
     if (CT == 3 || CT == 4) {                  // one broadcast ds_read_b128 per point, no branches
         float w[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) w[d] = (d < CT) ? W1[c * CT + d] : 0.f;
 #pragma unroll 8
-        for (int p = p0; p < p0 + TM / 2; ++p) {
+        for (int p = p0; p < p0 + PPT; ++p) {
             const float4 xv = *(const float4*)(Xs + p * PN_MAXC);
             float s = fmaf(w[0], xv.x, b1c);
             s = fmaf(w[1], xv.y, s);
@@ -119,7 +132,7 @@ __device__ __forceinline__ void layer1_tile(const float* __restrict__ Xs, const 
         float w1[PN_MAXC];
 #pragma unroll
         for (int d = 0; d < PN_MAXC; ++d) w1[d] = (d < C) ? W1[c * C + d] : 0.f;
-        for (int p = p0; p < p0 + TM / 2; ++p) {
+        for (int p = p0; p < p0 + PPT; ++p) {
             const float4 x0 = *(const float4*)(Xs + p * PN_MAXC), x1 = *(const float4*)(Xs + p * PN_MAXC + 4);
             float s = b1c;                     // Xs slots d >= C are zero-filled by stage_points
             s = fmaf(w1[0], x0.x, s); s = fmaf(w1[1], x0.y, s); s = fmaf(w1[2], x0.z, s); s = fmaf(w1[3], x0.w, s);
@@ -165,10 +178,27 @@ __device__ __forceinline__ void mfma_stream(const float* __restrict__ A, int lda
     load_set<MB, NB>(ping, A, lda, Bp, NG, 0);
 #pragma unroll 1
     for (int g = 0; g < NG; g += 2) {
+        // sched_barrier(0) pins the issue order "loads of the NEXT group, then this group's MFMAs":
+        // left alone, hipcc's scheduler sinks each load_set down to its first use (register pressure
+        // heuristic) and the loop degenerates to load -> s_waitcnt -> MFMA with the L2 latency exposed.
+#if (PN_ABLATE & 4)
+        pong = ping;                              // profiling only: no operand traffic inside the loop
+#else
         load_set<MB, NB>(pong, A, lda, Bp, NG, g + 1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
         mfma_set<MB, NB>(ping, acc);
-        if (g + 2 < NG) load_set<MB, NB>(ping, A, lda, Bp, NG, g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // UNCONDITIONAL: on the last trip this reads one k-group past the slice (the LDS row padding /
+        // the next packed block or the packed buffer's 4 KB tail pad) and discards it.  A conditional
+        // load gives the two loop paths different outstanding-load counts and hipcc then waits
+        // vmcnt(1)/(0) for the just-issued loads as well.
+#if !(PN_ABLATE & 4)
+        load_set<MB, NB>(ping, A, lda, Bp, NG, g + 2);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
         mfma_set<MB, NB>(pong, acc);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -182,43 +212,49 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MB][NB]) {
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 }
 
-// layer 2 MFMA part: acc[mb][nb] (MB*32 points x this wave's 64 channels) = H1 * W2^T, K = 128
-template <int MB>
+// layer 2 MFMA part: acc[mb][nb] (MB*32 points x this wave's NB*32 channels) = H1 * W2^T, K = 128
+template <int MB, int NB>
 __device__ __forceinline__ void layer2_mfma(const float* __restrict__ H1, const float4* __restrict__ P2v, int wave,
-                                            int lane, f32x16 (&acc)[MB][2]) {
+                                            int lane, f32x16 (&acc)[MB][NB]) {
     const int li = lane & 31, lh = lane >> 5;
-    mfma_stream<MB, 2, 16>(H1 + li * PN_LD1 + lh * 64, PN_LD1, P2v + (size_t)(wave * 2) * 16 * 64 + lane, acc);
+    mfma_stream<MB, NB, 16>(H1 + li * PN_LD1 + lh * 64, PN_LD1, P2v + (size_t)(wave * NB) * 16 * 64 + lane, acc);
 }
 
 // layer 2 epilogue: H2[row][ch] = tanh(acc + b2[ch])
-template <int MB>
-__device__ __forceinline__ void layer2_store(const f32x16 (&acc)[MB][2], const float* __restrict__ b2, int wave, int lane,
+template <int MB, int NB>
+__device__ __forceinline__ void layer2_store(const f32x16 (&acc)[MB][NB], const float* __restrict__ b2, int wave, int lane,
                                              float* __restrict__ H2) {
     const int li = lane & 31, lh = lane >> 5;
-    float b2v[2];
+    float b2v[NB];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) b2v[nb] = b2[wave * 64 + nb * 32 + li];
+    for (int nb = 0; nb < NB; ++nb) b2v[nb] = b2[(wave * NB + nb) * 32 + li];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                H2[row * PN_LD2 + wave * 64 + nb * 32 + li] = pm_tanh(acc[mb][nb][r] + b2v[nb]);
+                H2[row * PN_LD2 + (wave * NB + nb) * 32 + li] = pm_tanh(acc[mb][nb][r] + b2v[nb]);
             }
 }
 
 // =================================================================================== forward
-template <int CT>
-__global__ __launch_bounds__(256, 2) void pn_fwd_kernel(const float* __restrict__ x, long ldx, int P, int C,
-                                                         int sub_mean, const float* __restrict__ W1,
-                                                         const float* __restrict__ b1, const float* __restrict__ b2,
-                                                         const float* __restrict__ b3,
-                                                         const float* __restrict__ packed, int max_mean,
-                                                         float* __restrict__ feat, long ldf,
-                                                         int32_t* __restrict__ argmax) {
-    __shared__ __attribute__((aligned(16))) float smem[PN_TM * PN_LD2 + PN_TM * PN_MAXC + 16];
+// NW waves per work-group (template): the 512-channel output is split NW ways.  NW = 8 (512
+// threads, 64 channels per wave in layer 3, <=128 VGPRs) puts FOUR waves on every SIMD (two
+// work-groups per CU), so VALU / LDS / barrier phases of one wave hide under the MFMA phases of
+// three others; NW = 4 (128 channels per wave, 256 VGPRs, two waves per SIMD) is kept for A/B.
+template <int CT, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __restrict__ x, long ldx, int P, int C,
+                                                                  int sub_mean, const float* __restrict__ W1,
+                                                                  const float* __restrict__ b1,
+                                                                  const float* __restrict__ b2,
+                                                                  const float* __restrict__ b3,
+                                                                  const float* __restrict__ packed, int max_mean,
+                                                                  float* __restrict__ feat, long ldf,
+                                                                  int32_t* __restrict__ argmax) {
+    constexpr int NT = NW * 64, NB2 = 8 / NW, NB3 = 16 / NW;
+    __shared__ __attribute__((aligned(16))) float smem[PN_TM * PN_LD2 + PN_TM * PN_MAXC + 32];
     float* H = smem;                             // H1 [64][132] then H2 [64][260] (aliased)
     float* Xs = smem + PN_TM * PN_LD2;
     double* red = (double*)(Xs + PN_TM * PN_MAXC);
@@ -230,45 +266,49 @@ __global__ __launch_bounds__(256, 2) void pn_fwd_kernel(const float* __restrict_
     const float4* P3v = (const float4*)(packed + PN_P3_OFF);
 
     float cen[3] = {0.f, 0.f, 0.f};
-    if (sub_mean) cloud_centroid(xb, P, C, red, cen);
+    if (sub_mean) cloud_centroid<NT>(xb, P, C, red, cen);
 
-    float vmax[4], vsum[4];
-    int imax[4];
+    float vmax[NB3], vsum[NB3];
+    int imax[NB3];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
+    for (int nb = 0; nb < NB3; ++nb) {
         vmax[nb] = -INFINITY;
         vsum[nb] = 0.f;
         imax[nb] = 0;
     }
 
     const int ntiles = P / PN_TM;
+    stage_points<PN_TM, NT>(xb, 0, C, sub_mean, cen, Xs);
     for (int tile = 0; tile < ntiles; ++tile) {
-        __syncthreads();                          // previous tile's layer-3 reads of H are done
-        stage_points<PN_TM>(xb, tile, C, sub_mean, cen, Xs);
-        __syncthreads();
-        layer1_tile<CT, PN_TM>(Xs, W1, b1, C, H);
+        __syncthreads();                          // Xs staged; previous tile's layer-3 reads of H are done
+        layer1_tile<CT, PN_TM, NT>(Xs, W1, b1, C, H);
         __syncthreads();
         {
-            f32x16 acc2[2][2];
-            zero_acc<2, 2>(acc2);
-            layer2_mfma<2>(H, P2v, wave, lane, acc2);
-            __syncthreads();                      // every wave has finished reading H1
-            layer2_store<2>(acc2, b2, wave, lane, H);
+            f32x16 acc2[2][NB2];
+            zero_acc<2, NB2>(acc2);
+#if !(PN_ABLATE & 2)
+            layer2_mfma<2, NB2>(H, P2v, wave, lane, acc2);
+#endif
+            __syncthreads();                      // every wave has finished reading H1 (and Xs)
+            layer2_store<2, NB2>(acc2, b2, wave, lane, H);
+            if (tile + 1 < ntiles) stage_points<PN_TM, NT>(xb, tile + 1, C, sub_mean, cen, Xs);
         }
         __syncthreads();
 
-        // ---- layer 3: 64 points x this wave's 128 channels, K = 256 -------------------------
-        f32x16 acc[2][4];
+        // ---- layer 3: 64 points x this wave's NB3*32 channels, K = 256 ------------------------
+        f32x16 acc[2][NB3];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const float b3c = b3[wave * 128 + nb * 32 + li];
+        for (int nb = 0; nb < NB3; ++nb) {
+            const float b3c = b3[(wave * NB3 + nb) * 32 + li];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][nb][r] = acc[1][nb][r] = b3c;
         }
-        mfma_stream<2, 4, 32>(H + li * PN_LD2 + lh * 128, PN_LD2, P3v + (size_t)(wave * 4) * 32 * 64 + lane, acc);
+#if !(PN_ABLATE & 1)
+        mfma_stream<2, NB3, 32>(H + li * PN_LD2 + lh * 128, PN_LD2, P3v + (size_t)(wave * NB3) * 32 * 64 + lane, acc);
+#endif
         // ---- pooling over this tile's 64 points (rows), in increasing point order ------------
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < NB3; ++nb)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -284,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void pn_fwd_kernel(const float* __restrict_
     }
     // lanes l and l^32 hold the two interleaved row sets of the same channel
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
+    for (int nb = 0; nb < NB3; ++nb) {
         const float ov = __shfl_xor(vmax[nb], 32, 64);
         const int oi = __shfl_xor(imax[nb], 32, 64);
         const float os = __shfl_xor(vsum[nb], 32, 64);
@@ -295,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void pn_fwd_kernel(const float* __restrict_
             i = oi;
         }
         if (lh == 0) {
-            const int ch = wave * 128 + nb * 32 + li;
+            const int ch = (wave * NB3 + nb) * 32 + li;
             feat[(long)b * ldf + ch] = v;
             if (max_mean) feat[(long)b * ldf + PN_C3 + ch] = (vsum[nb] + os) / (float)P;
             argmax[(long)b * PN_C3 + ch] = i;
@@ -312,9 +352,9 @@ extern "C" int pm_pointnet_enc_fwd_f32(const float* x, long ldx, int B, int P, i
     PM_REQUIRE(ldf >= PN_C3 * (max_mean ? 2 : 1));
     PM_REQUIRE(!sub_mean || C >= 3);
     if (((uintptr_t)packed & 15) != 0) return PM_EALIGN;
-#define PN_FWD_LAUNCH(CT)                                                                                        \
-    hipLaunchKernelGGL(pn_fwd_kernel<CT>, dim3(B), dim3(256), 0, pm_stream(stream), x, ldx, P, C, sub_mean, W1, b1, b2, \
-                       b3, packed, max_mean, feat, ldf, argmax)
+#define PN_FWD_LAUNCH(CT)                                                                                  \
+    hipLaunchKernelGGL((pn_fwd_kernel<CT, PN_FWD_NW>), dim3(B), dim3(PN_FWD_NW * 64), 0, pm_stream(stream), x, ldx, P, \
+                       C, sub_mean, W1, b1, b2, b3, packed, max_mean, feat, ldf, argmax)
     if (C == 3) PN_FWD_LAUNCH(3);
     else if (C == 4) PN_FWD_LAUNCH(4);
     else PN_FWD_LAUNCH(0);
@@ -413,14 +453,16 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
         const float* xb = x + (long)b * ldx;
         float cen[3] = {0.f, 0.f, 0.f};
         __syncthreads();
-        if (sub_mean) cloud_centroid(xb, P, C, red, cen);
+        if (sub_mean) cloud_centroid<256>(xb, P, C, red, cen);
         // ---- per-cloud setup: u/P, dmax, CSR of argmax by point ---------------------------
         Us[tid] = max_mean ? U[(long)b * PN_C2 + tid] * invP : 0.f;
         for (int c = tid; c < PN_C3; c += 256) {
             Gm[c] = dfeat[(long)b * ldf + c];
             keys[c] = (argmax[(long)b * PN_C3 + c] << 9) | c;
         }
+#if !(PN_ABLATE & 16)
         bitonic_sort_512(keys);                           // by point, then channel: deterministic order
+#endif
         for (int p = tid; p <= P; p += 256) {            // offs[p] = #keys with point < p (binary search)
             int lo = 0, hi = PN_C3;
             const int target = p << 9;
@@ -434,18 +476,21 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
 
         for (int tile = 0; tile < ntiles; ++tile) {
             __syncthreads();
-            stage_points<BT>(xb, tile, C, sub_mean, cen, Xs);
+            stage_points<BT, 256>(xb, tile, C, sub_mean, cen, Xs);
             __syncthreads();
-            layer1_tile<CT, BT>(Xs, W1, b1, C, H1);
+            layer1_tile<CT, BT, 256>(Xs, W1, b1, C, H1);
             __syncthreads();
             {
                 f32x16 acc2[1][2];
                 zero_acc<1, 2>(acc2);
-                layer2_mfma<1>(H1, P2v, wave, lane, acc2);
-                layer2_store<1>(acc2, b2, wave, lane, H2);
+#if !(PN_ABLATE & 32)
+                layer2_mfma<1, 2>(H1, P2v, wave, lane, acc2);
+#endif
+                layer2_store<1, 2>(acc2, b2, wave, lane, H2);
             }
             __syncthreads();
             // ---- row-owner pass: wave w owns rows w*8..w*8+7; h2 -> dz2 in place -------------
+#if !(PN_ABLATE & 8)
             {
                 constexpr int RPW = BT / 4;
                 const int p0 = tile * BT + wave * RPW;
@@ -484,6 +529,7 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                     db2acc.x += dz.x; db2acc.y += dz.y; db2acc.z += dz.z; db2acc.w += dz.w;
                 }
             }
+#endif
             __syncthreads();
             // ---- dW2 += dz2^T * h1 : K = 32 points (lanes<32: point s, lanes>=32: point 16+s) ----
             {
@@ -500,10 +546,10 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
     }
                 DW2_LOAD(a0p, a1p, bvp, 0)
 #pragma unroll 1
-                for (int s = 0; s < BT / 2; s += 2) {
+                for (int s = 0; s < ((PN_ABLATE & 32) ? 0 : BT / 2); s += 2) {
                     DW2_LOAD(a0q, a1q, bvq, s + 1)
                     DW2_MMA(a0p, a1p, bvp)
-                    if (s + 2 < BT / 2) { DW2_LOAD(a0p, a1p, bvp, s + 2) }
+                    DW2_LOAD(a0p, a1p, bvp, s + 2)      // unconditional (last trip reads rows past the tile: discarded)
                     DW2_MMA(a0q, a1q, bvq)
                 }
 #undef DW2_LOAD
@@ -513,7 +559,9 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
             {
                 f32x16 accH[1][1];
                 zero_acc<1, 1>(accH);
+#if !(PN_ABLATE & 32)
                 mfma_stream<1, 1, 32>(H2 + li * PN_LD2 + lh * 128, PN_LD2, P2Tv + (size_t)wave * 32 * 64 + lane, accH);
+#endif
                 // dz1 = dh1 .* (1 - h1^2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
