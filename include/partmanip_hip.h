@@ -121,13 +121,15 @@ int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, int C, int s
  * (ppo.py:337-338) is realised by handing &scal_out[2] to pm_clip_adam_step_f32 as its
  * skip flag, so no host sync sits between loss and optimiser.  adv_moments: NULL, or
  * {sum,sumsq} of the mini-batch advantages (count adv_count) for ppo.py:329's
- * mini_adv_norm (data-parallel callers all-reduce them first).  Single work-group kernel. */
+ * mini_adv_norm (data-parallel callers all-reduce them first).  Two launches: <= 64 work-groups
+ * of 256 rows, then a one-wave fixed-order reduction of their partials (deterministic). */
 int pm_ppo_actor_loss_fwd_bwd_f32(const float* mu, long ldmu, const float* log_std, const float* actions,
                                   long lda, const float* old_logp, const float* adv, const float* old_mu,
                                   long ldom, const float* old_sigma, long ldos, int B, int A, float max_action,
                                   int act_tanh, float eps_clip, float desired_kl, const double* adv_moments,
                                   double adv_count, float* scal_out, float* dmu, long lddmu, float* dlog_std,
-                                  void* stream);
+                                  void* workspace, size_t workspace_bytes, void* stream);
+size_t pm_ppo_actor_loss_workspace_bytes(int B);
 /* forward-only: log-prob/entropy rows, actor_critic.py:71-82 (used by rollout + tests). */
 int pm_gaussian_logp_f32(const float* mu, long ldmu, const float* log_std, const float* actions, long lda,
                          int B, int A, float max_action, int act_tanh, float* logp, float* entropy,

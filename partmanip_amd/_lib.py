@@ -30,7 +30,8 @@ SIGNATURES = {
     "pm_pointnet_enc_fwd_f32": (I, [P, L, I, I, I, I, P, P, P, P, P, I, P, L, P, P]),
     "pm_pointnet_enc_bwd_workspace_bytes": (Z, [I, I, I]),
     "pm_pointnet_enc_bwd_f32": (I, [P, L, I, I, I, I, P, P, P, P, P, I, P, L, P, P, P, P, P, P, P, P, Z, P]),
-    "pm_ppo_actor_loss_fwd_bwd_f32": (I, [P, L, P, P, L, P, P, P, L, P, L, I, I, F, I, F, F, P, D, P, P, L, P, P]),
+    "pm_ppo_actor_loss_fwd_bwd_f32": (I, [P, L, P, P, L, P, P, P, L, P, L, I, I, F, I, F, F, P, D, P, P, L, P, P, Z, P]),
+    "pm_ppo_actor_loss_workspace_bytes": (Z, [I]),
     "pm_gaussian_logp_f32": (I, [P, L, P, P, L, I, I, F, I, P, P, P]),
     "pm_value_loss_fwd_bwd_f32": (I, [P, P, P, I, I, F, P, F, P, P, P]),
     "pm_mse_tanh_loss_fwd_bwd_f32": (I, [P, L, P, L, I, I, F, I, F, P, P, L, P]),

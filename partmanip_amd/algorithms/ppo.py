@@ -93,6 +93,7 @@ class ppo:
         self._acc = torch.zeros(8, device=dev)       # device-side running sums of `update`
         self._mom = torch.zeros(2, dtype=torch.float64, device=dev)
         self._ws = ops.Workspace(dev)
+        self._ws_loss = ops.Workspace(dev)
         self._stage = {}
 
         self.logger = logger
@@ -195,7 +196,7 @@ class ppo:
                 dmu = torch.empty(B, A, device=mu.device)
                 ops.ppo_actor_loss(mu, ac.log_std.data, mb['actions'], mb['old_logp'], mb['adv'], mb['old_mu'],
                                    mb['old_sigma'], ac.max_action, act_tanh, self.epsilon_clip, self.desired_kl,
-                                   mom, cnt, scal_a, dmu, f['grad_log_std'])
+                                   mom, cnt, scal_a, dmu, f['grad_log_std'], self._ws_loss)
                 ac.actor.hip_backward(dmu)
                 if sync:                                      # ONE all-reduce: grads + loss/kl in the tail
                     sync.mean_(f['grad_actor'])

@@ -31,6 +31,8 @@ struct GemmArgs {
     int kchunk;                   // split-K: reduction range per blockIdx.z
     long slab;                    // split-K: C offset per blockIdx.z (elements)
     int vecA, vecB;               // 16 B global loads allowed
+    float* dbias;                 // EPI_PLAIN (weight gradient): column sums of the k-major A operand
+                                  // (= bias gradient), written by the blockIdx.x == 0 tiles per z-slab
 };
 
 // ---- global -> register tile loads ------------------------------------------------------
@@ -122,6 +124,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool do_bias = (EPI == EPI_PLAIN) && g.dbias != nullptr && blockIdx.x == 0;
+    float bsum = 0.f;
 
     float ra[8], rb[8];
     if (kbeg < kend) {
@@ -135,6 +139,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         if (A_KMAJOR) store_kmajor(As, g.vecA, ra); else store_kcontig(As, g.vecA, ra);
         if (B_KMAJOR) store_kmajor(Bs, g.vecB, rb); else store_kcontig(Bs, g.vecB, rb);
         __syncthreads();
+        if (EPI == EPI_PLAIN && A_KMAJOR && do_bias && tid < GB_M) {   // db += column sums of this dY tile
+#pragma unroll 8
+            for (int k = 0; k < GB_K; ++k) bsum += As[k * LDR + tid];
+        }
         if (k0 + GB_K < kend) {                // prefetch next tile while this one is multiplied
             if (A_KMAJOR) load_kmajor(g.A, g.lda, m0, g.M, k0 + GB_K, kend, g.vecA, ra);
             else load_kcontig(g.A, g.lda, m0, g.M, k0 + GB_K, kend, g.vecA, ra);
@@ -166,6 +174,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
     }
 
+    if (EPI == EPI_PLAIN && A_KMAJOR && do_bias && tid < GB_M && m0 + tid < g.M)
+        g.dbias[(long)blockIdx.z * g.M + m0 + tid] = bsum;
     // epilogue: acc[r] is C[row = wm + (r&3) + 8*(r>>2) + 4*lh][col = wn + li]
     float* C = g.C + (long)blockIdx.z * g.slab;
     const int col = n0 + wn + li;
@@ -238,29 +248,26 @@ static inline int bww_splits(int M, int N, int K) {
 
 extern "C" size_t pm_linear_bwd_weight_workspace_bytes(int M, int N, int K) {
     const int s = bww_splits(M, N, K);
-    return s > 1 ? (size_t)s * N * K * sizeof(float) : 16;
+    return s > 1 ? (size_t)s * ((size_t)N * K + N) * sizeof(float) : 16;     // dW slabs + db slabs
 }
 
+// dW = sum_z slab_z (fixed order); the trailing N "elements" reduce the bias-gradient slabs.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int S, long slab,
-                                                           float* __restrict__ dW, long lddw, int N, int K) {
+                                                           float* __restrict__ dW, long lddw, int N, int K,
+                                                           const float* __restrict__ bslabs, float* __restrict__ db) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long)N * K) return;
-    float s = 0.f;
-    for (int z = 0; z < S; ++z) s += slabs[z * slab + e];
-    dW[(e / K) * lddw + (e % K)] = s;
-}
-
-// db[c] = sum_m dY[m][c]; one work-group per 64 columns, 4 row groups, fixed order.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dY, long ld, int M, int N,
-                                                      float* __restrict__ db) {
-    __shared__ float part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-    float s = 0.f;
-    if (c < N)
-        for (int m = rg; m < M; m += 4) s += dY[(long)m * ld + c];
-    part[rg][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (rg == 0 && c < N) db[c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    const long nk = (long)N * K;
+    if (e < nk) {
+        float s = 0.f;
+#pragma unroll 4
+        for (int z = 0; z < S; ++z) s += slabs[z * slab + e];
+        dW[(e / K) * lddw + (e % K)] = s;
+    } else if (db && e < nk + N) {
+        const int n = (int)(e - nk);
+        float s = 0.f;
+        for (int z = 0; z < S; ++z) s += bslabs[(long)z * N + n];
+        db[n] = s;
+    }
 }
 
 extern "C" int pm_linear_bwd_weight_f32(const float* dY, long lddy, const float* X, long ldx, float* dW,
@@ -268,29 +275,30 @@ extern "C" int pm_linear_bwd_weight_f32(const float* dY, long lddy, const float*
                                         size_t workspace_bytes, void* stream) {
     PM_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K);
     const int S = bww_splits(M, N, K);
-    if (S > 1 && (!workspace || workspace_bytes < (size_t)S * N * K * sizeof(float))) return PM_EWORKSPACE;
+    if (S > 1 && (!workspace || workspace_bytes < pm_linear_bwd_weight_workspace_bytes(M, N, K))) return PM_EWORKSPACE;
     GemmArgs g{};
     // C[N x K] = dY^T[N x M] * X[M x K]: reduction over M; both operands k-major
     g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx;
     g.M = N; g.N = K; g.K = M; g.act = 0;
     g.vecA = (N % 4 == 0) && (lddy % 4 == 0) && aligned16(dY);
     g.vecB = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
+    float* bslabs = (float*)workspace + (size_t)S * N * K;
     if (S > 1) {
         int kchunk = (M + S - 1) / S;
         kchunk = ((kchunk + GB_K - 1) / GB_K) * GB_K;
         g.C = (float*)workspace; g.ldc = K; g.kchunk = kchunk; g.slab = (long)N * K;
+        g.dbias = db ? bslabs : nullptr;
     } else {
         g.C = dW; g.ldc = lddw; g.kchunk = M; g.slab = 0;
+        g.dbias = db;                                  // single slab: the column sums ARE the bias gradient
     }
     dim3 grid((K + GB_N - 1) / GB_N, (N + GB_M - 1) / GB_M, S);
     hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI_PLAIN>), grid, dim3(256), 0, pm_stream(stream), g);
     if (S > 1) {
-        const long ne = (long)N * K;
+        const long ne = (long)N * K + (db ? N : 0);
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, pm_stream(stream),
-                           (const float*)workspace, S, (long)N * K, dW, lddw, N, K);
+                           (const float*)workspace, S, (long)N * K, dW, lddw, N, K, (const float*)bslabs, db);
     }
-    if (db)
-        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, pm_stream(stream), dY, lddy, M, N, db);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }

@@ -17,22 +17,31 @@ __device__ __forceinline__ float deactivate(float a, float max_action, int act_t
 }
 
 // ---------------------------------------------------------------------------------- K8
-__global__ __launch_bounds__(LOSS_THREADS) void ppo_actor_loss_kernel(
+// Stage 1: up to 64 work-groups of 256 rows each write dmu and a partial {loss, kl, dlog_std[A]};
+// stage 2 (one wave) sums the partials in fixed order.  (A single 1024-thread work-group took
+// 63 us for 2048 rows -- 12 % of a state-PPO optimiser step; the row math is atanh/exp/log heavy.)
+#define AL_THREADS 256
+#define AL_MAXG 64
+struct ActorLossPart {
+    double loss, kl;
+    float dls[MAX_A];
+};
+
+__global__ __launch_bounds__(AL_THREADS) void ppo_actor_loss_part_kernel(
     const float* __restrict__ mu, long ldmu, const float* __restrict__ log_std, const float* __restrict__ actions,
     long lda, const float* __restrict__ old_logp, const float* __restrict__ adv, const float* __restrict__ old_mu,
     long ldom, const float* __restrict__ old_sigma, long ldos, int B, int A, float max_action, int act_tanh,
-    float eps_clip, float desired_kl, const double* __restrict__ adv_moments, double adv_count,
-    float* __restrict__ scal_out, float* __restrict__ dmu, long lddmu, float* __restrict__ dlog_std) {
-    __shared__ float s_ls[MAX_A], s_s[MAX_A], s_en2[MAX_A];
-    __shared__ double red[LOSS_WAVES];
-    __shared__ float red_a[LOSS_WAVES][MAX_A];
+    float eps_clip, const double* __restrict__ adv_moments, double adv_count, float* __restrict__ dmu, long lddmu,
+    ActorLossPart* __restrict__ parts) {
+    __shared__ float s_ls[MAX_A], s_s[MAX_A];
+    __shared__ double red[AL_THREADS / 64];
+    __shared__ float red_a[AL_THREADS / 64][MAX_A];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid < A) {
         const float ls = log_std[tid];
         const float e = expf(ls);
         s_ls[tid] = ls;
-        s_s[tid] = e * e;                 // effective std: scale_tril = diag(exp(ls)*exp(ls)), actor_critic.py:74
-        s_en2[tid] = e * e;               // square(sigma.exp()) of the KL term, ppo.py:333
+        s_s[tid] = e * e;                 // effective std (actor_critic.py:74) == square(sigma.exp()) of ppo.py:333
     }
     for (int a = lane; a < A; a += 64) red_a[w][a] = 0.f;
     __syncthreads();
@@ -50,7 +59,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void ppo_actor_loss_kernel(
     }
     const float invB = 1.0f / (float)B;
     double loss_acc = 0.0, kl_acc = 0.0;
-    for (int base = 0; base < B; base += LOSS_THREADS) {     // uniform trip count: wave shuffles inside
+    for (int base = blockIdx.x * AL_THREADS; base < B; base += gridDim.x * AL_THREADS) {   // uniform trip count per block
         const int i = base + tid;
         const bool on = i < B;
         float M = 0.f, kl = 0.f;
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void ppo_actor_loss_kernel(
                 M += z * z;
                 const float eo = expf(old_sigma[i * ldos + a]);
                 const float dm = old_mu[i * ldom + a] - m;
-                kl += s_ls[a] - old_sigma[i * ldos + a] + (eo * eo + dm * dm) / (2.0f * s_en2[a]) - 0.5f;
+                kl += s_ls[a] - old_sigma[i * ldos + a] + (eo * eo + dm * dm) / (2.0f * s_s[a]) - 0.5f;
             }
         }
         float g = 0.f;
@@ -91,22 +100,56 @@ __global__ __launch_bounds__(LOSS_THREADS) void ppo_actor_loss_kernel(
             if (lane == 0) red_a[w][a] += c;
         }
     }
-    const double loss_sum = block_sum<double, LOSS_THREADS>(loss_acc, red);
-    const double kl_sum = block_sum<double, LOSS_THREADS>(kl_acc, red);
+    const double loss_sum = block_sum<double, AL_THREADS>(loss_acc, red);
+    const double kl_sum = block_sum<double, AL_THREADS>(kl_acc, red);
     __syncthreads();
+    ActorLossPart* part = parts + blockIdx.x;
     if (tid < A) {
         float t = 0.f;
-        for (int k = 0; k < LOSS_WAVES; ++k) t += red_a[k][tid];
+        for (int k = 0; k < AL_THREADS / 64; ++k) t += red_a[k][tid];
+        part->dls[tid] = t;
+    }
+    if (tid == 0) {
+        part->loss = loss_sum;
+        part->kl = kl_sum;
+    }
+}
+
+__global__ __launch_bounds__(64) void ppo_actor_loss_final_kernel(const ActorLossPart* __restrict__ parts, int G, int B,
+                                                                   int A, const float* __restrict__ log_std,
+                                                                   float desired_kl, float* __restrict__ scal_out,
+                                                                   float* __restrict__ dlog_std) {
+    const int tid = threadIdx.x;
+    if (tid < A) {
+        float t = 0.f;
+        for (int g = 0; g < G; ++g) t += parts[g].dls[tid];
         dlog_std[tid] = t;
     }
     if (tid == 0) {
-        const float klm = (float)(kl_sum / (double)B);
-        scal_out[0] = (float)(loss_sum / (double)B);
+        double ls = 0.0, ks = 0.0;
+        for (int g = 0; g < G; ++g) {
+            ls += parts[g].loss;
+            ks += parts[g].kl;
+        }
+        float sum_logs = 0.f;
+        for (int a = 0; a < A; ++a) {
+            const float e = expf(log_std[a]);
+            sum_logs += logf(e * e);
+        }
+        const float klm = (float)(ks / (double)B);
+        scal_out[0] = (float)(ls / (double)B);
         scal_out[1] = klm;
         scal_out[2] = (klm > desired_kl) ? 1.0f : 0.0f;
         scal_out[3] = 0.5f * (float)A * (1.0f + 1.8378770664093453f) + sum_logs;   // entropy (same every row)
     }
 }
+
+static inline int actor_loss_blocks(int B) {
+    int g = (B + AL_THREADS - 1) / AL_THREADS;
+    return g < 1 ? 1 : (g > AL_MAXG ? AL_MAXG : g);
+}
+
+extern "C" size_t pm_ppo_actor_loss_workspace_bytes(int B) { return (size_t)actor_loss_blocks(B) * sizeof(ActorLossPart); }
 
 extern "C" int pm_ppo_actor_loss_fwd_bwd_f32(const float* mu, long ldmu, const float* log_std,
                                              const float* actions, long lda, const float* old_logp,
@@ -114,13 +157,19 @@ extern "C" int pm_ppo_actor_loss_fwd_bwd_f32(const float* mu, long ldmu, const f
                                              const float* old_sigma, long ldos, int B, int A, float max_action,
                                              int act_tanh, float eps_clip, float desired_kl,
                                              const double* adv_moments, double adv_count, float* scal_out,
-                                             float* dmu, long lddmu, float* dlog_std, void* stream) {
+                                             float* dmu, long lddmu, float* dlog_std, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
     PM_REQUIRE(mu && log_std && actions && old_logp && adv && old_mu && old_sigma && scal_out && dmu && dlog_std);
     PM_REQUIRE(B > 0 && A > 0 && A <= MAX_A && max_action > 0.f);
     PM_REQUIRE(!adv_moments || adv_count > 1.0);
-    hipLaunchKernelGGL(ppo_actor_loss_kernel, dim3(1), dim3(LOSS_THREADS), 0, pm_stream(stream), mu, ldmu, log_std,
-                       actions, lda, old_logp, adv, old_mu, ldom, old_sigma, ldos, B, A, max_action, act_tanh,
-                       eps_clip, desired_kl, adv_moments, adv_count, scal_out, dmu, lddmu, dlog_std);
+    const int G = actor_loss_blocks(B);
+    if (!workspace || workspace_bytes < (size_t)G * sizeof(ActorLossPart) || ((uintptr_t)workspace & 7)) return PM_EWORKSPACE;
+    ActorLossPart* parts = (ActorLossPart*)workspace;
+    hipLaunchKernelGGL(ppo_actor_loss_part_kernel, dim3(G), dim3(AL_THREADS), 0, pm_stream(stream), mu, ldmu, log_std,
+                       actions, lda, old_logp, adv, old_mu, ldom, old_sigma, ldos, B, A, max_action, act_tanh, eps_clip,
+                       adv_moments, adv_count, dmu, lddmu, parts);
+    hipLaunchKernelGGL(ppo_actor_loss_final_kernel, dim3(1), dim3(64), 0, pm_stream(stream), parts, G, B, A, log_std,
+                       desired_kl, scal_out, dlog_std);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }

@@ -205,15 +205,16 @@ def pointnet_enc_bwd(x, P, Cc, sub_mean, w1, b1, b2, w3, packed, max_mean, dfeat
 
 # ----------------------------------------------------------------------------- K8-K11
 def ppo_actor_loss(mu, log_std, actions, old_logp, adv, old_mu, old_sigma, max_action, act_tanh, eps_clip, desired_kl,
-                   adv_moments, adv_count, scal, dmu, dlog_std):
+                   adv_moments, adv_count, scal, dmu, dlog_std, ws):
     _req(mu, log_std, actions, old_logp, adv, old_mu, old_sigma, scal, dmu, dlog_std)
     B, A = mu.shape
+    w = ws.get(lib.pm_ppo_actor_loss_workspace_bytes(B))
     check(lib.pm_ppo_actor_loss_fwd_bwd_f32(_ptr(mu), _rows(mu, "mu"), _ptr(log_std), _ptr(actions),
                                             _rows(actions, "actions"), _ptr(old_logp), _ptr(adv), _ptr(old_mu),
                                             _rows(old_mu, "old_mu"), _ptr(old_sigma), _rows(old_sigma, "old_sigma"),
                                             B, A, float(max_action), int(act_tanh), float(eps_clip), float(desired_kl),
                                             _ptr(adv_moments), float(adv_count), _ptr(scal), _ptr(dmu),
-                                            _rows(dmu, "dmu"), _ptr(dlog_std), _stream()),
+                                            _rows(dmu, "dmu"), _ptr(dlog_std), _ptr(w), w.numel(), _stream()),
           "pm_ppo_actor_loss_fwd_bwd_f32")
 
 

@@ -127,7 +127,7 @@ def test_linear_strided_views():
 
 
 # ------------------------------------------------------------------------------- losses
-@pytest.mark.parametrize("B,A,mini_norm", [(2048, 10, False), (2048, 10, True), (37, 7, True), (1500, 3, False)])
+@pytest.mark.parametrize("B,A,mini_norm", [(2048, 10, False), (2048, 10, True), (37, 7, True), (1500, 3, False), (40000, 10, False)])
 def test_ppo_actor_loss(B, A, mini_norm):
     o = ops()
     g = torch.Generator().manual_seed(B + A)
@@ -152,7 +152,7 @@ def test_ppo_actor_loss(B, A, mini_norm):
         o.moments(d(adv).view(-1), mom, o.Workspace(torch.device(DEV)))
         cnt = B
     o.ppo_actor_loss(d(mu), d(log_std), d(actions), d(old_logp), d(adv), d(old_mu), d(old_sigma), 1.0, True, 0.2, 0.1,
-                     mom, cnt, scal, dmu, dls)
+                     mom, cnt, scal, dmu, dls, o.Workspace(torch.device(DEV)))
     s = scal.cpu()
     np.testing.assert_allclose(float(s[0]), float(loss_ref.detach()), rtol=2e-5, atol=3e-5)   # mean of +-O(1) terms
     np.testing.assert_allclose(float(s[1]), float(kl_ref), rtol=2e-5, atol=1e-7)
