@@ -98,3 +98,31 @@ def test_state_dict_keys_match_reference_layout():
     assert float(ac.actor.model[6].weight.norm(dim=1).max()) < 0.011
     np.testing.assert_allclose(float(ac.critic.model[6].weight.norm()), 1.0, rtol=1e-4)
     np.testing.assert_allclose(ac.log_std.detach().numpy(), np.log(0.5), rtol=1e-6)
+
+
+def test_process_cfgs_merges_and_overrides(tmp_path):
+    import os
+    from partmanip_amd.config import process_cfgs, num_actions
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = process_cfgs(["--algocfg", "ppo_pointnet", "--taskcfg", "open_drawer", "--algo.lr", "1e-4",
+                        "--algo.tricks.use_grad_clip", "--algo.model.network.max_mean", "--exp_name", "t"], root=root)
+    assert cfg["algo_name"] == "ppo" and cfg["task_name"] == "open_drawer"
+    assert cfg["algo"]["lr"] == 1e-4
+    assert cfg["algo"]["tricks"]["use_grad_clip"] is False          # bool leaves are toggles (utils/config.py:56-60)
+    assert cfg["algo"]["model"]["network"]["max_mean"] is False
+    assert cfg["algo"]["model"]["clipAction"] == 1.0 and cfg["algo"]["succ_value"] is None
+    assert cfg["algo"]["device"] == "cuda:0" and cfg["task"]["num_envs"] == 4096
+    assert cfg["task"]["obs_mode"]["depth_pc"] == 3072 and num_actions(cfg["task"]) == 10
+    cfg = process_cfgs(["--taskcfg", "grasp_cube"], root=root)
+    assert cfg["algo"]["succ_value"] == 500 and num_actions(cfg["task"]) == 7
+
+
+def test_feeder_env_duck_type_cpu():
+    from partmanip_amd.feeder import FeederEnv
+    env = FeederEnv(6, {"normal_state": 53, "depth_pc": 3072, "proprio_state": 0}, 10, "cpu", seed=3)
+    obs = env.reset()
+    assert obs["normal_state"].shape == (6, 53) and obs["depth_pc"].shape == (6, 3072)
+    o2, rew, done, extras = env.step(torch.zeros(6, 10))
+    assert rew.shape == (6,) and done.dtype == torch.bool and extras["succ_rate"].shape == (1,)
+    assert env.reset_succ.shape == (6,) and (env.reset_succ <= done).all()
+    assert float(o2["depth_pc"].abs().max()) <= 1.5
