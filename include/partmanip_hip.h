@@ -191,6 +191,21 @@ int pm_group_points_f32(const float* feat, const int32_t* idx, int B, int P, int
 int pm_group_points_bwd_f32(const float* dout, const int32_t* idx, int B, int P, int C, int S, int nsample,
                             float* dfeat, void* stream);
 
+/* ------------------------------------------------------------------ K15 PointNet++ set-abstraction glue
+ * (absent from the reference; north-star mandated; parity unpinned, own oracle).
+ * group_concat: out[b,s,j,:] = [xyz[b,idx]-centers[b,s] (3) | feat[b,idx,:] (Cf) | zero pad to ldo]
+ * (the rows the shared per-point MLP consumes); its backward scatter-adds the feature columns
+ * (dfeat zero-filled by the caller; fp32 atomics).  maxpool_rows: max over the nsample axis of
+ * (G, nsample, C) with the lowest arg-max index; its backward writes every element of dx. */
+int pm_group_concat_f32(const float* xyz, const float* feat, const float* centers, const int32_t* idx, int B, int P,
+                        int Cf, int S, int nsample, int ldo, float* out, void* stream);
+int pm_group_concat_bwd_f32(const float* dout, const int32_t* idx, int B, int P, int Cf, int S, int nsample, int ldo,
+                            float* dfeat, void* stream);
+int pm_maxpool_rows_f32(const float* x, long G, int nsample, int C, float* out, long ldo, int32_t* arg, void* stream);
+int pm_maxpool_rows_bwd_f32(const float* dout, long lddo, const int32_t* arg, long G, int nsample, int C,
+                            const float* y_tanh /* NULL, or the pooled tanh outputs: dx *= 1-y^2 */, float* dx,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,6 +159,8 @@ def net_forward(p, prefix, net_cfg, x, proprio_shape=0):
         return mlp_forward(p, prefix, net_cfg, x)
     if net_cfg["name"] == "PointNet":
         return pointnet_forward(p, prefix, net_cfg, x, proprio_shape)
+    if net_cfg["name"] == "PointNet2":
+        return pointnet2_forward(p, prefix, net_cfg, x, proprio_shape)
     raise ValueError(net_cfg["name"])
 
 
@@ -484,3 +486,77 @@ def group_points(feat, idx):
     feat = np.asarray(feat)
     B = feat.shape[0]
     return np.stack([feat[b][idx[b]] for b in range(B)], axis=0)
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def pointnet2_forward(p, prefix, net_cfg, x, proprio_shape=0, pool_args=None, return_aux=False):
+    """PointNet++ single-scale-grouping encoder -- PARITY UNPINNED (absent from the reference; this
+    restates the published structure the way partmanip_amd.algo_utils.network.PointNet2 documents it:
+    per level FPS -> ball query -> rows [xyz-centre | feat | 0-pad to a multiple of 4] -> shared MLP with
+    the activation after every layer -> max over the group; a final group-all level on absolute
+    coordinates; the PointNet head).  `pool_args`: optional list of (G, C) index tensors pinning each
+    max-pool's arg-max (test hook, see pointnet_forward)."""
+    P = int(net_cfg.get("point_num", 1024))
+    B = x.shape[0]
+    C = x.shape[1] // P
+    act = net_cfg["activation"]
+    npoints = list(net_cfg.get("npoints", [256, 64]))
+    radii = list(net_cfg.get("radii", [0.2, 0.4]))
+    nsamples = list(net_cfg.get("nsamples", [32, 32]))
+    n_levels = len(npoints) + 1
+    pts = x[:, :P * C].reshape(B, P, C)
+    xyz, feat = pts[..., :3], (pts[..., 3:] if C > 3 else None)
+    aux, used_args = [], []
+
+    def shared_mlp(l, rows):
+        i = 0
+        while f"{prefix}.sa.{l}.{2 * i}.weight" in p:
+            rows = _act(act, _lin(p, f"{prefix}.sa.{l}.{2 * i}", rows))
+            i += 1
+        return rows
+
+    def pool(h, G, ns, k):
+        h = h.reshape(G, ns, -1)
+        if pool_args is not None:
+            idx = pool_args[k].long()
+            out = torch.gather(h, 1, idx.unsqueeze(1)).squeeze(1)
+        else:
+            out, idx = h.max(dim=1)
+        used_args.append(idx)
+        return out
+
+    for l in range(n_levels - 1):
+        S, ns = npoints[l], nsamples[l]
+        idx_c = torch.from_numpy(fps(xyz.detach().numpy(), S))                       # (B,S)
+        centers = torch.gather(xyz, 1, idx_c.unsqueeze(-1).expand(B, S, 3))
+        idx_g = torch.from_numpy(ball_query(xyz.detach().numpy(), centers.detach().numpy(), radii[l], ns)).long()
+        flat = idx_g.reshape(B, S * ns)
+        g_xyz = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(B, S * ns, 3)).reshape(B, S, ns, 3) - centers.unsqueeze(2)
+        cols = [g_xyz]
+        cf = 0
+        if feat is not None:
+            cf = feat.shape[2]
+            cols.append(torch.gather(feat, 1, flat.unsqueeze(-1).expand(B, S * ns, cf)).reshape(B, S, ns, cf))
+        pad = _pad4(3 + cf) - (3 + cf)
+        if pad:
+            cols.append(torch.zeros(B, S, ns, pad))
+        rows = torch.cat(cols, dim=-1).reshape(B * S * ns, -1)
+        pooled = pool(shared_mlp(l, rows), B * S, ns, l)
+        aux.append((idx_c, idx_g))
+        xyz, feat = centers, pooled.reshape(B, S, -1)
+    S, cf = xyz.shape[1], feat.shape[2]
+    cols = [xyz, feat]
+    pad = _pad4(3 + cf) - (3 + cf)
+    if pad:
+        cols.append(torch.zeros(B, S, pad))
+    rows = torch.cat(cols, dim=-1).reshape(B * S, -1)
+    f = pool(shared_mlp(n_levels - 1, rows), B, S, n_levels - 1)
+    if proprio_shape != 0:
+        f = torch.cat((f, x[:, -proprio_shape:]), dim=-1)
+    f = _act(act, _lin(p, f"{prefix}.final_mlp.0", f))
+    f = _act(act, _lin(p, f"{prefix}.final_mlp.2", f))
+    out = _lin(p, f"{prefix}.final_mlp.4", f)
+    return (out, aux, used_args) if return_aux else out

@@ -44,6 +44,10 @@ SIGNATURES = {
     "pm_ball_query_f32": (I, [P, P, I, I, I, F, I, P, P]),
     "pm_group_points_f32": (I, [P, P, I, I, I, I, I, P, P]),
     "pm_group_points_bwd_f32": (I, [P, P, I, I, I, I, I, P, P]),
+    "pm_group_concat_f32": (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
+    "pm_group_concat_bwd_f32": (I, [P, P, I, I, I, I, I, I, P, P]),
+    "pm_maxpool_rows_f32": (I, [P, L, I, I, P, L, P, P]),
+    "pm_maxpool_rows_bwd_f32": (I, [P, L, P, L, I, I, P, P, P]),
 }
 
 if not os.path.exists(LIB_PATH):

@@ -38,9 +38,11 @@ def _act_code(name):
 class _LinearChain:
     """Forward/backward of Linear-act-...-Linear over explicit buffers (K4/K5 kernels)."""
 
-    def __init__(self, linears, act_code):
+    def __init__(self, linears, act_code, final_act=False):
         self.linears = linears            # list[nn.Linear]
         self.act = act_code
+        self.final_act = final_act        # activation after the last Linear too (PointNet++ shared MLPs); the
+                                          # caller then folds act' of the chain OUTPUT into the dy it passes back
         self.h = []                        # saved activation outputs of the hidden layers
         self.grads = None                  # list[(dW view, db view)] set by ActorCritic.flatten()
 
@@ -52,7 +54,8 @@ class _LinearChain:
         for i, lin in enumerate(self.linears):
             last = i == n - 1
             y = out if (last and out is not None) else torch.empty(cur.shape[0], lin.out_features, device=cur.device)
-            ops.linear_fwd(cur, lin.weight.data, lin.bias.data, y, ops.ACT_NONE if last else self.act)
+            ops.linear_fwd(cur, lin.weight.data, lin.bias.data, y,
+                           self.act if (not last or self.final_act) else ops.ACT_NONE)
             if not last:
                 self.h.append(y)
             cur = y
@@ -194,6 +197,116 @@ class PointNet(_HipNet):
         ops.pointnet_enc_bwd(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
                              self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].weight.data, self._packed,
                              self.max_mean_concat, dfeat, argmax, g[0], g[1], g[2], g[3], g[4], g[5], ws)
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class PointNet2(_HipNet):
+    """PointNet++ (single-scale grouping) encoder as a backbone plug-in (`network.name: PointNet2`).
+
+    NOT in the reference snapshot (README.md:23,30 -- the paper's point-cloud backbone moved to an
+    unmounted branch); BASELINE.json's north_star mandates it, so this follows the published
+    PointNet++ SSG structure with the reference's conventions (no BatchNorm, `net_cfg['activation']`,
+    the PointNet head 128-32-out, proprio appended before the head):
+        SA level l: farthest-point-sample `npoints[l]` centres (K12) -> ball query `radii[l]`,
+        `nsamples[l]` (K13) -> rows [xyz - centre | features] (K15) -> shared per-point MLP
+        `mlps[l]` (Linear kernels, activation after every layer) -> max over the group (K15);
+        last entry of `mlps` = group-all level on absolute coordinates -> global max.
+    Inputs to each shared MLP are zero-padded to a multiple of 4 channels (16-B rows), so the first
+    Linear of a level has `pad4(3 + C_prev)` input features; the pad columns never receive data."""
+
+    def __init__(self, input_dim, output_dim, net_cfg, proprio_shape):
+        super().__init__()
+        self.point_num = int(net_cfg.get('point_num', 1024))
+        self.in_channels = input_dim // self.point_num
+        self.proprio_shape = proprio_shape
+        self.npoints = list(net_cfg.get('npoints', [256, 64]))
+        self.radii = list(net_cfg.get('radii', [0.2, 0.4]))
+        self.nsamples = list(net_cfg.get('nsamples', [32, 32]))
+        mlps = [list(m) for m in net_cfg.get('mlps', [[64, 64, 128], [128, 128, 256], [256, 512]])]
+        assert len(mlps) == len(self.npoints) + 1 == len(self.radii) + 1 == len(self.nsamples) + 1
+        act = net_cfg['activation']
+        code = _act_code(act)
+        cf = self.in_channels - 3
+        assert cf >= 0, "PointNet2 needs xyz as the first three channels"
+        self.sa = nn.ModuleList()
+        self.in_feats = []
+        chains = []
+        for dims in mlps:
+            cin = _pad4(3 + cf)
+            self.in_feats.append(cf)
+            layers, lins = [], []
+            for d in dims:
+                lin = nn.Linear(cin, d)
+                layers += [lin, get_activation(act)]
+                lins.append(lin)
+                cin = d
+            self.sa.append(nn.Sequential(*layers))
+            chains.append(_LinearChain(lins, code, final_act=True))
+            cf = dims[-1]
+        self.feat_dim = cf
+        self.final_mlp = nn.Sequential(
+            nn.Linear(cf + proprio_shape, 128), get_activation(act),
+            nn.Linear(128, 32), get_activation(act),
+            nn.Linear(32, output_dim),
+        )
+        object.__setattr__(self, "_chains", chains)
+        object.__setattr__(self, "_head", _LinearChain([self.final_mlp[0], self.final_mlp[2], self.final_mlp[4]], code))
+
+    def set_grad_views(self, views):
+        for l, ch in enumerate(self._chains):
+            ch.grads = [(views[f"sa.{l}.{2 * i}.weight"], views[f"sa.{l}.{2 * i}.bias"]) for i in range(len(ch.linears))]
+        self._head.grads = [(views[f"final_mlp.{i}.weight"], views[f"final_mlp.{i}.bias"]) for i in (0, 2, 4)]
+
+    def hip_forward(self, x, out=None):
+        B, P, C = x.shape[0], self.point_num, self.in_channels
+        ws = self._workspace(x.device)
+        pts = x[:, :P * C].reshape(B, P, C)
+        xyz = pts[..., :3].contiguous()
+        feat = pts[..., 3:].contiguous() if C > 3 else None
+        saved = []
+        for l, S in enumerate(self.npoints):
+            idx_c = ops.fps(xyz, S, ws)
+            centers = ops.group_points(xyz, idx_c.view(B, S, 1)).view(B, S, 3)
+            idx_g = ops.ball_query(xyz, centers, self.radii[l], self.nsamples[l])
+            ldo = self.sa[l][0].in_features
+            rows = ops.group_concat(xyz, feat, centers, idx_g, ldo)
+            h = self._chains[l].forward(rows)
+            pooled = torch.empty(B * S, h.shape[1], device=x.device)
+            arg = ops.maxpool_rows(h, B * S, self.nsamples[l], pooled)
+            saved.append((idx_g, arg, h, xyz.shape[1], 0 if feat is None else feat.shape[2], ldo))
+            xyz, feat = centers, pooled.view(B, S, -1)
+        S = xyz.shape[1]                                   # group-all level: absolute coordinates
+        idx_all = torch.arange(S, dtype=torch.int32, device=x.device).repeat(B, 1).view(B, 1, S)
+        zeros = torch.zeros(B, 1, 3, device=x.device)
+        ldo = self.sa[-1][0].in_features
+        rows = ops.group_concat(xyz, feat, zeros, idx_all, ldo)
+        h = self._chains[-1].forward(rows)
+        fbuf = torch.empty(B, self.feat_dim + self.proprio_shape, device=x.device)
+        arg = ops.maxpool_rows(h, B, S, fbuf[:, :self.feat_dim])
+        saved.append((idx_all, arg, h, S, feat.shape[2], ldo))
+        if self.proprio_shape != 0:
+            fbuf[:, self.feat_dim:].copy_(x[:, -self.proprio_shape:])
+        object.__setattr__(self, "_saved", saved)
+        return self._head.forward(fbuf, out)
+
+    def hip_backward(self, dy):
+        saved, B = self._saved, dy.shape[0]
+        ws = self._workspace(dy.device)
+        dfbuf = torch.empty(B, self.feat_dim + self.proprio_shape, device=dy.device)
+        self._head.backward(dy, ws, dx_out=dfbuf)
+        dpooled = dfbuf[:, :self.feat_dim]                 # (G, C) view with row stride feat_dim + proprio
+        for l in reversed(range(len(saved))):
+            idx_g, arg, h, P_l, cf, ldo = saved[l]
+            ns = idx_g.shape[2]
+            dh = ops.maxpool_rows_bwd(dpooled, arg, ns, y_tanh=h)      # max-pool + tanh' of the chain output
+            need_dx = l > 0                                               # level-0 inputs are data, not activations
+            drows = torch.empty(h.shape[0], ldo, device=dy.device) if need_dx else None
+            self._chains[l].backward(dh, ws, dx_out=drows)
+            if need_dx:
+                dpooled = ops.group_concat_bwd(drows, idx_g, B, P_l, cf, ldo).view(B * P_l, cf)
 
 
 def _out_of_scope(name):

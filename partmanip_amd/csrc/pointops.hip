@@ -234,4 +234,132 @@ extern "C" int pm_group_points_bwd_f32(const float* dout, const int32_t* idx, in
     return PM_OK;
 }
 
+
+// ---------------------------------------------------------------------------------- K15 pieces
+// PointNet++ set-abstraction glue (absent from the reference, north-star mandated):
+//   group_concat: out[b,s,j,:] = [ xyz[b,idx]-center[b,s] (3) | feat[b,idx,:] (Cf) | 0-pad ]  rows of ldo floats
+//   maxpool_rows: out[g,c] = max_j x[g,j,c], arg = lowest j attaining it  (x: (G, ns, C))
+__global__ __launch_bounds__(256) void group_concat_kernel(const float* __restrict__ xyz, const float* __restrict__ feat,
+                                                            const float* __restrict__ centers,
+                                                            const int32_t* __restrict__ idx, int P, int Cf, int S,
+                                                            int ns, long n_rows, int ldo, float* __restrict__ out) {
+    const long total = n_rows * ldo;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / ldo;
+        const int c = (int)(e - row * ldo);
+        const long q = row / ns;                         // (b, s) flat
+        const int b = (int)(q / S);
+        const long src = (long)b * P + idx[row];
+        float v = 0.f;
+        if (c < 3) v = sub_rn(xyz[src * 3 + c], centers[q * 3 + c]);
+        else if (c < 3 + Cf) v = feat[src * Cf + (c - 3)];
+        out[e] = v;
+    }
+}
+
+extern "C" int pm_group_concat_f32(const float* xyz, const float* feat, const float* centers, const int32_t* idx,
+                                   int B, int P, int Cf, int S, int nsample, int ldo, float* out, void* stream) {
+    PM_REQUIRE(xyz && centers && idx && out && B > 0 && P > 0 && Cf >= 0 && S > 0 && nsample > 0 && ldo >= 3 + Cf);
+    PM_REQUIRE(Cf == 0 || feat);
+    const long n_rows = (long)B * S * nsample;
+    long nb = (n_rows * ldo + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(group_concat_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), xyz, feat, centers, idx,
+                       P, Cf, S, nsample, n_rows, ldo, out);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// d feat[b, idx, :] += d out[row, 3:3+Cf]   (dfeat zero-filled by the caller; fp32 atomics)
+__global__ __launch_bounds__(256) void group_concat_bwd_kernel(const float* __restrict__ dout,
+                                                                const int32_t* __restrict__ idx, int P, int Cf, int S,
+                                                                int ns, long n_rows, int ldo, float* __restrict__ dfeat) {
+    const long total = n_rows * Cf;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / Cf;
+        const int c = (int)(e - row * Cf);
+        const int b = (int)(row / ((long)S * ns));
+        atomicAdd(&dfeat[((long)b * P + idx[row]) * Cf + c], dout[row * ldo + 3 + c]);
+    }
+}
+
+extern "C" int pm_group_concat_bwd_f32(const float* dout, const int32_t* idx, int B, int P, int Cf, int S, int nsample,
+                                       int ldo, float* dfeat, void* stream) {
+    PM_REQUIRE(dout && idx && dfeat && B > 0 && P > 0 && Cf > 0 && S > 0 && nsample > 0 && ldo >= 3 + Cf);
+    const long n_rows = (long)B * S * nsample;
+    long nb = (n_rows * Cf + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(group_concat_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), dout, idx, P, Cf, S,
+                       nsample, n_rows, ldo, dfeat);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+__global__ __launch_bounds__(256) void maxpool_rows_kernel(const float* __restrict__ x, long G, int ns, int C,
+                                                            float* __restrict__ out, long ldo, int32_t* __restrict__ arg) {
+    const long total = G * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long g = e / C;
+        const int c = (int)(e - g * C);
+        const float* p = x + g * ns * C + c;
+        float m = p[0];
+        int am = 0;
+        for (int j = 1; j < ns; ++j) {
+            const float v = p[(long)j * C];
+            if (v > m) {
+                m = v;
+                am = j;
+            }
+        }
+        out[g * ldo + c] = m;
+        arg[e] = am;
+    }
+}
+
+extern "C" int pm_maxpool_rows_f32(const float* x, long G, int nsample, int C, float* out, long ldo, int32_t* arg,
+                                   void* stream) {
+    PM_REQUIRE(x && out && arg && G > 0 && nsample > 0 && C > 0 && ldo >= C);
+    long nb = (G * C + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(maxpool_rows_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), x, G, nsample, C, out,
+                       ldo, arg);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// dx[g,j,c] = dout[g,c] * act'(y[g,j,c]) if j == arg[g,c] else 0  (writes every element of dx);
+// y_tanh (nullable) = the pooled tensor itself when it is a tanh output: act' = 1 - y^2.
+__global__ __launch_bounds__(256) void maxpool_rows_bwd_kernel(const float* __restrict__ dout, long lddo,
+                                                                const int32_t* __restrict__ arg, long G, int ns, int C,
+                                                                const float* __restrict__ y_tanh,
+                                                                float* __restrict__ dx) {
+    const long total = G * ns * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const long gj = e / C;
+        const int j = (int)(gj % ns);
+        const long g = gj / ns;
+        float v = 0.f;
+        if (arg[g * C + c] == j) {
+            v = dout[g * lddo + c];
+            if (y_tanh) {
+                const float y = y_tanh[e];
+                v *= (1.0f - y * y);
+            }
+        }
+        dx[e] = v;
+    }
+}
+
+extern "C" int pm_maxpool_rows_bwd_f32(const float* dout, long lddo, const int32_t* arg, long G, int nsample, int C,
+                                       const float* y_tanh, float* dx, void* stream) {
+    PM_REQUIRE(dout && arg && dx && G > 0 && nsample > 0 && C > 0 && lddo >= C);
+    long nb = (G * nsample * C + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(maxpool_rows_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), dout, lddo, arg, G,
+                       nsample, C, y_tanh, dx);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
 extern "C" int pm_version(void) { return 100; }

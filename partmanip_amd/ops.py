@@ -307,3 +307,46 @@ def group_points_bwd(dout, idx, P):
     check(lib.pm_group_points_bwd_f32(_ptr(dout), _ptr(idx), B, P, Cc, S, ns, _ptr(dfeat), _stream()),
           "pm_group_points_bwd_f32")
     return dfeat
+
+
+# ----------------------------------------------------------------------------- K15 (PointNet++ glue)
+def group_concat(xyz, feat, centers, idx, ldo):
+    """-> (B*S*ns, ldo) rows [xyz[idx]-center | feat[idx] | 0-pad]."""
+    _req(xyz, feat, centers, idx)
+    B, P, _ = xyz.shape
+    S, ns = idx.shape[1], idx.shape[2]
+    Cf = 0 if feat is None else feat.shape[2]
+    out = torch.empty(B * S * ns, ldo, dtype=torch.float32, device=xyz.device)
+    check(lib.pm_group_concat_f32(_ptr(xyz), _ptr(feat), _ptr(centers), _ptr(idx), B, P, Cf, S, ns, ldo, _ptr(out),
+                                  _stream()), "pm_group_concat_f32")
+    return out
+
+
+def group_concat_bwd(dout, idx, B, P, Cf, ldo):
+    _req(dout, idx)
+    S, ns = idx.shape[1], idx.shape[2]
+    dfeat = torch.zeros(B, P, Cf, dtype=torch.float32, device=dout.device)
+    check(lib.pm_group_concat_bwd_f32(_ptr(dout), _ptr(idx), B, P, Cf, S, ns, ldo, _ptr(dfeat), _stream()),
+          "pm_group_concat_bwd_f32")
+    return dfeat
+
+
+def maxpool_rows(x, G, ns, out):
+    """x (G*ns, C) -> out (G, C) view (any row stride), arg (G, C) int32."""
+    _req(x, out)
+    _f32c(x, "x")
+    Cc = x.shape[1]
+    arg = torch.empty(G, Cc, dtype=torch.int32, device=x.device)
+    check(lib.pm_maxpool_rows_f32(_ptr(x), G, ns, Cc, _ptr(out), _rows(out, "out"), _ptr(arg), _stream()),
+          "pm_maxpool_rows_f32")
+    return arg
+
+
+def maxpool_rows_bwd(dout, arg, ns, y_tanh=None):
+    """dx (G*ns, C); `y_tanh` = the pooled (G*ns, C) tanh outputs -> the activation derivative is fused in."""
+    _req(dout, arg, y_tanh)
+    G, Cc = arg.shape
+    dx = torch.empty(G * ns, Cc, dtype=torch.float32, device=dout.device)
+    check(lib.pm_maxpool_rows_bwd_f32(_ptr(dout), _rows(dout, "dout"), _ptr(arg), G, ns, Cc, _ptr(y_tanh), _ptr(dx),
+                                      _stream()), "pm_maxpool_rows_bwd_f32")
+    return dx
