@@ -18,14 +18,21 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # debugging aids for 1-GPU boxes: PARTMANIP_DIST_BACKEND=gloo lets several ranks share one device
+    # (PARTMANIP_SHARE_GPU=1 maps every rank to cuda:0); RCCL itself needs one GPU per rank.
+    backend = os.environ.get("PARTMANIP_DIST_BACKEND") or backend
+    if os.environ.get("PARTMANIP_SHARE_GPU") == "1":
+        local = 0
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)      # binds the communicator to this rank's GPU up front
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
