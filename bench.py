@@ -41,6 +41,60 @@ WORKLOADS = {
 }
 
 
+DAGGER = dict(name="dagger_pointnet_student_4096env_x_16buf_x_1024pt", N=4096, buf=16, O_s=3072, O_t=53, A=10)
+
+
+def run_dagger(args, device, rank, world):
+    """cfg 5 analogue: DAgger, N=4096, n_steps 1, buf_size 16, PointNet student on 1024-pt
+    clouds, frozen MLP teacher (O=53), random sampler, n_updates 2, n_minibatches 16 (-> 2048).
+    A step = one `dagger.update` over the full ring (65 536 rows); env-steps/s = N * n_steps / time."""
+    import tempfile
+    from partmanip_amd.algorithms import ppo, dagger
+    from partmanip_amd.feeder import FeederEnv, ScreenLogger
+    d = DAGGER
+    torch.manual_seed(1234)
+    tmp = tempfile.mkdtemp()
+    env = FeederEnv(d["N"], {"normal_state": d["O_t"], "depth_pc": d["O_s"], "proprio_state": 0}, d["A"], device,
+                    seed=1234 + rank)
+    tcfg = make_cfg(WORKLOADS["state"], device)
+    tcfg.update(num_envs=d["N"], n_steps=1, obs_mode="normal_state")
+    tea = ppo(env, tcfg, ScreenLogger(tmp, "tea", "n", quiet=True))
+    tea.save(1)
+    cfg = dict(num_envs=d["N"], obs_mode="depth_pc",
+               model=dict(action_std=0.1, action_activate="tanh", clipAction=1.0,
+                          network=dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False)),
+               max_iterations=10000, n_steps=1, n_updates=2, n_minibatches=16, device=device, buf_size=d["buf"],
+               reward_reset=False, add_proprio_obs=False, offline_data_pth=None, eval_round=1, eval_frequence=10 ** 9,
+               save_frequence=10 ** 9, test_only=False, save_pose=False, save_video=False, lr_schedule="fixed", lr=5e-5,
+               teacher=os.path.join(tea.save_ckpt_dir, "model_1.pth"), resume=None, pretrain=None, sampler="random")
+    run = dagger(env, cfg, ScreenLogger(tmp, "stu", "n", quiet=True))
+    for _ in range(d["buf"]):
+        obs = env.reset()
+        run.storage.add_transitions_dagger(obs["depth_pc"], obs["normal_state"])
+    run.log_dict = {}
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        run.update(1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.update(1)
+    fence()
+    dt = time.perf_counter() - t0
+    rows = d["N"] * d["buf"] * 2                        # samples through the student per update
+    return dict(metric="DAgger update throughput (cfg 5 analogue)", value=d["N"] * 1 * world / (dt / args.steps),
+                unit="env-steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                data="synthetic", config=dict(workload=d["name"], ring_rows=d["N"] * d["buf"], minibatch=2048,
+                                              student_samples_per_s=rows * world / (dt / args.steps),
+                                              dagger_loss=float(run.log_dict["Train/dagger_loss"])))
+
+
 def make_cfg(w, device):
     return dict(num_envs=w["N"], obs_mode="obs", succ_value=None,
                 model=dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=dict(w["net"])),
@@ -88,7 +142,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="vision", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="vision", choices=list(WORKLOADS) + ["dagger"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -99,6 +153,13 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
+    if args.workload == "dagger":
+        out = run_dagger(args, device, rank, world)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     w = WORKLOADS[args.workload]
     cfg = make_cfg(w, device)
 

@@ -2,21 +2,24 @@
 // exact fp32 products, fp32 accumulate -- bitwise an fmaf chain per output, so results are
 // fp32-roundoff-class against the reference's CPU sgemm).
 //
-// One work-group = 4 waves (2x2), tile 64x64, K-step 32.  Operand tiles are staged in LDS in
+// One work-group = 4 waves (2x2), tile 64x64, K-step 64 (one barrier pair per 32 MFMAs per wave).  Operand tiles are staged in LDS in
 // their natural global orientation:
-//   "k-contiguous" operand (row r, k fastest):   LDS [64][36]  -> fragments by ds_read_b128;
-//        row stride 36 floats: (36*r) mod 64 hits 16 distinct 4-bank slots -> conflict-free.
-//   "k-major" operand (k slowest, r fastest):    LDS [32][64]  -> fragments by ds_read_b32,
+//   "k-contiguous" operand (row r, k fastest):   LDS [64][68]  -> fragments by ds_read_b128;
+//        row stride 68 floats: (68*r) mod 64 hits 16 distinct 4-bank slots -> conflict-free.
+//   "k-major" operand (k slowest, r fastest):    LDS [64][64]  -> fragments by ds_read_b32,
 //        lanes read consecutive floats -> conflict-free.
-// Lane l of a wave feeds MFMA row/col (l&31); lanes 0-31 own k in [0,16) of the K-step and
-// lanes 32-63 own k in [16,32), so a k-contiguous lane reads its 16 k-values as 4 x 16 B.
+// Lane l of a wave feeds MFMA row/col (l&31); lanes 0-31 own k in [0,32) of the K-step and
+// lanes 32-63 own k in [32,64), so a k-contiguous lane reads its 32 k-values as 8 x 16 B.
 #include "common.h"
 
 #define GB_M 64
 #define GB_N 64
-#define GB_K 32
+#define GB_K 64
 #define LDK (GB_K + 4)   // k-contiguous LDS row stride (floats)
 #define LDR 64           // k-major LDS row stride (floats)
+#define NV4 (GB_M * GB_K / 4 / 256)   // float4 loads per thread per operand tile
+#define NSC (GB_M * GB_K / 256)       // scalar loads per thread per operand tile
+#define KH (GB_K / 2)                 // k-values per lane half
 
 enum { EPI_BIAS_ACT = 0, EPI_MUL_DACT = 1, EPI_PLAIN = 2 };
 
@@ -38,47 +41,47 @@ struct GemmArgs {
 // ---- global -> register tile loads ------------------------------------------------------
 // k-contiguous tile: 64 rows x 32 k.  vec: 2 float4 per thread; scalar: 8 floats per thread.
 __device__ __forceinline__ void load_kcontig(const float* __restrict__ P, long ld, int row0, int nrows, int k0,
-                                             int kend, int vec, float (&r)[8]) {
+                                             int kend, int vec, float (&r)[NSC]) {
     const int tid = threadIdx.x;
     if (vec) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 3, k = k0 + ((idx & 7) << 2);
+        for (int j = 0; j < NV4; ++j) {
+            const int idx = tid + 256 * j, row = idx / (GB_K / 4), k = k0 + ((idx % (GB_K / 4)) << 2);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row0 + row < nrows && k < kend) v = *(const float4*)(P + (long)(row0 + row) * ld + k);
             r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 5, k = k0 + (idx & 31);
+        for (int j = 0; j < NSC; ++j) {
+            const int idx = tid + 256 * j, row = idx / GB_K, k = k0 + (idx % GB_K);
             r[j] = (row0 + row < nrows && k < kend) ? P[(long)(row0 + row) * ld + k] : 0.f;
         }
     }
 }
-__device__ __forceinline__ void store_kcontig(float* __restrict__ S, int vec, const float (&r)[8]) {
+__device__ __forceinline__ void store_kcontig(float* __restrict__ S, int vec, const float (&r)[NSC]) {
     const int tid = threadIdx.x;
     if (vec) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 3, k = (idx & 7) << 2;
+        for (int j = 0; j < NV4; ++j) {
+            const int idx = tid + 256 * j, row = idx / (GB_K / 4), k = (idx % (GB_K / 4)) << 2;
             *(float4*)(S + row * LDK + k) = make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NSC; ++j) {
             const int idx = tid + 256 * j;
-            S[(idx >> 5) * LDK + (idx & 31)] = r[j];
+            S[(idx / GB_K) * LDK + (idx % GB_K)] = r[j];
         }
     }
 }
-// k-major tile: 32 k x 64 rows(cols).
+// k-major tile: GB_K k x 64 rows(cols).
 __device__ __forceinline__ void load_kmajor(const float* __restrict__ P, long ld, int row0, int nrows, int k0,
-                                            int kend, int vec, float (&r)[8]) {
+                                            int kend, int vec, float (&r)[NSC]) {
     const int tid = threadIdx.x;
     if (vec) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NV4; ++j) {
             const int idx = tid + 256 * j, k = k0 + (idx >> 4), row = row0 + ((idx & 15) << 2);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < kend && row < nrows) v = *(const float4*)(P + (long)k * ld + row);
@@ -86,24 +89,24 @@ __device__ __forceinline__ void load_kmajor(const float* __restrict__ P, long ld
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NSC; ++j) {
             const int idx = tid + 256 * j, k = k0 + (idx >> 6), row = row0 + (idx & 63);
             r[j] = (k < kend && row < nrows) ? P[(long)k * ld + row] : 0.f;
         }
     }
 }
-__device__ __forceinline__ void store_kmajor(float* __restrict__ S, int vec, const float (&r)[8]) {
+__device__ __forceinline__ void store_kmajor(float* __restrict__ S, int vec, const float (&r)[NSC]) {
     const int tid = threadIdx.x;
     if (vec) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NV4; ++j) {
             const int idx = tid + 256 * j;
             *(float4*)(S + (idx >> 4) * LDR + ((idx & 15) << 2)) =
                 make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NSC; ++j) {
             const int idx = tid + 256 * j;
             S[(idx >> 6) * LDR + (idx & 63)] = r[j];
         }
@@ -112,7 +115,7 @@ __device__ __forceinline__ void store_kmajor(float* __restrict__ S, int vec, con
 
 template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[GB_M * LDK];   // 64*36 >= 32*64
+    __shared__ __attribute__((aligned(16))) float As[GB_M * LDK];   // 64*68 >= 64*64
     __shared__ __attribute__((aligned(16))) float Bs[GB_N * LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const bool do_bias = (EPI == EPI_PLAIN) && g.dbias != nullptr && blockIdx.x == 0;
     float bsum = 0.f;
 
-    float ra[8], rb[8];
+    float ra[NSC], rb[NSC];
     if (kbeg < kend) {
         if (A_KMAJOR) load_kmajor(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
         else load_kcontig(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
@@ -149,29 +152,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             if (B_KMAJOR) load_kmajor(g.B, g.ldb, n0, g.N, k0 + GB_K, kend, g.vecB, rb);
             else load_kcontig(g.B, g.ldb, n0, g.N, k0 + GB_K, kend, g.vecB, rb);
         }
-        float fa[16], fb[16];
+        float fa[KH], fb[KH];
         if (A_KMAJOR) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) fa[s] = As[(lh * 16 + s) * LDR + wm + li];
+            for (int s = 0; s < KH; ++s) fa[s] = As[(lh * KH + s) * LDR + wm + li];
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = *(const float4*)(As + (wm + li) * LDK + lh * 16 + 4 * q);
+            for (int q = 0; q < KH / 4; ++q) {
+                const float4 v = *(const float4*)(As + (wm + li) * LDK + lh * KH + 4 * q);
                 fa[4 * q] = v.x; fa[4 * q + 1] = v.y; fa[4 * q + 2] = v.z; fa[4 * q + 3] = v.w;
             }
         }
         if (B_KMAJOR) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) fb[s] = Bs[(lh * 16 + s) * LDR + wn + li];
+            for (int s = 0; s < KH; ++s) fb[s] = Bs[(lh * KH + s) * LDR + wn + li];
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = *(const float4*)(Bs + (wn + li) * LDK + lh * 16 + 4 * q);
+            for (int q = 0; q < KH / 4; ++q) {
+                const float4 v = *(const float4*)(Bs + (wn + li) * LDK + lh * KH + 4 * q);
                 fb[4 * q] = v.x; fb[4 * q + 1] = v.y; fb[4 * q + 2] = v.z; fb[4 * q + 3] = v.w;
             }
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
+        for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
     }
 
     if (EPI == EPI_PLAIN && A_KMAJOR && do_bias && tid < GB_M && m0 + tid < g.M)
