@@ -94,7 +94,14 @@ class ppo:
         self._mom = torch.zeros(2, dtype=torch.float64, device=dev)
         self._ws = ops.Workspace(dev)
         self._ws_loss = ops.Workspace(dev)
-        self._stage = {}
+        self._stage, self._stage_c = {}, {}
+        self._pending_critic = []
+        self._side = None
+        # actor || critic on two HIP streams: pays in the small-kernel regime (MLP backbones: +12 % measured);
+        # the fused point-cloud encoders already fill every CU (+3 %, and it blurs per-kernel timing), so they
+        # default to the reference's serial order.  PARTMANIP_OVERLAP=0/1 overrides.
+        ov = os.environ.get("PARTMANIP_OVERLAP")
+        self.overlap = (ov == "1") if ov in ("0", "1") else self.model_cfg['network']['name'] == 'MLP'
 
         self.logger = logger
         self.total_envsteps = 0
@@ -150,83 +157,120 @@ class ppo:
         return dict(obs=v(st.observations), actions=v(st.actions), values=v(st.values), returns=v(st.returns),
                     old_logp=v(st.actions_log_prob), adv=v(st.advantages), old_mu=v(st.mu), old_sigma=v(st.sigma))
 
-    def _minibatch(self, views, indices, keys):
-        """Sequential sampler -> contiguous slices (zero copy); random -> HIP row gather (K3)."""
-        n = len(indices)
+    def _epoch_plan(self, batch):
+        """One pass over `mini_batch_generator`'s BatchSampler (storage.py:125-138) WITHOUT building
+        Python lists of ints (5 M int objects per iteration at 4096 x 128): sequential -> (lo, n)
+        ranges; random -> slices of one `torch.randperm`, which is exactly the draw
+        SubsetRandomSampler.__iter__ makes from the global RNG (same sample sets, same RNG state)."""
+        n_all, mb = self.storage.cur_buf_size, batch.batch_size
+        n_mb = n_all // mb                                     # drop_last
         if self.storage.sampler == "sequential":
-            lo = indices[0]
+            return [(k * mb, mb) for k in range(n_mb)]
+        perm = torch.randperm(n_all)
+        return [perm[k * mb:(k + 1) * mb] for k in range(n_mb)]
+
+    def _minibatch(self, views, indices, keys, stage):
+        """Sequential sampler -> contiguous slices (zero copy); random -> HIP row gather (K3)."""
+        if isinstance(indices, tuple):
+            lo, n = indices
             return {k: views[k][lo:lo + n] for k in keys}
+        n = len(indices)
         dev = views['obs'].device
-        idx = torch.tensor(indices, dtype=torch.int64).to(dev, non_blocking=True)
+        idx = indices.to(dev, non_blocking=True)
         out = {}
         for k in keys:
             src = views[k]
-            buf = self._stage.get(k)
+            buf = stage.get(k)
             if buf is None or buf.shape[0] != n:
-                buf = self._stage[k] = torch.empty(n, src.shape[1], device=dev)
+                buf = stage[k] = torch.empty(n, src.shape[1], device=dev)
             ops.gather_rows(src, idx, buf)
             out[k] = buf
         return out
 
-    def update(self, it):
-        """ppo.py:307-411."""
-        ac, tricks = self.actor_critic, self.tricks
-        f = ac.flat()
-        n_a, n_c, A = f['n_actor'], f['n_critic'], self.num_actions
-        scal_a, scal_c = f['scal_actor'], f['scal_critic']
+    def _actor_step(self, f, views, indices, stage):
+        """One mini-batch of ppo.py:316-357 (forward, loss fwd+bwd, backward, [all-reduce], clip+Adam)."""
+        ac, tricks, sync = self.actor_critic, self.tricks, self.sync
+        n_a, A = f['n_actor'], self.num_actions
+        scal_a = f['scal_actor']
         clip = tricks['use_grad_clip']
-        max_norm = self.max_grad_norm if clip else 0.0
-        act_tanh = ac.action_activate == 'tanh'
+        mb = self._minibatch(views, indices, ('obs', 'actions', 'old_logp', 'adv', 'old_mu', 'old_sigma'), stage)
+        B = mb['obs'].shape[0]
+        mu = ac.actor.hip_forward(mb['obs'])
+        mom, cnt = None, 0.0
+        if tricks['mini_adv_norm']:                          # ppo.py:329
+            ops.moments(mb['adv'].reshape(-1), self._mom, self._ws)
+            cnt = sync.moments_sync(self._mom, B) if sync else B
+            mom = self._mom
+        dmu = torch.empty(B, A, device=mu.device)
+        ops.ppo_actor_loss(mu, ac.log_std.data, mb['actions'], mb['old_logp'], mb['adv'], mb['old_mu'],
+                           mb['old_sigma'], ac.max_action, ac.action_activate == 'tanh', self.epsilon_clip,
+                           self.desired_kl, mom, cnt, scal_a, dmu, f['grad_log_std'], self._ws_loss)
+        ac.actor.hip_backward(dmu)
+        if sync:                                              # ONE all-reduce: grads + loss/kl in the tail
+            sync.mean_(f['grad_actor'])
+            scal_a[2:3].copy_((scal_a[1:2] > self.desired_kl).float())
+        ops.ppo_accumulate_stats(self._acc, scal_a, 0)
+        # log_std belongs to this optimiser but is outside the clipped norm (ppo.py:351)
+        self.optimizer_actor.step(n=n_a + A, n_clip=n_a if clip else 0,
+                                  max_norm=self.max_grad_norm if clip else 0.0, skip_flag=scal_a[2:3])
+
+    def _critic_step(self, f, views, indices, stage):
+        """One mini-batch of ppo.py:360-384."""
+        ac, tricks, sync = self.actor_critic, self.tricks, self.sync
+        n_c, scal_c = f['n_critic'], f['scal_critic']
+        clip = tricks['use_grad_clip']
+        mb = self._minibatch(views, indices, ('obs', 'returns', 'values'), stage)
+        B = mb['obs'].shape[0]
+        value = ac.critic.hip_forward(mb['obs'])
+        clip_mean = None
+        if tricks['use_clipped_value_loss'] and sync:
+            clip_mean = sync.mean_((self.epsilon_clip * mb['values']).abs().mean().reshape(1))
+        dv = torch.empty(B, 1, device=value.device)
+        ops.value_loss(value, mb['returns'], mb['values'], tricks['use_clipped_value_loss'], self.epsilon_clip,
+                       clip_mean, 1.0, scal_c, dv)
+        ac.critic.hip_backward(dv)
+        if sync:
+            sync.mean_(f['grad_critic'])
+        ops.ppo_accumulate_stats(self._acc, scal_c, 1)
+        self.optimizer_critic.step(n=n_c, n_clip=n_c if clip else 0, max_norm=self.max_grad_norm if clip else 0.0)
+
+    def update(self, it):
+        """ppo.py:307-411.  The reference runs all actor epochs, then all critic epochs; the two loops touch
+        disjoint parameters / optimisers and only read the rollout, so step k of the critic loop is issued on
+        a second HIP stream next to step k of the actor loop (bit-identical results): small kernels of one
+        network fill the CUs the other leaves idle, and under data parallelism each all-reduce overlaps the
+        other network's compute.  Index lists are drawn in the reference's order (all actor epochs first)."""
+        ac = self.actor_critic
+        f = ac.flat()
         views = self._views()
         self._acc.zero_()
-        sync = self.sync
-
         batch = self.storage.mini_batch_generator(self.num_mini_batches)
-        a_keys = ('obs', 'actions', 'old_logp', 'adv', 'old_mu', 'old_sigma')
-        for _ in range(self.n_updates):                      # actor loop, ppo.py:315-357
-            for indices in batch:
-                mb = self._minibatch(views, indices, a_keys)
-                B = len(indices)
-                mu = ac.actor.hip_forward(mb['obs'])
-                mom, cnt = None, 0.0
-                if tricks['mini_adv_norm']:                  # ppo.py:329
-                    ops.moments(mb['adv'].reshape(-1), self._mom, self._ws)
-                    cnt = sync.moments_sync(self._mom, B) if sync else B
-                    mom = self._mom
-                dmu = torch.empty(B, A, device=mu.device)
-                ops.ppo_actor_loss(mu, ac.log_std.data, mb['actions'], mb['old_logp'], mb['adv'], mb['old_mu'],
-                                   mb['old_sigma'], ac.max_action, act_tanh, self.epsilon_clip, self.desired_kl,
-                                   mom, cnt, scal_a, dmu, f['grad_log_std'], self._ws_loss)
-                ac.actor.hip_backward(dmu)
-                if sync:                                      # ONE all-reduce: grads + loss/kl in the tail
-                    sync.mean_(f['grad_actor'])
-                    scal_a[2:3].copy_((scal_a[1:2] > self.desired_kl).float())
-                ops.ppo_accumulate_stats(self._acc, scal_a, 0)
-                # log_std belongs to this optimiser but is outside the clipped norm (ppo.py:351)
-                self.optimizer_actor.step(n=n_a + A, n_clip=n_a if clip else 0, max_norm=max_norm,
-                                          skip_flag=scal_a[2:3])
-
-        c_keys = ('obs', 'returns', 'values')
-        for _ in range(self.n_updates):                      # critic loop, ppo.py:359-384
-            for indices in batch:
-                mb = self._minibatch(views, indices, c_keys)
-                B = len(indices)
-                value = ac.critic.hip_forward(mb['obs'])
-                clip_mean = None
-                if tricks['use_clipped_value_loss'] and sync:
-                    clip_mean = sync.mean_((self.epsilon_clip * mb['values']).abs().mean().reshape(1))
-                dv = torch.empty(B, 1, device=value.device)
-                ops.value_loss(value, mb['returns'], mb['values'], tricks['use_clipped_value_loss'],
-                               self.epsilon_clip, clip_mean, 1.0, scal_c, dv)
-                ac.critic.hip_backward(dv)
-                if sync:
-                    sync.mean_(f['grad_critic'])
-                ops.ppo_accumulate_stats(self._acc, scal_c, 1)
-                self.optimizer_critic.step(n=n_c, n_clip=n_c if clip else 0, max_norm=max_norm)
+        lists_a = [self._epoch_plan(batch) for _ in range(self.n_updates)]          # ppo.py:315-316
+        lists_c = [self._epoch_plan(batch) for _ in range(self.n_updates)]          # ppo.py:359-360
+        main = torch.cuda.current_stream()
+        if self.overlap:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            side = self._side
+            side.wait_stream(main)                                       # returns / advantages are ready
+        for la, lc in zip(lists_a, lists_c):
+            for ia, ic in zip(la, lc):
+                self._actor_step(f, views, ia, self._stage)
+                if self.overlap:
+                    with torch.cuda.stream(side):
+                        self._critic_step(f, views, ic, self._stage_c)
+                else:
+                    self._pending_critic.append(ic)
+        if self.overlap:
+            main.wait_stream(side)
+        else:                                                            # reference order: critic loop afterwards
+            for ic in self._pending_critic:
+                self._critic_step(f, views, ic, self._stage_c)
+            self._pending_critic = []
 
         acc = self._acc.tolist()                              # the only host sync of the update
         sum_surr, sum_kl, kl_max, count, sum_v, n_v = acc[:6]
-        mean_value_loss = sum_v / (self.n_updates * len(batch))
+        mean_value_loss = sum_v / (self.n_updates * len(lists_c[0]))
         mean_surrogate_loss = sum_surr / count                # ZeroDivisionError if every mb was skipped, as ppo.py:387
         mean_kl_mean = sum_kl / count
 

@@ -2,7 +2,11 @@
 // exact fp32 products, fp32 accumulate -- bitwise an fmaf chain per output, so results are
 // fp32-roundoff-class against the reference's CPU sgemm).
 //
-// One work-group = 4 waves (2x2), tile 64x64, K-step 64 (one barrier pair per 32 MFMAs per wave).  Operand tiles are staged in LDS in
+// One work-group = 8 waves on a 64x64 tile, K-step 64: waves 0-3 (2x2 blocks of 32x32) take
+// k in [0,32) of every K-step and waves 4-7 the same blocks with k in [32,64) (intra-work-group
+// split-K, combined through LDS at the end).  The output of these layers (2048 x 512) is only 1024
+// MFMA blocks -- one per SIMD -- so without the split every SIMD holds a single wave and nothing
+// hides the LDS staging; with it two waves per SIMD alternate staging and MFMA.  Operand tiles are staged in LDS in
 // their natural global orientation:
 //   "k-contiguous" operand (row r, k fastest):   LDS [64][68]  -> fragments by ds_read_b128;
 //        row stride 68 floats: (68*r) mod 64 hits 16 distinct 4-bank slots -> conflict-free.
@@ -17,9 +21,10 @@
 #define GB_K 64
 #define LDK (GB_K + 4)   // k-contiguous LDS row stride (floats)
 #define LDR 64           // k-major LDS row stride (floats)
-#define NV4 (GB_M * GB_K / 4 / 256)   // float4 loads per thread per operand tile
-#define NSC (GB_M * GB_K / 256)       // scalar loads per thread per operand tile
-#define KH (GB_K / 2)                 // k-values per lane half
+#define GB_T 512                      // threads per work-group
+#define NV4 (GB_M * GB_K / 4 / GB_T)  // float4 loads per thread per operand tile
+#define NSC (GB_M * GB_K / GB_T)      // scalar loads per thread per operand tile
+#define KH (GB_K / 4)                 // k-values per lane half per wave k-group (16)
 
 enum { EPI_BIAS_ACT = 0, EPI_MUL_DACT = 1, EPI_PLAIN = 2 };
 
@@ -46,7 +51,7 @@ __device__ __forceinline__ void load_kcontig(const float* __restrict__ P, long l
     if (vec) {
 #pragma unroll
         for (int j = 0; j < NV4; ++j) {
-            const int idx = tid + 256 * j, row = idx / (GB_K / 4), k = k0 + ((idx % (GB_K / 4)) << 2);
+            const int idx = tid + GB_T * j, row = idx / (GB_K / 4), k = k0 + ((idx % (GB_K / 4)) << 2);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row0 + row < nrows && k < kend) v = *(const float4*)(P + (long)(row0 + row) * ld + k);
             r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
@@ -54,7 +59,7 @@ __device__ __forceinline__ void load_kcontig(const float* __restrict__ P, long l
     } else {
 #pragma unroll
         for (int j = 0; j < NSC; ++j) {
-            const int idx = tid + 256 * j, row = idx / GB_K, k = k0 + (idx % GB_K);
+            const int idx = tid + GB_T * j, row = idx / GB_K, k = k0 + (idx % GB_K);
             r[j] = (row0 + row < nrows && k < kend) ? P[(long)(row0 + row) * ld + k] : 0.f;
         }
     }
@@ -64,13 +69,13 @@ __device__ __forceinline__ void store_kcontig(float* __restrict__ S, int vec, co
     if (vec) {
 #pragma unroll
         for (int j = 0; j < NV4; ++j) {
-            const int idx = tid + 256 * j, row = idx / (GB_K / 4), k = (idx % (GB_K / 4)) << 2;
+            const int idx = tid + GB_T * j, row = idx / (GB_K / 4), k = (idx % (GB_K / 4)) << 2;
             *(float4*)(S + row * LDK + k) = make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
         }
     } else {
 #pragma unroll
         for (int j = 0; j < NSC; ++j) {
-            const int idx = tid + 256 * j;
+            const int idx = tid + GB_T * j;
             S[(idx / GB_K) * LDK + (idx % GB_K)] = r[j];
         }
     }
@@ -82,7 +87,7 @@ __device__ __forceinline__ void load_kmajor(const float* __restrict__ P, long ld
     if (vec) {
 #pragma unroll
         for (int j = 0; j < NV4; ++j) {
-            const int idx = tid + 256 * j, k = k0 + (idx >> 4), row = row0 + ((idx & 15) << 2);
+            const int idx = tid + GB_T * j, k = k0 + (idx >> 4), row = row0 + ((idx & 15) << 2);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < kend && row < nrows) v = *(const float4*)(P + (long)k * ld + row);
             r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
@@ -90,7 +95,7 @@ __device__ __forceinline__ void load_kmajor(const float* __restrict__ P, long ld
     } else {
 #pragma unroll
         for (int j = 0; j < NSC; ++j) {
-            const int idx = tid + 256 * j, k = k0 + (idx >> 6), row = row0 + (idx & 63);
+            const int idx = tid + GB_T * j, k = k0 + (idx >> 6), row = row0 + (idx & 63);
             r[j] = (k < kend && row < nrows) ? P[(long)k * ld + row] : 0.f;
         }
     }
@@ -100,26 +105,28 @@ __device__ __forceinline__ void store_kmajor(float* __restrict__ S, int vec, con
     if (vec) {
 #pragma unroll
         for (int j = 0; j < NV4; ++j) {
-            const int idx = tid + 256 * j;
+            const int idx = tid + GB_T * j;
             *(float4*)(S + (idx >> 4) * LDR + ((idx & 15) << 2)) =
                 make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
         }
     } else {
 #pragma unroll
         for (int j = 0; j < NSC; ++j) {
-            const int idx = tid + 256 * j;
+            const int idx = tid + GB_T * j;
             S[(idx >> 6) * LDR + (idx & 63)] = r[j];
         }
     }
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GB_T) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[GB_M * LDK];   // 64*68 >= 64*64
     __shared__ __attribute__((aligned(16))) float Bs[GB_N * LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int kg = wave >> 2, wq = wave & 3;                  // k-group (intra-WG split-K), output quadrant
+    const int wm = (wq >> 1) * 32, wn = (wq & 1) * 32;
+    const int kofs = kg * (GB_K / 2) + lh * KH;               // this lane's first k inside a K-step
     const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
     const int kbeg = blockIdx.z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
@@ -155,21 +162,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         float fa[KH], fb[KH];
         if (A_KMAJOR) {
 #pragma unroll
-            for (int s = 0; s < KH; ++s) fa[s] = As[(lh * KH + s) * LDR + wm + li];
+            for (int s = 0; s < KH; ++s) fa[s] = As[(kofs + s) * LDR + wm + li];
         } else {
 #pragma unroll
             for (int q = 0; q < KH / 4; ++q) {
-                const float4 v = *(const float4*)(As + (wm + li) * LDK + lh * KH + 4 * q);
+                const float4 v = *(const float4*)(As + (wm + li) * LDK + kofs + 4 * q);
                 fa[4 * q] = v.x; fa[4 * q + 1] = v.y; fa[4 * q + 2] = v.z; fa[4 * q + 3] = v.w;
             }
         }
         if (B_KMAJOR) {
 #pragma unroll
-            for (int s = 0; s < KH; ++s) fb[s] = Bs[(lh * KH + s) * LDR + wn + li];
+            for (int s = 0; s < KH; ++s) fb[s] = Bs[(kofs + s) * LDR + wn + li];
         } else {
 #pragma unroll
             for (int q = 0; q < KH / 4; ++q) {
-                const float4 v = *(const float4*)(Bs + (wn + li) * LDK + lh * KH + 4 * q);
+                const float4 v = *(const float4*)(Bs + (wn + li) * LDK + kofs + 4 * q);
                 fb[4 * q] = v.x; fb[4 * q + 1] = v.y; fb[4 * q + 2] = v.z; fb[4 * q + 3] = v.w;
             }
         }
@@ -179,6 +186,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
     if (EPI == EPI_PLAIN && A_KMAJOR && do_bias && tid < GB_M && m0 + tid < g.M)
         g.dbias[(long)blockIdx.z * g.M + m0 + tid] = bsum;
+    // combine the two k-groups: waves 4-7 park their accumulators in LDS, waves 0-3 add them
+    __syncthreads();
+    float* red = As;                                           // 4 quadrants x 64 lanes x 16 floats = 16 KB
+    if (kg == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wq * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[(wq * 16 + r) * 64 + lane];
     // epilogue: acc[r] is C[row = wm + (r&3) + 8*(r>>2) + 4*lh][col = wn + li]
     float* C = g.C + (long)blockIdx.z * g.slab;
     const int col = n0 + wn + li;
@@ -216,7 +234,7 @@ extern "C" int pm_linear_fwd_f32(const float* X, long ldx, const float* W, long 
     g.vecA = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
     g.vecB = (K % 4 == 0) && (ldw % 4 == 0) && aligned16(W);
     dim3 grid((N + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_BIAS_ACT>), grid, dim3(256), 0, pm_stream(stream), g);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_BIAS_ACT>), grid, dim3(GB_T), 0, pm_stream(stream), g);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
@@ -233,7 +251,7 @@ extern "C" int pm_linear_bwd_data_f32(const float* dY, long lddy, const float* W
     g.vecA = (N % 4 == 0) && (lddy % 4 == 0) && aligned16(dY);
     g.vecB = (K % 4 == 0) && (ldw % 4 == 0) && aligned16(W);
     dim3 grid((K + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<false, true, EPI_MUL_DACT>), grid, dim3(256), 0, pm_stream(stream), g);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, true, EPI_MUL_DACT>), grid, dim3(GB_T), 0, pm_stream(stream), g);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
@@ -296,7 +314,7 @@ extern "C" int pm_linear_bwd_weight_f32(const float* dY, long lddy, const float*
         g.dbias = db;                                  // single slab: the column sums ARE the bias gradient
     }
     dim3 grid((K + GB_N - 1) / GB_N, (N + GB_M - 1) / GB_M, S);
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI_PLAIN>), grid, dim3(256), 0, pm_stream(stream), g);
+    hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI_PLAIN>), grid, dim3(GB_T), 0, pm_stream(stream), g);
     if (S > 1) {
         const long ne = (long)N * K + (db ? N : 0);
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, pm_stream(stream),
