@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
     const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ W3,
     const float* __restrict__ packed, int max_mean, const float* __restrict__ dfeat, long ldf,
     const int32_t* __restrict__ argmax, const float* __restrict__ U, float* __restrict__ H2sum,
-    float* __restrict__ Hg, PnBwdPart* __restrict__ parts) {
+    float* __restrict__ Hg, int32_t* __restrict__ slotmap, PnBwdPart* __restrict__ parts) {
     constexpr int BT = PN_BT;
     __shared__ __attribute__((aligned(16))) float smem[BT * PN_LD1 * 2 + BT * PN_LD2 + BT * PN_MAXC + PN_C2 + PN_C3 +
                                                         PN_C3 + 520 + 4 * PN_C2 + 16];
@@ -472,6 +472,31 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
             }
             offs[p] = (unsigned short)lo;
         }
+        // slot[e] = number of distinct arg-max points before sorted entry e (prefix count over the 512 keys):
+        // each distinct point's h2 row is stored ONCE (Hg[b, slot, :]) and the channels that share it find
+        // it through slotmap[b, c] -- typically 3-5x less HBM traffic than one row per channel.
+        {
+            const int e0 = 2 * tid, e1 = e0 + 1;
+            const int q0 = keys[e0] >> 9, q1 = keys[e1] >> 9, qm = (e0 > 0) ? (keys[e0 - 1] >> 9) : -1;
+            const int f0 = (q0 != qm), f1 = (q1 != q0);
+            int v = f0 + f1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(v, o, 64);
+                if (lane >= o) v += t;
+            }
+            int* wtot = (int*)wred;
+            __syncthreads();                                   // every neighbour key has been read
+            if (lane == 63) wtot[wave] = v;
+            __syncthreads();
+            int base = 0;
+            for (int w2 = 0; w2 < wave; ++w2) base += wtot[w2];
+            const int s1 = base + v - 1, s0 = s1 - f1;
+            keys[e0] |= s0 << 19;
+            keys[e1] |= s1 << 19;
+            slotmap[(long)b * PN_C3 + (keys[e0] & 511)] = s0;
+            slotmap[(long)b * PN_C3 + (keys[e1] & 511)] = s1;
+        }
         float4 h2s = make_float4(0.f, 0.f, 0.f, 0.f);    // sum_p h2[p][4*lane..] over this wave's rows
 
         for (int tile = 0; tile < ntiles; ++tile) {
@@ -509,6 +534,8 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                     h2s.x += h.x; h2s.y += h.y; h2s.z += h.z; h2s.w += h.w;
                     float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
                     const int row_end = offs[p0 + rr + 1];
+                    if (e < row_end)                                  // this point is some channel's arg-max
+                        *(float4*)(Hg + ((long)b * PN_C3 + (keys[e] >> 19)) * PN_C2 + 4 * lane) = h;
                     for (; e < row_end; ++e) {
                         const int c = c_next;
                         const float4 w3 = w_next;
@@ -517,7 +544,6 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                             w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
                         }
                         const float g = Gm[c];
-                        *(float4*)(Hg + ((long)b * PN_C3 + c) * PN_C2 + 4 * lane) = h;
                         S.x += g * w3.x; S.y += g * w3.y; S.z += g * w3.z; S.w += g * w3.w;
                     }
                     float4 dz;
@@ -631,16 +657,32 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
         }
     }
 }
-// sum the per-work-group partials in fixed order
-__global__ __launch_bounds__(256) void pn_bwd_reduce_kernel(const PnBwdPart* __restrict__ parts, int G, int C,
-                                                             float* __restrict__ dW1, float* __restrict__ db1,
-                                                             float* __restrict__ dW2, float* __restrict__ db2) {
+// sum the per-work-group partials in fixed order, two stages (68 MB of partials: a single pass with one
+// thread per element and 512 dependent-latency loads took 127 us; 16-way split + final takes ~25 us)
+#define PN_RED_SPLIT 16
+__global__ __launch_bounds__(256) void pn_bwd_reduce1_kernel(const PnBwdPart* __restrict__ parts, int G,
+                                                              float* __restrict__ tmp) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int n = (int)(sizeof(PnBwdPart) / sizeof(float));
     if (i >= n) return;
+    const int per = (G + PN_RED_SPLIT - 1) / PN_RED_SPLIT;
+    const int g0 = blockIdx.y * per, g1 = min(G, g0 + per);
     const float* base = (const float*)parts;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += base[(size_t)g * n + i];
+#pragma unroll 8
+    for (int g = g0; g < g1; ++g) s += base[(size_t)g * n + i];
+    tmp[(size_t)blockIdx.y * n + i] = s;
+}
+
+__global__ __launch_bounds__(256) void pn_bwd_reduce2_kernel(const float* __restrict__ tmp, int C,
+                                                              float* __restrict__ dW1, float* __restrict__ db1,
+                                                              float* __restrict__ dW2, float* __restrict__ db2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = (int)(sizeof(PnBwdPart) / sizeof(float));
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll
+    for (int y = 0; y < PN_RED_SPLIT; ++y) s += tmp[(size_t)y * n + i];
     const int o_db2 = PN_C2 * PN_C1, o_dW1 = o_db2 + PN_C2, o_db1 = o_dW1 + PN_C1 * PN_MAXC;
     if (i < o_db2) dW2[i] = s;
     else if (i < o_dW1) db2[i - o_db2] = s;
@@ -653,12 +695,14 @@ __global__ __launch_bounds__(256) void pn_bwd_reduce_kernel(const PnBwdPart* __r
 // dW3[c,:] (+)= sum_b dmax[b,c] * Hg[b,c,:] ;  db3[c] = sum_b (dmax[b,c] + dmean[b,c])
 __global__ __launch_bounds__(256) void pn_dw3_gather_kernel(const float* __restrict__ dfeat, long ldf, int B,
                                                              int max_mean, const float* __restrict__ Hg,
+                                                             const int32_t* __restrict__ slotmap,
                                                              float* __restrict__ dW3, float* __restrict__ db3) {
     __shared__ float red[4];
     const int c = blockIdx.x, k = threadIdx.x;
     float acc = 0.f;
 #pragma unroll 8
-    for (int b = 0; b < B; ++b) acc += dfeat[(long)b * ldf + c] * Hg[((long)b * PN_C3 + c) * PN_C2 + k];
+    for (int b = 0; b < B; ++b)
+        acc += dfeat[(long)b * ldf + c] * Hg[((long)b * PN_C3 + slotmap[(long)b * PN_C3 + c]) * PN_C2 + k];
     dW3[c * PN_C2 + k] = (max_mean ? dW3[c * PN_C2 + k] : 0.f) + acc;
     float s = 0.f;
     for (int b = k; b < B; b += 256) s += dfeat[(long)b * ldf + c] + (max_mean ? dfeat[(long)b * ldf + PN_C3 + c] : 0.f);
@@ -670,15 +714,16 @@ static inline int pn_bwd_grid(int B) { return B < PN_BWD_MAXG ? B : PN_BWD_MAXG;
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct PnBwdWs {
-    size_t off_U, off_H2sum, off_Hg, off_parts, off_gemm, total;
+    size_t off_U, off_H2sum, off_Hg, off_slot, off_parts, off_gemm, total;
 };
 static PnBwdWs pn_bwd_layout(int B) {
     PnBwdWs w;
     size_t o = 0;
     w.off_U = o;      o += align256((size_t)B * PN_C2 * 4);
     w.off_H2sum = o;  o += align256((size_t)B * PN_C2 * 4);
-    w.off_Hg = o;     o += align256((size_t)B * PN_C3 * PN_C2 * 4);
-    w.off_parts = o;  o += align256((size_t)pn_bwd_grid(B) * sizeof(PnBwdPart));
+    w.off_Hg = o;     o += align256((size_t)B * PN_C3 * PN_C2 * 4);      // worst case: every channel its own point
+    w.off_slot = o;   o += align256((size_t)B * PN_C3 * 4);
+    w.off_parts = o;  o += align256((size_t)(pn_bwd_grid(B) + PN_RED_SPLIT) * sizeof(PnBwdPart));
     w.off_gemm = o;   o += align256(pm_linear_bwd_weight_workspace_bytes(B, PN_C3, PN_C2));
     w.total = o;
     return w;
@@ -706,6 +751,7 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
     float* U = (float*)(ws + w.off_U);
     float* H2sum = (float*)(ws + w.off_H2sum);
     float* Hg = (float*)(ws + w.off_Hg);
+    int32_t* slotmap = (int32_t*)(ws + w.off_slot);
     PnBwdPart* parts = (PnBwdPart*)(ws + w.off_parts);
     int rc;
     if (max_mean) {   // U[B,256] = dmean[B,512] * W3[512,256]
@@ -716,13 +762,16 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
     const int G = pn_bwd_grid(B);
 #define PN_BWD_LAUNCH(CT)                                                                                          \
     hipLaunchKernelGGL(pn_bwd_kernel<CT>, dim3(G), dim3(256), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, b2, \
-                       W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, parts)
+                       W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, slotmap, parts)
     if (C == 3) PN_BWD_LAUNCH(3);
     else if (C == 4) PN_BWD_LAUNCH(4);
     else PN_BWD_LAUNCH(0);
 #undef PN_BWD_LAUNCH
     const int n = (int)(sizeof(PnBwdPart) / sizeof(float));
-    hipLaunchKernelGGL(pn_bwd_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, pm_stream(stream), parts, G, C, dW1,
+    float* red_tmp = (float*)(parts + G);
+    hipLaunchKernelGGL(pn_bwd_reduce1_kernel, dim3((n + 255) / 256, PN_RED_SPLIT), dim3(256), 0, pm_stream(stream), parts,
+                       G, red_tmp);
+    hipLaunchKernelGGL(pn_bwd_reduce2_kernel, dim3((n + 255) / 256), dim3(256), 0, pm_stream(stream), red_tmp, C, dW1,
                        db1, dW2, db2);
     if (max_mean) {   // dW3 = dmean^T * (sum_p h2 / P)
         rc = pm_linear_bwd_weight_f32(dfeat + PN_C3, ldf, H2sum, PN_C2, dW3, PN_C2, nullptr, B, PN_C3, PN_C2,
@@ -730,7 +779,7 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
         if (rc != PM_OK) return rc;
     }
     hipLaunchKernelGGL(pn_dw3_gather_kernel, dim3(PN_C3), dim3(256), 0, pm_stream(stream), dfeat, ldf, B, max_mean, Hg,
-                       dW3, db3);
+                       slotmap, dW3, db3);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
