@@ -259,8 +259,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
     float* Xs = smem + PN_TM * PN_LD2;
     double* red = (double*)(Xs + PN_TM * PN_MAXC);
 
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.x, tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
     const float* xb = x + (long)b * ldx;
     const float4* P2v = (const float4*)(packed + PN_P2_OFF);
     const float4* P3v = (const float4*)(packed + PN_P3_OFF);
@@ -280,6 +279,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
     const int ntiles = P / PN_TM;
     stage_points<PN_TM, NT>(xb, 0, C, sub_mean, cen, Xs);
     for (int tile = 0; tile < ntiles; ++tile) {
+        // Launder the lane id once per tile: every LDS / packed-weight address below is then recomputed from
+        // it inside the tile (a few VALU ops) instead of being hoisted to kernel entry as ~30 lane-constant
+        // VGPRs that do not fit the 128-register budget and get spilled to scratch (134 MB of spill stores
+        // per launch in the PMC WRITE_SIZE of the first 8-wave build).
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int li = lane & 31, lh = lane >> 5;
         __syncthreads();                          // Xs staged; previous tile's layer-3 reads of H are done
         layer1_tile<CT, PN_TM, NT>(Xs, W1, b1, C, H);
         __syncthreads();
@@ -323,6 +329,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
                 }
     }
     // lanes l and l^32 hold the two interleaved row sets of the same channel
+    const int li = lane0 & 31, lh = lane0 >> 5;
 #pragma unroll
     for (int nb = 0; nb < NB3; ++nb) {
         const float ov = __shfl_xor(vmax[nb], 32, 64);
@@ -434,8 +441,8 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
     float* wred = (float*)(keys + PN_C3) + 520;         // [4][256] cross-wave reductions
     double* red = (double*)(wred + 4 * PN_C2);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
+    const int lane = lane0, li = lane0 & 31, lh = lane0 >> 5;
     const float4* P2v = (const float4*)(packed + PN_P2_OFF);
     const float4* P2Tv = (const float4*)(packed + PN_P2T_OFF);
     const float invP = 1.0f / (float)P;
@@ -500,6 +507,9 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
         float4 h2s = make_float4(0.f, 0.f, 0.f, 0.f);    // sum_p h2[p][4*lane..] over this wave's rows
 
         for (int tile = 0; tile < ntiles; ++tile) {
+            int lane = lane0;                              // laundered per tile: see pn_fwd_kernel
+            asm volatile("" : "+v"(lane));
+            const int li = lane & 31, lh = lane >> 5;
             __syncthreads();
             stage_points<BT, 256>(xb, tile, C, sub_mean, cen, Xs);
             __syncthreads();
