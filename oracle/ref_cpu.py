@@ -328,7 +328,7 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None):
             if tricks["use_grad_clip"]:
                 clip_grad_norm(grads[:-1], tricks["max_grad_norm"])     # log_std is NOT clipped (ppo.py:351)
             adam_a.step(grads)
-            trace.append(float(loss))
+            trace.append(float(loss.detach()))
             sum_surr += float(loss)
             sum_kl += float(kl_mean)
             count += 1
@@ -347,7 +347,7 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None):
             if tricks["use_grad_clip"]:
                 clip_grad_norm(grads, tricks["max_grad_norm"])
             adam_c.step(grads)
-            trace.append(float(loss))
+            trace.append(float(loss.detach()))
             sum_v += float(loss)
             n_v += 1
 
@@ -396,7 +396,7 @@ def dagger_update(stu, tea, ring_obs, ring_tea, cur_buf_size, cfg, it, opt=None)
             loss = (tea_act - stu_act).pow(2).mean()
             grads = torch.autograd.grad(loss, [stu[k] for k in names], allow_unused=True)
             opt.step(list(grads))
-            trace.append(float(loss))
+            trace.append(float(loss.detach()))
     lr_now = opt.lrs[0]
     if cfg["lr_schedule"] == "linear_decay":
         lr_now = cfg["lr"] * max(1 - it / cfg["max_iterations"] * 1.8, 0.1)
