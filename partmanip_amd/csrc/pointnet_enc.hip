@@ -423,6 +423,27 @@ __device__ __forceinline__ void bitonic_sort_512(int* keys) {
     __syncthreads();
 }
 
+// dW1 / db1 (K = C) of one finished tile: thread (c, half) over its 16 points of DZ1 / Xs
+#define PN_DW1_ACCUM(XS)                                                         \
+    {                                                                            \
+        const int c_ = tid & 127, p0_ = (tid >> 7) * (BT / 2);                   \
+        _Pragma("unroll 4") for (int p = p0_; p < p0_ + BT / 2; ++p) {           \
+            const float dz = DZ1[p * PN_LD1 + c_];                               \
+            const float4 x0 = *(const float4*)((XS) + p * PN_MAXC);              \
+            db1acc += dz;                                                        \
+            dW1acc[0] = fmaf(dz, x0.x, dW1acc[0]);                               \
+            dW1acc[1] = fmaf(dz, x0.y, dW1acc[1]);                               \
+            dW1acc[2] = fmaf(dz, x0.z, dW1acc[2]);                               \
+            dW1acc[3] = fmaf(dz, x0.w, dW1acc[3]);                               \
+            if (CT != 3 && CT != 4) {                                            \
+                const float4 x1 = *(const float4*)((XS) + p * PN_MAXC + 4);      \
+                dW1acc[4] = fmaf(dz, x1.x, dW1acc[4]);                           \
+                dW1acc[5] = fmaf(dz, x1.y, dW1acc[5]);                           \
+                dW1acc[6] = fmaf(dz, x1.z, dW1acc[6]);                           \
+                dW1acc[7] = fmaf(dz, x1.w, dW1acc[7]);                           \
+            }                                                                    \
+        }                                                                        \
+    }
 template <int CT>
 __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
     const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
@@ -431,13 +452,13 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
     const int32_t* __restrict__ argmax, const float* __restrict__ U, float* __restrict__ H2sum,
     float* __restrict__ Hg, int32_t* __restrict__ slotmap, PnBwdPart* __restrict__ parts) {
     constexpr int BT = PN_BT;
-    __shared__ __attribute__((aligned(16))) float smem[BT * PN_LD1 * 2 + BT * PN_LD2 + BT * PN_MAXC + PN_C2 + PN_C3 +
+    __shared__ __attribute__((aligned(16))) float smem[BT * PN_LD1 * 2 + BT * PN_LD2 + 2 * BT * PN_MAXC + PN_C2 + PN_C3 +
                                                         PN_C3 + 520 + 4 * PN_C2 + 16];
     float* H1 = smem;                                   // [32][132]
     float* DZ1 = H1 + BT * PN_LD1;                      // [32][132]
     float* H2 = DZ1 + BT * PN_LD1;                      // [32][260]  h2, then dz2 in place
-    float* Xs = H2 + BT * PN_LD2;                       // [32][8]
-    float* Us = Xs + BT * PN_MAXC;                      // [256]  u[b,:]/P
+    float* Xs0 = H2 + BT * PN_LD2;                      // 2 x [32][8]: tile t and t+1 (double-buffered)
+    float* Us = Xs0 + 2 * BT * PN_MAXC;                 // [256]  u[b,:]/P
     float* Gm = Us + PN_C2;                             // [512]  dmax[b,:]
     int* keys = (int*)(Gm + PN_C3);                     // [512]  sorted (point<<9 | channel)
     unsigned short* offs = (unsigned short*)(keys + PN_C3);   // [P+1 <= 1025] first key index of each point
@@ -509,15 +530,19 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
         }
         float4 h2s = make_float4(0.f, 0.f, 0.f, 0.f);    // sum_p h2[p][4*lane..] over this wave's rows
 
+        // Four barriers per tile: the VALU phases of neighbouring tiles are merged (layer 1 of tile t runs
+        // next to dW1/db1 of tile t-1; the points of tile t+1 are staged next to the layer-2 epilogue).
+        stage_points<BT, 256>(xb, 0, C, sub_mean, cen, Xs0);
         for (int tile = 0; tile < ntiles; ++tile) {
             int lane = lane0;                              // laundered per tile: see pn_fwd_kernel
             asm volatile("" : "+v"(lane));
             const int li = lane & 31, lh = lane >> 5;
-            __syncthreads();
-            stage_points<BT, 256>(xb, tile, C, sub_mean, cen, Xs);
-            __syncthreads();
+            float* Xs = Xs0 + (tile & 1) * BT * PN_MAXC;
+            float* Xo = Xs0 + ((tile & 1) ^ 1) * BT * PN_MAXC;
+            __syncthreads();                               // (A) Xs staged; DZ1 of tile t-1 complete; H1/H2 free
             layer1_tile<CT, BT, 256>(Xs, W1, b1, C, H1);
-            __syncthreads();
+            if (tile > 0) PN_DW1_ACCUM(Xo)
+            __syncthreads();                               // (B)
             {
                 f32x16 acc2[1][2];
                 zero_acc<1, 2>(acc2);
@@ -525,8 +550,9 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                 layer2_mfma<1, 2>(H1, P2v, wave, lane, acc2);
 #endif
                 layer2_store<1, 2>(acc2, b2, wave, lane, H2);
+                if (tile + 1 < ntiles) stage_points<BT, 256>(xb, tile + 1, C, sub_mean, cen, Xo);
             }
-            __syncthreads();
+            __syncthreads();                               // (C)
             // ---- row-owner pass: wave w owns rows w*8..w*8+7; h2 -> dz2 in place -------------
 #if !(PN_ABLATE & 8)
             {
@@ -569,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                 }
             }
 #endif
-            __syncthreads();
+            __syncthreads();                               // (D)
             // ---- dW2 += dz2^T * h1 : K = 32 points (lanes<32: point s, lanes>=32: point 16+s) ----
             {
                 const float* Ap = H2 + (lh * (BT / 2)) * PN_LD2 + wave * 64 + li;     // A[i=out][k=pt] = dz2[pt][out]
@@ -609,29 +635,9 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                     DZ1[row * PN_LD1 + col] = accH[0][0][r] * (1.0f - h * h);
                 }
             }
-            __syncthreads();
-            // ---- dW1 / db1 (K = C): thread (c, half) over its 16 points ---------------------
-            {
-                const int c = tid & 127, p0 = (tid >> 7) * (BT / 2);
-#pragma unroll 4
-                for (int p = p0; p < p0 + BT / 2; ++p) {
-                    const float dz = DZ1[p * PN_LD1 + c];
-                    const float4 x0 = *(const float4*)(Xs + p * PN_MAXC);
-                    db1acc += dz;
-                    dW1acc[0] = fmaf(dz, x0.x, dW1acc[0]);
-                    dW1acc[1] = fmaf(dz, x0.y, dW1acc[1]);
-                    dW1acc[2] = fmaf(dz, x0.z, dW1acc[2]);
-                    dW1acc[3] = fmaf(dz, x0.w, dW1acc[3]);
-                    if (CT != 3 && CT != 4) {
-                        const float4 x1 = *(const float4*)(Xs + p * PN_MAXC + 4);
-                        dW1acc[4] = fmaf(dz, x1.x, dW1acc[4]);
-                        dW1acc[5] = fmaf(dz, x1.y, dW1acc[5]);
-                        dW1acc[6] = fmaf(dz, x1.z, dW1acc[6]);
-                        dW1acc[7] = fmaf(dz, x1.w, dW1acc[7]);
-                    }
-                }
-            }
         }
+        __syncthreads();
+        PN_DW1_ACCUM(Xs0 + ((ntiles - 1) & 1) * BT * PN_MAXC)           // dW1/db1 of the cloud's last tile
         // ---- per-cloud output: sum_p h2 / P (for dW3's mean term) ---------------------------
         __syncthreads();
         *(float4*)(wred + wave * PN_C2 + 4 * lane) = h2s;
@@ -670,6 +676,8 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
         }
     }
 }
+#undef PN_DW1_ACCUM
+
 // ---------------------------------------------------------------------------------- backward, 8 waves
 // EXPERIMENTAL (-DPN_BWD_NW=8), not the default: measured 4.90 ms vs 4.30 ms for the 4-wave kernel at
 // 2048 clouds -- the 64-register dW2 accumulator plus the running sums leave too little of the
