@@ -329,7 +329,7 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None):
                 clip_grad_norm(grads[:-1], tricks["max_grad_norm"])     # log_std is NOT clipped (ppo.py:351)
             adam_a.step(grads)
             trace.append(float(loss.detach()))
-            sum_surr += float(loss)
+            sum_surr += float(loss.detach())
             sum_kl += float(kl_mean)
             count += 1
 
@@ -348,7 +348,7 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None):
                 clip_grad_norm(grads, tricks["max_grad_norm"])
             adam_c.step(grads)
             trace.append(float(loss.detach()))
-            sum_v += float(loss)
+            sum_v += float(loss.detach())
             n_v += 1
 
     lr_now = adam_a.lrs[0]

@@ -180,6 +180,16 @@ def gen_ppo(ref_algos, cases):
         out["adam_step"] = np.float64(float(st_a[last]["step"]))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print("wrote", name, "losses", len(tr.losses), "count", out["log_kl_update_count"])
+        if name == "ppo_mlp_default":
+            # a checkpoint written by the REFERENCE's own ppo.save (ppo.py:83-100): wire-format fixture for
+            # resume() / FusedAdam.load_state_dict (data only: tensors + plain dicts)
+            with tempfile.TemporaryDirectory() as d:
+                run.save_ckpt_dir = d
+                run.total_envsteps = 12345
+                run.save(c["it"])
+                import shutil
+                shutil.copy(os.path.join(d, f"model_{c['it']}.pth"), os.path.join(HERE, "ref_ckpt_ppo_mlp_default.pth"))
+            print("wrote ref_ckpt_ppo_mlp_default.pth")
 
 
 def gen_dagger(ref_algos, cases):

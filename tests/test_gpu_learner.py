@@ -340,3 +340,38 @@ def test_pointnet2_ppo_iteration_runs():
         run = ppo(env, cfg, ScreenLogger(d, "g", "n", quiet=True))
         run.run()
     assert run.curr_iter == 2 and np.isfinite(float(run.log_dict["Train/surrogate_loss"]))
+
+
+def test_resume_from_reference_checkpoint_and_continue():
+    """`ppo(... resume=<checkpoint written by the reference>)` restores model + both optimisers on the GPU, and one
+    more HIP update from there follows the CPU oracle continuing from the same state."""
+    import os
+    from partmanip_amd.algorithms import ppo
+    from tests.helpers import GOLDEN
+    c, fx = cases.PPO_CASES["ppo_mlp_default"], load_fixture("ppo_mlp_default")
+    c = cases.case_copy(c)
+    c["desired_kl"] = 10.0        # the stale rollout is far from the resumed policy: keep the KL early-stop out of the way
+    cfg = ppo_cfg(c, device=DEV)
+    cfg["resume"] = os.path.join(GOLDEN, "ref_ckpt_ppo_mlp_default.pth")
+    with tempfile.TemporaryDirectory() as d:
+        run = ppo(FakeEnv(c["N"], {"normal_state": c["O"]}, c["A"]), cfg, FakeLogger(d))
+    assert run.curr_iter == c["it"] and run.total_envsteps == 12345
+    np.testing.assert_array_equal(flat_state(run.actor_critic.state_dict()), fx["final_flat"])
+    # continue: same rollout once more on both sides
+    fill_storage(run, c, fx)
+    run.storage.compute_returns(t(fx["last_values"]).to(DEV), c["gamma"], c["lam"])
+    run.log_dict = {}
+    run.update(c["it"] + 1)
+    ck = torch.load(cfg["resume"], map_location="cpu", weights_only=False)
+    p = {k: v.clone() for k, v in ck["model_state_dict"].items()}
+    ak, ckk = R.split_params(p)
+    opt_a, opt_c = R.Adam([p[k] for k in ak] + [p["log_std"]], c["lr"]), R.Adam([p[k] for k in ckk], c["lr"])
+    for opt, sd in ((opt_a, ck["optimizer_actor"]), (opt_c, ck["optimizer_critic"])):
+        for i, st_ in sd["state"].items():
+            opt.m[i], opt.v[i], opt.t[i] = st_["exp_avg"].clone(), st_["exp_avg_sq"].clone(), int(st_["step"])
+    st = ppo_rollout(c, fx)
+    st["returns"], st["advantages"] = t(fx["returns"]), t(fx["advantages"])
+    keys = ("observations", "actions", "values", "returns", "actions_log_prob", "advantages", "mu", "sigma")
+    out = R.ppo_update(p, {k: st[k] for k in keys}, ppo_cfg(c), c["it"] + 1, opt=(opt_a, opt_c))
+    assert run.log_dict["Train/kl_update_count"] == out["log"]["Train/kl_update_count"]
+    check_params(flat_state(run.actor_critic.state_dict()), flat_state(p), 1, c["lr"], len(out["loss_trace"]))

@@ -126,3 +126,60 @@ def test_feeder_env_duck_type_cpu():
     assert rew.shape == (6,) and done.dtype == torch.bool and extras["succ_rate"].shape == (1,)
     assert env.reset_succ.shape == (6,) and (env.reset_succ <= done).all()
     assert float(o2["depth_pc"].abs().max()) <= 1.5
+
+
+def test_reference_checkpoint_wire_format_loads():
+    """A checkpoint written by the REFERENCE's ppo.save (tests/golden/ref_ckpt_ppo_mlp_default.pth) loads into
+    this build's ActorCritic / FusedAdam (same state_dict keys, torch.optim.Adam state layout), and what we
+    write back has the same structure."""
+    import os
+    from partmanip_amd.algo_utils import ActorCritic, FusedAdam
+    from tests.helpers import GOLDEN, flat_state
+    c, fx = cases.PPO_CASES["ppo_mlp_default"], load_fixture("ppo_mlp_default")
+    ck = torch.load(os.path.join(GOLDEN, "ref_ckpt_ppo_mlp_default.pth"), map_location="cpu", weights_only=False)
+    assert ck["iteration"] == c["it"] and ck["total_steps"] == 12345 and ck["obs_mode"] == "normal_state"
+    ac = ActorCritic(c["O"], c["A"], ck["model_cfg"])
+    f = ac.flat()
+    ac.load_state_dict(ck["model_state_dict"])
+    np.testing.assert_array_equal(flat_state(ac.state_dict()), fx["final_flat"])
+    n_a, A = f["n_actor"], c["A"]
+    assert torch.equal(f["actor"][n_a:], ac.log_std.data)            # log_std lives at the tail of the actor buffer
+    opt_a = FusedAdam(f["actor"], f["grad_actor"][:n_a + A], [list(ac.actor.parameters()), [ac.log_std]], lr=1.0)
+    opt_c = FusedAdam(f["critic"], f["grad_critic"][:f["n_critic"]], [list(ac.critic.parameters())], lr=1.0)
+    opt_a.load_state_dict(ck["optimizer_actor"])
+    opt_c.load_state_dict(ck["optimizer_critic"])
+    assert opt_a.param_groups[0]["lr"] == c["lr"] and int(opt_a.state_dev[0]) == int(fx["adam_step"])
+    np.testing.assert_array_equal(opt_a.m[n_a:].numpy(), fx["adam_logstd_m"])
+    np.testing.assert_array_equal(opt_a.v[n_a:].numpy(), fx["adam_logstd_v"])
+    ours, ref = opt_a.state_dict(), ck["optimizer_actor"]
+    assert len(ours["param_groups"]) == len(ref["param_groups"]) == 2
+    assert [g["params"] for g in ours["param_groups"]] == [g["params"] for g in ref["param_groups"]]
+    assert set(ours["state"].keys()) == set(ref["state"].keys())
+    for k in ref["state"]:
+        assert set(ref["state"][k].keys()) <= set(ours["state"][k].keys()) | {"step"}
+        assert torch.equal(ours["state"][k]["exp_avg"], ref["state"][k]["exp_avg"])
+        assert float(ours["state"][k]["step"]) == float(ref["state"][k]["step"])
+
+
+def test_add_transitions_offline_reads_scene_step_npy(tmp_path):
+    """storage.py:58-82: scene_*/step_*.npy dicts {tsdf, proprio_state, tea_obs} fill the DAgger ring row by row."""
+    from partmanip_amd.algo_utils import RolloutStorage
+    g = np.random.default_rng(0)
+    rows = []
+    for s in range(2):
+        d = tmp_path / f"scene_{s:05d}"
+        d.mkdir()
+        for k in range(3):
+            rec = dict(tsdf=g.standard_normal((2, 2, 2)).astype(np.float32),
+                       proprio_state=g.standard_normal(3).astype(np.float32),
+                       tea_obs=g.standard_normal(5).astype(np.float32))
+            np.save(d / f"step_{k:05d}.npy", rec, allow_pickle=True)
+            rows.append(rec)
+    st = RolloutStorage(2, 2, 11, 4, "cpu", sampler="random", tea_obs_shape=5, max_length=10)    # ring of 4 rows
+    st.add_transitions_offline(str(tmp_path), "cpu", add_proprio_obs=True)
+    assert st.cur_buf_size == 4 and st.mix_buf_ind == 6 % 4 and st.last_episode_buf_ind == 2
+    want = [np.concatenate([r["tsdf"].reshape(-1), r["proprio_state"]]) for r in rows]
+    np.testing.assert_array_equal(st.observations[0].numpy(), want[4])        # rows 4,5 wrapped over rows 0,1
+    np.testing.assert_array_equal(st.observations[1].numpy(), want[5])
+    np.testing.assert_array_equal(st.observations[2].numpy(), want[2])
+    np.testing.assert_array_equal(st.tea_obs[3].numpy(), rows[3]["tea_obs"])
