@@ -220,11 +220,13 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = w["N"] * w["T"] * world / (dt / args.steps)
 
-    out = dict(metric="PPO env-steps/sec (whole node), 4096 envs x 1024-pt clouds", value=value, unit="env-steps/s",
+    metric = ("PPO env-steps/sec (whole node), 4096 envs x 1024-pt clouds" if args.workload == "vision"
+              else "PPO env-steps/sec (whole node), 4096 envs x 128 steps, state obs (BASELINE cfg 2)")
+    out = dict(metric=metric, value=value, unit="env-steps/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                config=dict(workload=w["name"], envs_per_gpu=w["N"], n_steps=w["T"], points=1024 if args.workload == "vision" else 0,
-                           minibatch=2048, n_updates=5, backbone=w["net"]["name"], parallelism=f"dp{world}",
+                           minibatch=2048, n_updates=5, parallelism=f"dp{world}",
                            train_scalars={k: float(v) for k, v in run.log_dict.items() if k.startswith("Train/")}))
     if dominant:
         mean_ms, n_launch = ops.TIMER.mean_ms(dominant)

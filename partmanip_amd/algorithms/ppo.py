@@ -101,7 +101,15 @@ class ppo:
         # the fused point-cloud encoders already fill every CU (+3 %, and it blurs per-kernel timing), so they
         # default to the reference's serial order.  PARTMANIP_OVERLAP=0/1 overrides.
         ov = os.environ.get("PARTMANIP_OVERLAP")
-        self.overlap = (ov == "1") if ov in ("0", "1") else self.model_cfg['network']['name'] == 'MLP'
+        is_mlp = self.model_cfg['network']['name'] == 'MLP'
+        self.overlap = (ov == "1") if ov in ("0", "1") else is_mlp
+        # hipGraph replay of the per-mini-batch launch chains: the MLP step is ~24 kernels of 5-15 us, i.e.
+        # host-launch-bound (3.7 us per launch measured).  Needs constant kernel arguments per step: sequential
+        # sampler (slices of persistent storage), a fixed learning rate, no collective inside the chain.
+        gr = os.environ.get("PARTMANIP_GRAPHS")
+        self.use_graphs = (gr != "0") and is_mlp and self.overlap and cfg['sampler'] == 'sequential' and \
+            self.lr_schedule == 'fixed' and self.sync is None
+        self._graphs = {}
 
         self.logger = logger
         self.total_envsteps = 0
@@ -234,6 +242,39 @@ class ppo:
         ops.ppo_accumulate_stats(self._acc, scal_c, 1)
         self.optimizer_critic.step(n=n_c, n_clip=n_c if clip else 0, max_norm=self.max_grad_norm if clip else 0.0)
 
+    # ---- hipGraph replay of the per-mini-batch launch chains (small-step regime) -----------------
+    def _graph_table(self, views):
+        """Graphs are valid for one (rollout buffers, learning rates) configuration: every kernel argument of a
+        mini-batch step is then a constant -- device pointers into persistent storage / flat buffers, sizes,
+        hyper-parameters -- while everything that changes between steps (parameters, Adam moments and step
+        counter, the KL skip flag, the running sums) lives in device memory."""
+        key = (views['obs'].data_ptr(), views['adv'].data_ptr(), views['returns'].data_ptr(),
+               self.optimizer_actor.param_groups[0]['lr'], self.optimizer_critic.param_groups[0]['lr'])
+        if self._graphs.get('key') != key:
+            self._graphs = {'key': key, 'seen': set(),
+                            'pool': {'a': torch.cuda.graph_pool_handle(), 'c': torch.cuda.graph_pool_handle()}}
+        return self._graphs
+
+    def _replay(self, graphs, k, fn, stream):
+        """1st encounter of step k: run eagerly (sizes workspaces, warms allocator); 2nd: capture; then replay."""
+        with torch.cuda.stream(stream):
+            g = graphs.get(k)
+            if g is not None:
+                g.replay()
+            elif k not in graphs['seen']:
+                graphs['seen'].add(k)
+                fn()
+            else:
+                # capture needs a non-default stream; replay may use any stream (the actor's is the default one)
+                cap = self._side if stream is not self._side else self._cap
+                cap.wait_stream(stream)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=graphs['pool'][k[0]], stream=cap):
+                    fn()
+                stream.wait_stream(cap)
+                graphs[k] = g
+                g.replay()
+
     def update(self, it):
         """ppo.py:307-411.  The reference runs all actor epochs, then all critic epochs; the two loops touch
         disjoint parameters / optimisers and only read the rollout, so step k of the critic loop is issued on
@@ -250,11 +291,16 @@ class ppo:
         main = torch.cuda.current_stream()
         if self.overlap:
             if self._side is None:
-                self._side = torch.cuda.Stream()
+                self._side, self._cap = torch.cuda.Stream(), torch.cuda.Stream()
             side = self._side
             side.wait_stream(main)                                       # returns / advantages are ready
-        for la, lc in zip(lists_a, lists_c):
+        graphs = self._graph_table(views) if self.use_graphs else None
+        for ep, (la, lc) in enumerate(zip(lists_a, lists_c)):
             for ia, ic in zip(la, lc):
+                if graphs is not None:
+                    self._replay(graphs, ('a', ia), lambda: self._actor_step(f, views, ia, self._stage), main)
+                    self._replay(graphs, ('c', ic), lambda: self._critic_step(f, views, ic, self._stage_c), side)
+                    continue
                 self._actor_step(f, views, ia, self._stage)
                 if self.overlap:
                     with torch.cuda.stream(side):
