@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="vision", choices=list(WORKLOADS) + ["dagger"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n-steps", type=int, default=0, help="override the rollout length T (e.g. 128 for the vision workload)")
     args = ap.parse_args()
 
     from partmanip_amd import dist as pdist, ops
@@ -160,7 +161,10 @@ def main():
         if world > 1:
             torch.distributed.destroy_process_group()
         return
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.n_steps:
+        w["T"] = args.n_steps
+        w["name"] = w["name"] + f"_T{args.n_steps}"
     cfg = make_cfg(w, device)
 
     from partmanip_amd.algorithms import ppo
