@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--workload", default="vision", choices=list(WORKLOADS) + ["dagger"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-steps", type=int, default=0, help="override the rollout length T (e.g. 128 for the vision workload)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+                    help="vision encoder forward: exact fp32 MFMA (default) or the opt-in split-bf16 path")
     args = ap.parse_args()
 
     from partmanip_amd import dist as pdist, ops
@@ -165,6 +167,9 @@ def main():
     if args.n_steps:
         w["T"] = args.n_steps
         w["name"] = w["name"] + f"_T{args.n_steps}"
+    if args.precision != "f32" and w["net"]["name"] == "PointNet":
+        w["net"] = dict(w["net"], precision=args.precision)
+        w["name"] = w["name"] + "_" + args.precision
     cfg = make_cfg(w, device)
 
     from partmanip_amd.algorithms import ppo
@@ -228,7 +233,8 @@ def main():
               else "PPO env-steps/sec (whole node), 4096 envs x 128 steps, state obs (BASELINE cfg 2)")
     out = dict(metric=metric, value=value, unit="env-steps/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               scaling="weak", vs_baseline=None, dtype="f32" if args.precision == "f32" else "f32 (encoder forward: bf16x3 split MFMA)",
+               data="synthetic",
                config=dict(workload=w["name"], envs_per_gpu=w["N"], n_steps=w["T"], points=1024 if args.workload == "vision" else 0,
                            minibatch=2048, n_updates=5, parallelism=f"dp{world}",
                            train_scalars={k: float(v) for k, v in run.log_dict.items() if k.startswith("Train/")}))
@@ -246,6 +252,21 @@ def main():
         bwd = ops.TIMER.mean_ms("pointnet_enc_bwd")
         if bwd:
             out["roofline"]["enc_bwd_mean_ms"] = bwd[0]
+    if args.workload == "vision" and args.precision == "f32" and world == 1:
+        # the same workload on the opt-in split-bf16 encoder forward (reported next to, not instead of, the fp32 line)
+        ac.actor.precision = ac.critic.precision = "bf16x3"
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        fence()
+        dt3 = (time.perf_counter() - t1) / 2
+        ac.actor.precision = ac.critic.precision = "f32"
+        out["optional_paths"] = dict(encoder_forward_bf16x3=dict(
+            value=w["N"] * w["T"] / dt3, unit="env-steps/s", ms_per_step=dt3 * 1e3,
+            note="pm_pointnet_enc_fwd_bf3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on bf16 MFMAs, fp32 accumulate; "
+                 "~1e-5 relative; passes the golden vision-PPO cases at the fp32 path's tolerances; backward stays fp32"))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = lambda t: t.detach().cpu()
         roll = dict(observations=cpu(st.observations), actions=cpu(st.actions), values=cpu(st.values),

@@ -99,6 +99,15 @@ int pm_pointnet_pack_weights_f32(const float* W2, const float* W3, float* packed
 int pm_pointnet_enc_fwd_f32(const float* x, long ldx, int B, int P, int C, int sub_mean, const float* W1,
                             const float* b1, const float* b2, const float* b3, const float* packed,
                             int max_mean, float* feat, long ldf, int32_t* argmax, void* stream);
+/* OPT-IN split-bf16 forward: same contract as pm_pointnet_enc_fwd_f32, but the two big per-point GEMMs run as
+ * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on bf16 MFMAs with fp32 accumulation (~1e-5 relative instead of ~1e-7;
+ * 5.3x less matrix-pipe time).  P must be a multiple of 128.  `packed` = pm_pointnet_packed_bf3_bytes() bytes
+ * written by pm_pointnet_pack_weights_bf3 (hi/lo bf16 planes of W2, W3 in MFMA B-operand order). */
+size_t pm_pointnet_packed_bf3_bytes(void);
+int pm_pointnet_pack_weights_bf3(const float* W2, const float* W3, void* packed, void* stream);
+int pm_pointnet_enc_fwd_bf3(const float* x, long ldx, int B, int P, int C, int sub_mean, const float* W1,
+                            const float* b1, const float* b2, const float* b3, const void* packed, int max_mean,
+                            float* feat, long ldf, int32_t* argmax, void* stream);
 /* Backward of the above w.r.t. the six encoder parameters given dfeat (B, ldf) =
  * [d max(512) | d mean(512)].  Uses the pooling structure: the gradient of the 512-wide
  * layer-3 output is (d mean)/P on every point plus (d max) on the argmax point only, so

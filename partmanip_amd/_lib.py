@@ -28,6 +28,9 @@ SIGNATURES = {
     "pm_pointnet_packed_elems": (Z, []),
     "pm_pointnet_pack_weights_f32": (I, [P, P, P, P]),
     "pm_pointnet_enc_fwd_f32": (I, [P, L, I, I, I, I, P, P, P, P, P, I, P, L, P, P]),
+    "pm_pointnet_packed_bf3_bytes": (Z, []),
+    "pm_pointnet_pack_weights_bf3": (I, [P, P, P, P]),
+    "pm_pointnet_enc_fwd_bf3": (I, [P, L, I, I, I, I, P, P, P, P, P, I, P, L, P, P]),
     "pm_pointnet_enc_bwd_workspace_bytes": (Z, [I, I, I]),
     "pm_pointnet_enc_bwd_f32": (I, [P, L, I, I, I, I, P, P, P, P, P, I, P, L, P, P, P, P, P, P, P, P, Z, P]),
     "pm_ppo_actor_loss_fwd_bwd_f32": (I, [P, L, P, P, L, P, P, P, L, P, L, I, I, F, I, F, F, P, D, P, P, L, P, P, Z, P]),

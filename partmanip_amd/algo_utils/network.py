@@ -159,11 +159,17 @@ class PointNet(_HipNet):
         self.count = 0
         self.in_channels = input_dim // self.point_num
         self.feat_dim = 512 * (1 + int(self.max_mean_concat))
+        # 'f32' (default): exact fp32 MFMA.  'bf16x3' (opt-in, not a reference key): encoder forward on split-bf16
+        # MFMAs (~1e-5 relative, see csrc/pointnet_enc_bf3.hip); the backward stays fp32.
+        self.precision = net_cfg.get('precision', 'f32')
+        if self.precision not in ('f32', 'bf16x3'):
+            raise ValueError(f"PointNet precision '{self.precision}'")
         _act_code(act)
         object.__setattr__(self, "_head", _LinearChain([self.final_mlp[0], self.final_mlp[2], self.final_mlp[4]],
                                                        _act_code(act)))
         object.__setattr__(self, "_enc_grads", None)
         object.__setattr__(self, "_packed", None)
+        object.__setattr__(self, "_packed3", None)
 
     def set_grad_views(self, views):
         self._head.grads = [(views[f"final_mlp.{i}.weight"], views[f"final_mlp.{i}.bias"]) for i in (0, 2, 4)]
@@ -180,9 +186,18 @@ class PointNet(_HipNet):
         packed = self._pack(x.device)
         feat = torch.empty(B, self.feat_dim + self.proprio_shape, device=x.device)
         argmax = torch.empty(B, 512, dtype=torch.int32, device=x.device)
-        ops.pointnet_enc_fwd(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
-                             self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].bias.data, packed,
-                             self.max_mean_concat, feat, argmax)
+        if self.precision == 'bf16x3':
+            if self._packed3 is None or self._packed3.device != x.device:
+                object.__setattr__(self, "_packed3", torch.empty(int(ops.lib.pm_pointnet_packed_bf3_bytes()),
+                                                                 dtype=torch.uint8, device=x.device))
+            ops.pointnet_pack_bf3(self.mlp[2].weight.data, self.mlp[4].weight.data, self._packed3)
+            ops.pointnet_enc_fwd_bf3(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
+                                     self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].bias.data,
+                                     self._packed3, self.max_mean_concat, feat, argmax)
+        else:
+            ops.pointnet_enc_fwd(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
+                                 self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].bias.data, packed,
+                                 self.max_mean_concat, feat, argmax)
         if self.proprio_shape != 0:
             feat[:, self.feat_dim:].copy_(x[:, -self.proprio_shape:])     # network.py:166-168,193-194
         object.__setattr__(self, "_saved", (x, feat, argmax))

@@ -375,3 +375,58 @@ def test_resume_from_reference_checkpoint_and_continue():
     out = R.ppo_update(p, {k: st[k] for k in keys}, ppo_cfg(c), c["it"] + 1, opt=(opt_a, opt_c))
     assert run.log_dict["Train/kl_update_count"] == out["log"]["Train/kl_update_count"]
     check_params(flat_state(run.actor_critic.state_dict()), flat_state(p), 1, c["lr"], len(out["loss_trace"]))
+
+
+@pytest.mark.parametrize("B,C,max_mean,sub_mean", [(5, 3, True, False), (3, 4, False, True), (130, 3, True, False)])
+def test_pointnet_bf16x3_forward(B, C, max_mean, sub_mean):
+    """Opt-in split-bf16 encoder forward (`precision: bf16x3`): a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on bf16 MFMAs.
+    Stated tolerance 1e-4 relative to the feature scale (fp32 path: 3e-6); arg-max equal where the top-2 gap > 1e-3."""
+    from partmanip_amd.algo_utils import ActorCritic
+    net = dict(name="PointNet", activation="tanh", max_mean=max_mean, sub_mean=sub_mean, precision="bf16x3")
+    torch.manual_seed(B + C)
+    ac = ActorCritic(1024 * C, 10, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net)).to(DEV)
+    ac.flat()
+    g = torch.Generator().manual_seed(B)
+    x = (torch.rand(B, 1024, C, generator=g) * 2 - 1).reshape(B, -1).contiguous()
+    p = {k: v.detach().cpu().clone() for k, v in ac.state_dict().items()}
+    with torch.no_grad():
+        out_ref = R.pointnet_forward(p, "actor", net, x.clone(), 0)
+        pc = x.reshape(B, 1024, C)
+        if sub_mean:
+            pc = torch.cat([pc[..., :3] - pc[..., :3].mean(dim=1, keepdim=True), pc[..., 3:]], dim=-1)
+        h = torch.tanh(torch.nn.functional.linear(pc, p["actor.mlp.0.weight"], p["actor.mlp.0.bias"]))
+        h = torch.tanh(torch.nn.functional.linear(h, p["actor.mlp.2.weight"], p["actor.mlp.2.bias"]))
+        h = torch.nn.functional.linear(h, p["actor.mlp.4.weight"], p["actor.mlp.4.bias"])
+        vmax, imax = h.max(dim=1)
+        top2 = h.topk(2, dim=1)[0]
+    out = ac.actor.hip_forward(x.to(DEV))
+    _, feat, argmax = ac.actor._saved
+    assert rel_err(feat[:, :512], vmax) < 1e-4
+    if max_mean:
+        assert rel_err(feat[:, 512:1024], h.mean(dim=1)) < 1e-4
+    assert rel_err(out, out_ref) < 2e-4
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-3
+    assert torch.equal(argmax.cpu().long()[clear], imax[clear])
+    # the backward (fp32 kernels) runs on top of the bf16x3 forward
+    ac.actor.hip_backward(torch.randn(B, 10, generator=g).to(DEV))
+    assert torch.isfinite(ac.flat()["grad_actor"]).all()
+
+
+@pytest.mark.parametrize("name", ["ppo_pn_maxmean", "ppo_pn_max"])
+def test_ppo_update_bf16x3_forward_within_reference_tolerances(name):
+    """The golden vision-PPO cases with the opt-in bf16x3 encoder forward: the SAME tolerances as the fp32 path
+    on the Train/* scalars and on the parameters after the update (against the vectors captured from the reference)."""
+    c = cases.case_copy(cases.PPO_CASES[name])
+    c["net"] = dict(c["net"], precision="bf16x3")
+    fx = load_fixture(name)
+    run = make_ppo(c)
+    fill_storage(run, c, fx)
+    run.storage.compute_returns(t(fx["last_values"]).to(DEV), c["gamma"], c["lam"])
+    run.log_dict = {}
+    run.update(c["it"])
+    log = run.log_dict
+    assert log["Train/kl_update_count"] == int(fx["log_kl_update_count"])
+    for k in ("value_function_loss", "surrogate_loss", "kl", "kl_max"):
+        np.testing.assert_allclose(float(log["Train/" + k]), float(fx["log_" + k]), rtol=5e-4, atol=5e-6, err_msg=k)
+    check_params(flat_state(run.actor_critic.state_dict()), fx["final_flat"], int(fx["final_stride"]), c["lr"],
+                 len(fx["loss_trace"]))
