@@ -35,6 +35,9 @@ WORKLOADS = {
     # cfg3: open_drawer vision PPO, ppo.yaml hyper-parameters, PointNet(tanh, max_mean, no sub_mean)
     "vision": dict(name="ppo_vision_pointnet_4096env_x_8step_x_1024pt", N=4096, T=8, O=3072, A=10,
                    net=dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False)),
+    # same rollouts through the PointNet++ (SSG) plug-in backbone: FPS + ball query + grouped shared MLPs
+    "vision_pn2": dict(name="ppo_vision_pointnet2ssg_4096env_x_8step_x_1024pt", N=4096, T=8, O=3072, A=10,
+                       net=dict(name="PointNet2", activation="tanh")),
     # cfg2: open_drawer state PPO, MLP 53-512-512-512
     "state": dict(name="ppo_state_mlp_4096env_x_128step", N=4096, T=128, O=53, A=10,
                   net=dict(name="MLP", hid_dim=[512, 512, 512], activation="tanh")),
@@ -112,7 +115,7 @@ def cpu_baseline(w, rollout_cpu, sd_cpu, cfg):
     from oracle import ref_cpu as R
     ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
-    vision = w["net"]["name"] == "PointNet"
+    vision = w["net"]["name"] in ("PointNet", "PointNet2")
     mb = 128 if vision else 2048                     # CPU PointNet pass: ~6 s per 128 samples
     n_mb = 1 if vision else 4
     T, N = w["T"], w["N"]
@@ -229,13 +232,13 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = w["N"] * w["T"] * world / (dt / args.steps)
 
-    metric = ("PPO env-steps/sec (whole node), 4096 envs x 1024-pt clouds" if args.workload == "vision"
+    metric = ("PPO env-steps/sec (whole node), 4096 envs x 1024-pt clouds" if args.workload.startswith("vision")
               else "PPO env-steps/sec (whole node), 4096 envs x 128 steps, state obs (BASELINE cfg 2)")
     out = dict(metric=metric, value=value, unit="env-steps/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32" if args.precision == "f32" else "f32 (encoder forward: bf16x3 split MFMA)",
                data="synthetic",
-               config=dict(workload=w["name"], envs_per_gpu=w["N"], n_steps=w["T"], points=1024 if args.workload == "vision" else 0,
+               config=dict(workload=w["name"], envs_per_gpu=w["N"], n_steps=w["T"], points=1024 if args.workload.startswith("vision") else 0,
                            minibatch=2048, n_updates=5, parallelism=f"dp{world}",
                            train_scalars={k: float(v) for k, v in run.log_dict.items() if k.startswith("Train/")}))
     if dominant:

@@ -35,6 +35,7 @@ extern "C" {
 #define PM_EINVAL (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define PM_EWORKSPACE (-2) /* workspace too small                                                */
 #define PM_EALIGN (-3)     /* pointer / stride not aligned as required                           */
+#define PM_EUNSUPPORTED (-4) /* shape has no fused instantiation: use the generic kernels instead  */
 
 #define PM_ACT_NONE 0
 #define PM_ACT_TANH 1
@@ -214,6 +215,30 @@ int pm_maxpool_rows_f32(const float* x, long G, int nsample, int C, float* out, 
 int pm_maxpool_rows_bwd_f32(const float* dout, long lddo, const int32_t* arg, long G, int nsample, int C,
                             const float* y_tanh /* NULL, or the pooled tanh outputs: dx *= 1-y^2 */, float* dx,
                             void* stream);
+
+/* ------------------------------------------------------------------ K15 fused set-abstraction level
+ * One PointNet++ SA level (north_star; not in the reference snapshot, README.md:23,30) as one forward and
+ * one backward kernel: ball-query groups of `nsample` = 32 rows [xyz[idx]-centre | feat[idx]] -> Linear C1,
+ * tanh -> Linear C2, tanh -> Linear C3, tanh -> max over the group.  Layer 1's feature part is passed in
+ * pre-multiplied per SOURCE point: Y (B*P, C1) = feat * W1[:, 3:3+Cf]^T (pm_linear_fwd_f32, no bias, no
+ * activation), NULL when the level has no input features.  The grouped rows and per-row activations never
+ * reach HBM.  pooled (B*S, ldp) = tanh(max_j z3 + b3), arg (B*S, C3) = lowest row j attaining the max of the
+ * pre-activation.  Instantiated for (C1,C2,C3) in {(64,64,128), (128,128,256)} and nsample = 32
+ * (pm_sa_supported); other shapes return PM_EUNSUPPORTED and the caller uses K4/K13-K15 separately.
+ * Backward: dpooled (B*S, lddp) -> dW1[:, 0:3] (leading dimension lddw1; other columns untouched), db1, dW2,
+ * db2, dW3, db3 (all overwritten) and dY (B*P, C1), which the caller zero-fills (fp32 atomics), or NULL. */
+int pm_sa_supported(int C1, int C2, int C3, int nsample);
+size_t pm_sa_packed_elems(int C1, int C2, int C3);
+int pm_sa_pack_weights_f32(const float* W2, const float* W3, int C1, int C2, int C3, float* packed, void* stream);
+int pm_sa_fwd_f32(const float* xyz, const float* centers, const int32_t* idx, const float* Y, int B, int P, int S,
+                  int nsample, const float* W1, long ldw1, const float* b1, const float* b2, const float* b3,
+                  const float* packed, int C1, int C2, int C3, float* pooled, long ldp, int32_t* arg, void* stream);
+size_t pm_sa_bwd_workspace_bytes(int C1, int C2, int C3);
+int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32_t* idx, const float* Y, int B, int P, int S,
+                  int nsample, const float* W1, long ldw1, const float* b1, const float* b2, const float* W3,
+                  const float* packed, int C1, int C2, int C3, const float* pooled, long ldp, const int32_t* arg,
+                  const float* dpooled, long lddp, float* dW1, long lddw1, float* db1, float* dW2, float* db2,
+                  float* dW3, float* db3, float* dY, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

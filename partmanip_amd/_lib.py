@@ -51,6 +51,13 @@ SIGNATURES = {
     "pm_group_concat_bwd_f32": (I, [P, P, I, I, I, I, I, I, P, P]),
     "pm_maxpool_rows_f32": (I, [P, L, I, I, P, L, P, P]),
     "pm_maxpool_rows_bwd_f32": (I, [P, L, P, L, I, I, P, P, P]),
+    "pm_sa_supported": (I, [I, I, I, I]),
+    "pm_sa_packed_elems": (Z, [I, I, I]),
+    "pm_sa_pack_weights_f32": (I, [P, P, I, I, I, P, P]),
+    "pm_sa_fwd_f32": (I, [P, P, P, P, I, I, I, I, P, L, P, P, P, P, I, I, I, P, L, P, P]),
+    "pm_sa_bwd_workspace_bytes": (Z, [I, I, I]),
+    "pm_sa_bwd_f32": (I, [P, P, P, P, I, I, I, I, P, L, P, P, P, P, I, I, I, P, L, P, P, L, P, L, P, P, P, P, P, P,
+                          P, Z, P]),
 }
 
 if not os.path.exists(LIB_PATH):
@@ -64,7 +71,8 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ERRORS = {-1: "PM_EINVAL (bad argument)", -2: "PM_EWORKSPACE (workspace too small)", -3: "PM_EALIGN (misaligned pointer)"}
+ERRORS = {-1: "PM_EINVAL (bad argument)", -2: "PM_EWORKSPACE (workspace too small)", -3: "PM_EALIGN (misaligned pointer)",
+          -4: "PM_EUNSUPPORTED (no fused instantiation for this shape)"}
 
 
 def check(rc, what):

@@ -269,11 +269,59 @@ class PointNet2(_HipNet):
         )
         object.__setattr__(self, "_chains", chains)
         object.__setattr__(self, "_head", _LinearChain([self.final_mlp[0], self.final_mlp[2], self.final_mlp[4]], code))
+        # levels that run as ONE fused kernel per direction (pm_sa_fwd_f32 / pm_sa_bwd_f32); the others use the
+        # separate gather / Linear / max-pool kernels (still HIP, just unfused)
+        fused_ok = bool(net_cfg.get('fused_sa', True))
+        object.__setattr__(self, "_fused", [
+            fused_ok and len(mlps[l]) == 3 and ops.sa_supported(*mlps[l], self.nsamples[l])
+            for l in range(len(self.npoints))])
+        object.__setattr__(self, "_sa_packed", [None] * len(self.npoints))
+        object.__setattr__(self, "_sa_grads", None)
 
     def set_grad_views(self, views):
         for l, ch in enumerate(self._chains):
             ch.grads = [(views[f"sa.{l}.{2 * i}.weight"], views[f"sa.{l}.{2 * i}.bias"]) for i in range(len(ch.linears))]
         self._head.grads = [(views[f"final_mlp.{i}.weight"], views[f"final_mlp.{i}.bias"]) for i in (0, 2, 4)]
+
+    def _sa_forward_fused(self, l, xyz, feat, centers, idx_g, pooled):
+        """One fused SA level.  Layer 1's feature part is applied per SOURCE point (Y) by the Linear kernel."""
+        B, Pl = xyz.shape[0], xyz.shape[1]
+        lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
+        dims = (lin1.out_features, lin2.out_features, lin3.out_features)
+        cf = 0 if feat is None else feat.shape[2]
+        Y = None
+        if cf > 0:
+            Y = torch.empty(B * Pl, dims[0], device=xyz.device)
+            ops.linear_fwd(feat.reshape(B * Pl, cf), lin1.weight.data[:, 3:3 + cf], None, Y, ops.ACT_NONE)
+        packed = self._sa_packed[l]
+        if packed is None or packed.device != xyz.device:
+            packed = torch.empty(int(ops.lib.pm_sa_packed_elems(*dims)), device=xyz.device)
+            self._sa_packed[l] = packed
+        ops.sa_pack(lin2.weight.data, lin3.weight.data, packed)
+        arg = ops.sa_fwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
+                         packed, dims, pooled)
+        return (idx_g, arg, "fused", xyz, feat, centers, Y, packed, dims, pooled)
+
+    def _sa_backward_fused(self, l, rec, dpooled, ws, need_dfeat):
+        idx_g, arg, _, xyz, feat, centers, Y, packed, dims, pooled = rec
+        B, Pl = xyz.shape[0], xyz.shape[1]
+        lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
+        (dW1, db1), (dW2, db2), (dW3, db3) = self._chains[l].grads
+        cf = 0 if feat is None else feat.shape[2]
+        dY = torch.zeros(B * Pl, dims[0], device=xyz.device) if cf > 0 else None
+        ops.sa_bwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data, packed,
+                   dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws)
+        if dW1.shape[1] > 3 + cf:
+            dW1[:, 3 + cf:].zero_()                        # pad columns never receive data
+        if cf == 0:
+            return None
+        feat2 = feat.reshape(B * Pl, cf)
+        ops.linear_bwd_weight(dY, feat2, dW1[:, 3:3 + cf], None, ws)
+        if not need_dfeat:
+            return None
+        dfeat = torch.empty(B * Pl, cf, device=xyz.device)
+        ops.linear_bwd_data(dY, lin1.weight.data[:, 3:3 + cf], None, dfeat, ops.ACT_NONE)
+        return dfeat
 
     def hip_forward(self, x, out=None):
         B, P, C = x.shape[0], self.point_num, self.in_channels
@@ -286,6 +334,11 @@ class PointNet2(_HipNet):
             idx_c = ops.fps(xyz, S, ws)
             centers = ops.group_points(xyz, idx_c.view(B, S, 1)).view(B, S, 3)
             idx_g = ops.ball_query(xyz, centers, self.radii[l], self.nsamples[l])
+            if self._fused[l]:
+                pooled = torch.empty(B * S, self.sa[l][4].out_features, device=x.device)
+                saved.append(self._sa_forward_fused(l, xyz, feat, centers, idx_g, pooled))
+                xyz, feat = centers, pooled.view(B, S, -1)
+                continue
             ldo = self.sa[l][0].in_features
             rows = ops.group_concat(xyz, feat, centers, idx_g, ldo)
             h = self._chains[l].forward(rows)
@@ -314,6 +367,10 @@ class PointNet2(_HipNet):
         self._head.backward(dy, ws, dx_out=dfbuf)
         dpooled = dfbuf[:, :self.feat_dim]                 # (G, C) view with row stride feat_dim + proprio
         for l in reversed(range(len(saved))):
+            if isinstance(saved[l][2], str):                 # fused level record
+                # level-0 features are data: no gradient flows to them
+                dpooled = self._sa_backward_fused(l, saved[l], dpooled, ws, need_dfeat=l > 0)
+                continue
             idx_g, arg, h, P_l, cf, ldo = saved[l]
             ns = idx_g.shape[2]
             dh = ops.maxpool_rows_bwd(dpooled, arg, ns, y_tanh=h)      # max-pool + tanh' of the chain output

@@ -1,0 +1,574 @@
+// K15 fused: one PointNet++ set-abstraction level (ball-query groups of 32 -> shared 3-layer MLP,
+// tanh after every layer -> max over the group) as ONE forward and ONE backward kernel.  Absent from the
+// reference snapshot (README.md:23,30); mandated by BASELINE.json's north_star; the structure follows
+// partmanip_amd.algo_utils.network.PointNet2 (rows = [xyz[idx]-centre | feat[idx] | 0-pad]).
+//
+// What is never materialised: the grouped rows and the three per-row activations
+// ((B*S*32) x (C0+C1+C2+C3) floats: 17 GB + 11 GB per net at B = 2048 for the default two levels).
+//
+// Layer 1 is split by linearity:  z1[row] = W1[:, :3] (xyz[idx]-centre) + b1  +  Y[b, idx[row], :]
+// with Y = feat * W1[:, 3:3+Cf]^T computed ONCE PER SOURCE POINT by the Linear kernel (K4) instead of
+// once per grouped row (every point sits in ~S*32/P = 8 groups): 8x fewer MACs for that layer and for its
+// two backward GEMMs, and the kernels here become the same for every level (VALU layer 1 + gather).
+//
+// Forward, per tile of TM rows (TM/32 groups), NW waves:
+//   gather idx -> rel. xyz (LDS) -> H1 = tanh(z1) (VALU, Y gathered coalesced) -> LDS
+//   H2 = tanh(H1 W2^T + b2)   fp32 MFMA, A from LDS (ds_read_b128), B streamed from L2 in operand order
+//   Z3 = H2 W3^T              fp32 MFMA; a group's 32 rows are exactly one MFMA M-block, so the max-pool
+//                             is an in-lane reduction over the 16 accumulator registers + one lane^32
+//                             exchange;  pooled = tanh(max + b3)  (tanh is monotone: max commutes with it;
+//                             arg = the lowest row attaining the max of the PRE-activation)
+// Backward (structured max-pool gradient, see sa_bwd_kernel below).
+#include "common.h"
+#include "mfma_f32.h"
+
+#define SA_NS 32
+
+struct SaArgs {
+    const float* xyz;        // (B*P, 3)
+    const float* centers;    // (G, 3)      G = B*S groups
+    const int32_t* idx;      // (G, 32)     neighbour index inside the cloud
+    const float* Y;          // (B*P, C1)   feature part of layer 1 (pre-bias), or null
+    const float* W1;         // (C1, ldw1)  columns 0..2 = xyz weights
+    long ldw1;
+    const float* b1;
+    const float* b2;
+    const float* b3;
+    const float* packed;     // pm_sa_pack_weights_f32
+    float* pooled;           // (G, ldp)
+    long ldp;
+    int32_t* arg;            // (G, C3)
+    long G;
+    int S, P;
+    // backward only
+    const float* W3;         // (C3, C2) plain
+    const float* dpooled;    // (G, lddp)
+    long lddp;
+    float* dY;               // (B*P, C1) zero-filled by the caller, or null
+    float* parts;            // per-work-group partial sums
+};
+
+extern "C" size_t pm_sa_packed_elems(int C1, int C2, int C3) {
+    return (size_t)C1 * C2 * 2 + (size_t)C2 * C3 + 1024;   // W2 fwd | W3 fwd | W2 bwd | 4 KB tail pad
+}
+
+__global__ __launch_bounds__(256) void sa_pack_kernel(const float* __restrict__ W2, const float* __restrict__ W3,
+                                                       int C1, int C2, int C3, float* __restrict__ packed) {
+    const long n2 = (long)C1 * C2, n3 = (long)C2 * C3, total = 2 * n2 + n3 + 1024;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int e = i & 3, lane = (i >> 2) & 63, li = lane & 31, lh = lane >> 5;
+    if (i < n2) {                                          // B[k=in][n=out] = W2[out][in], K = C1
+        const int ng = C1 / 8, g = (int)((i >> 8) % ng), nb = (int)((i >> 8) / ng);
+        packed[i] = W2[(nb * 32 + li) * C1 + lh * (C1 / 2) + g * 4 + e];
+    } else if (i < n2 + n3) {                              // W3, K = C2
+        const long j = i - n2;
+        const int ng = C2 / 8, g = (int)((j >> 8) % ng), nb = (int)((j >> 8) / ng);
+        packed[i] = W3[(nb * 32 + li) * C2 + lh * (C2 / 2) + g * 4 + e];
+    } else if (i < 2 * n2 + n3) {                          // dH1 = dZ2 * W2:  B[k=out][n=in] = W2[out][in], K = C2
+        const long j = i - n2 - n3;
+        const int ng = C2 / 8, g = (int)((j >> 8) % ng), nb = (int)((j >> 8) / ng);
+        packed[i] = W2[(lh * (C2 / 2) + g * 4 + e) * C1 + nb * 32 + li];
+    } else {
+        packed[i] = 0.f;
+    }
+}
+
+extern "C" int pm_sa_pack_weights_f32(const float* W2, const float* W3, int C1, int C2, int C3, float* packed,
+                                      void* stream) {
+    PM_REQUIRE(W2 && W3 && packed && C1 > 0 && C2 > 0 && C3 > 0 && C1 % 32 == 0 && C2 % 32 == 0 && C3 % 32 == 0);
+    const long total = (long)pm_sa_packed_elems(C1, C2, C3);
+    hipLaunchKernelGGL(sa_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, pm_stream(stream), W2, W3,
+                       C1, C2, C3, packed);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// ---- shared pieces -------------------------------------------------------------------------
+// wave -> (M part, N part) for a TM x N output over NW waves: as many waves along N as there are 32-column
+// blocks (each streamed weight block is then reused by MB row blocks), the rest along M.
+template <int TM, int N, int NW>
+struct WaveMap {
+    static constexpr int NBLK = N / 32, MBLK = TM / 32;
+    static constexpr int NBW = NBLK < NW ? NBLK : NW;
+    static constexpr int MW = NW / NBW;
+    static constexpr int NB = NBLK / NBW, MB = MBLK / MW;
+    static_assert(NBW * MW == NW && NB * NBW == NBLK && MB * MW == MBLK && MB >= 1, "tile/wave mapping");
+};
+
+// gather one tile: relative xyz -> Xz[TM][4], flat source point -> Src[TM]
+template <int TM, int NT>
+__device__ __forceinline__ void sa_stage(const SaArgs& a, long tile, float* __restrict__ Xz, int* __restrict__ Src) {
+    for (int t = threadIdx.x; t < TM; t += NT) {
+        long g = tile * (TM / SA_NS) + (t >> 5);
+        if (g >= a.G) g = a.G - 1;                          // ragged last tile: recompute the last group, never stored
+        const long row = g * SA_NS + (t & 31);
+        const long sp = (long)(g / a.S) * a.P + a.idx[row];
+        float4 v;
+        v.x = sub_rn(a.xyz[sp * 3], a.centers[g * 3]);
+        v.y = sub_rn(a.xyz[sp * 3 + 1], a.centers[g * 3 + 1]);
+        v.z = sub_rn(a.xyz[sp * 3 + 2], a.centers[g * 3 + 2]);
+        v.w = 0.f;
+        *(float4*)(Xz + t * 4) = v;
+        Src[t] = (int)sp;
+    }
+}
+
+// layer 1: thread (c = tid % C1, part = tid / C1) computes its rows of H1 = tanh(W1z . xyz + b1 + Y[src])
+template <int C1, int TM, int NT>
+__device__ __forceinline__ void sa_layer1(const SaArgs& a, const float* __restrict__ Xz, const int* __restrict__ Src,
+                                          float* __restrict__ H1) {
+    static_assert(NT % C1 == 0 && TM % (NT / C1) == 0, "layer-1 thread mapping");
+    constexpr int PARTS = NT / C1, RPT = TM / PARTS, LD1 = C1 + 4;
+    const int c = threadIdx.x % C1, p0 = (threadIdx.x / C1) * RPT;
+    const float w0 = a.W1[c * a.ldw1], w1 = a.W1[c * a.ldw1 + 1], w2 = a.W1[c * a.ldw1 + 2], bb = a.b1[c];
+    if (a.Y) {
+#pragma unroll 8
+        for (int p = p0; p < p0 + RPT; ++p) {
+            const float y = a.Y[(long)Src[p] * C1 + c];
+            const float4 x = *(const float4*)(Xz + p * 4);
+            float s = fmaf(w0, x.x, bb);
+            s = fmaf(w1, x.y, s);
+            s = fmaf(w2, x.z, s);
+            H1[p * LD1 + c] = pm_tanh(s + y);
+        }
+    } else {
+#pragma unroll 8
+        for (int p = p0; p < p0 + RPT; ++p) {
+            const float4 x = *(const float4*)(Xz + p * 4);
+            float s = fmaf(w0, x.x, bb);
+            s = fmaf(w1, x.y, s);
+            s = fmaf(w2, x.z, s);
+            H1[p * LD1 + c] = pm_tanh(s);
+        }
+    }
+}
+
+// H2 = tanh(H1 * W2^T + b2): this wave's MB x NB blocks
+template <int C1, int C2, int TM, int NW>
+__device__ __forceinline__ void sa_layer2(const float* __restrict__ H1, const float4* __restrict__ P2v,
+                                          const float* __restrict__ b2, int wave, int lane, float* __restrict__ H2) {
+    using M = WaveMap<TM, C2, NW>;
+    constexpr int LD1 = C1 + 4, LD2 = C2 + 4, NG = C1 / 8;
+    const int li = lane & 31, lh = lane >> 5, wn = wave % M::NBW, wm = wave / M::NBW;
+    f32x16 acc[M::MB][M::NB];
+    zero_acc<M::MB, M::NB>(acc);
+    mfma_stream<M::MB, M::NB, NG>(H1 + (wm * M::MB * 32 + li) * LD1 + lh * (C1 / 2), LD1,
+                                  P2v + (size_t)(wn * M::NB) * NG * 64 + lane, acc);
+#pragma unroll
+    for (int nb = 0; nb < M::NB; ++nb) {
+        const int col = (wn * M::NB + nb) * 32 + li;
+        const float bv = b2[col];
+#pragma unroll
+        for (int mb = 0; mb < M::MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * M::MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                H2[row * LD2 + col] = pm_tanh(acc[mb][nb][r] + bv);
+            }
+    }
+}
+
+// ==================================================================================== forward
+template <int C1, int C2, int C3, int TM, int NW>
+__global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaArgs a) {
+    constexpr int NT = NW * 64, LD1 = C1 + 4, LD2 = C2 + 4;
+    __shared__ __attribute__((aligned(16))) float smem[TM * (LD1 + LD2 + 4) + TM];
+    float* H1 = smem;
+    float* H2 = H1 + TM * LD1;
+    float* Xz = H2 + TM * LD2;
+    int* Src = (int*)(Xz + TM * 4);
+    using M3 = WaveMap<TM, C3, NW>;
+    constexpr int NG3 = C2 / 8;
+
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
+    const float4* P2v = (const float4*)a.packed;
+    const float4* P3v = (const float4*)(a.packed + (size_t)C1 * C2);
+    const long ntiles = (a.G + TM / SA_NS - 1) / (TM / SA_NS);
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));                  // recompute lane-derived addresses per tile (no hoisted spills)
+        const int li = lane & 31, lh = lane >> 5;
+        sa_stage<TM, NT>(a, tile, Xz, Src);
+        __syncthreads();
+        sa_layer1<C1, TM, NT>(a, Xz, Src, H1);
+        __syncthreads();
+        sa_layer2<C1, C2, TM, NW>(H1, P2v, a.b2, wave, lane, H2);
+        __syncthreads();
+        // ---- layer 3 + max-pool over each 32-row block --------------------------------------
+        const int wn = wave % M3::NBW, wm = wave / M3::NBW;
+        f32x16 acc[M3::MB][M3::NB];
+        zero_acc<M3::MB, M3::NB>(acc);
+        mfma_stream<M3::MB, M3::NB, NG3>(H2 + (wm * M3::MB * 32 + li) * LD2 + lh * (C2 / 2), LD2,
+                                         P3v + (size_t)(wn * M3::NB) * NG3 * 64 + lane, acc);
+#pragma unroll
+        for (int nb = 0; nb < M3::NB; ++nb) {
+            const int ch = (wn * M3::NB + nb) * 32 + li;
+            const float bv = a.b3[ch];
+#pragma unroll
+            for (int mb = 0; mb < M3::MB; ++mb) {
+                float best = acc[mb][nb][0];
+                int bi = 4 * lh;
+#pragma unroll
+                for (int r = 1; r < 16; ++r) {
+                    const float v = acc[mb][nb][r];
+                    if (v > best) {
+                        best = v;
+                        bi = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    }
+                }
+                const float ov = __shfl_xor(best, 32, 64);
+                const int oi = __shfl_xor(bi, 32, 64);
+                if (ov > best || (ov == best && oi < bi)) {
+                    best = ov;
+                    bi = oi;
+                }
+                const long g = tile * (TM / SA_NS) + wm * M3::MB + mb;
+                if (lh == 0 && g < a.G) {
+                    a.pooled[g * a.ldp + ch] = pm_tanh(best + bv);
+                    a.arg[g * C3 + ch] = bi;
+                }
+            }
+        }
+    }
+}
+
+#define SA_CFG_A(C1, C2, C3) ((C1) == 64 && (C2) == 64 && (C3) == 128)
+#define SA_CFG_B(C1, C2, C3) ((C1) == 128 && (C2) == 128 && (C3) == 256)
+
+extern "C" int pm_sa_supported(int C1, int C2, int C3, int nsample) {
+    return nsample == SA_NS && (SA_CFG_A(C1, C2, C3) || SA_CFG_B(C1, C2, C3));
+}
+
+static int sa_cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+extern "C" int pm_sa_fwd_f32(const float* xyz, const float* centers, const int32_t* idx, const float* Y, int B, int P,
+                             int S, int nsample, const float* W1, long ldw1, const float* b1, const float* b2,
+                             const float* b3, const float* packed, int C1, int C2, int C3, float* pooled, long ldp,
+                             int32_t* arg, void* stream) {
+    PM_REQUIRE(xyz && centers && idx && W1 && b1 && b2 && b3 && packed && pooled && arg);
+    PM_REQUIRE(B > 0 && P > 0 && S > 0 && ldw1 >= 3 && ldp >= C3);
+    if (!pm_sa_supported(C1, C2, C3, nsample)) return PM_EUNSUPPORTED;
+    if (((uintptr_t)packed & 15) != 0) return PM_EALIGN;
+    SaArgs a = {};
+    a.xyz = xyz; a.centers = centers; a.idx = idx; a.Y = Y; a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.b2 = b2; a.b3 = b3;
+    a.packed = packed; a.pooled = pooled; a.ldp = ldp; a.arg = arg; a.G = (long)B * S; a.S = S; a.P = P;
+    const int ncu = sa_cu_count();
+#define SA_FWD_LAUNCH(C1_, C2_, C3_, TM_, NW_, WGCU_)                                                          \
+    {                                                                                                          \
+        const long ntiles = (a.G + (TM_) / SA_NS - 1) / ((TM_) / SA_NS);                                       \
+        const long grid = ntiles < (long)ncu * (WGCU_) ? ntiles : (long)ncu * (WGCU_);                         \
+        hipLaunchKernelGGL((sa_fwd_kernel<C1_, C2_, C3_, TM_, NW_>), dim3((unsigned)grid), dim3((NW_) * 64), 0, \
+                           pm_stream(stream), a);                                                              \
+    }
+    if (SA_CFG_A(C1, C2, C3)) SA_FWD_LAUNCH(64, 64, 128, 128, 4, 2)
+    else SA_FWD_LAUNCH(128, 128, 256, 64, 4, 2)
+#undef SA_FWD_LAUNCH
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// =================================================================================== backward
+// The gradient w.r.t. the layer-3 pre-activation is structured: per (group, channel) ONE non-zero,
+//   val[g,c] = dpooled[g,c] * (1 - pooled[g,c]^2)   at row arg[g,c],
+// so layer 3 needs no dense backward:
+//   dW3[c,:] += val * H2[row,:]      (VALU; thread (c, k-slice) keeps its slice of dW3 in registers for the
+//                                     whole kernel)
+//   dH2[row,:] += val * W3[c,:]      (one wave per (g,c) pair, lanes over k: coalesced W3 row from L2,
+//                                     conflict-free ds_add_f32 into a zeroed LDS tile)
+// Layers 1-2 are recomputed per tile exactly as in the forward, then
+//   dZ2 = dH2 .* (1-H2^2)            (in place; db2 on the way)
+//   dW2 += dZ2^T * H1                (MFMA, both operands from LDS, accumulators persistent in registers)
+//   dH1  = dZ2 * W2                  (MFMA, B streamed from L2)   dZ1 = dH1 .* (1-H1^2) (in place of H1)
+//   dW1[:, :3], db1 += dZ1^T [xyz 1] (VALU)      dY[src[row], :] += dZ1[row, :]  (global fp32 atomics)
+// Work-groups are persistent over tiles; per-work-group partial sums are reduced by sa_bwd_reduce_kernel.
+// fp32 atomics (LDS and global) make the summation order, hence the last bits, run-dependent.
+template <int C1, int C2, int C3>
+struct SaPart {
+    static constexpr int O_DW2 = 0, O_DB2 = C2 * C1, O_DW3 = O_DB2 + C2, O_DB3 = O_DW3 + C3 * C2, O_DW1 = O_DB3 + C3,
+                         N = O_DW1 + C1 * 4;
+};
+#define SA_BWD_MAXGRID 512
+
+template <int C1, int C2, int C3, int TM, int NW, int WGCU>
+__global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
+    constexpr int NT = NW * 64, LD1 = C1 + 4, LD2 = C2 + 4, NGRP = TM / SA_NS;
+    __shared__ __attribute__((aligned(16))) float smem[TM * (LD1 + 2 * LD2 + 4) + TM + 2 * NGRP * C3];
+    float* H1 = smem;                        // H1, later dZ1 in place
+    float* H2 = H1 + TM * LD1;
+    float* D = H2 + TM * LD2;                // dH2 -> dZ2
+    float* Xz = D + TM * LD2;
+    int* Src = (int*)(Xz + TM * 4);
+    float* Val = (float*)(Src + TM);
+    int* Arg = (int*)(Val + NGRP * C3);
+    using P = SaPart<C1, C2, C3>;
+    using MH = WaveMap<TM, C1, NW>;          // dH1 output mapping
+    constexpr int NGT = C2 / 8;
+
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
+    const float4* P2v = (const float4*)a.packed;
+    const float4* P2Tv = (const float4*)(a.packed + (size_t)C1 * C2 + (size_t)C2 * C3);
+    const long ntiles = (a.G + NGRP - 1) / NGRP;
+
+    // persistent accumulators
+    constexpr int TPC = NT / C3, KS = C2 / TPC;             // dW3: thread (c3 = tid % C3, ks = tid / C3) owns KS k's
+    static_assert(NT % C3 == 0 && C2 % TPC == 0 && KS % 4 == 0, "dW3 thread mapping");
+    float accW3[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) accW3[j] = 0.f;
+    float accb3 = 0.f, accb2 = 0.f, accW1[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int WBLK = (C2 / 32) * (C1 / 32), NBK = WBLK / NW;   // dW2 blocks per wave (same c2 block, NBK c1 blocks)
+    static_assert(NBK * NW == WBLK && (C1 / 32) % NBK == 0, "dW2 wave mapping");
+    f32x16 accW2[NBK];
+#pragma unroll
+    for (int j = 0; j < NBK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW2[j][r] = 0.f;
+    const int w2_m = wave % (C2 / 32), w2_n0 = (wave / (C2 / 32)) * NBK;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int li = lane & 31, lh = lane >> 5;
+        // ---- P0: gather ------------------------------------------------------------------
+        sa_stage<TM, NT>(a, tile, Xz, Src);
+        for (int i = tid; i < NGRP * C3; i += NT) {
+            const long g = tile * NGRP + i / C3;
+            const int c = i % C3;
+            float v = 0.f;
+            int r = 0;
+            if (g < a.G) {
+                const float p = a.pooled[g * a.ldp + c];
+                v = a.dpooled[g * a.lddp + c] * (1.0f - p * p);
+                r = a.arg[g * C3 + c];
+            }
+            Val[i] = v;
+            Arg[i] = r;
+        }
+        __syncthreads();
+        // ---- P1/P2: recompute H1, H2; zero the dH2 tile --------------------------------------
+        sa_layer1<C1, TM, NT>(a, Xz, Src, H1);
+        for (int i = tid; i < TM * LD2 / 4; i += NT) ((float4*)D)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        sa_layer2<C1, C2, TM, NW>(H1, P2v, a.b2, wave, lane, H2);
+        __syncthreads();
+        // ---- P3: structured layer-3 backward ---------------------------------------------------
+        {
+            const int c = tid % C3, ks = tid / C3;
+#pragma unroll
+            for (int gi = 0; gi < NGRP; ++gi) {
+                const float v = Val[gi * C3 + c];
+                const float* hrow = H2 + (gi * SA_NS + Arg[gi * C3 + c]) * LD2 + ks * KS;
+#pragma unroll
+                for (int k4 = 0; k4 < KS / 4; ++k4) {
+                    const float4 h = *(const float4*)(hrow + 4 * k4);
+                    accW3[4 * k4] = fmaf(v, h.x, accW3[4 * k4]);
+                    accW3[4 * k4 + 1] = fmaf(v, h.y, accW3[4 * k4 + 1]);
+                    accW3[4 * k4 + 2] = fmaf(v, h.z, accW3[4 * k4 + 2]);
+                    accW3[4 * k4 + 3] = fmaf(v, h.w, accW3[4 * k4 + 3]);
+                }
+                if (ks == 0) accb3 += v;
+            }
+            constexpr int NPAIR = NGRP * C3;
+#pragma unroll 4
+            for (int q = wave; q < NPAIR; q += NW) {
+                const float v = Val[q];
+                const int c3 = q % C3;
+                float* drow = D + ((q / C3) * SA_NS + Arg[q]) * LD2;
+#pragma unroll
+                for (int kk = 0; kk < C2 / 64; ++kk) {
+                    const int k = lane + 64 * kk;
+                    atomicAdd(drow + k, v * a.W3[c3 * C2 + k]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P4: dZ2 = dH2 .* (1 - H2^2), db2 ------------------------------------------------------
+        {
+            constexpr int PARTS = NT / C2, RPT = TM / PARTS;
+            static_assert(NT % C2 == 0 && TM % PARTS == 0, "dZ2 thread mapping");
+            const int k = tid % C2, p0 = (tid / C2) * RPT;
+#pragma unroll 8
+            for (int p = p0; p < p0 + RPT; ++p) {
+                const float h = H2[p * LD2 + k];
+                const float z = D[p * LD2 + k] * (1.0f - h * h);
+                D[p * LD2 + k] = z;
+                accb2 += z;
+            }
+        }
+        __syncthreads();
+        // ---- P5: dW2 += dZ2^T * H1  (K = TM rows; lanes < 32: rows [0,TM/2), lanes >= 32: the rest) ----
+        {
+            const float* Ap = D + (lh * (TM / 2)) * LD2 + w2_m * 32 + li;       // A[m = c2][k = row]
+            const float* Bp = H1 + (lh * (TM / 2)) * LD1 + w2_n0 * 32 + li;     // B[k = row][n = c1]
+            float ap, bp[NBK], aq, bq[NBK];
+#define SA_DW2_LOAD(a_, b_, s_)  \
+    a_ = Ap[(s_) * LD2];         \
+    _Pragma("unroll") for (int j = 0; j < NBK; ++j) b_[j] = Bp[(s_) * LD1 + j * 32];
+#define SA_DW2_MMA(a_, b_) _Pragma("unroll") for (int j = 0; j < NBK; ++j) accW2[j] = MFMA(a_, b_[j], accW2[j]);
+            SA_DW2_LOAD(ap, bp, 0)
+#pragma unroll 1
+            for (int s = 0; s < TM / 2; s += 2) {
+                SA_DW2_LOAD(aq, bq, s + 1)
+                SA_DW2_MMA(ap, bp)
+                SA_DW2_LOAD(ap, bp, s + 2)          // last trip reads one row past this half: discarded
+                SA_DW2_MMA(aq, bq)
+            }
+#undef SA_DW2_LOAD
+#undef SA_DW2_MMA
+        }
+        // ---- P6: dH1 = dZ2 * W2 -> dZ1 = dH1 .* (1 - H1^2), in place of H1 ----------------------------
+        {
+            const int wn = wave % MH::NBW, wm = wave / MH::NBW;
+            f32x16 accH[MH::MB][MH::NB];
+            zero_acc<MH::MB, MH::NB>(accH);
+            mfma_stream<MH::MB, MH::NB, NGT>(D + (wm * MH::MB * 32 + li) * LD2 + lh * (C2 / 2), LD2,
+                                             P2Tv + (size_t)(wn * MH::NB) * NGT * 64 + lane, accH);
+            __syncthreads();                         // every wave is done reading H1 (P5) and D
+#pragma unroll
+            for (int nb = 0; nb < MH::NB; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < MH::MB; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (wm * MH::MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int col = (wn * MH::NB + nb) * 32 + li;
+                        const float h = H1[row * LD1 + col];
+                        H1[row * LD1 + col] = accH[mb][nb][r] * (1.0f - h * h);
+                    }
+        }
+        __syncthreads();
+        // ---- P7: dW1[:, :3], db1, scatter dZ1 to the source points -------------------------------
+        {
+            constexpr int PARTS = NT / C1, RPT = TM / PARTS;
+            const int c = tid % C1, p0 = (tid / C1) * RPT;
+#pragma unroll 4
+            for (int p = p0; p < p0 + RPT; ++p) {
+                const float z = H1[p * LD1 + c];
+                const float4 x = *(const float4*)(Xz + p * 4);
+                accW1[0] = fmaf(z, x.x, accW1[0]);
+                accW1[1] = fmaf(z, x.y, accW1[1]);
+                accW1[2] = fmaf(z, x.z, accW1[2]);
+                accW1[3] += z;
+                if (a.dY) unsafeAtomicAdd(a.dY + (long)Src[p] * C1 + c, z);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- write this work-group's partial sums ---------------------------------------------------------
+    float* part = a.parts + (size_t)blockIdx.x * P::N;
+    const int lh0 = lane0 >> 5, li0 = lane0 & 31;
+#pragma unroll
+    for (int j = 0; j < NBK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c2 = w2_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh0;
+            part[P::O_DW2 + c2 * C1 + (w2_n0 + j) * 32 + li0] = accW2[j][r];
+        }
+    {
+        const int c = tid % C3, ks = tid / C3;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) part[P::O_DW3 + c * C2 + ks * KS + j] = accW3[j];
+        if (ks == 0) part[P::O_DB3 + c] = accb3;
+    }
+    // db2 and dW1z/db1: reduce the row-parts through LDS (H1/H2 are free now)
+    __syncthreads();
+    {
+        constexpr int PARTS2 = NT / C2, PARTS1 = NT / C1;
+        float* s2 = H1;                              // [PARTS2][C2]
+        float* s1 = H2;                              // [PARTS1][C1][4]
+        static_assert(PARTS2 * C2 <= TM * LD1 && PARTS1 * C1 * 4 <= TM * LD2, "reduction scratch");
+        s2[tid] = accb2;                             // tid = part * C2 + k
+#pragma unroll
+        for (int d = 0; d < 4; ++d) s1[tid * 4 + d] = accW1[d];       // tid = part * C1 + c
+        __syncthreads();
+        if (tid < C2) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS2; ++q) s += s2[q * C2 + tid];
+            part[P::O_DB2 + tid] = s;
+        }
+        if (tid < C1 * 4) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS1; ++q) s += s1[q * C1 * 4 + tid];
+            part[P::O_DW1 + tid] = s;                // [c][x,y,z,bias]
+        }
+    }
+}
+
+template <int C1, int C2, int C3>
+__global__ __launch_bounds__(256) void sa_bwd_reduce_kernel(const float* __restrict__ parts, int nparts,
+                                                             float* __restrict__ dW1, long lddw1,
+                                                             float* __restrict__ db1, float* __restrict__ dW2,
+                                                             float* __restrict__ db2, float* __restrict__ dW3,
+                                                             float* __restrict__ db3) {
+    using P = SaPart<C1, C2, C3>;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P::N) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int w = 0; w < nparts; ++w) s += parts[(size_t)w * P::N + i];
+    if (i < P::O_DB2) dW2[i] = s;
+    else if (i < P::O_DW3) db2[i - P::O_DB2] = s;
+    else if (i < P::O_DB3) dW3[i - P::O_DW3] = s;
+    else if (i < P::O_DW1) db3[i - P::O_DB3] = s;
+    else {
+        const int j = i - P::O_DW1, c = j >> 2, d = j & 3;
+        if (d < 3) dW1[c * lddw1 + d] = s;
+        else db1[c] = s;
+    }
+}
+
+extern "C" size_t pm_sa_bwd_workspace_bytes(int C1, int C2, int C3) {
+    const size_t n = (size_t)C2 * C1 + C2 + (size_t)C3 * C2 + C3 + (size_t)C1 * 4;
+    return n * SA_BWD_MAXGRID * sizeof(float);
+}
+
+extern "C" int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32_t* idx, const float* Y, int B, int P,
+                             int S, int nsample, const float* W1, long ldw1, const float* b1, const float* b2,
+                             const float* W3, const float* packed, int C1, int C2, int C3, const float* pooled,
+                             long ldp, const int32_t* arg, const float* dpooled, long lddp, float* dW1, long lddw1,
+                             float* db1, float* dW2, float* db2, float* dW3, float* db3, float* dY, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(xyz && centers && idx && W1 && b1 && b2 && W3 && packed && pooled && arg && dpooled);
+    PM_REQUIRE(dW1 && db1 && dW2 && db2 && dW3 && db3 && workspace);
+    PM_REQUIRE(B > 0 && P > 0 && S > 0 && ldw1 >= 3 && lddw1 >= 3 && ldp >= C3 && lddp >= C3);
+    if (!pm_sa_supported(C1, C2, C3, nsample)) return PM_EUNSUPPORTED;
+    if (((uintptr_t)packed & 15) != 0) return PM_EALIGN;
+    if (workspace_bytes < pm_sa_bwd_workspace_bytes(C1, C2, C3)) return PM_EWORKSPACE;
+    SaArgs a = {};
+    a.xyz = xyz; a.centers = centers; a.idx = idx; a.Y = Y; a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.b2 = b2;
+    a.packed = packed; a.pooled = const_cast<float*>(pooled); a.ldp = ldp; a.arg = const_cast<int32_t*>(arg);
+    a.G = (long)B * S; a.S = S; a.P = P; a.W3 = W3; a.dpooled = dpooled; a.lddp = lddp; a.dY = dY;
+    a.parts = (float*)workspace;
+    const int ncu = sa_cu_count();
+#define SA_BWD_LAUNCH(C1_, C2_, C3_, TM_, NW_, WGCU_)                                                              \
+    {                                                                                                              \
+        const long ntiles = (a.G + (TM_) / SA_NS - 1) / ((TM_) / SA_NS);                                           \
+        long grid = (long)ncu * (WGCU_);                                                                           \
+        if (grid > SA_BWD_MAXGRID) grid = SA_BWD_MAXGRID;                                                          \
+        if (grid > ntiles) grid = ntiles;                                                                          \
+        hipLaunchKernelGGL((sa_bwd_kernel<C1_, C2_, C3_, TM_, NW_, WGCU_>), dim3((unsigned)grid), dim3((NW_) * 64), \
+                           0, pm_stream(stream), a);                                                               \
+        constexpr int n = SaPart<C1_, C2_, C3_>::N;                                                                \
+        hipLaunchKernelGGL((sa_bwd_reduce_kernel<C1_, C2_, C3_>), dim3((n + 255) / 256), dim3(256), 0,             \
+                           pm_stream(stream), a.parts, (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3);            \
+    }
+    if (SA_CFG_A(C1, C2, C3)) SA_BWD_LAUNCH(64, 64, 128, 64, 4, 2)
+    else SA_BWD_LAUNCH(128, 128, 256, 64, 8, 1)
+#undef SA_BWD_LAUNCH
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}

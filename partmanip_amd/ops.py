@@ -364,3 +364,49 @@ def maxpool_rows_bwd(dout, arg, ns, y_tanh=None):
     check(lib.pm_maxpool_rows_bwd_f32(_ptr(dout), _rows(dout, "dout"), _ptr(arg), G, ns, Cc, _ptr(y_tanh), _ptr(dx),
                                       _stream()), "pm_maxpool_rows_bwd_f32")
     return dx
+
+
+# ----------------------------------------------------------------------------- K15 fused SA level
+def sa_supported(C1, C2, C3, ns):
+    return bool(lib.pm_sa_supported(C1, C2, C3, ns))
+
+
+def sa_pack(w2, w3, packed):
+    _req(w2, w3, packed)
+    C2, C1 = w2.shape
+    C3 = w3.shape[0]
+    _f32c(w2, "w2")
+    _f32c(w3, "w3")
+    check(lib.pm_sa_pack_weights_f32(_ptr(w2), _ptr(w3), C1, C2, C3, _ptr(packed), _stream()),
+          "pm_sa_pack_weights_f32")
+
+
+def sa_fwd(xyz, centers, idx, Y, w1, b1, b2, b3, packed, dims, pooled):
+    """xyz (B,P,3), centers (B,S,3), idx (B,S,32) int32, Y (B*P,C1) or None -> pooled (B*S, C3) view, arg int32."""
+    _req(xyz, centers, idx, Y, w1, packed, pooled)
+    B, P, _ = xyz.shape
+    S, ns = idx.shape[1], idx.shape[2]
+    C1, C2, C3 = dims
+    _f32c(xyz, "xyz")
+    _f32c(centers, "centers")
+    arg = torch.empty(B * S, C3, dtype=torch.int32, device=xyz.device)
+    with TIMER.bracket("sa_fwd"):
+        check(lib.pm_sa_fwd_f32(_ptr(xyz), _ptr(centers), _ptr(idx), _ptr(Y), B, P, S, ns,
+                                _ptr(w1), _rows(w1, "w1"), _ptr(b1), _ptr(b2), _ptr(b3), _ptr(packed), C1, C2, C3,
+                                _ptr(pooled), _rows(pooled, "pooled"), _ptr(arg), _stream()), "pm_sa_fwd_f32")
+    return arg
+
+
+def sa_bwd(xyz, centers, idx, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpooled, dw1, db1, dw2, db2, dw3, db3, dY, ws):
+    _req(xyz, centers, idx, Y, w1, w3, packed, pooled, arg, dpooled, dw1, dw2, dw3, dY)
+    B, P, _ = xyz.shape
+    S, ns = idx.shape[1], idx.shape[2]
+    C1, C2, C3 = dims
+    _f32c(w3, "w3")
+    w = ws.get(lib.pm_sa_bwd_workspace_bytes(C1, C2, C3))
+    with TIMER.bracket("sa_bwd"):
+        check(lib.pm_sa_bwd_f32(_ptr(xyz), _ptr(centers), _ptr(idx), _ptr(Y), B, P, S, ns, _ptr(w1), _rows(w1, "w1"),
+                                _ptr(b1), _ptr(b2), _ptr(w3), _ptr(packed), C1, C2, C3, _ptr(pooled),
+                                _rows(pooled, "pooled"), _ptr(arg), _ptr(dpooled), _rows(dpooled, "dpooled"), _ptr(dw1),
+                                _rows(dw1, "dw1"), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(dw3), _ptr(db3), _ptr(dY),
+                                _ptr(w), w.numel(), _stream()), "pm_sa_bwd_f32")

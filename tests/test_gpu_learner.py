@@ -284,14 +284,20 @@ def test_dagger_small_buffer_is_noop(tmp_path, monkeypatch):
 
 
 # ------------------------------------------------------------------------------- PointNet++ backbone
-@pytest.mark.parametrize("B,C,proprio", [(3, 3, 0), (2, 5, 6)])
-def test_pointnet2_forward_backward(B, C, proprio):
+PN2_UNFUSED = dict(npoints=[128, 32], radii=[0.25, 0.5], nsamples=[16, 16], mlps=[[32, 32, 64], [64, 64, 128], [128, 256]])
+# the shapes the fused SA kernels are instantiated for (pm_sa_fwd_f32 / pm_sa_bwd_f32); 130 / 33 centres make the
+# last tile of both levels ragged
+PN2_FUSED = dict(npoints=[130, 33], radii=[0.25, 0.5], nsamples=[32, 32], mlps=[[64, 64, 128], [128, 128, 256], [256, 512]])
+
+
+@pytest.mark.parametrize("B,C,proprio,shape", [(3, 3, 0, PN2_UNFUSED), (2, 5, 6, PN2_UNFUSED), (3, 3, 0, PN2_FUSED),
+                                               (2, 5, 6, PN2_FUSED)])
+def test_pointnet2_forward_backward(B, C, proprio, shape):
     """PointNet2 plug-in (FPS + ball query + grouping + shared MLP + max-pool; absent from the reference,
     parity unpinned): HIP path vs this build's CPU restatement -- sampled / grouped indices bit-exact,
     outputs to fp32 round-off, gradients with the pooling indices pinned."""
     from partmanip_amd.algo_utils import ActorCritic
-    net = dict(name="PointNet2", activation="tanh", npoints=[128, 32], radii=[0.25, 0.5], nsamples=[16, 16],
-               mlps=[[32, 32, 64], [64, 64, 128], [128, 256]])
+    net = dict(name="PointNet2", activation="tanh", **shape)
     O = 1024 * C + proprio
     torch.manual_seed(11 * B + C)
     ac = ActorCritic(O, 10, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net), proprio).to(DEV)
@@ -303,6 +309,7 @@ def test_pointnet2_forward_backward(B, C, proprio):
     out_ref, aux, ref_args = R.pointnet2_forward(p, "actor", net, x.clone(), proprio, return_aux=True)
     out = ac.actor.hip_forward(x.to(DEV))
     saved = ac.actor._saved
+    assert ac.actor._fused == [shape is PN2_FUSED] * 2
     for l, (idx_c, idx_g) in enumerate(aux):
         assert torch.equal(saved[l][0].cpu().long(), idx_g), f"ball-query indices differ at level {l}"
     assert rel_err(out, out_ref.detach()) < 3e-5
