@@ -80,3 +80,26 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MB][NB]) {
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 }
 
+
+// Same pipeline with the A operand produced by a functor `aload(mb, g) -> float4` (4 consecutive k of this lane's
+// row in M-block mb) instead of an LDS tile -- used where A is generated on the fly.
+template <int MB, int NB, int NG, class AF>
+__device__ __forceinline__ void mfma_stream_fn(AF aload, const float4* __restrict__ Bp, f32x16 (&acc)[MB][NB]) {
+    OperandSet<MB, NB> ping, pong;
+#define PM_LOAD_FN(o, g_)                                                                  \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) o.b[nb] = Bp[(size_t)(nb * NG + (g_)) * 64]; \
+    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) o.a[mb] = aload(mb, (g_));
+    PM_LOAD_FN(ping, 0)
+#pragma unroll 1
+    for (int g = 0; g < NG; g += 2) {
+        PM_LOAD_FN(pong, g + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set<MB, NB>(ping, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        PM_LOAD_FN(ping, g + 2)                    // unconditional: one group past the end, discarded
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set<MB, NB>(pong, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef PM_LOAD_FN
+}

@@ -23,6 +23,9 @@
 #include "mfma_f32.h"
 
 #define SA_NS 32
+#ifndef SA_ABLATE
+#define SA_ABLATE 0   // profiling only (wrong results): 1 dH2 atomics, 2 dW3, 4 dW2 MFMA, 8 dH1 MFMA, 16 P7, 32 layer-2 recompute, 64 layer 1, 128 dZ2
+#endif
 
 struct SaArgs {
     const float* xyz;        // (B*P, 3)
@@ -49,12 +52,12 @@ struct SaArgs {
 };
 
 extern "C" size_t pm_sa_packed_elems(int C1, int C2, int C3) {
-    return (size_t)C1 * C2 * 2 + (size_t)C2 * C3 + 1024;   // W2 fwd | W3 fwd | W2 bwd | 4 KB tail pad
+    return (size_t)C1 * C2 * 2 + (size_t)C2 * C3 * 2 + 1024;   // W2 fwd | W3 fwd | W2 bwd | W3 bwd | 4 KB tail pad
 }
 
 __global__ __launch_bounds__(256) void sa_pack_kernel(const float* __restrict__ W2, const float* __restrict__ W3,
                                                        int C1, int C2, int C3, float* __restrict__ packed) {
-    const long n2 = (long)C1 * C2, n3 = (long)C2 * C3, total = 2 * n2 + n3 + 1024;
+    const long n2 = (long)C1 * C2, n3 = (long)C2 * C3, total = 2 * n2 + 2 * n3 + 1024;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int e = i & 3, lane = (i >> 2) & 63, li = lane & 31, lh = lane >> 5;
@@ -69,6 +72,10 @@ __global__ __launch_bounds__(256) void sa_pack_kernel(const float* __restrict__ 
         const long j = i - n2 - n3;
         const int ng = C2 / 8, g = (int)((j >> 8) % ng), nb = (int)((j >> 8) / ng);
         packed[i] = W2[(lh * (C2 / 2) + g * 4 + e) * C1 + nb * 32 + li];
+    } else if (i < 2 * n2 + 2 * n3) {                      // dH2 = dZ3 * W3:  B[k=out][n=in] = W3[out][in], K = C3
+        const long j = i - 2 * n2 - n3;
+        const int ng = C3 / 8, g = (int)((j >> 8) % ng), nb = (int)((j >> 8) / ng);
+        packed[i] = W3[(lh * (C3 / 2) + g * 4 + e) * C2 + nb * 32 + li];
     } else {
         packed[i] = 0.f;
     }
@@ -284,15 +291,17 @@ extern "C" int pm_sa_fwd_f32(const float* xyz, const float* centers, const int32
 // so layer 3 needs no dense backward:
 //   dW3[c,:] += val * H2[row,:]      (VALU; thread (c, k-slice) keeps its slice of dW3 in registers for the
 //                                     whole kernel)
-//   dH2[row,:] += val * W3[c,:]      (one wave per (g,c) pair, lanes over k: coalesced W3 row from L2,
-//                                     conflict-free ds_add_f32 into a zeroed LDS tile)
+//   dH2 = dZ3 * W3                   (MFMA; the sparse A operand is generated in registers from (val, arg) --
+//                                     one compare-select per element, no dZ3 tile anywhere.  A scatter with
+//                                     ds_add_f32 does 32x fewer FLOPs but measured 4x slower than this whole
+//                                     kernel: LDS float atomics retire ~1 lane per 12 clocks)
 // Layers 1-2 are recomputed per tile exactly as in the forward, then
 //   dZ2 = dH2 .* (1-H2^2)            (in place; db2 on the way)
 //   dW2 += dZ2^T * H1                (MFMA, both operands from LDS, accumulators persistent in registers)
 //   dH1  = dZ2 * W2                  (MFMA, B streamed from L2)   dZ1 = dH1 .* (1-H1^2) (in place of H1)
 //   dW1[:, :3], db1 += dZ1^T [xyz 1] (VALU)      dY[src[row], :] += dZ1[row, :]  (global fp32 atomics)
 // Work-groups are persistent over tiles; per-work-group partial sums are reduced by sa_bwd_reduce_kernel.
-// fp32 atomics (LDS and global) make the summation order, hence the last bits, run-dependent.
+// The global fp32 atomics of the dY scatter make its summation order, hence its last bits, run-dependent.
 template <int C1, int C2, int C3>
 struct SaPart {
     static constexpr int O_DW2 = 0, O_DB2 = C2 * C1, O_DW3 = O_DB2 + C2, O_DB3 = O_DW3 + C3 * C2, O_DW1 = O_DB3 + C3,
@@ -303,21 +312,23 @@ struct SaPart {
 template <int C1, int C2, int C3, int TM, int NW, int WGCU>
 __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
     constexpr int NT = NW * 64, LD1 = C1 + 4, LD2 = C2 + 4, NGRP = TM / SA_NS;
-    __shared__ __attribute__((aligned(16))) float smem[TM * (LD1 + 2 * LD2 + 4) + TM + 2 * NGRP * C3];
+    __shared__ __attribute__((aligned(16))) float smem[TM * (LD1 + 2 * LD2 + 4) + TM + 2 * (NGRP * C3 + 4)];
     float* H1 = smem;                        // H1, later dZ1 in place
     float* H2 = H1 + TM * LD1;
     float* D = H2 + TM * LD2;                // dH2 -> dZ2
     float* Xz = D + TM * LD2;
     int* Src = (int*)(Xz + TM * 4);
     float* Val = (float*)(Src + TM);
-    int* Arg = (int*)(Val + NGRP * C3);
+    int* Arg = (int*)(Val + NGRP * C3 + 4);      // +4: the operand stream reads one k-group past the end
     using P = SaPart<C1, C2, C3>;
+    using M2 = WaveMap<TM, C2, NW>;          // dH2 output mapping
     using MH = WaveMap<TM, C1, NW>;          // dH1 output mapping
     constexpr int NGT = C2 / 8;
 
     const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
     const float4* P2v = (const float4*)a.packed;
     const float4* P2Tv = (const float4*)(a.packed + (size_t)C1 * C2 + (size_t)C2 * C3);
+    const float4* P3Tv = (const float4*)(a.packed + (size_t)C1 * C2 * 2 + (size_t)C2 * C3);
     const long ntiles = (a.G + NGRP - 1) / NGRP;
 
     // persistent accumulators
@@ -326,7 +337,10 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
     float accW3[KS];
 #pragma unroll
     for (int j = 0; j < KS; ++j) accW3[j] = 0.f;
-    float accb3 = 0.f, accb2 = 0.f, accW1[4] = {0.f, 0.f, 0.f, 0.f};
+    float accb3 = 0.f, accW1[4] = {0.f, 0.f, 0.f, 0.f};
+    float accb2[M2::NB];                                    // column sums of dZ2 over this lane's rows
+#pragma unroll
+    for (int nb = 0; nb < M2::NB; ++nb) accb2[nb] = 0.f;
     constexpr int WBLK = (C2 / 32) * (C1 / 32), NBK = WBLK / NW;   // dW2 blocks per wave (same c2 block, NBK c1 blocks)
     static_assert(NBK * NW == WBLK && (C1 / 32) % NBK == 0, "dW2 wave mapping");
     f32x16 accW2[NBK];
@@ -356,17 +370,16 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
             Arg[i] = r;
         }
         __syncthreads();
-        // ---- P1/P2: recompute H1, H2; zero the dH2 tile --------------------------------------
-        sa_layer1<C1, TM, NT>(a, Xz, Src, H1);
-        for (int i = tid; i < TM * LD2 / 4; i += NT) ((float4*)D)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // ---- P1/P2: recompute H1, H2 ------------------------------------------------------------
+        if (!(SA_ABLATE & 64)) sa_layer1<C1, TM, NT>(a, Xz, Src, H1);
         __syncthreads();
-        sa_layer2<C1, C2, TM, NW>(H1, P2v, a.b2, wave, lane, H2);
+        if (!(SA_ABLATE & 32)) sa_layer2<C1, C2, TM, NW>(H1, P2v, a.b2, wave, lane, H2);
         __syncthreads();
         // ---- P3: structured layer-3 backward ---------------------------------------------------
         {
             const int c = tid % C3, ks = tid / C3;
 #pragma unroll
-            for (int gi = 0; gi < NGRP; ++gi) {
+            for (int gi = 0; gi < ((SA_ABLATE & 2) ? 0 : NGRP); ++gi) {
                 const float v = Val[gi * C3 + c];
                 const float* hrow = H2 + (gi * SA_NS + Arg[gi * C3 + c]) * LD2 + ks * KS;
 #pragma unroll
@@ -379,31 +392,38 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
                 }
                 if (ks == 0) accb3 += v;
             }
-            constexpr int NPAIR = NGRP * C3;
-#pragma unroll 4
-            for (int q = wave; q < NPAIR; q += NW) {
-                const float v = Val[q];
-                const int c3 = q % C3;
-                float* drow = D + ((q / C3) * SA_NS + Arg[q]) * LD2;
-#pragma unroll
-                for (int kk = 0; kk < C2 / 64; ++kk) {
-                    const int k = lane + 64 * kk;
-                    atomicAdd(drow + k, v * a.W3[c3 * C2 + k]);
-                }
-            }
         }
-        __syncthreads();
-        // ---- P4: dZ2 = dH2 .* (1 - H2^2), db2 ------------------------------------------------------
+        // ---- P3b/P4: dH2 = dZ3 * W3 (sparse A built in registers), dZ2 = dH2 .* (1 - H2^2) -> D, db2 ----
         {
-            constexpr int PARTS = NT / C2, RPT = TM / PARTS;
-            static_assert(NT % C2 == 0 && TM % PARTS == 0, "dZ2 thread mapping");
-            const int k = tid % C2, p0 = (tid / C2) * RPT;
-#pragma unroll 8
-            for (int p = p0; p < p0 + RPT; ++p) {
-                const float h = H2[p * LD2 + k];
-                const float z = D[p * LD2 + k] * (1.0f - h * h);
-                D[p * LD2 + k] = z;
-                accb2 += z;
+            const int wn = wave % M2::NBW, wm = wave / M2::NBW;
+            f32x16 acc[M2::MB][M2::NB];
+            zero_acc<M2::MB, M2::NB>(acc);
+            auto asel = [&](int mb, int g) -> float4 {
+                const int base = (wm * M2::MB + mb) * C3 + lh * (C3 / 2) + g * 4;
+                const int4 ar = *(const int4*)(Arg + base);
+                const float4 vv = *(const float4*)(Val + base);
+                float4 o;
+                o.x = ar.x == li ? vv.x : 0.f;
+                o.y = ar.y == li ? vv.y : 0.f;
+                o.z = ar.z == li ? vv.z : 0.f;
+                o.w = ar.w == li ? vv.w : 0.f;
+                return o;
+            };
+            if (!(SA_ABLATE & 1))
+                mfma_stream_fn<M2::MB, M2::NB, C3 / 8>(asel, P3Tv + (size_t)(wn * M2::NB) * (C3 / 8) * 64 + lane, acc);
+#pragma unroll
+            for (int nb = 0; nb < M2::NB; ++nb) {
+                const int col = (wn * M2::NB + nb) * 32 + li;
+#pragma unroll
+                for (int mb = 0; mb < M2::MB; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (wm * M2::MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float h = H2[row * LD2 + col];
+                        const float z = acc[mb][nb][r] * (1.0f - h * h);
+                        D[row * LD2 + col] = z;
+                        accb2[nb] += z;
+                    }
             }
         }
         __syncthreads();
@@ -418,7 +438,7 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
 #define SA_DW2_MMA(a_, b_) _Pragma("unroll") for (int j = 0; j < NBK; ++j) accW2[j] = MFMA(a_, b_[j], accW2[j]);
             SA_DW2_LOAD(ap, bp, 0)
 #pragma unroll 1
-            for (int s = 0; s < TM / 2; s += 2) {
+            for (int s = 0; s < ((SA_ABLATE & 4) ? 0 : TM / 2); s += 2) {
                 SA_DW2_LOAD(aq, bq, s + 1)
                 SA_DW2_MMA(ap, bp)
                 SA_DW2_LOAD(ap, bp, s + 2)          // last trip reads one row past this half: discarded
@@ -432,8 +452,9 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
             const int wn = wave % MH::NBW, wm = wave / MH::NBW;
             f32x16 accH[MH::MB][MH::NB];
             zero_acc<MH::MB, MH::NB>(accH);
-            mfma_stream<MH::MB, MH::NB, NGT>(D + (wm * MH::MB * 32 + li) * LD2 + lh * (C2 / 2), LD2,
-                                             P2Tv + (size_t)(wn * MH::NB) * NGT * 64 + lane, accH);
+            if (!(SA_ABLATE & 8))
+                mfma_stream<MH::MB, MH::NB, NGT>(D + (wm * MH::MB * 32 + li) * LD2 + lh * (C2 / 2), LD2,
+                                                 P2Tv + (size_t)(wn * MH::NB) * NGT * 64 + lane, accH);
             __syncthreads();                         // every wave is done reading H1 (P5) and D
 #pragma unroll
             for (int nb = 0; nb < MH::NB; ++nb)
@@ -453,7 +474,7 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
             constexpr int PARTS = NT / C1, RPT = TM / PARTS;
             const int c = tid % C1, p0 = (tid / C1) * RPT;
 #pragma unroll 4
-            for (int p = p0; p < p0 + RPT; ++p) {
+            for (int p = p0; p < ((SA_ABLATE & 16) ? p0 : p0 + RPT); ++p) {
                 const float z = H1[p * LD1 + c];
                 const float4 x = *(const float4*)(Xz + p * 4);
                 accW1[0] = fmaf(z, x.x, accW1[0]);
@@ -482,21 +503,26 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
         for (int j = 0; j < KS; ++j) part[P::O_DW3 + c * C2 + ks * KS + j] = accW3[j];
         if (ks == 0) part[P::O_DB3 + c] = accb3;
     }
-    // db2 and dW1z/db1: reduce the row-parts through LDS (H1/H2 are free now)
+    // db2 and dW1z/db1: reduce the per-lane / per-row-part sums through LDS (H1/H2 are free now)
     __syncthreads();
     {
-        constexpr int PARTS2 = NT / C2, PARTS1 = NT / C1;
-        float* s2 = H1;                              // [PARTS2][C2]
+        constexpr int PARTS1 = NT / C1;
+        float* s2 = H1;                              // [M2::MW][C2]
         float* s1 = H2;                              // [PARTS1][C1][4]
-        static_assert(PARTS2 * C2 <= TM * LD1 && PARTS1 * C1 * 4 <= TM * LD2, "reduction scratch");
-        s2[tid] = accb2;                             // tid = part * C2 + k
+        static_assert(M2::MW * C2 <= TM * LD1 && PARTS1 * C1 * 4 <= TM * LD2, "reduction scratch");
+        const int wn = wave % M2::NBW, wm = wave / M2::NBW;
+#pragma unroll
+        for (int nb = 0; nb < M2::NB; ++nb) {
+            const float v = accb2[nb] + __shfl_xor(accb2[nb], 32, 64);
+            if (lh0 == 0) s2[wm * C2 + (wn * M2::NB + nb) * 32 + li0] = v;
+        }
 #pragma unroll
         for (int d = 0; d < 4; ++d) s1[tid * 4 + d] = accW1[d];       // tid = part * C1 + c
         __syncthreads();
         if (tid < C2) {
             float s = 0.f;
 #pragma unroll
-            for (int q = 0; q < PARTS2; ++q) s += s2[q * C2 + tid];
+            for (int q = 0; q < M2::MW; ++q) s += s2[q * C2 + tid];
             part[P::O_DB2 + tid] = s;
         }
         if (tid < C1 * 4) {

@@ -1,0 +1,49 @@
+"""Time the fused set-abstraction kernels alone (B=2048 clouds, default PointNet2 levels) with HIP events.
+usage: python tools/time_sa.py [B]   (env PARTMANIP_HIP_LIB selects an A/B build of the library)"""
+import sys, torch
+sys.path.insert(0, '.')
+from partmanip_amd import ops
+DEV = 'cuda:0'
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+torch.manual_seed(0)
+ws = ops.Workspace(DEV)
+xyz = torch.rand(B, 1024, 3, device=DEV) * 2 - 1
+LEVELS = [("A", 1024, 256, 0.2, (64, 64, 128), 0), ("B", 256, 64, 0.4, (128, 128, 256), 128)]
+feat = None
+for name, P, S, radius, dims, cf in LEVELS:
+    C1, C2, C3 = dims
+    idx_c = ops.fps(xyz, S, ws)
+    centers = ops.group_points(xyz, idx_c.view(B, S, 1)).view(B, S, 3)
+    idx_g = ops.ball_query(xyz, centers, radius, 32)
+    ldw1 = (3 + cf + 3) // 4 * 4
+    W1 = torch.randn(C1, ldw1, device=DEV) * 0.3
+    W2 = torch.randn(C2, C1, device=DEV) / C1 ** 0.5
+    W3 = torch.randn(C3, C2, device=DEV) / C2 ** 0.5
+    b1, b2, b3 = (torch.randn(c, device=DEV) * 0.1 for c in dims)
+    packed = torch.empty(int(ops.lib.pm_sa_packed_elems(*dims)), device=DEV)
+    ops.sa_pack(W2, W3, packed)
+    Y = None
+    if cf:
+        feat = torch.randn(B * P, cf, device=DEV) * 0.5
+        Y = torch.empty(B * P, C1, device=DEV)
+        ops.linear_fwd(feat, W1[:, 3:3 + cf], None, Y, ops.ACT_NONE)
+    pooled = torch.empty(B * S, C3, device=DEV)
+    dpooled = torch.randn(B * S, C3, device=DEV)
+    g = [torch.empty_like(t) for t in (W1, b1, W2, b2, W3, b3)]
+    dY = torch.zeros(B * P, C1, device=DEV) if cf else None
+
+    def run(n):
+        for _ in range(n):
+            arg = ops.sa_fwd(xyz, centers, idx_g, Y, W1, b1, b2, b3, packed, dims, pooled)
+            ops.sa_bwd(xyz, centers, idx_g, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws)
+    run(2)
+    ops.TIMER.enable("sa_fwd", "sa_bwd")
+    run(5)
+    f = ops.TIMER.mean_ms("sa_fwd")[0]
+    b = ops.TIMER.mean_ms("sa_bwd")[0]
+    ops.TIMER.disable()
+    rows = B * S * 32
+    ff = 2.0 * rows * (C1 * C2 + C2 * C3) / 1e9                 # MFMA flops fwd
+    fb = 2.0 * rows * (3 * C1 * C2) / 1e9                        # L2 recompute + dW2 + dH1
+    print(f"level {name}: fwd {f:.3f} ms ({ff / f:.1f} TF)  bwd {b:.3f} ms ({fb / b:.1f} TF dense part)")
+    xyz = centers.contiguous()
