@@ -105,8 +105,9 @@ struct WaveMap {
 
 // gather one tile: relative xyz -> Xz[TM][4], flat source point -> Src[TM]
 template <int TM, int NT>
-__device__ __forceinline__ void sa_stage(const SaArgs& a, long tile, float* __restrict__ Xz, int* __restrict__ Src) {
-    for (int t = threadIdx.x; t < TM; t += NT) {
+__device__ __forceinline__ void sa_stage(const SaArgs& a, long tile, int tid, float* __restrict__ Xz,
+                                         int* __restrict__ Src) {
+    for (int t = tid; t < TM; t += NT) {
         long g = tile * (TM / SA_NS) + (t >> 5);
         if (g >= a.G) g = a.G - 1;                          // ragged last tile: recompute the last group, never stored
         const long row = g * SA_NS + (t & 31);
@@ -123,11 +124,11 @@ __device__ __forceinline__ void sa_stage(const SaArgs& a, long tile, float* __re
 
 // layer 1: thread (c = tid % C1, part = tid / C1) computes its rows of H1 = tanh(W1z . xyz + b1 + Y[src])
 template <int C1, int TM, int NT>
-__device__ __forceinline__ void sa_layer1(const SaArgs& a, const float* __restrict__ Xz, const int* __restrict__ Src,
-                                          float* __restrict__ H1) {
+__device__ __forceinline__ void sa_layer1(const SaArgs& a, int tid, const float* __restrict__ Xz,
+                                          const int* __restrict__ Src, float* __restrict__ H1) {
     static_assert(NT % C1 == 0 && TM % (NT / C1) == 0, "layer-1 thread mapping");
     constexpr int PARTS = NT / C1, RPT = TM / PARTS, LD1 = C1 + 4;
-    const int c = threadIdx.x % C1, p0 = (threadIdx.x / C1) * RPT;
+    const int c = tid % C1, p0 = (tid / C1) * RPT;
     const float w0 = a.W1[c * a.ldw1], w1 = a.W1[c * a.ldw1 + 1], w2 = a.W1[c * a.ldw1 + 2], bb = a.b1[c];
     if (a.Y) {
 #pragma unroll 8
@@ -151,8 +152,9 @@ __device__ __forceinline__ void sa_layer1(const SaArgs& a, const float* __restri
     }
 }
 
-// H2 = tanh(H1 * W2^T + b2): this wave's MB x NB blocks
-template <int C1, int C2, int TM, int NW>
+// H2 = tanh(H1 * W2^T + b2): this wave's MB x NB blocks.  ALIAS: H2 overwrites H1 (same buffer), so every
+// wave must have finished its MFMA reads of H1 before the first store.
+template <int C1, int C2, int TM, int NW, bool ALIAS>
 __device__ __forceinline__ void sa_layer2(const float* __restrict__ H1, const float4* __restrict__ P2v,
                                           const float* __restrict__ b2, int wave, int lane, float* __restrict__ H2) {
     using M = WaveMap<TM, C2, NW>;
@@ -160,8 +162,10 @@ __device__ __forceinline__ void sa_layer2(const float* __restrict__ H1, const fl
     const int li = lane & 31, lh = lane >> 5, wn = wave % M::NBW, wm = wave / M::NBW;
     f32x16 acc[M::MB][M::NB];
     zero_acc<M::MB, M::NB>(acc);
-    mfma_stream<M::MB, M::NB, NG>(H1 + (wm * M::MB * 32 + li) * LD1 + lh * (C1 / 2), LD1,
-                                  P2v + (size_t)(wn * M::NB) * NG * 64 + lane, acc);
+    if (!(SA_ABLATE & 32))
+        mfma_stream<M::MB, M::NB, NG>(H1 + (wm * M::MB * 32 + li) * LD1 + lh * (C1 / 2), LD1,
+                                      P2v + (size_t)(wn * M::NB) * NG * 64 + lane, acc);
+    if (ALIAS) __syncthreads();
 #pragma unroll
     for (int nb = 0; nb < M::NB; ++nb) {
         const int col = (wn * M::NB + nb) * 32 + li;
@@ -177,31 +181,39 @@ __device__ __forceinline__ void sa_layer2(const float* __restrict__ H1, const fl
 }
 
 // ==================================================================================== forward
-template <int C1, int C2, int C3, int TM, int NW>
-__global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaArgs a) {
-    constexpr int NT = NW * 64, LD1 = C1 + 4, LD2 = C2 + 4;
-    __shared__ __attribute__((aligned(16))) float smem[TM * (LD1 + LD2 + 4) + TM];
+// WPE = waves per SIMD the register budget is sized for (HIP's second __launch_bounds__ argument).  H1 and H2
+// share one LDS buffer (H2 is written after a barrier that ends the layer-2 MFMA reads), which brings a
+// work-group to ~36 KB: four 4-wave groups per CU, so the gather / tanh / barrier phases of one group hide
+// under the MFMA phases of the others.
+template <int C1, int C2, int C3, int TM, int NW, int WPE>
+__global__ __launch_bounds__(NW * 64, WPE) void sa_fwd_kernel(SaArgs a) {
+    constexpr int NT = NW * 64, LD1 = C1 + 4, LD2 = C2 + 4, LDM = LD1 > LD2 ? LD1 : LD2;
+    __shared__ __attribute__((aligned(16))) float smem[TM * (LDM + 4) + TM];
     float* H1 = smem;
-    float* H2 = H1 + TM * LD1;
-    float* Xz = H2 + TM * LD2;
+    float* H2 = smem;
+    float* Xz = smem + TM * LDM;
     int* Src = (int*)(Xz + TM * 4);
     using M3 = WaveMap<TM, C3, NW>;
     constexpr int NG3 = C2 / 8;
 
-    const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
+    const int tid0 = threadIdx.x;
     const float4* P2v = (const float4*)a.packed;
     const float4* P3v = (const float4*)(a.packed + (size_t)C1 * C2);
     const long ntiles = (a.G + TM / SA_NS - 1) / (TM / SA_NS);
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));                  // recompute lane-derived addresses per tile (no hoisted spills)
+        // Launder the thread id once per tile: every thread-derived address below is then recomputed inside the
+        // tile (a few VALU ops) instead of being hoisted to kernel entry as dozens of loop-invariant VGPRs
+        // that do not fit next to the accumulators and get spilled.
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int li = lane & 31, lh = lane >> 5;
-        sa_stage<TM, NT>(a, tile, Xz, Src);
+        sa_stage<TM, NT>(a, tile, tid, Xz, Src);
         __syncthreads();
-        sa_layer1<C1, TM, NT>(a, Xz, Src, H1);
+        sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
         __syncthreads();
-        sa_layer2<C1, C2, TM, NW>(H1, P2v, a.b2, wave, lane, H2);
+        sa_layer2<C1, C2, TM, NW, true>(H1, P2v, a.b2, wave, lane, H2);
         __syncthreads();
         // ---- layer 3 + max-pool over each 32-row block --------------------------------------
         const int wn = wave % M3::NBW, wm = wave / M3::NBW;
@@ -275,11 +287,11 @@ extern "C" int pm_sa_fwd_f32(const float* xyz, const float* centers, const int32
     {                                                                                                          \
         const long ntiles = (a.G + (TM_) / SA_NS - 1) / ((TM_) / SA_NS);                                       \
         const long grid = ntiles < (long)ncu * (WGCU_) ? ntiles : (long)ncu * (WGCU_);                         \
-        hipLaunchKernelGGL((sa_fwd_kernel<C1_, C2_, C3_, TM_, NW_>), dim3((unsigned)grid), dim3((NW_) * 64), 0, \
+        hipLaunchKernelGGL((sa_fwd_kernel<C1_, C2_, C3_, TM_, NW_, WGCU_>), dim3((unsigned)grid), dim3((NW_) * 64), 0, \
                            pm_stream(stream), a);                                                              \
     }
-    if (SA_CFG_A(C1, C2, C3)) SA_FWD_LAUNCH(64, 64, 128, 128, 4, 2)
-    else SA_FWD_LAUNCH(128, 128, 256, 64, 4, 2)
+    if (SA_CFG_A(C1, C2, C3)) SA_FWD_LAUNCH(64, 64, 128, 128, 4, 4)
+    else SA_FWD_LAUNCH(128, 128, 256, 64, 4, 4)
 #undef SA_FWD_LAUNCH
     PM_CHECK_LAUNCH();
     return PM_OK;
@@ -307,16 +319,23 @@ struct SaPart {
     static constexpr int O_DW2 = 0, O_DB2 = C2 * C1, O_DW3 = O_DB2 + C2, O_DB3 = O_DW3 + C3 * C2, O_DW1 = O_DB3 + C3,
                          N = O_DW1 + C1 * 4;
 };
-#define SA_BWD_MAXGRID 512
+#define SA_BWD_MAXGRID 1024
+#ifndef SA_A_BWD_WPE
+#define SA_A_BWD_WPE 3        // SA1-shaped level: 4-wave work-groups, this many per CU
+#endif
+#ifndef SA_B_BWD_NW
+#define SA_B_BWD_NW 8         // SA2-shaped level: one work-group per CU of 16 waves x 128 rows (or 8 x 64)
+#endif
+#define SA_B_BWD_TM (SA_B_BWD_NW * 8)
 
-template <int C1, int C2, int C3, int TM, int NW, int WGCU>
-__global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
+template <int C1, int C2, int C3, int TM, int NW, int WPE>
+__global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_kernel(SaArgs a) {
     constexpr int NT = NW * 64, LD1 = C1 + 4, LD2 = C2 + 4, NGRP = TM / SA_NS;
-    __shared__ __attribute__((aligned(16))) float smem[TM * (LD1 + 2 * LD2 + 4) + TM + 2 * (NGRP * C3 + 4)];
+    __shared__ __attribute__((aligned(16))) float smem[TM * (LD1 + LD2 + 4) + TM + 2 * (NGRP * C3 + 4)];
     float* H1 = smem;                        // H1, later dZ1 in place
     float* H2 = H1 + TM * LD1;
-    float* D = H2 + TM * LD2;                // dH2 -> dZ2
-    float* Xz = D + TM * LD2;
+    float* D = H2;                           // dZ2 overwrites H2 in place (after a barrier, element by element)
+    float* Xz = H2 + TM * LD2;
     int* Src = (int*)(Xz + TM * 4);
     float* Val = (float*)(Src + TM);
     int* Arg = (int*)(Val + NGRP * C3 + 4);      // +4: the operand stream reads one k-group past the end
@@ -325,7 +344,7 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
     using MH = WaveMap<TM, C1, NW>;          // dH1 output mapping
     constexpr int NGT = C2 / 8;
 
-    const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
     const float4* P2v = (const float4*)a.packed;
     const float4* P2Tv = (const float4*)(a.packed + (size_t)C1 * C2 + (size_t)C2 * C3);
     const float4* P3Tv = (const float4*)(a.packed + (size_t)C1 * C2 * 2 + (size_t)C2 * C3);
@@ -348,14 +367,15 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
     for (int j = 0; j < NBK; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accW2[j][r] = 0.f;
-    const int w2_m = wave % (C2 / 32), w2_n0 = (wave / (C2 / 32)) * NBK;
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));                    // see sa_fwd_kernel: recompute, don't hoist
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int li = lane & 31, lh = lane >> 5;
+        const int w2_m = wave % (C2 / 32), w2_n0 = (wave / (C2 / 32)) * NBK;
         // ---- P0: gather ------------------------------------------------------------------
-        sa_stage<TM, NT>(a, tile, Xz, Src);
+        sa_stage<TM, NT>(a, tile, tid, Xz, Src);
         for (int i = tid; i < NGRP * C3; i += NT) {
             const long g = tile * NGRP + i / C3;
             const int c = i % C3;
@@ -371,9 +391,9 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
         }
         __syncthreads();
         // ---- P1/P2: recompute H1, H2 ------------------------------------------------------------
-        if (!(SA_ABLATE & 64)) sa_layer1<C1, TM, NT>(a, Xz, Src, H1);
+        if (!(SA_ABLATE & 64)) sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
         __syncthreads();
-        if (!(SA_ABLATE & 32)) sa_layer2<C1, C2, TM, NW>(H1, P2v, a.b2, wave, lane, H2);
+        sa_layer2<C1, C2, TM, NW, false>(H1, P2v, a.b2, wave, lane, H2);
         __syncthreads();
         // ---- P3: structured layer-3 backward ---------------------------------------------------
         {
@@ -389,10 +409,17 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
                     accW3[4 * k4 + 1] = fmaf(v, h.y, accW3[4 * k4 + 1]);
                     accW3[4 * k4 + 2] = fmaf(v, h.z, accW3[4 * k4 + 2]);
                     accW3[4 * k4 + 3] = fmaf(v, h.w, accW3[4 * k4 + 3]);
+                    // keep at most 4 row reads in flight: hipcc otherwise hoists all KS/4 ds_read_b128 of both
+                    // groups (up to 128 VGPRs) above the FMAs and spills the persistent accumulators
+                    if ((k4 & 3) == 3) {
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 if (ks == 0) accb3 += v;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- P3b/P4: dH2 = dZ3 * W3 (sparse A built in registers), dZ2 = dH2 .* (1 - H2^2) -> D, db2 ----
         {
             const int wn = wave % M2::NBW, wm = wave / M2::NBW;
@@ -411,6 +438,7 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
             };
             if (!(SA_ABLATE & 1))
                 mfma_stream_fn<M2::MB, M2::NB, C3 / 8>(asel, P3Tv + (size_t)(wn * M2::NB) * (C3 / 8) * 64 + lane, acc);
+            __syncthreads();                         // every wave is done with its dW3 reads of H2 rows
 #pragma unroll
             for (int nb = 0; nb < M2::NB; ++nb) {
                 const int col = (wn * M2::NB + nb) * 32 + li;
@@ -489,7 +517,8 @@ __global__ __launch_bounds__(NW * 64, WGCU) void sa_bwd_kernel(SaArgs a) {
 
     // ---- write this work-group's partial sums ---------------------------------------------------------
     float* part = a.parts + (size_t)blockIdx.x * P::N;
-    const int lh0 = lane0 >> 5, li0 = lane0 & 31;
+    const int tid = tid0, wave = wave0, lh0 = lane0 >> 5, li0 = lane0 & 31;
+    const int w2_m = wave % (C2 / 32), w2_n0 = (wave / (C2 / 32)) * NBK;
 #pragma unroll
     for (int j = 0; j < NBK; ++j)
 #pragma unroll
@@ -580,20 +609,20 @@ extern "C" int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32
     a.G = (long)B * S; a.S = S; a.P = P; a.W3 = W3; a.dpooled = dpooled; a.lddp = lddp; a.dY = dY;
     a.parts = (float*)workspace;
     const int ncu = sa_cu_count();
-#define SA_BWD_LAUNCH(C1_, C2_, C3_, TM_, NW_, WGCU_)                                                              \
+#define SA_BWD_LAUNCH(C1_, C2_, C3_, TM_, NW_, WPE_, WGCU_)                                                        \
     {                                                                                                              \
         const long ntiles = (a.G + (TM_) / SA_NS - 1) / ((TM_) / SA_NS);                                           \
         long grid = (long)ncu * (WGCU_);                                                                           \
         if (grid > SA_BWD_MAXGRID) grid = SA_BWD_MAXGRID;                                                          \
         if (grid > ntiles) grid = ntiles;                                                                          \
-        hipLaunchKernelGGL((sa_bwd_kernel<C1_, C2_, C3_, TM_, NW_, WGCU_>), dim3((unsigned)grid), dim3((NW_) * 64), \
+        hipLaunchKernelGGL((sa_bwd_kernel<C1_, C2_, C3_, TM_, NW_, WPE_>), dim3((unsigned)grid), dim3((NW_) * 64), \
                            0, pm_stream(stream), a);                                                               \
         constexpr int n = SaPart<C1_, C2_, C3_>::N;                                                                \
         hipLaunchKernelGGL((sa_bwd_reduce_kernel<C1_, C2_, C3_>), dim3((n + 255) / 256), dim3(256), 0,             \
                            pm_stream(stream), a.parts, (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3);            \
     }
-    if (SA_CFG_A(C1, C2, C3)) SA_BWD_LAUNCH(64, 64, 128, 64, 4, 2)
-    else SA_BWD_LAUNCH(128, 128, 256, 64, 8, 1)
+    if (SA_CFG_A(C1, C2, C3)) SA_BWD_LAUNCH(64, 64, 128, 64, 4, SA_A_BWD_WPE, SA_A_BWD_WPE)
+    else SA_BWD_LAUNCH(128, 128, 256, SA_B_BWD_TM, SA_B_BWD_NW, (SA_B_BWD_NW / 4), 1)
 #undef SA_BWD_LAUNCH
     PM_CHECK_LAUNCH();
     return PM_OK;
