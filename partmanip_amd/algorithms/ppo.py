@@ -110,6 +110,10 @@ class ppo:
         self.use_graphs = (gr != "0") and is_mlp and self.overlap and cfg['sampler'] == 'sequential' and \
             self.lr_schedule == 'fixed' and self.sync is None
         self._graphs = {}
+        # neighbourhood tables (FPS centres + ball-query indices) once per rollout; PARTMANIP_GEOM_CACHE=0 recomputes
+        # them in every forward (A/B; identical results)
+        self.cache_geometry = os.environ.get("PARTMANIP_GEOM_CACHE", "1") != "0"
+        self._geom = None
 
         self.logger = logger
         self.total_envsteps = 0
@@ -203,6 +207,8 @@ class ppo:
         clip = tricks['use_grad_clip']
         mb = self._minibatch(views, indices, ('obs', 'actions', 'old_logp', 'adv', 'old_mu', 'old_sigma'), stage)
         B = mb['obs'].shape[0]
+        if self._geom is not None:
+            ac.actor.use_geometry(self._geom, indices)
         mu = ac.actor.hip_forward(mb['obs'])
         mom, cnt = None, 0.0
         if tricks['mini_adv_norm']:                          # ppo.py:329
@@ -229,6 +235,8 @@ class ppo:
         clip = tricks['use_grad_clip']
         mb = self._minibatch(views, indices, ('obs', 'returns', 'values'), stage)
         B = mb['obs'].shape[0]
+        if self._geom is not None:
+            ac.critic.use_geometry(self._geom, indices)
         value = ac.critic.hip_forward(mb['obs'])
         clip_mean = None
         if tricks['use_clipped_value_loss'] and sync:
@@ -285,6 +293,11 @@ class ppo:
         f = ac.flat()
         views = self._views()
         self._acc.zero_()
+        # backbones whose sampling / grouping depends on the coordinates only (PointNet2) build their
+        # neighbourhood tables once per rollout; every epoch of both networks then reuses them
+        self._geom = None
+        if self.cache_geometry and hasattr(ac.actor, 'precompute_geometry'):
+            self._geom = ac.actor.precompute_geometry(views['obs'])
         batch = self.storage.mini_batch_generator(self.num_mini_batches)
         lists_a = [self._epoch_plan(batch) for _ in range(self.n_updates)]          # ppo.py:315-316
         lists_c = [self._epoch_plan(batch) for _ in range(self.n_updates)]          # ppo.py:359-360
@@ -314,6 +327,7 @@ class ppo:
                 self._critic_step(f, views, ic, self._stage_c)
             self._pending_critic = []
 
+        self._geom = None
         acc = self._acc.tolist()                              # the only host sync of the update
         sum_surr, sum_kl, kl_max, count, sum_v, n_v = acc[:6]
         mean_value_loss = sum_v / (self.n_updates * len(lists_c[0]))

@@ -349,6 +349,26 @@ def test_pointnet2_ppo_iteration_runs():
     assert run.curr_iter == 2 and np.isfinite(float(run.log_dict["Train/surrogate_loss"]))
 
 
+@pytest.mark.parametrize("shape", [PN2_UNFUSED, PN2_FUSED])
+def test_pointnet2_neighbourhood_tables_reproduce_the_recomputed_forward(shape):
+    """precompute_geometry() + use_geometry() (what ppo.update does once per rollout) must give the bit-identical
+    forward as running FPS + ball query inside every forward, for slice and for index-tensor row selections."""
+    from partmanip_amd.algo_utils import ActorCritic
+    net = dict(name="PointNet2", activation="tanh", **shape)
+    torch.manual_seed(5)
+    ac = ActorCritic(3072, 10, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net), 0).to(DEV)
+    ac.flat()
+    obs = (torch.rand(12, 3072, device=DEV) * 2 - 1).contiguous()
+    tabs = ac.actor.precompute_geometry(obs, chunk=5)
+    ref = ac.actor.hip_forward(obs)
+    ac.actor.use_geometry(tabs, (4, 6))
+    assert torch.equal(ac.actor.hip_forward(obs[4:10]), ref[4:10])
+    rows = torch.tensor([7, 0, 11, 3])
+    ac.actor.use_geometry(tabs, rows)
+    assert torch.equal(ac.actor.hip_forward(obs[rows.to(DEV)].contiguous()), ref[rows.to(DEV)])
+    assert torch.equal(ac.actor.hip_forward(obs), ref)                       # tables are consumed by ONE forward
+
+
 def test_resume_from_reference_checkpoint_and_continue():
     """`ppo(... resume=<checkpoint written by the reference>)` restores model + both optimisers on the GPU, and one
     more HIP update from there follows the CPU oracle continuing from the same state."""
