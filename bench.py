@@ -140,6 +140,42 @@ def cpu_baseline(w, rollout_cpu, sd_cpu, cfg):
                        f"{cfg['n_updates']} epochs x {T * N} samples; {ncores} torch threads")
 
 
+def build_runner(w, cfg, device, rank):
+    """Runner + one synthetic rollout produced by the freshly initialised policy (ratio ~ 1, KL ~ 0) + the
+    timed step: restore the initial policy / optimiser state, then the reference's `learn` window."""
+    from partmanip_amd.algorithms import ppo
+    from partmanip_amd.feeder import FeederEnv, ScreenLogger
+    torch.manual_seed(1234)                            # identical initial weights on every rank
+    env = FeederEnv(w["N"], {"obs": w["O"]}, w["A"], device, seed=1234 + rank)
+    run = ppo(env, cfg, ScreenLogger(quiet=True))
+    ac, st = run.actor_critic, run.storage
+    obs = env.reset()["obs"]
+    for _ in range(w["T"]):
+        actions, logp, values, mu, sigma = ac.random_act_cri(obs)
+        nxt, rew, done, _ = env.step(actions)
+        st.add_transitions(obs, actions, rew, done, env.reset_succ, values, logp, mu, sigma)
+        obs = nxt["obs"]
+    last_values = ac.cri(obs)
+    f = ac.flat()
+    snap = dict(a=f["actor"].clone(), c=f["critic"].clone())
+
+    def restore():                                     # every timed step starts from the same policy
+        f["actor"].copy_(snap["a"])
+        f["critic"].copy_(snap["c"])
+        for opt in (run.optimizer_actor, run.optimizer_critic):
+            opt.m.zero_()
+            opt.v.zero_()
+            opt.state_dev.zero_()
+
+    def step():
+        restore()
+        st.step = w["T"]
+        run.log_dict = {}
+        run.learn(last_values)
+
+    return run, ac, st, last_values, step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,38 +210,7 @@ def main():
         w["net"] = dict(w["net"], precision=args.precision)
         w["name"] = w["name"] + "_" + args.precision
     cfg = make_cfg(w, device)
-
-    from partmanip_amd.algorithms import ppo
-    from partmanip_amd.feeder import FeederEnv, ScreenLogger
-    torch.manual_seed(1234)                            # identical initial weights on every rank
-    env = FeederEnv(w["N"], {"obs": w["O"]}, w["A"], device, seed=1234 + rank)
-    run = ppo(env, cfg, ScreenLogger(quiet=True))
-    ac, st = run.actor_critic, run.storage
-
-    # ---- one synthetic rollout, produced by the freshly initialised policy (ratio ~ 1, KL ~ 0) ----
-    obs = env.reset()["obs"]
-    for _ in range(w["T"]):
-        actions, logp, values, mu, sigma = ac.random_act_cri(obs)
-        nxt, rew, done, _ = env.step(actions)
-        st.add_transitions(obs, actions, rew, done, env.reset_succ, values, logp, mu, sigma)
-        obs = nxt["obs"]
-    last_values = ac.cri(obs)
-    f = ac.flat()
-    snap = dict(a=f["actor"].clone(), c=f["critic"].clone())
-
-    def restore():                                     # every timed step starts from the same policy
-        f["actor"].copy_(snap["a"])
-        f["critic"].copy_(snap["c"])
-        for opt in (run.optimizer_actor, run.optimizer_critic):
-            opt.m.zero_()
-            opt.v.zero_()
-            opt.state_dev.zero_()
-
-    def step():
-        restore()
-        st.step = w["T"]
-        run.log_dict = {}
-        run.learn(last_values)
+    run, ac, st, last_values, step = build_runner(w, cfg, device, rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -218,6 +223,9 @@ def main():
     dominant = "pointnet_enc_fwd" if args.workload == "vision" else None
     if dominant:
         ops.TIMER.enable(dominant, "pointnet_enc_bwd")
+    SA_LEVELS = {"64x64x128": (64, 64, 128, 256), "128x128x256": (128, 128, 256, 64)}     # C1, C2, C3, groups per cloud
+    if args.workload == "vision_pn2":
+        ops.TIMER.enable(*[f"sa_{d}_{k}" for d in ("fwd", "bwd") for k in SA_LEVELS])
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -255,6 +263,21 @@ def main():
         bwd = ops.TIMER.mean_ms("pointnet_enc_bwd")
         if bwd:
             out["roofline"]["enc_bwd_mean_ms"] = bwd[0]
+    if args.workload == "vision_pn2":
+        # the four fused set-abstraction kernels; `achieved` counts the MFMA flops each launch EXECUTES
+        # (fwd: layers 2-3; bwd: layer-2 recompute + dH2 + dW2 + dH1) on 2048 clouds
+        kern = {}
+        for k, (c1, c2, c3, S) in SA_LEVELS.items():
+            rows = 2048.0 * S * 32
+            for d, macs in (("fwd", c1 * c2 + c2 * c3), ("bwd", 3 * c1 * c2 + c2 * c3)):
+                t = ops.TIMER.mean_ms(f"sa_{d}_{k}")
+                if t:
+                    kern[f"sa_{d}_{k}"] = dict(mean_launch_ms=t[0], launches=t[1], tflops=2 * rows * macs / (t[0] * 1e-3) / 1e12)
+        if kern:
+            name = max(kern, key=lambda n: kern[n]["mean_launch_ms"] * kern[n]["launches"])
+            out["roofline"] = dict(bound="mfma", kernel=name, achieved=kern[name]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
+                                   unit="TFLOP/s", frac=kern[name]["tflops"] / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                                   kernels=kern)
     if args.workload == "vision" and args.precision == "f32" and world == 1:
         # the same workload on the opt-in split-bf16 encoder forward (reported next to, not instead of, the fp32 line)
         ac.actor.precision = ac.critic.precision = "bf16x3"
@@ -270,6 +293,21 @@ def main():
             value=w["N"] * w["T"] / dt3, unit="env-steps/s", ms_per_step=dt3 * 1e3,
             note="pm_pointnet_enc_fwd_bf3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on bf16 MFMAs, fp32 accumulate; "
                  "~1e-5 relative; passes the golden vision-PPO cases at the fp32 path's tolerances; backward stays fp32"))
+        # ... and through the PointNet++ (SSG) plug-in backbone BASELINE.json's config text names: FPS + ball query
+        # once per rollout, fused set-abstraction kernels (pm_sa_fwd_f32 / pm_sa_bwd_f32)
+        w2 = dict(WORKLOADS["vision_pn2"])
+        _, _, _, _, step2 = build_runner(w2, make_cfg(w2, device), device, rank)
+        step2()
+        fence()
+        t1 = time.perf_counter()
+        step2()
+        fence()
+        dt2 = time.perf_counter() - t1
+        out["optional_paths"]["pointnet2_ssg_backbone"] = dict(
+            value=w2["N"] * w2["T"] / dt2, unit="env-steps/s", ms_per_step=dt2 * 1e3, workload=w2["name"],
+            note="same rollouts, network.name = PointNet2 (npoints 256/64, radii 0.2/0.4, 32 samples, mlps 64-64-128 / "
+                 "128-128-256 / 256-512); fp32")
+        del step2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = lambda t: t.detach().cpu()
         roll = dict(observations=cpu(st.observations), actions=cpu(st.actions), values=cpu(st.values),

@@ -390,7 +390,7 @@ def sa_fwd(xyz, centers, idx, Y, w1, b1, b2, b3, packed, dims, pooled):
     _f32c(xyz, "xyz")
     _f32c(centers, "centers")
     arg = torch.empty(B * S, C3, dtype=torch.int32, device=xyz.device)
-    with TIMER.bracket("sa_fwd"):
+    with TIMER.bracket(f"sa_fwd_{C1}x{C2}x{C3}"):
         check(lib.pm_sa_fwd_f32(_ptr(xyz), _ptr(centers), _ptr(idx), _ptr(Y), B, P, S, ns,
                                 _ptr(w1), _rows(w1, "w1"), _ptr(b1), _ptr(b2), _ptr(b3), _ptr(packed), C1, C2, C3,
                                 _ptr(pooled), _rows(pooled, "pooled"), _ptr(arg), _stream()), "pm_sa_fwd_f32")
@@ -404,7 +404,7 @@ def sa_bwd(xyz, centers, idx, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpoo
     C1, C2, C3 = dims
     _f32c(w3, "w3")
     w = ws.get(lib.pm_sa_bwd_workspace_bytes(C1, C2, C3))
-    with TIMER.bracket("sa_bwd"):
+    with TIMER.bracket(f"sa_bwd_{C1}x{C2}x{C3}"):
         check(lib.pm_sa_bwd_f32(_ptr(xyz), _ptr(centers), _ptr(idx), _ptr(Y), B, P, S, ns, _ptr(w1), _rows(w1, "w1"),
                                 _ptr(b1), _ptr(b2), _ptr(w3), _ptr(packed), C1, C2, C3, _ptr(pooled),
                                 _rows(pooled, "pooled"), _ptr(arg), _ptr(dpooled), _rows(dpooled, "dpooled"), _ptr(dw1),

@@ -37,10 +37,11 @@ for name, P, S, radius, dims, cf in LEVELS:
             arg = ops.sa_fwd(xyz, centers, idx_g, Y, W1, b1, b2, b3, packed, dims, pooled)
             ops.sa_bwd(xyz, centers, idx_g, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws)
     run(2)
-    ops.TIMER.enable("sa_fwd", "sa_bwd")
+    nf, nb = f"sa_fwd_{C1}x{C2}x{C3}", f"sa_bwd_{C1}x{C2}x{C3}"
+    ops.TIMER.enable(nf, nb)
     run(5)
-    f = ops.TIMER.mean_ms("sa_fwd")[0]
-    b = ops.TIMER.mean_ms("sa_bwd")[0]
+    f = ops.TIMER.mean_ms(nf)[0]
+    b = ops.TIMER.mean_ms(nb)[0]
     ops.TIMER.disable()
     rows = B * S * 32
     ff = 2.0 * rows * (C1 * C2 + C2 * C3) / 1e9                 # MFMA flops fwd
