@@ -369,6 +369,39 @@ def test_pointnet2_neighbourhood_tables_reproduce_the_recomputed_forward(shape):
     assert torch.equal(ac.actor.hip_forward(obs), ref)                       # tables are consumed by ONE forward
 
 
+@pytest.mark.parametrize("sampler", ["sequential", "random"])
+def test_ppo_update_pointnet2_follows_the_cpu_restatement(sampler):
+    """Whole `ppo.update` through the PointNet2 backbone (fused SA kernels + neighbourhood tables built once per
+    rollout) against oracle/ref_cpu.py's ppo_update on the same rollout.  Parity unpinned (no PointNet2 in the
+    reference): this checks the HIP path against this build's own restatement, same tolerances as the golden cases."""
+    from partmanip_amd.algorithms import ppo
+    c = cases.case_copy(cases.PPO_CASES["ppo_pn_maxmean"])
+    fx = load_fixture("ppo_pn_maxmean")
+    c["net"] = dict(name="PointNet2", activation="tanh", **PN2_FUSED)
+    c["desired_kl"] = 10.0                 # the fixture's old policy is a PointNet: keep the KL early-stop out of the way
+    c["sampler"] = sampler
+    with tempfile.TemporaryDirectory() as d:
+        torch.manual_seed(3)
+        run = ppo(FakeEnv(c["N"], {"normal_state": c["O"]}, c["A"]), ppo_cfg(c, device=DEV), FakeLogger(d))
+    assert run.actor_critic.actor._fused == [True, True]
+    p = {k: v.detach().cpu().clone() for k, v in run.actor_critic.state_dict().items()}
+    fill_storage(run, c, fx)
+    run.storage.compute_returns(t(fx["last_values"]).to(DEV), c["gamma"], c["lam"])
+    torch.manual_seed(c["seed"])
+    run.log_dict = {}
+    run.update(c["it"])
+    st = ppo_rollout(c, fx)
+    st["returns"], st["advantages"] = run.storage.returns.cpu(), run.storage.advantages.cpu()
+    keys = ("observations", "actions", "values", "returns", "actions_log_prob", "advantages", "mu", "sigma")
+    torch.manual_seed(c["seed"])
+    out = R.ppo_update(p, {k: st[k] for k in keys}, ppo_cfg(c), c["it"])
+    assert run.log_dict["Train/kl_update_count"] == out["log"]["Train/kl_update_count"]
+    for k in ("value_function_loss", "surrogate_loss", "kl", "kl_max"):
+        np.testing.assert_allclose(float(run.log_dict["Train/" + k]), float(out["log"]["Train/" + k]), rtol=5e-4,
+                                   atol=5e-6, err_msg=k)
+    check_params(flat_state(run.actor_critic.state_dict()), flat_state(p), 1, c["lr"], len(out["loss_trace"]))
+
+
 def test_resume_from_reference_checkpoint_and_continue():
     """`ppo(... resume=<checkpoint written by the reference>)` restores model + both optimisers on the GPU, and one
     more HIP update from there follows the CPU oracle continuing from the same state."""
