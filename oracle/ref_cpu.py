@@ -158,7 +158,7 @@ def net_forward(p, prefix, net_cfg, x, proprio_shape=0):
     if net_cfg["name"] == "MLP":
         return mlp_forward(p, prefix, net_cfg, x)
     if net_cfg["name"] == "PointNet":
-        return pointnet_forward(p, prefix, net_cfg, x, proprio_shape)
+        return pointnet_forward(p, prefix, net_cfg, x, proprio_shape, point_num=int(net_cfg.get("point_num", 1024)))
     if net_cfg["name"] == "PointNet2":
         return pointnet2_forward(p, prefix, net_cfg, x, proprio_shape)
     raise ValueError(net_cfg["name"])

@@ -137,7 +137,7 @@ class PointNet(_HipNet):
     pooling over the 1024 points -> (+proprio) -> 128 -> 32 -> out.  The per-point MLP and
     the pooling are ONE HIP kernel (pm_pointnet_enc_fwd_f32); the (B,1024,512) activation never
     exists.  `point_num` stays 1024 as in the reference (network.py:146) unless
-    net_cfg['point_num'] overrides it (multiple of 64, <= 1024)."""
+    net_cfg['point_num'] overrides it (multiple of 64, <= 4096: BASELINE cfg 5's 4096-point clouds)."""
 
     def __init__(self, input_dim, output_dim, net_cfg, proprio_shape):
         super().__init__()

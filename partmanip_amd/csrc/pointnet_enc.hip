@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
     float* Us = Xs0 + 2 * BT * PN_MAXC;                 // [256]  u[b,:]/P
     float* Gm = Us + PN_C2;                             // [512]  dmax[b,:]
     int* keys = (int*)(Gm + PN_C3);                     // [512]  sorted (point<<9 | channel)
-    unsigned short* offs = (unsigned short*)(keys + PN_C3);   // [P+1 <= 1025] first key index of each point
+    unsigned short* offs = (unsigned short*)(keys + PN_C3);   // [P/8+1 <= 1025] first key index of each wave's row block
     float* wred = (float*)(keys + PN_C3) + 520;         // [4][256] cross-wave reductions
     double* red = (double*)(wred + 4 * PN_C2);
 
@@ -425,9 +425,9 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
 #if !(PN_ABLATE & 16)
         bitonic_sort_512(keys);                           // by point, then channel: deterministic order
 #endif
-        for (int p = tid; p <= P; p += 256) {            // offs[p] = #keys with point < p (binary search)
+        for (int p = tid; p <= P / (BT / 4); p += 256) {   // offs[i] = #keys with point < i * (rows per wave)
             int lo = 0, hi = PN_C3;
-            const int target = p << 9;
+            const int target = (p * (BT / 4)) << 9;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (keys[mid] < target) lo = mid + 1; else hi = mid;
@@ -454,8 +454,8 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
             int base = 0;
             for (int w2 = 0; w2 < wave; ++w2) base += wtot[w2];
             const int s1 = base + v - 1, s0 = s1 - f1;
-            keys[e0] |= s0 << 19;
-            keys[e1] |= s1 << 19;
+            keys[e0] |= s0 << 22;
+            keys[e1] |= s1 << 22;
             slotmap[(long)b * PN_C3 + (keys[e0] & 511)] = s0;
             slotmap[(long)b * PN_C3 + (keys[e1] & 511)] = s1;
         }
@@ -490,8 +490,13 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                 constexpr int RPW = BT / 4;
                 const int p0 = tile * BT + wave * RPW;
                 const float4 u4 = *(const float4*)(Us + 4 * lane);
-                const int e_end = offs[p0 + RPW];
-                int e = offs[p0];
+                const int e_end = offs[p0 / RPW + 1];
+                int e = offs[p0 / RPW];
+                // Row boundaries inside this wave's run of sorted keys (slot<<22 | point<<9 | channel) come from
+                // one ballot per row over the run (lane j looks at entry e + j) -- wave-uniform, no per-point
+                // table, so clouds up to 4096 points fit the same LDS; runs longer than 64 entries (rare) search.
+                const int e0 = e, span = e_end - e0;
+                const int pj = (lane < span) ? ((keys[e0 + lane] >> 9) & 0x1FFF) : 0x7FFFFFFF;
                 int c_next = 0;
                 float4 w_next = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (e < e_end) {
@@ -503,9 +508,20 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                     const float4 h = *(const float4*)hrow;
                     h2s.x += h.x; h2s.y += h.y; h2s.z += h.z; h2s.w += h.w;
                     float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int row_end = offs[p0 + rr + 1];
+                    int row_end;
+                    if (span <= 64) {
+                        row_end = e0 + __popcll(__ballot(pj <= p0 + rr));
+                    } else {
+                        int lo = e, hi = e_end;
+                        const int target = (p0 + rr + 1) << 9;
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if ((keys[mid] & 0x3FFFFF) < target) lo = mid + 1; else hi = mid;
+                        }
+                        row_end = lo;
+                    }
                     if (e < row_end)                                  // this point is some channel's arg-max
-                        *(float4*)(Hg + ((long)b * PN_C3 + (keys[e] >> 19)) * PN_C2 + 4 * lane) = h;
+                        *(float4*)(Hg + ((long)b * PN_C3 + (keys[e] >> 22)) * PN_C2 + 4 * lane) = h;
                     for (; e < row_end; ++e) {
                         const int c = c_next;
                         const float4 w3 = w_next;
@@ -638,7 +654,7 @@ __global__ __launch_bounds__(512, 4) void pn_bwd8_kernel(
     float* Us = Xs + BT * PN_MAXC;                      // [256]  u[b,:]/P
     float* Gm = Us + PN_C2;                             // [512]  dmax[b,:]
     int* keys = (int*)(Gm + PN_C3);                     // [512]  sorted (slot<<19 | point<<9 | channel)
-    unsigned short* offs = (unsigned short*)(keys + PN_C3);   // [P+1 <= 1025]
+    unsigned short* offs = (unsigned short*)(keys + PN_C3);   // [P/RPW+1 <= 1025]
     double* red = (double*)((float*)(keys + PN_C3) + 520);    // 16 doubles
 
     const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
@@ -680,9 +696,9 @@ __global__ __launch_bounds__(512, 4) void pn_bwd8_kernel(
             }
         }
         __syncthreads();
-        for (int p = tid; p <= P; p += NT) {             // offs[p] = #keys with point < p
+        for (int p = tid; p <= P / RPW; p += NT) {       // offs[i] = #keys with point < i * RPW
             int lo = 0, hi = PN_C3;
-            const int target = p << 9;
+            const int target = (p * RPW) << 9;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (keys[mid] < target) lo = mid + 1; else hi = mid;
@@ -705,7 +721,7 @@ __global__ __launch_bounds__(512, 4) void pn_bwd8_kernel(
             int base = 0;
             for (int w2 = 0; w2 < wave; ++w2) base += wtot[w2];
             const int sl = base + v - 1;
-            keys[tid] |= sl << 19;
+            keys[tid] |= sl << 22;
             slotmap[(long)b * PN_C3 + (keys[tid] & 511)] = sl;
         }
         float4 h2s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -730,8 +746,13 @@ __global__ __launch_bounds__(512, 4) void pn_bwd8_kernel(
             {
                 const int p0 = tile * BT + wave * RPW;
                 const float4 u4 = *(const float4*)(Us + 4 * lane);
-                const int e_end = offs[p0 + RPW];
-                int e = offs[p0];
+                const int e_end = offs[p0 / RPW + 1];
+                int e = offs[p0 / RPW];
+                // Row boundaries inside this wave's run of sorted keys (slot<<22 | point<<9 | channel) come from
+                // one ballot per row over the run (lane j looks at entry e + j) -- wave-uniform, no per-point
+                // table, so clouds up to 4096 points fit the same LDS; runs longer than 64 entries (rare) search.
+                const int e0 = e, span = e_end - e0;
+                const int pj = (lane < span) ? ((keys[e0 + lane] >> 9) & 0x1FFF) : 0x7FFFFFFF;
                 int c_next = 0;
                 float4 w_next = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (e < e_end) {
@@ -744,9 +765,20 @@ __global__ __launch_bounds__(512, 4) void pn_bwd8_kernel(
                     const float4 h = *(const float4*)hrow;
                     h2s.x += h.x; h2s.y += h.y; h2s.z += h.z; h2s.w += h.w;
                     float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int row_end = offs[p0 + rr + 1];
-                    if (e < row_end)
-                        *(float4*)(Hg + ((long)b * PN_C3 + (keys[e] >> 19)) * PN_C2 + 4 * lane) = h;
+                    int row_end;
+                    if (span <= 64) {
+                        row_end = e0 + __popcll(__ballot(pj <= p0 + rr));
+                    } else {
+                        int lo = e, hi = e_end;
+                        const int target = (p0 + rr + 1) << 9;
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if ((keys[mid] & 0x3FFFFF) < target) lo = mid + 1; else hi = mid;
+                        }
+                        row_end = lo;
+                    }
+                    if (e < row_end)                                  // this point is some channel's arg-max
+                        *(float4*)(Hg + ((long)b * PN_C3 + (keys[e] >> 22)) * PN_C2 + 4 * lane) = h;
                     for (; e < row_end; ++e) {
                         const int c = c_next;
                         const float4 w3 = w_next;
@@ -976,7 +1008,7 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
                                        float* dW3, float* db3, void* workspace, size_t workspace_bytes,
                                        void* stream) {
     PM_REQUIRE(x && W1 && b1 && b2 && W3 && packed && dfeat && argmax && dW1 && db1 && dW2 && db2 && dW3 && db3);
-    PM_REQUIRE(B > 0 && P > 0 && P % PN_TM == 0 && P <= 1024 && C >= 1 && C <= PN_MAXC && ldx >= (long)P * C);
+    PM_REQUIRE(B > 0 && P > 0 && P % PN_TM == 0 && P <= 4096 && C >= 1 && C <= PN_MAXC && ldx >= (long)P * C);
     PM_REQUIRE(ldf >= PN_C3 * (max_mean ? 2 : 1));
     PM_REQUIRE(!sub_mean || C >= 3);
     if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)W3 & 15) != 0 || ((uintptr_t)workspace & 255) != 0) return PM_EALIGN;

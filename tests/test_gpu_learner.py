@@ -148,23 +148,27 @@ def test_ppo_checkpoint_roundtrip():
 
 
 # ------------------------------------------------------------------------------- PointNet encoder
-@pytest.mark.parametrize("B,C,max_mean,sub_mean,proprio", [(6, 3, True, False, 0), (5, 3, False, False, 0),
-                                                           (4, 4, True, True, 0), (3, 3, True, True, 7), (2, 6, True, False, 0),
-                                                           (300, 3, True, False, 0)])
-def test_pointnet_forward_backward(B, C, max_mean, sub_mean, proprio):
+@pytest.mark.parametrize("B,C,max_mean,sub_mean,proprio,P", [
+    (6, 3, True, False, 0, 1024), (5, 3, False, False, 0, 1024), (4, 4, True, True, 0, 1024), (3, 3, True, True, 7, 1024),
+    (2, 6, True, False, 0, 1024), (300, 3, True, False, 0, 1024),
+    # generalised point_num (the reference hard-codes 1024, network.py:146)
+    (3, 3, True, True, 5, 4096), (2, 4, False, False, 0, 2048), (3, 3, True, False, 0, 320)])
+def test_pointnet_forward_backward(B, C, max_mean, sub_mean, proprio, P):
     from partmanip_amd.algo_utils import ActorCritic
     net = dict(name="PointNet", activation="tanh", max_mean=max_mean, sub_mean=sub_mean)
-    O = 1024 * C + proprio
+    if P != 1024:
+        net["point_num"] = P
+    O = P * C + proprio
     torch.manual_seed(B * 10 + C)
     ac = ActorCritic(O, 10, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net), proprio).to(DEV)
     f = ac.flat()
     g = torch.Generator().manual_seed(B)
-    pts = torch.rand(B, 1024, C, generator=g) * 2 - 1 + (torch.rand(B, 1, C, generator=g) - 0.5)
+    pts = torch.rand(B, P, C, generator=g) * 2 - 1 + (torch.rand(B, 1, C, generator=g) - 0.5)
     if B <= 8:
         pts[:, 100] = pts[:, 7]                               # duplicate points: max ties -> lowest index wins
     x = torch.cat([pts.reshape(B, -1), torch.randn(B, proprio, generator=g)], dim=1).contiguous()
     p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in ac.state_dict().items()}
-    out_ref = R.pointnet_forward(p, "actor", net, x.clone(), proprio)
+    out_ref = R.pointnet_forward(p, "actor", net, x.clone(), proprio, point_num=P)
     dy = torch.randn(B, 10, generator=g)
     names = [k for k in p if k.startswith("actor.")]
 
@@ -173,12 +177,13 @@ def test_pointnet_forward_backward(B, C, max_mean, sub_mean, proprio):
     assert rel_err(out, out_ref.detach()) < 2e-5
     # gradient reference with the pooling index pinned to the kernel's (checked against torch.max's below
     # wherever the top-2 gap is resolvable in fp32): see oracle.pointnet_forward's docstring
-    out_pin = R.pointnet_forward(p, "actor", net, x.clone(), proprio, argmax_override=ac.actor._saved[2].cpu().long())
+    out_pin = R.pointnet_forward(p, "actor", net, x.clone(), proprio, point_num=P,
+                                 argmax_override=ac.actor._saved[2].cpu().long())
     assert rel_err(out_pin.detach(), out_ref.detach()) < 1e-6
     grads_ref = torch.autograd.grad((out_pin * dy).sum(), [p[k] for k in names])
     # pooled features + argmax against the oracle's own intermediate
     with torch.no_grad():
-        pc = x[:, :1024 * C].reshape(B, 1024, C)
+        pc = x[:, :P * C].reshape(B, P, C)
         if sub_mean:
             pc = torch.cat([pc[..., :3] - pc[..., :3].mean(dim=1, keepdim=True), pc[..., 3:]], dim=-1)
         h = torch.tanh(torch.nn.functional.linear(pc, p["actor.mlp.0.weight"], p["actor.mlp.0.bias"]))
@@ -281,6 +286,37 @@ def test_dagger_small_buffer_is_noop(tmp_path, monkeypatch):
     st = RolloutStorage(4, 3, 8, 2, DEV, sampler="random", tea_obs_shape=5, max_length=10)
     st.add_transitions_dagger(torch.ones(4, 8, device=DEV), torch.ones(4, 5, device=DEV))
     assert st.cur_buf_size == 4 and st.mix_buf_ind == 4
+
+
+def test_pointnet_backward_when_one_point_wins_every_channel():
+    """Degenerate clouds: all points identical (every channel's arg-max is point 0 -> a 512-entry run inside one
+    8-row block: the backward's >64-entry search path) and a cloud whose maxima all sit in its last point."""
+    from partmanip_amd.algo_utils import ActorCritic
+    net = dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False)
+    torch.manual_seed(21)
+    ac = ActorCritic(3072, 10, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net), 0).to(DEV)
+    f = ac.flat()
+    g = torch.Generator().manual_seed(4)
+    pts = torch.rand(3, 1024, 3, generator=g) * 0.02
+    pts[0] = pts[0, :1]                                        # constant cloud
+    pts[1, :1023] = pts[1, :1]                                 # constant except the last point ...
+    pts[1, 1023] = torch.tensor([5.0, -4.0, 3.0])              # ... which saturates (most of) the maxima
+    x = pts.reshape(3, -1).contiguous()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in ac.state_dict().items()}
+    out = ac.actor.hip_forward(x.to(DEV))
+    am = ac.actor._saved[2].cpu().long()
+    assert (am[0] == 0).all() and ((am[1] == 0) | (am[1] == 1023)).all() and (am[1] == 1023).sum() > 64
+    out_pin = R.pointnet_forward(p, "actor", net, x.clone(), 0, argmax_override=am)
+    assert rel_err(out, out_pin.detach()) < 2e-5
+    dy = torch.randn(3, 10, generator=g)
+    names = [k for k in p if k.startswith("actor.")]
+    grads_ref = torch.autograd.grad((out_pin * dy).sum(), [p[k] for k in names])
+    ac.actor.hip_backward(dy.to(DEV))
+    off = 0
+    for k, v in ac.actor.named_parameters():
+        got = f["grad_actor"][off:off + v.numel()].view(v.shape)
+        off += v.numel()
+        assert rel_err(got, grads_ref[names.index("actor." + k)]) < 2e-4, k
 
 
 # ------------------------------------------------------------------------------- PointNet++ backbone
