@@ -216,6 +216,14 @@ int pm_maxpool_rows_bwd_f32(const float* dout, long lddo, const int32_t* arg, lo
                             const float* y_tanh /* NULL, or the pooled tanh outputs: dx *= 1-y^2 */, float* dx,
                             void* stream);
 
+/* ------------------------------------------------------------------ depth images -> world-frame cloud
+ * utils/depth2tsdf.py:142-157 (TSDFVolume.depth2pc before the sampling at :160): pinhole back-projection of
+ * depth (B, M, H, W), rigid transform with cam_pose (M, 4, 4 row-major, camera -> world), points outside the
+ * OPEN box (lo, hi) zeroed.  out (B, M*H*W, 3).  lo / hi are HOST pointers to 3 floats.  K12 then samples it. */
+int pm_depth_backproject_f32(const float* depth, int B, int M, int H, int W, const float* cam_pose, float fx,
+                             float fy, float cx, float cy, const float* lo, const float* hi, float* out,
+                             void* stream);
+
 /* ------------------------------------------------------------------ K15 fused set-abstraction level
  * One PointNet++ SA level (north_star; not in the reference snapshot, README.md:23,30) as one forward and
  * one backward kernel: ball-query groups of `nsample` = 32 rows [xyz[idx]-centre | feat[idx]] -> Linear C1,

@@ -458,6 +458,43 @@ def fps(points, K, lengths=None):
     return out
 
 
+def depth2pc(depth, cam_pose, cam_intr, size, vol_origin, K=1024, return_world=False):
+    """utils/depth2tsdf.py:136-173 `TSDFVolume.depth2pc`: depth (b,m,h,w) -> (b,K,3).  fp32 op by op in the
+    order of the reference's tensor expression -- PINNED bit for bit to the reference's own world cloud
+    (fixture generated by tests/golden/make_golden.py) -- then `fps` above in place of
+    pytorch3d.ops.sample_farthest_points (absent here: PARITY UNPINNED for the sampling)."""
+    f = np.float32
+    depth = np.asarray(depth, dtype=f)
+    b, m, h, w = depth.shape
+    pose = np.asarray(cam_pose, dtype=f)
+    cx, cy = f(cam_intr[0][2]), f(cam_intr[1][2])
+    fx, fy = f(cam_intr[0][0]), f(cam_intr[1][1])
+    pt2 = depth.reshape(b, m, h * w)
+    xmap = np.repeat(np.arange(h), w).astype(f)                  # row index of each pixel (depth2tsdf.py:64)
+    ymap = np.tile(np.arange(w), h).astype(f)                    # column index (depth2tsdf.py:65)
+    pt0 = ((ymap - cx) * pt2).astype(f) / fx
+    pt1 = ((xmap - cy) * pt2).astype(f) / fy
+    R, tr = pose[:, :3, :3], pose[:, :3, 3]
+    world = np.empty((b, m, h * w, 3), dtype=f)
+    def fma(a, bb, c):                                           # exact product in fp64, one rounding to fp32
+        return (a.astype(np.float64) * bb.astype(np.float64) + c.astype(np.float64)).astype(f)
+
+    for d in range(3):
+        # cld @ R^T: torch.bmm's K=3 inner product is the fused chain fma(p2,r2, fma(p1,r1, p0*r0)) -- checked
+        # bit for bit against the reference's own output (tests/golden/depth2pc_small.npz); then + t
+        r0, r1, r2 = (np.broadcast_to(R[None, :, d, k, None], pt0.shape) for k in range(3))
+        acc = fma(pt2, r2, fma(pt1, r1, (pt0 * r0).astype(f)))
+        world[..., d] = (acc + tr[None, :, d, None]).astype(f)
+    world = world.reshape(b, m * h * w, 3)
+    lo = np.asarray(vol_origin, dtype=f)
+    hi = (f(size) + lo).astype(f)
+    valid = ((world < hi) & (world > lo)).sum(axis=-1, keepdims=True) == 3
+    world = (world * valid).astype(f)
+    idx = fps(world, K)
+    out = np.take_along_axis(world, idx[..., None].repeat(3, axis=-1), axis=1)
+    return (out, world, idx) if return_world else out
+
+
 def ball_query(xyz, centers, radius, nsample):
     """PointNet++ ball query: for each centre the first `nsample` point indices (ascending
     index order) with squared distance < radius^2, padded with the first hit; if no point

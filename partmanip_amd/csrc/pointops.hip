@@ -363,3 +363,49 @@ extern "C" int pm_maxpool_rows_bwd_f32(const float* dout, long lddo, const int32
 }
 
 extern "C" int pm_version(void) { return 100; }
+
+// ---------------------------------------------------------------------------------- depth -> world cloud
+// utils/depth2tsdf.py:142-157 (`TSDFVolume.depth2pc` before the sampling): back-project every pixel of
+// every view with the pinhole intrinsics, move it to world coordinates with the view's pose, and zero
+// the points outside the open workspace box (lo, hi) so that farthest point sampling (K12) sees them as one
+// point at the origin.  Pure streaming: 4 B in, 12 B out per pixel.  Rounding follows the reference's tensor
+// expression bit for bit (checked against its own output, tests/golden/depth2pc_small.npz):
+//   p0 = ((col - cx) * z) / fx,  p1 = ((row - cy) * z) / fy,  p2 = z   (each op rounded)
+//   w[d] = fma(p2, R[d][2], fma(p1, R[d][1], p0 * R[d][0])) + t[d]      (torch.bmm's K=3 inner product)
+__global__ __launch_bounds__(256) void depth_backproject_kernel(const float* __restrict__ depth, long n_per_env,
+                                                                 int HW, int W, const float* __restrict__ pose,
+                                                                 float fx, float fy, float cx, float cy, float lo0,
+                                                                 float lo1, float lo2, float hi0, float hi1, float hi2,
+                                                                 long total, float* __restrict__ out) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e % n_per_env;                     // pixel inside the env: view * HW + pix
+        const int m = (int)(r / HW), pix = (int)(r - (long)m * HW);
+        const int row = pix / W, col = pix - row * W;
+        const float z = depth[e];
+        const float p0 = __fdiv_rn(mul_rn(sub_rn((float)col, cx), z), fx);
+        const float p1 = __fdiv_rn(mul_rn(sub_rn((float)row, cy), z), fy);
+        const float* T = pose + m * 16;                   // row-major 4x4
+        float w[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            w[d] = add_rn(__fmaf_rn(z, T[d * 4 + 2], __fmaf_rn(p1, T[d * 4 + 1], mul_rn(p0, T[d * 4]))), T[d * 4 + 3]);
+        const bool ok = w[0] < hi0 && w[1] < hi1 && w[2] < hi2 && w[0] > lo0 && w[1] > lo1 && w[2] > lo2;
+        out[e * 3] = ok ? w[0] : 0.f;
+        out[e * 3 + 1] = ok ? w[1] : 0.f;
+        out[e * 3 + 2] = ok ? w[2] : 0.f;
+    }
+}
+
+extern "C" int pm_depth_backproject_f32(const float* depth, int B, int M, int H, int W, const float* cam_pose,
+                                        float fx, float fy, float cx, float cy, const float* lo, const float* hi,
+                                        float* out, void* stream) {
+    PM_REQUIRE(depth && cam_pose && lo && hi && out && B > 0 && M > 0 && H > 0 && W > 0);
+    const long total = (long)B * M * H * W;
+    long nb = (total + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(depth_backproject_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), depth,
+                       (long)M * H * W, H * W, W, cam_pose, fx, fy, cx, cy, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2],
+                       total, out);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}

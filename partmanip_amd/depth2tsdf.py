@@ -1,0 +1,55 @@
+"""Observation-side depth -> point-cloud step, mirroring the reference's
+`utils/depth2tsdf.py:TSDFVolume` for the part the point-cloud learner consumes:
+
+    tsdf = TSDFVolume(device, size, resolution, _vol_origin)
+    tsdf.register_camera(cam_pose (m,4,4), cam_intr (3,3), im_h, im_w, num_env)     # depth2tsdf.py:30-66
+    clouds = tsdf.depth2pc(depth_im (b, m, h, w))  -> (b, 1024, 3)                  # depth2tsdf.py:136-173
+
+`depth2pc` = back-projection + workspace crop (pm_depth_backproject_f32) and farthest point sampling with
+pytorch3d's defaults (pm_fps_f32: start index 0, lowest-index ties; the reference calls
+`pytorch3d.ops.sample_farthest_points(world_cld, K=1024)`, depth2tsdf.py:160), both on the GPU.
+The TSDF integration / marching-cubes methods (`integrate`, `extract_point_cloud`) feed the Conv3D students,
+which are outside this build's scope: they raise NotImplementedError.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+class TSDFVolume(object):
+    def __init__(self, device, size=0.5, resolution=50, _vol_origin=(-0.25, -0.25, -0.0503)):
+        self._size = size
+        self._resolution = resolution
+        self._voxel_size = self._size / self._resolution
+        self._sdf_trunc = 4 * self._voxel_size
+        self.device = device
+        self._vol_origin = torch.tensor(list(_vol_origin), dtype=torch.float32, device=device)
+        self.default_tsdf = 1
+        self._ws = ops.Workspace(device)
+
+    def register_camera(self, cam_pose, cam_intr, im_h, im_w, num_env):
+        """cam_pose (m,4,4) camera->world, cam_intr (3,3), image size, env count (depth2tsdf.py:30-40)."""
+        cam_pose = torch.as_tensor(np.asarray(cam_pose), dtype=torch.float32)
+        self.registered_shape = (num_env, cam_pose.shape[0], im_h, im_w)
+        self.cam_pose = cam_pose.to(self.device).contiguous()                      # (m,4,4); not repeated per env
+        self.cam_intr = cam_intr
+
+    def depth2pc(self, depth_im, K=1024):
+        """depth_im (b, m, h, w) float32 on the device -> (b, K, 3) world-frame clouds."""
+        assert tuple(depth_im.shape) == tuple(self.registered_shape)
+        intr = self.cam_intr
+        # the reference's naming is swapped (cam_cx pairs with the column map, depth2tsdf.py:146-149); kept as is
+        cam_cx, cam_cy = float(intr[0][2]), float(intr[1][2])
+        cam_fx, cam_fy = float(intr[0][0]), float(intr[1][1])
+        lo = self._vol_origin.cpu().numpy().astype(np.float32)
+        hi = (np.float32(self._size) + lo).astype(np.float32)                       # `self._size + self._vol_origin`
+        world = ops.depth_backproject(depth_im.float().contiguous(), self.cam_pose, cam_fx, cam_fy, cam_cx, cam_cy, lo, hi)
+        idx = ops.fps(world, K, self._ws)                                          # (b, K) int32
+        return ops.group_points(world, idx.view(idx.shape[0], K, 1)).view(idx.shape[0], K, 3)
+
+    def integrate(self, depth_im):
+        raise NotImplementedError("TSDF integration feeds the Conv3D students, outside this build's scope (SURVEY.md §8f)")
+
+    def extract_point_cloud(self):
+        raise NotImplementedError("marching cubes is outside this build's scope (SURVEY.md §8f)")

@@ -410,3 +410,20 @@ def sa_bwd(xyz, centers, idx, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpoo
                                 _rows(pooled, "pooled"), _ptr(arg), _ptr(dpooled), _rows(dpooled, "dpooled"), _ptr(dw1),
                                 _rows(dw1, "dw1"), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(dw3), _ptr(db3), _ptr(dY),
                                 _ptr(w), w.numel(), _stream()), "pm_sa_bwd_f32")
+
+
+# ----------------------------------------------------------------------------- depth -> cloud
+def depth_backproject(depth, cam_pose, fx, fy, cx, cy, lo, hi):
+    """depth (B,M,H,W), cam_pose (M,4,4) device -> world cloud (B, M*H*W, 3), out-of-box points zeroed."""
+    import ctypes
+    _req(depth, cam_pose)
+    _f32c(depth, "depth")
+    _f32c(cam_pose, "cam_pose")
+    B, M, H, W = depth.shape
+    out = torch.empty(B, M * H * W, 3, dtype=torch.float32, device=depth.device)
+    lo3 = (ctypes.c_float * 3)(*[float(v) for v in lo])
+    hi3 = (ctypes.c_float * 3)(*[float(v) for v in hi])
+    check(lib.pm_depth_backproject_f32(_ptr(depth), B, M, H, W, _ptr(cam_pose), float(fx), float(fy), float(cx),
+                                       float(cy), ctypes.cast(lo3, ctypes.c_void_p), ctypes.cast(hi3, ctypes.c_void_p),
+                                       _ptr(out), _stream()), "pm_depth_backproject_f32")
+    return out

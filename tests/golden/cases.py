@@ -143,3 +143,28 @@ def dagger_raw_inputs(c):
 
 def case_copy(c):
     return copy.deepcopy(c)
+
+
+# ---- observation side: depth images -> world cloud (utils/depth2tsdf.py:136-173) ---------------------------------
+DEPTH2PC_CASES = {
+    # 2 envs x 3 views of 24 x 32 pixels; a workspace box that cuts roughly half of the points away
+    "depth2pc_small": dict(b=2, m=3, h=24, w=32, K=64, size=0.5, vol_origin=[-0.25, -0.25, 0.35], seed=301,
+                           intr=[[30.0, 0.0, 15.5], [0.0, 28.0, 11.5], [0.0, 0.0, 1.0]]),
+}
+
+
+def depth2pc_inputs(c):
+    from .detgen import det_uniform
+    depth = det_uniform((c["b"], c["m"], c["h"], c["w"]), c["seed"], 0.3, 1.0)
+    depth[:, :, :2, :] = 0.0                                     # invalid depth rows -> points at the camera centre
+    pose = np.zeros((c["m"], 4, 4), dtype=np.float32)
+    ang = det_uniform((c["m"],), c["seed"] + 1, -0.6, 0.6)
+    for i in range(c["m"]):
+        ca, sa = np.cos(ang[i]), np.sin(ang[i])
+        cb, sb = np.cos(0.5 * ang[i] + 0.2), np.sin(0.5 * ang[i] + 0.2)
+        rz = np.array([[ca, -sa, 0.0], [sa, ca, 0.0], [0.0, 0.0, 1.0]])
+        rx = np.array([[1.0, 0.0, 0.0], [0.0, cb, -sb], [0.0, sb, cb]])
+        pose[i, :3, :3] = (rz @ rx).astype(np.float32)              # a general rotation: no zero entries
+        pose[i, :3, 3] = det_uniform((3,), c["seed"] + 2 + i, -0.1, 0.1)
+        pose[i, 3, 3] = 1.0
+    return dict(depth=depth, cam_pose=pose)

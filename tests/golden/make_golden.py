@@ -256,12 +256,53 @@ def gen_dagger(ref_algos, cases):
         print("wrote", name, "losses", out["loss_trace"])
 
 
+def gen_depth2pc(cases):
+    """Runs the reference's own TSDFVolume.depth2pc (utils/depth2tsdf.py) file by path.  Its two absent
+    dependencies are stubbed: `skimage` (unused by this method) and `pytorch3d.ops.sample_farthest_points`,
+    which is replaced by the CPU restatement's fps and RECORDS its input -- so `world` (everything before the
+    sampling) is the reference's own output, and `final_pc` = reference gather of restated indices."""
+    import importlib.util
+    sys.modules["skimage"] = types.ModuleType("skimage")
+    sys.modules["skimage"].measure = types.ModuleType("skimage.measure")
+    sys.modules["skimage.measure"] = sys.modules["skimage"].measure
+    from oracle import ref_cpu as R
+    rec = {}
+
+    def sample_farthest_points(points, K):
+        rec["world"] = points.detach().cpu().numpy().copy()
+        idx = torch.from_numpy(R.fps(rec["world"], K))
+        return torch.gather(points, 1, idx.unsqueeze(-1).expand(-1, -1, 3)), idx
+
+    p3d, p3d_ops = types.ModuleType("pytorch3d"), types.ModuleType("pytorch3d.ops")
+    p3d_ops.sample_farthest_points = sample_farthest_points
+    p3d.ops = p3d_ops
+    sys.modules["pytorch3d"], sys.modules["pytorch3d.ops"] = p3d, p3d_ops
+    spec = importlib.util.spec_from_file_location("ref_depth2tsdf", os.path.join(REF, "utils", "depth2tsdf.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name, c in cases.DEPTH2PC_CASES.items():
+        inp = cases.depth2pc_inputs(c)
+        vol = mod.TSDFVolume("cpu", size=c["size"], resolution=10, _vol_origin=c["vol_origin"])
+        vol.register_camera(inp["cam_pose"], np.asarray(c["intr"], dtype=np.float32), c["h"], c["w"], c["b"])
+        final = vol.depth2pc(torch.from_numpy(inp["depth"]))
+        # the method hard-codes K=1024 (depth2tsdf.py:160); the case's K-sample prefix is what the tests compare
+        idx = R.fps(rec["world"], c["K"])
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), world=rec["world"], final_pc_1024=final.numpy(),
+                            idx=idx.astype(np.int32))
+        print("wrote", name, "valid fraction", float((rec["world"] != 0).any(-1).mean()))
+
+
 def main():
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
     from tests.golden import cases
+    which = sys.argv[1:] or ["gae", "ppo", "dagger", "depth2pc"]
+    if "depth2pc" in which:
+        gen_depth2pc(cases)
+        which = [w for w in which if w != "depth2pc"]
+        if not which:
+            return
     ref = _import_reference()
-    which = sys.argv[1:] or ["gae", "ppo", "dagger"]
     if "gae" in which:
         gen_gae(ref, cases)
     if "ppo" in which:

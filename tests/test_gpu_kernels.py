@@ -277,3 +277,43 @@ def test_fast_tanh_accuracy():
     assert float((err / ulp).max()) < 6.0, float((err / ulp).max())
     assert float(err.max()) < 2.5e-7
     assert got[-2] == 1.0 and got[-1] == -1.0 and got[-8] == 0.0
+
+
+# ------------------------------------------------------------------------------- depth -> cloud (observation side)
+def test_depth2pc_matches_reference_world_cloud_and_restated_sampling():
+    """TSDFVolume.depth2pc (partmanip_amd/depth2tsdf.py): the back-projected, cropped world cloud is bit-identical
+    to the REFERENCE's own output (fixture), the sampled indices to the CPU restatement's FPS."""
+    from tests.golden import cases
+    from partmanip_amd.depth2tsdf import TSDFVolume
+    from partmanip_amd import ops
+    c = cases.DEPTH2PC_CASES["depth2pc_small"]
+    inp, fx = cases.depth2pc_inputs(c), load_fixture("depth2pc_small")
+    vol = TSDFVolume(DEV, size=c["size"], resolution=10, _vol_origin=c["vol_origin"])
+    vol.register_camera(inp["cam_pose"], np.asarray(c["intr"], dtype=np.float32), c["h"], c["w"], c["b"])
+    depth = torch.from_numpy(inp["depth"]).to(DEV)
+    lo = np.asarray(c["vol_origin"], dtype=np.float32)
+    world = ops.depth_backproject(depth, vol.cam_pose, c["intr"][0][0], c["intr"][1][1], c["intr"][0][2], c["intr"][1][2],
+                                  lo, np.float32(c["size"]) + lo)
+    assert np.array_equal(world.cpu().numpy(), fx["world"])
+    pc = vol.depth2pc(depth, K=c["K"])
+    assert np.array_equal(pc.cpu().numpy(), fx["final_pc_1024"][:, :c["K"]])
+    pc_full = vol.depth2pc(depth)                                   # the reference's K = 1024
+    assert np.array_equal(pc_full.cpu().numpy(), fx["final_pc_1024"])
+
+
+def test_depth2pc_streaming_fps_on_a_camera_sized_cloud():
+    """One env x 3 views x 96 x 128 pixels = 36 864 points (> the register-resident limit): the streaming FPS
+    variant against the restatement, indices bit-exact."""
+    from partmanip_amd import ops
+    g = torch.Generator().manual_seed(9)
+    depth = (torch.rand(1, 3, 96, 128, generator=g) * 0.7 + 0.3)
+    pose = torch.eye(4).repeat(3, 1, 1)
+    pose[1, :3, 3] = torch.tensor([0.05, -0.02, 0.0])
+    pose[2, :3, 3] = torch.tensor([-0.04, 0.03, 0.01])
+    intr = [[120.0, 0.0, 63.5], [0.0, 110.0, 47.5], [0.0, 0.0, 1.0]]
+    out_ref, world_ref, idx_ref = R.depth2pc(depth.numpy(), pose.numpy(), intr, 0.5, [-0.25, -0.25, 0.3], K=48, return_world=True)
+    lo = np.asarray([-0.25, -0.25, 0.3], dtype=np.float32)
+    world = ops.depth_backproject(depth.to(DEV), pose.to(DEV).contiguous(), 120.0, 110.0, 63.5, 47.5, lo, np.float32(0.5) + lo)
+    assert np.array_equal(world.cpu().numpy(), world_ref)
+    idx = ops.fps(world, 48, ops.Workspace(DEV))
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), idx_ref)

@@ -125,3 +125,21 @@ def test_dagger(name):
 
 def test_dagger_small_buffer_returns_early():
     assert R.dagger_update({}, {}, None, None, 15, {}, 1) is None
+
+
+def test_depth2pc_restatement_matches_reference_world_cloud():
+    """utils/depth2tsdf.py:136-157 run by the REFERENCE's own code (make_golden.gen_depth2pc): the restatement's
+    world cloud (back-projection + pose + crop) is bit-identical; the sampling after it has no reference
+    implementation here (pytorch3d absent) -- the fixture's indices are the restatement's own (parity unpinned)."""
+    import numpy as np
+    from tests.golden import cases
+    from tests.helpers import load_fixture
+    from oracle import ref_cpu as R
+    c = cases.DEPTH2PC_CASES["depth2pc_small"]
+    inp, fx = cases.depth2pc_inputs(c), load_fixture("depth2pc_small")
+    out, world, idx = R.depth2pc(inp["depth"], inp["cam_pose"], c["intr"], c["size"], c["vol_origin"], K=c["K"],
+                                 return_world=True)
+    assert np.array_equal(world, fx["world"])
+    assert 0.2 < float((world != 0).any(-1).mean()) < 0.8           # the crop is exercised both ways
+    assert np.array_equal(idx, fx["idx"])
+    assert np.array_equal(out, fx["final_pc_1024"][:, :c["K"]])     # reference gather of those indices
