@@ -321,12 +321,14 @@ struct SaPart {
 };
 #define SA_BWD_MAXGRID 1024
 #ifndef SA_A_BWD_WPE
-#define SA_A_BWD_WPE 3        // SA1-shaped level: 4-wave work-groups, this many per CU
+#define SA_A_BWD_WPE 4        // SA1-shaped level: 4-wave work-groups, this many per CU
 #endif
 #ifndef SA_B_BWD_NW
-#define SA_B_BWD_NW 8         // SA2-shaped level: one work-group per CU of 16 waves x 128 rows (or 8 x 64)
+#define SA_B_BWD_NW 16        // SA2-shaped level: one work-group per CU of 16 waves x 128 rows (or 8 x 64)
 #endif
+#ifndef SA_B_BWD_TM
 #define SA_B_BWD_TM (SA_B_BWD_NW * 8)
+#endif
 
 template <int C1, int C2, int C3, int TM, int NW, int WPE>
 __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_kernel(SaArgs a) {
@@ -419,7 +421,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_kernel(SaArgs a) {
                 if (ks == 0) accb3 += v;
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        // A real barrier, not just a scheduling fence: without it hipcc overlaps the dW3 row reads with the
+        // operand stream below and the live ranges of both add up (256 VGPRs + 94-212 spilled; 128-170 with it).
+        __syncthreads();
         // ---- P3b/P4: dH2 = dZ3 * W3 (sparse A built in registers), dZ2 = dH2 .* (1 - H2^2) -> D, db2 ----
         {
             const int wn = wave % M2::NBW, wm = wave / M2::NBW;
