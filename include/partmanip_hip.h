@@ -155,7 +155,8 @@ int pm_value_loss_fwd_bwd_f32(const float* V, const float* returns, const float*
 
 /* ------------------------------------------------------------------ K11 DAgger loss
  * dagger.py:310-314: mean((tanh(tea_mu)*max_a - tanh(stu_mu)*max_a)^2) over B*A and
- * d/d stu_mu.  act_tanh==0 -> identity squashing (actor_critic.py:87-88). */
+ * d/d stu_mu.  act_tanh==0 -> identity squashing (actor_critic.py:87-88).  act_tanh==3: the student is
+ * squashed but `tea_mu` already holds recorded ACTIONS -- bc.py:139 `(actions - stu_act).pow(2).mean()`. */
 int pm_mse_tanh_loss_fwd_bwd_f32(const float* stu_mu, long lds, const float* tea_mu, long ldt, int B, int A,
                                  float max_action, int act_tanh, float grad_scale, float* scal_out,
                                  float* dstu_mu, long ldd, void* stream);

@@ -458,6 +458,48 @@ def fps(points, K, lengths=None):
     return out
 
 
+def bc_index_batches(n, n_minibatches):
+    """bc.py:113-115: `DataLoader(dataset, batch_size=n // n_minibatches, shuffle=True)` -- the index batches of ONE
+    epoch, drawn from the global torch RNG exactly as the loader does (base seed, then the sampler's own seed);
+    the ragged tail batch is kept (drop_last=False)."""
+    loader = torch.utils.data.DataLoader(range(n), batch_size=n // n_minibatches, shuffle=True, num_workers=0)
+    return [b.clone() for b in loader]
+
+
+def bc_run(p, data, cfg, net_cfg):
+    """bc.py:109-177 `bc.run()`: per iteration one shuffled pass; loss = mean((action - tanh(mu)*max_a)^2) (bc.py:139),
+    Adam over the student's actor parameters (the only ones with a gradient), lr schedule at iteration end."""
+    names = [k for k in p if k.startswith("actor.")]
+    for k in names:
+        p[k].requires_grad_(True)
+    opt = Adam([p[k] for k in names], cfg["lr"])
+    x_all = torch.cat([data["tsdf"], data["proprio_state"]], dim=-1) if cfg["add_proprio_obs"] else data["tsdf"]
+    n = x_all.shape[0]
+    losses, lrs, it = [], [], 0
+    while it < cfg["max_iterations"]:
+        it += 1
+        tot, cnt = 0.0, 0
+        for idx in bc_index_batches(n, cfg["n_minibatches"]):
+            mu = net_forward(p, "actor", net_cfg, x_all[idx], cfg.get("proprio_shape", 0))
+            stu_act = action_activation(mu, cfg["action_activate"], cfg["max_action"])
+            loss = (data["action"][idx] - stu_act).pow(2).mean()
+            grads = torch.autograd.grad(loss, [p[k] for k in names])
+            opt.step(list(grads))
+            tot += float(loss.detach())
+            cnt += 1
+        lr_now = opt.lrs[0]
+        if cfg["lr_schedule"] == "linear_decay":
+            lr_now = cfg["lr"] * (1 - it / cfg["max_iterations"])
+        elif cfg["lr_schedule"] == "step_decay":
+            lr_now = cfg["lr"] if it < cfg["max_iterations"] / 2 else cfg["lr"] * 0.1
+        elif cfg["lr_schedule"] != "fixed":
+            raise NotImplementedError
+        opt.lrs = [lr_now for _ in opt.lrs]
+        losses.append(tot / cnt)
+        lrs.append(lr_now)
+    return dict(loss_trace=losses, lr_trace=lrs)
+
+
 def depth2pc(depth, cam_pose, cam_intr, size, vol_origin, K=1024, return_world=False):
     """utils/depth2tsdf.py:136-173 `TSDFVolume.depth2pc`: depth (b,m,h,w) -> (b,K,3).  fp32 op by op in the
     order of the reference's tensor expression -- PINNED bit for bit to the reference's own world cloud

@@ -1,2 +1,3 @@
 from .ppo import ppo
 from .dagger import dagger
+from .bc import bc

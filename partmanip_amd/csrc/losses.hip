@@ -270,10 +270,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void mse_tanh_loss_kernel(const float
         const long i = e / A, a = e % A;
         const float sm = stu_mu[i * lds + a], tm = tea_mu[i * ldt + a];
         float sa, ta, ds;
-        if (act_tanh) {
+        if (act_tanh & 1) {
             const float th = pm_tanh(sm);
             sa = th * max_action;
-            ta = pm_tanh(tm) * max_action;
+            ta = (act_tanh & 2) ? tm : pm_tanh(tm) * max_action;      // bit 1: the target is a recorded ACTION (bc.py:139)
             ds = max_action * (1.0f - th * th);
         } else {
             sa = sm;

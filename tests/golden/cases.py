@@ -168,3 +168,31 @@ def depth2pc_inputs(c):
         pose[i, :3, 3] = det_uniform((3,), c["seed"] + 2 + i, -0.1, 0.1)
         pose[i, 3, 3] = 1.0
     return dict(depth=depth, cam_pose=pose)
+
+
+# ---- behaviour cloning from offline shards (algorithms/bc.py) -----------------------------------------------------
+BC_CASES = {
+    # one scene x 22 steps (a single scene keeps the index -> file map independent of os.listdir order);
+    # batch = 22 // 4 = 5 -> 5 mini-batches per epoch, the last one ragged with 2 rows (DataLoader keeps it; a
+    # 1-row tail would crash the reference itself: bc.py:128 squeezes the batch axis away)
+    "bc_mlp": dict(net=_MLP_NET, n_steps=22, D=40, S=5, A=10, n_minibatches=4, max_iterations=3, lr=3e-3,
+                   lr_schedule="linear_decay", seed=401, action_std=0.1, torch_seed=91),
+}
+
+
+def bc_dataset(c):
+    """rows of the offline shards: tsdf (n, D) ~N(0,1), action (n, A) in (-1, 1), proprio_state (n, S)."""
+    n = c["n_steps"]
+    return dict(tsdf=det_normal((n, c["D"]), c["seed"]), action=det_uniform((n, c["A"]), c["seed"] + 1, -0.9, 0.9),
+                proprio_state=det_normal((n, c["S"]), c["seed"] + 2))
+
+
+def bc_write_dataset(c, folder):
+    import os
+    d = bc_dataset(c)
+    scene = os.path.join(folder, "scene_00000")
+    os.makedirs(scene, exist_ok=True)
+    for i in range(c["n_steps"]):
+        np.save(os.path.join(scene, f"step_{str(i).zfill(5)}.npy"),
+                dict(tsdf=d["tsdf"][i], action=d["action"][i], proprio_state=d["proprio_state"][i]), allow_pickle=True)
+    return d

@@ -256,6 +256,37 @@ def gen_dagger(ref_algos, cases):
         print("wrote", name, "losses", out["loss_trace"])
 
 
+def gen_bc(ref_algos, cases):
+    """The reference's own bc.run() (10 DataLoader workers) on shards written by cases.bc_write_dataset."""
+    from algorithms import bc
+    for name, c in cases.BC_CASES.items():
+        with tempfile.TemporaryDirectory() as d:
+            cases.bc_write_dataset(c, os.path.join(d, "data"))
+            env = FakeEnv(4, {"tsdf": c["D"] + c["S"], "proprio_state": c["S"]}, c["A"])
+            trace = []
+
+            class Log(FakeLogger):
+                def info(self, log, it):
+                    trace.append((float(log["Train/bc_loss"]), float(log["Train/learning_rate"])))
+
+            cfg = dict(num_envs=4, obs_mode="tsdf", model=dict(action_std=c["action_std"], action_activate="tanh",
+                                                                clipAction=1.0, network=dict(c["net"])),
+                       max_iterations=c["max_iterations"], device="cpu", data_path=os.path.join(d, "data"),
+                       n_minibatches=c["n_minibatches"], add_proprio_obs=True, eval_round=1, eval_frequence=10 ** 9,
+                       save_frequence=10 ** 9, test_only=False, save_pose=False, save_video=False,
+                       lr_schedule=c["lr_schedule"], lr=c["lr"], resume=None)
+            run = bc(env, cfg, Log(d))
+            sd0 = cases.actor_critic_state(c["net"], c["D"] + c["S"], c["A"], c["action_std"], c["seed"])
+            load_sd(run.student, sd0)
+            torch.manual_seed(c["torch_seed"])
+            run.run()
+            out = dict(loss_trace=np.asarray([t[0] for t in trace], dtype=np.float64),
+                       lr_trace=np.asarray([t[1] for t in trace], dtype=np.float64),
+                       final_flat=flat_params(run.student.state_dict()))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print("wrote", name, "losses", out["loss_trace"])
+
+
 def gen_depth2pc(cases):
     """Runs the reference's own TSDFVolume.depth2pc (utils/depth2tsdf.py) file by path.  Its two absent
     dependencies are stubbed: `skimage` (unused by this method) and `pytorch3d.ops.sample_farthest_points`,
@@ -296,7 +327,7 @@ def main():
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
     from tests.golden import cases
-    which = sys.argv[1:] or ["gae", "ppo", "dagger", "depth2pc"]
+    which = sys.argv[1:] or ["gae", "ppo", "dagger", "depth2pc", "bc"]
     if "depth2pc" in which:
         gen_depth2pc(cases)
         which = [w for w in which if w != "depth2pc"]
@@ -309,6 +340,8 @@ def main():
         gen_ppo(ref, cases)
     if "dagger" in which:
         gen_dagger(ref, cases)
+    if "bc" in which:
+        gen_bc(ref, cases)
 
 
 if __name__ == "__main__":

@@ -281,6 +281,41 @@ def test_dagger_update_matches_reference(name, tmp_path, monkeypatch):
     assert set(ck) >= {"iteration", "model_state_dict", "optimizer_state_dict", "total_steps", "obs_mode", "teacher"}
 
 
+def test_bc_run_matches_reference(tmp_path):
+    """`bc(...).run()` (dataset resident in HBM, HIP step) against the reference's own bc.run() on the same shards:
+    same shuffled batches (same RNG consumption), per-iteration losses, lr schedule, final student."""
+    from partmanip_amd.algorithms import bc
+    c, fx = cases.BC_CASES["bc_mlp"], load_fixture("bc_mlp")
+    cases.bc_write_dataset(c, str(tmp_path / "data"))
+    trace = []
+
+    class Log(FakeLogger):
+        def info(self, log, it):
+            trace.append((float(log["Train/bc_loss"]), float(log["Train/learning_rate"])))
+
+    env = FakeEnv(4, {"tsdf": c["D"] + c["S"], "proprio_state": c["S"]}, c["A"])
+    cfg = dict(num_envs=4, obs_mode="tsdf", model=dict(action_std=c["action_std"], action_activate="tanh", clipAction=1.0,
+                                                        network=dict(c["net"])),
+               max_iterations=c["max_iterations"], device=DEV, data_path=str(tmp_path / "data"),
+               n_minibatches=c["n_minibatches"], add_proprio_obs=True, eval_round=1, eval_frequence=10 ** 9,
+               save_frequence=2, test_only=False, save_pose=False, save_video=False, lr_schedule=c["lr_schedule"],
+               lr=c["lr"], resume=None)
+    run = bc(env, cfg, Log(str(tmp_path)))
+    sd = cases.actor_critic_state(c["net"], c["D"] + c["S"], c["A"], c["action_std"], c["seed"])
+    run.student.load_state_dict({k: t(v.copy()) for k, v in sd.items()})
+    torch.manual_seed(c["torch_seed"])
+    run.run()
+    np.testing.assert_allclose([x[0] for x in trace], fx["loss_trace"], rtol=2e-5)
+    np.testing.assert_allclose([x[1] for x in trace], fx["lr_trace"], rtol=1e-12)
+    n_steps = c["max_iterations"] * 5
+    check_params(flat_state(run.student.state_dict()), fx["final_flat"], 1, c["lr"], n_steps)
+    ck = torch.load(str(tmp_path / "model_2.pth"), map_location="cpu", weights_only=False)
+    assert set(ck) >= {"iteration", "model_state_dict", "optimizer_state_dict", "obs_mode", "total_steps", "tricks", "teacher"}
+    cfg2 = dict(cfg, resume=str(tmp_path / "model_2.pth"))
+    run2 = bc(env, cfg2, Log(str(tmp_path)))
+    assert run2.curr_iter == 2
+
+
 def test_dagger_small_buffer_is_noop(tmp_path, monkeypatch):
     from partmanip_amd.algo_utils import RolloutStorage
     st = RolloutStorage(4, 3, 8, 2, DEV, sampler="random", tea_obs_shape=5, max_length=10)

@@ -143,3 +143,25 @@ def test_depth2pc_restatement_matches_reference_world_cloud():
     assert 0.2 < float((world != 0).any(-1).mean()) < 0.8           # the crop is exercised both ways
     assert np.array_equal(idx, fx["idx"])
     assert np.array_equal(out, fx["final_pc_1024"][:, :c["K"]])     # reference gather of those indices
+
+
+def test_bc_restatement_matches_reference_run():
+    """algorithms/bc.py `bc.run()` executed by the reference itself (10 DataLoader workers, shards on disk): the
+    restatement reproduces its shuffled index batches from the same global RNG state, the per-iteration mean
+    losses, the lr schedule and the final student."""
+    import numpy as np
+    import torch
+    from tests.golden import cases
+    from tests.helpers import load_fixture, flat_state
+    from oracle import ref_cpu as R
+    c, fx = cases.BC_CASES["bc_mlp"], load_fixture("bc_mlp")
+    d = {k: torch.from_numpy(v) for k, v in cases.bc_dataset(c).items()}
+    sd = cases.actor_critic_state(c["net"], c["D"] + c["S"], c["A"], c["action_std"], c["seed"])
+    p = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+    torch.manual_seed(c["torch_seed"])
+    out = R.bc_run(p, d, dict(lr=c["lr"], lr_schedule=c["lr_schedule"], max_iterations=c["max_iterations"],
+                              n_minibatches=c["n_minibatches"], add_proprio_obs=True, action_activate="tanh",
+                              max_action=1.0), c["net"])
+    np.testing.assert_allclose(out["loss_trace"], fx["loss_trace"], rtol=2e-6)
+    np.testing.assert_allclose(out["lr_trace"], fx["lr_trace"], rtol=1e-12)
+    np.testing.assert_allclose(flat_state(p), fx["final_flat"], rtol=0, atol=2e-6)

@@ -13,7 +13,7 @@ import random
 import numpy as np
 import torch
 
-from algorithms import ppo, dagger  # noqa: F401  (resolved by name below, like the reference's eval())
+from algorithms import ppo, dagger, bc  # noqa: F401  (resolved by name below, like the reference's eval())
 from partmanip_amd import dist as pdist
 from partmanip_amd.config import process_cfgs, num_actions
 from partmanip_amd.feeder import FeederEnv, ScreenLogger
@@ -57,7 +57,7 @@ def main():
     torch.cuda.set_device(cfg['device'])
     env = FeederEnv(cfg['algo']['num_envs'], cfg['task']['obs_mode'], num_actions(cfg['task']), cfg['device'],
                     seed=cfg['seed'] + rank, max_episode_length=cfg['task']['maxEpisodeLength'])
-    runner = {'ppo': ppo, 'dagger': dagger}[cfg['algo_name']](env, cfg['algo'], logger)
+    runner = {'ppo': ppo, 'dagger': dagger, 'bc': bc}[cfg['algo_name']](env, cfg['algo'], logger)
     runner.run()
 
 
