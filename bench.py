@@ -44,28 +44,30 @@ WORKLOADS = {
 }
 
 
-DAGGER = dict(name="dagger_pointnet_student_4096env_x_16buf_x_1024pt", N=4096, buf=16, O_s=3072, O_t=53, A=10)
+DAGGER = dict(name="dagger_pointnet_student_4096env_x_16buf_x_{P}pt", N=4096, buf=16, O_t=53, A=10)
 
 
 def run_dagger(args, device, rank, world):
-    """cfg 5 analogue: DAgger, N=4096, n_steps 1, buf_size 16, PointNet student on 1024-pt
-    clouds, frozen MLP teacher (O=53), random sampler, n_updates 2, n_minibatches 16 (-> 2048).
+    """cfg 5 analogue: DAgger, N=4096, n_steps 1, buf_size 16, PointNet student on 4096-pt
+    clouds (`--points`; the reference hard-codes 1024, network.py:146; the 3D-Sparse-UNet cfg 5 names does not exist
+    in the reference), frozen MLP teacher (O=53), random sampler, n_updates 2, n_minibatches 16 (-> 2048).
     A step = one `dagger.update` over the full ring (65 536 rows); env-steps/s = N * n_steps / time."""
     import tempfile
     from partmanip_amd.algorithms import ppo, dagger
     from partmanip_amd.feeder import FeederEnv, ScreenLogger
-    d = DAGGER
+    d = dict(DAGGER, O_s=3 * args.points, name=DAGGER["name"].format(P=args.points))
     torch.manual_seed(1234)
     tmp = tempfile.mkdtemp()
     env = FeederEnv(d["N"], {"normal_state": d["O_t"], "depth_pc": d["O_s"], "proprio_state": 0}, d["A"], device,
-                    seed=1234 + rank)
+                    seed=1234 + rank, point_num=args.points)
     tcfg = make_cfg(WORKLOADS["state"], device)
     tcfg.update(num_envs=d["N"], n_steps=1, obs_mode="normal_state")
     tea = ppo(env, tcfg, ScreenLogger(tmp, "tea", "n", quiet=True))
     tea.save(1)
     cfg = dict(num_envs=d["N"], obs_mode="depth_pc",
                model=dict(action_std=0.1, action_activate="tanh", clipAction=1.0,
-                          network=dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False)),
+                          network=dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False,
+                                       point_num=args.points)),
                max_iterations=10000, n_steps=1, n_updates=2, n_minibatches=16, device=device, buf_size=d["buf"],
                reward_reset=False, add_proprio_obs=False, offline_data_pth=None, eval_round=1, eval_frequence=10 ** 9,
                save_frequence=10 ** 9, test_only=False, save_pose=False, save_video=False, lr_schedule="fixed", lr=5e-5,
@@ -184,6 +186,7 @@ def main():
     ap.add_argument("--workload", default="vision", choices=list(WORKLOADS) + ["dagger"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-steps", type=int, default=0, help="override the rollout length T (e.g. 128 for the vision workload)")
+    ap.add_argument("--points", type=int, default=4096, help="dagger workload: points per student cloud (BASELINE cfg 5: 4096)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
                     help="vision encoder forward: exact fp32 MFMA (default) or the opt-in split-bf16 path")
     args = ap.parse_args()
