@@ -119,6 +119,63 @@ __global__ __launch_bounds__(FPS_NT) void fps_kernel(const float* __restrict__ x
     }
 }
 
+// Wave-per-cloud variant for xyz clouds of up to 2048 points (the learner's sizes: 1024 -> 256 -> 64): the cloud
+// and its running min-distances live in ONE wave's registers (PPL points per lane, interleaved so the loads
+// coalesce), each round is PPL distance updates + a 6-step (value, index, x, y, z) butterfly arg-max over the 64
+// lanes -- no LDS, no barrier, no reload of the selected point.  Four clouds per 256-thread work-group.
+// Same fp32 expression and tie-breaks as fps_kernel (bit-identical indices).
+template <int PPL>
+__global__ __launch_bounds__(256) void fps_wave_kernel(const float* __restrict__ xyz, int B, int P, int K,
+                                                        int32_t* __restrict__ idx_out) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* pts = xyz + (long)b * P * 3;
+    float px[PPL], py[PPL], pz[PPL], mind[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const int p = lane + 64 * j;
+        const bool ok = p < P;
+        px[j] = ok ? pts[p * 3] : 0.f;
+        py[j] = ok ? pts[p * 3 + 1] : 0.f;
+        pz[j] = ok ? pts[p * 3 + 2] : 0.f;
+        mind[j] = INFINITY;
+    }
+    int cur = 0;
+    float cx = __shfl(px[0], 0, 64), cy = __shfl(py[0], 0, 64), cz = __shfl(pz[0], 0, 64);
+    for (int k = 0; k < K; ++k) {
+        if (k >= P) {                           // more samples than points: pytorch3d pads with -1
+            if (lane == 0) idx_out[(long)b * K + k] = -1;
+            continue;
+        }
+        if (lane == 0) idx_out[(long)b * K + k] = cur;
+        float bv = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const int p = lane + 64 * j;
+            if (p < P) {
+                const float tx = sub_rn(px[j], cx), ty = sub_rn(py[j], cy), tz = sub_rn(pz[j], cz);
+                const float d2 = add_rn(add_rn(mul_rn(tx, tx), mul_rn(ty, ty)), mul_rn(tz, tz));
+                const float m = fminf(mind[j], d2);
+                mind[j] = m;
+                if (m > bv) {                   // strict: keeps the lowest index within the lane
+                    bv = m; bi = p; bx = px[j]; by = py[j]; bz = pz[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            const float ox = __shfl_xor(bx, o, 64), oy = __shfl_xor(by, o, 64), oz = __shfl_xor(bz, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov; bi = oi; bx = ox; by = oy; bz = oz;
+            }
+        }
+        cur = bi; cx = bx; cy = by; cz = bz;
+    }
+}
+
 extern "C" size_t pm_fps_workspace_bytes(int B, int P) {
     return (P > FPS_NT * FPS_RPT) ? (size_t)B * P * sizeof(float) : 0;
 }
@@ -126,7 +183,17 @@ extern "C" size_t pm_fps_workspace_bytes(int B, int P) {
 extern "C" int pm_fps_f32(const float* xyz, int B, int P, int D, int K, int32_t* idx_out, void* workspace,
                           size_t workspace_bytes, void* stream) {
     PM_REQUIRE(xyz && idx_out && B > 0 && P > 0 && D >= 1 && D <= FPS_MAXD && K > 0);
-    if (P <= FPS_NT * FPS_RPT) {
+    if (D == 3 && P <= 2048) {
+#define FPS_WAVE_LAUNCH(PPL)                                                                                  \
+    hipLaunchKernelGGL(fps_wave_kernel<PPL>, dim3((B + 3) / 4), dim3(256), 0, pm_stream(stream), xyz, B, P, K, idx_out)
+        if (P <= 64) FPS_WAVE_LAUNCH(1);
+        else if (P <= 128) FPS_WAVE_LAUNCH(2);
+        else if (P <= 256) FPS_WAVE_LAUNCH(4);
+        else if (P <= 512) FPS_WAVE_LAUNCH(8);
+        else if (P <= 1024) FPS_WAVE_LAUNCH(16);
+        else FPS_WAVE_LAUNCH(32);
+#undef FPS_WAVE_LAUNCH
+    } else if (P <= FPS_NT * FPS_RPT) {
         hipLaunchKernelGGL(fps_kernel<true>, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, P, D, K, idx_out,
                            (float*)nullptr);
     } else {

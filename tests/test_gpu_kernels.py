@@ -230,7 +230,11 @@ def test_clip_adam_steps(n, n_clip, max_norm):
 
 
 # ------------------------------------------------------------------------------- point-set ops
-@pytest.mark.parametrize("B,P,D,K", [(3, 1024, 3, 128), (2, 777, 3, 64), (2, 5000, 3, 256), (1, 20000, 3, 64), (2, 50, 4, 80)])
+# wave-per-cloud variant: P <= 2048 with D == 3 (every points-per-lane instantiation, B not a multiple of 4,
+# K > P); work-group variant: 2048 < P <= 8192 or D != 3; streaming variant beyond
+@pytest.mark.parametrize("B,P,D,K", [(3, 1024, 3, 128), (2, 777, 3, 64), (2, 5000, 3, 256), (1, 20000, 3, 64), (2, 50, 4, 80),
+                                     (5, 64, 3, 64), (6, 100, 3, 30), (3, 256, 3, 64), (2, 300, 3, 77), (7, 2048, 3, 96),
+                                     (2, 40, 3, 50), (2, 1500, 4, 40)])
 def test_fps_bit_exact(B, P, D, K):
     o = ops()
     g = torch.Generator().manual_seed(P)
