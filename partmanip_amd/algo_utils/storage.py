@@ -64,36 +64,42 @@ class RolloutStorage:
             buf[t].copy_(val)
         self.step = t + 1
 
+    def _ring_write(self, stu_rows, tea_rows):
+        """Append k rows to the DAgger ring at `mix_buf_ind`, wrapping modulo its size (one or two block copies)."""
+        size, k = self.n_steps * self.num_envs, stu_rows.shape[0]
+        at = self.mix_buf_ind
+        head = min(k, size - at)
+        for ring, rows in ((self.observations, stu_rows), (self.tea_obs, tea_rows)):
+            ring[at:at + head].copy_(rows[:head])
+            if head < k:                                  # wrapped: the remainder restarts at row 0
+                ring[:k - head].copy_(rows[head:])
+        self.mix_buf_ind = (at + k) % size
+        self.cur_buf_size = min(size, self.cur_buf_size + k)
+
     def add_transitions_offline(self, folder, device, add_proprio_obs=False):
-        """storage.py:58-82: scene_*/step_*.npy dicts {tsdf, proprio_state, tea_obs} row by row."""
+        """storage.py:58-82: every `scene_*/step_*.npy` shard {tsdf, proprio_state, tea_obs} becomes one ring row, in
+        sorted (scene, step) order.  The shards are stacked on the host and land in the ring as block copies."""
         print('Read offline data from ', folder)
-        scene_list = sorted(os.listdir(folder))
-        step_list = sorted(os.listdir(pjoin(folder, scene_list[0])))
-        max_buf_size = self.n_steps * self.num_envs
-        for scene in scene_list:
-            for step in step_list:
-                data = np.load(pjoin(folder, scene, step), allow_pickle=True).item()
-                tsdf = torch.tensor(data['tsdf']).reshape(-1).to(device)
+        scenes = sorted(os.listdir(folder))
+        steps = sorted(os.listdir(pjoin(folder, scenes[0])))
+        size = self.n_steps * self.num_envs
+        stu, tea = [], []
+        for scene in scenes:
+            for step in steps:
+                shard = np.load(pjoin(folder, scene, step), allow_pickle=True).item()
+                row = np.asarray(shard['tsdf'], dtype=np.float32).reshape(-1)
                 if add_proprio_obs:
-                    stu_obs = torch.cat((tsdf, torch.tensor(data['proprio_state']).to(device)), dim=-1)
-                else:
-                    stu_obs = tsdf
-                tea_obs = torch.tensor(data['tea_obs']).to(device)
-                self.observations[self.mix_buf_ind:self.mix_buf_ind + 1].copy_(stu_obs)
-                self.tea_obs[self.mix_buf_ind:self.mix_buf_ind + 1].copy_(tea_obs)
-                self.mix_buf_ind = (self.mix_buf_ind + 1) % max_buf_size
-                self.last_episode_buf_ind = self.mix_buf_ind
-                if self.cur_buf_size < max_buf_size:
-                    self.cur_buf_size += 1
+                    row = np.concatenate([row, np.asarray(shard['proprio_state'], dtype=np.float32).reshape(-1)])
+                stu.append(row)
+                tea.append(np.asarray(shard['tea_obs'], dtype=np.float32).reshape(-1))
+        stu, tea = torch.from_numpy(np.stack(stu)).to(device), torch.from_numpy(np.stack(tea)).to(device)
+        for lo in range(0, stu.shape[0], size):           # more shards than ring rows: later ones overwrite, as row by row
+            self._ring_write(stu[lo:lo + size], tea[lo:lo + size])
+        self.last_episode_buf_ind = self.mix_buf_ind
 
     def add_transitions_dagger(self, stu_obs, tea_obs):
-        """storage.py:84-91: N rows at mix_buf_ind, wrap modulo the ring size."""
-        self.observations[self.mix_buf_ind:self.mix_buf_ind + self.num_envs].copy_(stu_obs)
-        self.tea_obs[self.mix_buf_ind:self.mix_buf_ind + self.num_envs].copy_(tea_obs)
-        max_buf_size = self.n_steps * self.num_envs
-        self.mix_buf_ind = (self.mix_buf_ind + self.num_envs) % max_buf_size
-        if self.cur_buf_size < max_buf_size:
-            self.cur_buf_size += self.num_envs
+        """storage.py:84-91: the N rows of one env step go to the ring at `mix_buf_ind`."""
+        self._ring_write(stu_obs, tea_obs)
 
     def clear(self):
         self.step = 0

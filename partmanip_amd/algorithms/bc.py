@@ -46,41 +46,27 @@ class Tsdf_Dataset(torch.utils.data.Dataset):
 
 
 class bc:
+    # cfg key -> attribute name, exactly the public attributes the reference's runner exposes (bc.py:36-62)
+    _CFG_ATTRS = dict(num_envs='num_envs', obs_mode='stu_obs_mode', model='model_cfg', max_iterations='max_iter',
+                      device='device', data_path='data_path', n_minibatches='n_minibatches',
+                      add_proprio_obs='add_proprio_obs', eval_round='eval_round', eval_frequence='eval_freq',
+                      save_frequence='save_freq', test_only='test_only', save_pose='save_pose', save_video='save_video',
+                      lr_schedule='lr_schedule', lr='lr')
+
     def __init__(self, vec_env, cfg, logger):
-        self.vec_env = vec_env
-        self.num_envs = cfg['num_envs']
-        self.stu_obs_mode = cfg['obs_mode']
+        for key, attr in self._CFG_ATTRS.items():
+            setattr(self, attr, cfg[key])
+        self.vec_env, self.logger = vec_env, logger
         self.stu_num_obs = vec_env.num_obs[self.stu_obs_mode]
-        self.num_actions = vec_env.num_actions
-        self.max_episode_length = vec_env.max_episode_length
-
-        self.model_cfg = cfg['model']
-        self.max_iter = cfg['max_iterations']
-        self.device = cfg['device']
-        self.data_path = cfg['data_path']
-        self.n_minibatches = cfg['n_minibatches']
-        self.add_proprio_obs = cfg['add_proprio_obs']
-
-        self.eval_round = cfg['eval_round']
-        self.eval_freq = cfg['eval_frequence']
-        self.save_freq = cfg['save_frequence']
-        self.test_only = cfg['test_only']
-        self.save_pose = cfg['save_pose']
-        self.save_video = cfg['save_video']
+        self.num_actions, self.max_episode_length = vec_env.num_actions, vec_env.max_episode_length
         self.save_ckpt_dir = logger.save_ckpt_dir
-
-        self.lr_schedule = cfg['lr_schedule']
-        self.lr = cfg['lr']
-
-        self.student = ActorCritic(self.stu_num_obs, self.num_actions, self.model_cfg,
-                                   cfg['add_proprio_obs'] * vec_env.num_obs['proprio_state']).to(self.device)
+        proprio = self.add_proprio_obs * vec_env.num_obs['proprio_state']
+        self.student = ActorCritic(self.stu_num_obs, self.num_actions, self.model_cfg, proprio).to(self.device)
         f = self.student.flat()
         # Adam over student.parameters() (bc.py:68); only the actor ever receives gradients
         self.optimizer = FusedAdam(f['actor'], f['grad_actor'][:f['n_actor'] + self.num_actions],
                                    [list(self.student.parameters())], lr=self.lr)
-        self.logger = logger
-        self.total_time = 0
-        self.curr_iter = 0
+        self.total_time = self.curr_iter = 0
         self._loss_sum = torch.zeros(1, device=f['actor'].device)
         self._stage = {}
         self.resume(cfg['resume'])
