@@ -2,7 +2,7 @@
 import collections, csv, glob, json, sys
 out = {}
 for d in sorted(glob.glob(sys.argv[1] + "/pmc_*")):
-    for f in glob.glob(d + "/*counter_collection.csv"):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(lambda: [0, 0.0])
         for r in csv.DictReader(open(f)):
             k = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
@@ -12,5 +12,5 @@ for d in sorted(glob.glob(sys.argv[1] + "/pmc_*")):
             out.setdefault(kern, {})[ctr] = dict(launches=n, mean=s / n)
 json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
 for kern in out:
-    if kern.startswith(("pn_", "void gemm", "clip_adam", "gae")):
+    if kern.startswith(("pn_", "void gemm", "clip_adam", "gae", "void sa_", "void fps")):
         print(kern, {c: round(v["mean"], 1) for c, v in out[kern].items()})
