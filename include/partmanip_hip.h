@@ -225,6 +225,27 @@ int pm_depth_backproject_f32(const float* depth, int B, int M, int H, int W, con
                              float fy, float cx, float cy, const float* lo, const float* hi, float* out,
                              void* stream);
 
+/* ------------------------------------------------------------------ Conv3D students: patch gather / scatter
+ * network.py:56-94 (`Conv3DNet` / `Encoder`: nn.Conv3d(k, stride, padding = k/2)).  A convolution runs as
+ * cols = im2col(x) -> pm_linear_fwd_f32 with conv.weight viewed (Cout, Cin*k^3) -> rows (b, od, oh, ow) x Cout;
+ * its backward as pm_linear_bwd_weight_f32 / pm_linear_bwd_data_f32 on the same cols and dx = col2im(dcols).
+ * x / dx are addressed by ELEMENT strides (sb, sc, sd, sh, sw): channels-first inputs and channels-last layer
+ * outputs both work.  cols / dcols: (B*Do*Ho*Wo, ldc), column (c, kd, kh, kw) with c slowest; im2col zero-fills
+ * columns [C*k^3, ldc).  Do = (D + 2*pad - k)/stride + 1 etc.  col2im overwrites every dx element. */
+int pm_im2col3d_f32(const float* x, int B, int C, int D, int H, int W, int k, int stride, int pad, long sb, long sc,
+                    long sd, long sh, long sw, float* cols, int ldc, void* stream);
+int pm_col2im3d_f32(const float* dcols, int B, int C, int D, int H, int W, int k, int stride, int pad, long sb,
+                    long sc, long sd, long sh, long sw, const float* y_tanh /* NULL, or x itself when it is a tanh
+                    output laid out like dx: dx *= 1 - x^2 */, float* dx, int ldc, void* stream);
+
+/* ------------------------------------------------------------------ TSDF integration (observation side)
+ * utils/depth2tsdf.py:68-86 `TSDFVolume.integrate`: depth (B, M, H*W) -> out (B, V) truncated signed distances
+ * averaged over the views that see each voxel.  pix_idx (M, V) int32 = row*W + col of the voxel's pixel in view m,
+ * or -1 outside the frustum; pix_z (M, V) = its camera-frame depth (both built at register_camera time,
+ * depth2tsdf.py:41-60).  trunc = 4 voxels; default_tsdf for voxels no view sees. */
+int pm_tsdf_integrate_f32(const float* depth, const int32_t* pix_idx, const float* pix_z, int B, int M, long HW,
+                          long V, float trunc, float default_tsdf, float* out, void* stream);
+
 /* ------------------------------------------------------------------ K15 fused set-abstraction level
  * One PointNet++ SA level (north_star; not in the reference snapshot, README.md:23,30) as one forward and
  * one backward kernel: ball-query groups of `nsample` = 32 rows [xyz[idx]-centre | feat[idx]] -> Linear C1,

@@ -23,6 +23,7 @@ import math
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 LN2PI = math.log(2.0 * math.pi)
 
@@ -153,6 +154,24 @@ def pointnet_forward(p, prefix, net_cfg, x, proprio_shape=0, point_num=1024, arg
     return _lin(p, f"{prefix}.final_mlp.4", f)
 
 
+def conv3dnet_forward(p, prefix, net_cfg, x, proprio_shape=0):
+    """network.py:67-94 `Conv3DNet.forward` with `Encoder` :116-139: three strided Conv3d (k 5/3/3, stride 3/3/2,
+    padding k//2), the activation after each, channels-first flatten, [+ proprio], Linear-act-Linear."""
+    B = x.shape[0]
+    n = x.shape[1] - proprio_shape
+    res = round(n ** (1 / 3))
+    act = net_cfg["activation"]
+    h = x[:, :n].reshape(B, 1, res, res, res)
+    for i, (k, st) in enumerate(((5, 3), (3, 3), (3, 2))):
+        h = _act(act, F.conv3d(h, p[f"{prefix}.encoder.conv{i + 1}.weight"], p[f"{prefix}.encoder.conv{i + 1}.bias"],
+                               stride=st, padding=k // 2))
+    h = h.reshape(B, -1)
+    if proprio_shape != 0:
+        h = torch.cat((h, x[:, -proprio_shape:]), dim=-1)
+    h = _act(act, _lin(p, f"{prefix}.final_mlp.0", h))
+    return _lin(p, f"{prefix}.final_mlp.2", h)
+
+
 def net_forward(p, prefix, net_cfg, x, proprio_shape=0):
     """actor_critic.py:16,19: backbone chosen by `net_cfg['name']`."""
     if net_cfg["name"] == "MLP":
@@ -161,6 +180,8 @@ def net_forward(p, prefix, net_cfg, x, proprio_shape=0):
         return pointnet_forward(p, prefix, net_cfg, x, proprio_shape, point_num=int(net_cfg.get("point_num", 1024)))
     if net_cfg["name"] == "PointNet2":
         return pointnet2_forward(p, prefix, net_cfg, x, proprio_shape)
+    if net_cfg["name"] == "Conv3DNet":
+        return conv3dnet_forward(p, prefix, net_cfg, x, proprio_shape)
     raise ValueError(net_cfg["name"])
 
 
@@ -535,6 +556,42 @@ def depth2pc(depth, cam_pose, cam_intr, size, vol_origin, K=1024, return_world=F
     idx = fps(world, K)
     out = np.take_along_axis(world, idx[..., None].repeat(3, axis=-1), axis=1)
     return (out, world, idx) if return_world else out
+
+
+def tsdf_tables(cam_pose, cam_intr, im_h, im_w, size, resolution, vol_origin):
+    """depth2tsdf.py:14-28,41-60 (`__init__` + `register_camera`): per view and voxel the pixel it projects to
+    (row*W + col, or -1 outside the frustum) and its camera-frame depth."""
+    cam_pose = torch.as_tensor(np.asarray(cam_pose), dtype=torch.float32)
+    voxel = size / resolution
+    ax = torch.arange(0, resolution)
+    xv, yv, zv = torch.meshgrid(ax, ax, ax, indexing="ij")
+    vox = torch.stack([xv.flatten(), yv.flatten(), zv.flatten()], dim=1).long()
+    world_c = torch.tensor(list(vol_origin), dtype=torch.float32) + (voxel * vox)
+    world_c = world_c[None, ...].repeat(cam_pose.shape[0], 1, 1)
+    cam_c = torch.bmm(world_c - cam_pose[:, :3, 3].unsqueeze(-2), cam_pose[:, :3, :3])
+    fx, fy, cx, cy = float(cam_intr[0][0]), float(cam_intr[1][1]), float(cam_intr[0][2]), float(cam_intr[1][2])
+    pix_z = cam_c[..., 2]
+    pix_x = torch.round((cam_c[..., 0] * fx / cam_c[..., 2]) + cx).long()
+    pix_y = torch.round((cam_c[..., 1] * fy / cam_c[..., 2]) + cy).long()
+    valid = (pix_x >= 0) & (pix_x < im_w) & (pix_y >= 0) & (pix_y < im_h) & (pix_z > 0)
+    return torch.where(valid, pix_y * im_w + pix_x, torch.full_like(pix_x, -1)), pix_z
+
+
+def tsdf_integrate(depth, pix_idx, pix_z, size, resolution, default_tsdf=1.0):
+    """depth2tsdf.py:68-86 `TSDFVolume.integrate`: depth (b,m,h,w) -> (b, res, res, res)."""
+    depth = torch.as_tensor(depth, dtype=torch.float32)
+    b, m = depth.shape[:2]
+    trunc = 4 * (size / resolution)
+    valid_pix = pix_idx >= 0
+    flat = depth.reshape(b, m, -1)
+    depth_val = torch.gather(flat, 2, pix_idx.clamp(min=0).unsqueeze(0).expand(b, -1, -1))
+    depth_diff = depth_val - pix_z
+    tsdf = torch.clamp(depth_diff / trunc, max=1)
+    valid_pts = valid_pix & (depth_val > 0) & (depth_diff >= -trunc)
+    n_valid = valid_pts.float().sum(dim=1)
+    weight = torch.where(valid_pts != 0, 1.0 / n_valid.unsqueeze(1), torch.zeros(1))
+    vol = (tsdf * weight).sum(dim=1) + default_tsdf * (n_valid == 0)
+    return vol.reshape(b, resolution, resolution, resolution)
 
 
 def ball_query(xyz, centers, radius, nsample):

@@ -52,6 +52,9 @@ SIGNATURES = {
     "pm_maxpool_rows_f32": (I, [P, L, I, I, P, L, P, P]),
     "pm_maxpool_rows_bwd_f32": (I, [P, L, P, L, I, I, P, P, P]),
     "pm_depth_backproject_f32": (I, [P, I, I, I, I, P, F, F, F, F, P, P, P, P]),
+    "pm_im2col3d_f32": (I, [P, I, I, I, I, I, I, I, I, L, L, L, L, L, P, I, P]),
+    "pm_col2im3d_f32": (I, [P, I, I, I, I, I, I, I, I, L, L, L, L, L, P, P, I, P]),
+    "pm_tsdf_integrate_f32": (I, [P, P, P, I, I, L, L, F, F, P, P]),
     "pm_sa_supported": (I, [I, I, I, I]),
     "pm_sa_packed_elems": (Z, [I, I, I]),
     "pm_sa_pack_weights_f32": (I, [P, P, I, I, I, P, P]),

@@ -422,17 +422,122 @@ class PointNet2(_HipNet):
                 dpooled = ops.group_concat_bwd(drows, idx_g, B, P_l, cf, ldo).view(B * P_l, cf)
 
 
+class _ConvEncoder(nn.Module):
+    """Parameter container with the reference's names (network.py:116-139 `Encoder`: conv1..conv3)."""
+
+    def __init__(self, in_channels, filters, kernels, strides):
+        super().__init__()
+        chans = [in_channels] + list(filters)
+        for i in range(3):
+            setattr(self, f"conv{i + 1}", nn.Conv3d(chans[i], chans[i + 1], kernels[i], stride=strides[i],
+                                                    padding=kernels[i] // 2))
+
+
+class Conv3DNet(_HipNet):
+    """network.py:67-94: TSDF student.  Encoder = Conv3d(1,16,k5,s3) - act - Conv3d(16,32,k3,s3) - act -
+    Conv3d(32,32,k3,s2) - act on a res^3 volume (50^3 -> 17^3 -> 6^3 -> 3^3), flatten (channels first, 32*27)
+    [+ proprio] -> Linear 256 - act - Linear out.  `state_dict` keys and default initialisation are the
+    reference's (`encoder.conv{1,2,3}.{weight,bias}`, `final_mlp.{0,2}.*`).
+    Each convolution runs as a patch gather (pm_im2col3d_f32) + the fp32 MFMA Linear kernel on
+    conv.weight viewed (Cout, Cin*k^3); layer outputs stay channels-last ((b, d, h, w) rows x Cout) and are read
+    through strides by the next gather.  Backward: Linear backward kernels + pm_col2im3d_f32 (which folds tanh')."""
+
+    FILTERS, KERNELS, STRIDES = (16, 32, 32), (5, 3, 3), (3, 3, 2)
+
+    def __init__(self, input_dim, output_dim, net_cfg, proprio_shape):
+        super().__init__()
+        self.res = round(input_dim ** (1 / 3))
+        act = net_cfg['activation']
+        code = _act_code(act)
+        self.encoder = _ConvEncoder(1, self.FILTERS, self.KERNELS, self.STRIDES)
+        self.activation = get_activation(act)
+        self.final_mlp = nn.Sequential(nn.Linear(32 * 27 + proprio_shape, 256), self.activation, nn.Linear(256, output_dim))
+        self.proprio_shape = proprio_shape
+        ext = [self.res]
+        for k, st in zip(self.KERNELS, self.STRIDES):
+            ext.append(ops.conv3d_out(ext[-1], k, st, k // 2))
+        if ext[-1] ** 3 * self.FILTERS[-1] != 32 * 27:
+            raise ValueError(f"Conv3DNet: a {self.res}^3 volume does not reduce to 3^3 (network.py:75 hard-codes 32*27)")
+        object.__setattr__(self, "_ext", ext)
+        object.__setattr__(self, "_act", code)
+        object.__setattr__(self, "_head", _LinearChain([self.final_mlp[0], self.final_mlp[2]], code))
+        object.__setattr__(self, "_conv_grads", None)
+        object.__setattr__(self, "_w1p", None)
+
+    def _convs(self):
+        return [self.encoder.conv1, self.encoder.conv2, self.encoder.conv3]
+
+    def set_grad_views(self, views):
+        self._head.grads = [(views[f"final_mlp.{i}.weight"], views[f"final_mlp.{i}.bias"]) for i in (0, 2)]
+        object.__setattr__(self, "_conv_grads", [(views[f"encoder.conv{i}.weight"], views[f"encoder.conv{i}.bias"])
+                                                 for i in (1, 2, 3)])
+
+    def hip_forward(self, x, out=None):
+        B, r = x.shape[0], self.res
+        vol = x[:, :r ** 3].unflatten(1, (1, r, r, r))                   # 5-D view (row stride = the obs width)
+        convs, ext = self._convs(), self._ext
+        # conv1's K = 125 is not a multiple of 4: a (16,128) zero-padded copy of the weight lets the GEMM use 16-B loads
+        w1 = convs[0].weight.data.view(self.FILTERS[0], -1)
+        k1 = w1.shape[1]
+        k1p = (k1 + 3) // 4 * 4
+        if self._w1p is None or self._w1p.device != x.device:
+            object.__setattr__(self, "_w1p", torch.zeros(self.FILTERS[0], k1p, device=x.device))
+        self._w1p[:, :k1].copy_(w1)
+        saved = []
+        cur = vol
+        for i, conv in enumerate(convs):
+            k, st = self.KERNELS[i], self.STRIDES[i]
+            w = self._w1p if i == 0 else conv.weight.data.view(conv.out_channels, -1)
+            cols = ops.im2col3d(cur, k, st, k // 2, w.shape[1])
+            y = torch.empty(cols.shape[0], conv.out_channels, device=x.device)
+            ops.linear_fwd(cols, w, conv.bias.data, y, self._act)
+            e = ext[i + 1]
+            saved.append((cur, cols, y))
+            cur = y.view(B, e, e, e, conv.out_channels).permute(0, 4, 1, 2, 3)      # channels-last storage, NCDHW view
+        fbuf = torch.empty(B, 32 * 27 + self.proprio_shape, device=x.device)
+        fbuf[:, :32 * 27].view(B, 32, 27).copy_(cur.reshape(B, 32, 27))           # channels-first flatten (network.py:88,90)
+        if self.proprio_shape != 0:
+            fbuf[:, 32 * 27:].copy_(x[:, -self.proprio_shape:])
+        object.__setattr__(self, "_saved", saved)
+        return self._head.forward(fbuf, out)
+
+    def hip_backward(self, dy):
+        saved, B = self._saved, dy.shape[0]
+        ws = self._workspace(dy.device)
+        convs, ext = self._convs(), self._ext
+        dfbuf = torch.empty(B, 32 * 27 + self.proprio_shape, device=dy.device)
+        self._head.backward(dy, ws, dx_out=dfbuf, x_is_activation=True)       # d z3 in the flattened layout (tanh' folded)
+        dz = torch.empty(B * 27, 32, device=dy.device)
+        dz.view(B, 27, 32).copy_(dfbuf[:, :32 * 27].view(B, 32, 27).transpose(1, 2))
+        for i in (2, 1, 0):
+            conv, (x5, cols, y) = convs[i], saved[i]
+            k, st = self.KERNELS[i], self.STRIDES[i]
+            dW, db = self._conv_grads[i]
+            if i == 0:
+                dwp = torch.empty_like(self._w1p)
+                ops.linear_bwd_weight(dz, cols, dwp, db, ws)
+                dW.view(conv.out_channels, -1).copy_(dwp[:, :dW[0].numel()])
+                break                                                        # the volume is data: no gradient to it
+            ops.linear_bwd_weight(dz, cols, dW.view(conv.out_channels, -1), db, ws)
+            dcols = torch.empty_like(cols)
+            ops.linear_bwd_data(dz, conv.weight.data.view(conv.out_channels, -1), None, dcols, ops.ACT_NONE)
+            y_prev = saved[i - 1][2]                                          # this layer's input = previous tanh output
+            dz = torch.empty_like(y_prev)
+            e, c = ext[i], convs[i - 1].out_channels
+            as5 = lambda t: t.view(B, e, e, e, c).permute(0, 4, 1, 2, 3)
+            ops.col2im3d(dcols, as5(dz), k, st, k // 2, as5(y_prev))
+
+
 def _out_of_scope(name):
     class _Stub(nn.Module):
         def __init__(self, *a, **k):
             raise NotImplementedError(
-                f"backbone '{name}' (reference network.py) is an image/TSDF student outside this build's hot-path "
-                "scope (SURVEY.md §8f rank 4); MLP and PointNet are implemented")
+                f"backbone '{name}' (reference network.py) is an image / pooled-TSDF student outside this build's hot-path "
+                "scope (SURVEY.md §8f rank 4); MLP, PointNet, PointNet2 and Conv3DNet are implemented")
     _Stub.__name__ = name
     return _Stub
 
 
-Conv3DNet = _out_of_scope("Conv3DNet")
 PoolConv3DNet = _out_of_scope("PoolConv3DNet")
 ResNet = _out_of_scope("ResNet")
 depthResNet = _out_of_scope("depthResNet")

@@ -427,3 +427,43 @@ def depth_backproject(depth, cam_pose, fx, fy, cx, cy, lo, hi):
                                        float(cy), ctypes.cast(lo3, ctypes.c_void_p), ctypes.cast(hi3, ctypes.c_void_p),
                                        _ptr(out), _stream()), "pm_depth_backproject_f32")
     return out
+
+
+# ----------------------------------------------------------------------------- Conv3D students
+def conv3d_out(n, k, stride, pad):
+    return (n + 2 * pad - k) // stride + 1
+
+
+def im2col3d(x5, k, stride, pad, ldc):
+    """x5: a 5-D VIEW (B, C, D, H, W) with arbitrary strides -> cols (B*Do*Ho*Wo, ldc)."""
+    _req(x5)
+    B, Cc, D, H, W = x5.shape
+    Do, Ho, Wo = (conv3d_out(n, k, stride, pad) for n in (D, H, W))
+    cols = torch.empty(B * Do * Ho * Wo, ldc, dtype=torch.float32, device=x5.device)
+    check(lib.pm_im2col3d_f32(_ptr(x5), B, Cc, D, H, W, k, stride, pad, *x5.stride(), _ptr(cols), ldc, _stream()),
+          "pm_im2col3d_f32")
+    return cols
+
+
+def col2im3d(dcols, dx5, k, stride, pad, y_tanh5=None):
+    """dcols (B*Do*Ho*Wo, ldc) -> every element of the 5-D view dx5 (B, C, D, H, W); y_tanh5 = the layer input
+    (a tanh output, same shape AND strides as dx5): its derivative is folded in."""
+    _req(dcols, dx5, y_tanh5)
+    B, Cc, D, H, W = dx5.shape
+    if y_tanh5 is not None and (y_tanh5.shape != dx5.shape or y_tanh5.stride() != dx5.stride()):
+        raise ValueError("col2im3d: y_tanh5 must be laid out like dx5")
+    check(lib.pm_col2im3d_f32(_ptr(dcols), B, Cc, D, H, W, k, stride, pad, *dx5.stride(), _ptr(y_tanh5), _ptr(dx5),
+                              _rows(dcols, "dcols"), _stream()), "pm_col2im3d_f32")
+
+
+def tsdf_integrate(depth, pix_idx, pix_z, trunc, default_tsdf):
+    """depth (B,M,H,W), pix_idx (M,V) int32, pix_z (M,V) -> (B,V)."""
+    _req(depth, pix_idx, pix_z)
+    _f32c(depth, "depth")
+    _f32c(pix_z, "pix_z")
+    B, M, H, W = depth.shape
+    V = pix_idx.shape[1]
+    out = torch.empty(B, V, dtype=torch.float32, device=depth.device)
+    check(lib.pm_tsdf_integrate_f32(_ptr(depth), _ptr(pix_idx), _ptr(pix_z), B, M, H * W, V, float(trunc),
+                                    float(default_tsdf), _ptr(out), _stream()), "pm_tsdf_integrate_f32")
+    return out

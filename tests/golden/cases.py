@@ -196,3 +196,32 @@ def bc_write_dataset(c, folder):
         np.save(os.path.join(scene, f"step_{str(i).zfill(5)}.npy"),
                 dict(tsdf=d["tsdf"][i], action=d["action"][i], proprio_state=d["proprio_state"][i]), allow_pickle=True)
     return d
+
+
+# ---- Conv3D TSDF student (network.py:67-94) -----------------------------------------------------------------------
+CONV3D_CASES = {
+    "conv3d_proprio": dict(B=3, res=50, proprio=5, out=10, seed=501),
+    "conv3d_plain": dict(B=2, res=50, proprio=0, out=1, seed=502),
+}
+
+
+def conv3d_state(c):
+    """Deterministic `Conv3DNet.state_dict()` (keys of network.py:71-79,119-121), fan-in scaled uniforms."""
+    sd = {}
+    chans, kern = [1, 16, 32, 32], [5, 3, 3]
+    for i in range(3):
+        fan = chans[i] * kern[i] ** 3
+        w, b = linear_init(chans[i + 1], fan, c["seed"] * 10 + i, 1.7)
+        sd[f"encoder.conv{i + 1}.weight"] = w.reshape(chans[i + 1], chans[i], kern[i], kern[i], kern[i])
+        sd[f"encoder.conv{i + 1}.bias"] = b
+    for j, (o, i_) in zip((0, 2), ((256, 32 * 27 + c["proprio"]), (c["out"], 256))):
+        w, b = linear_init(o, i_, c["seed"] * 10 + 5 + j, 1.7)
+        sd[f"final_mlp.{j}.weight"], sd[f"final_mlp.{j}.bias"] = w, b
+    return sd
+
+
+def conv3d_inputs(c):
+    """TSDF-like volumes in [-1, 1] (+ proprio tail) and the upstream gradient."""
+    x = det_uniform((c["B"], c["res"] ** 3 + c["proprio"]), c["seed"] + 100, -1.0, 1.0)
+    dy = det_normal((c["B"], c["out"]), c["seed"] + 200)
+    return dict(x=x, dy=dy)

@@ -287,6 +287,23 @@ def gen_bc(ref_algos, cases):
         print("wrote", name, "losses", out["loss_trace"])
 
 
+def gen_conv3d(ref_algos, cases):
+    """The reference's own Conv3DNet (algorithms/algo_utils/network.py:67-94): forward outputs and a strided sample
+    of every parameter gradient of sum(out * dy)."""
+    from algorithms.algo_utils.network import Conv3DNet
+    for name, c in cases.CONV3D_CASES.items():
+        net = Conv3DNet(c["res"] ** 3, c["out"], {"activation": "tanh"}, c["proprio"])
+        load_sd(net, cases.conv3d_state(c))
+        inp = cases.conv3d_inputs(c)
+        out = net(torch.from_numpy(inp["x"]))
+        (out * torch.from_numpy(inp["dy"])).sum().backward()
+        fx = dict(out=out.detach().numpy())
+        for k, v in net.named_parameters():
+            fx["grad_" + k] = v.grad.numpy().reshape(-1)[::7].copy()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+        print("wrote", name, "out[0]", fx["out"][0][:3])
+
+
 def gen_depth2pc(cases):
     """Runs the reference's own TSDFVolume.depth2pc (utils/depth2tsdf.py) file by path.  Its two absent
     dependencies are stubbed: `skimage` (unused by this method) and `pytorch3d.ops.sample_farthest_points`,
@@ -316,10 +333,15 @@ def gen_depth2pc(cases):
         vol = mod.TSDFVolume("cpu", size=c["size"], resolution=10, _vol_origin=c["vol_origin"])
         vol.register_camera(inp["cam_pose"], np.asarray(c["intr"], dtype=np.float32), c["h"], c["w"], c["b"])
         final = vol.depth2pc(torch.from_numpy(inp["depth"]))
+        tsdf = vol.integrate(torch.from_numpy(inp["depth"])).numpy().copy()          # depth2tsdf.py:68-86, resolution 10
         # the method hard-codes K=1024 (depth2tsdf.py:160); the case's K-sample prefix is what the tests compare
         idx = R.fps(rec["world"], c["K"])
+        # registration-time voxel -> pixel tables of the reference (they come out of a host bmm whose last bit
+        # depends on the CPU, so they are part of the fixture)
+        pix_idx = torch.where(vol.valid_pix, vol.valid_pix_y * c["w"] + vol.valid_pix_x,
+                              torch.full_like(vol.valid_pix_x, -1)).numpy().astype(np.int32)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), world=rec["world"], final_pc_1024=final.numpy(),
-                            idx=idx.astype(np.int32))
+                            idx=idx.astype(np.int32), tsdf=tsdf, tsdf_pix_idx=pix_idx, tsdf_pix_z=vol.pix_z.numpy())
         print("wrote", name, "valid fraction", float((rec["world"] != 0).any(-1).mean()))
 
 
@@ -327,7 +349,7 @@ def main():
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
     from tests.golden import cases
-    which = sys.argv[1:] or ["gae", "ppo", "dagger", "depth2pc", "bc"]
+    which = sys.argv[1:] or ["gae", "ppo", "dagger", "depth2pc", "bc", "conv3d"]
     if "depth2pc" in which:
         gen_depth2pc(cases)
         which = [w for w in which if w != "depth2pc"]
@@ -342,6 +364,8 @@ def main():
         gen_dagger(ref, cases)
     if "bc" in which:
         gen_bc(ref, cases)
+    if "conv3d" in which:
+        gen_conv3d(ref, cases)
 
 
 if __name__ == "__main__":

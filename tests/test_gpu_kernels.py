@@ -321,3 +321,22 @@ def test_depth2pc_streaming_fps_on_a_camera_sized_cloud():
     assert np.array_equal(world.cpu().numpy(), world_ref)
     idx = ops.fps(world, 48, ops.Workspace(DEV))
     assert np.array_equal(idx.cpu().numpy().astype(np.int64), idx_ref)
+
+
+def test_tsdf_integrate_matches_reference():
+    """TSDFVolume.integrate (pm_tsdf_integrate_f32) against the REFERENCE's own volume (fixture), bit for bit."""
+    from partmanip_amd.depth2tsdf import TSDFVolume
+    c = cases.DEPTH2PC_CASES["depth2pc_small"]
+    inp, fx = cases.depth2pc_inputs(c), load_fixture("depth2pc_small")
+    vol = TSDFVolume(DEV, size=c["size"], resolution=10, _vol_origin=c["vol_origin"])
+    vol.register_camera(inp["cam_pose"], np.asarray(c["intr"], dtype=np.float32), c["h"], c["w"], c["b"])
+    depth = torch.from_numpy(inp["depth"]).to(DEV)
+    out = vol.integrate(depth)
+    assert tuple(out.shape) == (c["b"], 10, 10, 10)
+    # own registration tables (host bmm: last bit of the voxel depths is CPU-dependent) -> fp32 round-off class
+    assert np.array_equal(vol._pix_idx.cpu().numpy(), fx["tsdf_pix_idx"])
+    np.testing.assert_allclose(out.cpu().numpy(), fx["tsdf"], rtol=0, atol=2e-6)
+    # the kernel itself, on the reference's tables: bit-identical
+    vol._pix_idx = torch.from_numpy(fx["tsdf_pix_idx"]).to(DEV)
+    vol.pix_z = torch.from_numpy(fx["tsdf_pix_z"]).to(DEV)
+    assert np.array_equal(vol.integrate(depth).cpu().numpy(), fx["tsdf"])

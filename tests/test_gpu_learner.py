@@ -354,6 +354,31 @@ def test_pointnet_backward_when_one_point_wins_every_channel():
         assert rel_err(got, grads_ref[names.index("actor." + k)]) < 2e-4, k
 
 
+# ------------------------------------------------------------------------------- Conv3D TSDF student
+@pytest.mark.parametrize("name", ["conv3d_proprio", "conv3d_plain"])
+def test_conv3dnet_forward_backward_matches_reference_module(name):
+    """`network.name: Conv3DNet` on the HIP path (patch gather + MFMA Linear kernels + col2im) against the
+    REFERENCE's own module (fixture from make_golden.gen_conv3d): outputs and parameter gradients."""
+    from partmanip_amd.algo_utils import ActorCritic
+    c, fx = cases.CONV3D_CASES[name], load_fixture(name)
+    net = dict(name="Conv3DNet", activation="tanh")
+    O = c["res"] ** 3 + c["proprio"]
+    ac = ActorCritic(O, c["out"], dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net), c["proprio"]).to(DEV)
+    sd = cases.conv3d_state(c)
+    ac.actor.load_state_dict({k: t(v.copy()) for k, v in sd.items()})
+    f = ac.flat()
+    inp = cases.conv3d_inputs(c)
+    out = ac.actor.hip_forward(t(inp["x"]).to(DEV))
+    np.testing.assert_allclose(out.cpu().numpy(), fx["out"], rtol=2e-5, atol=3e-6)
+    ac.actor.hip_backward(t(inp["dy"]).to(DEV))
+    off = 0
+    for k, v in ac.actor.named_parameters():
+        got = f["grad_actor"][off:off + v.numel()].cpu().numpy()[::7]
+        off += v.numel()
+        ref = fx["grad_" + k]
+        assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-7, k
+
+
 # ------------------------------------------------------------------------------- PointNet++ backbone
 PN2_UNFUSED = dict(npoints=[128, 32], radii=[0.25, 0.5], nsamples=[16, 16], mlps=[[32, 32, 64], [64, 64, 128], [128, 256]])
 # the shapes the fused SA kernels are instantiated for (pm_sa_fwd_f32 / pm_sa_bwd_f32); 130 / 33 centres make the

@@ -7,7 +7,7 @@ import torch
 
 from oracle import ref_cpu as R
 from tests.golden import cases
-from tests.helpers import load_fixture, t, state_dict_t, ppo_cfg, ppo_rollout, flat_state
+from tests.helpers import load_fixture, t, state_dict_t, ppo_cfg, ppo_rollout, flat_state, assert_params_close
 
 
 @pytest.mark.parametrize("name", list(cases.GAE_CASES))
@@ -76,8 +76,13 @@ def test_ppo_update(name):
         np.testing.assert_allclose(log["Train/" + k], float(fx["log_" + k]), rtol=2e-4, atol=2e-6, err_msg=k)
     fin = flat_state(p)
     s = int(fx["final_stride"])
-    np.testing.assert_allclose(fin[::s], fx["final_flat"], rtol=0, atol=2e-5)
-    np.testing.assert_allclose(fin.astype(np.float64).sum(), float(fx["final_sum"]), rtol=1e-6, atol=1e-4)
+    # same torch, different host CPU => different sgemm summation order; Adam turns a gradient element that is ~0
+    # at step 1 into a move of up to lr whatever its sign, so a handful of elements may differ by O(lr):
+    # 99.9 % within 2e-5, none beyond 2.5 * lr * steps (the bound the GPU tests use, tests/test_gpu_learner.py)
+    diff = np.abs(fin[::s].astype(np.float64) - fx["final_flat"].astype(np.float64))
+    assert np.quantile(diff, 0.999) < 2e-5, np.quantile(diff, 0.999)
+    assert diff.max() < 2.5 * c["lr"] * len(fx["loss_trace"]), diff.max()
+    np.testing.assert_allclose(fin.astype(np.float64).sum(), float(fx["final_sum"]), rtol=1e-6, atol=1e-3)
     adam_a = out["opt"][0]
     np.testing.assert_allclose(adam_a.m[-1].numpy(), fx["adam_logstd_m"], rtol=1e-3, atol=1e-7)
     np.testing.assert_allclose(adam_a.v[-1].numpy(), fx["adam_logstd_v"], rtol=1e-3, atol=1e-9)
@@ -120,7 +125,7 @@ def test_dagger(name):
     np.testing.assert_allclose(out["log"]["Train/learning_rate"], float(fx["log_learning_rate"]), rtol=1e-12)
     fin = flat_state(stu)
     s = int(fx["final_stride"])
-    np.testing.assert_allclose(fin[::s], fx["final_flat"], rtol=0, atol=2e-5)
+    assert_params_close(fin[::s], fx["final_flat"], c["lr"], len(fx["loss_trace"]))
 
 
 def test_dagger_small_buffer_returns_early():
@@ -165,3 +170,42 @@ def test_bc_restatement_matches_reference_run():
     np.testing.assert_allclose(out["loss_trace"], fx["loss_trace"], rtol=2e-6)
     np.testing.assert_allclose(out["lr_trace"], fx["lr_trace"], rtol=1e-12)
     np.testing.assert_allclose(flat_state(p), fx["final_flat"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["conv3d_proprio", "conv3d_plain"])
+def test_conv3dnet_restatement_matches_reference_module(name):
+    """network.py:67-94 `Conv3DNet` instantiated and run by the reference itself (make_golden.gen_conv3d): outputs
+    and a strided sample of every parameter gradient."""
+    import numpy as np
+    import torch
+    from tests.golden import cases
+    from tests.helpers import load_fixture
+    from oracle import ref_cpu as R
+    c, fx = cases.CONV3D_CASES[name], load_fixture(name)
+    p = {"actor." + k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in cases.conv3d_state(c).items()}
+    inp = cases.conv3d_inputs(c)
+    out = R.net_forward(p, "actor", dict(name="Conv3DNet", activation="tanh"), torch.from_numpy(inp["x"]), c["proprio"])
+    np.testing.assert_allclose(out.detach().numpy(), fx["out"], rtol=1e-5, atol=1e-6)
+    grads = torch.autograd.grad((out * torch.from_numpy(inp["dy"])).sum(), list(p.values()))
+    for k, g in zip(p, grads):
+        ref = fx["grad_" + k[len("actor."):]]
+        np.testing.assert_allclose(g.numpy().reshape(-1)[::7], ref, rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(ref).max())))
+
+
+def test_tsdf_integrate_restatement_matches_reference():
+    """utils/depth2tsdf.py:68-86 run by the reference's own TSDFVolume (resolution 10): bit-identical volume."""
+    import numpy as np
+    from tests.golden import cases
+    from tests.helpers import load_fixture
+    from oracle import ref_cpu as R
+    c = cases.DEPTH2PC_CASES["depth2pc_small"]
+    inp, fx = cases.depth2pc_inputs(c), load_fixture("depth2pc_small")
+    import torch
+    idx, z = R.tsdf_tables(inp["cam_pose"], c["intr"], c["h"], c["w"], c["size"], 10, c["vol_origin"])
+    # the tables come out of a host bmm: pixel indices must agree, depths to the last bit or two (CPU-dependent)
+    assert np.array_equal(idx.numpy(), fx["tsdf_pix_idx"])
+    np.testing.assert_allclose(z.numpy(), fx["tsdf_pix_z"], rtol=3e-7)
+    vol = R.tsdf_integrate(inp["depth"], torch.from_numpy(fx["tsdf_pix_idx"]).long(), torch.from_numpy(fx["tsdf_pix_z"]),
+                           c["size"], 10).numpy()
+    assert np.array_equal(vol, fx["tsdf"])                          # with the reference's tables: bit-identical
+    assert 0.05 < float((vol != 1.0).mean()) < 0.95                 # some voxels are seen, some keep the default
