@@ -59,6 +59,11 @@ DAGGER_CASES = {
                        proprio=0, A=10, n_minibatches=3, n_updates=2, lr=3e-3, lr_schedule="linear_decay",
                        sampler="random", seed=201, action_std=0.1, max_iterations=1000, it=5, torch_seed=77),
     # student PointNet (+7-d proprio appended), teacher MLP
+    # the reference's shipped default student (cfg/algos/dagger_tsdf.yaml): Conv3DNet on a 50^3 volume + proprio
+    "dagger_conv3d": dict(stu_net=dict(name="Conv3DNet", activation="tanh"), tea_net=_MLP_NET, N=4, buf_size=5, n_fill=4,
+                          O_s=50 ** 3 + 7, O_t=32, proprio=7, A=10, n_minibatches=2, n_updates=2, lr=1e-4,
+                          lr_schedule="fixed", sampler="random", seed=203, action_std=0.1, max_iterations=1000, it=5,
+                          torch_seed=79),
     "dagger_pn":  dict(stu_net=_PN_NET, tea_net=_MLP_NET, N=4, buf_size=5, n_fill=4, O_s=3072 + 7, O_t=32,
                        proprio=7, A=10, n_minibatches=2, n_updates=2, lr=1e-3, lr_schedule="fixed",
                        sampler="sequential", seed=202, action_std=0.1, max_iterations=1000, it=5, torch_seed=78),
@@ -92,6 +97,11 @@ def net_param_shapes(net, in_dim, out_dim, proprio=0):
 def actor_critic_state(net, in_dim, A, action_std, seed, proprio=0):
     """Deterministic initial `ActorCritic.state_dict()` (numpy float32), keys as actor_critic.py:16-22."""
     sd = {"log_std": np.full((A,), np.log(action_std), dtype=np.float32)}
+    if net["name"] == "Conv3DNet":
+        for which, out_dim, s0 in (("actor", A, seed * 100), ("critic", 1, seed * 100 + 50)):
+            for k, v in conv3d_state(dict(proprio=proprio, out=out_dim, seed=s0)).items():
+                sd[f"{which}.{k}"] = v
+        return sd
     for which, out_dim, s0 in (("actor", A, seed * 100), ("critic", 1, seed * 100 + 50)):
         shapes = net_param_shapes(net, in_dim, out_dim, proprio)
         for li, (key, (o, i)) in enumerate(shapes):
@@ -135,6 +145,9 @@ def dagger_raw_inputs(c):
             pts = det_uniform((N, 1024, npc // 1024), s + 10 * k + 1, -1.0, 1.0).reshape(N, npc)
             pro = det_normal((N, c["proprio"]), s + 10 * k + 2)
             stu.append(np.concatenate([pts, pro], axis=1).astype(np.float32))
+        elif c["stu_net"]["name"] == "Conv3DNet":
+            stu.append(np.concatenate([det_uniform((N, c["O_s"] - c["proprio"]), s + 10 * k + 1, -1.0, 1.0),
+                                       det_normal((N, c["proprio"]), s + 10 * k + 2)], axis=1).astype(np.float32))
         else:
             stu.append(det_normal((N, c["O_s"]), s + 10 * k + 1))
         tea.append(det_normal((N, c["O_t"]), s + 10 * k + 3))

@@ -247,7 +247,7 @@ def gen_dagger(ref_algos, cases):
         out["log_dagger_loss"] = np.float64(float(run.log_dict["Train/dagger_loss"]))
         out["log_learning_rate"] = np.float64(float(run.log_dict["Train/learning_rate"]))
         fin = flat_params(run.student.state_dict())
-        stride = 3 if c["stu_net"]["name"] == "PointNet" else 1
+        stride = 3 if c["stu_net"]["name"] in ("PointNet", "Conv3DNet") else 1
         out["final_flat"] = fin[::stride]
         out["final_stride"] = np.int64(stride)
         out["final_sum"] = np.float64(fin.astype(np.float64).sum())
