@@ -75,6 +75,11 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
+ABI_VERSION = 110                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+if lib.pm_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
+                      "Rebuild it with `python -m partmanip_amd.build`.")
+
 ERRORS = {-1: "PM_EINVAL (bad argument)", -2: "PM_EWORKSPACE (workspace too small)", -3: "PM_EALIGN (misaligned pointer)",
           -4: "PM_EUNSUPPORTED (no fused instantiation for this shape)"}
 

@@ -324,7 +324,9 @@ extern "C" int pm_pointnet_enc_fwd_f32(const float* x, long ldx, int B, int P, i
 // Work-groups are persistent over clouds (grid <= 512) so the dW2 partials stay small.
 
 #define PN_BT 32                 // backward tile (points)
+#ifndef PN_BWD_MAXG
 #define PN_BWD_MAXG 512
+#endif
 
 struct PnBwdPart {          // per-work-group partial sums (floats)
     float dW2[PN_C2 * PN_C1];

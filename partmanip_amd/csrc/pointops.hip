@@ -429,7 +429,7 @@ extern "C" int pm_maxpool_rows_bwd_f32(const float* dout, long lddo, const int32
     return PM_OK;
 }
 
-extern "C" int pm_version(void) { return 100; }
+extern "C" int pm_version(void) { return PM_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------- depth -> world cloud
 // utils/depth2tsdf.py:142-157 (`TSDFVolume.depth2pc` before the sampling): back-project every pixel of

@@ -40,7 +40,11 @@ def test_library_exports_every_declared_symbol_and_ctypes_table_matches():
         assert len(args) == nargs, f"{name}: header has {nargs} parameters, ctypes table {len(args)}"
         assert (res is ctypes.c_size_t) == (ret == "size_t"), name
     assert set(_lib.SIGNATURES) == set(fns)
-    assert so.pm_version() == 100
+    import re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "partmanip_hip.h")).read()
+    want = int(re.search(r"#define PM_ABI_VERSION (\d+)", hdr).group(1))
+    from partmanip_amd import _lib
+    assert so.pm_version() == want == _lib.ABI_VERSION
 
 
 def test_argument_validation_without_gpu():
