@@ -41,7 +41,7 @@ extern "C" {
 #define PM_ACT_TANH 1
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 110 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 111 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -225,6 +225,16 @@ int pm_maxpool_rows_bwd_f32(const float* dout, long lddo, const int32_t* arg, lo
 int pm_depth_backproject_f32(const float* depth, int B, int M, int H, int W, const float* cam_pose, float fx,
                              float fy, float cx, float cy, const float* lo, const float* hi, float* out,
                              void* stream);
+
+/* Crop compaction + variable-length FPS for the step above.  pm_depth_compact_f32: out (B, P, 3) receives, per
+ * env and in the original order, every non-zero point plus the FIRST zero point; lengths[b] = how many.  FPS over
+ * that prefix selects the same sequence of POINTS as FPS over the full cropped cloud (the zeroed points are one
+ * candidate).  pm_fps_varlen_f32: clouds are the first lengths[b] rows of a (B, ld, D) buffer; K rounds always
+ * (no -1 padding: once every point is taken the lowest index repeats, as on the full cloud); workspace
+ * B*ld floats when ld > 8192. */
+int pm_depth_compact_f32(const float* xyz, int B, int P, float* out, int32_t* lengths, void* stream);
+int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths, int32_t* idx_out,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ Conv3D students: patch gather / scatter
  * network.py:56-94 (`Conv3DNet` / `Encoder`: nn.Conv3d(k, stride, padding = k/2)).  A convolution runs as

@@ -53,15 +53,13 @@ __device__ __forceinline__ int block_argmax(float v, int i, float* sv, int* si) 
 // One work-group per cloud.  REG variant keeps the cloud and the running min-distance in
 // registers (P <= 8192); the streaming variant re-reads points from L2/HBM and keeps the
 // min-distance in a caller-supplied fp32 workspace (depth2pc-sized clouds: P = 442 368).
-template <bool REG>
-__global__ __launch_bounds__(FPS_NT) void fps_kernel(const float* __restrict__ xyz, int P, int D, int K,
-                                                      int32_t* __restrict__ idx_out, float* __restrict__ mind_ws) {
-    __shared__ float sv[FPS_NT / 64];
-    __shared__ int si[FPS_NT / 64];
-    __shared__ float sel[FPS_MAXD];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float* pts = xyz + (long)b * P * D;
-    float* mind_g = REG ? nullptr : mind_ws + (long)b * P;
+// PAD: pytorch3d's fixed-length semantics (K > P -> -1 indices); !PAD: keep sampling (all min-distances are 0 by
+// then, so the lowest index wins) -- what the full, uncompacted cloud would have produced (see depth_compact_kernel).
+template <bool REG, bool PAD>
+__device__ __forceinline__ void fps_body(const float* __restrict__ pts, int P, int D, int K,
+                                         int32_t* __restrict__ idx_b, float* __restrict__ mind_g, float* sv, int* si,
+                                         float* sel) {
+    const int tid = threadIdx.x;
     float px[FPS_RPT][FPS_MAXD];
     float mind[FPS_RPT];
     if (REG) {
@@ -77,11 +75,11 @@ __global__ __launch_bounds__(FPS_NT) void fps_kernel(const float* __restrict__ x
     }
     int cur = 0;
     for (int j = 0; j < K; ++j) {
-        if (j >= P) {                       // more samples than points: pytorch3d pads with -1
-            if (tid == 0) idx_out[(long)b * K + j] = -1;
+        if (PAD && j >= P) {                // more samples than points: pytorch3d pads with -1
+            if (tid == 0) idx_b[j] = -1;
             continue;
         }
-        if (tid == 0) idx_out[(long)b * K + j] = cur;
+        if (tid == 0) idx_b[j] = cur;
         if (tid < D) sel[tid] = pts[(long)cur * D + tid];
         __syncthreads();
         float s[FPS_MAXD];
@@ -117,6 +115,33 @@ __global__ __launch_bounds__(FPS_NT) void fps_kernel(const float* __restrict__ x
         }
         cur = block_argmax(bv, bi, sv, si);
     }
+}
+
+template <bool REG>
+__global__ __launch_bounds__(FPS_NT) void fps_kernel(const float* __restrict__ xyz, int P, int D, int K,
+                                                      int32_t* __restrict__ idx_out, float* __restrict__ mind_ws) {
+    __shared__ float sv[FPS_NT / 64];
+    __shared__ int si[FPS_NT / 64];
+    __shared__ float sel[FPS_MAXD];
+    const int b = blockIdx.x;
+    fps_body<REG, true>(xyz + (long)b * P * D, P, D, K, idx_out + (long)b * K, REG ? nullptr : mind_ws + (long)b * P, sv,
+                        si, sel);
+}
+
+// Variable-length clouds (rows of a (B, ld, D) buffer, the first lengths[b] of each are points): the path is
+// chosen per cloud on the device (no host sync on the lengths) -- registers if it fits, streaming otherwise.
+__global__ __launch_bounds__(FPS_NT) void fps_varlen_kernel(const float* __restrict__ xyz, int ld, int D, int K,
+                                                             const int32_t* __restrict__ lengths,
+                                                             int32_t* __restrict__ idx_out,
+                                                             float* __restrict__ mind_ws) {
+    __shared__ float sv[FPS_NT / 64];
+    __shared__ int si[FPS_NT / 64];
+    __shared__ float sel[FPS_MAXD];
+    const int b = blockIdx.x, n = lengths[b];
+    const float* pts = xyz + (long)b * ld * D;
+    int32_t* idx_b = idx_out + (long)b * K;
+    if (n <= FPS_NT * FPS_RPT) fps_body<true, false>(pts, n, D, K, idx_b, nullptr, sv, si, sel);
+    else fps_body<false, false>(pts, n, D, K, idx_b, mind_ws + (long)b * ld, sv, si, sel);
 }
 
 // Wave-per-cloud variant for xyz clouds of up to 2048 points (the learner's sizes: 1024 -> 256 -> 64): the cloud
@@ -430,6 +455,80 @@ extern "C" int pm_maxpool_rows_bwd_f32(const float* dout, long lddo, const int32
 }
 
 extern "C" int pm_version(void) { return PM_ABI_VERSION; }
+
+extern "C" int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths,
+                                 int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(xyz && lengths && idx_out && B > 0 && ld > 0 && D >= 1 && D <= FPS_MAXD && K > 0);
+    if (ld > FPS_NT * FPS_RPT && (!workspace || workspace_bytes < (size_t)B * ld * sizeof(float))) return PM_EWORKSPACE;
+    hipLaunchKernelGGL(fps_varlen_kernel, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, ld, D, K, lengths, idx_out,
+                       (float*)workspace);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// ---------------------------------------------------------------------------------- crop compaction
+// The cropped world cloud (depth2tsdf.py:155-159) is mostly points zeroed to the origin.  For farthest point
+// sampling they are ONE point: FPS on [all non-zero points + the first zero point, original order kept] selects
+// the same sequence of POINTS as FPS on the full cloud (equal candidates have equal distances, ties go to the
+// lowest index, and the first point of the cloud is always kept) -- and reads 3-20x less per round.
+// One work-group per env: pass 1 finds the first zero point (block min), pass 2 is a stable stream compaction:
+// wave ballot + popcount for the slot inside a wave, an LDS prefix over the 16 waves, a running base per chunk.
+__global__ __launch_bounds__(1024) void depth_compact_kernel(const float* __restrict__ xyz, int P,
+                                                              float* __restrict__ out, int32_t* __restrict__ lengths) {
+    __shared__ int wcnt[16];
+    __shared__ int s_first;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* pts = xyz + (long)b * P * 3;
+    float* dst = out + (long)b * P * 3;
+    if (tid == 0) s_first = 0x7fffffff;
+    __syncthreads();
+    int first = 0x7fffffff;
+    for (int p = tid; p < P; p += 1024)
+        if (pts[p * 3] == 0.f && pts[p * 3 + 1] == 0.f && pts[p * 3 + 2] == 0.f) {
+            first = p;                                    // ascending p per thread: the first hit is the thread's minimum
+            break;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+    if (lane == 0 && first != 0x7fffffff) atomicMin(&s_first, first);
+    __syncthreads();
+    first = s_first;
+    int base = 0;
+    for (int p0 = 0; p0 < P; p0 += 1024) {
+        const int p = p0 + tid;
+        float x = 0.f, y = 0.f, z = 0.f;
+        bool keep = false;
+        if (p < P) {
+            x = pts[p * 3]; y = pts[p * 3 + 1]; z = pts[p * 3 + 2];
+            keep = (x != 0.f || y != 0.f || z != 0.f) || p == first;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int within = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = wcnt[w];
+            before += (w < wave) ? c : 0;
+            total += c;
+        }
+        if (keep) {
+            const long q = base + before + within;
+            dst[q * 3] = x; dst[q * 3 + 1] = y; dst[q * 3 + 2] = z;
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) lengths[b] = base;
+}
+
+extern "C" int pm_depth_compact_f32(const float* xyz, int B, int P, float* out, int32_t* lengths, void* stream) {
+    PM_REQUIRE(xyz && out && lengths && B > 0 && P > 0 && xyz != out);
+    hipLaunchKernelGGL(depth_compact_kernel, dim3(B), dim3(1024), 0, pm_stream(stream), xyz, P, out, lengths);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
 
 // ---------------------------------------------------------------------------------- depth -> world cloud
 // utils/depth2tsdf.py:142-157 (`TSDFVolume.depth2pc` before the sampling): back-project every pixel of

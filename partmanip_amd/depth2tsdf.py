@@ -5,8 +5,9 @@
     tsdf.register_camera(cam_pose (m,4,4), cam_intr (3,3), im_h, im_w, num_env)     # depth2tsdf.py:30-66
     clouds = tsdf.depth2pc(depth_im (b, m, h, w))  -> (b, 1024, 3)                  # depth2tsdf.py:136-173
 
-`depth2pc` = back-projection + workspace crop (pm_depth_backproject_f32) and farthest point sampling with
-pytorch3d's defaults (pm_fps_f32: start index 0, lowest-index ties; the reference calls
+`depth2pc` = back-projection + workspace crop (pm_depth_backproject_f32), compaction of the zeroed points
+(pm_depth_compact_f32) and farthest point sampling with pytorch3d's defaults (pm_fps_varlen_f32: start index 0,
+lowest-index ties -- the same points as sampling the full cloud; the reference calls
 `pytorch3d.ops.sample_farthest_points(world_cld, K=1024)`, depth2tsdf.py:160), both on the GPU.
 `integrate` (depth -> TSDF volume for the Conv3D students, depth2tsdf.py:68-86) is pm_tsdf_integrate_f32 over voxel ->
 pixel tables built at registration time.  `sparse_voxel` and the marching-cubes `extract_point_cloud` are outside
@@ -65,8 +66,11 @@ class TSDFVolume(object):
         lo = self._vol_origin.cpu().numpy().astype(np.float32)
         hi = (np.float32(self._size) + lo).astype(np.float32)                       # `self._size + self._vol_origin`
         world = ops.depth_backproject(depth_im.float().contiguous(), self.cam_pose, cam_fx, cam_fy, cam_cx, cam_cy, lo, hi)
-        idx = ops.fps(world, K, self._ws)                                          # (b, K) int32
-        return ops.group_points(world, idx.view(idx.shape[0], K, 1)).view(idx.shape[0], K, 3)
+        # the zeroed out-of-crop points are ONE candidate for the sampler: compact them away first (same selected
+        # points, 3-20x less to read per round), then sample the variable-length clouds
+        compact, lengths = ops.depth_compact(world)
+        idx = ops.fps_varlen(compact, lengths, K, self._ws)                        # (b, K) int32 into `compact`
+        return ops.group_points(compact, idx.view(idx.shape[0], K, 1)).view(idx.shape[0], K, 3)
 
     def integrate(self, depth_im):
         """depth_im (b, m, h, w) -> TSDF volume (b, res, res, res) (depth2tsdf.py:68-86)."""

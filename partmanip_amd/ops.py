@@ -467,3 +467,27 @@ def tsdf_integrate(depth, pix_idx, pix_z, trunc, default_tsdf):
     check(lib.pm_tsdf_integrate_f32(_ptr(depth), _ptr(pix_idx), _ptr(pix_z), B, M, H * W, V, float(trunc),
                                     float(default_tsdf), _ptr(out), _stream()), "pm_tsdf_integrate_f32")
     return out
+
+
+def depth_compact(world):
+    """world (B,P,3) cropped cloud -> (compact (B,P,3): non-zero points + the first zero point, order kept; lengths (B) i32)."""
+    _req(world)
+    _f32c(world, "world")
+    B, P, _ = world.shape
+    out = torch.empty_like(world)
+    lengths = torch.empty(B, dtype=torch.int32, device=world.device)
+    check(lib.pm_depth_compact_f32(_ptr(world), B, P, _ptr(out), _ptr(lengths), _stream()), "pm_depth_compact_f32")
+    return out, lengths
+
+
+def fps_varlen(xyz, lengths, K, ws):
+    """FPS over the first lengths[b] rows of each cloud of xyz (B, ld, D) -> idx (B, K) int32 (no -1 padding)."""
+    _req(xyz, lengths)
+    _f32c(xyz, "xyz")
+    B, ld, Dd = xyz.shape
+    idx = torch.empty(B, K, dtype=torch.int32, device=xyz.device)
+    nb = B * ld * 4 if ld > 8192 else 0
+    w = ws.get(nb) if nb else None
+    check(lib.pm_fps_varlen_f32(_ptr(xyz), B, ld, Dd, K, _ptr(lengths), _ptr(idx), _ptr(w), w.numel() if w is not None else 0,
+                                _stream()), "pm_fps_varlen_f32")
+    return idx

@@ -340,3 +340,28 @@ def test_tsdf_integrate_matches_reference():
     vol._pix_idx = torch.from_numpy(fx["tsdf_pix_idx"]).to(DEV)
     vol.pix_z = torch.from_numpy(fx["tsdf_pix_z"]).to(DEV)
     assert np.array_equal(vol.integrate(depth).cpu().numpy(), fx["tsdf"])
+
+
+@pytest.mark.parametrize("P,frac_valid,K", [(5000, 0.3, 64), (40000, 0.1, 48), (3000, 0.0, 16), (2000, 1.0, 32), (700, 0.01, 40)])
+def test_depth_compact_then_varlen_fps_selects_the_same_points_as_the_full_cloud(P, frac_valid, K):
+    """Crop compaction + variable-length FPS (what TSDFVolume.depth2pc runs) against FPS over the FULL cloud by the
+    CPU restatement: the selected POINTS are identical, including when fewer distinct points than K exist."""
+    o = ops()
+    g = torch.Generator().manual_seed(P)
+    B = 3
+    xyz = torch.rand(B, P, 3, generator=g) * 2 - 1
+    keep = torch.rand(B, P, 1, generator=g) < frac_valid
+    if frac_valid > 0:
+        keep[1, 0] = True                                  # env 1 starts with a valid point, env 0/2 as drawn
+        keep[0, 0] = False
+    world = (xyz * keep).contiguous()
+    compact, lengths = o.depth_compact(world.to(DEV))
+    n = lengths.cpu().numpy()
+    nz = (world != 0).any(-1)
+    want_n = nz.sum(1).numpy() + (~nz).any(1).numpy().astype(np.int64)
+    assert np.array_equal(n, want_n)
+    idx = o.fps_varlen(compact, lengths, K, o.Workspace(torch.device(DEV)))
+    got = o.group_points(compact, idx.view(B, K, 1)).view(B, K, 3).cpu().numpy()
+    ref_idx = R.fps(world.numpy(), K)
+    want = np.take_along_axis(world.numpy(), ref_idx[..., None].repeat(3, axis=-1), axis=1)
+    assert np.array_equal(got, want)
