@@ -31,9 +31,6 @@
 #ifndef PN_ABLATE
 #define PN_ABLATE 0          // profiling only: bit0 = skip layer-3 MFMAs, bit1 = skip layer-2 MFMAs (wrong results)
 #endif
-#ifndef PN_BWD_NW
-#define PN_BWD_NW 4          // waves per backward work-group: 4 (default) or 8 (experimental, see pn_bwd8_kernel)
-#endif
 #ifndef PN_FWD_NW
 #define PN_FWD_NW 8          // waves per forward work-group (4 or 8)
 #endif
@@ -627,305 +624,6 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
 }
 #undef PN_DW1_ACCUM
 
-// ---------------------------------------------------------------------------------- backward, 8 waves
-// EXPERIMENTAL (-DPN_BWD_NW=8), not the default: measured 4.90 ms vs 4.30 ms for the 4-wave kernel at
-// 2048 clouds -- the 64-register dW2 accumulator plus the running sums leave too little of the
-// 128-VGPR budget and hipcc spills 61 dwords with ~40 scratch reloads per tile.  Kept because the
-// decomposition is the right one once the register pressure is solved (PMC says why it is wanted):
-// same algorithm with 512-thread work-groups (two per CU => FOUR waves per SIMD, <= 128 VGPRs): with two
-// waves per SIMD the two resident work-groups drift into phase (both in MFMA loops, then both in
-// VALU/LDS phases) and the MFMA pipe idled 34 % of the time (PMC: SQ_VALU_MFMA_BUSY 65.6 %).
-//   layer 2 : wave w -> channels [32w, 32w+32)                      acc 1x1
-//   dW2     : wave w -> out-channels [32w, 32w+32) x all 128 in     acc 1x4 (lives for the whole kernel)
-//   dh1     : wave w -> in-block (w&3), k-half (w>>2) of K = 256    acc 1x1, halves combined through LDS
-//   rows    : wave w owns tile rows [4w, 4w+4)
-template <int CT>
-__global__ __launch_bounds__(512, 4) void pn_bwd8_kernel(
-    const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
-    const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ W3,
-    const float* __restrict__ packed, int max_mean, const float* __restrict__ dfeat, long ldf,
-    const int32_t* __restrict__ argmax, const float* __restrict__ U, float* __restrict__ H2sum,
-    float* __restrict__ Hg, int32_t* __restrict__ slotmap, PnBwdPart* __restrict__ parts) {
-    constexpr int BT = PN_BT, NT = 512, RPW = BT / 8;
-    __shared__ __attribute__((aligned(16))) float smem[BT * PN_LD1 * 2 + BT * PN_LD2 + BT * PN_MAXC + PN_C2 + PN_C3 +
-                                                        PN_C3 + 520 + 32];
-    float* H1 = smem;                                   // [32][132]  (also scratch for cross-wave reductions)
-    float* DZ1 = H1 + BT * PN_LD1;                      // [32][132]
-    float* H2 = DZ1 + BT * PN_LD1;                      // [32][260]  h2, then dz2 in place
-    float* Xs = H2 + BT * PN_LD2;                       // [32][8]
-    float* Us = Xs + BT * PN_MAXC;                      // [256]  u[b,:]/P
-    float* Gm = Us + PN_C2;                             // [512]  dmax[b,:]
-    int* keys = (int*)(Gm + PN_C3);                     // [512]  sorted (slot<<19 | point<<9 | channel)
-    unsigned short* offs = (unsigned short*)(keys + PN_C3);   // [P/RPW+1 <= 1025]
-    double* red = (double*)((float*)(keys + PN_C3) + 520);    // 16 doubles
-
-    const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
-    const float4* P2v = (const float4*)(packed + PN_P2_OFF);
-    const float4* P2Tv = (const float4*)(packed + PN_P2T_OFF);
-    const float invP = 1.0f / (float)P;
-
-    f32x16 accW2[1][4];                                  // dW2[out = wave*32 + row][in = nb*32 + li]
-    zero_acc<1, 4>(accW2);
-    float4 db2acc = make_float4(0.f, 0.f, 0.f, 0.f);   // columns 4*lane..+3 over this wave's rows
-    float dW1acc[PN_MAXC], db1acc = 0.f;                 // channel tid&127, point quarter tid>>7
-#pragma unroll
-    for (int d = 0; d < PN_MAXC; ++d) dW1acc[d] = 0.f;
-
-    const int ntiles = P / BT;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        const float* xb = x + (long)b * ldx;
-        float cen[3] = {0.f, 0.f, 0.f};
-        __syncthreads();
-        if (sub_mean) cloud_centroid<NT>(xb, P, C, red, cen);
-        if (tid < PN_C2) Us[tid] = max_mean ? U[(long)b * PN_C2 + tid] * invP : 0.f;
-        Gm[tid] = dfeat[(long)b * ldf + tid];
-        keys[tid] = (argmax[(long)b * PN_C3 + tid] << 9) | tid;
-        // bitonic sort of the 512 keys: threads 0..255 each own one compare-exchange pair per stage
-#pragma unroll 1
-        for (int k = 2; k <= 512; k <<= 1) {
-#pragma unroll 1
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                __syncthreads();
-                if (tid < 256) {
-                    const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
-                    const int ixj = i | j;
-                    const int a = keys[i], c = keys[ixj];
-                    if ((a > c) == ((i & k) == 0)) {
-                        keys[i] = c;
-                        keys[ixj] = a;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        for (int p = tid; p <= P / RPW; p += NT) {       // offs[i] = #keys with point < i * RPW
-            int lo = 0, hi = PN_C3;
-            const int target = (p * RPW) << 9;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (keys[mid] < target) lo = mid + 1; else hi = mid;
-            }
-            offs[p] = (unsigned short)lo;
-        }
-        {   // slot[e] = number of distinct arg-max points before sorted entry e (one entry per thread)
-            const int q = keys[tid] >> 9, qm = (tid > 0) ? (keys[tid - 1] >> 9) : -1;
-            const int f = (q != qm);
-            int v = f;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(v, o, 64);
-                if (lane0 >= o) v += t;
-            }
-            int* wtot = (int*)red;
-            __syncthreads();                              // neighbour keys read; binary searches done
-            if (lane0 == 63) wtot[wave] = v;
-            __syncthreads();
-            int base = 0;
-            for (int w2 = 0; w2 < wave; ++w2) base += wtot[w2];
-            const int sl = base + v - 1;
-            keys[tid] |= sl << 22;
-            slotmap[(long)b * PN_C3 + (keys[tid] & 511)] = sl;
-        }
-        float4 h2s = make_float4(0.f, 0.f, 0.f, 0.f);
-
-        for (int tile = 0; tile < ntiles; ++tile) {
-            int lane = lane0;                              // laundered per tile: see pn_fwd_kernel
-            asm volatile("" : "+v"(lane));
-            const int li = lane & 31, lh = lane >> 5;
-            __syncthreads();
-            stage_points<BT, NT>(xb, tile, C, sub_mean, cen, Xs);
-            __syncthreads();
-            layer1_tile<CT, BT, NT>(Xs, W1, b1, C, H1);
-            __syncthreads();
-            {
-                f32x16 acc2[1][1];
-                zero_acc<1, 1>(acc2);
-                layer2_mfma<1, 1>(H1, P2v, wave, lane, acc2);
-                layer2_store<1, 1>(acc2, b2, wave, lane, H2);
-            }
-            __syncthreads();
-            // ---- row-owner pass: wave w owns rows 4w..4w+3; h2 -> dz2 in place -----------------
-            {
-                const int p0 = tile * BT + wave * RPW;
-                const float4 u4 = *(const float4*)(Us + 4 * lane);
-                const int e_end = offs[p0 / RPW + 1];
-                int e = offs[p0 / RPW];
-                // Row boundaries inside this wave's run of sorted keys (slot<<22 | point<<9 | channel) come from
-                // one ballot per row over the run (lane j looks at entry e + j) -- wave-uniform, no per-point
-                // table, so clouds up to 4096 points fit the same LDS; runs longer than 64 entries (rare) search.
-                const int e0 = e, span = e_end - e0;
-                const int pj = (lane < span) ? ((keys[e0 + lane] >> 9) & 0x1FFF) : 0x7FFFFFFF;
-                int c_next = 0;
-                float4 w_next = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < e_end) {
-                    c_next = keys[e] & 511;
-                    w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
-                }
-#pragma unroll 1
-                for (int rr = 0; rr < RPW; ++rr) {
-                    float* hrow = H2 + (wave * RPW + rr) * PN_LD2 + 4 * lane;
-                    const float4 h = *(const float4*)hrow;
-                    h2s.x += h.x; h2s.y += h.y; h2s.z += h.z; h2s.w += h.w;
-                    float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
-                    int row_end;
-                    if (span <= 64) {
-                        row_end = e0 + __popcll(__ballot(pj <= p0 + rr));
-                    } else {
-                        int lo = e, hi = e_end;
-                        const int target = (p0 + rr + 1) << 9;
-                        while (lo < hi) {
-                            const int mid = (lo + hi) >> 1;
-                            if ((keys[mid] & 0x3FFFFF) < target) lo = mid + 1; else hi = mid;
-                        }
-                        row_end = lo;
-                    }
-                    if (e < row_end)                                  // this point is some channel's arg-max
-                        *(float4*)(Hg + ((long)b * PN_C3 + (keys[e] >> 22)) * PN_C2 + 4 * lane) = h;
-                    for (; e < row_end; ++e) {
-                        const int c = c_next;
-                        const float4 w3 = w_next;
-                        if (e + 1 < e_end) {
-                            c_next = keys[e + 1] & 511;
-                            w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
-                        }
-                        const float g = Gm[c];
-                        S.x += g * w3.x; S.y += g * w3.y; S.z += g * w3.z; S.w += g * w3.w;
-                    }
-                    float4 dz;
-                    dz.x = (u4.x + S.x) * (1.0f - h.x * h.x);
-                    dz.y = (u4.y + S.y) * (1.0f - h.y * h.y);
-                    dz.z = (u4.z + S.z) * (1.0f - h.z * h.z);
-                    dz.w = (u4.w + S.w) * (1.0f - h.w * h.w);
-                    *(float4*)hrow = dz;
-                    db2acc.x += dz.x; db2acc.y += dz.y; db2acc.z += dz.z; db2acc.w += dz.w;
-                }
-            }
-            __syncthreads();
-            // ---- dW2 += dz2^T * h1 : K = 32 points (lanes<32: point s, lanes>=32: point 16+s) ----
-            {
-                const float* Ap = H2 + (lh * (BT / 2)) * PN_LD2 + wave * 32 + li;     // A[i=out][k=pt] = dz2[pt][out]
-                const float* Bp = H1 + (lh * (BT / 2)) * PN_LD1 + li;                 // B[k=pt][j=in] = h1[pt][in]
-                float ap, bvp[4], aq, bvq[4];
-#define DW2_LOAD(a, bv, s_)                                        \
-    a = Ap[(s_) * PN_LD2];                                         \
-    _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) bv[nb] = Bp[(s_) * PN_LD1 + nb * 32];
-#define DW2_MMA(a, bv)                                              \
-    _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) accW2[0][nb] = MFMA(a, bv[nb], accW2[0][nb]);
-                DW2_LOAD(ap, bvp, 0)
-#pragma unroll 1
-                for (int s = 0; s < BT / 2; s += 2) {
-                    DW2_LOAD(aq, bvq, s + 1)
-                    __builtin_amdgcn_sched_barrier(0);
-                    DW2_MMA(ap, bvp)
-                    __builtin_amdgcn_sched_barrier(0);
-                    DW2_LOAD(ap, bvp, s + 2)               // unconditional (last trip reads rows past the tile: discarded)
-                    __builtin_amdgcn_sched_barrier(0);
-                    DW2_MMA(aq, bvq)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#undef DW2_LOAD
-#undef DW2_MMA
-            }
-            // ---- dh1 = dz2 * W2 : in-block (wave&3), k-half (wave>>2): 64 k per lane half --------
-            {
-                const int nbw = wave & 3, kh = wave >> 2;
-                f32x16 accH[1][1];
-                zero_acc<1, 1>(accH);
-                // packed P2T is [nb][32 groups][lane'][4] with k = (lane'>>5)*128 + 4*g' + e: this wave's
-                // k = kh*128 + lh*64 + 4*g + e is the element (lane' = kh*32 + li, g' = lh*16 + g)
-                mfma_stream<1, 1, 16>(H2 + li * PN_LD2 + kh * 128 + lh * 64, PN_LD2,
-                                      P2Tv + (size_t)(nbw * 32 + lh * 16) * 64 + kh * 32 + li, accH);
-                const int col = nbw * 32 + li;
-                if (kh == 1) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) DZ1[((r & 3) + 8 * (r >> 2) + 4 * lh) * PN_LD1 + col] = accH[0][0][r];
-                }
-                __syncthreads();
-                if (kh == 0) {                             // dz1 = (dh1_lo + dh1_hi) .* (1 - h1^2)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const float h = H1[row * PN_LD1 + col];
-                        DZ1[row * PN_LD1 + col] = (accH[0][0][r] + DZ1[row * PN_LD1 + col]) * (1.0f - h * h);
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- dW1 / db1 (K = C): thread (c, quarter) over its 8 points -----------------------
-            {
-                const int c = tid & 127, p0 = (tid >> 7) * (BT / 4);
-#pragma unroll 4
-                for (int p = p0; p < p0 + BT / 4; ++p) {
-                    const float dz = DZ1[p * PN_LD1 + c];
-                    const float4 x0 = *(const float4*)(Xs + p * PN_MAXC);
-                    db1acc += dz;
-                    dW1acc[0] = fmaf(dz, x0.x, dW1acc[0]);
-                    dW1acc[1] = fmaf(dz, x0.y, dW1acc[1]);
-                    dW1acc[2] = fmaf(dz, x0.z, dW1acc[2]);
-                    dW1acc[3] = fmaf(dz, x0.w, dW1acc[3]);
-                    if (CT != 3 && CT != 4) {
-                        const float4 x1 = *(const float4*)(Xs + p * PN_MAXC + 4);
-                        dW1acc[4] = fmaf(dz, x1.x, dW1acc[4]);
-                        dW1acc[5] = fmaf(dz, x1.y, dW1acc[5]);
-                        dW1acc[6] = fmaf(dz, x1.z, dW1acc[6]);
-                        dW1acc[7] = fmaf(dz, x1.w, dW1acc[7]);
-                    }
-                }
-            }
-        }
-        // ---- per-cloud output: sum_p h2 / P (cross-wave sum through the H1 region) ------------
-        __syncthreads();
-        *(float4*)(H1 + wave * PN_C2 + 4 * lane0) = h2s;
-        __syncthreads();
-        if (tid < PN_C2) {
-            float t = 0.f;
-#pragma unroll
-            for (int w2 = 0; w2 < 8; ++w2) t += H1[w2 * PN_C2 + tid];
-            H2sum[(long)b * PN_C2 + tid] = t * invP;
-        }
-    }
-
-    // ---- write this work-group's partial sums ------------------------------------------------
-    PnBwdPart* part = parts + blockIdx.x;
-    {
-        const int li = lane0 & 31, lh = lane0 >> 5;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int out = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                part->dW2[out * PN_C1 + nb * 32 + li] = accW2[0][nb][r];
-            }
-    }
-    __syncthreads();
-    *(float4*)(H1 + wave * PN_C2 + 4 * lane0) = db2acc;
-    __syncthreads();
-    if (tid < PN_C2) {
-        float t = 0.f;
-#pragma unroll
-        for (int w2 = 0; w2 < 8; ++w2) t += H1[w2 * PN_C2 + tid];
-        part->db2[tid] = t;
-    }
-    __syncthreads();
-    {   // combine the four point-quarters of dW1/db1 through LDS (H1|DZ1 region: 4*128*9 floats <= 2*32*132)
-        float* t = H1;
-        const int c = tid & 127, q = tid >> 7;
-#pragma unroll
-        for (int d = 0; d < PN_MAXC; ++d) t[(q * 128 + c) * (PN_MAXC + 1) + d] = dW1acc[d];
-        t[(q * 128 + c) * (PN_MAXC + 1) + PN_MAXC] = db1acc;
-        __syncthreads();
-        if (q == 0) {
-#pragma unroll
-            for (int d = 0; d <= PN_MAXC; ++d) {
-                float v = 0.f;
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) v += t[(qq * 128 + c) * (PN_MAXC + 1) + d];
-                if (d < PN_MAXC) part->dW1[c * PN_MAXC + d] = v; else part->db1[c] = v;
-            }
-        }
-    }
-}
-
 // sum the per-work-group partials in fixed order, two stages (68 MB of partials: a single pass with one
 // thread per element and 512 dependent-latency loads took 127 us; 16-way split + final takes ~25 us)
 #define PN_RED_SPLIT 16
@@ -1029,15 +727,9 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
         if (rc != PM_OK) return rc;
     }
     const int G = pn_bwd_grid(B);
-#if PN_BWD_NW == 8
-#define PN_BWD_LAUNCH(CT)                                                                                           \
-    hipLaunchKernelGGL(pn_bwd8_kernel<CT>, dim3(G), dim3(512), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, b2, \
-                       W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, slotmap, parts)
-#else
 #define PN_BWD_LAUNCH(CT)                                                                                          \
     hipLaunchKernelGGL(pn_bwd_kernel<CT>, dim3(G), dim3(256), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, b2, \
                        W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, slotmap, parts)
-#endif
     if (C == 3) PN_BWD_LAUNCH(3);
     else if (C == 4) PN_BWD_LAUNCH(4);
     else PN_BWD_LAUNCH(0);
