@@ -41,7 +41,7 @@ extern "C" {
 #define PM_ACT_TANH 1
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 111 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 112 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -100,7 +100,9 @@ size_t pm_pointnet_packed_elems(void);
 int pm_pointnet_pack_weights_f32(const float* W2, const float* W3, float* packed, void* stream);
 int pm_pointnet_enc_fwd_f32(const float* x, long ldx, int B, int P, int C, int sub_mean, const float* W1,
                             const float* b1, const float* b2, const float* b3, const float* packed,
-                            int max_mean, float* feat, long ldf, int32_t* argmax, void* stream);
+                            int max_mean, float* feat, long ldf, int32_t* argmax,
+                            float* h2_save /* NULL, or (B, P, 256): the layer-2 activations for the backward */,
+                            void* stream);
 /* OPT-IN split-bf16 forward: same contract as pm_pointnet_enc_fwd_f32, but the two big per-point GEMMs run as
  * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on bf16 MFMAs with fp32 accumulation (~1e-5 relative instead of ~1e-7;
  * 5.3x less matrix-pipe time).  P must be a multiple of 128.  `packed` = pm_pointnet_packed_bf3_bytes() bytes
@@ -119,8 +121,9 @@ size_t pm_pointnet_enc_bwd_workspace_bytes(int B, int P, int C);
 int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, int C, int sub_mean, const float* W1,
                             const float* b1, const float* b2, const float* W3, const float* packed,
                             int max_mean, const float* dfeat, long ldf, const int32_t* argmax, float* dW1,
-                            float* db1, float* dW2, float* db2, float* dW3, float* db3, void* workspace,
-                            size_t workspace_bytes, void* stream);
+                            float* db1, float* dW2, float* db2, float* dW3, float* db3,
+                            const float* h2_saved /* NULL = recompute layer 2; else what the forward saved */,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ K8  PPO actor loss
  * actor_critic.py:74-78,93-100 + ppo.py:327-344 in one pass over a mini-batch of B rows:

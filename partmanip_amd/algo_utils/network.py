@@ -162,6 +162,7 @@ class PointNet(_HipNet):
         # 'f32' (default): exact fp32 MFMA.  'bf16x3' (opt-in, not a reference key): encoder forward on split-bf16
         # MFMAs (~1e-5 relative, see csrc/pointnet_enc_bf3.hip); the backward stays fp32.
         self.precision = net_cfg.get('precision', 'f32')
+        self.save_h2 = bool(net_cfg.get('save_h2', True))
         if self.precision not in ('f32', 'bf16x3'):
             raise ValueError(f"PointNet precision '{self.precision}'")
         _act_code(act)
@@ -181,11 +182,29 @@ class PointNet(_HipNet):
         ops.pointnet_pack(self.mlp[2].weight.data, self.mlp[4].weight.data, self._packed)
         return self._packed
 
-    def hip_forward(self, x, out=None):
+    def forward(self, x):                 # rollout / eval inference: nothing is kept for a backward
+        with torch.no_grad():
+            return self.hip_forward(x, save_h2=False)
+
+    def _h2_buffer(self, B, device):
+        """(B, P, 256) fp32, reused across steps: the training forward stores the layer-2 activations here and the
+        backward loads them instead of recomputing layer 2 (2 GB at 2048 clouds x 1024 points; HBM is 288 GB and
+        the kernels are MFMA-bound, so the extra 1 KB per point each way is free and a third of the backward's
+        matrix work disappears).  `net_cfg['save_h2']: False` restores the recompute path."""
+        n = B * self.point_num * 256
+        buf = getattr(self, "_h2buf", None)
+        if buf is None or buf.numel() < n or buf.device != device:
+            buf = torch.empty(n, device=device)
+            object.__setattr__(self, "_h2buf", buf)
+        return buf[:n].view(B, self.point_num, 256)
+
+    def hip_forward(self, x, out=None, save_h2=None):
         B = x.shape[0]
         packed = self._pack(x.device)
         feat = torch.empty(B, self.feat_dim + self.proprio_shape, device=x.device)
         argmax = torch.empty(B, 512, dtype=torch.int32, device=x.device)
+        save_h2 = self.save_h2 if save_h2 is None else save_h2
+        h2 = self._h2_buffer(B, x.device) if (save_h2 and self.precision == 'f32') else None
         if self.precision == 'bf16x3':
             if self._packed3 is None or self._packed3.device != x.device:
                 object.__setattr__(self, "_packed3", torch.empty(int(ops.lib.pm_pointnet_packed_bf3_bytes()),
@@ -197,21 +216,21 @@ class PointNet(_HipNet):
         else:
             ops.pointnet_enc_fwd(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
                                  self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].bias.data, packed,
-                                 self.max_mean_concat, feat, argmax)
+                                 self.max_mean_concat, feat, argmax, h2)
         if self.proprio_shape != 0:
             feat[:, self.feat_dim:].copy_(x[:, -self.proprio_shape:])     # network.py:166-168,193-194
-        object.__setattr__(self, "_saved", (x, feat, argmax))
+        object.__setattr__(self, "_saved", (x, feat, argmax, h2))
         return self._head.forward(feat, out)
 
     def hip_backward(self, dy):
-        x, feat, argmax = self._saved
+        x, feat, argmax, h2 = self._saved
         ws = self._workspace(dy.device)
         dfeat = torch.empty_like(feat)
         self._head.backward(dy, ws, dx_out=dfeat)
         g = self._enc_grads
         ops.pointnet_enc_bwd(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
                              self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].weight.data, self._packed,
-                             self.max_mean_concat, dfeat, argmax, g[0], g[1], g[2], g[3], g[4], g[5], ws)
+                             self.max_mean_concat, dfeat, argmax, g[0], g[1], g[2], g[3], g[4], g[5], ws, h2)
 
 
 def _pad4(n):

@@ -154,7 +154,7 @@ __device__ __forceinline__ void layer2_mfma(const float* __restrict__ H1, const 
 // layer 2 epilogue: H2[row][ch] = tanh(acc + b2[ch])
 template <int MB, int NB>
 __device__ __forceinline__ void layer2_store(const f32x16 (&acc)[MB][NB], const float* __restrict__ b2, int wave, int lane,
-                                             float* __restrict__ H2) {
+                                             float* __restrict__ H2, float* __restrict__ h2_global = nullptr) {
     const int li = lane & 31, lh = lane >> 5;
     float b2v[NB];
 #pragma unroll
@@ -166,7 +166,9 @@ __device__ __forceinline__ void layer2_store(const f32x16 (&acc)[MB][NB], const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                H2[row * PN_LD2 + (wave * NB + nb) * 32 + li] = pm_tanh(acc[mb][nb][r] + b2v[nb]);
+                const float v = pm_tanh(acc[mb][nb][r] + b2v[nb]);
+                H2[row * PN_LD2 + (wave * NB + nb) * 32 + li] = v;
+                if (h2_global) h2_global[row * PN_C2 + (wave * NB + nb) * 32 + li] = v;   // 128-B row segments per half-wave
             }
 }
 
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
                                                                   const float* __restrict__ b3,
                                                                   const float* __restrict__ packed, int max_mean,
                                                                   float* __restrict__ feat, long ldf,
-                                                                  int32_t* __restrict__ argmax) {
+                                                                  int32_t* __restrict__ argmax,
+                                                                  float* __restrict__ h2_save) {
     constexpr int NT = NW * 64, NB2 = 8 / NW, NB3 = 16 / NW;
     __shared__ __attribute__((aligned(16))) float smem[PN_TM * PN_LD2 + PN_TM * PN_MAXC + 32];
     float* H = smem;                             // H1 [64][132] then H2 [64][260] (aliased)
@@ -258,6 +261,20 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
                     }
                     vsum[nb] += v;
                 }
+        // Training forward: the H2 tile (still intact in LDS) also goes to HBM, 1 KB rows, so that the backward
+        // LOADS h2 instead of recomputing layer 2 -- 1 KB per point against 65.5 kFLOP of exact-fp32 MFMA work
+        // (64 FLOP/B where the machine balance is ~20).  Costs the forward +0.25 ms per 2048 clouds (instruction
+        // issue: 16 LDS/VMEM ops per thread and tile; plain, nt and sc1 stores, or storing from the layer-2
+        // epilogue registers, all measure the same) and saves the backward 0.69 ms.
+        if (h2_save) {
+            float* dst = h2_save + ((long)b * P + (long)tile * PN_TM) * PN_C2;
+#pragma unroll 2
+            for (int i = 0; i < PN_TM * PN_C2 / 4 / NT; ++i) {
+                const int q = tid + NT * i, row = q >> 6, c4 = q & 63;
+                const f32x4 v = *(const f32x4*)(H + row * PN_LD2 + 4 * c4);
+                *(f32x4*)(dst + row * PN_C2 + 4 * c4) = v;
+            }
+        }
     }
     // lanes l and l^32 hold the two interleaved row sets of the same channel
     const int li = lane0 & 31, lh = lane0 >> 5;
@@ -284,15 +301,16 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
 extern "C" int pm_pointnet_enc_fwd_f32(const float* x, long ldx, int B, int P, int C, int sub_mean,
                                        const float* W1, const float* b1, const float* b2, const float* b3,
                                        const float* packed, int max_mean, float* feat, long ldf, int32_t* argmax,
-                                       void* stream) {
+                                       float* h2_save, void* stream) {
     PM_REQUIRE(x && W1 && b1 && b2 && b3 && packed && feat && argmax);
+    if (h2_save && ((uintptr_t)h2_save & 15) != 0) return PM_EALIGN;
     PM_REQUIRE(B > 0 && P > 0 && P % PN_TM == 0 && C >= 1 && C <= PN_MAXC && ldx >= (long)P * C);
     PM_REQUIRE(ldf >= PN_C3 * (max_mean ? 2 : 1));
     PM_REQUIRE(!sub_mean || C >= 3);
     if (((uintptr_t)packed & 15) != 0) return PM_EALIGN;
 #define PN_FWD_LAUNCH(CT)                                                                                  \
     hipLaunchKernelGGL((pn_fwd_kernel<CT, PN_FWD_NW>), dim3(B), dim3(PN_FWD_NW * 64), 0, pm_stream(stream), x, ldx, P, \
-                       C, sub_mean, W1, b1, b2, b3, packed, max_mean, feat, ldf, argmax)
+                       C, sub_mean, W1, b1, b2, b3, packed, max_mean, feat, ldf, argmax, h2_save)
     if (C == 3) PN_FWD_LAUNCH(3);
     else if (C == 4) PN_FWD_LAUNCH(4);
     else PN_FWD_LAUNCH(0);
@@ -374,13 +392,17 @@ __device__ __forceinline__ void bitonic_sort_512(int* keys) {
             }                                                                    \
         }                                                                        \
     }
-template <int CT>
+// SAVED: h2 comes from HBM (written by the training forward) instead of a layer-2 recompute: one MFMA phase and
+// one barrier less per tile, and the row-owner pass reads its rows straight from global memory (1 KB coalesced
+// rows, issued before the tile's first barrier) -- it no longer waits for other waves' layer-2 output.
+template <int CT, bool SAVED>
 __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
     const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
     const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ W3,
     const float* __restrict__ packed, int max_mean, const float* __restrict__ dfeat, long ldf,
     const int32_t* __restrict__ argmax, const float* __restrict__ U, float* __restrict__ H2sum,
-    float* __restrict__ Hg, int32_t* __restrict__ slotmap, PnBwdPart* __restrict__ parts) {
+    float* __restrict__ Hg, int32_t* __restrict__ slotmap, PnBwdPart* __restrict__ parts,
+    const float* __restrict__ h2_saved) {
     constexpr int BT = PN_BT;
     __shared__ __attribute__((aligned(16))) float smem[BT * PN_LD1 * 2 + BT * PN_LD2 + 2 * BT * PN_MAXC + PN_C2 + PN_C3 +
                                                         PN_C3 + 520 + 4 * PN_C2 + 16];
@@ -472,8 +494,8 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
             __syncthreads();                               // (A) Xs staged; DZ1 of tile t-1 complete; H1/H2 free
             layer1_tile<CT, BT, 256>(Xs, W1, b1, C, H1);
             if (tile > 0) PN_DW1_ACCUM(Xo)
-            __syncthreads();                               // (B)
-            {
+            if (!SAVED) {
+                __syncthreads();                           // (B)
                 f32x16 acc2[1][2];
                 zero_acc<1, 2>(acc2);
 #if !(PN_ABLATE & 32)
@@ -481,9 +503,9 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
 #endif
                 layer2_store<1, 2>(acc2, b2, wave, lane, H2);
                 if (tile + 1 < ntiles) stage_points<BT, 256>(xb, tile + 1, C, sub_mean, cen, Xo);
+                __syncthreads();                           // (C)
             }
-            __syncthreads();                               // (C)
-            // ---- row-owner pass: wave w owns rows w*8..w*8+7; h2 -> dz2 in place -------------
+            // ---- row-owner pass: wave w owns rows w*8..w*8+7; h2 -> dz2 (into the LDS tile) -------------
 #if !(PN_ABLATE & 8)
             {
                 constexpr int RPW = BT / 4;
@@ -502,9 +524,19 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                     c_next = keys[e] & 511;
                     w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
                 }
+                // SAVED: this wave's rows come from HBM, one row ahead of their use (h_nx)
+                const float* hsrc = SAVED ? h2_saved + ((long)b * P + p0) * PN_C2 + 4 * lane : nullptr;
+                float4 h_nx = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (SAVED) h_nx = *(const float4*)hsrc;
                 for (int rr = 0; rr < RPW; ++rr) {
                     float* hrow = H2 + (wave * RPW + rr) * PN_LD2 + 4 * lane;
-                    const float4 h = *(const float4*)hrow;
+                    float4 h;
+                    if (SAVED) {
+                        h = h_nx;
+                        if (rr + 1 < RPW) h_nx = *(const float4*)(hsrc + (rr + 1) * PN_C2);
+                    } else {
+                        h = *(const float4*)hrow;
+                    }
                     h2s.x += h.x; h2s.y += h.y; h2s.z += h.z; h2s.w += h.w;
                     float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
                     int row_end;
@@ -542,6 +574,8 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
             }
 #endif
             __syncthreads();                               // (D)
+            // SAVED: the next tile's points are staged here (Xo was read by the dW1 accumulation before (D))
+            if (SAVED && tile + 1 < ntiles) stage_points<BT, 256>(xb, tile + 1, C, sub_mean, cen, Xo);
             // ---- dW2 += dz2^T * h1 : K = 32 points (lanes<32: point s, lanes>=32: point 16+s) ----
             {
                 const float* Ap = H2 + (lh * (BT / 2)) * PN_LD2 + wave * 64 + li;     // A[i=out][k=pt] = dz2[pt][out]
@@ -705,9 +739,10 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
                                        const float* W1, const float* b1, const float* b2, const float* W3,
                                        const float* packed, int max_mean, const float* dfeat, long ldf,
                                        const int32_t* argmax, float* dW1, float* db1, float* dW2, float* db2,
-                                       float* dW3, float* db3, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
+                                       float* dW3, float* db3, const float* h2_saved, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
     PM_REQUIRE(x && W1 && b1 && b2 && W3 && packed && dfeat && argmax && dW1 && db1 && dW2 && db2 && dW3 && db3);
+    if (h2_saved && ((uintptr_t)h2_saved & 15) != 0) return PM_EALIGN;
     PM_REQUIRE(B > 0 && P > 0 && P % PN_TM == 0 && P <= 4096 && C >= 1 && C <= PN_MAXC && ldx >= (long)P * C);
     PM_REQUIRE(ldf >= PN_C3 * (max_mean ? 2 : 1));
     PM_REQUIRE(!sub_mean || C >= 3);
@@ -727,13 +762,19 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
         if (rc != PM_OK) return rc;
     }
     const int G = pn_bwd_grid(B);
-#define PN_BWD_LAUNCH(CT)                                                                                          \
-    hipLaunchKernelGGL(pn_bwd_kernel<CT>, dim3(G), dim3(256), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, b2, \
-                       W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, slotmap, parts)
+#define PN_BWD_LAUNCH_(CT, SV)                                                                                   \
+    hipLaunchKernelGGL((pn_bwd_kernel<CT, SV>), dim3(G), dim3(256), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, \
+                       b1, b2, W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, slotmap, parts, h2_saved)
+#define PN_BWD_LAUNCH(CT)                       \
+    do {                                        \
+        if (h2_saved) PN_BWD_LAUNCH_(CT, true); \
+        else PN_BWD_LAUNCH_(CT, false);         \
+    } while (0)
     if (C == 3) PN_BWD_LAUNCH(3);
     else if (C == 4) PN_BWD_LAUNCH(4);
     else PN_BWD_LAUNCH(0);
 #undef PN_BWD_LAUNCH
+#undef PN_BWD_LAUNCH_
     const int n = (int)(sizeof(PnBwdPart) / sizeof(float));
     float* red_tmp = (float*)(parts + G);
     hipLaunchKernelGGL(pn_bwd_reduce1_kernel, dim3((n + 255) / 256, PN_RED_SPLIT), dim3(256), 0, pm_stream(stream), parts,
