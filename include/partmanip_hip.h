@@ -41,7 +41,7 @@ extern "C" {
 #define PM_ACT_TANH 1
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 112 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 113 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -276,13 +276,15 @@ size_t pm_sa_packed_elems(int C1, int C2, int C3);
 int pm_sa_pack_weights_f32(const float* W2, const float* W3, int C1, int C2, int C3, float* packed, void* stream);
 int pm_sa_fwd_f32(const float* xyz, const float* centers, const int32_t* idx, const float* Y, int B, int P, int S,
                   int nsample, const float* W1, long ldw1, const float* b1, const float* b2, const float* b3,
-                  const float* packed, int C1, int C2, int C3, float* pooled, long ldp, int32_t* arg, void* stream);
+                  const float* packed, int C1, int C2, int C3, float* pooled, long ldp, int32_t* arg,
+                  float* h2_save /* NULL, or (B*S*32, C2): layer-2 activations kept for the backward */, void* stream);
 size_t pm_sa_bwd_workspace_bytes(int C1, int C2, int C3);
 int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32_t* idx, const float* Y, int B, int P, int S,
                   int nsample, const float* W1, long ldw1, const float* b1, const float* b2, const float* W3,
                   const float* packed, int C1, int C2, int C3, const float* pooled, long ldp, const int32_t* arg,
                   const float* dpooled, long lddp, float* dW1, long lddw1, float* db1, float* dW2, float* db2,
-                  float* dW3, float* db3, float* dY, void* workspace, size_t workspace_bytes, void* stream);
+                  float* dW3, float* db3, float* dY, const float* h2_saved /* NULL = recompute layer 2 */,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -295,6 +295,9 @@ class PointNet2(_HipNet):
             fused_ok and len(mlps[l]) == 3 and ops.sa_supported(*mlps[l], self.nsamples[l])
             for l in range(len(self.npoints))])
         object.__setattr__(self, "_sa_packed", [None] * len(self.npoints))
+        object.__setattr__(self, "_sa_h2", [None] * len(self.npoints))
+        object.__setattr__(self, "_save_h2_now", False)
+        self.save_h2 = bool(net_cfg.get('save_h2', True))
         object.__setattr__(self, "_sa_grads", None)
 
     def set_grad_views(self, views):
@@ -317,19 +320,26 @@ class PointNet2(_HipNet):
             packed = torch.empty(int(ops.lib.pm_sa_packed_elems(*dims)), device=xyz.device)
             self._sa_packed[l] = packed
         ops.sa_pack(lin2.weight.data, lin3.weight.data, packed)
+        h2 = None
+        if self._save_h2_now:                              # training forward: keep layer 2 for the backward (reused buffer)
+            n = idx_g.numel() * dims[1]
+            buf = self._sa_h2[l]
+            if buf is None or buf.numel() < n or buf.device != xyz.device:
+                buf = self._sa_h2[l] = torch.empty(n, device=xyz.device)
+            h2 = buf[:n]
         arg = ops.sa_fwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
-                         packed, dims, pooled)
-        return (idx_g, arg, "fused", xyz, feat, centers, Y, packed, dims, pooled)
+                         packed, dims, pooled, h2)
+        return (idx_g, arg, "fused", xyz, feat, centers, Y, packed, dims, pooled, h2)
 
     def _sa_backward_fused(self, l, rec, dpooled, ws, need_dfeat):
-        idx_g, arg, _, xyz, feat, centers, Y, packed, dims, pooled = rec
+        idx_g, arg, _, xyz, feat, centers, Y, packed, dims, pooled, h2 = rec
         B, Pl = xyz.shape[0], xyz.shape[1]
         lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
         (dW1, db1), (dW2, db2), (dW3, db3) = self._chains[l].grads
         cf = 0 if feat is None else feat.shape[2]
         dY = torch.zeros(B * Pl, dims[0], device=xyz.device) if cf > 0 else None
         ops.sa_bwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data, packed,
-                   dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws)
+                   dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws, h2)
         if dW1.shape[1] > 3 + cf:
             dW1[:, 3 + cf:].zero_()                        # pad columns never receive data
         if cf == 0:
@@ -376,8 +386,13 @@ class PointNet2(_HipNet):
             sel = [(c.index_select(0, r), i.index_select(0, r)) for c, i in tabs]
         object.__setattr__(self, "_geom_next", sel)
 
-    def hip_forward(self, x, out=None):
+    def forward(self, x):                 # rollout / eval inference: nothing is kept for a backward
+        with torch.no_grad():
+            return self.hip_forward(x, save_h2=False)
+
+    def hip_forward(self, x, out=None, save_h2=None):
         B, P, C = x.shape[0], self.point_num, self.in_channels
+        object.__setattr__(self, "_save_h2_now", self.save_h2 if save_h2 is None else save_h2)
         ws = self._workspace(x.device)
         pts = x[:, :P * C].reshape(B, P, C)
         xyz = pts[..., :3].contiguous()

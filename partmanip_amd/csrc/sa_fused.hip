@@ -49,6 +49,9 @@ struct SaArgs {
     long lddp;
     float* dY;               // (B*P, C1) zero-filled by the caller, or null
     float* parts;            // per-work-group partial sums
+    // layer-2 activations (G*32, C2): written by the training forward, read back by the backward instead of a
+    // recompute (C2*4 B per row against 2*C1*C2 FLOP: 32-64 FLOP/B, machine balance ~20); null = recompute
+    float* h2;
 };
 
 extern "C" size_t pm_sa_packed_elems(int C1, int C2, int C3) {
@@ -250,6 +253,15 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_fwd_kernel(SaArgs a) {
                 }
             }
         }
+        if (a.h2) {                                          // training forward: keep H2 for the backward
+            const long row0 = tile * TM, nrows = a.G * SA_NS;
+#pragma unroll 2
+            for (int q = tid; q < TM * C2 / 4; q += NT) {
+                const int row = q / (C2 / 4), c4 = q % (C2 / 4);
+                if (row0 + row < nrows)
+                    *(float4*)(a.h2 + (row0 + row) * C2 + 4 * c4) = *(const float4*)(H2 + row * LD2 + 4 * c4);
+            }
+        }
     }
 }
 
@@ -274,7 +286,7 @@ static int sa_cu_count() {
 extern "C" int pm_sa_fwd_f32(const float* xyz, const float* centers, const int32_t* idx, const float* Y, int B, int P,
                              int S, int nsample, const float* W1, long ldw1, const float* b1, const float* b2,
                              const float* b3, const float* packed, int C1, int C2, int C3, float* pooled, long ldp,
-                             int32_t* arg, void* stream) {
+                             int32_t* arg, float* h2_save, void* stream) {
     PM_REQUIRE(xyz && centers && idx && W1 && b1 && b2 && b3 && packed && pooled && arg);
     PM_REQUIRE(B > 0 && P > 0 && S > 0 && ldw1 >= 3 && ldp >= C3);
     if (!pm_sa_supported(C1, C2, C3, nsample)) return PM_EUNSUPPORTED;
@@ -282,6 +294,7 @@ extern "C" int pm_sa_fwd_f32(const float* xyz, const float* centers, const int32
     SaArgs a = {};
     a.xyz = xyz; a.centers = centers; a.idx = idx; a.Y = Y; a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.b2 = b2; a.b3 = b3;
     a.packed = packed; a.pooled = pooled; a.ldp = ldp; a.arg = arg; a.G = (long)B * S; a.S = S; a.P = P;
+    a.h2 = h2_save;
     const int ncu = sa_cu_count();
 #define SA_FWD_LAUNCH(C1_, C2_, C3_, TM_, NW_, WGCU_)                                                          \
     {                                                                                                          \
@@ -395,7 +408,18 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_kernel(SaArgs a) {
         // ---- P1/P2: recompute H1, H2 ------------------------------------------------------------
         if (!(SA_ABLATE & 64)) sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
         __syncthreads();
-        sa_layer2<C1, C2, TM, NW, false>(H1, P2v, a.b2, wave, lane, H2);
+        if (a.h2) {                                          // saved by the forward: 1 coalesced pass instead of a GEMM
+            const long row0 = tile * TM, nrows = a.G * SA_NS;
+#pragma unroll 2
+            for (int q = tid; q < TM * C2 / 4; q += NT) {
+                const int row = q / (C2 / 4), c4 = q % (C2 / 4);
+                long gr = row0 + row;
+                if (gr >= nrows) gr = nrows - 1;             // ragged last tile (its Val entries are 0)
+                *(float4*)(H2 + row * LD2 + 4 * c4) = *(const float4*)(a.h2 + gr * C2 + 4 * c4);
+            }
+        } else {
+            sa_layer2<C1, C2, TM, NW, false>(H1, P2v, a.b2, wave, lane, H2);
+        }
         __syncthreads();
         // ---- P3: structured layer-3 backward ---------------------------------------------------
         {
@@ -599,8 +623,8 @@ extern "C" int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32
                              int S, int nsample, const float* W1, long ldw1, const float* b1, const float* b2,
                              const float* W3, const float* packed, int C1, int C2, int C3, const float* pooled,
                              long ldp, const int32_t* arg, const float* dpooled, long lddp, float* dW1, long lddw1,
-                             float* db1, float* dW2, float* db2, float* dW3, float* db3, float* dY, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+                             float* db1, float* dW2, float* db2, float* dW3, float* db3, float* dY,
+                             const float* h2_saved, void* workspace, size_t workspace_bytes, void* stream) {
     PM_REQUIRE(xyz && centers && idx && W1 && b1 && b2 && W3 && packed && pooled && arg && dpooled);
     PM_REQUIRE(dW1 && db1 && dW2 && db2 && dW3 && db3 && workspace);
     PM_REQUIRE(B > 0 && P > 0 && S > 0 && ldw1 >= 3 && lddw1 >= 3 && ldp >= C3 && lddp >= C3);
@@ -612,6 +636,7 @@ extern "C" int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32
     a.packed = packed; a.pooled = const_cast<float*>(pooled); a.ldp = ldp; a.arg = const_cast<int32_t*>(arg);
     a.G = (long)B * S; a.S = S; a.P = P; a.W3 = W3; a.dpooled = dpooled; a.lddp = lddp; a.dY = dY;
     a.parts = (float*)workspace;
+    a.h2 = const_cast<float*>(h2_saved);
     const int ncu = sa_cu_count();
 #define SA_BWD_LAUNCH(C1_, C2_, C3_, TM_, NW_, WPE_, WGCU_)                                                        \
     {                                                                                                              \

@@ -383,7 +383,7 @@ def sa_pack(w2, w3, packed):
           "pm_sa_pack_weights_f32")
 
 
-def sa_fwd(xyz, centers, idx, Y, w1, b1, b2, b3, packed, dims, pooled):
+def sa_fwd(xyz, centers, idx, Y, w1, b1, b2, b3, packed, dims, pooled, h2_save=None):
     """xyz (B,P,3), centers (B,S,3), idx (B,S,32) int32, Y (B*P,C1) or None -> pooled (B*S, C3) view, arg int32."""
     _req(xyz, centers, idx, Y, w1, packed, pooled)
     B, P, _ = xyz.shape
@@ -395,11 +395,12 @@ def sa_fwd(xyz, centers, idx, Y, w1, b1, b2, b3, packed, dims, pooled):
     with TIMER.bracket(f"sa_fwd_{C1}x{C2}x{C3}"):
         check(lib.pm_sa_fwd_f32(_ptr(xyz), _ptr(centers), _ptr(idx), _ptr(Y), B, P, S, ns,
                                 _ptr(w1), _rows(w1, "w1"), _ptr(b1), _ptr(b2), _ptr(b3), _ptr(packed), C1, C2, C3,
-                                _ptr(pooled), _rows(pooled, "pooled"), _ptr(arg), _stream()), "pm_sa_fwd_f32")
+                                _ptr(pooled), _rows(pooled, "pooled"), _ptr(arg), _ptr(h2_save), _stream()), "pm_sa_fwd_f32")
     return arg
 
 
-def sa_bwd(xyz, centers, idx, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpooled, dw1, db1, dw2, db2, dw3, db3, dY, ws):
+def sa_bwd(xyz, centers, idx, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpooled, dw1, db1, dw2, db2, dw3, db3, dY, ws,
+           h2_saved=None):
     _req(xyz, centers, idx, Y, w1, w3, packed, pooled, arg, dpooled, dw1, dw2, dw3, dY)
     B, P, _ = xyz.shape
     S, ns = idx.shape[1], idx.shape[2]
@@ -411,7 +412,7 @@ def sa_bwd(xyz, centers, idx, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpoo
                                 _ptr(b1), _ptr(b2), _ptr(w3), _ptr(packed), C1, C2, C3, _ptr(pooled),
                                 _rows(pooled, "pooled"), _ptr(arg), _ptr(dpooled), _rows(dpooled, "dpooled"), _ptr(dw1),
                                 _rows(dw1, "dw1"), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(dw3), _ptr(db3), _ptr(dY),
-                                _ptr(w), w.numel(), _stream()), "pm_sa_bwd_f32")
+                                _ptr(h2_saved), _ptr(w), w.numel(), _stream()), "pm_sa_bwd_f32")
 
 
 # ----------------------------------------------------------------------------- depth -> cloud

@@ -31,11 +31,13 @@ for name, P, S, radius, dims, cf in LEVELS:
     dpooled = torch.randn(B * S, C3, device=DEV)
     g = [torch.empty_like(t) for t in (W1, b1, W2, b2, W3, b3)]
     dY = torch.zeros(B * P, C1, device=DEV) if cf else None
+    import os
+    h2 = torch.empty(B * S * 32, C2, device=DEV) if os.environ.get("SA_SAVE_H2", "1") == "1" else None
 
     def run(n):
         for _ in range(n):
-            arg = ops.sa_fwd(xyz, centers, idx_g, Y, W1, b1, b2, b3, packed, dims, pooled)
-            ops.sa_bwd(xyz, centers, idx_g, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws)
+            arg = ops.sa_fwd(xyz, centers, idx_g, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
+            ops.sa_bwd(xyz, centers, idx_g, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws, h2)
     run(2)
     nf, nb = f"sa_fwd_{C1}x{C2}x{C3}", f"sa_bwd_{C1}x{C2}x{C3}"
     ops.TIMER.enable(nf, nb)
@@ -45,6 +47,6 @@ for name, P, S, radius, dims, cf in LEVELS:
     ops.TIMER.disable()
     rows = B * S * 32
     ff = 2.0 * rows * (C1 * C2 + C2 * C3) / 1e9                 # MFMA flops fwd
-    fb = 2.0 * rows * (3 * C1 * C2) / 1e9                        # L2 recompute + dW2 + dH1
-    print(f"level {name}: fwd {f:.3f} ms ({ff / f:.1f} TF)  bwd {b:.3f} ms ({fb / b:.1f} TF dense part)")
+    fb = 2.0 * rows * ((2 if h2 is not None else 3) * C1 * C2 + C2 * C3) / 1e9   # [L2 recompute +] dW2 + dH1 + dH2
+    print(f"level {name}: fwd {f:.3f} ms ({ff / f:.1f} TF)  bwd {b:.3f} ms ({fb / b:.1f} TF executed)")
     xyz = centers.contiguous()
