@@ -262,7 +262,9 @@ def main():
             traffic = json.load(open(tfile)).get("pn_fwd_kernel_bytes_per_launch")
         out["roofline"] = dict(bound="mfma", kernel="pn_fwd_kernel", achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS,
                                unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=traffic,
-                               launches=n_launch, mean_launch_ms=mean_ms, flops_per_launch=flops)
+                               launches=n_launch, mean_launch_ms=mean_ms, flops_per_launch=flops,
+                               note="training forward: also writes the layer-2 activations (1 KB/point) that spare the "
+                                    "backward a recompute; 0.83 without that store (DESIGN.md 3.2)")
         bwd = ops.TIMER.mean_ms("pointnet_enc_bwd")
         if bwd:
             out["roofline"]["enc_bwd_mean_ms"] = bwd[0]
