@@ -41,7 +41,7 @@ extern "C" {
 #define PM_ACT_TANH 1
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 113 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 114 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -111,7 +111,8 @@ size_t pm_pointnet_packed_bf3_bytes(void);
 int pm_pointnet_pack_weights_bf3(const float* W2, const float* W3, void* packed, void* stream);
 int pm_pointnet_enc_fwd_bf3(const float* x, long ldx, int B, int P, int C, int sub_mean, const float* W1,
                             const float* b1, const float* b2, const float* b3, const void* packed, int max_mean,
-                            float* feat, long ldf, int32_t* argmax, void* stream);
+                            float* feat, long ldf, int32_t* argmax, float* h2_save /* as pm_pointnet_enc_fwd_f32 */,
+                            void* stream);
 /* Backward of the above w.r.t. the six encoder parameters given dfeat (B, ldf) =
  * [d max(512) | d mean(512)].  Uses the pooling structure: the gradient of the 512-wide
  * layer-3 output is (d mean)/P on every point plus (d max) on the argmax point only, so

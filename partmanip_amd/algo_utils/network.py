@@ -204,7 +204,7 @@ class PointNet(_HipNet):
         feat = torch.empty(B, self.feat_dim + self.proprio_shape, device=x.device)
         argmax = torch.empty(B, 512, dtype=torch.int32, device=x.device)
         save_h2 = self.save_h2 if save_h2 is None else save_h2
-        h2 = self._h2_buffer(B, x.device) if (save_h2 and self.precision == 'f32') else None
+        h2 = self._h2_buffer(B, x.device) if save_h2 else None
         if self.precision == 'bf16x3':
             if self._packed3 is None or self._packed3.device != x.device:
                 object.__setattr__(self, "_packed3", torch.empty(int(ops.lib.pm_pointnet_packed_bf3_bytes()),
@@ -212,7 +212,7 @@ class PointNet(_HipNet):
             ops.pointnet_pack_bf3(self.mlp[2].weight.data, self.mlp[4].weight.data, self._packed3)
             ops.pointnet_enc_fwd_bf3(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
                                      self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].bias.data,
-                                     self._packed3, self.max_mean_concat, feat, argmax)
+                                     self._packed3, self.max_mean_concat, feat, argmax, h2)
         else:
             ops.pointnet_enc_fwd(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
                                  self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].bias.data, packed,

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(B3_NT, 2) void pn_fwd_bf3_kernel(const float* __res
                                                                const float* __restrict__ b3,
                                                                const unsigned short* __restrict__ packed, int max_mean,
                                                                float* __restrict__ feat, long ldf,
-                                                               int32_t* __restrict__ argmax) {
+                                                               int32_t* __restrict__ argmax,
+                                                               float* __restrict__ h2_save) {
     __shared__ __attribute__((aligned(16))) unsigned short Hs[2 * B3_TM * B3_LD2];
     __shared__ __attribute__((aligned(16))) float Xs[B3_TM * B3_MAXC];
     __shared__ double red[16];
@@ -237,9 +238,12 @@ __global__ __launch_bounds__(B3_NT, 2) void pn_fwd_bf3_kernel(const float* __res
                 for (int r = 0; r < 16; ++r) {
                     const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq;
                     unsigned short h, l;
-                    split_bf16(pm_tanh(acc2[mb][0][r] + b2c), h, l);
+                    const float v = pm_tanh(acc2[mb][0][r] + b2c);
+                    split_bf16(v, h, l);
                     H2h[row * B3_LD2 + wave * 32 + li] = h;
                     H2l[row * B3_LD2 + wave * 32 + li] = l;
+                    // training forward: the fp32 activation also goes to HBM for the (fp32) backward, see pn_fwd_kernel
+                    if (h2_save) h2_save[((long)b * P + (long)tile * B3_TM + row) * 256 + wave * 32 + li] = v;
                 }
         }
         __syncthreads();
@@ -293,7 +297,8 @@ __global__ __launch_bounds__(B3_NT, 2) void pn_fwd_bf3_kernel(const float* __res
 
 extern "C" int pm_pointnet_enc_fwd_bf3(const float* x, long ldx, int B, int P, int C, int sub_mean, const float* W1,
                                        const float* b1, const float* b2, const float* b3, const void* packed,
-                                       int max_mean, float* feat, long ldf, int32_t* argmax, void* stream) {
+                                       int max_mean, float* feat, long ldf, int32_t* argmax, float* h2_save,
+                                       void* stream) {
     PM_REQUIRE(x && W1 && b1 && b2 && b3 && packed && feat && argmax);
     PM_REQUIRE(B > 0 && P > 0 && P % B3_TM == 0 && C >= 1 && C <= B3_MAXC && ldx >= (long)P * C);
     PM_REQUIRE(ldf >= B3_C3 * (max_mean ? 2 : 1));
@@ -301,7 +306,7 @@ extern "C" int pm_pointnet_enc_fwd_bf3(const float* x, long ldx, int B, int P, i
     if (((uintptr_t)packed & 15) != 0) return PM_EALIGN;
 #define B3_LAUNCH(CT)                                                                                          \
     hipLaunchKernelGGL(pn_fwd_bf3_kernel<CT>, dim3(B), dim3(B3_NT), 0, pm_stream(stream), x, ldx, P, C, sub_mean, W1, \
-                       b1, b2, b3, (const unsigned short*)packed, max_mean, feat, ldf, argmax)
+                       b1, b2, b3, (const unsigned short*)packed, max_mean, feat, ldf, argmax, h2_save)
     if (C == 3) B3_LAUNCH(3);
     else if (C == 4) B3_LAUNCH(4);
     else B3_LAUNCH(0);
