@@ -491,6 +491,14 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
             const int li = lane & 31, lh = lane >> 5;
             float* Xs = Xs0 + (tile & 1) * BT * PN_MAXC;
             float* Xo = Xs0 + ((tile & 1) ^ 1) * BT * PN_MAXC;
+            // SAVED: the first two of this wave's 8 saved-h2 rows are requested before the barrier and layer 1, so
+            // their HBM latency runs under that VALU phase
+            const float* hsrc = SAVED ? h2_saved + ((long)b * P + tile * BT + wave * (BT / 4)) * PN_C2 + 4 * lane : nullptr;
+            float4 h_nx = make_float4(0.f, 0.f, 0.f, 0.f), h_nx2 = h_nx;
+            if (SAVED) {
+                h_nx = *(const float4*)hsrc;
+                h_nx2 = *(const float4*)(hsrc + PN_C2);
+            }
             __syncthreads();                               // (A) Xs staged; DZ1 of tile t-1 complete; H1/H2 free
             layer1_tile<CT, BT, 256>(Xs, W1, b1, C, H1);
             if (tile > 0) PN_DW1_ACCUM(Xo)
@@ -524,16 +532,14 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                     c_next = keys[e] & 511;
                     w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
                 }
-                // SAVED: this wave's rows come from HBM, one row ahead of their use (h_nx)
-                const float* hsrc = SAVED ? h2_saved + ((long)b * P + p0) * PN_C2 + 4 * lane : nullptr;
-                float4 h_nx = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (SAVED) h_nx = *(const float4*)hsrc;
+                // SAVED: this wave's rows come from HBM, two rows ahead of their use (h_nx, h_nx2)
                 for (int rr = 0; rr < RPW; ++rr) {
                     float* hrow = H2 + (wave * RPW + rr) * PN_LD2 + 4 * lane;
                     float4 h;
                     if (SAVED) {
                         h = h_nx;
-                        if (rr + 1 < RPW) h_nx = *(const float4*)(hsrc + (rr + 1) * PN_C2);
+                        h_nx = h_nx2;
+                        if (rr + 2 < RPW) h_nx2 = *(const float4*)(hsrc + (rr + 2) * PN_C2);
                     } else {
                         h = *(const float4*)hrow;
                     }
