@@ -117,7 +117,7 @@ class bc:
         for index_batch in loader:
             idx = index_batch.to(tsdf.device, non_blocking=True)
             x = self._gather('tsdf', tsdf, idx)
-            if self.add_proprio_obs:
+            if self.add_proprio_obs and states.shape[1] > 0:       # a task may declare a 0-wide proprio state
                 x = torch.cat([x, self._gather('state', states, idx)], dim=-1)
             act = self._gather('action', actions, idx)
             stu_mu = stu.actor.hip_forward(x)

@@ -83,3 +83,36 @@ def test_train_py_command_line(tmp_path):
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "Train/surrogate_loss" in out.stdout and "Learning iteration 2" in out.stdout
+
+
+def _cli(args, cwd=ROOT):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "train.py")] + args, capture_output=True, text=True,
+                         timeout=900, cwd=cwd)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return out.stdout
+
+
+def test_train_py_dagger_tsdf_and_bc_configs(tmp_path):
+    """The reference's shipped DAgger default (`dagger_tsdf.yaml`: Conv3DNet student on 50^3 TSDF volumes, state
+    teacher) and `bc.yaml` through the command line: a teacher is trained and saved by `--algocfg ppo`, then
+    distilled; then behaviour cloning from shards on disk."""
+    root = str(tmp_path)
+    _cli(["--algocfg", "ppo", "--taskcfg", "open_drawer", "--exp_name", "tea", "--algo.num_envs", "16", "--algo.n_steps", "4",
+          "--algo.max_iterations", "1", "--algo.n_minibatches", "2", "--algo.save_frequence", "1",
+          "--algo.tricks.use_state_norm", "--log.log_root", root])   # bool flags toggle the yaml value: state norm OFF, as dagger.py:73 requires of its teacher
+    ck = [os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs if f == "model_1.pth"]
+    assert len(ck) == 1
+    out = _cli(["--algocfg", "dagger_tsdf", "--taskcfg", "open_drawer", "--exp_name", "stu", "--algo.num_envs", "16",
+                "--algo.buf_size", "4", "--algo.max_iterations", "2", "--algo.n_minibatches", "2", "--algo.teacher", ck[0],
+                "--log.log_root", root])
+    assert "Train/dagger_loss" in out
+    data = os.path.join(root, "bc_data", "scene_00000")
+    os.makedirs(data)
+    rng = np.random.default_rng(0)
+    for i in range(12):
+        np.save(os.path.join(data, f"step_{str(i).zfill(5)}.npy"),
+                dict(tsdf=rng.uniform(-1, 1, 50 ** 3).astype(np.float32), action=rng.uniform(-0.9, 0.9, 10).astype(np.float32),
+                     proprio_state=np.zeros(0, dtype=np.float32)), allow_pickle=True)
+    out = _cli(["--algocfg", "bc", "--taskcfg", "open_drawer", "--exp_name", "bc", "--algo.max_iterations", "2",
+                "--algo.n_minibatches", "3", "--algo.data_path", os.path.dirname(data), "--log.log_root", root])
+    assert "Train/bc_loss" in out

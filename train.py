@@ -40,6 +40,21 @@ def set_seed(seed, exp_name, resume):
     return seed, exp_name
 
 
+def feeder_obs_dims(cfg):
+    """Observation widths per mode, as tasks/hand_base.py:45-54 derives them: plain modes from the task yaml; the
+    TSDF modes ('mesh_tsdf' / 'depth_tsdf') are resolution^3 volumes, plus the proprio state when the algo asks."""
+    dims = {k: v for k, v in cfg['task']['obs_mode'].items() if not isinstance(v, dict)}
+    mode = cfg['algo']['obs_mode']
+    if mode not in dims:
+        if 'tsdf' in mode and 'tsdf' in cfg['task']['obs_mode']:
+            dims[mode] = cfg['task']['obs_mode']['tsdf']['resolution'] ** 3
+        else:
+            raise KeyError(f"obs_mode '{mode}' is not declared in the task yaml")
+    if cfg['algo'].get('add_proprio_obs'):
+        dims[mode] += dims.get('proprio_state', 0)
+    return dims
+
+
 def main():
     cfg = process_cfgs(root=os.path.dirname(os.path.abspath(__file__)))
     rank, world, local = pdist.init_from_env()
@@ -55,7 +70,7 @@ def main():
     if cfg['pretrain'] is not None:
         cfg['algo']['pretrain'] = cfg['pretrain'] = logger.update_resume_path(cfg['pretrain'])
     torch.cuda.set_device(cfg['device'])
-    env = FeederEnv(cfg['algo']['num_envs'], cfg['task']['obs_mode'], num_actions(cfg['task']), cfg['device'],
+    env = FeederEnv(cfg['algo']['num_envs'], feeder_obs_dims(cfg), num_actions(cfg['task']), cfg['device'],
                     seed=cfg['seed'] + rank, max_episode_length=cfg['task']['maxEpisodeLength'])
     runner = {'ppo': ppo, 'dagger': dagger, 'bc': bc}[cfg['algo_name']](env, cfg['algo'], logger)
     runner.run()
