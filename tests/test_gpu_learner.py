@@ -19,7 +19,7 @@ import torch
 
 from oracle import ref_cpu as R
 from tests.golden import cases
-from tests.helpers import load_fixture, t, state_dict_t, ppo_cfg, ppo_rollout, flat_state, FakeEnv, FakeLogger
+from tests.helpers import load_fixture, t, ppo_cfg, ppo_rollout, flat_state, FakeEnv, FakeLogger
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
