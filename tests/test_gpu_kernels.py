@@ -365,3 +365,66 @@ def test_depth_compact_then_varlen_fps_selects_the_same_points_as_the_full_cloud
     ref_idx = R.fps(world.numpy(), K)
     want = np.take_along_axis(world.numpy(), ref_idx[..., None].repeat(3, axis=-1), axis=1)
     assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------- fused set-abstraction level
+@pytest.mark.parametrize("dims,P,S,cf", [((64, 64, 128), 1024, 256, 0), ((128, 128, 256), 256, 64, 128)])
+def test_sa_kernels_are_invariant_to_neighbour_order_at_bench_size(dims, P, S, cf):
+    """Size-independent property at the benchmark's per-level shapes (512 clouds): max-pooling over a group does not
+    depend on the order of its 32 neighbours.  Forward: pooled features bit-identical, arg-max follows the
+    permutation.  Backward (saved layer 2 and recompute): weight gradients equal to fp32 summation round-off, the
+    scattered dY likewise."""
+    o = ops()
+    B, (C1, C2, C3) = 512, dims
+    g = torch.Generator().manual_seed(P + cf)
+    xyz = (torch.rand(B, P, 3, generator=g) * 2 - 1).to(DEV)
+    ws = o.Workspace(torch.device(DEV))
+    idx_c = o.fps(xyz, S, ws)
+    centers = o.group_points(xyz, idx_c.view(B, S, 1)).view(B, S, 3)
+    idx = o.ball_query(xyz, centers, 0.3 if cf == 0 else 0.6, 32)
+    perm = torch.stack([torch.randperm(32, generator=g) for _ in range(B * S)]).view(B, S, 32).to(DEV)
+    idx_p = torch.gather(idx, 2, perm).contiguous()
+    ldw1 = (3 + cf + 3) // 4 * 4
+    W1 = (torch.randn(C1, ldw1, generator=g) * 0.3).to(DEV)
+    W2 = (torch.randn(C2, C1, generator=g) / C1 ** 0.5).to(DEV)
+    W3 = (torch.randn(C3, C2, generator=g) / C2 ** 0.5).to(DEV)
+    b1, b2, b3 = ((torch.randn(c, generator=g) * 0.1).to(DEV) for c in dims)
+    packed = torch.empty(int(o.lib.pm_sa_packed_elems(*dims)), device=DEV)
+    o.sa_pack(W2, W3, packed)
+    Y = None
+    if cf:
+        feat = (torch.randn(B * P, cf, generator=g) * 0.5).to(DEV)
+        Y = torch.empty(B * P, C1, device=DEV)
+        o.linear_fwd(feat, W1[:, 3:3 + cf], None, Y, o.ACT_NONE)
+    dpooled = torch.randn(B * S, C3, generator=g).to(DEV)
+    res = []
+    for ii, save in ((idx, True), (idx_p, True), (idx, False)):
+        pooled = torch.empty(B * S, C3, device=DEV)
+        h2 = torch.empty(B * S * 32, C2, device=DEV) if save else None
+        arg = o.sa_fwd(xyz, centers, ii, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
+        grads = [torch.empty_like(t_) for t_ in (W1, b1, W2, b2, W3, b3)]
+        dY = torch.zeros(B * P, C1, device=DEV) if cf else None
+        o.sa_bwd(xyz, centers, ii, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *grads, dY, ws, h2)
+        res.append((pooled, arg, grads, dY))
+    (p0, a0, g0, y0), (p1, a1, g1, y1), (p2, a2, g2, y2) = res
+    assert torch.equal(p0, p1) and torch.equal(p0, p2) and torch.equal(a0, a2)
+    # the arg-max row of the permuted run points at the same neighbour wherever the maximum is unique
+    src0 = torch.gather(idx.view(B * S, 32), 1, a0.long())
+    src1 = torch.gather(idx_p.view(B * S, 32), 1, a1.long())
+    flips = float((src0 != src1).float().mean())               # exact fp32 ties between two distinct neighbours
+    assert flips < 1e-5, flips                                 # (about one in 10^7 (group, channel) pairs)
+    for k, (x0, x1, x2) in enumerate(zip(g0, g1, g2)):
+        gw = x0[:, :3] if k == 0 else x0                       # dW1: only the xyz columns are written by the kernel
+        hw = x1[:, :3] if k == 0 else x1
+        rw = x2[:, :3] if k == 0 else x2
+        scale = float(gw.abs().max()) + 1e-12
+        # permuted neighbours = another summation order over millions of fp32 rows (round-off of long, cancelling
+        # sums), plus an O(1) change in ONE row of dW3 for every exact-tie flip above
+        d = (gw - hw).abs()
+        assert float((d > 2e-3 * scale).float().mean()) < 1e-3 and float(d.max()) < 2e-2 * scale, k
+        # saved vs recomputed layer 2, same order: the two backward paths see bit-identical H2
+        assert float((gw - rw).abs().max()) < 1e-6 * scale, k
+    if cf:
+        dyd = (y0 - y1).abs()                                  # a tie flip moves one row's gradient to another source point
+        assert float((dyd > 1e-4 * float(y0.abs().max())).float().mean()) < 1e-4
+        assert float((y0 - y2).abs().max()) < 1e-5 * float(y0.abs().max())      # global fp32 atomics: order varies
