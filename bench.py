@@ -298,6 +298,20 @@ def main():
             value=w["N"] * w["T"] / dt3, unit="env-steps/s", ms_per_step=dt3 * 1e3,
             note="pm_pointnet_enc_fwd_bf3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on bf16 MFMAs, fp32 accumulate; "
                  "~1e-5 relative; passes the golden vision-PPO cases at the fp32 path's tolerances; backward stays fp32"))
+        # ... with the critic loop issued on a second HIP stream next to the actor loop (bit-identical results; off by
+        # default for this workload because concurrent kernels blur the per-kernel timing the roofline block reports)
+        run.overlap = True
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        fence()
+        dto = (time.perf_counter() - t1) / 2
+        run.overlap = False
+        out["optional_paths"]["actor_critic_on_two_streams"] = dict(
+            value=w["N"] * w["T"] / dto, unit="env-steps/s", ms_per_step=dto * 1e3,
+            note="PARTMANIP_OVERLAP=1: same arithmetic, critic step k runs concurrently with actor step k")
         # ... and through the PointNet++ (SSG) plug-in backbone BASELINE.json's config text names: FPS + ball query
         # once per rollout, fused set-abstraction kernels (pm_sa_fwd_f32 / pm_sa_bwd_f32)
         w2 = dict(WORKLOADS["vision_pn2"])
