@@ -199,7 +199,9 @@ def main():
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     if args.workload == "dagger":
-        out = run_dagger(args, device, rank, world)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):       # the runners print progress lines: keep stdout = ONE JSON line
+            out = run_dagger(args, device, rank, world)
         if rank == 0:
             print(json.dumps(out))
         if world > 1:
