@@ -142,6 +142,50 @@ def cpu_baseline(w, rollout_cpu, sd_cpu, cfg):
                        f"{cfg['n_updates']} epochs x {T * N} samples; {ncores} torch threads")
 
 
+def run_depth2pc(args, device):
+    """Observation-side step with the only timing the reference publishes: the cloud sampling
+    of `TSDFVolume.depth2pc` for 64 envs x 6 views x 180 x 320 px -> 1024 points, "slow.. ~0.5s"
+    (utils/depth2tsdf.py:158, unstated NVIDIA GPU).  A step = one depth2pc call (back-projection, crop, compaction,
+    FPS, gather); `sampling_ms` isolates the part the reference's comment is about."""
+    from partmanip_amd import ops
+    from partmanip_amd.depth2tsdf import TSDFVolume
+    b, m, h, w_ = 64, 6, 180, 320
+    vol = TSDFVolume(device)
+    pose = torch.eye(4).repeat(m, 1, 1)
+    for i in range(m):
+        pose[i, :3, 3] = torch.tensor([0.02 * i, -0.01 * i, -0.6])
+    vol.register_camera(pose.numpy(), [[250.0, 0.0, w_ / 2 - 0.5], [0.0, 250.0, h / 2 - 0.5], [0.0, 0.0, 1.0]], h, w_, b)
+    torch.manual_seed(0)
+    depth = torch.rand(b, m, h, w_, device=device) * 0.5 + 0.45
+
+    def timed(fn, n):
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    dt = timed(lambda: vol.depth2pc(depth), args.steps)
+    lo = vol._vol_origin.cpu().numpy()
+    world = ops.depth_backproject(depth, vol.cam_pose, 250.0, 250.0, w_ / 2 - 0.5, h / 2 - 0.5, lo, vol._size + lo)
+    ws = ops.Workspace(device)
+
+    def sample():
+        c, n = ops.depth_compact(world)
+        ops.group_points(c, ops.fps_varlen(c, n, 1024, ws).view(b, 1024, 1))
+    ds = timed(sample, args.steps)
+    valid = float((world != 0).any(-1).float().mean())
+    return dict(metric="depth2pc seconds per call, 64 envs x 6 views x 180x320 px -> 1024 pts", value=dt, unit="s",
+                n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3, higher_is_better=False,
+                scaling="weak", vs_baseline=ds / 0.5, dtype="f32", data="synthetic",
+                config=dict(workload="depth2pc_64env_x_6view_x_180x320", sampling_ms=ds * 1e3, in_crop_fraction=valid,
+                            baseline="'~0.5s' for the sampling alone, utils/depth2tsdf.py:158 (BASELINE.md); "
+                                     "vs_baseline = sampling time / 0.5 s"))
+
+
 def build_runner(w, cfg, device, rank):
     """Runner + one synthetic rollout produced by the freshly initialised policy (ratio ~ 1, KL ~ 0) + the
     timed step: restore the initial policy / optimiser state, then the reference's `learn` window."""
@@ -183,7 +227,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="vision", choices=list(WORKLOADS) + ["dagger"])
+    ap.add_argument("--workload", default="vision", choices=list(WORKLOADS) + ["dagger", "depth2pc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-steps", type=int, default=0, help="override the rollout length T (e.g. 128 for the vision workload)")
     ap.add_argument("--points", type=int, default=4096, help="dagger workload: points per student cloud (BASELINE cfg 5: 4096)")
@@ -198,6 +242,12 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
+    if args.workload == "depth2pc":
+        if rank == 0:
+            print(json.dumps(run_depth2pc(args, device)))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     if args.workload == "dagger":
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):       # the runners print progress lines: keep stdout = ONE JSON line
