@@ -85,7 +85,7 @@ def _f32c(t, name):
 
 def _rows(t, name):
     """(ptr-able 2-D view, row stride in elements); last dim must be contiguous."""
-    if t.dim() != 2 or t.dtype != torch.float32 or t.stride(1) != 1:
+    if t.dim() != 2 or t.dtype != torch.float32 or (t.shape[1] != 1 and t.stride(1) != 1):   # a size-1 inner dim may carry any stride
         raise ValueError(f"{name}: expected a 2-D float32 tensor with unit inner stride, got {tuple(t.shape)} {t.stride()}")
     return t.stride(0)
 
