@@ -154,3 +154,68 @@ def test_pointnet_encoder_random_configs():
             got = f["grad_actor"][off:off + v.numel()].view(v.shape)
             off += v.numel()
             assert rel(got, grads[names.index("actor." + k)]) < 3e-4, (it, B, P, C, k)
+
+
+def test_pointnet2_random_level_geometry():
+    """PointNet2 with the fused set-abstraction shapes over random (B, centres per level, radii, input channels,
+    proprio): sampled / grouped indices bit-exact, outputs and gradients against the CPU restatement (pooling pinned)."""
+    from partmanip_amd.algo_utils import ActorCritic
+    rng = np.random.default_rng(5)
+    for it in range(5):
+        B, C = int(rng.integers(1, 4)), int(rng.choice([3, 4, 6]))
+        n0 = int(rng.integers(20, 140))
+        n1 = int(rng.integers(3, min(40, n0) + 1))
+        proprio = int(rng.choice([0, 4]))
+        net = dict(name="PointNet2", activation="tanh", npoints=[n0, n1], radii=[float(rng.uniform(0.15, 0.4)), float(rng.uniform(0.3, 0.8))],
+                   nsamples=[32, 32], mlps=[[64, 64, 128], [128, 128, 256], [256, 512]], save_h2=bool(it % 2))
+        torch.manual_seed(600 + it)
+        ac = ActorCritic(1024 * C + proprio, 5, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net),
+                         proprio).to(DEV)
+        f = ac.flat()
+        assert ac.actor._fused == [True, True]
+        g = torch.Generator().manual_seed(700 + it)
+        x = torch.cat([(torch.rand(B, 1024, C, generator=g) * 2 - 1).reshape(B, -1), torch.randn(B, proprio, generator=g)], 1).contiguous()
+        p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in ac.state_dict().items()}
+        out_ref, aux, _ = R.pointnet2_forward(p, "actor", net, x.clone(), proprio, return_aux=True)
+        out = ac.actor.hip_forward(x.to(DEV))
+        saved = ac.actor._saved
+        for l, (_, idx_g) in enumerate(aux):
+            assert torch.equal(saved[l][0].cpu().long(), idx_g), (it, l)
+        assert rel(out, out_ref.detach()) < 5e-5, it
+        pin = R.pointnet2_forward(p, "actor", net, x.clone(), proprio, pool_args=[s_[1].cpu().long() for s_ in saved])
+        dy = torch.randn(B, 5, generator=g)
+        names = [k for k in p if k.startswith("actor.")]
+        grads = torch.autograd.grad((pin * dy).sum(), [p[k] for k in names])
+        ac.actor.hip_backward(dy.to(DEV))
+        off = 0
+        for k, v in ac.actor.named_parameters():
+            got = f["grad_actor"][off:off + v.numel()].view(v.shape)
+            off += v.numel()
+            assert rel(got, grads[names.index("actor." + k)]) < 3e-4, (it, k)
+
+
+def test_loss_kernels_random_sizes():
+    """Value loss and the DAgger / BC MSE loss (all three target modes) over random sizes against plain torch."""
+    o = ops()
+    rng = np.random.default_rng(6)
+    for it in range(12):
+        B, A = int(rng.integers(1, 3000)), int(rng.integers(1, 12))
+        g = torch.Generator().manual_seed(800 + it)
+        v, ret, old = (torch.randn(B, 1, generator=g) for _ in range(3))
+        scal, dv = torch.zeros(8, device=DEV), torch.empty(B, 1, device=DEV)
+        clipped = bool(it % 2)
+        o.value_loss(v.to(DEV), ret.to(DEV), old.to(DEV), clipped, 0.2, None, 1.0, scal, dv)
+        vv = v.clone().requires_grad_(True)
+        loss = R.value_loss_fn(vv, ret, old, 0.2, clipped)
+        (gv,) = torch.autograd.grad(loss, vv)
+        assert abs(float(scal[0]) - float(loss)) <= 2e-5 * max(1.0, abs(float(loss))) and rel(dv, gv) < 2e-5, (it, B)
+        stu, tea = torch.randn(B, A, generator=g), torch.randn(B, A, generator=g)
+        for mode in (1, 3, 0):
+            d = torch.empty(B, A, device=DEV)
+            o.mse_tanh_loss(stu.to(DEV), tea.to(DEV), 1.0, mode, 1.0, scal, d)
+            s_ = stu.clone().requires_grad_(True)
+            sa = torch.tanh(s_) if mode & 1 else s_
+            ta = tea if (mode & 2 or not mode & 1) else torch.tanh(tea)
+            l2 = (ta - sa).pow(2).mean()
+            (gs,) = torch.autograd.grad(l2, s_)
+            assert abs(float(scal[0]) - float(l2)) <= 3e-5 * max(1e-3, float(l2)) and rel(d, gs) < 3e-5, (it, mode)
