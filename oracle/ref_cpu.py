@@ -7,9 +7,11 @@ checker for `tests/`, `__graft_entry__.smoke()` and `bench.py`'s
 never imports it (tests/test_no_oracle_in_product.py enforces that).
 
 Parity status: PINNED for GAE, PPO update (MLP and PointNet backbones), the
-actor-critic heads, the mini-batch sampler and the DAgger update -- each is
-checked in tests/test_oracle_golden.py against fixtures produced by running
-the reference itself (tests/golden/make_golden.py).  The point-set operators
+actor-critic heads, the mini-batch sampler, the DAgger update (MLP, PointNet and
+Conv3DNet students), the `bc` runner, the Conv3DNet module (outputs + parameter
+gradients), `TSDFVolume.depth2pc`'s world cloud and `TSDFVolume.integrate` --
+each is checked in tests/test_oracle_golden.py against fixtures produced by
+running the reference itself (tests/golden/make_golden.py).  The point-set operators
 at the bottom (farthest point sampling, ball query, grouping, PointNet++ set
 abstraction) have NO implementation in the reference tree (SURVEY.md §8a A15,
 A16: the only FPS is a call into un-vendored, unpinned pytorch3d) -- for those
