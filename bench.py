@@ -178,10 +178,17 @@ def run_depth2pc(args, device):
         ops.group_points(c, ops.fps_varlen(c, n, 1024, ws).view(b, 1024, 1))
     ds = timed(sample, args.steps)
     valid = float((world != 0).any(-1).float().mean())
+    # the other sampling call site (depth2tsdf.py:88-120, the 'depth_sparse' observation) on a scene with a surface:
+    # a tilted plane seen by all views, 50^3 grid -> integrate + band select + FPS(1024) + gather
+    yy, xx = torch.meshgrid(torch.arange(h, device=device), torch.arange(w_, device=device), indexing="ij")
+    plane = (0.75 + 0.0004 * xx + 0.0006 * yy).float().expand(b, m, h, w_).contiguous()
+    band = vol.integrate(plane).abs().lt(0.2).flatten(1).sum(-1).float().mean().item()
+    dv = timed(lambda: vol.sparse_voxel(plane), args.steps)
     return dict(metric="depth2pc seconds per call, 64 envs x 6 views x 180x320 px -> 1024 pts", value=dt, unit="s",
                 n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3, higher_is_better=False,
                 scaling="weak", vs_baseline=ds / 0.5, dtype="f32", data="synthetic",
                 config=dict(workload="depth2pc_64env_x_6view_x_180x320", sampling_ms=ds * 1e3, in_crop_fraction=valid,
+                            sparse_voxel_ms=dv * 1e3, sparse_voxel_band_voxels=band,
                             baseline="'~0.5s' for the sampling alone, utils/depth2tsdf.py:158 (BASELINE.md); "
                                      "vs_baseline = sampling time / 0.5 s"))
 

@@ -41,7 +41,7 @@ extern "C" {
 #define PM_ACT_TANH 1
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 114 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 115 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -237,8 +237,17 @@ int pm_depth_backproject_f32(const float* depth, int B, int M, int H, int W, con
  * (no -1 padding: once every point is taken the lowest index repeats, as on the full cloud); workspace
  * B*ld floats when ld > 8192. */
 int pm_depth_compact_f32(const float* xyz, int B, int P, float* out, int32_t* lengths, void* stream);
-int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths, int32_t* idx_out,
-                      void* workspace, size_t workspace_bytes, void* stream);
+int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths,
+                      int pad /* 1: pytorch3d semantics, -1 once a cloud is exhausted; 0: keep sampling (see above) */,
+                      int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream);
+/* utils/depth2tsdf.py:103-119 (`TSDFVolume.sparse_voxel` after pm_tsdf_integrate_f32): pm_tsdf_select_f32 writes, per
+ * env and in row-major voxel order (= torch.where), the integer coordinates (as floats) of the voxels with
+ * lo < tsdf < hi into coords (B, res^3, 3) and their count into lengths; pm_fps_varlen_f32 (pad = 1) samples them;
+ * pm_tsdf_sparse_gather_f32 emits out (B, K, 4) = (x, y, z, tsdf), padding indices reading voxel (0,0,0). */
+int pm_tsdf_select_f32(const float* vol, int B, int res, float lo, float hi, float* coords, int32_t* lengths,
+                       void* stream);
+int pm_tsdf_sparse_gather_f32(const float* coords, const int32_t* idx, const float* vol, int B, int res, int K,
+                              float* out, void* stream);
 
 /* ------------------------------------------------------------------ Conv3D students: patch gather / scatter
  * network.py:56-94 (`Conv3DNet` / `Encoder`: nn.Conv3d(k, stride, padding = k/2)).  A convolution runs as

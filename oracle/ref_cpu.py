@@ -9,7 +9,8 @@ never imports it (tests/test_no_oracle_in_product.py enforces that).
 Parity status: PINNED for GAE, PPO update (MLP and PointNet backbones), the
 actor-critic heads, the mini-batch sampler, the DAgger update (MLP, PointNet and
 Conv3DNet students), the `bc` runner, the Conv3DNet module (outputs + parameter
-gradients), `TSDFVolume.depth2pc`'s world cloud and `TSDFVolume.integrate` --
+gradients), `TSDFVolume.depth2pc`'s world cloud, `TSDFVolume.integrate` and
+`TSDFVolume.sparse_voxel` (everything around its pytorch3d call) --
 each is checked in tests/test_oracle_golden.py against fixtures produced by
 running the reference itself (tests/golden/make_golden.py).  The point-set operators
 at the bottom (farthest point sampling, ball query, grouping, PointNet++ set
@@ -594,6 +595,24 @@ def tsdf_integrate(depth, pix_idx, pix_z, size, resolution, default_tsdf=1.0):
     weight = torch.where(valid_pts != 0, 1.0 / n_valid.unsqueeze(1), torch.zeros(1))
     vol = (tsdf * weight).sum(dim=1) + default_tsdf * (n_valid == 0)
     return vol.reshape(b, resolution, resolution, resolution)
+
+
+def tsdf_sparse_voxel(vol, K=1024, lo=-0.2, hi=0.2):
+    """depth2tsdf.py:103-119 (`TSDFVolume.sparse_voxel` after the integration): per env the voxels with lo < tsdf < hi
+    in `torch.where` (row-major) order, farthest point sampling over their integer coordinates (squared distances
+    are exact integers, so the float restatement `fps` picks the same voxels), padding rows (fewer candidates than K)
+    = voxel (0,0,0) as pytorch3d's zero-filled gather leaves them; returns (b, K, 4) float32 rows (x, y, z, tsdf)."""
+    vol = torch.as_tensor(vol, dtype=torch.float32)
+    rows = []
+    for i in range(vol.shape[0]):
+        ind = torch.stack(torch.where((vol[i] < hi) & (vol[i] > lo)), dim=-1)
+        idx = torch.from_numpy(fps(ind.unsqueeze(0).numpy().astype(np.float32), K))[0]
+        sel = torch.where(idx.unsqueeze(-1) >= 0, ind[idx.clamp(min=0)], torch.zeros(1, dtype=ind.dtype))
+        rows.append(sel)
+    all_ind = torch.stack(rows).long()
+    help_ = torch.arange(all_ind.shape[0]).unsqueeze(-1).repeat(1, all_ind.shape[1])
+    val = vol[help_, all_ind[..., 0], all_ind[..., 1], all_ind[..., 2]]
+    return torch.cat((all_ind, val.unsqueeze(-1)), dim=-1)
 
 
 def ball_query(xyz, centers, radius, nsample):

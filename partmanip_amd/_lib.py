@@ -53,7 +53,9 @@ SIGNATURES = {
     "pm_maxpool_rows_bwd_f32": (I, [P, L, P, L, I, I, P, P, P]),
     "pm_depth_backproject_f32": (I, [P, I, I, I, I, P, F, F, F, F, P, P, P, P]),
     "pm_depth_compact_f32": (I, [P, I, I, P, P, P]),
-    "pm_fps_varlen_f32": (I, [P, I, I, I, I, P, P, P, Z, P]),
+    "pm_fps_varlen_f32": (I, [P, I, I, I, I, P, I, P, P, Z, P]),
+    "pm_tsdf_select_f32": (I, [P, I, I, F, F, P, P, P]),
+    "pm_tsdf_sparse_gather_f32": (I, [P, P, P, I, I, I, P, P]),
     "pm_im2col3d_f32": (I, [P, I, I, I, I, I, I, I, I, L, L, L, L, L, P, I, P]),
     "pm_col2im3d_f32": (I, [P, I, I, I, I, I, I, I, I, L, L, L, L, L, P, P, I, P]),
     "pm_tsdf_integrate_f32": (I, [P, P, P, I, I, L, L, F, F, P, P]),
@@ -77,7 +79,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 114                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 115                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(FPS_NT) void fps_kernel(const float* __restrict__ x
 // Variable-length clouds (rows of a (B, ld, D) buffer, the first lengths[b] of each are points): the path is
 // chosen per cloud on the device (no host sync on the lengths) -- registers if it fits, streaming otherwise.
 __global__ __launch_bounds__(FPS_NT) void fps_varlen_kernel(const float* __restrict__ xyz, int ld, int D, int K,
-                                                             const int32_t* __restrict__ lengths,
+                                                             const int32_t* __restrict__ lengths, int pad,
                                                              int32_t* __restrict__ idx_out,
                                                              float* __restrict__ mind_ws) {
     __shared__ float sv[FPS_NT / 64];
@@ -140,8 +140,15 @@ __global__ __launch_bounds__(FPS_NT) void fps_varlen_kernel(const float* __restr
     const int b = blockIdx.x, n = lengths[b];
     const float* pts = xyz + (long)b * ld * D;
     int32_t* idx_b = idx_out + (long)b * K;
-    if (n <= FPS_NT * FPS_RPT) fps_body<true, false>(pts, n, D, K, idx_b, nullptr, sv, si, sel);
-    else fps_body<false, false>(pts, n, D, K, idx_b, mind_ws + (long)b * ld, sv, si, sel);
+    if (n <= 0) {                                        // empty cloud: pytorch3d yields -1 everywhere
+        for (int j = threadIdx.x; j < K; j += FPS_NT) idx_b[j] = -1;
+    } else if (n <= FPS_NT * FPS_RPT) {
+        if (pad) fps_body<true, true>(pts, n, D, K, idx_b, nullptr, sv, si, sel);
+        else fps_body<true, false>(pts, n, D, K, idx_b, nullptr, sv, si, sel);
+    } else {
+        if (pad) fps_body<false, true>(pts, n, D, K, idx_b, mind_ws + (long)b * ld, sv, si, sel);
+        else fps_body<false, false>(pts, n, D, K, idx_b, mind_ws + (long)b * ld, sv, si, sel);
+    }
 }
 
 // Wave-per-cloud variant for xyz clouds of up to 2048 points (the learner's sizes: 1024 -> 256 -> 64): the cloud
@@ -456,12 +463,12 @@ extern "C" int pm_maxpool_rows_bwd_f32(const float* dout, long lddo, const int32
 
 extern "C" int pm_version(void) { return PM_ABI_VERSION; }
 
-extern "C" int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths,
+extern "C" int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths, int pad,
                                  int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream) {
     PM_REQUIRE(xyz && lengths && idx_out && B > 0 && ld > 0 && D >= 1 && D <= FPS_MAXD && K > 0);
     if (ld > FPS_NT * FPS_RPT && (!workspace || workspace_bytes < (size_t)B * ld * sizeof(float))) return PM_EWORKSPACE;
-    hipLaunchKernelGGL(fps_varlen_kernel, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, ld, D, K, lengths, idx_out,
-                       (float*)workspace);
+    hipLaunchKernelGGL(fps_varlen_kernel, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, ld, D, K, lengths, pad,
+                       idx_out, (float*)workspace);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
@@ -526,6 +533,90 @@ __global__ __launch_bounds__(1024) void depth_compact_kernel(const float* __rest
 extern "C" int pm_depth_compact_f32(const float* xyz, int B, int P, float* out, int32_t* lengths, void* stream) {
     PM_REQUIRE(xyz && out && lengths && B > 0 && P > 0 && xyz != out);
     hipLaunchKernelGGL(depth_compact_kernel, dim3(B), dim3(1024), 0, pm_stream(stream), xyz, P, out, lengths);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// ---------------------------------------------------------------------------------- sparse TSDF voxels
+// utils/depth2tsdf.py:103-119 (`TSDFVolume.sparse_voxel` after the integration): per env the voxels whose TSDF lies
+// in the open band (lo, hi) -- `torch.where` order = row-major voxel index -- go to farthest point sampling as
+// integer coordinates, and the sampled (x, y, z, tsdf) rows are the 'depth_sparse' observation of the PointNet
+// learner.  Same stable stream compaction as depth_compact_kernel (wave ballot + popcount, LDS prefix over waves).
+__global__ __launch_bounds__(1024) void tsdf_select_kernel(const float* __restrict__ vol, int V, int res, float lo,
+                                                            float hi, float* __restrict__ coords,
+                                                            int32_t* __restrict__ lengths) {
+    __shared__ int wcnt[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* vb = vol + (long)b * V;
+    float* dst = coords + (long)b * V * 3;
+    int base = 0;
+    for (int v0 = 0; v0 < V; v0 += 1024) {
+        const int v = v0 + tid;
+        bool keep = false;
+        if (v < V) {
+            const float t = vb[v];
+            keep = t < hi && t > lo;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int within = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = wcnt[w];
+            before += (w < wave) ? c : 0;
+            total += c;
+        }
+        if (keep) {
+            const long q = base + before + within;
+            dst[q * 3] = (float)(v / (res * res));
+            dst[q * 3 + 1] = (float)((v / res) % res);
+            dst[q * 3 + 2] = (float)(v % res);
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) lengths[b] = base;
+}
+
+// out[b,k,:] = (x, y, z, vol[b,x,y,z]) of the sampled voxel; a padding index (-1: fewer candidates than K) reads as
+// voxel (0,0,0), as the reference's zero-filled gather does (depth2tsdf.py:116-119).
+__global__ __launch_bounds__(256) void tsdf_sparse_gather_kernel(const float* __restrict__ coords,
+                                                                  const int32_t* __restrict__ idx,
+                                                                  const float* __restrict__ vol, int V, int res, int K,
+                                                                  long total, float* __restrict__ out) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long b = e / K;
+        const int i = idx[e];
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (i >= 0) {
+            const float* c = coords + ((long)b * V + i) * 3;
+            x = c[0]; y = c[1]; z = c[2];
+        }
+        const int v = ((int)x * res + (int)y) * res + (int)z;
+        out[e * 4] = x; out[e * 4 + 1] = y; out[e * 4 + 2] = z;
+        out[e * 4 + 3] = vol[b * V + v];
+    }
+}
+
+extern "C" int pm_tsdf_select_f32(const float* vol, int B, int res, float lo, float hi, float* coords,
+                                  int32_t* lengths, void* stream) {
+    PM_REQUIRE(vol && coords && lengths && B > 0 && res > 0 && res <= 1024);
+    hipLaunchKernelGGL(tsdf_select_kernel, dim3(B), dim3(1024), 0, pm_stream(stream), vol, res * res * res, res, lo, hi,
+                       coords, lengths);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_tsdf_sparse_gather_f32(const float* coords, const int32_t* idx, const float* vol, int B, int res,
+                                         int K, float* out, void* stream) {
+    PM_REQUIRE(coords && idx && vol && out && B > 0 && res > 0 && K > 0);
+    const long total = (long)B * K;
+    long nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(tsdf_sparse_gather_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), coords, idx, vol,
+                       res * res * res, res, K, total, out);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }

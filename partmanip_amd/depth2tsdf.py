@@ -10,8 +10,9 @@
 lowest-index ties -- the same points as sampling the full cloud; the reference calls
 `pytorch3d.ops.sample_farthest_points(world_cld, K=1024)`, depth2tsdf.py:160), both on the GPU.
 `integrate` (depth -> TSDF volume for the Conv3D students, depth2tsdf.py:68-86) is pm_tsdf_integrate_f32 over voxel ->
-pixel tables built at registration time.  `sparse_voxel` and the marching-cubes `extract_point_cloud` are outside
-this build's scope: they raise NotImplementedError.
+pixel tables built at registration time; `sparse_voxel` (depth2tsdf.py:88-120, the 'depth_sparse' observation) selects the
+surface band, samples it with pm_fps_varlen_f32 and gathers (x, y, z, tsdf).  The marching-cubes `extract_point_cloud`
+is outside this build's scope: it raises NotImplementedError.
 """
 import numpy as np
 import torch
@@ -79,8 +80,11 @@ class TSDFVolume(object):
         self._tsdf_vol = vol.view(depth_im.shape[0], self._resolution, self._resolution, self._resolution)
         return self._tsdf_vol
 
-    def sparse_voxel(self, depth_im):
-        raise NotImplementedError("sparse_voxel (depth2tsdf.py:88-120) is outside this build's scope (SURVEY.md §8f)")
+    def sparse_voxel(self, depth_im, K=1024):
+        """depth_im (b, m, h, w) -> (b, K, 4) rows (x, y, z, tsdf): the 'depth_sparse' observation (depth2tsdf.py:88-120):
+        integrate, keep the voxels with -0.2 < tsdf < 0.2, farthest-point-sample their integer coordinates."""
+        vol = self.integrate(depth_im)
+        return ops.tsdf_sparse_voxel(vol.contiguous(), K, -0.2, 0.2, self._ws)
 
     def extract_point_cloud(self):
         raise NotImplementedError("marching cubes is outside this build's scope (SURVEY.md §8f)")

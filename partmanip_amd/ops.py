@@ -483,14 +483,32 @@ def depth_compact(world):
     return out, lengths
 
 
-def fps_varlen(xyz, lengths, K, ws):
-    """FPS over the first lengths[b] rows of each cloud of xyz (B, ld, D) -> idx (B, K) int32 (no -1 padding)."""
+def fps_varlen(xyz, lengths, K, ws, pad=False):
+    """FPS over the first lengths[b] rows of each cloud of xyz (B, ld, D) -> idx (B, K) int32; pad=True: pytorch3d's
+    -1 once a cloud is exhausted, pad=False: keep sampling (index 0 repeats), as the full depth cloud would."""
     _req(xyz, lengths)
     _f32c(xyz, "xyz")
     B, ld, Dd = xyz.shape
     idx = torch.empty(B, K, dtype=torch.int32, device=xyz.device)
     nb = B * ld * 4 if ld > 8192 else 0
     w = ws.get(nb) if nb else None
-    check(lib.pm_fps_varlen_f32(_ptr(xyz), B, ld, Dd, K, _ptr(lengths), _ptr(idx), _ptr(w), w.numel() if w is not None else 0,
-                                _stream()), "pm_fps_varlen_f32")
+    check(lib.pm_fps_varlen_f32(_ptr(xyz), B, ld, Dd, K, _ptr(lengths), int(pad), _ptr(idx), _ptr(w),
+                                w.numel() if w is not None else 0, _stream()), "pm_fps_varlen_f32")
     return idx
+
+
+def tsdf_sparse_voxel(vol, K, lo, hi, ws):
+    """vol (B, res, res, res) -> (B, K, 4) rows (x, y, z, tsdf) of FPS-sampled voxels with lo < tsdf < hi."""
+    _req(vol)
+    _f32c(vol, "vol")
+    B, res = vol.shape[0], vol.shape[1]
+    V = res ** 3
+    coords = torch.empty(B, V, 3, dtype=torch.float32, device=vol.device)
+    lengths = torch.empty(B, dtype=torch.int32, device=vol.device)
+    check(lib.pm_tsdf_select_f32(_ptr(vol), B, res, float(lo), float(hi), _ptr(coords), _ptr(lengths), _stream()),
+          "pm_tsdf_select_f32")
+    idx = fps_varlen(coords, lengths, K, ws, pad=True)
+    out = torch.empty(B, K, 4, dtype=torch.float32, device=vol.device)
+    check(lib.pm_tsdf_sparse_gather_f32(_ptr(coords), _ptr(idx), _ptr(vol), B, res, K, _ptr(out), _stream()),
+          "pm_tsdf_sparse_gather_f32")
+    return out

@@ -317,9 +317,10 @@ def gen_depth2pc(cases):
     rec = {}
 
     def sample_farthest_points(points, K):
-        rec["world"] = points.detach().cpu().numpy().copy()
-        idx = torch.from_numpy(R.fps(rec["world"], K))
-        return torch.gather(points, 1, idx.unsqueeze(-1).expand(-1, -1, 3)), idx
+        rec["points"] = points.detach().cpu().numpy().copy()
+        idx = torch.from_numpy(R.fps(rec["points"].astype(np.float32), K))
+        got = torch.gather(points, 1, idx.clamp(min=0).unsqueeze(-1).expand(-1, -1, 3))
+        return got * (idx >= 0).unsqueeze(-1), idx                # pytorch3d's masked_gather: -1 -> zero row
 
     p3d, p3d_ops = types.ModuleType("pytorch3d"), types.ModuleType("pytorch3d.ops")
     p3d_ops.sample_farthest_points = sample_farthest_points
@@ -333,6 +334,8 @@ def gen_depth2pc(cases):
         vol = mod.TSDFVolume("cpu", size=c["size"], resolution=10, _vol_origin=c["vol_origin"])
         vol.register_camera(inp["cam_pose"], np.asarray(c["intr"], dtype=np.float32), c["h"], c["w"], c["b"])
         final = vol.depth2pc(torch.from_numpy(inp["depth"]))
+        rec["world"] = rec["points"]
+        sparse = vol.sparse_voxel(torch.from_numpy(inp["depth"])).numpy().copy()      # depth2tsdf.py:88-120, K = 1024
         tsdf = vol.integrate(torch.from_numpy(inp["depth"])).numpy().copy()          # depth2tsdf.py:68-86, resolution 10
         # the method hard-codes K=1024 (depth2tsdf.py:160); the case's K-sample prefix is what the tests compare
         idx = R.fps(rec["world"], c["K"])
@@ -341,8 +344,10 @@ def gen_depth2pc(cases):
         pix_idx = torch.where(vol.valid_pix, vol.valid_pix_y * c["w"] + vol.valid_pix_x,
                               torch.full_like(vol.valid_pix_x, -1)).numpy().astype(np.int32)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), world=rec["world"], final_pc_1024=final.numpy(),
-                            idx=idx.astype(np.int32), tsdf=tsdf, tsdf_pix_idx=pix_idx, tsdf_pix_z=vol.pix_z.numpy())
-        print("wrote", name, "valid fraction", float((rec["world"] != 0).any(-1).mean()))
+                            idx=idx.astype(np.int32), tsdf=tsdf, tsdf_pix_idx=pix_idx, tsdf_pix_z=vol.pix_z.numpy(),
+                            sparse_voxel=sparse)
+        print("wrote", name, "valid fraction", float((rec["world"] != 0).any(-1).mean()),
+              "band voxels", ((tsdf < 0.2) & (tsdf > -0.2)).reshape(tsdf.shape[0], -1).sum(-1))
 
 
 def main():

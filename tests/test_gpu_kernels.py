@@ -342,6 +342,38 @@ def test_tsdf_integrate_matches_reference():
     assert np.array_equal(vol.integrate(depth).cpu().numpy(), fx["tsdf"])
 
 
+def test_sparse_voxel_matches_reference():
+    """TSDFVolume.sparse_voxel (select -> pm_fps_varlen_f32 with padding -> gather) against the REFERENCE's own
+    (b, 1024, 4) output (fixture), bit for bit, on the reference's registration tables."""
+    from partmanip_amd.depth2tsdf import TSDFVolume
+    c = cases.DEPTH2PC_CASES["depth2pc_small"]
+    inp, fx = cases.depth2pc_inputs(c), load_fixture("depth2pc_small")
+    vol = TSDFVolume(DEV, size=c["size"], resolution=10, _vol_origin=c["vol_origin"])
+    vol.register_camera(inp["cam_pose"], np.asarray(c["intr"], dtype=np.float32), c["h"], c["w"], c["b"])
+    vol._pix_idx = torch.from_numpy(fx["tsdf_pix_idx"]).to(DEV)
+    vol.pix_z = torch.from_numpy(fx["tsdf_pix_z"]).to(DEV)
+    out = vol.sparse_voxel(torch.from_numpy(inp["depth"]).to(DEV))
+    assert tuple(out.shape) == (c["b"], 1024, 4) and out.dtype == torch.float32
+    assert np.array_equal(out.cpu().numpy(), fx["sparse_voxel"])
+
+
+@pytest.mark.parametrize("res,band,K", [(12, 0.9, 256), (20, 0.5, 1024), (50, 0.25, 1024), (9, 0.0, 64), (16, 2.0, 128)])
+def test_sparse_voxel_kernels_against_restatement(res, band, K):
+    """Random volumes with many more band voxels than K (the 50^3 production grid: ~31k candidates -> the streaming
+    FPS), none at all (band 0), and every voxel (band 2): selection order, sampling and gather vs the restatement."""
+    o = ops()
+    g = torch.Generator().manual_seed(res * 7 + K)
+    vol = torch.rand(3, res, res, res, generator=g) * 2 - 1
+    vol[1, :, : res // 2] = 1.0                                      # ragged: env 1 has about half the candidates
+    if band == 0.0:
+        ref = np.zeros((3, K, 4), np.float32)
+        ref[..., 3] = vol[:, 0, 0, 0].numpy()[:, None]
+    else:
+        ref = R.tsdf_sparse_voxel(vol.numpy(), K=K, lo=-band, hi=band).numpy()
+    out = o.tsdf_sparse_voxel(vol.to(DEV), K, -band, band, o.Workspace(DEV))
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("P,frac_valid,K", [(5000, 0.3, 64), (40000, 0.1, 48), (3000, 0.0, 16), (2000, 1.0, 32), (700, 0.01, 40)])
 def test_depth_compact_then_varlen_fps_selects_the_same_points_as_the_full_cloud(P, frac_valid, K):
     """Crop compaction + variable-length FPS (what TSDFVolume.depth2pc runs) against FPS over the FULL cloud by the

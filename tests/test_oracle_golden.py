@@ -209,3 +209,16 @@ def test_tsdf_integrate_restatement_matches_reference():
                            c["size"], 10).numpy()
     assert np.array_equal(vol, fx["tsdf"])                          # with the reference's tables: bit-identical
     assert 0.05 < float((vol != 1.0).mean()) < 0.95                 # some voxels are seen, some keep the default
+
+
+def test_sparse_voxel_restatement_matches_reference():
+    """utils/depth2tsdf.py:88-120 run by the reference's own TSDFVolume.sparse_voxel (its pytorch3d dependency stubbed
+    by the restated FPS, make_golden.gen_depth2pc): (b, 1024, 4) rows incl. the zero-padded tail, bit-identical."""
+    fx = load_fixture("depth2pc_small")
+    out = R.tsdf_sparse_voxel(fx["tsdf"], K=1024).numpy()
+    assert out.dtype == np.float32 and np.array_equal(out, fx["sparse_voxel"])
+    n_band = ((fx["tsdf"] < 0.2) & (fx["tsdf"] > -0.2)).reshape(2, -1).sum(-1)
+    assert (n_band < 1024).all() and (n_band > 100).all()           # the fixture exercises the padded branch
+    for b in range(2):                                               # padding rows read voxel (0,0,0)
+        assert np.array_equal(out[b, n_band[b]:, :3], np.zeros((1024 - n_band[b], 3), np.float32))
+        assert (out[b, n_band[b]:, 3] == fx["tsdf"][b, 0, 0, 0]).all()
