@@ -664,6 +664,321 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
 }
 #undef PN_DW1_ACCUM
 
+// ---- 16-wave variant of the saved-h2 backward: ONE work-group of 1024 threads per CU, 64-point tiles ----
+// The 4-wave kernel above keeps the whole 256x128 dW2 accumulator in 4 waves (128 VGPRs each), which caps a CU at
+// two waves per SIMD and leaves the matrix pipe idle whenever both resident groups are in a VALU / barrier phase
+// (busy 55 %).  Here 16 waves share it (two 32x32 blocks = 32 registers each) and dh1 = dz2 * W2 (64 points x 128
+// channels = 8 blocks) is split over wave PAIRS along K: with the packed k-split layout, k-groups [0,16) and
+// [16,32) of a block are the disjoint halves {0..63, 128..191} / {64..127, 192..255} of K, so each wave streams
+// half of the block's weights and the pair meets in LDS (each finishes 8 of the 16 accumulator rows).  Four waves
+// per SIMD feed the matrix pipe, and the VALU phases (layer 1, row-owner pass, dW1) run 16 waves wide: 4 rows per
+// wave and tile instead of 8, three barriers per 64 points instead of two per 32.
+#ifndef PN_BWD16
+#define PN_BWD16 1
+#endif
+#define PN_BT16 64
+template <int CT>
+__global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
+    const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
+    const float* __restrict__ b1, const float* __restrict__ W3, const float* __restrict__ packed, int max_mean,
+    const float* __restrict__ dfeat, long ldf, const int32_t* __restrict__ argmax, const float* __restrict__ U,
+    float* __restrict__ H2sum, float* __restrict__ Hg, int32_t* __restrict__ slotmap, PnBwdPart* __restrict__ parts,
+    const float* __restrict__ h2_saved) {
+    constexpr int BT = PN_BT16, NT = 1024, NW = 16, RPW = BT / NW, PARTS = NT / PN_C1, PPT = BT / PARTS;
+    __shared__ __attribute__((aligned(16))) float smem[BT * PN_LD1 * 2 + BT * PN_LD2 + 2 * BT * PN_MAXC + PN_C2 + PN_C3 +
+                                                        PN_C3 + 520 + 32];
+    float* H1 = smem;                                   // [64][132]
+    float* DZ1 = H1 + BT * PN_LD1;                      // [64][132]; end of cloud / kernel: [16][256] wave partials
+    float* H2 = DZ1 + BT * PN_LD1;                      // [64][260]  dz2 (h2 itself only passes through registers)
+    float* Xs0 = H2 + BT * PN_LD2;                      // 2 x [64][8]
+    float* Us = Xs0 + 2 * BT * PN_MAXC;                 // [256]  u[b,:]/P
+    float* Gm = Us + PN_C2;                             // [512]  dmax[b,:]
+    int* keys = (int*)(Gm + PN_C3);                     // [512]  sorted (slot<<22 | point<<9 | channel)
+    unsigned short* offs = (unsigned short*)(keys + PN_C3);   // [P/4+1 <= 1025] first key of each wave's row block
+    double* red = (double*)((float*)(keys + PN_C3) + 520);    // [16]
+    float* wred = DZ1;
+
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float4* P2Tv = (const float4*)(packed + PN_P2T_OFF);
+    const float invP = 1.0f / (float)P;
+
+    const int w2_m = wave & 7, w2_n0 = (wave >> 3) * 2;  // dW2[out = w2_m*32 + row][in = (w2_n0 + j)*32 + li]
+    f32x16 accW2[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW2[nb][r] = 0.f;
+    float4 db2acc = make_float4(0.f, 0.f, 0.f, 0.f);   // columns 4*lane..+3 over this wave's rows
+    float dW1acc[PN_MAXC], db1acc = 0.f;                 // channel tid&127, point part tid>>7
+#pragma unroll
+    for (int d = 0; d < PN_MAXC; ++d) dW1acc[d] = 0.f;
+
+#define PN_DW1_ACCUM16(XS)                                                       \
+    {                                                                            \
+        const int c_ = tid & 127, p0_ = (tid >> 7) * PPT;                        \
+        _Pragma("unroll 4") for (int p = p0_; p < p0_ + PPT; ++p) {              \
+            const float dz = DZ1[p * PN_LD1 + c_];                               \
+            const float4 x0 = *(const float4*)((XS) + p * PN_MAXC);              \
+            db1acc += dz;                                                        \
+            dW1acc[0] = fmaf(dz, x0.x, dW1acc[0]);                               \
+            dW1acc[1] = fmaf(dz, x0.y, dW1acc[1]);                               \
+            dW1acc[2] = fmaf(dz, x0.z, dW1acc[2]);                               \
+            dW1acc[3] = fmaf(dz, x0.w, dW1acc[3]);                               \
+            if (CT != 3 && CT != 4) {                                            \
+                const float4 x1 = *(const float4*)((XS) + p * PN_MAXC + 4);      \
+                dW1acc[4] = fmaf(dz, x1.x, dW1acc[4]);                           \
+                dW1acc[5] = fmaf(dz, x1.y, dW1acc[5]);                           \
+                dW1acc[6] = fmaf(dz, x1.z, dW1acc[6]);                           \
+                dW1acc[7] = fmaf(dz, x1.w, dW1acc[7]);                           \
+            }                                                                    \
+        }                                                                        \
+    }
+
+    const int ntiles = P / BT;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const float* xb = x + (long)b * ldx;
+        float cen[3] = {0.f, 0.f, 0.f};
+        __syncthreads();
+        if (sub_mean) cloud_centroid<NT>(xb, P, C, red, cen);
+        // ---- per-cloud setup: u/P, dmax, CSR of argmax by point (see pn_bwd_kernel) -------------------------
+        if (tid < PN_C2) Us[tid] = max_mean ? U[(long)b * PN_C2 + tid] * invP : 0.f;
+        if (tid < PN_C3) {
+            Gm[tid] = dfeat[(long)b * ldf + tid];
+            keys[tid] = (argmax[(long)b * PN_C3 + tid] << 9) | tid;
+        }
+#pragma unroll 1
+        for (int k = 2; k <= 512; k <<= 1) {             // bitonic sort of the 512 keys by threads 0-255
+#pragma unroll 1
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                __syncthreads();
+                if (tid < 256) {
+                    const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
+                    const int ixj = i | j;
+                    const int a = keys[i], c = keys[ixj];
+                    if ((a > c) == ((i & k) == 0)) {
+                        keys[i] = c;
+                        keys[ixj] = a;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int p = tid; p <= P / RPW; p += NT) {       // offs[i] = #keys with point < i * RPW
+            int lo = 0, hi = PN_C3;
+            const int target = (p * RPW) << 9;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (keys[mid] < target) lo = mid + 1; else hi = mid;
+            }
+            offs[p] = (unsigned short)lo;
+        }
+        {   // slot[e] = number of distinct arg-max points before sorted entry e; each distinct point's h2 row is
+            // stored once (Hg[b, slot, :]) and found through slotmap[b, c]
+            int* wtot = (int*)red;
+            int v = 0, f1 = 0;
+            const int e0 = 2 * tid, e1 = e0 + 1;
+            if (tid < 256) {
+                const int q0 = keys[e0] >> 9, q1 = keys[e1] >> 9, qm = (e0 > 0) ? (keys[e0 - 1] >> 9) : -1;
+                f1 = (q1 != q0);
+                v = (q0 != qm) + f1;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(v, o, 64);
+                    if (lane0 >= o) v += t;
+                }
+            }
+            __syncthreads();                                   // every neighbour key has been read
+            if (tid < 256 && lane0 == 63) wtot[wave] = v;
+            __syncthreads();
+            if (tid < 256) {
+                int base = 0;
+                for (int w2 = 0; w2 < wave; ++w2) base += wtot[w2];
+                const int s1 = base + v - 1, s0 = s1 - f1;
+                keys[e0] |= s0 << 22;
+                keys[e1] |= s1 << 22;
+                slotmap[(long)b * PN_C3 + (keys[e0] & 511)] = s0;
+                slotmap[(long)b * PN_C3 + (keys[e1] & 511)] = s1;
+            }
+        }
+        float4 h2s = make_float4(0.f, 0.f, 0.f, 0.f);    // sum_p h2[p][4*lane..] over this wave's rows
+
+        stage_points<BT, NT>(xb, 0, C, sub_mean, cen, Xs0);
+        for (int tile = 0; tile < ntiles; ++tile) {
+            int lane = lane0;                              // laundered per tile: recompute addresses, don't hoist
+            asm volatile("" : "+v"(lane));
+            const int li = lane & 31, lh = lane >> 5;
+            float* Xs = Xs0 + (tile & 1) * BT * PN_MAXC;
+            float* Xo = Xs0 + ((tile & 1) ^ 1) * BT * PN_MAXC;
+            // this wave's 4 saved-h2 rows are requested before the barrier: their HBM latency runs under layer 1
+            const float* hsrc = h2_saved + ((long)b * P + tile * BT + wave * RPW) * PN_C2 + 4 * lane;
+            float4 hrows[RPW];
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) hrows[rr] = *(const float4*)(hsrc + rr * PN_C2);
+            __syncthreads();                               // (A) Xs staged; DZ1 of tile t-1 complete; H1/H2 free
+            if (!(PN_ABLATE & 128)) {
+                layer1_tile<CT, BT, NT>(Xs, W1, b1, C, H1);
+                if (tile > 0) PN_DW1_ACCUM16(Xo)
+            }
+            // ---- row-owner pass: wave w owns rows w*4..w*4+3; h2 -> dz2 (into the LDS tile) ---------------------
+            if (!(PN_ABLATE & 8)) {
+                const int p0 = tile * BT + wave * RPW;
+                const float4 u4 = *(const float4*)(Us + 4 * lane);
+                const int e_end = offs[p0 / RPW + 1];
+                int e = offs[p0 / RPW];
+                const int e0 = e, span = e_end - e0;
+                const int pj = (lane < span) ? ((keys[e0 + lane] >> 9) & 0x1FFF) : 0x7FFFFFFF;
+                int c_next = 0;
+                float4 w_next = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < e_end) {
+                    c_next = keys[e] & 511;
+                    w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
+                }
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) {
+                    float* hrow = H2 + (wave * RPW + rr) * PN_LD2 + 4 * lane;
+                    const float4 h = hrows[rr];
+                    h2s.x += h.x; h2s.y += h.y; h2s.z += h.z; h2s.w += h.w;
+                    float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+                    int row_end;
+                    if (span <= 64) {
+                        row_end = e0 + __popcll(__ballot(pj <= p0 + rr));
+                    } else {
+                        int lo = e, hi = e_end;
+                        const int target = (p0 + rr + 1) << 9;
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if ((keys[mid] & 0x3FFFFF) < target) lo = mid + 1; else hi = mid;
+                        }
+                        row_end = lo;
+                    }
+                    if (e < row_end)                                  // this point is some channel's arg-max
+                        *(float4*)(Hg + ((long)b * PN_C3 + (keys[e] >> 22)) * PN_C2 + 4 * lane) = h;
+                    for (; e < row_end; ++e) {
+                        const int c = c_next;
+                        const float4 w3 = w_next;
+                        if (e + 1 < e_end) {
+                            c_next = keys[e + 1] & 511;
+                            w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
+                        }
+                        const float g = Gm[c];
+                        S.x += g * w3.x; S.y += g * w3.y; S.z += g * w3.z; S.w += g * w3.w;
+                    }
+                    float4 dz;
+                    dz.x = (u4.x + S.x) * (1.0f - h.x * h.x);
+                    dz.y = (u4.y + S.y) * (1.0f - h.y * h.y);
+                    dz.z = (u4.z + S.z) * (1.0f - h.z * h.z);
+                    dz.w = (u4.w + S.w) * (1.0f - h.w * h.w);
+                    *(float4*)hrow = dz;
+                    db2acc.x += dz.x; db2acc.y += dz.y; db2acc.z += dz.z; db2acc.w += dz.w;
+                }
+            }
+            __syncthreads();                               // (D) dz2 tile complete
+            if (tile + 1 < ntiles) stage_points<BT, NT>(xb, tile + 1, C, sub_mean, cen, Xo);
+            {
+                // ---- dW2 += dz2^T * h1 : K = 64 points (lanes < 32: point s, lanes >= 32: point 32 + s) ----------
+                const float* Ap = H2 + (lh * (BT / 2)) * PN_LD2 + w2_m * 32 + li;             // A[i=out][k=pt] = dz2[pt][out]
+                const float* Bp = H1 + (lh * (BT / 2)) * PN_LD1 + w2_n0 * 32 + li;            // B[k=pt][j=in] = h1[pt][in]
+                float ap, bvp[2], aq, bvq[2];
+#define DW2_LOAD(a_, bv, s_) \
+    a_ = Ap[(s_) * PN_LD2];  \
+    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) bv[nb] = Bp[(s_) * PN_LD1 + nb * 32];
+#define DW2_MMA(a_, bv) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) accW2[nb] = MFMA(a_, bv[nb], accW2[nb]);
+                DW2_LOAD(ap, bvp, 0)
+#pragma unroll 1
+                for (int s = 0; s < ((PN_ABLATE & 32) ? 0 : BT / 2); s += 2) {
+                    DW2_LOAD(aq, bvq, s + 1)
+                    DW2_MMA(ap, bvp)
+                    DW2_LOAD(ap, bvp, s + 2)            // unconditional (last trip reads one row past the half: discarded)
+                    DW2_MMA(aq, bvq)
+                }
+#undef DW2_LOAD
+#undef DW2_MMA
+            }
+            {
+                // ---- dh1 = dz2 * W2 : wave pair q = wave>>1 owns points (q&1)*32.., channels (q>>1)*32..; this wave
+                // accumulates k-groups [kh*16, kh*16+16) of both lane halves, kh = wave&1 -------------------------------
+                const int q = wave >> 1, kh = wave & 1, mb = q & 1, nbk = q >> 1;
+                f32x16 accH[1][1];
+                zero_acc<1, 1>(accH);
+                if (!(PN_ABLATE & 64))
+                    mfma_stream<1, 1, 16>(H2 + (mb * 32 + li) * PN_LD2 + lh * 128 + kh * 64, PN_LD2,
+                                          P2Tv + ((size_t)nbk * 32 + kh * 16) * 64 + lane, accH);
+                // the partner finishes accumulator rows r in [8*(1-kh), +8): hand it this wave's partial sums
+                const int col = nbk * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int rq = r + 8 * (1 - kh);
+                    DZ1[(mb * 32 + (rq & 3) + 8 * (rq >> 2) + 4 * lh) * PN_LD1 + col] = accH[0][0][rq];
+                }
+                __syncthreads();                           // (E)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {              // dz1 = dh1 .* (1 - h1^2) for this wave's 8 rows
+                    const int rq = r + 8 * kh;
+                    const int row = mb * 32 + (rq & 3) + 8 * (rq >> 2) + 4 * lh;
+                    const float h = H1[row * PN_LD1 + col];
+                    // fixed order: k-half 0's partial first
+                    const float other = DZ1[row * PN_LD1 + col];
+                    const float sum = kh ? other + accH[0][0][rq] : accH[0][0][rq] + other;
+                    DZ1[row * PN_LD1 + col] = sum * (1.0f - h * h);
+                }
+            }
+        }
+        __syncthreads();
+        PN_DW1_ACCUM16(Xs0 + ((ntiles - 1) & 1) * BT * PN_MAXC)          // dW1/db1 of the cloud's last tile
+        __syncthreads();
+        *(float4*)(wred + wave * PN_C2 + 4 * lane0) = h2s;
+        __syncthreads();
+        if (tid < PN_C2) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) sum += wred[w2 * PN_C2 + tid];
+            H2sum[(long)b * PN_C2 + tid] = sum * invP;
+        }
+    }
+
+    // ---- write this work-group's partial sums ------------------------------------------------
+    PnBwdPart* part = parts + blockIdx.x;
+    {
+        const int li = lane0 & 31, lh = lane0 >> 5;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int out = w2_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                part->dW2[out * PN_C1 + (w2_n0 + nb) * 32 + li] = accW2[nb][r];
+            }
+    }
+    __syncthreads();
+    *(float4*)(wred + wave * PN_C2 + 4 * lane0) = db2acc;
+    {   // dW1/db1: the 8 point-parts meet in LDS (H2 region: 8*128*9 floats)
+        float* t = H2;
+        const int c = tid & 127, part_i = tid >> 7;
+#pragma unroll
+        for (int d = 0; d < PN_MAXC; ++d) t[(part_i * 128 + c) * (PN_MAXC + 1) + d] = dW1acc[d];
+        t[(part_i * 128 + c) * (PN_MAXC + 1) + PN_MAXC] = db1acc;
+    }
+    __syncthreads();
+    if (tid < PN_C2) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) sum += wred[w2 * PN_C2 + tid];
+        part->db2[tid] = sum;
+    }
+    if (tid < PN_C1) {
+        const float* t = H2;
+#pragma unroll
+        for (int d = 0; d <= PN_MAXC; ++d) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) sum += t[(q * 128 + tid) * (PN_MAXC + 1) + d];
+            if (d < PN_MAXC) part->dW1[tid * PN_MAXC + d] = sum;
+            else part->db1[tid] = sum;
+        }
+    }
+}
+#undef PN_DW1_ACCUM16
+
 // sum the per-work-group partials in fixed order, two stages (68 MB of partials: a single pass with one
 // thread per element and 512 dependent-latency loads took 127 us; 16-way split + final takes ~25 us)
 #define PN_RED_SPLIT 16
@@ -718,6 +1033,17 @@ __global__ __launch_bounds__(256) void pn_dw3_gather_kernel(const float* __restr
 }
 
 static inline int pn_bwd_grid(int B) { return B < PN_BWD_MAXG ? B : PN_BWD_MAXG; }
+static int pn_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        n = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n > PN_BWD_MAXG) n = PN_BWD_MAXG;
+    }
+    return n;
+}
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct PnBwdWs {
@@ -767,7 +1093,18 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
                                     stream);
         if (rc != PM_OK) return rc;
     }
-    const int G = pn_bwd_grid(B);
+    int G = pn_bwd_grid(B);
+    if (PN_BWD16 && h2_saved) {                   // saved layer 2: one 16-wave work-group per CU
+        const int ncu = pn_cu_count();
+        G = B < ncu ? B : ncu;
+#define PN_BWD16_LAUNCH(CT)                                                                                            \
+    hipLaunchKernelGGL((pn_bwd16_kernel<CT>), dim3(G), dim3(1024), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, \
+                       W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, slotmap, parts, h2_saved)
+        if (C == 3) PN_BWD16_LAUNCH(3);
+        else if (C == 4) PN_BWD16_LAUNCH(4);
+        else PN_BWD16_LAUNCH(0);
+#undef PN_BWD16_LAUNCH
+    } else {
 #define PN_BWD_LAUNCH_(CT, SV)                                                                                   \
     hipLaunchKernelGGL((pn_bwd_kernel<CT, SV>), dim3(G), dim3(256), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, \
                        b1, b2, W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, slotmap, parts, h2_saved)
@@ -781,6 +1118,7 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
     else PN_BWD_LAUNCH(0);
 #undef PN_BWD_LAUNCH
 #undef PN_BWD_LAUNCH_
+    }
     const int n = (int)(sizeof(PnBwdPart) / sizeof(float));
     float* red_tmp = (float*)(parts + G);
     hipLaunchKernelGGL(pn_bwd_reduce1_kernel, dim3((n + 255) / 256, PN_RED_SPLIT), dim3(256), 0, pm_stream(stream), parts,
