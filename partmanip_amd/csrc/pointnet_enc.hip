@@ -40,7 +40,8 @@
 #define PN_P2_OFF 0                      // [8][16][64][4]  W2 as fwd B operand
 #define PN_P3_OFF 32768                  // [16][32][64][4] W3 as fwd B operand
 #define PN_P2T_OFF (32768 + 131072)      // [4][32][64][4]  W2 as bwd (dh1 = dz2 * W2) B operand
-#define PN_PACKED_DATA (32768 + 131072 + 32768)
+#define PN_P2T16_OFF (32768 + 131072 + 32768)   // [8][16][64][4] W2 as B operand of the 16x16x4 MFMA (pn_bwd16_kernel's dh1)
+#define PN_PACKED_DATA (32768 + 131072 + 32768 + 32768)
 #define PN_PACKED_ELEMS (PN_PACKED_DATA + 1024)   // + 4 KB tail pad: the operand stream prefetches one group past the end
 
 extern "C" size_t pm_pointnet_packed_elems(void) { return PN_PACKED_ELEMS; }
@@ -60,9 +61,12 @@ __global__ __launch_bounds__(256) void pn_pack_kernel(const float* __restrict__ 
     } else if (i < PN_P2T_OFF) {                           // W3 fwd: half = 128 k, 32 groups
         const int j = i - PN_P3_OFF, s4 = (j >> 8) & 31, nb = j >> 13;
         packed[i] = W3[(nb * 32 + li) * PN_C2 + lh * 128 + s4 * 4 + e];
-    } else {                                               // W2 bwd: B[k=out][j=in], half = 128 k
+    } else if (i < PN_P2T16_OFF) {                         // W2 bwd: B[k=out][j=in], half = 128 k
         const int j = i - PN_P2T_OFF, s4 = (j >> 8) & 31, nb = j >> 13;
         packed[i] = W2[(lh * 128 + s4 * 4 + e) * PN_C1 + nb * 32 + li];
+    } else {                                               // W2 bwd, 16x16x4: lane quarter q owns k in [64q, 64q+64)
+        const int j = i - PN_P2T16_OFF, g = (j >> 8) & 15, nb = j >> 12, l16 = lane & 15, q = lane >> 4;
+        packed[i] = W2[(q * 64 + g * 4 + e) * PN_C1 + nb * 16 + l16];
     }
 }
 
@@ -664,19 +668,25 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
 }
 #undef PN_DW1_ACCUM
 
-// ---- 16-wave variant of the saved-h2 backward: ONE work-group of 1024 threads per CU, 64-point tiles ----
+// ---- 16-wave variant of the saved-h2 backward: ONE work-group of 1024 threads per CU ------------------------
 // The 4-wave kernel above keeps the whole 256x128 dW2 accumulator in 4 waves (128 VGPRs each), which caps a CU at
-// two waves per SIMD and leaves the matrix pipe idle whenever both resident groups are in a VALU / barrier phase
-// (busy 55 %).  Here 16 waves share it (two 32x32 blocks = 32 registers each) and dh1 = dz2 * W2 (64 points x 128
-// channels = 8 blocks) is split over wave PAIRS along K: with the packed k-split layout, k-groups [0,16) and
-// [16,32) of a block are the disjoint halves {0..63, 128..191} / {64..127, 192..255} of K, so each wave streams
-// half of the block's weights and the pair meets in LDS (each finishes 8 of the 16 accumulator rows).  Four waves
-// per SIMD feed the matrix pipe, and the VALU phases (layer 1, row-owner pass, dW1) run 16 waves wide: 4 rows per
-// wave and tile instead of 8, three barriers per 64 points instead of two per 32.
+// two waves per SIMD, and its VALU / memory phases wait for HBM and L2 round trips between barriers.  Here
+//   * 16 waves share the dW2 accumulator (two 32x32 blocks = 32 registers each): four waves per SIMD feed the pipe;
+//   * dh1 = dz2 * W2 (32 points x 128 channels) runs on v_mfma_f32_16x16x4_f32: 16 blocks of 16x16, one per wave,
+//     full K = 256 (no K-split exchange), finished in registers: dz1 = dh1 .* (1 - h1^2) feeds dW1 / db1 directly;
+//   * the H1 / H2 tiles are double-buffered in LDS and the tile loop is software-pipelined by one tile: the memory
+//     requests of tile t+1's VALU stage (saved h2 rows, key run, first W3 row) are issued BEFORE the MFMA stage of
+//     tile t and consumed after it, so their round trips run under the MFMAs.  One barrier per 32-point tile.
+// Measured (2048 clouds): 3.50 -> 3.35 ms with the follow-up kernels; alone: MFMA stage 2.1 ms (ideal 1.75), VALU
+// stage 0.7, per-cloud setup 0.2.  Tried on this skeleton and dropped: splitting the waves into a VALU-first and an
+// MFMA-first half so the two stages overlap inside a SIMD (4.0 ms without / 4.8 ms with the request split: with two
+// waves per SIMD in the MFMA stage its L2 operand stream is no longer covered); 64-point tiles with the VALU
+// results held in registers across the stage (24 VGPRs: spills, 5.6 ms).
 #ifndef PN_BWD16
 #define PN_BWD16 1
 #endif
-#define PN_BT16 64
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 template <int CT>
 __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
     const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
@@ -684,56 +694,37 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
     const float* __restrict__ dfeat, long ldf, const int32_t* __restrict__ argmax, const float* __restrict__ U,
     float* __restrict__ H2sum, float* __restrict__ Hg, int32_t* __restrict__ slotmap, PnBwdPart* __restrict__ parts,
     const float* __restrict__ h2_saved) {
-    constexpr int BT = PN_BT16, NT = 1024, NW = 16, RPW = BT / NW, PARTS = NT / PN_C1, PPT = BT / PARTS;
-    __shared__ __attribute__((aligned(16))) float smem[BT * PN_LD1 * 2 + BT * PN_LD2 + 2 * BT * PN_MAXC + PN_C2 + PN_C3 +
-                                                        PN_C3 + 520 + 32];
-    float* H1 = smem;                                   // [64][132]
-    float* DZ1 = H1 + BT * PN_LD1;                      // [64][132]; end of cloud / kernel: [16][256] wave partials
-    float* H2 = DZ1 + BT * PN_LD1;                      // [64][260]  dz2 (h2 itself only passes through registers)
-    float* Xs0 = H2 + BT * PN_LD2;                      // 2 x [64][8]
-    float* Us = Xs0 + 2 * BT * PN_MAXC;                 // [256]  u[b,:]/P
+    constexpr int BT = 32, NT = 1024, NW = 16, RPW = BT / NW, PPT = BT * PN_C1 / NT;
+    constexpr int NXC = (CT == 3 || CT == 4) ? 4 : PN_MAXC;      // point coordinates that can be non-zero
+    constexpr int XSZ = BT * PN_MAXC, H1SZ = BT * PN_LD1, H2SZ = BT * PN_LD2;
+    __shared__ __attribute__((aligned(16))) float smem[2 * H1SZ + 2 * H2SZ + 3 * XSZ + PN_C2 + PN_C3 + PN_C3 + 1028 + 32];
+    float* H1b = smem;                                  // 2 x [32][132]  h1 of tiles t, t+1
+    float* H2b = H1b + 2 * H1SZ;                        // 2 x [32][260]  dz2 of tiles t, t+1 (h2 only passes through registers);
+                                                        //                end of cloud / kernel: [16][256] wave partial sums
+    float* Xs0 = H2b + 2 * H2SZ;                        // 3 x [32][8]: points of tiles t, t+1, t+2
+    float* Us = Xs0 + 3 * XSZ;                          // [256]  u[b,:]/P
     float* Gm = Us + PN_C2;                             // [512]  dmax[b,:]
     int* keys = (int*)(Gm + PN_C3);                     // [512]  sorted (slot<<22 | point<<9 | channel)
-    unsigned short* offs = (unsigned short*)(keys + PN_C3);   // [P/4+1 <= 1025] first key of each wave's row block
-    double* red = (double*)((float*)(keys + PN_C3) + 520);    // [16]
-    float* wred = DZ1;
+    unsigned short* offs = (unsigned short*)(keys + PN_C3);   // [P/2+1 <= 2049] first key of each wave's row block
+    double* red = (double*)((float*)(keys + PN_C3) + 1028);   // [16]
+    float* wred = H2b;
 
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float4* P2Tv = (const float4*)(packed + PN_P2T_OFF);
+    const float4* P2T16 = (const float4*)(packed + PN_P2T16_OFF);
     const float invP = 1.0f / (float)P;
 
     const int w2_m = wave & 7, w2_n0 = (wave >> 3) * 2;  // dW2[out = w2_m*32 + row][in = (w2_n0 + j)*32 + li]
+    const int hmb = wave & 1, hnb = wave >> 1;           // dh1 block: points hmb*16.., channels hnb*16..
     f32x16 accW2[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accW2[nb][r] = 0.f;
     float4 db2acc = make_float4(0.f, 0.f, 0.f, 0.f);   // columns 4*lane..+3 over this wave's rows
-    float dW1acc[PN_MAXC], db1acc = 0.f;                 // channel tid&127, point part tid>>7
+    float dW1acc[NXC], db1acc = 0.f;                     // channel hnb*16 + (lane&15) over this lane's 4 rows per tile
 #pragma unroll
-    for (int d = 0; d < PN_MAXC; ++d) dW1acc[d] = 0.f;
-
-#define PN_DW1_ACCUM16(XS)                                                       \
-    {                                                                            \
-        const int c_ = tid & 127, p0_ = (tid >> 7) * PPT;                        \
-        _Pragma("unroll 4") for (int p = p0_; p < p0_ + PPT; ++p) {              \
-            const float dz = DZ1[p * PN_LD1 + c_];                               \
-            const float4 x0 = *(const float4*)((XS) + p * PN_MAXC);              \
-            db1acc += dz;                                                        \
-            dW1acc[0] = fmaf(dz, x0.x, dW1acc[0]);                               \
-            dW1acc[1] = fmaf(dz, x0.y, dW1acc[1]);                               \
-            dW1acc[2] = fmaf(dz, x0.z, dW1acc[2]);                               \
-            dW1acc[3] = fmaf(dz, x0.w, dW1acc[3]);                               \
-            if (CT != 3 && CT != 4) {                                            \
-                const float4 x1 = *(const float4*)((XS) + p * PN_MAXC + 4);      \
-                dW1acc[4] = fmaf(dz, x1.x, dW1acc[4]);                           \
-                dW1acc[5] = fmaf(dz, x1.y, dW1acc[5]);                           \
-                dW1acc[6] = fmaf(dz, x1.z, dW1acc[6]);                           \
-                dW1acc[7] = fmaf(dz, x1.w, dW1acc[7]);                           \
-            }                                                                    \
-        }                                                                        \
-    }
+    for (int d = 0; d < NXC; ++d) dW1acc[d] = 0.f;
 
     const int ntiles = P / BT;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -748,7 +739,7 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
             keys[tid] = (argmax[(long)b * PN_C3 + tid] << 9) | tid;
         }
 #pragma unroll 1
-        for (int k = 2; k <= 512; k <<= 1) {             // bitonic sort of the 512 keys by threads 0-255
+        for (int k = 2; k <= ((PN_ABLATE & 16) ? 0 : 512); k <<= 1) {   // bitonic sort of the 512 keys by threads 0-255
 #pragma unroll 1
             for (int j = k >> 1; j > 0; j >>= 1) {
                 __syncthreads();
@@ -803,40 +794,57 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
         }
         float4 h2s = make_float4(0.f, 0.f, 0.f, 0.f);    // sum_p h2[p][4*lane..] over this wave's rows
 
-        stage_points<BT, NT>(xb, 0, C, sub_mean, cen, Xs0);
-        for (int tile = 0; tile < ntiles; ++tile) {
-            int lane = lane0;                              // laundered per tile: recompute addresses, don't hoist
-            asm volatile("" : "+v"(lane));
-            const int li = lane & 31, lh = lane >> 5;
-            float* Xs = Xs0 + (tile & 1) * BT * PN_MAXC;
-            float* Xo = Xs0 + ((tile & 1) ^ 1) * BT * PN_MAXC;
-            // this wave's 4 saved-h2 rows are requested before the barrier: their HBM latency runs under layer 1
-            const float* hsrc = h2_saved + ((long)b * P + tile * BT + wave * RPW) * PN_C2 + 4 * lane;
-            float4 hrows[RPW];
+        // ---- VALU stage of tile tt, in two parts.  valu_issue: everything that waits on HBM / L2 is REQUESTED (this
+        // wave's two saved-h2 rows, its run of sorted keys, the W3 row of the first key); valu_finish: layer 1 -> H1n and
+        // the row-owner pass (wave w owns rows 2w, 2w+1) h2 -> dz2 -> H2n.  The MFMA stage of the previous tile runs
+        // between the two, so the round trips are over when valu_finish starts.
+        float4 hrows[RPW], w_next, u4;
+        int e, e_end, pj, c_next;
+        auto valu_issue = [&](int tt, int tl) __attribute__((always_inline)) {
+            const int lane = tl & 63;
 #pragma unroll
-            for (int rr = 0; rr < RPW; ++rr) hrows[rr] = *(const float4*)(hsrc + rr * PN_C2);
-            __syncthreads();                               // (A) Xs staged; DZ1 of tile t-1 complete; H1/H2 free
-            if (!(PN_ABLATE & 128)) {
-                layer1_tile<CT, BT, NT>(Xs, W1, b1, C, H1);
-                if (tile > 0) PN_DW1_ACCUM16(Xo)
+            for (int rr = 0; rr < RPW; ++rr)
+                hrows[rr] = *(const float4*)(h2_saved + ((long)b * P + tt * BT + wave * RPW + rr) * PN_C2 + 4 * lane);
+            const int p0 = tt * BT + wave * RPW;
+            u4 = *(const float4*)(Us + 4 * lane);
+            e_end = offs[p0 / RPW + 1];
+            e = offs[p0 / RPW];
+            pj = (lane < e_end - e) ? ((keys[e + lane] >> 9) & 0x1FFF) : 0x7FFFFFFF;
+            c_next = 0;
+            w_next = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < e_end) {
+                c_next = keys[e] & 511;
+                w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
             }
-            // ---- row-owner pass: wave w owns rows w*4..w*4+3; h2 -> dz2 (into the LDS tile) ---------------------
-            if (!(PN_ABLATE & 8)) {
-                const int p0 = tile * BT + wave * RPW;
-                const float4 u4 = *(const float4*)(Us + 4 * lane);
-                const int e_end = offs[p0 / RPW + 1];
-                int e = offs[p0 / RPW];
-                const int e0 = e, span = e_end - e0;
-                const int pj = (lane < span) ? ((keys[e0 + lane] >> 9) & 0x1FFF) : 0x7FFFFFFF;
-                int c_next = 0;
-                float4 w_next = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < e_end) {
-                    c_next = keys[e] & 511;
-                    w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
+        };
+        auto valu_finish = [&](int tt, const float* Xs, float* H1n, float* H2n, int tl) __attribute__((always_inline)) {
+            const int lane = tl & 63;
+            if (!(PN_ABLATE & 128)) {
+                const int c = tl & 127, p0 = (tl >> 7) * PPT, CC = (CT == 3 || CT == 4) ? CT : C;
+                const float b1c = b1[c];
+                float w[NXC];
+#pragma unroll
+                for (int d = 0; d < NXC; ++d) w[d] = d < CC ? W1[c * CC + d] : 0.f;
+#pragma unroll
+                for (int i = 0; i < PPT; ++i) {
+                    const float4 xv = *(const float4*)(Xs + (p0 + i) * PN_MAXC);
+                    float sacc = fmaf(w[0], xv.x, b1c);
+                    sacc = fmaf(w[1], xv.y, sacc);
+                    sacc = fmaf(w[2], xv.z, sacc);
+                    if (CT != 3) sacc = fmaf(w[3], xv.w, sacc);
+                    if (CT != 3 && CT != 4) {
+                        const float4 x1 = *(const float4*)(Xs + (p0 + i) * PN_MAXC + 4);
+                        sacc = fmaf(w[4 % NXC], x1.x, sacc); sacc = fmaf(w[5 % NXC], x1.y, sacc);
+                        sacc = fmaf(w[6 % NXC], x1.z, sacc); sacc = fmaf(w[7 % NXC], x1.w, sacc);
+                    }
+                    H1n[(p0 + i) * PN_LD1 + c] = pm_tanh(sacc);
                 }
+            }
+            if (!(PN_ABLATE & 8)) {
+                const int p0 = tt * BT + wave * RPW;
+                const int e0 = e, span = e_end - e0;
 #pragma unroll
                 for (int rr = 0; rr < RPW; ++rr) {
-                    float* hrow = H2 + (wave * RPW + rr) * PN_LD2 + 4 * lane;
                     const float4 h = hrows[rr];
                     h2s.x += h.x; h2s.y += h.y; h2s.z += h.z; h2s.w += h.w;
                     float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -869,16 +877,18 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
                     dz.y = (u4.y + S.y) * (1.0f - h.y * h.y);
                     dz.z = (u4.z + S.z) * (1.0f - h.z * h.z);
                     dz.w = (u4.w + S.w) * (1.0f - h.w * h.w);
-                    *(float4*)hrow = dz;
+                    *(float4*)(H2n + (wave * RPW + rr) * PN_LD2 + 4 * lane) = dz;
                     db2acc.x += dz.x; db2acc.y += dz.y; db2acc.z += dz.z; db2acc.w += dz.w;
                 }
             }
-            __syncthreads();                               // (D) dz2 tile complete
-            if (tile + 1 < ntiles) stage_points<BT, NT>(xb, tile + 1, C, sub_mean, cen, Xo);
-            {
-                // ---- dW2 += dz2^T * h1 : K = 64 points (lanes < 32: point s, lanes >= 32: point 32 + s) ----------
-                const float* Ap = H2 + (lh * (BT / 2)) * PN_LD2 + w2_m * 32 + li;             // A[i=out][k=pt] = dz2[pt][out]
-                const float* Bp = H1 + (lh * (BT / 2)) * PN_LD1 + w2_n0 * 32 + li;            // B[k=pt][j=in] = h1[pt][in]
+        };
+        // ---- MFMA stage of the tile in H1c / H2c (its points in Xs) ------------------------------------------------
+        auto mfma_stage = [&](const float* H1c, const float* H2c, const float* Xs, int tl) __attribute__((always_inline)) {
+            const int lane = tl & 63;
+            {   // dW2 += dz2^T * h1 : K = 32 points (lanes < 32: point s, lanes >= 32: point 16 + s)
+                const int li = lane & 31, lh = lane >> 5;
+                const float* Ap = H2c + (lh * (BT / 2)) * PN_LD2 + w2_m * 32 + li;            // A[i=out][k=pt] = dz2[pt][out]
+                const float* Bp = H1c + (lh * (BT / 2)) * PN_LD1 + w2_n0 * 32 + li;           // B[k=pt][j=in] = h1[pt][in]
                 float ap, bvp[2], aq, bvq[2];
 #define DW2_LOAD(a_, bv, s_) \
     a_ = Ap[(s_) * PN_LD2];  \
@@ -895,38 +905,89 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
 #undef DW2_LOAD
 #undef DW2_MMA
             }
-            {
-                // ---- dh1 = dz2 * W2 : wave pair q = wave>>1 owns points (q&1)*32.., channels (q>>1)*32..; this wave
-                // accumulates k-groups [kh*16, kh*16+16) of both lane halves, kh = wave&1 -------------------------------
-                const int q = wave >> 1, kh = wave & 1, mb = q & 1, nbk = q >> 1;
-                f32x16 accH[1][1];
-                zero_acc<1, 1>(accH);
-                if (!(PN_ABLATE & 64))
-                    mfma_stream<1, 1, 16>(H2 + (mb * 32 + li) * PN_LD2 + lh * 128 + kh * 64, PN_LD2,
-                                          P2Tv + ((size_t)nbk * 32 + kh * 16) * 64 + lane, accH);
-                // the partner finishes accumulator rows r in [8*(1-kh), +8): hand it this wave's partial sums
-                const int col = nbk * 32 + li;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int rq = r + 8 * (1 - kh);
-                    DZ1[(mb * 32 + (rq & 3) + 8 * (rq >> 2) + 4 * lh) * PN_LD1 + col] = accH[0][0][rq];
+            {   // dh1 = dz2 * W2 on 16x16x4: lane (l16 = lane&15, q = lane>>4) holds A[row l16][k = 64q + 4g + e],
+                // B[k][col l16] and the results of rows 4q..4q+3, column l16 of this wave's block
+                const int l16 = lane & 15, q = lane >> 4;
+                const float* Ap = H2c + (hmb * 16 + l16) * PN_LD2 + q * 64;
+                const float4* Bp = P2T16 + (size_t)hnb * 16 * 64 + lane;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                float4 a0 = *(const float4*)Ap, b0 = Bp[0], a1, b1v;
+#define DH_MMA(a_, b_)                    \
+    acc = MFMA16(a_.x, b_.x, acc);        \
+    acc = MFMA16(a_.y, b_.y, acc);        \
+    acc = MFMA16(a_.z, b_.z, acc);        \
+    acc = MFMA16(a_.w, b_.w, acc);
+#pragma unroll 1
+                for (int g = 0; g < ((PN_ABLATE & 64) ? 0 : 16); g += 2) {
+                    a1 = *(const float4*)(Ap + (g + 1) * 4);
+                    b1v = Bp[(size_t)(g + 1) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                    DH_MMA(a0, b0)
+                    __builtin_amdgcn_sched_barrier(0);
+                    a0 = *(const float4*)(Ap + (g + 2) * 4);     // unconditional: one group past the end, discarded
+                    b0 = Bp[(size_t)(g + 2) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                    DH_MMA(a1, b1v)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __syncthreads();                           // (E)
+#undef DH_MMA
+                // dz1 = dh1 .* (1 - h1^2); dW1 / db1 straight from the accumulator registers
+                const int col = hnb * 16 + l16;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {              // dz1 = dh1 .* (1 - h1^2) for this wave's 8 rows
-                    const int rq = r + 8 * kh;
-                    const int row = mb * 32 + (rq & 3) + 8 * (rq >> 2) + 4 * lh;
-                    const float h = H1[row * PN_LD1 + col];
-                    // fixed order: k-half 0's partial first
-                    const float other = DZ1[row * PN_LD1 + col];
-                    const float sum = kh ? other + accH[0][0][rq] : accH[0][0][rq] + other;
-                    DZ1[row * PN_LD1 + col] = sum * (1.0f - h * h);
+                for (int r = 0; r < 4; ++r) {
+                    const int row = hmb * 16 + 4 * q + r;
+                    const float h = H1c[row * PN_LD1 + col];
+                    const float dz = acc[r] * (1.0f - h * h);
+                    const float4 x0 = *(const float4*)(Xs + row * PN_MAXC);
+                    db1acc += dz;
+                    dW1acc[0] = fmaf(dz, x0.x, dW1acc[0]);
+                    dW1acc[1] = fmaf(dz, x0.y, dW1acc[1]);
+                    dW1acc[2] = fmaf(dz, x0.z, dW1acc[2]);
+                    dW1acc[3] = fmaf(dz, x0.w, dW1acc[3]);
+                    if (CT != 3 && CT != 4) {
+                        const float4 x1 = *(const float4*)(Xs + row * PN_MAXC + 4);
+                        dW1acc[4 % NXC] = fmaf(dz, x1.x, dW1acc[4 % NXC]);
+                        dW1acc[5 % NXC] = fmaf(dz, x1.y, dW1acc[5 % NXC]);
+                        dW1acc[6 % NXC] = fmaf(dz, x1.z, dW1acc[6 % NXC]);
+                        dW1acc[7 % NXC] = fmaf(dz, x1.w, dW1acc[7 % NXC]);
+                    }
                 }
             }
+        };
+
+        // ---- pipeline prologue: tile 0 through the VALU stage ----------------------------------------------------
+        stage_points<BT, NT>(xb, 0, C, sub_mean, cen, Xs0);
+        if (ntiles > 1) stage_points<BT, NT>(xb, 1, C, sub_mean, cen, Xs0 + XSZ);
+        __syncthreads();
+        {
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            valu_issue(0, tl);
+            valu_finish(0, Xs0, H1b, H2b, tl);
         }
         __syncthreads();
-        PN_DW1_ACCUM16(Xs0 + ((ntiles - 1) & 1) * BT * PN_MAXC)          // dW1/db1 of the cloud's last tile
-        __syncthreads();
+        int ix = 0;                                        // Xs buffer of tile t (t+1: ix+1, t+2: ix+2, mod 3)
+        for (int tile = 0; tile < ntiles; ++tile) {
+            int tl = tid;                                  // laundered per tile: recompute addresses, don't hoist
+            asm volatile("" : "+v"(tl));                   // (the stages derive lane / channel / point indices from it)
+            const int ix1 = ix == 2 ? 0 : ix + 1, ix2 = ix1 == 2 ? 0 : ix1 + 1, cur = tile & 1;
+            const bool more = tile + 1 < ntiles;
+            // the points of tile t+2 are requested here as well (threads 0-255, one coordinate each) and only stored to
+            // LDS at the end of the interval: a load -> ds_write right before the barrier exposed one HBM round trip
+            // per tile (0.2 ms per launch)
+            float xnext = 0.f;
+            const bool stage2 = tile + 2 < ntiles && tl < XSZ;
+            if (stage2 && (tl & 7) < C) {
+                xnext = xb[((tile + 2) * BT + (tl >> 3)) * C + (tl & 7)];
+                if (sub_mean && (tl & 7) < 3) xnext -= cen[tl & 7];
+            }
+            if (more) valu_issue(tile + 1, tl);
+            mfma_stage(H1b + cur * H1SZ, H2b + cur * H2SZ, Xs0 + ix * XSZ, tl);
+            if (more) valu_finish(tile + 1, Xs0 + ix1 * XSZ, H1b + (cur ^ 1) * H1SZ, H2b + (cur ^ 1) * H2SZ, tl);
+            if (stage2) Xs0[ix2 * XSZ + tl] = xnext;
+            __syncthreads();                               // tile t's buffers are free, tile t+1's complete
+            ix = ix1;
+        }
         *(float4*)(wred + wave * PN_C2 + 4 * lane0) = h2s;
         __syncthreads();
         if (tid < PN_C2) {
@@ -951,12 +1012,12 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
     }
     __syncthreads();
     *(float4*)(wred + wave * PN_C2 + 4 * lane0) = db2acc;
-    {   // dW1/db1: the 8 point-parts meet in LDS (H2 region: 8*128*9 floats)
-        float* t = H2;
-        const int c = tid & 127, part_i = tid >> 7;
+    float* t1 = H2b + NW * PN_C2;                       // dW1/db1: the 8 row subsets (point half, lane quarter) of a channel
+    {                                                   // meet in LDS: [8][128][9] floats behind the wave partials
+        const int c = hnb * 16 + (lane0 & 15), part_i = hmb * 4 + (lane0 >> 4);
 #pragma unroll
-        for (int d = 0; d < PN_MAXC; ++d) t[(part_i * 128 + c) * (PN_MAXC + 1) + d] = dW1acc[d];
-        t[(part_i * 128 + c) * (PN_MAXC + 1) + PN_MAXC] = db1acc;
+        for (int d = 0; d < PN_MAXC; ++d) t1[(part_i * 128 + c) * (PN_MAXC + 1) + d] = d < NXC ? dW1acc[d % NXC] : 0.f;
+        t1[(part_i * 128 + c) * (PN_MAXC + 1) + PN_MAXC] = db1acc;
     }
     __syncthreads();
     if (tid < PN_C2) {
@@ -966,18 +1027,16 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
         part->db2[tid] = sum;
     }
     if (tid < PN_C1) {
-        const float* t = H2;
 #pragma unroll
         for (int d = 0; d <= PN_MAXC; ++d) {
             float sum = 0.f;
 #pragma unroll
-            for (int q = 0; q < PARTS; ++q) sum += t[(q * 128 + tid) * (PN_MAXC + 1) + d];
+            for (int q = 0; q < 8; ++q) sum += t1[(q * 128 + tid) * (PN_MAXC + 1) + d];
             if (d < PN_MAXC) part->dW1[tid * PN_MAXC + d] = sum;
             else part->db1[tid] = sum;
         }
     }
 }
-#undef PN_DW1_ACCUM16
 
 // sum the per-work-group partials in fixed order, two stages (68 MB of partials: a single pass with one
 // thread per element and 512 dependent-latency loads took 127 us; 16-way split + final takes ~25 us)
@@ -1014,17 +1073,47 @@ __global__ __launch_bounds__(256) void pn_bwd_reduce2_kernel(const float* __rest
     } else db1[i - o_db1] = s;
 }
 
-// dW3[c,:] (+)= sum_b dmax[b,c] * Hg[b,c,:] ;  db3[c] = sum_b (dmax[b,c] + dmean[b,c])
+// dW3[c,:] (+)= sum_b dmax[b,c] * Hg[b, slot(b,c), :] ;  db3[c] = sum_b (dmax[b,c] + dmean[b,c])
+// One 1 KB row read per (cloud, channel) = 1 GB for 2048 clouds although only ~250 MB of distinct rows exist (several
+// channels share an arg-max point), so the kernel is laid out for L2 reuse: the clouds are split into PN_DW3_SPLIT
+// ranges with the range index as blockIdx.x -- consecutive work-groups go round-robin to the 8 XCDs, so a range (and
+// its rows) stays on ONE XCD's L2 -- and each work-group handles PN_DW3_CPB channels so that the whole grid is
+// resident at once and the groups of a range walk its clouds together.  Partials are added in fixed order by
+// pn_dw3_finish_kernel.  (One work-group per channel over all clouds: 0.31 ms; this layout: see DESIGN.md 3.2.)
+#define PN_DW3_SPLIT 16
+#define PN_DW3_CPB 4
 __global__ __launch_bounds__(256) void pn_dw3_gather_kernel(const float* __restrict__ dfeat, long ldf, int B,
-                                                             int max_mean, const float* __restrict__ Hg,
+                                                             const float* __restrict__ Hg,
                                                              const int32_t* __restrict__ slotmap,
+                                                             float* __restrict__ tmp) {
+    const int c0 = blockIdx.y * PN_DW3_CPB, k = threadIdx.x;
+    const int per = (B + PN_DW3_SPLIT - 1) / PN_DW3_SPLIT;
+    const int b0 = blockIdx.x * per, b1 = min(B, b0 + per);
+    float acc[PN_DW3_CPB];
+#pragma unroll
+    for (int j = 0; j < PN_DW3_CPB; ++j) acc[j] = 0.f;
+#pragma unroll 4
+    for (int b = b0; b < b1; ++b) {
+        const int4 sl = *(const int4*)(slotmap + (long)b * PN_C3 + c0);
+        const float* gp = dfeat + (long)b * ldf + c0;       // (no alignment assumption on the caller's gradient rows)
+        const float4 g = make_float4(gp[0], gp[1], gp[2], gp[3]);
+        const float* rows = Hg + (long)b * PN_C3 * PN_C2 + k;
+        acc[0] += g.x * rows[(long)sl.x * PN_C2];
+        acc[1] += g.y * rows[(long)sl.y * PN_C2];
+        acc[2] += g.z * rows[(long)sl.z * PN_C2];
+        acc[3] += g.w * rows[(long)sl.w * PN_C2];
+    }
+#pragma unroll
+    for (int j = 0; j < PN_DW3_CPB; ++j) tmp[((size_t)blockIdx.x * PN_C3 + c0 + j) * PN_C2 + k] = acc[j];
+}
+__global__ __launch_bounds__(256) void pn_dw3_finish_kernel(const float* __restrict__ dfeat, long ldf, int B,
+                                                             int max_mean, const float* __restrict__ tmp,
                                                              float* __restrict__ dW3, float* __restrict__ db3) {
     __shared__ float red[4];
     const int c = blockIdx.x, k = threadIdx.x;
     float acc = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < B; ++b)
-        acc += dfeat[(long)b * ldf + c] * Hg[((long)b * PN_C3 + slotmap[(long)b * PN_C3 + c]) * PN_C2 + k];
+#pragma unroll
+    for (int y = 0; y < PN_DW3_SPLIT; ++y) acc += tmp[((size_t)y * PN_C3 + c) * PN_C2 + k];
     dW3[c * PN_C2 + k] = (max_mean ? dW3[c * PN_C2 + k] : 0.f) + acc;
     float s = 0.f;
     for (int b = k; b < B; b += 256) s += dfeat[(long)b * ldf + c] + (max_mean ? dfeat[(long)b * ldf + PN_C3 + c] : 0.f);
@@ -1047,7 +1136,7 @@ static int pn_cu_count() {
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct PnBwdWs {
-    size_t off_U, off_H2sum, off_Hg, off_slot, off_parts, off_gemm, total;
+    size_t off_U, off_H2sum, off_Hg, off_slot, off_parts, off_dw3, off_gemm, total;
 };
 static PnBwdWs pn_bwd_layout(int B) {
     PnBwdWs w;
@@ -1057,6 +1146,7 @@ static PnBwdWs pn_bwd_layout(int B) {
     w.off_Hg = o;     o += align256((size_t)B * PN_C3 * PN_C2 * 4);      // worst case: every channel its own point
     w.off_slot = o;   o += align256((size_t)B * PN_C3 * 4);
     w.off_parts = o;  o += align256((size_t)(pn_bwd_grid(B) + PN_RED_SPLIT) * sizeof(PnBwdPart));
+    w.off_dw3 = o;    o += align256((size_t)PN_DW3_SPLIT * PN_C3 * PN_C2 * 4);
     w.off_gemm = o;   o += align256(pm_linear_bwd_weight_workspace_bytes(B, PN_C3, PN_C2));
     w.total = o;
     return w;
@@ -1130,8 +1220,11 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
                                       ws + w.off_gemm, w.total - w.off_gemm, stream);
         if (rc != PM_OK) return rc;
     }
-    hipLaunchKernelGGL(pn_dw3_gather_kernel, dim3(PN_C3), dim3(256), 0, pm_stream(stream), dfeat, ldf, B, max_mean, Hg,
-                       slotmap, dW3, db3);
+    float* dw3_tmp = (float*)(ws + w.off_dw3);
+    hipLaunchKernelGGL(pn_dw3_gather_kernel, dim3(PN_DW3_SPLIT, PN_C3 / PN_DW3_CPB), dim3(256), 0, pm_stream(stream), dfeat,
+                       ldf, B, Hg, slotmap, dw3_tmp);
+    hipLaunchKernelGGL(pn_dw3_finish_kernel, dim3(PN_C3), dim3(256), 0, pm_stream(stream), dfeat, ldf, B, max_mean,
+                       dw3_tmp, dW3, db3);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
