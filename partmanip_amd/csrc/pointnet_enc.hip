@@ -677,10 +677,10 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
 //   * the H1 / H2 tiles are double-buffered in LDS and the tile loop is software-pipelined by one tile: the memory
 //     requests of tile t+1's VALU stage (saved h2 rows, key run, first W3 row) are issued BEFORE the MFMA stage of
 //     tile t and consumed after it, so their round trips run under the MFMAs.  One barrier per 32-point tile.
-// Measured (2048 clouds): 3.50 -> 3.35 ms with the follow-up kernels; alone: MFMA stage 2.1 ms (ideal 1.75), VALU
-// stage 0.7, per-cloud setup 0.2.  Tried on this skeleton and dropped: splitting the waves into a VALU-first and an
-// MFMA-first half so the two stages overlap inside a SIMD (4.0 ms without / 4.8 ms with the request split: with two
-// waves per SIMD in the MFMA stage its L2 operand stream is no longer covered); 64-point tiles with the VALU
+// Measured (2048 clouds): kernel 3.27 -> 2.95 ms; alone: MFMA stage 2.1 ms (ideal 1.75), VALU stage 0.65, per-cloud
+// setup 0.2.  Tried on this skeleton and dropped: splitting the waves into a VALU-first and an MFMA-first half so
+// the two stages overlap inside a SIMD (three variants, 3.7-4.8 ms: with two waves per SIMD in the MFMA stage its
+// operand streams are no longer covered, and the second code path costs registers); 64-point tiles with the VALU
 // results held in registers across the stage (24 VGPRs: spills, 5.6 ms).
 #ifndef PN_BWD16
 #define PN_BWD16 1
@@ -911,25 +911,29 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
                 const float* Ap = H2c + (hmb * 16 + l16) * PN_LD2 + q * 64;
                 const float4* Bp = P2T16 + (size_t)hnb * 16 * 64 + lane;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                float4 a0 = *(const float4*)Ap, b0 = Bp[0], a1, b1v;
+                // the B stream comes from L2 (~700 clk): four groups in flight (b0..b3); A from LDS: one group ahead
+                float4 a0 = *(const float4*)Ap, a1;
+                float4 b0 = Bp[0], b1v = Bp[64], b2v = Bp[128], b3v = Bp[192];
 #define DH_MMA(a_, b_)                    \
     acc = MFMA16(a_.x, b_.x, acc);        \
     acc = MFMA16(a_.y, b_.y, acc);        \
     acc = MFMA16(a_.z, b_.z, acc);        \
     acc = MFMA16(a_.w, b_.w, acc);
+#define DH_STEP(acur, anext, bcur, g_)                                                        \
+    anext = *(const float4*)(Ap + ((g_) + 1) * 4);                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    DH_MMA(acur, bcur)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    bcur = Bp[(size_t)((g_) + 4) * 64];        /* unconditional: up to 4 groups past the end (next block / tail pad) */ \
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-                for (int g = 0; g < ((PN_ABLATE & 64) ? 0 : 16); g += 2) {
-                    a1 = *(const float4*)(Ap + (g + 1) * 4);
-                    b1v = Bp[(size_t)(g + 1) * 64];
-                    __builtin_amdgcn_sched_barrier(0);
-                    DH_MMA(a0, b0)
-                    __builtin_amdgcn_sched_barrier(0);
-                    a0 = *(const float4*)(Ap + (g + 2) * 4);     // unconditional: one group past the end, discarded
-                    b0 = Bp[(size_t)(g + 2) * 64];
-                    __builtin_amdgcn_sched_barrier(0);
-                    DH_MMA(a1, b1v)
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int g = 0; g < ((PN_ABLATE & 64) ? 0 : 16); g += 4) {
+                    DH_STEP(a0, a1, b0, g)
+                    DH_STEP(a1, a0, b1v, g + 1)
+                    DH_STEP(a0, a1, b2v, g + 2)
+                    DH_STEP(a1, a0, b3v, g + 3)
                 }
+#undef DH_STEP
 #undef DH_MMA
                 // dz1 = dh1 .* (1 - h1^2); dW1 / db1 straight from the accumulator registers
                 const int col = hnb * 16 + l16;
