@@ -41,7 +41,7 @@ extern "C" {
 #define PM_ACT_TANH 1
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 116 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 117 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -295,6 +295,23 @@ int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32_t* idx, co
                   const float* dpooled, long lddp, float* dW1, long lddw1, float* db1, float* dW2, float* db2,
                   float* dW3, float* db3, float* dY, const float* h2_saved /* NULL = recompute layer 2 */,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- rollout side ------------------------------------------------------------------------
+ * algorithms/algo_utils/actor_critic.py:36-47 `random_act_cri` after the two network forwards: x = mu + sigma^2 * eps
+ * (MultivariateNormal(mu, scale_tril = diag(sigma^2)).sample() with the caller's standard-normal eps (B, A), so the
+ * torch RNG stream stays the reference's), logp (B) = its log_prob, actions (B, A) = tanh(x) * max_action (or x),
+ * log_std_rows (B, A) = log_std repeated (may be NULL). */
+int pm_gaussian_sample_f32(const float* mu, long ldmu, const float* log_std, const float* eps, int B, int A,
+                           float max_action, int act_tanh, float* actions, float* logp, float* log_std_rows,
+                           void* stream);
+/* algorithms/algo_utils/RMS.py:10-18 `RunningMeanStd.update(x)` for one (N, D) batch: n_new = the reference's n AFTER
+ * its increment; mean / S / std (D floats each) are updated in place.  RMS.py:40-45 `Normalization.__call__`:
+ * out = (x - mean) / std. */
+size_t pm_rms_update_workspace_bytes(int D);
+int pm_rms_update_f32(const float* x, long ldx, int N, int D, int n_new, float* mean, float* S, float* std,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int pm_rms_normalize_f32(const float* x, long ldx, int N, int D, const float* mean, const float* std, float* out,
+                         long ldo, void* stream);
 
 #ifdef __cplusplus
 }

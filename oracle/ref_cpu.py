@@ -10,7 +10,8 @@ Parity status: PINNED for GAE, PPO update (MLP and PointNet backbones), the
 actor-critic heads, the mini-batch sampler, the DAgger update (MLP, PointNet and
 Conv3DNet students), the `bc` runner, the Conv3DNet module (outputs + parameter
 gradients), `TSDFVolume.depth2pc`'s world cloud, `TSDFVolume.integrate` and
-`TSDFVolume.sparse_voxel` (everything around its pytorch3d call) --
+`TSDFVolume.sparse_voxel` (everything around its pytorch3d call), and the rollout
+side (`Normalization`, `ActorCritic.random_act_cri`) --
 each is checked in tests/test_oracle_golden.py against fixtures produced by
 running the reference itself (tests/golden/make_golden.py).  The point-set operators
 at the bottom (farthest point sampling, ball query, grouping, PointNet++ set
@@ -452,6 +453,26 @@ class RunningMeanStd:
         self.mean = old + (new - old) / self.n
         self.S = self.S + (x - new).pow(2).mean(dim=0, keepdim=True) + (old - new).pow(2) * (self.n - 1) / self.n
         self.std = torch.sqrt(self.S / self.n)
+
+
+    def normalize(self, x, update=True):
+        """RMS.py:40-45 `Normalization.__call__`."""
+        if update:
+            self.update(x)
+        return (x - self.mean) / self.std
+
+
+def random_act_cri(p, model_cfg, obs, eps, proprio_shape=0):
+    """actor_critic.py:36-47: `MultivariateNormal(mu, scale_tril=diag(exp(log_std)^2)).sample()` = mu + sigma^2 * eps
+    with the standard-normal draw `eps` passed in; returns (squashed actions, log_prob of the raw sample, value, mu,
+    log_std rows)."""
+    mu = net_forward(p, "actor", model_cfg["network"], obs, proprio_shape)
+    sig2 = p["log_std"].exp() * p["log_std"].exp()
+    x = mu + sig2 * eps
+    logp, _ = gaussian_logp_entropy(mu, p["log_std"], x)
+    value = net_forward(p, "critic", model_cfg["network"], obs, proprio_shape)
+    return (action_activation(x, model_cfg["action_activate"], model_cfg["clipAction"]), logp, value, mu,
+            p["log_std"].repeat(mu.shape[0], 1))
 
 
 # =============================================================================

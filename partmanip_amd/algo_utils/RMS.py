@@ -1,7 +1,9 @@
 """Running observation statistics with the reference's interface
 (algorithms/algo_utils/RMS.py:3-56: `Normalization(shape, device)(x, update)`,
-`running_ms.{mean,std,S,n}`, `save()/load()`).  Rollout side and tiny -- tensor plumbing,
-outside the kernel scope."""
+`running_ms.{mean,std,S,n}`, `save()/load()`).  Rollout side: on a GPU
+device the batch moments and the normalisation run in pm_rms_update_f32 / pm_rms_normalize_f32
+(one read of the batch for the update, one read + one write to normalise); a CPU device keeps
+the reference's tensor expressions (checkpoint tooling, CPU tests of the host logic)."""
 import torch
 
 _KEYS = ("mean", "std", "S", "n")
@@ -17,8 +19,22 @@ class RunningMeanStd:
         self.S = torch.full((1, shape), 1e-4, device=device)
         self.std = self.S.sqrt()
 
+    def _hip(self, x):
+        return x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+
     def update(self, x):
         self.n += 1
+        if self._hip(x):
+            from .. import ops
+            if getattr(self, "_ws", None) is None:
+                self._ws = ops.Workspace(x.device)
+            # state tensors may have been replaced by load(): keep them fp32, contiguous and on the batch's device
+            for k in ("mean", "S", "std"):
+                t = getattr(self, k)
+                if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                    setattr(self, k, t.to(device=x.device, dtype=torch.float32).contiguous())
+            ops.rms_update(x, self.n, self.mean, self.S, self.std, self._ws)
+            return
         prev = self.mean.clone()
         cur = x.mean(dim=0, keepdim=True)
         within = (x - cur).pow(2).mean(dim=0, keepdim=True)
@@ -43,6 +59,9 @@ class Normalization:
         rms = self.running_ms
         if update:
             rms.update(x)
+        if rms._hip(x) and rms.mean.is_cuda:
+            from .. import ops
+            return ops.rms_normalize(x, rms.mean.contiguous(), rms.std.contiguous())
         return (x - rms.mean) / rms.std
 
 

@@ -101,17 +101,17 @@ class ActorCritic(nn.Module):
         mu = self.actor(observations)
         # MultivariateNormal(loc, scale_tril=diag(sigma^2)).sample(): loc + sigma^2 * eps
         eps = torch.normal(torch.zeros_like(mu), torch.ones_like(mu))
-        actions = mu + self._sigma2() * eps
-        logp, _ = self._logp_entropy(mu, actions, squashed=False)
+        actions, logp, log_std_rows = ops.gaussian_sample(mu, self.log_std.data, eps, self.max_action,
+                                                          self.action_activate == 'tanh')
         value = self.critic(observations)
-        return (self.action_activation(actions), logp, value, mu,
-                self.log_std.data.repeat(mu.shape[0], 1))
+        return actions, logp, value, mu, log_std_rows
 
     def random_act(self, observations):
         self.flat()
         mu = self.actor(observations)
         eps = torch.normal(torch.zeros_like(mu), torch.ones_like(mu))
-        return self.action_activation(mu + self._sigma2() * eps)
+        return ops.gaussian_sample(mu, self.log_std.data, eps, self.max_action, self.action_activate == 'tanh',
+                                   want_log_std_rows=False)[0]
 
     def act(self, observations):
         self.flat()

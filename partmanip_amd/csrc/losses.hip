@@ -339,3 +339,121 @@ extern "C" int pm_ppo_accumulate_stats_f32(float* acc, const float* scal, int wh
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
+
+// ---------------------------------------------------------------------------------- rollout side
+// actor_critic.py:36-47 `random_act_cri` after the two network forwards, in one launch: the sample of
+// MultivariateNormal(mu, scale_tril = diag(sigma^2)) from caller-provided standard-normal noise (so the global torch
+// RNG stream stays the reference's), its log-prob, and the squashed action that goes to the simulator.
+__global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* __restrict__ mu, long ldmu,
+                                                               const float* __restrict__ log_std,
+                                                               const float* __restrict__ eps, int B, int A,
+                                                               float max_action, int act_tanh,
+                                                               float* __restrict__ actions, float* __restrict__ logp,
+                                                               float* __restrict__ log_std_rows) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    float M = 0.f, sum_logs = 0.f;
+    for (int a = 0; a < A; ++a) {
+        const float e = expf(log_std[a]);
+        const float s = e * e;
+        sum_logs += logf(s);
+        const float m = mu[i * ldmu + a];
+        const float x = add_rn(m, mul_rn(s, eps[(long)i * A + a]));     // loc + scale_tril @ eps, op by op
+        const float z = (x - m) / s;
+        M += z * z;
+        actions[(long)i * A + a] = act_tanh ? pm_tanh(x) * max_action : x;
+        if (log_std_rows) log_std_rows[(long)i * A + a] = log_std[a];
+    }
+    logp[i] = -0.5f * ((float)A * 1.8378770664093453f + M) - sum_logs;
+}
+
+extern "C" int pm_gaussian_sample_f32(const float* mu, long ldmu, const float* log_std, const float* eps, int B, int A,
+                                      float max_action, int act_tanh, float* actions, float* logp, float* log_std_rows,
+                                      void* stream) {
+    PM_REQUIRE(mu && log_std && eps && actions && logp && B > 0 && A > 0 && ldmu >= A && max_action > 0.f);
+    hipLaunchKernelGGL(gaussian_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, pm_stream(stream), mu, ldmu, log_std,
+                       eps, B, A, max_action, act_tanh, actions, logp, log_std_rows);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// RMS.py:10-18 `RunningMeanStd.update` + RMS.py:40-45 `Normalization.__call__`: one read of the (N, D) observation
+// batch for the column moments (fp64 sums over row slabs, fixed-order finish), one read + one write for the
+// normalisation -- HBM-bound; the torch expression makes five passes and three (N, D) temporaries.
+#define RMS_ROWSPLIT 64
+__global__ __launch_bounds__(256) void rms_partial_kernel(const float* __restrict__ x, long ldx, int N, int D,
+                                                           double* __restrict__ part) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= D) return;
+    const int per = (N + RMS_ROWSPLIT - 1) / RMS_ROWSPLIT;
+    const int r0 = blockIdx.y * per, r1 = min(N, r0 + per);
+    double s = 0.0, q = 0.0;
+#pragma unroll 4
+    for (int r = r0; r < r1; ++r) {
+        const double v = (double)x[(long)r * ldx + col];
+        s += v;
+        q += v * v;
+    }
+    part[((size_t)blockIdx.y * D + col) * 2] = s;
+    part[((size_t)blockIdx.y * D + col) * 2 + 1] = q;
+}
+__global__ __launch_bounds__(256) void rms_finish_kernel(const double* __restrict__ part, int N, int D, int n_new,
+                                                          float* __restrict__ mean, float* __restrict__ S,
+                                                          float* __restrict__ stdv) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= D) return;
+    double s = 0.0, q = 0.0;
+    for (int y = 0; y < RMS_ROWSPLIT; ++y) {
+        s += part[((size_t)y * D + col) * 2];
+        q += part[((size_t)y * D + col) * 2 + 1];
+    }
+    const double m64 = s / (double)N;
+    double w64 = q / (double)N - m64 * m64;             // mean((x - cur)^2), exact to fp64 round-off
+    if (w64 < 0.0) w64 = 0.0;
+    const float cur = (float)m64, within = (float)w64, prev = mean[col], n = (float)n_new;
+    const float d = prev - cur;
+    const float between = d * d * (float)(n_new - 1) / n;               // RMS.py:16, left to right
+    mean[col] = prev + (cur - prev) / n;                                // RMS.py:15
+    const float Sn = S[col] + within + between;
+    S[col] = Sn;
+    stdv[col] = sqrtf(Sn / n);                                          // RMS.py:17
+}
+__global__ __launch_bounds__(256) void rms_normalize_kernel(const float* __restrict__ x, long ldx, int N, int D,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ stdv, float* __restrict__ out,
+                                                             long ldo) {
+    const long total = (long)N * D;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / D;
+        const int c = (int)(e - r * D);
+        out[r * ldo + c] = (x[r * ldx + c] - mean[c]) / stdv[c];        // RMS.py:44 (a true division, as the reference)
+    }
+}
+
+extern "C" size_t pm_rms_update_workspace_bytes(int D) { return D > 0 ? (size_t)RMS_ROWSPLIT * D * 2 * sizeof(double) : 0; }
+
+extern "C" int pm_rms_update_f32(const float* x, long ldx, int N, int D, int n_new, float* mean, float* S, float* stdv,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(x && mean && S && stdv && N > 0 && D > 0 && ldx >= D && n_new >= 1);
+    if (!workspace || workspace_bytes < pm_rms_update_workspace_bytes(D)) return PM_EWORKSPACE;
+    if (((uintptr_t)workspace & 7) != 0) return PM_EALIGN;
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL(rms_partial_kernel, dim3((D + 255) / 256, RMS_ROWSPLIT), dim3(256), 0, pm_stream(stream), x, ldx, N,
+                       D, part);
+    hipLaunchKernelGGL(rms_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, pm_stream(stream), part, N, D, n_new, mean,
+                       S, stdv);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_rms_normalize_f32(const float* x, long ldx, int N, int D, const float* mean, const float* stdv,
+                                    float* out, long ldo, void* stream) {
+    PM_REQUIRE(x && mean && stdv && out && N > 0 && D > 0 && ldx >= D && ldo >= D);
+    const long total = (long)N * D;
+    long nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(rms_normalize_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), x, ldx, N, D, mean, stdv,
+                       out, ldo);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}

@@ -512,3 +512,35 @@ def tsdf_sparse_voxel(vol, K, lo, hi, ws):
     check(lib.pm_tsdf_sparse_gather_f32(_ptr(coords), _ptr(idx), _ptr(vol), B, res, K, _ptr(out), _stream()),
           "pm_tsdf_sparse_gather_f32")
     return out
+
+
+def gaussian_sample(mu, log_std, eps, max_action, act_tanh, want_log_std_rows=True):
+    """actor_critic.py:36-47 after the forwards: -> (squashed actions (B, A), logp (B,), log_std rows (B, A))."""
+    _req(mu, log_std, eps)
+    _f32c(eps, "eps")
+    B, A = mu.shape
+    actions = torch.empty(B, A, dtype=torch.float32, device=mu.device)
+    logp = torch.empty(B, dtype=torch.float32, device=mu.device)
+    rows = torch.empty(B, A, dtype=torch.float32, device=mu.device) if want_log_std_rows else None
+    check(lib.pm_gaussian_sample_f32(_ptr(mu), _rows(mu, "mu"), _ptr(log_std), _ptr(eps), B, A, float(max_action),
+                                     int(act_tanh), _ptr(actions), _ptr(logp), _ptr(rows), _stream()),
+          "pm_gaussian_sample_f32")
+    return actions, logp, rows
+
+
+def rms_update(x, n_new, mean, S, std, ws):
+    """RMS.py:10-18 for one (N, D) batch; mean / S / std ((1, D) fp32, contiguous) are updated in place."""
+    _req(x, mean, S, std)
+    N, D = x.shape
+    w = ws.get(lib.pm_rms_update_workspace_bytes(D))
+    check(lib.pm_rms_update_f32(_ptr(x), _rows(x, "x"), N, D, int(n_new), _ptr(mean), _ptr(S), _ptr(std), _ptr(w),
+                                w.numel(), _stream()), "pm_rms_update_f32")
+
+
+def rms_normalize(x, mean, std):
+    _req(x, mean, std)
+    N, D = x.shape
+    out = torch.empty(N, D, dtype=torch.float32, device=x.device)
+    check(lib.pm_rms_normalize_f32(_ptr(x), _rows(x, "x"), N, D, _ptr(mean), _ptr(std), _ptr(out), D, _stream()),
+          "pm_rms_normalize_f32")
+    return out

@@ -53,6 +53,9 @@ PPO_CASES = {
     "ppo_pn_max":      _ppo(_PN_NET_MAX, 4, 4, 3072, 2, 2, TRICKS_ALLON, seed=108, lr=2e-4, old_noise=0.02),
 }
 
+# rollout side: Normalization over three (N, O) batches; random_act_cri of an MLP actor-critic (actor_critic.py:36-47)
+ROLLOUT_CASE = dict(N=37, O=19, A=6, seed=401, torch_seed=4242, action_std=0.7, max_action=1.5, net=_MLP_NET)
+
 DAGGER_CASES = {
     # student MLP on a 40-d obs, teacher MLP on a 32-d state
     "dagger_mlp": dict(stu_net=_MLP_NET, tea_net=_MLP_NET, N=8, buf_size=6, n_fill=8, O_s=40, O_t=32,

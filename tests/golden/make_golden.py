@@ -350,11 +350,42 @@ def gen_depth2pc(cases):
               "band voxels", ((tsdf < 0.2) & (tsdf > -0.2)).reshape(tsdf.shape[0], -1).sum(-1))
 
 
+def gen_rollout(ref_algos, cases):
+    """Rollout side, by the reference's own classes: `Normalization` (RMS.py:36-45) fed three
+    observation batches, and `ActorCritic.random_act_cri` (actor_critic.py:36-47) under a fixed torch seed -- with the
+    standard-normal draw `MultivariateNormal.sample` consumes recorded next to its outputs."""
+    from algorithms.algo_utils import Normalization, ActorCritic
+    from tests.golden.detgen import det_uniform, det_normal
+    c = cases.ROLLOUT_CASE
+    N, O, A = c["N"], c["O"], c["A"]
+    norm = Normalization(O, "cpu")
+    outs, stats = [], []
+    for i in range(3):
+        x = torch.from_numpy((det_normal((N, O), c["seed"] + i) * (1.0 + 0.5 * i) + det_uniform((1, O), c["seed"] + 9, -2, 2))
+                             .astype(np.float32))
+        outs.append(norm(x).numpy().copy())
+        stats.append(np.stack([norm.running_ms.mean.numpy()[0], norm.running_ms.std.numpy()[0], norm.running_ms.S.numpy()[0]]))
+    frozen = norm(x, update=False).numpy().copy()                     # Normalization(x, update=False): eval path
+    ac = ActorCritic(O, A, dict(action_std=c["action_std"], action_activate="tanh", clipAction=c["max_action"],
+                                network=c["net"]))
+    load_sd(ac, cases.actor_critic_state(c["net"], O, A, c["action_std"], c["seed"]))
+    obs = torch.from_numpy(det_normal((N, O), c["seed"] + 20).astype(np.float32))
+    torch.manual_seed(c["torch_seed"])
+    with torch.no_grad():
+        act, logp, val, mu, ls = ac.random_act_cri(obs)
+    torch.manual_seed(c["torch_seed"])
+    eps = torch.normal(torch.zeros(N, A), torch.ones(N, A))
+    np.savez_compressed(os.path.join(HERE, "rollout_side.npz"), norm_out=np.stack(outs), norm_stats=np.stack(stats),
+                        norm_frozen=frozen, n=np.int64(norm.running_ms.n), actions=act.numpy(), logp=logp.numpy(),
+                        value=val.numpy(), mu=mu.numpy(), log_std_rows=ls.numpy(), eps=eps.numpy())
+    print("wrote rollout_side", "n", norm.running_ms.n, "std range", float(stats[-1][1].min()), float(stats[-1][1].max()))
+
+
 def main():
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
     from tests.golden import cases
-    which = sys.argv[1:] or ["gae", "ppo", "dagger", "depth2pc", "bc", "conv3d"]
+    which = sys.argv[1:] or ["gae", "ppo", "dagger", "depth2pc", "bc", "conv3d", "rollout"]
     if "depth2pc" in which:
         gen_depth2pc(cases)
         which = [w for w in which if w != "depth2pc"]
@@ -371,6 +402,8 @@ def main():
         gen_bc(ref, cases)
     if "conv3d" in which:
         gen_conv3d(ref, cases)
+    if "rollout" in which:
+        gen_rollout(ref, cases)
 
 
 if __name__ == "__main__":

@@ -607,3 +607,64 @@ def test_ppo_update_bf16x3_forward_within_reference_tolerances(name):
         np.testing.assert_allclose(float(log["Train/" + k]), float(fx["log_" + k]), rtol=5e-4, atol=5e-6, err_msg=k)
     check_params(flat_state(run.actor_critic.state_dict()), fx["final_flat"], int(fx["final_stride"]), c["lr"],
                  len(fx["loss_trace"]))
+
+
+# ------------------------------------------------------------------------------- rollout side
+def test_rollout_side_matches_reference():
+    """`Normalization` (pm_rms_update_f32 / pm_rms_normalize_f32) and `ActorCritic.random_act_cri`
+    (pm_gaussian_sample_f32) against the REFERENCE's own outputs (rollout_side.npz): running statistics to fp32
+    round-off of the batch moments (fp64 sums here, torch's fp32 pairwise sums there), everything downstream to match."""
+    from tests.test_oracle_golden import _rollout_inputs
+    from partmanip_amd.algo_utils import Normalization, ActorCritic
+    c, xs, obs = _rollout_inputs()
+    fx = load_fixture("rollout_side")
+    norm = Normalization(c["O"], DEV)
+    for i, x in enumerate(xs):
+        out = norm(t(x).to(DEV))
+        st = np.stack([norm.running_ms.mean.cpu().numpy()[0], norm.running_ms.std.cpu().numpy()[0],
+                       norm.running_ms.S.cpu().numpy()[0]])
+        np.testing.assert_allclose(st, fx["norm_stats"][i], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(out.cpu().numpy(), fx["norm_out"][i], rtol=1e-5, atol=5e-6)
+    assert norm.running_ms.n == int(fx["n"]) and tuple(norm.running_ms.mean.shape) == (1, c["O"])
+    np.testing.assert_allclose(norm(t(xs[2]).to(DEV), update=False).cpu().numpy(), fx["norm_frozen"], rtol=1e-5, atol=5e-6)
+    assert norm.running_ms.n == int(fx["n"])                       # update=False leaves the statistics alone
+    # save() / load() round trip keeps the kernels usable (RMS.py:20-34)
+    norm2 = Normalization(c["O"], DEV)
+    norm2.running_ms.load({k: (v.clone() if torch.is_tensor(v) else v) for k, v in norm.running_ms.save().items()})
+    assert torch.equal(norm2(t(xs[1]).to(DEV), update=False), norm(t(xs[1]).to(DEV), update=False))
+
+    ac = ActorCritic(c["O"], c["A"], dict(action_std=c["action_std"], action_activate="tanh", clipAction=c["max_action"],
+                                          network=dict(c["net"]))).to(DEV)
+    ac.load_state_dict({k: t(v.copy()) for k, v in
+                        cases.actor_critic_state(c["net"], c["O"], c["A"], c["action_std"], c["seed"]).items()})
+    torch.manual_seed(c["torch_seed"])
+    # the reference draws on the CPU generator; the same draw is injected so that every output is comparable
+    real_normal = torch.normal
+    try:
+        torch.normal = lambda *a, **k: t(fx["eps"]).to(DEV)
+        act, logp, val, mu, ls = ac.random_act_cri(t(obs).to(DEV))
+        act_only = ac.random_act(t(obs).to(DEV))
+    finally:
+        torch.normal = real_normal
+    np.testing.assert_allclose(mu.cpu().numpy(), fx["mu"], rtol=2e-5, atol=3e-6)
+    np.testing.assert_allclose(val.cpu().numpy(), fx["value"], rtol=2e-5, atol=3e-6)
+    np.testing.assert_allclose(act.cpu().numpy(), fx["actions"], rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), fx["logp"], rtol=3e-5, atol=3e-4)
+    assert np.array_equal(ls.cpu().numpy(), fx["log_std_rows"])
+    assert torch.equal(act_only, act)
+
+
+@pytest.mark.parametrize("N,D", [(4096, 3072), (4096, 53), (1, 7), (333, 1000)])
+def test_rms_kernels_against_restatement(N, D):
+    """Observation-sized batches (4096 envs x 3072-d clouds / 53-d states), one row, ragged sizes: three updates with a
+    drifting mean against the CPU restatement."""
+    from partmanip_amd.algo_utils import Normalization
+    g = torch.Generator().manual_seed(N + D)
+    norm, ref = Normalization(D, DEV), R.RunningMeanStd(D)
+    for i in range(3):
+        x = torch.randn(N, D, generator=g) * (0.5 + i) + 3.0 * i + torch.linspace(-5, 5, D)
+        out = norm(x.to(DEV))
+        want = ref.normalize(x)
+        np.testing.assert_allclose(norm.running_ms.mean.cpu().numpy(), ref.mean.numpy(), rtol=3e-6, atol=3e-6)
+        np.testing.assert_allclose(norm.running_ms.S.cpu().numpy(), ref.S.numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=3e-5, atol=3e-5)

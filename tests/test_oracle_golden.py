@@ -222,3 +222,36 @@ def test_sparse_voxel_restatement_matches_reference():
     for b in range(2):                                               # padding rows read voxel (0,0,0)
         assert np.array_equal(out[b, n_band[b]:, :3], np.zeros((1024 - n_band[b], 3), np.float32))
         assert (out[b, n_band[b]:, 3] == fx["tsdf"][b, 0, 0, 0]).all()
+
+
+def _rollout_inputs():
+    from tests.golden.detgen import det_uniform, det_normal
+    c = cases.ROLLOUT_CASE
+    xs = [(det_normal((c["N"], c["O"]), c["seed"] + i) * (1.0 + 0.5 * i) + det_uniform((1, c["O"]), c["seed"] + 9, -2, 2))
+          .astype(np.float32) for i in range(3)]
+    obs = det_normal((c["N"], c["O"]), c["seed"] + 20).astype(np.float32)
+    return c, xs, obs
+
+
+def test_rollout_side_restatement_matches_reference():
+    """RMS.py:10-18,40-45 and actor_critic.py:36-47 run by the reference's own `Normalization` / `ActorCritic`
+    (make_golden.gen_rollout): running statistics after each of three batches, the normalised batches, the frozen
+    (update=False) call, and `random_act_cri` with the recorded standard-normal draw."""
+    c, xs, obs = _rollout_inputs()
+    fx = load_fixture("rollout_side")
+    rms = R.RunningMeanStd(c["O"])
+    for i, x in enumerate(xs):
+        out = rms.normalize(t(x))
+        assert np.array_equal(out.numpy(), fx["norm_out"][i])
+        assert np.array_equal(np.stack([rms.mean.numpy()[0], rms.std.numpy()[0], rms.S.numpy()[0]]), fx["norm_stats"][i])
+    assert rms.n == int(fx["n"])
+    assert np.array_equal(rms.normalize(t(xs[2]), update=False).numpy(), fx["norm_frozen"])
+    p = state_dict_t(cases.actor_critic_state(c["net"], c["O"], c["A"], c["action_std"], c["seed"]))
+    model = dict(action_std=c["action_std"], action_activate="tanh", clipAction=c["max_action"], network=dict(c["net"]))
+    with torch.no_grad():
+        act, logp, val, mu, ls = R.random_act_cri(p, model, t(obs), t(fx["eps"]))
+    np.testing.assert_allclose(mu.numpy(), fx["mu"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(val.numpy(), fx["value"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(act.numpy(), fx["actions"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(logp.numpy(), fx["logp"], rtol=2e-5, atol=1e-4)
+    assert np.array_equal(ls.numpy(), fx["log_std_rows"])
