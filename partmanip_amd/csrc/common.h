@@ -61,22 +61,63 @@ __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, 
 __device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
 
 // ---- tanh -------------------------------------------------------------------------------
-// Branch-free fp32 tanh, ~17 VALU ops (2 transcendental) instead of ocml tanhf's ~100 with
-// divergent branches -- the encoder evaluates 384 tanh per point, so this is hot.
-//   |x| <  0.35 : odd Taylor polynomial through x^13 (truncation < 1e-9 relative)
-//   |x| >= 0.35 : 1 - 2/(exp(2|x|)+1) on v_exp_f32 / v_rcp_f32 (<= ~4 ulp; -> 1 for large |x|)
-// Max observed error vs fp64 tanh: see tests/test_gpu_kernels.py::test_fast_tanh_accuracy.
+// fp32 tanh as the odd rational x * P(x^2) / Q(x^2) (degree 13 / 6 minimax, the coefficients of Eigen's float
+// tanh), |x| clamped to 7.905 where it rounds to 1: branch-free, one transcendental (v_rcp_f32 + one Newton
+// step), <= ~5 ulp against fp64 tanh everywhere incl. denormal inputs (tests/test_gpu_kernels.py::
+// test_fast_tanh_accuracy) -- ocml tanhf is ~100 instructions with divergent branches, and the encoder evaluates
+// 384 tanh per point.  On gfx950 fp32 MFMA and VALU instructions of different waves do NOT overlap on a SIMD
+// (tools/ubench/mfma_valu_overlap.hip: two MFMA waves + two VALU waves take the SUM of their times), so every VALU
+// slot here is paid for in MFMA time.  pm_tanh2 evaluates two values on the packed-fp32 pipe (v_pk_fma_f32 /
+// v_pk_mul_f32: 14 packed + 2 clamp + 2 rcp instructions per pair = 12 issue slots per value with v_rcp at quarter
+// rate; the previous exp2/rcp + Taylor-seam version cost ~22).  Both forms round identically (same fma chain).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define PM_TANH_CLAMP 7.90531110763549805f
+#define PM_TANH_A13 -2.76076847742355e-16f
+#define PM_TANH_A11 2.00018790482477e-13f
+#define PM_TANH_A9 -8.60467152213735e-11f
+#define PM_TANH_A7 5.12229709037114e-08f
+#define PM_TANH_A5 1.48572235717979e-05f
+#define PM_TANH_A3 6.37261928875436e-04f
+#define PM_TANH_A1 4.89352455891786e-03f
+#define PM_TANH_B6 1.19825839466702e-06f
+#define PM_TANH_B4 1.18534705686654e-04f
+#define PM_TANH_B2 2.26843463243900e-03f
+#define PM_TANH_B0 4.89352518554385e-03f
 __device__ __forceinline__ float pm_tanh(float x) {
-    const float ax = fabsf(x);
-    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);      // exp(2|x|)
-    const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
-    const float x2 = ax * ax;
-    float p = 0.0035921280365724810f;                                        // 21844/6081075
-    p = fmaf(p, x2, -0.0088632355299021966f);                                // -1382/155925
-    p = fmaf(p, x2, 0.021869488536155203f);                                  // 62/2835
-    p = fmaf(p, x2, -0.053968253968253971f);                                 // -17/315
-    p = fmaf(p, x2, 0.13333333333333333f);                                   // 2/15
-    p = fmaf(p, x2, -0.33333333333333331f);                                  // -1/3
-    const float small = fmaf(ax * x2, p, ax);
-    return copysignf(ax < 0.35f ? small : big, x);
+    x = __builtin_amdgcn_fmed3f(x, -PM_TANH_CLAMP, PM_TANH_CLAMP);
+    const float x2 = x * x;
+    float p = fmaf(PM_TANH_A13, x2, PM_TANH_A11);
+    p = fmaf(p, x2, PM_TANH_A9);
+    p = fmaf(p, x2, PM_TANH_A7);
+    p = fmaf(p, x2, PM_TANH_A5);
+    p = fmaf(p, x2, PM_TANH_A3);
+    p = fmaf(p, x2, PM_TANH_A1);
+    float q = fmaf(PM_TANH_B6, x2, PM_TANH_B4);
+    q = fmaf(q, x2, PM_TANH_B2);
+    q = fmaf(q, x2, PM_TANH_B0);
+    float r = __builtin_amdgcn_rcpf(q);
+    r = fmaf(fmaf(-q, r, 1.0f), r, r);                     // one Newton step: 1/q to ~0.5 ulp
+    return x * (p * r);                                     // P/Q ~ 1 first, then times x: no denormal intermediates
 }
+__device__ __forceinline__ f32x2 pm_tanh2(f32x2 x) {
+#define PM_S2(v) ((f32x2){(v), (v)})
+    x.x = __builtin_amdgcn_fmed3f(x.x, -PM_TANH_CLAMP, PM_TANH_CLAMP);
+    x.y = __builtin_amdgcn_fmed3f(x.y, -PM_TANH_CLAMP, PM_TANH_CLAMP);
+    const f32x2 x2 = x * x;
+    f32x2 p = __builtin_elementwise_fma(PM_S2(PM_TANH_A13), x2, PM_S2(PM_TANH_A11));
+    p = __builtin_elementwise_fma(p, x2, PM_S2(PM_TANH_A9));
+    p = __builtin_elementwise_fma(p, x2, PM_S2(PM_TANH_A7));
+    p = __builtin_elementwise_fma(p, x2, PM_S2(PM_TANH_A5));
+    p = __builtin_elementwise_fma(p, x2, PM_S2(PM_TANH_A3));
+    p = __builtin_elementwise_fma(p, x2, PM_S2(PM_TANH_A1));
+    f32x2 q = __builtin_elementwise_fma(PM_S2(PM_TANH_B6), x2, PM_S2(PM_TANH_B4));
+    q = __builtin_elementwise_fma(q, x2, PM_S2(PM_TANH_B2));
+    q = __builtin_elementwise_fma(q, x2, PM_S2(PM_TANH_B0));
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(q.x);
+    r.y = __builtin_amdgcn_rcpf(q.y);
+    r = __builtin_elementwise_fma(__builtin_elementwise_fma(-q, r, PM_S2(1.0f)), r, r);
+    return x * (p * r);
+#undef PM_S2
+}
+__device__ __forceinline__ f32x2 pm_tanh2(float a, float b) { return pm_tanh2((f32x2){a, b}); }

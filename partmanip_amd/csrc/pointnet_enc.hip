@@ -124,14 +124,22 @@ __device__ __forceinline__ void layer1_tile(const float* __restrict__ Xs, const 
         float w[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) w[d] = (d < CT) ? W1[c * CT + d] : 0.f;
-#pragma unroll 8
-        for (int p = p0; p < p0 + PPT; ++p) {
-            const float4 xv = *(const float4*)(Xs + p * PN_MAXC);
-            float s = fmaf(w[0], xv.x, b1c);
-            s = fmaf(w[1], xv.y, s);
-            s = fmaf(w[2], xv.z, s);
-            if (CT == 4) s = fmaf(w[3], xv.w, s);
-            H1[p * PN_LD1 + c] = pm_tanh(s);
+        static_assert(PPT % 2 == 0, "layer 1 pairs points for the packed tanh");
+#pragma unroll 4
+        for (int p = p0; p < p0 + PPT; p += 2) {
+            float s2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 xv = *(const float4*)(Xs + (p + j) * PN_MAXC);
+                float s = fmaf(w[0], xv.x, b1c);
+                s = fmaf(w[1], xv.y, s);
+                s = fmaf(w[2], xv.z, s);
+                if (CT == 4) s = fmaf(w[3], xv.w, s);
+                s2[j] = s;
+            }
+            const f32x2 t = pm_tanh2(s2[0], s2[1]);
+            H1[p * PN_LD1 + c] = t.x;
+            H1[(p + 1) * PN_LD1 + c] = t.y;
         }
     } else {
         float w1[PN_MAXC];
@@ -168,11 +176,15 @@ __device__ __forceinline__ void layer2_store(const f32x16 (&acc)[MB][NB], const 
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float v = pm_tanh(acc[mb][nb][r] + b2v[nb]);
-                H2[row * PN_LD2 + (wave * NB + nb) * 32 + li] = v;
-                if (h2_global) h2_global[row * PN_C2 + (wave * NB + nb) * 32 + li] = v;   // 128-B row segments per half-wave
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 v2 = pm_tanh2(acc[mb][nb][r] + b2v[nb], acc[mb][nb][r + 1] + b2v[nb]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = mb * 32 + ((r + j) & 3) + 8 * ((r + j) >> 2) + 4 * lh;
+                    const float v = j ? v2.y : v2.x;
+                    H2[row * PN_LD2 + (wave * NB + nb) * 32 + li] = v;
+                    if (h2_global) h2_global[row * PN_C2 + (wave * NB + nb) * 32 + li] = v;   // 128-B row segments per half-wave
+                }
             }
 }
 
@@ -825,6 +837,7 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
                 float w[NXC];
 #pragma unroll
                 for (int d = 0; d < NXC; ++d) w[d] = d < CC ? W1[c * CC + d] : 0.f;
+                float z[PPT];
 #pragma unroll
                 for (int i = 0; i < PPT; ++i) {
                     const float4 xv = *(const float4*)(Xs + (p0 + i) * PN_MAXC);
@@ -837,7 +850,13 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
                         sacc = fmaf(w[4 % NXC], x1.x, sacc); sacc = fmaf(w[5 % NXC], x1.y, sacc);
                         sacc = fmaf(w[6 % NXC], x1.z, sacc); sacc = fmaf(w[7 % NXC], x1.w, sacc);
                     }
-                    H1n[(p0 + i) * PN_LD1 + c] = pm_tanh(sacc);
+                    z[i] = sacc;
+                }
+#pragma unroll
+                for (int i = 0; i < PPT; i += 2) {
+                    const f32x2 t = pm_tanh2(z[i], z[i + 1]);
+                    H1n[(p0 + i) * PN_LD1 + c] = t.x;
+                    H1n[(p0 + i + 1) * PN_LD1 + c] = t.y;
                 }
             }
             if (!(PN_ABLATE & 8)) {

