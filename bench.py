@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-steps", type=int, default=0, help="override the rollout length T (e.g. 128 for the vision workload)")
     ap.add_argument("--points", type=int, default=4096, help="dagger workload: points per student cloud (BASELINE cfg 5: 4096)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x6"],
                     help="vision encoder forward: exact fp32 MFMA (default) or the opt-in split-bf16 path")
     args = ap.parse_args()
 
@@ -306,7 +306,7 @@ def main():
               else "PPO env-steps/sec (whole node), 4096 envs x 128 steps, state obs (BASELINE cfg 2)")
     out = dict(metric=metric, value=value, unit="env-steps/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="f32" if args.precision == "f32" else "f32 (encoder forward: bf16x3 split MFMA)",
+               scaling="weak", vs_baseline=None, dtype="f32" if args.precision == "f32" else f"f32 (encoder forward: {args.precision} split MFMA)",
                data="synthetic",
                config=dict(workload=w["name"], envs_per_gpu=w["N"], n_steps=w["T"], points=1024 if args.workload.startswith("vision") else 0,
                            minibatch=2048, n_updates=5, parallelism=f"dp{world}",
@@ -357,6 +357,21 @@ def main():
             value=w["N"] * w["T"] / dt3, unit="env-steps/s", ms_per_step=dt3 * 1e3,
             note="pm_pointnet_enc_fwd_bf3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on bf16 MFMAs, fp32 accumulate; "
                  "~1e-5 relative; passes the golden vision-PPO cases at the fp32 path's tolerances; backward stays fp32"))
+        # ... and on the three-plane split (six bf16 MFMAs per product block): the fp32 kernel's error level
+        ac.actor.precision = ac.critic.precision = "bf16x6"
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        fence()
+        dt6 = (time.perf_counter() - t1) / 2
+        ac.actor.precision = ac.critic.precision = "f32"
+        out["optional_paths"]["encoder_forward_bf16x6"] = dict(
+            value=w["N"] * w["T"] / dt6, unit="env-steps/s", ms_per_step=dt6 * 1e3,
+            note="pm_pointnet_enc_fwd_bf6: operands split into three bf16 planes, products a0b0+a0b1+a1b0+a0b2+a1b1+a2b0 "
+                 "on bf16 MFMAs with fp32 accumulate; error against fp64 no larger than the fp32 MFMA kernel's "
+                 "(tests/test_gpu_learner.py::test_pointnet_bf16x6_forward_has_fp32_class_error); backward stays fp32")
         # ... with the critic loop issued on a second HIP stream next to the actor loop (bit-identical results; off by
         # default for this workload because concurrent kernels blur the per-kernel timing the roofline block reports)
         run.overlap = True

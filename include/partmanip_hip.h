@@ -41,7 +41,7 @@ extern "C" {
 #define PM_ACT_TANH 1
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 117 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 118 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -110,6 +110,16 @@ int pm_pointnet_enc_fwd_f32(const float* x, long ldx, int B, int P, int C, int s
 size_t pm_pointnet_packed_bf3_bytes(void);
 int pm_pointnet_pack_weights_bf3(const float* W2, const float* W3, void* packed, void* stream);
 int pm_pointnet_enc_fwd_bf3(const float* x, long ldx, int B, int P, int C, int sub_mean, const float* W1,
+                            const float* b1, const float* b2, const float* b3, const void* packed, int max_mean,
+                            float* feat, long ldf, int32_t* argmax, float* h2_save /* as pm_pointnet_enc_fwd_f32 */,
+                            void* stream);
+/* OPT-IN fp32-class split-bf16 forward: same contract again, with every operand split into THREE bf16 planes and the
+ * six products a0b0, a0b1, a1b0, a0b2, a1b1, a2b0 accumulated in fp32 (dropped terms <= 2^-24 relative: the error
+ * against fp64 is that of the fp32 MFMA kernel, at 2.7x less matrix-pipe time).  P must be a multiple of 64.
+ * `packed` = pm_pointnet_packed_bf6_bytes() bytes written by pm_pointnet_pack_weights_bf6. */
+size_t pm_pointnet_packed_bf6_bytes(void);
+int pm_pointnet_pack_weights_bf6(const float* W2, const float* W3, void* packed, void* stream);
+int pm_pointnet_enc_fwd_bf6(const float* x, long ldx, int B, int P, int C, int sub_mean, const float* W1,
                             const float* b1, const float* b2, const float* b3, const void* packed, int max_mean,
                             float* feat, long ldf, int32_t* argmax, float* h2_save /* as pm_pointnet_enc_fwd_f32 */,
                             void* stream);

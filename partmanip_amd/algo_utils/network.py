@@ -159,11 +159,12 @@ class PointNet(_HipNet):
         self.count = 0
         self.in_channels = input_dim // self.point_num
         self.feat_dim = 512 * (1 + int(self.max_mean_concat))
-        # 'f32' (default): exact fp32 MFMA.  'bf16x3' (opt-in, not a reference key): encoder forward on split-bf16
-        # MFMAs (~1e-5 relative, see csrc/pointnet_enc_bf3.hip); the backward stays fp32.
+        # 'f32' (default): exact fp32 MFMA.  Opt-in (not reference keys), encoder forward on split-bf16 MFMAs, the
+        # backward stays fp32: 'bf16x3' (two planes, ~1e-5 relative, csrc/pointnet_enc_bf3.hip) and 'bf16x6' (three
+        # planes, six products: the fp32 kernel's error level, csrc/pointnet_enc_bf6.hip).
         self.precision = net_cfg.get('precision', 'f32')
         self.save_h2 = bool(net_cfg.get('save_h2', True))
-        if self.precision not in ('f32', 'bf16x3'):
+        if self.precision not in ('f32', 'bf16x3', 'bf16x6'):
             raise ValueError(f"PointNet precision '{self.precision}'")
         _act_code(act)
         object.__setattr__(self, "_head", _LinearChain([self.final_mlp[0], self.final_mlp[2], self.final_mlp[4]],
@@ -171,6 +172,7 @@ class PointNet(_HipNet):
         object.__setattr__(self, "_enc_grads", None)
         object.__setattr__(self, "_packed", None)
         object.__setattr__(self, "_packed3", None)
+        object.__setattr__(self, "_packed6", None)
 
     def set_grad_views(self, views):
         self._head.grads = [(views[f"final_mlp.{i}.weight"], views[f"final_mlp.{i}.bias"]) for i in (0, 2, 4)]
@@ -213,6 +215,14 @@ class PointNet(_HipNet):
             ops.pointnet_enc_fwd_bf3(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
                                      self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].bias.data,
                                      self._packed3, self.max_mean_concat, feat, argmax, h2)
+        elif self.precision == 'bf16x6':
+            if self._packed6 is None or self._packed6.device != x.device:
+                object.__setattr__(self, "_packed6", torch.empty(int(ops.lib.pm_pointnet_packed_bf6_bytes()),
+                                                                 dtype=torch.uint8, device=x.device))
+            ops.pointnet_pack_bf6(self.mlp[2].weight.data, self.mlp[4].weight.data, self._packed6)
+            ops.pointnet_enc_fwd_bf6(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
+                                     self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].bias.data,
+                                     self._packed6, self.max_mean_concat, feat, argmax, h2)
         else:
             ops.pointnet_enc_fwd(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
                                  self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].bias.data, packed,

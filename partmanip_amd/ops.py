@@ -204,6 +204,20 @@ def pointnet_enc_fwd_bf3(x, P, Cc, sub_mean, w1, b1, b2, b3, packed, max_mean, f
                                           _ptr(argmax), _ptr(h2_save), _stream()), "pm_pointnet_enc_fwd_bf3")
 
 
+def pointnet_pack_bf6(w2, w3, packed):
+    _req(w2, w3, packed)
+    check(lib.pm_pointnet_pack_weights_bf6(_ptr(w2), _ptr(w3), _ptr(packed), _stream()), "pm_pointnet_pack_weights_bf6")
+
+
+def pointnet_enc_fwd_bf6(x, P, Cc, sub_mean, w1, b1, b2, b3, packed, max_mean, feat, argmax, h2_save=None):
+    _req(x, w1, b1, b2, b3, packed, feat, argmax)
+    B = x.shape[0]
+    with TIMER.bracket("pointnet_enc_fwd"):
+        check(lib.pm_pointnet_enc_fwd_bf6(_ptr(x), _rows(x, "x"), B, P, Cc, int(sub_mean), _ptr(w1), _ptr(b1), _ptr(b2),
+                                          _ptr(b3), _ptr(packed), int(max_mean), _ptr(feat), _rows(feat, "feat"),
+                                          _ptr(argmax), _ptr(h2_save), _stream()), "pm_pointnet_enc_fwd_bf6")
+
+
 def pointnet_enc_bwd(x, P, Cc, sub_mean, w1, b1, b2, w3, packed, max_mean, dfeat, argmax, dw1, db1, dw2, db2, dw3, db3,
                      ws, h2_saved=None):
     _req(x, w1, b1, b2, w3, packed, dfeat, argmax, dw1, db1, dw2, db2, dw3, db3, h2_saved)

@@ -609,6 +609,67 @@ def test_ppo_update_bf16x3_forward_within_reference_tolerances(name):
                  len(fx["loss_trace"]))
 
 
+@pytest.mark.parametrize("B,C,max_mean,sub_mean", [(5, 3, True, False), (3, 4, False, True), (130, 3, True, False)])
+def test_pointnet_bf16x6_forward_has_fp32_class_error(B, C, max_mean, sub_mean):
+    """Opt-in three-plane split-bf16 encoder forward (`precision: bf16x6`, six bf16 MFMAs per product block).  Claim:
+    the error against an fp64 evaluation of the same network is that of the fp32 MFMA kernel.  Checked here: both
+    kernels against fp64 on the same inputs -- the split kernel's mean error must not exceed 1.5x the fp32 kernel's,
+    and it must meet the fp32 path's own tolerance (3e-6 of the feature scale); arg-max equal where the top-2 gap
+    exceeds 1e-5 (the fp32 path's rule)."""
+    from partmanip_amd.algo_utils import ActorCritic
+    errs = {}
+    for prec in ("f32", "bf16x6"):
+        net = dict(name="PointNet", activation="tanh", max_mean=max_mean, sub_mean=sub_mean, precision=prec)
+        torch.manual_seed(B + C)
+        ac = ActorCritic(1024 * C, 10, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net)).to(DEV)
+        ac.flat()
+        g = torch.Generator().manual_seed(B)
+        x = (torch.rand(B, 1024, C, generator=g) * 2 - 1).reshape(B, -1).contiguous()
+        p = {k: v.detach().cpu().double() for k, v in ac.state_dict().items()}
+        pc = x.double().reshape(B, 1024, C)
+        if sub_mean:
+            pc = torch.cat([pc[..., :3] - pc[..., :3].mean(dim=1, keepdim=True), pc[..., 3:]], dim=-1)
+        h = torch.tanh(torch.nn.functional.linear(pc, p["actor.mlp.0.weight"], p["actor.mlp.0.bias"]))
+        h = torch.tanh(torch.nn.functional.linear(h, p["actor.mlp.2.weight"], p["actor.mlp.2.bias"]))
+        h = torch.nn.functional.linear(h, p["actor.mlp.4.weight"], p["actor.mlp.4.bias"])
+        vmax, imax = h.max(dim=1)
+        top2 = h.topk(2, dim=1)[0]
+        ac.actor.hip_forward(x.to(DEV))
+        _, feat, argmax = ac.actor._saved[:3]
+        f = feat.cpu().double()
+        scale = float(vmax.abs().mean())
+        errs[prec] = (float((f[:, :512] - vmax).abs().mean()) / scale, float((f[:, :512] - vmax).abs().max()) / scale)
+        if max_mean:
+            assert float((f[:, 512:1024] - h.mean(dim=1)).abs().max()) / float(h.mean(dim=1).abs().mean()) < 1e-5
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+        assert torch.equal(argmax.cpu().long()[clear], imax[clear])
+        if prec == "bf16x6":                                   # the fp32 backward runs on top of it
+            ac.actor.hip_backward(torch.randn(B, 10, generator=g).to(DEV))
+            assert torch.isfinite(ac.flat()["grad_actor"]).all()
+    assert errs["bf16x6"][1] < 3e-6, errs
+    assert errs["bf16x6"][0] <= 1.5 * errs["f32"][0] + 1e-9, errs
+
+
+@pytest.mark.parametrize("name", ["ppo_pn_maxmean", "ppo_pn_max"])
+def test_ppo_update_bf16x6_forward_within_reference_tolerances(name):
+    """The golden vision-PPO cases with the bf16x6 encoder forward: the fp32 path's tolerances on the Train/* scalars and
+    on the parameters after the update (against the vectors captured from the reference)."""
+    c = cases.case_copy(cases.PPO_CASES[name])
+    c["net"] = dict(c["net"], precision="bf16x6")
+    fx = load_fixture(name)
+    run = make_ppo(c)
+    fill_storage(run, c, fx)
+    run.storage.compute_returns(t(fx["last_values"]).to(DEV), c["gamma"], c["lam"])
+    run.log_dict = {}
+    run.update(c["it"])
+    log = run.log_dict
+    assert log["Train/kl_update_count"] == int(fx["log_kl_update_count"])
+    for k in ("value_function_loss", "surrogate_loss", "kl", "kl_max"):
+        np.testing.assert_allclose(float(log["Train/" + k]), float(fx["log_" + k]), rtol=5e-4, atol=5e-6, err_msg=k)
+    check_params(flat_state(run.actor_critic.state_dict()), fx["final_flat"], int(fx["final_stride"]), c["lr"],
+                 len(fx["loss_trace"]))
+
+
 # ------------------------------------------------------------------------------- rollout side (SURVEY.md 8f rank 2)
 def test_rollout_side_matches_reference():
     """`Normalization` (pm_rms_update_f32 / pm_rms_normalize_f32) and `ActorCritic.random_act_cri`
