@@ -11,6 +11,15 @@
 // work-group of 8 waves per CU): layer 1 (VALU) -> H1 planes; layer 2: wave w -> channels [32w,32w+32), 2x1
 // accumulators; tanh + split -> H2 planes (aliasing H1); layer 3: wave w -> channels [64w,64w+64), 2x2 accumulators;
 // pooling in-lane over the accumulator registers (rows = points).
+//
+// Where its 4.1 ms go (A/B ablation builds, 2048 clouds): everything outside the two MFMA loops 0.7 ms; the loops with
+// no operand traffic at all 2.4 ms (the bf16 pipe sustains 2.15 PFLOP/s with two waves per SIMD,
+// tools/ubench/mfma_bf16_rate.hip: 1.9 ms for these 4.13 PFLOP); the L2 weight stream +1.0 ms; the LDS activation
+// reads +0.  The weight stream is a BANDWIDTH limit, not a latency one (three steps of prefetch instead of one, or
+// prefetching A as well, change nothing): with 64-row tiles every 1 KB weight fragment feeds two 32-cycle MFMAs per
+// product class = 16 B/clk per wave, 64 B/clk per CU at full matrix rate -- the L1 fill rate.  More rows per fragment
+// need more than the 160 KB of LDS for three activation planes (128 rows: 203 KB); a 96-row tile (147 KB) is the next
+// thing to try.  A 16-wave work-group (four waves per SIMD) measured 4.3 ms.
 #include "common.h"
 
 
