@@ -129,9 +129,14 @@ def test_pointnet_encoder_random_configs():
     centring, proprio) against the CPU restatement with the pooling index pinned."""
     from partmanip_amd.algo_utils import ActorCritic
     rng = np.random.default_rng(4)
-    for it in range(10):
+    # plus fixed corner cases: more clouds than CUs (persistent work-groups take several clouds each, 300 and 515 are
+    # not multiples of the grid), the largest cloud the backward's key tables hold (4096 points), one cloud
+    corners = {10: (300, 64, 3), 11: (515, 128, 4), 12: (2, 4096, 3), 13: (1, 2048, 5)}
+    for it in range(14):
         B, P, C = int(rng.integers(1, 9)), int(rng.choice([64, 128, 320, 1024, 1536])), int(rng.integers(3, 9))
         max_mean, sub_mean, proprio = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.choice([0, 3]))
+        if it in corners:
+            B, P, C = corners[it]
         net = dict(name="PointNet", activation="tanh", max_mean=max_mean, sub_mean=sub_mean, point_num=P,
                    save_h2=bool(it % 2))
         torch.manual_seed(400 + it)
