@@ -327,6 +327,11 @@ def main():
         bwd = ops.TIMER.mean_ms("pointnet_enc_bwd")
         if bwd:
             out["roofline"]["enc_bwd_mean_ms"] = bwd[0]
+            # second kernel of the step: the structured backward EXECUTES 2 dense GEMMs (dW2 = dz2^T h1, dh1 = dz2 W2:
+            # 2 x 2*256*128 flops per point); the timer brackets the whole C call (kernel + its five small follow-ups)
+            bflops = 2.0 * 2 * 256 * 128 * 1024 * 2048
+            out["roofline"]["enc_bwd_executed_tflops"] = bflops / (bwd[0] * 1e-3) / 1e12
+            out["roofline"]["enc_bwd_frac"] = out["roofline"]["enc_bwd_executed_tflops"] / PEAK_F32_MFMA_TFLOPS
     if args.workload == "vision_pn2":
         # the four fused set-abstraction kernels; `achieved` counts the MFMA flops each launch EXECUTES
         # (fwd: layers 2-3; bwd: dH2 + dW2 + dH1 -- layer 2 is loaded from what the forward saved) on 2048 clouds
