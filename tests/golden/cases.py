@@ -29,6 +29,7 @@ GAE_CASES = {
 _MLP_NET = dict(name="MLP", hid_dim=[64, 64, 64], activation="tanh")
 _PN_NET = dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False)
 _PN_NET_MAX = dict(name="PointNet", activation="tanh", max_mean=False, sub_mean=False)
+_PN_NET_SUB = dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=True)
 
 
 def _ppo(net, N, T, O, n_mb, n_up, tricks, sampler="sequential", succ_value=None,
@@ -51,6 +52,9 @@ PPO_CASES = {
     "ppo_mlp_ragged":  _ppo(_MLP_NET, 7, 9, 19, 4, 3, TRICKS_ALLON, seed=106, A=7),
     "ppo_pn_maxmean":  _ppo(_PN_NET, 4, 4, 3072, 2, 2, TRICKS_DEFAULT, seed=107, lr=2e-4, old_noise=0.02),
     "ppo_pn_max":      _ppo(_PN_NET_MAX, 4, 4, 3072, 2, 2, TRICKS_ALLON, seed=108, lr=2e-4, old_noise=0.02),
+    # NOTE sub_mean=True cannot be pinned through ppo.update without proprio: the reference centres IN PLACE on a view of
+    # the mini-batch (network.py:172-173), the critic's forward then rewrites the tensor the actor's graph saved, and
+    # its backward raises "modified by an inplace operation".  Centring is pinned by DAGGER_CASES["dagger_pn_submean"].
 }
 
 # rollout side: Normalization over three (N, O) batches; random_act_cri of an MLP actor-critic (actor_critic.py:36-47)
@@ -70,6 +74,10 @@ DAGGER_CASES = {
     "dagger_pn":  dict(stu_net=_PN_NET, tea_net=_MLP_NET, N=4, buf_size=5, n_fill=4, O_s=3072 + 7, O_t=32,
                        proprio=7, A=10, n_minibatches=2, n_updates=2, lr=1e-3, lr_schedule="fixed",
                        sampler="sequential", seed=202, action_std=0.1, max_iterations=1000, it=5, torch_seed=78),
+    # the same student with per-cloud centring (network.py:172-173); the clouds get a per-cloud offset below
+    "dagger_pn_submean":  dict(stu_net=_PN_NET_SUB, tea_net=_MLP_NET, N=4, buf_size=5, n_fill=4, O_s=3072 + 7, O_t=32,
+                       proprio=7, A=10, n_minibatches=2, n_updates=2, lr=1e-3, lr_schedule="fixed",
+                       sampler="sequential", seed=204, action_std=0.1, max_iterations=1000, it=5, torch_seed=78),
 }
 
 
@@ -145,7 +153,10 @@ def dagger_raw_inputs(c):
     for k in range(nf):
         if c["stu_net"]["name"] == "PointNet":
             npc = c["O_s"] - c["proprio"]
-            pts = det_uniform((N, 1024, npc // 1024), s + 10 * k + 1, -1.0, 1.0).reshape(N, npc)
+            pts = det_uniform((N, 1024, npc // 1024), s + 10 * k + 1, -1.0, 1.0)
+            if c["stu_net"].get("sub_mean"):                     # a per-cloud offset, so that centring matters
+                pts = pts + det_uniform((N, 1, npc // 1024), s + 10 * k + 7, -0.5, 0.5)
+            pts = pts.reshape(N, npc)
             pro = det_normal((N, c["proprio"]), s + 10 * k + 2)
             stu.append(np.concatenate([pts, pro], axis=1).astype(np.float32))
         elif c["stu_net"]["name"] == "Conv3DNet":
