@@ -264,7 +264,10 @@ static inline int bww_splits(int M, int N, int K) {
     long s = (M <= 4096 ? 256 : 512) / tiles;
     const long maxs = (M + GB_K - 1) / GB_K;
     if (s > maxs) s = maxs;
-    if (s > 32) s = 32;
+    // reductions over >= 256 K rows with one or two output tiles (conv1 of Conv3DNet: dW (16 x 125) over 7.9 M patch rows;
+    // the PointNet++ glue: 64-128 wide over 0.5-2 M rows) get up to 256 slabs: with 32 the 7.9 M-row one ran on 64
+    // work-groups at 0.66 TB/s (6.8 ms)
+    if (s > (M >= 262144 ? 256 : 32)) s = (M >= 262144 ? 256 : 32);
     if (s < 1) s = 1;
     return (int)s;
 }
