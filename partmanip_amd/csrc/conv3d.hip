@@ -18,25 +18,35 @@ struct Conv3dGeom {
     int ldc;                   // row stride of the patch matrix (>= C*k^3; the tail is zero-filled)
 };
 
+// One thread per (patch row, channel, kd, kh): it decodes its indices once and copies the k taps along w (contiguous
+// in the input when sw == 1, contiguous in the patch row) -- the first version decoded every ELEMENT (five div/mod
+// chains each) and was integer-VALU-bound: 5.3 ms for conv1's 4 GB patch matrix.  One extra group per row zero-fills
+// the ldc - C*k^3 pad columns.
 __global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__ x, Conv3dGeom g, long total,
                                                         float* __restrict__ cols) {
-    const int k3 = g.k * g.k * g.k, kk = g.k * g.k, ncol = g.C * k3;
+    const int kk = g.k * g.k, k3 = kk * g.k, ncol = g.C * k3, gpr = g.C * kk + 1;     // groups per row
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const long row = e / g.ldc;
-        const int col = (int)(e - row * g.ldc);
-        float v = 0.f;
-        if (col < ncol) {
-            const int c = col / k3, t = col - c * k3, kd = t / kk, kh = (t - kd * kk) / g.k, kw = t - kd * kk - kh * g.k;
-            long r = row;
-            const int ow = (int)(r % g.Wo); r /= g.Wo;
-            const int oh = (int)(r % g.Ho); r /= g.Ho;
-            const int od = (int)(r % g.Do);
-            const long b = r / g.Do;
-            const int d = od * g.stride - g.pad + kd, h = oh * g.stride - g.pad + kh, w = ow * g.stride - g.pad + kw;
-            if (d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W)
-                v = x[b * g.sb + c * g.sc + d * g.sd + h * g.sh + w * g.sw];
+        const long row = e / gpr;
+        const int grp = (int)(e - row * gpr);
+        float* dst = cols + row * g.ldc;
+        if (grp == g.C * kk) {
+            for (int col = ncol; col < g.ldc; ++col) dst[col] = 0.f;
+            continue;
         }
-        cols[e] = v;
+        const int c = grp / kk, t = grp - c * kk, kd = t / g.k, kh = t - kd * g.k;
+        long r = row;
+        const int ow = (int)(r % g.Wo); r /= g.Wo;
+        const int oh = (int)(r % g.Ho); r /= g.Ho;
+        const int od = (int)(r % g.Do);
+        const long b = r / g.Do;
+        const int d = od * g.stride - g.pad + kd, h = oh * g.stride - g.pad + kh, w0 = ow * g.stride - g.pad;
+        const bool ok = d >= 0 && d < g.D && h >= 0 && h < g.H;
+        const float* src = x + b * g.sb + c * g.sc + (long)d * g.sd + (long)h * g.sh;
+        dst += c * k3 + kd * kk + kh * g.k;
+        for (int kw = 0; kw < g.k; ++kw) {
+            const int w = w0 + kw;
+            dst[kw] = (ok && w >= 0 && w < g.W) ? src[(long)w * g.sw] : 0.f;
+        }
     }
 }
 
@@ -101,7 +111,7 @@ extern "C" int pm_im2col3d_f32(const float* x, int B, int C, int D, int H, int W
     Conv3dGeom g;
     const int rc = conv3d_geom(g, C, D, H, W, k, stride, pad, sb, sc, sd, sh, sw, ldc);
     if (rc != PM_OK) return rc;
-    const long total = (long)B * g.Do * g.Ho * g.Wo * ldc;
+    const long total = (long)B * g.Do * g.Ho * g.Wo * (C * k * k + 1);
     long nb = (total + 255) / 256;
     if (nb > 16384) nb = 16384;
     hipLaunchKernelGGL(im2col3d_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), x, g, total, cols);
