@@ -41,7 +41,7 @@ extern "C" {
 #define PM_ACT_TANH 1
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 118 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 119 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -259,6 +259,19 @@ int pm_tsdf_select_f32(const float* vol, int B, int res, float lo, float hi, flo
 int pm_tsdf_sparse_gather_f32(const float* coords, const int32_t* idx, const float* vol, int B, int res, int K,
                               float* out, void* stream);
 
+/* algorithms/algo_utils/network.py:72,119 -- Conv3DNet's INPUT layer, Conv3d(1, Cout, k, stride, padding k/2), as a direct
+ * stencil over the single-channel volume (no patch matrix): x (B, D, H, W) through element strides (sb, sd, sh, sw);
+ * wt = conv.weight viewed (Cout, k^3) TRANSPOSED to (k^3, Cout); y (B*Do*Ho*Wo, ldy) rows of Cout = act(conv + bias)
+ * (channels-last, what the next layer's pm_im2col3d_f32 reads through strides).  pm_conv3d_c1_wgrad_f32: dW (Cout, lddw
+ * >= k^3) and db (Cout, may be NULL) from dz (rows, lddz) = the gradient at this layer's pre-activation.  Instantiated
+ * for k = 5, Cout = 16 (pm_conv3d_c1_supported); other shapes return PM_EUNSUPPORTED: use im2col + the Linear kernels. */
+int pm_conv3d_c1_supported(int k, int Cout);
+size_t pm_conv3d_c1_wgrad_workspace_bytes(int Cout);
+int pm_conv3d_c1_fwd_f32(const float* x, int B, int D, int H, int W, int k, int stride, int pad, long sb, long sd, long sh,
+                         long sw, const float* wt, const float* bias, int Cout, int act, float* y, long ldy, void* stream);
+int pm_conv3d_c1_wgrad_f32(const float* dz, long lddz, const float* x, int B, int D, int H, int W, int k, int stride,
+                           int pad, long sb, long sd, long sh, long sw, int Cout, float* dW, long lddw, float* db,
+                           void* workspace, size_t workspace_bytes, void* stream);
 /* ------------------------------------------------------------------ Conv3D students: patch gather / scatter
  * network.py:56-94 (`Conv3DNet` / `Encoder`: nn.Conv3d(k, stride, padding = k/2)).  A convolution runs as
  * cols = im2col(x) -> pm_linear_fwd_f32 with conv.weight viewed (Cout, Cin*k^3) -> rows (b, od, oh, ow) x Cout;

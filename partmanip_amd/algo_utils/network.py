@@ -535,11 +535,17 @@ class Conv3DNet(_HipNet):
         cur = vol
         for i, conv in enumerate(convs):
             k, st = self.KERNELS[i], self.STRIDES[i]
+            e = ext[i + 1]
+            if i == 0 and self._act in (ops.ACT_NONE, ops.ACT_TANH) and ops.conv3d_c1_supported(k, conv.out_channels):
+                # the single-channel input layer runs as a direct stencil: no 4 GB patch matrix (csrc/conv3d.hip)
+                y = ops.conv3d_c1_fwd(cur, k, st, k // 2, w1.t().contiguous(), conv.bias.data, self._act)
+                saved.append((cur, None, y))
+                cur = y.view(B, e, e, e, conv.out_channels).permute(0, 4, 1, 2, 3)
+                continue
             w = self._w1p if i == 0 else conv.weight.data.view(conv.out_channels, -1)
             cols = ops.im2col3d(cur, k, st, k // 2, w.shape[1])
             y = torch.empty(cols.shape[0], conv.out_channels, device=x.device)
             ops.linear_fwd(cols, w, conv.bias.data, y, self._act)
-            e = ext[i + 1]
             saved.append((cur, cols, y))
             cur = y.view(B, e, e, e, conv.out_channels).permute(0, 4, 1, 2, 3)      # channels-last storage, NCDHW view
         fbuf = torch.empty(B, 32 * 27 + self.proprio_shape, device=x.device)
@@ -561,6 +567,9 @@ class Conv3DNet(_HipNet):
             conv, (x5, cols, y) = convs[i], saved[i]
             k, st = self.KERNELS[i], self.STRIDES[i]
             dW, db = self._conv_grads[i]
+            if i == 0 and cols is None:
+                ops.conv3d_c1_wgrad(dz, x5, k, st, k // 2, dW.view(conv.out_channels, -1), db, ws)
+                break
             if i == 0:
                 dwp = torch.empty_like(self._w1p)
                 ops.linear_bwd_weight(dz, cols, dwp, db, ws)

@@ -134,6 +134,163 @@ extern "C" int pm_col2im3d_f32(const float* dcols, int B, int C, int D, int H, i
     return PM_OK;
 }
 
+// ---------------------------------------------------------------------------------- direct conv of the input layer
+// Conv3DNet's first layer (network.py:72,119: Conv3d(1, 16, k=5, stride 3, pad 2) on the 50^3 TSDF) dominated the shipped
+// DAgger step through its patch matrix: 4 GB per mini-batch of 1600 volumes, written once (im2col, 3.7 ms) and read
+// twice (forward GEMM 2.1 ms, weight-gradient GEMM 1.3 ms).  With ONE input channel the layer is a 125-tap stencil,
+// so both directions run straight from the volume (0.8 GB, re-read through L1/L2):
+//   forward   one thread per output position, all CO filters in registers; the 125 x CO weights come TAP-major
+//             (wt[tap][o]) so that a tap's CO weights are one wave-uniform (scalar) load; bias + tanh fused;
+//   gradient  dW[o][tap] = sum_rows dz[row][o] * x[patch(row)][tap]: lane = tap (125 of 128 lanes; lane 125 sees the
+//             constant 1 and so accumulates the bias gradient), the row's CO dz values are wave-uniform, CO
+//             accumulators per lane; work-groups own contiguous row slices, slabs are added in fixed order.
+// The input volume is data, so this layer has no input gradient.
+template <int K, int CO>
+__global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restrict__ x, Conv3dGeom g,
+                                                             const float* __restrict__ wt,
+                                                             const float* __restrict__ bias, int act_tanh, long nrows,
+                                                             float* __restrict__ y, long ldy) {
+    // one row per thread, no grid-stride loop: inside a loop the 125 x CO wave-uniform weight loads are loop-invariant
+    // and hipcc hoists all of them (2010 spilled SGPRs)
+    {
+        const long row = (long)blockIdx.x * 256 + threadIdx.x;
+        if (row >= nrows) return;
+        long r = row;
+        const int ow = (int)(r % g.Wo); r /= g.Wo;
+        const int oh = (int)(r % g.Ho); r /= g.Ho;
+        const int od = (int)(r % g.Do);
+        const long b = r / g.Do;
+        const int d0 = od * g.stride - g.pad, h0 = oh * g.stride - g.pad, w0 = ow * g.stride - g.pad;
+        const float* xb = x + b * g.sb;
+        float acc[CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] = bias ? bias[o] : 0.f;
+#pragma unroll 1                                   // ROLLED over (kd, kh): a tap row's 5 x CO wave-uniform weights fit
+        for (int kd = 0; kd < K; ++kd) {               // the SGPR file; fully unrolled, hipcc hoists all 125 x CO scalar
+            const int d = d0 + kd;                     // loads to the top and spills 1900 SGPRs
+            const bool okd = d >= 0 && d < g.D;
+#pragma unroll 1
+            for (int kh = 0; kh < K; ++kh) {
+                const int h = h0 + kh;
+                const bool ok = okd && h >= 0 && h < g.H;
+                const float* src = xb + (long)d * g.sd + (long)h * g.sh;
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                    const int w = w0 + kw;
+                    const float v = (ok && w >= 0 && w < g.W) ? src[(long)w * g.sw] : 0.f;
+                    const float* wp = wt + ((kd * K + kh) * K + kw) * CO;
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) acc[o] = fmaf(wp[o], v, acc[o]);
+                }
+            }
+        }
+        float* yr = y + row * ldy;
+#pragma unroll
+        for (int o = 0; o < CO; o += 2) {
+            if (act_tanh) {
+                const f32x2 t = pm_tanh2(acc[o], acc[o + 1]);
+                yr[o] = t.x;
+                yr[o + 1] = t.y;
+            } else {
+                yr[o] = acc[o];
+                yr[o + 1] = acc[o + 1];
+            }
+        }
+    }
+}
+
+#define C1_WG_SLABS 1024
+template <int K, int CO>
+__global__ __launch_bounds__(128) void conv3d_c1_wgrad_kernel(const float* __restrict__ dz, long lddz,
+                                                               const float* __restrict__ x, Conv3dGeom g, long nrows,
+                                                               long rows_per_wg, float* __restrict__ slabs) {
+    constexpr int K3 = K * K * K;
+    static_assert(K3 < 128, "one lane per tap plus the bias lane");
+    const int tap = threadIdx.x;
+    const int kd = tap / (K * K), kh = (tap / K) % K, kw = tap % K;
+    const long r0 = (long)blockIdx.x * rows_per_wg;
+    long r1 = r0 + rows_per_wg;
+    if (r1 > nrows) r1 = nrows;
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+#pragma unroll 4
+    for (long row = r0; row < r1; ++row) {
+        long r = row;                                      // wave-uniform: decoded on the scalar unit
+        const int ow = (int)(r % g.Wo); r /= g.Wo;
+        const int oh = (int)(r % g.Ho); r /= g.Ho;
+        const int od = (int)(r % g.Do);
+        const long b = r / g.Do;
+        const int d = od * g.stride - g.pad + kd, h = oh * g.stride - g.pad + kh, w = ow * g.stride - g.pad + kw;
+        float v = 0.f;
+        if (tap < K3) {
+            if (d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W)
+                v = x[b * g.sb + (long)d * g.sd + (long)h * g.sh + (long)w * g.sw];
+        } else if (tap == K3) {
+            v = 1.0f;                                      // bias lane
+        }
+        const float* dzr = dz + row * lddz;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] = fmaf(dzr[o], v, acc[o]);
+    }
+    float* out = slabs + (size_t)blockIdx.x * CO * 128;
+#pragma unroll
+    for (int o = 0; o < CO; ++o) out[o * 128 + tap] = acc[o];
+}
+// dW[o][tap] = sum_slabs (fixed order), db[o] from lane K^3
+__global__ __launch_bounds__(128) void conv3d_c1_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslabs, int CO,
+                                                                      int K3, float* __restrict__ dW, long lddw,
+                                                                      float* __restrict__ db) {
+    const int o = blockIdx.x, tap = threadIdx.x;
+    float s = 0.f;
+#pragma unroll 8
+    for (int z = 0; z < nslabs; ++z) s += slabs[((size_t)z * CO + o) * 128 + tap];
+    if (tap < K3) dW[o * lddw + tap] = s;
+    else if (tap == K3 && db) db[o] = s;
+}
+
+extern "C" int pm_conv3d_c1_supported(int k, int Cout) { return k == 5 && Cout == 16; }
+extern "C" size_t pm_conv3d_c1_wgrad_workspace_bytes(int Cout) { return (size_t)C1_WG_SLABS * Cout * 128 * sizeof(float); }
+
+extern "C" int pm_conv3d_c1_fwd_f32(const float* x, int B, int D, int H, int W, int k, int stride, int pad, long sb,
+                                    long sd, long sh, long sw, const float* wt, const float* bias, int Cout, int act,
+                                    float* y, long ldy, void* stream) {
+    PM_REQUIRE(x && wt && y && B > 0 && ldy >= Cout);
+    if (!pm_conv3d_c1_supported(k, Cout)) return PM_EUNSUPPORTED;
+    if (act != PM_ACT_NONE && act != PM_ACT_TANH) return PM_EUNSUPPORTED;
+    Conv3dGeom g;
+    const int rc = conv3d_geom(g, 1, D, H, W, k, stride, pad, sb, 0, sd, sh, sw, k * k * k);
+    if (rc != PM_OK) return rc;
+    const long nrows = (long)B * g.Do * g.Ho * g.Wo;
+    const long nb = (nrows + 255) / 256;
+    if (nb > 0x7fffffffL) return PM_EINVAL;
+    hipLaunchKernelGGL((conv3d_c1_fwd_kernel<5, 16>), dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), x, g, wt, bias,
+                       act == PM_ACT_TANH, nrows, y, ldy);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_conv3d_c1_wgrad_f32(const float* dz, long lddz, const float* x, int B, int D, int H, int W, int k,
+                                      int stride, int pad, long sb, long sd, long sh, long sw, int Cout, float* dW,
+                                      long lddw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(dz && x && dW && B > 0 && lddz >= Cout && lddw >= k * k * k);
+    if (!pm_conv3d_c1_supported(k, Cout)) return PM_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < pm_conv3d_c1_wgrad_workspace_bytes(Cout)) return PM_EWORKSPACE;
+    Conv3dGeom g;
+    const int rc = conv3d_geom(g, 1, D, H, W, k, stride, pad, sb, 0, sd, sh, sw, k * k * k);
+    if (rc != PM_OK) return rc;
+    const long nrows = (long)B * g.Do * g.Ho * g.Wo;
+    long per = (nrows + C1_WG_SLABS - 1) / C1_WG_SLABS;
+    if (per < 64) per = 64;
+    const int nwg = (int)((nrows + per - 1) / per);
+    hipLaunchKernelGGL((conv3d_c1_wgrad_kernel<5, 16>), dim3(nwg), dim3(128), 0, pm_stream(stream), dz, lddz, x, g, nrows,
+                       per, (float*)workspace);
+    hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(Cout), dim3(128), 0, pm_stream(stream),
+                       (const float*)workspace, nwg, Cout, k * k * k, dW, lddw, db);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
 // ---------------------------------------------------------------------------------- TSDF integration
 // utils/depth2tsdf.py:68-86 `TSDFVolume.integrate`: every voxel looks up its (precomputed, registration-time)
 // pixel in every view, turns the depth difference into a truncated signed distance and averages the views

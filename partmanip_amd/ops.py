@@ -462,6 +462,38 @@ def im2col3d(x5, k, stride, pad, ldc):
     return cols
 
 
+def conv3d_c1_supported(k, cout):
+    return bool(lib.pm_conv3d_c1_supported(int(k), int(cout)))
+
+
+def conv3d_c1_fwd(x5, k, stride, pad, wt, bias, act):
+    """Direct conv of a single-channel 5-D VIEW (B, 1, D, H, W) with wt (k^3, Cout) -> y (B*Do*Ho*Wo, Cout) = act(conv + b)."""
+    _req(x5, wt, bias)
+    B, Cc, D, H, W = x5.shape
+    if Cc != 1:
+        raise ValueError("conv3d_c1_fwd: one input channel")
+    _f32c(wt, "wt")
+    Do, Ho, Wo = (conv3d_out(n, k, stride, pad) for n in (D, H, W))
+    cout = wt.shape[1]
+    y = torch.empty(B * Do * Ho * Wo, cout, dtype=torch.float32, device=x5.device)
+    sb, _, sd, sh, sw = x5.stride()
+    check(lib.pm_conv3d_c1_fwd_f32(_ptr(x5), B, D, H, W, k, stride, pad, sb, sd, sh, sw, _ptr(wt), _ptr(bias), cout, int(act),
+                                   _ptr(y), cout, _stream()), "pm_conv3d_c1_fwd_f32")
+    return y
+
+
+def conv3d_c1_wgrad(dz, x5, k, stride, pad, dw, db, ws):
+    """dw (Cout, k^3) / db (Cout) of the direct input-layer conv from dz (rows, Cout)."""
+    _req(dz, x5, dw, db)
+    B, Cc, D, H, W = x5.shape
+    cout = dw.shape[0]
+    w = ws.get(lib.pm_conv3d_c1_wgrad_workspace_bytes(cout))
+    sb, _, sd, sh, sw = x5.stride()
+    check(lib.pm_conv3d_c1_wgrad_f32(_ptr(dz), _rows(dz, "dz"), _ptr(x5), B, D, H, W, k, stride, pad, sb, sd, sh, sw, cout,
+                                     _ptr(dw), _rows(dw, "dw"), _ptr(db), _ptr(w), w.numel(), _stream()),
+          "pm_conv3d_c1_wgrad_f32")
+
+
 def col2im3d(dcols, dx5, k, stride, pad, y_tanh5=None):
     """dcols (B*Do*Ho*Wo, ldc) -> every element of the 5-D view dx5 (B, C, D, H, W); y_tanh5 = the layer input
     (a tanh output, same shape AND strides as dx5): its derivative is folded in."""
