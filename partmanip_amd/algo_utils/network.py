@@ -536,7 +536,8 @@ class Conv3DNet(_HipNet):
         for i, conv in enumerate(convs):
             k, st = self.KERNELS[i], self.STRIDES[i]
             e = ext[i + 1]
-            if i == 0 and self._act in (ops.ACT_NONE, ops.ACT_TANH) and ops.conv3d_c1_supported(k, conv.out_channels):
+            if (i == 0 and self._act in (ops.ACT_NONE, ops.ACT_TANH) and self.res <= 64
+                    and ops.conv3d_c1_supported(k, conv.out_channels)):
                 # the single-channel input layer runs as a direct stencil: no 4 GB patch matrix (csrc/conv3d.hip)
                 y = ops.conv3d_c1_fwd(cur, k, st, k // 2, w1.t().contiguous(), conv.bias.data, self._act)
                 saved.append((cur, None, y))

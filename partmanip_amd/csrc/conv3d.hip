@@ -199,39 +199,72 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restr
     }
 }
 
-#define C1_WG_SLABS 1024
+#define C1_WG_SLABS 2048
+#define C1_MAXW 64                                           // widest volume row the LDS slab holds
+// Work-groups own contiguous runs of output LINES (fixed b, od, oh; ow = 0..Wo-1).  A line's patches all lie in the K x K
+// input rows x[d0..d0+K)[h0..h0+K)[*]: they are staged in LDS by coalesced row loads (zero-filled outside the volume),
+// then lane = tap gathers its value for each ow from LDS -- the first version gathered from global memory, 25-50 cache
+// lines per wave load, and was bound by the texture addresser (2.5 ms).
 template <int K, int CO>
 __global__ __launch_bounds__(128) void conv3d_c1_wgrad_kernel(const float* __restrict__ dz, long lddz,
-                                                               const float* __restrict__ x, Conv3dGeom g, long nrows,
-                                                               long rows_per_wg, float* __restrict__ slabs) {
+                                                               const float* __restrict__ x, Conv3dGeom g, long nlines,
+                                                               long lines_per_wg, float* __restrict__ slabs) {
     constexpr int K3 = K * K * K;
     static_assert(K3 < 128, "one lane per tap plus the bias lane");
+    __shared__ float slab[2][K * K][C1_MAXW + 2 * K];      // [buffer][kd*K+kh][pad + w], double-buffered over lines
     const int tap = threadIdx.x;
     const int kd = tap / (K * K), kh = (tap / K) % K, kw = tap % K;
-    const long r0 = (long)blockIdx.x * rows_per_wg;
-    long r1 = r0 + rows_per_wg;
-    if (r1 > nrows) r1 = nrows;
+    const int WP = g.W + 2 * g.pad;                         // padded row length actually used
+    const long l0 = (long)blockIdx.x * lines_per_wg;
+    long l1 = l0 + lines_per_wg;
+    if (l1 > nlines) l1 = nlines;
     float acc[CO];
 #pragma unroll
     for (int o = 0; o < CO; ++o) acc[o] = 0.f;
-#pragma unroll 4
-    for (long row = r0; row < r1; ++row) {
-        long r = row;                                      // wave-uniform: decoded on the scalar unit
-        const int ow = (int)(r % g.Wo); r /= g.Wo;
-        const int oh = (int)(r % g.Ho); r /= g.Ho;
-        const int od = (int)(r % g.Do);
-        const long b = r / g.Do;
-        const int d = od * g.stride - g.pad + kd, h = oh * g.stride - g.pad + kh, w = ow * g.stride - g.pad + kw;
-        float v = 0.f;
-        if (tap < K3) {
-            if (d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W)
-                v = x[b * g.sb + (long)d * g.sd + (long)h * g.sh + (long)w * g.sw];
-        } else if (tap == K3) {
-            v = 1.0f;                                      // bias lane
+    long rr = l0;                                           // wave-uniform line counters, advanced by carry
+    int oh = (int)(rr % g.Ho); rr /= g.Ho;
+    int od = (int)(rr % g.Do);
+    long b = rr / g.Do;
+    // staging: K threads per input row (kd, kh) = tap / K, each copies every K-th padded column -- no runtime divisions
+    const int srow = tap / K, spart = tap % K;
+    auto stage = [&](int buf, long bb, int odd, int ohh) __attribute__((always_inline)) {
+        if (srow >= K * K) return;
+        const int d = odd * g.stride - g.pad + srow / K, h = ohh * g.stride - g.pad + srow % K;
+        const bool ok = d >= 0 && d < g.D && h >= 0 && h < g.H;
+        const float* src = x + bb * g.sb + (long)d * g.sd + (long)h * g.sh;
+        for (int c = spart; c < WP; c += K) {
+            const int w = c - g.pad;
+            slab[buf][srow][c] = (ok && w >= 0 && w < g.W) ? src[(long)w * g.sw] : 0.f;
         }
-        const float* dzr = dz + row * lddz;
+    };
+    if (l0 < l1) stage(0, b, od, oh);
+    __syncthreads();
+    for (long line = l0; line < l1; ++line) {
+        const int buf = (int)((line - l0) & 1);
+        // next line's counters, and its rows staged into the other buffer while this line is consumed
+        int oh2 = oh + 1, od2 = od;
+        long b2 = b;
+        if (oh2 == g.Ho) {
+            oh2 = 0;
+            if (++od2 == g.Do) {
+                od2 = 0;
+                ++b2;
+            }
+        }
+        if (line + 1 < l1) stage(buf ^ 1, b2, od2, oh2);
+        const float* sp = &slab[buf][kd * K + kh][kw];
+        const float* dzl = dz + line * g.Wo * lddz;
+#pragma unroll 4
+        for (int ow = 0; ow < g.Wo; ++ow) {
+            float v = 0.f;
+            if (tap < K3) v = sp[ow * g.stride];
+            else if (tap == K3) v = 1.0f;                   // bias lane
+            const float* dzr = dzl + (long)ow * lddz;       // wave-uniform: scalar loads
 #pragma unroll
-        for (int o = 0; o < CO; ++o) acc[o] = fmaf(dzr[o], v, acc[o]);
+            for (int o = 0; o < CO; ++o) acc[o] = fmaf(dzr[o], v, acc[o]);
+        }
+        oh = oh2; od = od2; b = b2;
+        __syncthreads();
     }
     float* out = slabs + (size_t)blockIdx.x * CO * 128;
 #pragma unroll
@@ -279,11 +312,12 @@ extern "C" int pm_conv3d_c1_wgrad_f32(const float* dz, long lddz, const float* x
     Conv3dGeom g;
     const int rc = conv3d_geom(g, 1, D, H, W, k, stride, pad, sb, 0, sd, sh, sw, k * k * k);
     if (rc != PM_OK) return rc;
-    const long nrows = (long)B * g.Do * g.Ho * g.Wo;
-    long per = (nrows + C1_WG_SLABS - 1) / C1_WG_SLABS;
-    if (per < 64) per = 64;
-    const int nwg = (int)((nrows + per - 1) / per);
-    hipLaunchKernelGGL((conv3d_c1_wgrad_kernel<5, 16>), dim3(nwg), dim3(128), 0, pm_stream(stream), dz, lddz, x, g, nrows,
+    if (W > C1_MAXW) return PM_EUNSUPPORTED;
+    const long nlines = (long)B * g.Do * g.Ho;
+    long per = (nlines + C1_WG_SLABS - 1) / C1_WG_SLABS;
+    if (per < 4) per = 4;
+    const int nwg = (int)((nlines + per - 1) / per);
+    hipLaunchKernelGGL((conv3d_c1_wgrad_kernel<5, 16>), dim3(nwg), dim3(128), 0, pm_stream(stream), dz, lddz, x, g, nlines,
                        per, (float*)workspace);
     hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(Cout), dim3(128), 0, pm_stream(stream),
                        (const float*)workspace, nwg, Cout, k * k * k, dW, lddw, db);
