@@ -64,20 +64,17 @@ __global__ __launch_bounds__(256) void col2im3d_kernel(const float* __restrict__
         const int d = (int)(r % g.D);
         const long b = r / g.D;
         float s = 0.f;
-        for (int kd = 0; kd < g.k; ++kd) {
-            const int td = d + g.pad - kd;
-            if (td < 0 || td % g.stride) continue;
-            const int od = td / g.stride;
+        // only the taps congruent to (x + pad) mod stride can have read this element: start there and step by the stride
+        // (with stride == k, the shipped layers, that is ONE tap per dimension instead of k tests); same summation order
+        const int pd = d + g.pad, ph = h + g.pad, pw = w + g.pad;
+        for (int kd = pd % g.stride; kd < g.k && kd <= pd; kd += g.stride) {
+            const int od = (pd - kd) / g.stride;
             if (od >= g.Do) continue;
-            for (int kh = 0; kh < g.k; ++kh) {
-                const int th = h + g.pad - kh;
-                if (th < 0 || th % g.stride) continue;
-                const int oh = th / g.stride;
+            for (int kh = ph % g.stride; kh < g.k && kh <= ph; kh += g.stride) {
+                const int oh = (ph - kh) / g.stride;
                 if (oh >= g.Ho) continue;
-                for (int kw = 0; kw < g.k; ++kw) {
-                    const int tw = w + g.pad - kw;
-                    if (tw < 0 || tw % g.stride) continue;
-                    const int ow = tw / g.stride;
+                for (int kw = pw % g.stride; kw < g.k && kw <= pw; kw += g.stride) {
+                    const int ow = (pw - kw) / g.stride;
                     if (ow >= g.Wo) continue;
                     const long row = ((b * g.Do + od) * g.Ho + oh) * g.Wo + ow;
                     s += dcols[row * g.ldc + c * k3 + kd * kk + kh * g.k + kw];
