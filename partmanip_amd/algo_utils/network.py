@@ -486,9 +486,10 @@ class Conv3DNet(_HipNet):
     Conv3d(32,32,k3,s2) - act on a res^3 volume (50^3 -> 17^3 -> 6^3 -> 3^3), flatten (channels first, 32*27)
     [+ proprio] -> Linear 256 - act - Linear out.  `state_dict` keys and default initialisation are the
     reference's (`encoder.conv{1,2,3}.{weight,bias}`, `final_mlp.{0,2}.*`).
-    Each convolution runs as a patch gather (pm_im2col3d_f32) + the fp32 MFMA Linear kernel on
-    conv.weight viewed (Cout, Cin*k^3); layer outputs stay channels-last ((b, d, h, w) rows x Cout) and are read
-    through strides by the next gather.  Backward: Linear backward kernels + pm_col2im3d_f32 (which folds tanh')."""
+    The single-channel input layer is a direct 125-tap stencil (pm_conv3d_c1_fwd_f32 / pm_conv3d_c1_wgrad_f32: no patch
+    matrix); layers 2-3 run as a patch gather (pm_im2col3d_f32) + the fp32 MFMA Linear kernel on conv.weight viewed
+    (Cout, Cin*k^3); layer outputs stay channels-last ((b, d, h, w) rows x Cout) and are read through strides by the
+    next gather.  Backward: Linear backward kernels + pm_col2im3d_f32 (which folds tanh')."""
 
     FILTERS, KERNELS, STRIDES = (16, 32, 32), (5, 3, 3), (3, 3, 2)
 

@@ -8,6 +8,7 @@
 // HBM-bound, coalesced over the column index.
 // x is addressed through element strides (sb, sc, sd, sh, sw), so the same kernels read the channels-first
 // network input and the channels-last (rows x Cout) outputs of the previous layer's Linear kernel.
+// The single-channel INPUT layer does not take this route: see "direct conv of the input layer" below.
 #include "common.h"
 
 struct Conv3dGeom {
