@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void col2im3d_kernel(const float* __restrict__ dcols, Conv3dGeom g, long total,
                                                         const float* __restrict__ y_tanh, float* __restrict__ dx) {
     const int k3 = g.k * g.k * g.k, kk = g.k * g.k;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+#pragma unroll 4                                   // four independent elements in flight per thread: the chain decode -> load ->
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {   // load -> store is latency-bound
         // e enumerates (b, d, h, w, c) with c fastest: consecutive threads read consecutive patch columns' channels
         long r = e;
         const int c = (int)(r % g.C); r /= g.C;
