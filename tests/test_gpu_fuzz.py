@@ -90,6 +90,42 @@ def test_conv3d_gather_scatter_random_geometry():
         assert rel(dx, dx_ref) < 3e-5, (it, B, C, D, H, W, k, st, pad)
 
 
+def test_conv3d_input_layer_direct_kernels_random_geometry():
+    """pm_conv3d_c1_fwd_f32 / pm_conv3d_c1_wgrad_f32 (the single-channel 5^3 x 16 input layer as a direct stencil) against
+    F.conv3d and its autograd weight / bias gradients for random extents (D != H != W), strides, paddings, batch sizes
+    (work-group slices that end mid-volume) and a strided (row-of-a-wider-tensor) input view."""
+    o = ops()
+    rng = np.random.default_rng(7)
+    for it in range(12):
+        B = int(rng.choice([1, 2, 5, 40]))
+        D, H, W = (int(v) for v in rng.integers(5, 30, size=3))
+        st, pad = int(rng.integers(1, 4)), int(rng.integers(0, 4))
+        g = torch.Generator().manual_seed(700 + it)
+        tail = int(rng.integers(0, 9))                       # the volume is the head of a wider observation row
+        row = torch.randn(B, D * H * W + tail, generator=g)
+        x = row[:, :D * H * W].unflatten(1, (1, D, H, W)).detach().clone().requires_grad_(True)
+        w = (torch.randn(16, 1, 5, 5, 5, generator=g) * 0.1).requires_grad_(True)
+        bias = (torch.randn(16, generator=g) * 0.1).requires_grad_(True)
+        act = bool(it % 2)
+        ref = F.conv3d(x, w, bias, stride=st, padding=pad)
+        if act:
+            ref = torch.tanh(ref)
+        x5 = row.to(DEV)[:, :D * H * W].unflatten(1, (1, D, H, W))
+        wt = w.detach().reshape(16, 125).t().contiguous().to(DEV)
+        y = o.conv3d_c1_fwd(x5, 5, st, pad, wt, bias.detach().to(DEV), o.ACT_TANH if act else o.ACT_NONE)
+        got = y.view(B, *ref.shape[2:], 16).permute(0, 4, 1, 2, 3)
+        assert rel(got, ref.detach()) < 3e-5, (it, B, D, H, W, st, pad)
+        dyr = torch.randn(ref.shape, generator=g)
+        dw_ref, db_ref = torch.autograd.grad((ref * dyr).sum(), [w, bias])
+        dz = dyr * (1 - ref.detach() ** 2) if act else dyr    # gradient at the pre-activation
+        dz2 = dz.permute(0, 2, 3, 4, 1).reshape(-1, 16).contiguous().to(DEV)
+        dw = torch.empty(16, 125, device=DEV)
+        db = torch.empty(16, device=DEV)
+        o.conv3d_c1_wgrad(dz2, x5, 5, st, pad, dw, db, o.Workspace(DEV))
+        assert rel(dw, dw_ref.reshape(16, 125)) < 5e-5, (it, "dW", B, D, H, W, st, pad)
+        assert rel(db, db_ref) < 5e-5, (it, "db")
+
+
 def test_gae_random_shapes_bit_exact():
     o = ops()
     rng = np.random.default_rng(2)
