@@ -2,22 +2,24 @@
 """bench.py -- PPO learner throughput on MI355X (BASELINE.json metric: PPO env-steps/sec,
 4096 envs x 1024-pt clouds).
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload vision|state]
+    python bench.py [--gpus N --steps K --warmup W] [--workload vision|vision_pn2|state|dagger|depth2pc]
 
 A "step" is one learner iteration = the reference's `learn_time` window (ppo.py:256-262:
 compute_returns + update + storage.clear) over one synthetic rollout batch that is already
-resident in HBM.  env-steps/s = N_env * T * world / (time per step).  One process per GPU;
-for N > 1 launch under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from the env):
-each rank owns its own 4096 envs (weak scaling) and gradients are all-reduced over RCCL once
-per optimiser step.
+resident in HBM.  env-steps/s = N_env * T * world / (time per step).  One process per GPU:
+under torch.distributed.run the ranks come from RANK / LOCAL_RANK / WORLD_SIZE; a bare
+`python bench.py --gpus N` starts the N ranks itself (and refuses when fewer than N GPUs are
+visible).  Each rank owns its own 4096 envs (weak scaling) and gradients are all-reduced over
+RCCL once per optimiser step.
 
-Rank 0 prints ONE JSON line including
-  roofline     : live HIP-event timing of the dominant kernel (fused PointNet encoder forward)
-                 against the fp32-MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
-  cpu_baseline : the CPU oracle (oracle/ref_cpu.py, pinned to the reference) timed on this
-                 box's host cores on a bounded sample of the same workload (N = 1 only).
+Rank 0 prints ONE JSON line; every workload's line carries
+  roofline     : live HIP-event timing of the workload's dominant kernel against the roofline that
+                 bounds it (fp32-MFMA 157.3 TFLOP/s or HBM 8 TB/s, MI355X_MICROARCH.md)
+  cpu_baseline : the CPU oracle (oracle/ref_cpu.py, pinned to the reference) timed on this box's
+                 host cores on a bounded, warmed sample of the same workload (N = 1 only).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -29,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
 ENC_MAC_PER_POINT = 3 * 128 + 128 * 256 + 256 * 512          # 164 224
 
 WORKLOADS = {
@@ -42,17 +45,105 @@ WORKLOADS = {
     "state": dict(name="ppo_state_mlp_4096env_x_128step", N=4096, T=128, O=53, A=10,
                   net=dict(name="MLP", hid_dim=[512, 512, 512], activation="tanh")),
 }
-
+SA_LEVELS = {"64x64x128": (64, 64, 128, 256), "128x128x256": (128, 128, 256, 64)}     # C1, C2, C3, groups per cloud
 
 DAGGER = dict(name="dagger_pointnet_student_4096env_x_16buf_x_{P}pt", N=4096, buf=16, O_t=53, A=10)
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _pick_threads(trial, ncpu):
+    """The oracle is plain PyTorch-CPU; `torch.set_num_threads(os.cpu_count())` on a 2-socket SMT box oversubscribes
+    the intra-op pool (round 1 measured 2.6x SLOWER per sample with 256 threads than the survey's 8-thread probe).
+    Time a small warm-up pass at a few thread counts and keep the fastest; the passes double as the warm-up."""
+    cand = sorted({n for n in (8, 16, 32, 64, 96, 128, ncpu // 2, ncpu) if 1 <= n <= ncpu})
+    best, tbest, log = cand[0], float("inf"), {}
+    for n in cand:
+        torch.set_num_threads(n)
+        trial()                                        # first touch at this thread count (allocator, thread pool)
+        t0 = time.perf_counter()
+        trial()
+        dt = time.perf_counter() - t0
+        log[n] = round(dt, 3)
+        if dt < tbest:
+            best, tbest = n, dt
+    torch.set_num_threads(best)
+    return best, log
+
+
+def cpu_baseline_ppo(w, rollout_cpu, sd_cpu, cfg):
+    """the oracle's `ppo_update` (which, like the reference, runs BOTH networks forward in both loops)
+    warmed, on >= 3 actor + >= 3 critic mini-batch steps -- B = 512 for the point-cloud backbones (B = 2048 needs ~15 GB
+    of activations per net; stated fallback), B = 2048 for the MLP -- plus the full-size GAE, extrapolated by the exact
+    step count n_updates * T * N / B per loop."""
+    from oracle import ref_cpu as R
+    ncpu = os.cpu_count() or 1
+    vision = w["net"]["name"] in ("PointNet", "PointNet2")
+    mb, n_mb = (512, 3) if vision else (2048, 16)
+    T, N = w["T"], w["N"]
+    keys = ("observations", "actions", "values", "returns", "actions_log_prob", "advantages", "mu", "sigma")
+
+    def sample(mb_, n_):
+        return {k: rollout_cpu[k].reshape(-1, rollout_cpu[k].shape[-1])[: mb_ * n_].reshape(n_, mb_, -1).clone() for k in keys}
+
+    def run(mb_, n_):
+        c = dict(cfg)
+        c.update(n_updates=1, n_minibatches=n_, sampler="sequential", device="cpu")
+        p = {k: v.clone() for k, v in sd_cpu.items()}
+        t0 = time.perf_counter()
+        R.ppo_update(p, sample(mb_, n_), c, 1)          # n_ actor steps + n_ critic steps
+        return time.perf_counter() - t0
+
+    used, tried = _pick_threads(lambda: run(32 if vision else 2048, 1), ncpu)
+    gae = lambda: R.gae_returns(rollout_cpu["rewards_full"], rollout_cpu["values_full"], rollout_cpu["dones_full"],
+                                rollout_cpu["succs_full"], rollout_cpu["last_values"], 0.99, 0.95, None, False)
+    gae()
+    t0 = time.perf_counter()
+    gae()
+    t_gae = time.perf_counter() - t0
+    t_upd = run(mb, n_mb)
+    per_sample = t_upd / (mb * n_mb)                    # one actor pass + one critic pass of one sample
+    t_iter = t_gae + per_sample * cfg["n_updates"] * T * N
+    return dict(value=T * N / t_iter, unit="env-steps/s", cores=used, kind="port", host_cpus=ncpu,
+                threads_tried_s=tried,
+                sample=f"oracle/ref_cpu.py ppo_update, warmed, {n_mb} actor + {n_mb} critic mini-batch steps of {mb} samples "
+                       f"({t_upd:.1f} s) + full GAE ({t_gae * 1e3:.1f} ms), extrapolated to {cfg['n_updates']} epochs x "
+                       f"{T * N} samples per loop; {used} torch threads (fastest of {sorted(tried)} on {ncpu} host CPUs)")
+
+
+def cpu_baseline_dagger(d, net, ring_obs, ring_tea, stu_sd, tea_sd, tea_net, rows_total, proprio):
+    """Oracle `dagger_update` (frozen teacher forward + student forward/backward + Adam) on 3 mini-batches of `mb`
+    ring rows, warmed; extrapolated by the row count of one update (n_updates passes over the ring)."""
+    from oracle import ref_cpu as R
+    ncpu = os.cpu_count() or 1
+    mb = 128
+    model = lambda n, std: dict(action_std=std, action_activate="tanh", clipAction=1.0, network=dict(n))
+    cfg = dict(model=model(net, 0.1), tea_model=model(tea_net, 0.5), n_updates=1, n_minibatches=3, sampler="sequential",
+               lr=5e-5, lr_schedule="fixed", max_iterations=10000, proprio_shape=proprio)
+
+    def run(mb_, n_):
+        c = dict(cfg, n_minibatches=n_)
+        stu = {k: v.clone() for k, v in stu_sd.items()}
+        t0 = time.perf_counter()
+        R.dagger_update(stu, tea_sd, ring_obs[: mb_ * n_], ring_tea[: mb_ * n_], mb_ * n_, c, 1)
+        return time.perf_counter() - t0
+
+    used, tried = _pick_threads(lambda: run(16, 1), ncpu)
+    t = run(mb, 3)
+    per_row = t / (3 * mb)
+    t_upd = per_row * rows_total
+    return dict(value=d["N"] / t_upd, unit="env-steps/s", cores=used, kind="port", host_cpus=ncpu, threads_tried_s=tried,
+                sample=f"oracle/ref_cpu.py dagger_update, warmed, 3 mini-batch steps of {mb} ring rows ({t:.1f} s), extrapolated to "
+                       f"{rows_total} rows per update; {used} torch threads (fastest of {sorted(tried)} on {ncpu} host CPUs)")
+
+
+# ------------------------------------------------------------------------------------------------ DAgger
 def run_dagger(args, device, rank, world):
     """cfg 5 analogue: DAgger, N=4096, n_steps 1, buf_size 16, PointNet student on 4096-pt
     clouds (`--points`; the reference hard-codes 1024, network.py:146; the 3D-Sparse-UNet cfg 5 names does not exist
     in the reference), frozen MLP teacher (O=53), random sampler, n_updates 2, n_minibatches 16 (-> 2048).
     A step = one `dagger.update` over the full ring (65 536 rows); env-steps/s = N * n_steps / time."""
     import tempfile
+    from partmanip_amd import ops
     from partmanip_amd.algorithms import ppo, dagger
     from partmanip_amd.feeder import FeederEnv, ScreenLogger
     conv = args.student == "conv3d"
@@ -70,7 +161,8 @@ def run_dagger(args, device, rank, world):
                     seed=1234 + rank, point_num=args.points)
     tcfg = make_cfg(WORKLOADS["state"], device)
     tcfg.update(num_envs=d["N"], n_steps=1, obs_mode="normal_state")
-    tea = ppo(env, tcfg, ScreenLogger(tmp, "tea", "n", quiet=True))
+    tea = ppo(env, tcfg, ScreenLogger(tmp, f"tea{rank}", "n", quiet=True))
+    tea.sync = None                                      # every rank writes its own (identical) teacher checkpoint
     tea.save(1)
     net = (dict(name="Conv3DNet", activation="tanh") if conv else
            dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False, point_num=args.points))
@@ -93,21 +185,62 @@ def run_dagger(args, device, rank, world):
             torch.cuda.synchronize()
     for _ in range(args.warmup):
         run.update(1)
+    timed = ("conv3d_c1_wgrad", "conv3d_c1_fwd") if conv else ("pointnet_enc_fwd", "pointnet_enc_bwd")
+    ops.TIMER.enable(*timed)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run.update(1)
     fence()
     dt = time.perf_counter() - t0
+    ops.TIMER.disable()
+    dt = _max_over_ranks(dt, device, world)
     rows = d["N"] * d["buf"] * 2                        # samples through the student per update
-    return dict(metric="DAgger update throughput (shipped dagger_tsdf.yaml)" if conv else "DAgger update throughput (cfg 5 analogue)",
-                value=d["N"] * 1 * world / (dt / args.steps),
-                unit="env-steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
-                data="synthetic", config=dict(workload=d["name"], ring_rows=d["N"] * d["buf"],
-                                              minibatch=min(d["N"] * d["buf"] // 16, 2048),
-                                              student_samples_per_s=rows * world / (dt / args.steps),
-                                              dagger_loss=float(run.log_dict["Train/dagger_loss"])))
+    mb = min(d["N"] * d["buf"] // 16, 2048)
+    out = dict(metric="DAgger update throughput (shipped dagger_tsdf.yaml)" if conv else "DAgger update throughput (cfg 5 analogue)",
+               value=d["N"] * 1 * world / (dt / args.steps),
+               unit="env-steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+               data="synthetic", config=dict(workload=d["name"], ring_rows=d["N"] * d["buf"], minibatch=mb,
+                                             parallelism=f"dp{world}", world_size_observed=_world_observed(),
+                                             student_samples_per_s=rows * world / (dt / args.steps),
+                                             dagger_loss=float(run.log_dict["Train/dagger_loss"])))
+    if conv:
+        # dominant kernel: the input layer's weight gradient (a 125-tap stencil reduction): per sample it reads the 50^3
+        # volume (500 KB) and the 17^3 x 16 dz rows (314 KB) once -> HBM-bound by construction (FMA bound 3x lower)
+        t = ops.TIMER.mean_ms("conv3d_c1_wgrad")
+        if t:
+            nbytes = mb * (50 ** 3 + 17 ** 3 * 16) * 4.0
+            gbs = nbytes / (t[0] * 1e-3) / 1e9
+            out["roofline"] = dict(bound="hbm", kernel="conv3d_c1_wgrad_kernel", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
+                                   frac=gbs / PEAK_HBM_GBS, traffic=None, launches=t[1], mean_launch_ms=t[0],
+                                   bytes_per_launch=nbytes)
+            f = ops.TIMER.mean_ms("conv3d_c1_fwd")
+            if f:
+                out["roofline"]["conv1_fwd_mean_ms"] = f[0]
+                out["roofline"]["conv1_fwd_gbs"] = nbytes / (f[0] * 1e-3) / 1e9
+    else:
+        t = ops.TIMER.mean_ms("pointnet_enc_fwd")
+        if t:
+            flops = 2.0 * ENC_MAC_PER_POINT * args.points * mb
+            tf = flops / (t[0] * 1e-3) / 1e12
+            out["roofline"] = dict(bound="mfma", kernel="pn_fwd_kernel", achieved=tf, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                                   frac=tf / PEAK_F32_MFMA_TFLOPS, traffic=None, launches=t[1], mean_launch_ms=t[0],
+                                   flops_per_launch=flops)
+            b = ops.TIMER.mean_ms("pointnet_enc_bwd")
+            if b:
+                bflops = 2.0 * 2 * 256 * 128 * args.points * mb
+                out["roofline"].update(enc_bwd_mean_ms=b[0], enc_bwd_executed_tflops=bflops / (b[0] * 1e-3) / 1e12,
+                                       enc_bwd_frac=bflops / (b[0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = lambda t: t.detach().cpu()
+        n_rows = 3 * 128
+        out["cpu_baseline"] = cpu_baseline_dagger(
+            d, net, cpu(run.storage.observations.view(-1, d["O_s"])[:n_rows]), cpu(run.storage.tea_obs.view(-1, d["O_t"])[:n_rows]),
+            {k: cpu(v).clone() for k, v in run.student.state_dict().items()},
+            {k: cpu(v).clone() for k, v in run.teacher.state_dict().items()}, WORKLOADS["state"]["net"], rows, d["proprio"])
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
 
 
 def make_cfg(w, device):
@@ -121,37 +254,7 @@ def make_cfg(w, device):
                 sampler="sequential", resume=None)
 
 
-def cpu_baseline(w, rollout_cpu, sd_cpu, cfg):
-    """Time the oracle's actor + critic mini-batch passes on a bounded sample and extrapolate to a
-    full iteration: per-sample cost x (n_updates * T*N samples) for each of the two loops."""
-    from oracle import ref_cpu as R
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
-    vision = w["net"]["name"] in ("PointNet", "PointNet2")
-    mb = 128 if vision else 2048                     # CPU PointNet pass: ~6 s per 128 samples (SURVEY.md §6)
-    n_mb = 1 if vision else 4
-    T, N = w["T"], w["N"]
-    keys = ("observations", "actions", "values", "returns", "actions_log_prob", "advantages", "mu", "sigma")
-    sub = {k: rollout_cpu[k].reshape(-1, rollout_cpu[k].shape[-1])[: mb * n_mb].reshape(n_mb, mb, -1).clone() for k in keys}
-    p = {k: v.clone() for k, v in sd_cpu.items()}
-    c = dict(cfg)
-    c.update(n_updates=1, n_minibatches=n_mb, sampler="sequential", device="cpu")
-    t0 = time.perf_counter()
-    R.gae_returns(rollout_cpu["rewards_full"], rollout_cpu["values_full"], rollout_cpu["dones_full"],
-                  rollout_cpu["succs_full"], rollout_cpu["last_values"], 0.99, 0.95, None, False)
-    t_gae = time.perf_counter() - t0
-    st = {k: sub[k] for k in keys}
-    t0 = time.perf_counter()
-    R.ppo_update(p, st, c, 1)                         # n_mb actor steps + n_mb critic steps
-    t_upd = time.perf_counter() - t0
-    per_sample = t_upd / (mb * n_mb)                  # one actor pass + one critic pass of one sample
-    t_iter = t_gae + per_sample * cfg["n_updates"] * T * N
-    return dict(value=T * N / t_iter, unit="env-steps/s", cores=ncores, kind="port",
-                sample=f"oracle/ref_cpu.py ppo_update on {n_mb} actor + {n_mb} critic mini-batches of {mb} samples "
-                       f"({t_upd:.1f} s) + full GAE ({t_gae * 1e3:.1f} ms), extrapolated to "
-                       f"{cfg['n_updates']} epochs x {T * N} samples; {ncores} torch threads")
-
-
+# ------------------------------------------------------------------------------------------------ depth2pc
 def run_depth2pc(args, device):
     """Observation-side step with the only timing the reference publishes: the cloud sampling
     of `TSDFVolume.depth2pc` for 64 envs x 6 views x 180 x 320 px -> 1024 points, "slow.. ~0.5s"
@@ -164,7 +267,8 @@ def run_depth2pc(args, device):
     pose = torch.eye(4).repeat(m, 1, 1)
     for i in range(m):
         pose[i, :3, 3] = torch.tensor([0.02 * i, -0.01 * i, -0.6])
-    vol.register_camera(pose.numpy(), [[250.0, 0.0, w_ / 2 - 0.5], [0.0, 250.0, h / 2 - 0.5], [0.0, 0.0, 1.0]], h, w_, b)
+    intr = [[250.0, 0.0, w_ / 2 - 0.5], [0.0, 250.0, h / 2 - 0.5], [0.0, 0.0, 1.0]]
+    vol.register_camera(pose.numpy(), intr, h, w_, b)
     torch.manual_seed(0)
     depth = torch.rand(b, m, h, w_, device=device) * 0.5 + 0.45
 
@@ -182,11 +286,13 @@ def run_depth2pc(args, device):
     lo = vol._vol_origin.cpu().numpy()
     world = ops.depth_backproject(depth, vol.cam_pose, 250.0, 250.0, w_ / 2 - 0.5, h / 2 - 0.5, lo, vol._size + lo)
     ws = ops.Workspace(device)
+    c0, n0 = ops.depth_compact(world)
 
     def sample():
         c, n = ops.depth_compact(world)
         ops.group_points(c, ops.fps_varlen(c, n, 1024, ws).view(b, 1024, 1))
     ds = timed(sample, args.steps)
+    dfps = timed(lambda: ops.fps_varlen(c0, n0, 1024, ws), args.steps)
     valid = float((world != 0).any(-1).float().mean())
     # the other sampling call site (depth2tsdf.py:88-120, the 'depth_sparse' observation) on a scene with a surface:
     # a tilted plane seen by all views, 50^3 grid -> integrate + band select + FPS(1024) + gather
@@ -194,15 +300,40 @@ def run_depth2pc(args, device):
     plane = (0.75 + 0.0004 * xx + 0.0006 * yy).float().expand(b, m, h, w_).contiguous()
     band = vol.integrate(plane).abs().lt(0.2).flatten(1).sum(-1).float().mean().item()
     dv = timed(lambda: vol.sparse_voxel(plane), args.steps)
-    return dict(metric="depth2pc seconds per call, 64 envs x 6 views x 180x320 px -> 1024 pts", value=dt, unit="s",
-                n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3, higher_is_better=False,
-                scaling="weak", vs_baseline=ds / 0.5, dtype="f32", data="synthetic",
-                config=dict(workload="depth2pc_64env_x_6view_x_180x320", sampling_ms=ds * 1e3, in_crop_fraction=valid,
-                            sparse_voxel_ms=dv * 1e3, sparse_voxel_band_voxels=band,
-                            baseline="'~0.5s' for the sampling alone, utils/depth2tsdf.py:158 (BASELINE.md); "
-                                     "vs_baseline = sampling time / 0.5 s"))
+    out = dict(metric="depth2pc seconds per call, 64 envs x 6 views x 180x320 px -> 1024 pts", value=dt, unit="s",
+               n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3, higher_is_better=False,
+               scaling="weak", vs_baseline=ds / 0.5, dtype="f32", data="synthetic",
+               config=dict(workload="depth2pc_64env_x_6view_x_180x320", sampling_ms=ds * 1e3, in_crop_fraction=valid,
+                           sparse_voxel_ms=dv * 1e3, sparse_voxel_band_voxels=band,
+                           baseline="'~0.5s' for the sampling alone, utils/depth2tsdf.py:158 (BASELINE.md); "
+                                    "vs_baseline = sampling time / 0.5 s"))
+    # dominant kernel: streaming farthest-point sampling -- every one of the K rounds re-reads each surviving point
+    # (12 B) and its running min-distance (4 B) and writes the min-distance back (4 B)
+    pts = float(n0.float().sum().item())
+    nbytes = 1024.0 * pts * 20.0
+    gbs = nbytes / dfps / 1e9
+    out["roofline"] = dict(bound="hbm", kernel="fps_varlen (streaming rounds)", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
+                           frac=gbs / PEAK_HBM_GBS, traffic=None, mean_launch_ms=dfps * 1e3, bytes_per_launch=nbytes,
+                           note="64 clouds x ~134 k surviving points: the 1024 rounds re-read a working set that sits in the 256 MB "
+                                "Infinity Cache, so `achieved` is cache + HBM bandwidth, not DRAM traffic")
+    if not args.no_cpu_baseline:
+        from oracle import ref_cpu as R
+        ncpu = os.cpu_count() or 1
+        nt = 1                                            # the restatement is numpy, one thread
+        nb = 2                                            # bounded sample: 2 of the 64 envs
+        dc = depth[:nb].cpu()
+        size = float(vol._size)
+        R.depth2pc(dc[:1], pose, intr, size, lo, K=16)    # warm-up
+        t0 = time.perf_counter()
+        R.depth2pc(dc, pose, intr, size, lo, K=1024)
+        tc = (time.perf_counter() - t0) * b / nb
+        out["cpu_baseline"] = dict(value=tc, unit="s", cores=nt, kind="port", host_cpus=ncpu,
+                                   sample=f"oracle/ref_cpu.py depth2pc (numpy, single-threaded) on {nb} of the {b} envs, scaled by {b // nb}")
+        out["gpu_over_cpu"] = tc / dt
+    return out
 
 
+# ------------------------------------------------------------------------------------------------ PPO workloads
 def build_runner(w, cfg, device, rank):
     """Runner + one synthetic rollout produced by the freshly initialised policy (ratio ~ 1, KL ~ 0) + the
     timed step: restore the initial policy / optimiser state, then the reference's `learn` window."""
@@ -239,43 +370,32 @@ def build_runner(w, cfg, device, rank):
     return run, ac, st, last_values, step
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="vision", choices=list(WORKLOADS) + ["dagger", "depth2pc"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--n-steps", type=int, default=0, help="override the rollout length T (e.g. 128 for the vision workload)")
-    ap.add_argument("--student", default="pointnet", choices=["pointnet", "conv3d"],
-                    help="dagger workload: PointNet on --points clouds (cfg 5 analogue) or the reference's shipped Conv3DNet config")
-    ap.add_argument("--points", type=int, default=4096, help="dagger workload: points per student cloud (BASELINE cfg 5: 4096)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x6"],
-                    help="vision encoder forward: exact fp32 MFMA (default) or the opt-in split-bf16 path")
-    args = ap.parse_args()
+def _world_observed():
+    d = torch.distributed
+    return d.get_world_size() if d.is_available() and d.is_initialized() else 1
 
-    from partmanip_amd import dist as pdist, ops
-    rank, world, local = pdist.init_from_env("nccl")
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
-    torch.cuda.set_device(local)
-    device = f"cuda:{local}"
-    if args.workload == "depth2pc":
-        if rank == 0:
-            print(json.dumps(run_depth2pc(args, device)))
-        if world > 1:
-            torch.distributed.destroy_process_group()
-        return
-    if args.workload == "dagger":
-        import contextlib
-        with contextlib.redirect_stdout(sys.stderr):       # the runners print progress lines: keep stdout = ONE JSON line
-            out = run_dagger(args, device, rank, world)
-        if rank == 0:
-            print(json.dumps(out))
-        if world > 1:
-            torch.distributed.destroy_process_group()
-        return
+
+def _max_over_ranks(dt, device, world):
+    if world == 1:
+        return dt
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    return float(tmax.item())
+
+
+def _hbm_traffic(key):
+    """HBM bytes per launch from the PMC pass (rocprofv3 --pmc in its own run, gfx950 corrections applied, as
+    MI355X_MICROARCH.md prescribes; tools/pmc_run.sh -> profiles/hbm_traffic.json).  Counters cannot be collected from
+    inside this process, so the figure is the committed measurement of the same kernel at the same launch shape."""
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(tfile):
+        return None, None
+    j = json.load(open(tfile))
+    return j.get(key), j.get("source")
+
+
+def run_ppo(args, device, rank, world):
+    from partmanip_amd import ops
     w = dict(WORKLOADS[args.workload])
     if args.n_steps:
         w["T"] = args.n_steps
@@ -294,12 +414,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    dominant = "pointnet_enc_fwd" if args.workload == "vision" else None
-    if dominant:
-        ops.TIMER.enable(dominant, "pointnet_enc_bwd")
-    SA_LEVELS = {"64x64x128": (64, 64, 128, 256), "128x128x256": (128, 128, 256, 64)}     # C1, C2, C3, groups per cloud
+    timers = ["gae_scan"]
+    if args.workload == "vision":
+        timers += ["pointnet_enc_fwd", "pointnet_enc_bwd"]
     if args.workload == "vision_pn2":
-        ops.TIMER.enable(*[f"sa_{d}_{k}" for d in ("fwd", "bwd") for k in SA_LEVELS])
+        timers += [f"sa_{d}_{k}" for d in ("fwd", "bwd") for k in SA_LEVELS]
+    ops.TIMER.enable(*timers)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -307,35 +427,42 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ops.TIMER.disable()
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = _max_over_ranks(dt, device, world)
     ms_per_step = dt / args.steps * 1e3
     value = w["N"] * w["T"] * world / (dt / args.steps)
 
-    metric = ("PPO env-steps/sec (whole node), 4096 envs x 1024-pt clouds" if args.workload.startswith("vision")
+    vision = args.workload.startswith("vision")
+    metric = ("PPO env-steps/sec (whole node), 4096 envs x 1024-pt clouds" if vision
               else "PPO env-steps/sec (whole node), 4096 envs x 128 steps, state obs (BASELINE cfg 2)")
     out = dict(metric=metric, value=value, unit="env-steps/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32" if args.precision == "f32" else f"f32 (encoder forward: {args.precision} split MFMA)",
                data="synthetic",
-               config=dict(workload=w["name"], envs_per_gpu=w["N"], n_steps=w["T"], points=1024 if args.workload.startswith("vision") else 0,
-                           minibatch=2048, n_updates=5, parallelism=f"dp{world}",
+               config=dict(workload=w["name"], envs_per_gpu=w["N"], n_steps=w["T"], points=1024 if vision else 0,
+                           minibatch=2048, n_updates=5, parallelism=f"dp{world}", world_size_observed=_world_observed(),
+                           backend=(torch.distributed.get_backend() if world > 1 else None),
                            train_scalars={k: float(v) for k, v in run.log_dict.items() if k.startswith("Train/")}))
-    if dominant:
-        mean_ms, n_launch = ops.TIMER.mean_ms(dominant)
+    gae = ops.TIMER.mean_ms("gae_scan")
+    gae_blk = None
+    if gae:
+        nbytes = 18.0 * w["T"] * w["N"]                    # r, V 8 B + 2 mask B in; ret, adv 8 B out
+        gae_blk = dict(kernel="gae_scan_kernel", bound="hbm", mean_launch_ms=gae[0], launches=gae[1], bytes_per_launch=nbytes,
+                       achieved_gbs=nbytes / (gae[0] * 1e-3) / 1e9, frac=nbytes / (gae[0] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                       note="T dependent steps per env, one launch per iteration: latency-bound")
+    if args.workload == "vision":
+        mean_ms, n_launch = ops.TIMER.mean_ms("pointnet_enc_fwd")
         flops = 2.0 * ENC_MAC_PER_POINT * 1024 * 2048           # one launch = 2048 clouds x 1024 points
         achieved = flops / (mean_ms * 1e-3) / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("pn_fwd_kernel_bytes_per_launch")
+        traffic, tsrc = _hbm_traffic("pn_fwd_kernel_bytes_per_launch")
         out["roofline"] = dict(bound="mfma", kernel="pn_fwd_kernel", achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS,
                                unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=traffic,
                                launches=n_launch, mean_launch_ms=mean_ms, flops_per_launch=flops,
-                               note="training forward: also writes the layer-2 activations (1 KB/point) that spare the "
-                                    "backward a recompute; 0.83 without that store (DESIGN.md 3.2)")
+                               traffic_source=tsrc,
+                               traffic_note="the TRAINING forward also writes the layer-2 activations (1 KB/point = 2.15 GB per "
+                                            "launch) that spare the backward a recompute: the traffic is ~1.1x the training "
+                                            "forward's algorithmic bytes (2.19 GB) but ~60x the op's own 38.5 MB (points in, "
+                                            "features out); at < 0.5 TB/s (6 % of the HBM peak) the kernel stays MFMA-bound "
+                                            "(DESIGN.md 3.2: backward -0.69 ms, forward +0.25 ms)")
         bwd = ops.TIMER.mean_ms("pointnet_enc_bwd")
         if bwd:
             out["roofline"]["enc_bwd_mean_ms"] = bwd[0]
@@ -346,78 +473,34 @@ def main():
             out["roofline"]["enc_bwd_frac"] = out["roofline"]["enc_bwd_executed_tflops"] / PEAK_F32_MFMA_TFLOPS
     if args.workload == "vision_pn2":
         # the four fused set-abstraction kernels; `achieved` counts the MFMA flops each launch EXECUTES
-        # (fwd: layers 2-3; bwd: dH2 + dW2 + dH1 -- layer 2 is loaded from what the forward saved) on 2048 clouds
+        # (fwd: layers 2-3; bwd: dW2 + dH1 [+ dH2 where it is dense] -- layer 2 is loaded from what the forward saved)
         kern = {}
         for k, (c1, c2, c3, S) in SA_LEVELS.items():
             rows = 2048.0 * S * 32
-            for d, macs in (("fwd", c1 * c2 + c2 * c3), ("bwd", 2 * c1 * c2 + c2 * c3)):
-                t = ops.TIMER.mean_ms(f"sa_{d}_{k}")
+            for d_, macs in (("fwd", c1 * c2 + c2 * c3), ("bwd", 2 * c1 * c2 + c2 * c3)):
+                t = ops.TIMER.mean_ms(f"sa_{d_}_{k}")
                 if t:
-                    kern[f"sa_{d}_{k}"] = dict(mean_launch_ms=t[0], launches=t[1], tflops=2 * rows * macs / (t[0] * 1e-3) / 1e12)
+                    kern[f"sa_{d_}_{k}"] = dict(mean_launch_ms=t[0], launches=t[1], tflops=2 * rows * macs / (t[0] * 1e-3) / 1e12)
         if kern:
             name = max(kern, key=lambda n: kern[n]["mean_launch_ms"] * kern[n]["launches"])
             out["roofline"] = dict(bound="mfma", kernel=name, achieved=kern[name]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
                                    unit="TFLOP/s", frac=kern[name]["tflops"] / PEAK_F32_MFMA_TFLOPS, traffic=None,
-                                   kernels=kern)
-    if args.workload == "vision" and args.precision == "f32" and world == 1:
-        # the same workload on the opt-in split-bf16 encoder forward (reported next to, not instead of, the fp32 line)
-        ac.actor.precision = ac.critic.precision = "bf16x3"
-        step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            step()
-        fence()
-        dt3 = (time.perf_counter() - t1) / 2
-        ac.actor.precision = ac.critic.precision = "f32"
-        out["optional_paths"] = dict(encoder_forward_bf16x3=dict(
-            value=w["N"] * w["T"] / dt3, unit="env-steps/s", ms_per_step=dt3 * 1e3,
-            note="pm_pointnet_enc_fwd_bf3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on bf16 MFMAs, fp32 accumulate; "
-                 "~1e-5 relative; passes the golden vision-PPO cases at the fp32 path's tolerances; backward stays fp32"))
-        # ... and on the three-plane split (six bf16 MFMAs per product block): the fp32 kernel's error level
-        ac.actor.precision = ac.critic.precision = "bf16x6"
-        step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            step()
-        fence()
-        dt6 = (time.perf_counter() - t1) / 2
-        ac.actor.precision = ac.critic.precision = "f32"
-        out["optional_paths"]["encoder_forward_bf16x6"] = dict(
-            value=w["N"] * w["T"] / dt6, unit="env-steps/s", ms_per_step=dt6 * 1e3,
-            note="pm_pointnet_enc_fwd_bf6: operands split into three bf16 planes, products a0b0+a0b1+a1b0+a0b2+a1b1+a2b0 "
-                 "on bf16 MFMAs with fp32 accumulate; error against fp64 no larger than the fp32 MFMA kernel's "
-                 "(tests/test_gpu_learner.py::test_pointnet_bf16x6_forward_has_fp32_class_error); backward stays fp32")
-        # ... with the critic loop issued on a second HIP stream next to the actor loop (bit-identical results; off by
-        # default for this workload because concurrent kernels blur the per-kernel timing the roofline block reports)
-        run.overlap = True
-        step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            step()
-        fence()
-        dto = (time.perf_counter() - t1) / 2
-        run.overlap = False
-        out["optional_paths"]["actor_critic_on_two_streams"] = dict(
-            value=w["N"] * w["T"] / dto, unit="env-steps/s", ms_per_step=dto * 1e3,
-            note="PARTMANIP_OVERLAP=1: same arithmetic, critic step k runs concurrently with actor step k")
-        # ... and through the PointNet++ (SSG) plug-in backbone BASELINE.json's config text names: FPS + ball query
-        # once per rollout, fused set-abstraction kernels (pm_sa_fwd_f32 / pm_sa_bwd_f32)
-        w2 = dict(WORKLOADS["vision_pn2"])
-        _, _, _, _, step2 = build_runner(w2, make_cfg(w2, device), device, rank)
-        step2()
-        fence()
-        t1 = time.perf_counter()
-        step2()
-        fence()
-        dt2 = time.perf_counter() - t1
-        out["optional_paths"]["pointnet2_ssg_backbone"] = dict(
-            value=w2["N"] * w2["T"] / dt2, unit="env-steps/s", ms_per_step=dt2 * 1e3, workload=w2["name"],
-            note="same rollouts, network.name = PointNet2 (npoints 256/64, radii 0.2/0.4, 32 samples, mlps 64-64-128 / "
-                 "128-128-256 / 256-512); fp32")
-        del step2
+                                   launches=kern[name]["launches"], mean_launch_ms=kern[name]["mean_launch_ms"], kernels=kern)
+    if args.workload == "state":
+        # 33.3 MFLOP of useful work per env-step (n_updates x 3 x (F_actor + F_critic)); the step is
+        # 2 x 1280 dependent mini-batch updates of 2048 samples
+        F = lambda dims: 2.0 * sum(a * b for a, b in zip(dims, dims[1:]))
+        hid = w["net"]["hid_dim"]
+        per_env_step = 5 * 3 * (F([w["O"]] + hid + [w["A"]]) + F([w["O"]] + hid + [1]))
+        tf = per_env_step * w["N"] * w["T"] / (dt / args.steps) / 1e12
+        out["roofline"] = dict(bound="mfma", kernel="whole learner iteration (2 x 1280 dependent MLP mini-batch updates)",
+                               achieved=tf, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
+                               traffic=None, flops_per_env_step=per_env_step,
+                               note="algorithmic flops of the iteration / its wall time: every launch gap is inside")
+    if gae_blk:
+        out.setdefault("roofline", {})["gae_scan"] = gae_blk
+    if args.workload == "vision" and args.precision == "f32" and world == 1 and not args.no_optional:
+        out["optional_paths"] = optional_paths(run, ac, w, step, fence)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = lambda t: t.detach().cpu()
         roll = dict(observations=cpu(st.observations), actions=cpu(st.actions), values=cpu(st.values),
@@ -425,11 +508,104 @@ def main():
                     mu=cpu(st.mu), sigma=cpu(st.sigma), rewards_full=cpu(st.rewards), values_full=cpu(st.values),
                     dones_full=cpu(st.dones), succs_full=cpu(st.succs), last_values=cpu(last_values))
         sd_cpu = {k: cpu(v).clone() for k, v in ac.state_dict().items()}
-        out["cpu_baseline"] = cpu_baseline(w, roll, sd_cpu, cfg)
+        out["cpu_baseline"] = cpu_baseline_ppo(w, roll, sd_cpu, cfg)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    return out
+
+
+def optional_paths(run, ac, w, step, fence):
+    """The same workload on the opt-in paths (reported next to, not instead of, the exact-fp32 line)."""
+    def timed(n=2):
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            step()
+        fence()
+        return (time.perf_counter() - t1) / n
+    res = {}
+    ac.actor.precision = ac.critic.precision = "bf16x3"
+    dt3 = timed()
+    res["encoder_forward_bf16x3"] = dict(
+        value=w["N"] * w["T"] / dt3, unit="env-steps/s", ms_per_step=dt3 * 1e3,
+        note="pm_pointnet_enc_fwd_bf3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on bf16 MFMAs, fp32 accumulate; "
+             "~1e-5 relative; passes the golden vision-PPO cases at the fp32 path's tolerances; backward stays fp32")
+    ac.actor.precision = ac.critic.precision = "bf16x6"
+    dt6 = timed()
+    ac.actor.precision = ac.critic.precision = "f32"
+    res["encoder_forward_bf16x6"] = dict(
+        value=w["N"] * w["T"] / dt6, unit="env-steps/s", ms_per_step=dt6 * 1e3,
+        note="pm_pointnet_enc_fwd_bf6: operands split into three bf16 planes, products a0b0+a0b1+a1b0+a0b2+a1b1+a2b0 "
+             "on bf16 MFMAs with fp32 accumulate; error against fp64 no larger than the fp32 MFMA kernel's "
+             "(tests/test_gpu_learner.py::test_pointnet_bf16x6_forward_has_fp32_class_error); backward stays fp32")
+    run.overlap = True
+    dto = timed()
+    run.overlap = False
+    res["actor_critic_on_two_streams"] = dict(
+        value=w["N"] * w["T"] / dto, unit="env-steps/s", ms_per_step=dto * 1e3,
+        note="PARTMANIP_OVERLAP=1: same arithmetic, critic step k runs concurrently with actor step k")
+    return res
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) of this same command line under
+    torch.distributed.run on this node and pass rank 0's ONE JSON line through.  Exits non-zero when fewer than N
+    devices are visible (PARTMANIP_SHARE_GPU=1 + PARTMANIP_DIST_BACKEND=gloo -- the 1-GPU debugging mode of
+    partmanip_amd/dist.py -- lifts that check)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("PARTMANIP_SHARE_GPU") != "1":
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="vision", choices=list(WORKLOADS) + ["dagger", "depth2pc"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optional", action="store_true", help="vision workload: skip the opt-in paths (profiling runs)")
+    ap.add_argument("--n-steps", type=int, default=0, help="override the rollout length T (e.g. 128 for the vision workload)")
+    ap.add_argument("--student", default="pointnet", choices=["pointnet", "conv3d"],
+                    help="dagger workload: PointNet on --points clouds (cfg 5 analogue) or the reference's shipped Conv3DNet config")
+    ap.add_argument("--points", type=int, default=4096, help="dagger workload: points per student cloud (BASELINE cfg 5: 4096)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x6"],
+                    help="vision encoder forward: exact fp32 MFMA (default) or the opt-in split-bf16 path")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))                  # re-exec as N ranks under torch.distributed.run
+    from partmanip_amd import dist as pdist
+    rank, world, local = pdist.init_from_env("nccl")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong "
+              "device count", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    with contextlib.redirect_stdout(sys.stderr):           # the runners print progress lines: keep stdout = ONE JSON line
+        if args.workload == "depth2pc":
+            out = run_depth2pc(args, device) if rank == 0 else None
+        elif args.workload == "dagger":
+            out = run_dagger(args, device, rank, world)
+        else:
+            out = run_ppo(args, device, rank, world)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -41,7 +41,7 @@ extern "C" {
 #define PM_ACT_TANH 1
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 119 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 120 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -335,6 +335,14 @@ int pm_rms_update_f32(const float* x, long ldx, int N, int D, int n_new, float* 
                       void* workspace, size_t workspace_bytes, void* stream);
 int pm_rms_normalize_f32(const float* x, long ldx, int N, int D, const float* mean, const float* std, float* out,
                          long ldo, void* stream);
+/* The same update in two halves for the data-parallel learner (new functionality: the reference has no distributed
+ * path; each rank holds an env shard of the batch RMS.py:10-18 sees): mom[2*c] = sum_r x[r][c], mom[2*c+1] =
+ * sum_r x[r][c]^2 (fp64; workspace as pm_rms_update_workspace_bytes(D)) -> the caller all-reduces `mom` ->
+ * pm_rms_apply_moments_f32 applies RMS.py:10-18 for a batch of n_rows rows with those moments. */
+int pm_rms_moments_f64(const float* x, long ldx, int N, int D, double* mom, void* workspace, size_t workspace_bytes,
+                       void* stream);
+int pm_rms_apply_moments_f32(const double* mom, long n_rows, int D, int n_new, float* mean, float* S, float* std,
+                             void* stream);
 
 #ifdef __cplusplus
 }

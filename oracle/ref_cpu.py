@@ -400,9 +400,10 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None):
 # =============================================================================
 # dagger.py
 # =============================================================================
-def dagger_update(stu, tea, ring_obs, ring_tea, cur_buf_size, cfg, it, opt=None):
+def dagger_update(stu, tea, ring_obs, ring_tea, cur_buf_size, cfg, it, opt=None, grad_sync=None):
     """dagger.py:299-337.  `stu`/`tea`: state dicts; cfg has model (student), tea_model,
-    n_updates, n_minibatches, sampler, lr, lr_schedule, max_iterations, proprio_shape."""
+    n_updates, n_minibatches, sampler, lr, lr_schedule, max_iterations, proprio_shape.
+    grad_sync: as in ppo_update (multi-process parity tests average the gradients across ranks)."""
     if cur_buf_size < 16:
         return None
     for k in stu:
@@ -419,8 +420,12 @@ def dagger_update(stu, tea, ring_obs, ring_tea, cur_buf_size, cfg, it, opt=None)
             mu = net_forward(stu, "actor", cfg["model"]["network"], ring_obs[idx], cfg.get("proprio_shape", 0))
             stu_act = action_activation(mu, cfg["model"]["action_activate"], cfg["model"]["clipAction"])
             loss = (tea_act - stu_act).pow(2).mean()
-            grads = torch.autograd.grad(loss, [stu[k] for k in names], allow_unused=True)
-            opt.step(list(grads))
+            grads = list(torch.autograd.grad(loss, [stu[k] for k in names], allow_unused=True))
+            if grad_sync is not None:
+                live = [g for g in grads if g is not None]
+                grad_sync.mean_grads(live)
+                loss = grad_sync.mean_scalar(loss.detach())
+            opt.step(grads)
             trace.append(float(loss.detach()))
     lr_now = opt.lrs[0]
     if cfg["lr_schedule"] == "linear_decay":

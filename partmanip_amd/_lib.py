@@ -62,6 +62,8 @@ SIGNATURES = {
     "pm_rms_update_workspace_bytes": (Z, [I]),
     "pm_rms_update_f32": (I, [P, L, I, I, I, P, P, P, P, Z, P]),
     "pm_rms_normalize_f32": (I, [P, L, I, I, P, P, P, L, P]),
+    "pm_rms_moments_f64": (I, [P, L, I, I, P, P, Z, P]),
+    "pm_rms_apply_moments_f32": (I, [P, L, I, I, P, P, P, P]),
     "pm_tsdf_sparse_gather_f32": (I, [P, P, P, I, I, I, P, P]),
     "pm_im2col3d_f32": (I, [P, I, I, I, I, I, I, I, I, L, L, L, L, L, P, I, P]),
     "pm_conv3d_c1_supported": (I, [I, I]),
@@ -90,7 +92,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 119                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 120                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -18,6 +18,9 @@ class RunningMeanStd:
         self.mean = torch.zeros((1, shape), device=device)
         self.S = torch.full((1, shape), 1e-4, device=device)
         self.std = self.S.sqrt()
+        # data parallelism (partmanip_amd.dist.GradSync, set by the runner): every rank sees an env shard of the batch;
+        # the column moments are summed over ranks so that all replicas keep the statistics of the WHOLE batch
+        self.sync = None
 
     def _hip(self, x):
         return x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
@@ -33,8 +36,16 @@ class RunningMeanStd:
                 t = getattr(self, k)
                 if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
                     setattr(self, k, t.to(device=x.device, dtype=torch.float32).contiguous())
+            sync = getattr(self, "sync", None)
+            if sync is not None:
+                if getattr(self, "_mom", None) is None or self._mom.numel() != 2 * x.shape[1]:
+                    self._mom = torch.empty(2 * x.shape[1], dtype=torch.float64, device=x.device)
+                ops.rms_update_dp(x, self.n, self.mean, self.S, self.std, self._ws, self._mom, sync.sum_, sync.world)
+                return
             ops.rms_update(x, self.n, self.mean, self.S, self.std, self._ws)
             return
+        if getattr(self, "sync", None) is not None:
+            raise RuntimeError("data-parallel RunningMeanStd needs device batches (the moments are all-reduced on the GPU)")
         prev = self.mean.clone()
         cur = x.mean(dim=0, keepdim=True)
         within = (x - cur).pow(2).mean(dim=0, keepdim=True)

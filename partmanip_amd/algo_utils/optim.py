@@ -24,6 +24,21 @@ class FusedAdam:
                              for g in groups]
         self._touched = set()          # group indices that have received a gradient (for state_dict)
 
+    def rebind(self, flat_params, flat_grads):
+        """Follow the owner's flat buffers after `ActorCritic.flatten()` rebuilt them (a later `.to()` / `.float()` /
+        `load_state_dict(assign=True)` re-creates the parameter tensors): stepping the orphaned old buffers would
+        silently stop training.  The Adam moments and the step counter carry over."""
+        if flat_params.numel() != self.p.numel() or flat_grads.numel() != self.g.numel():
+            raise RuntimeError("FusedAdam.rebind: the parameter set changed size")
+        dev = flat_params.device
+        self.p, self.g = flat_params, flat_grads
+        self.m, self.v, self.state_dev, self.gnorm = (t.to(dev) for t in (self.m, self.v, self.state_dev, self.gnorm))
+        if self.ws.device != dev:
+            self.ws = ops.Workspace(dev)
+
+    def bound_to(self, flat_params):
+        return self.p.data_ptr() == flat_params.data_ptr()
+
     def zero_grad(self, set_to_none=False):
         self.g.zero_()
 

@@ -90,9 +90,14 @@ class dagger:
         self.sync = pdist.maybe_sync()
         self._stage = {}
         self._loss_sum = torch.zeros(1, device=f['actor'].device)
+        if self.sync is not None:                        # one student: rank 0's parameters / Adam state on every replica
+            for t in (f['actor'], f['critic'], self.optimizer.m, self.optimizer.v, self.optimizer.state_dev):
+                self.sync.broadcast_(t)
 
     # ------------------------------------------------------------------ checkpoints (dagger.py:81-120)
     def save(self, it):
+        if self.sync is not None and self.sync.rank != 0:
+            return                                       # replicas are identical: rank 0 writes the checkpoint
         os.makedirs(self.save_ckpt_dir, exist_ok=True)
         save_path = pjoin(self.save_ckpt_dir, f'model_{it}.pth')
         n_actor_params = len(list(self.student.actor.parameters()))
@@ -143,8 +148,15 @@ class dagger:
         f = stu.flat()
         tea.flat()
         n_a, A = f['n_actor'], self.num_actions
+        if not self.optimizer.bound_to(f['actor']):
+            self.optimizer.rebind(f['actor'], f['grad_actor'][:n_a + A])
         scal = f['scal_actor']
-        act_tanh = stu.action_activate == 'tanh'
+        stu_tanh, tea_tanh = stu.action_activate == 'tanh', tea.action_activate == 'tanh'
+        # dagger.py:310 `teacher.act(tea_obs)` squashes with the TEACHER's action_activate / clipAction (its checkpoint's
+        # model_cfg).  When both networks squash alike, K11 squashes the two raw means in one pass; otherwise the
+        # teacher's action is formed first and K11 runs in action-target mode (bit 1, as bc.py does).
+        same_squash = stu_tanh == tea_tanh and (not stu_tanh or stu.max_action == tea.max_action)
+        mode = int(stu_tanh) | (0 if same_squash else 2)
         self._loss_sum.zero_()
         count = 0
         obs_all = self.storage.observations.view(-1, self.storage.observations.size(-1))
@@ -156,9 +168,12 @@ class dagger:
                 tea_obs = self._rows('tea', tea_all, indices)
                 with torch.no_grad():
                     tea_mu = tea.actor.hip_forward(tea_obs)                  # teacher.act, squashing fused into K11
+                    if not same_squash:
+                        tea_mu = tea_mu.contiguous()
+                        ops.action_activation(tea_mu, tea_mu, tea.max_action, tea_tanh)
                 stu_mu = stu.actor.hip_forward(stu_obs)
                 dstu = torch.empty_like(stu_mu)
-                ops.mse_tanh_loss(stu_mu, tea_mu, stu.max_action, act_tanh, 1.0, scal, dstu)
+                ops.mse_tanh_loss(stu_mu, tea_mu, stu.max_action, mode, 1.0, scal, dstu)
                 stu.actor.hip_backward(dstu)
                 if self.sync:
                     self.sync.mean_(f['grad_actor'])

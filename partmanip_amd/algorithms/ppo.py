@@ -120,9 +120,30 @@ class ppo:
         self.total_time = 0
         self.curr_iter = 0
         self.resume(cfg['resume'])
+        self._broadcast_state()
+
+    def _broadcast_state(self):
+        """Data parallelism keeps ONE model: whatever each rank initialised or loaded, rank 0's parameters, Adam
+        moments / step counters and observation statistics are what every replica starts from (gradients are the only
+        thing exchanged afterwards, so replicas that start equal stay equal)."""
+        if self.sync is None:
+            return
+        f = self.actor_critic.flat()
+        for opt, key in ((self.optimizer_actor, 'actor'), (self.optimizer_critic, 'critic')):
+            for t in (f[key], opt.m, opt.v, opt.state_dev):
+                self.sync.broadcast_(t)
+        if self.tricks['use_state_norm']:
+            rms = self.state_norm.running_ms
+            for k in ('mean', 'S', 'std'):
+                setattr(rms, k, self.sync.broadcast_(getattr(rms, k).to(f['actor'].device).float().contiguous()))
+            n = torch.tensor([rms.n], dtype=torch.int64, device=f['actor'].device)
+            rms.n = int(self.sync.broadcast_(n).item())
+            rms.sync = self.sync                         # batch moments are summed over ranks from now on (RMS.py)
 
     # ------------------------------------------------------------------ checkpoints (ppo.py:83-137)
     def save(self, it):
+        if self.sync is not None and self.sync.rank != 0:
+            return                                       # replicas are identical: rank 0 writes the checkpoint
         os.makedirs(self.save_ckpt_dir, exist_ok=True)
         save_path = pjoin(self.save_ckpt_dir, f'model_{it}.pth')
         save_dict = {
@@ -256,8 +277,9 @@ class ppo:
         mini-batch step is then a constant -- device pointers into persistent storage / flat buffers, sizes,
         hyper-parameters -- while everything that changes between steps (parameters, Adam moments and step
         counter, the KL skip flag, the running sums) lives in device memory."""
+        f = self.actor_critic.flat()
         key = (views['obs'].data_ptr(), views['adv'].data_ptr(), views['returns'].data_ptr(),
-               self.optimizer_actor.param_groups[0]['lr'], self.optimizer_critic.param_groups[0]['lr'])
+               f['actor'].data_ptr(), f['critic'].data_ptr(), self.optimizer_actor.param_groups[0]['lr'], self.optimizer_critic.param_groups[0]['lr'])
         if self._graphs.get('key') != key:
             self._graphs = {'key': key, 'seen': set(),
                             'pool': {'a': torch.cuda.graph_pool_handle(), 'c': torch.cuda.graph_pool_handle()}}
@@ -291,6 +313,10 @@ class ppo:
         other network's compute.  Index lists are drawn in the reference's order (all actor epochs first)."""
         ac = self.actor_critic
         f = ac.flat()
+        if not self.optimizer_actor.bound_to(f['actor']):        # the flat buffers were rebuilt (.to() / .float() / ...)
+            self.optimizer_actor.rebind(f['actor'], f['grad_actor'][:f['n_actor'] + self.num_actions])
+        if not self.optimizer_critic.bound_to(f['critic']):
+            self.optimizer_critic.rebind(f['critic'], f['grad_critic'][:f['n_critic']])
         views = self._views()
         self._acc.zero_()
         # backbones whose sampling / grouping depends on the coordinates only (PointNet2) build their
@@ -330,6 +356,9 @@ class ppo:
         self._geom = None
         acc = self._acc.tolist()                              # the only host sync of the update
         sum_surr, sum_kl, kl_max, count, sum_v, n_v = acc[:6]
+        if not all(np.isfinite(acc[:6])):
+            print("WARNING: non-finite training statistics (loss / KL sums: "
+                  f"{acc[:6]}): the policy has diverged or the rollout holds NaN/Inf")
         mean_value_loss = sum_v / (self.n_updates * len(lists_c[0]))
         mean_surrogate_loss = sum_surr / count                # ZeroDivisionError if every mb was skipped, as ppo.py:387
         mean_kl_mean = sum_kl / count
@@ -406,8 +435,12 @@ class ppo:
                     path2video(pjoin(self.logger.save_video_dir, f"Iter{self.curr_iter}"))
         mode = 'Test' if self.test_only else 'Val'
         self.use_info_update_logdict(ep_infos, mode)
-        if self.tricks['use_state_norm'] and self.log_dict[f'{mode}/succ_rate_max'] > 0.5 and self.update_RMS:
-            self.update_RMS = False
+        if self.tricks['use_state_norm'] and self.update_RMS:
+            rate = self.log_dict[f'{mode}/succ_rate_max']
+            if self.sync is not None:                    # one decision for all replicas: the mean over the env shards
+                rate = self.sync.mean_(torch.as_tensor(rate, dtype=torch.float32, device=self.device).reshape(1).clone())[0]
+            if rate > 0.5:
+                self.update_RMS = False
 
     def run(self):
         """ppo.py:205-293: collect n_steps transitions per env, learn, log."""

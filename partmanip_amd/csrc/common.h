@@ -83,8 +83,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PM_TANH_B4 1.18534705686654e-04f
 #define PM_TANH_B2 2.26843463243900e-03f
 #define PM_TANH_B0 4.89352518554385e-03f
-__device__ __forceinline__ float pm_tanh(float x) {
-    x = __builtin_amdgcn_fmed3f(x, -PM_TANH_CLAMP, PM_TANH_CLAMP);
+// v_med3_f32 drops a NaN operand (a NaN pre-activation would come out as -1): the scalar form selects the input back
+// when it is NaN so that a diverged network / a NaN observation stays visible in the losses, as with torch.tanh; the
+// packed form in the encoders' inner loops does not pay for the test (NaN WEIGHTS still surface through the last,
+// activation-free Linear of every backbone, and the runners check the loss scalars they read back).
+__device__ __forceinline__ float pm_tanh(float x0) {
+    float x = __builtin_amdgcn_fmed3f(x0, -PM_TANH_CLAMP, PM_TANH_CLAMP);
     const float x2 = x * x;
     float p = fmaf(PM_TANH_A13, x2, PM_TANH_A11);
     p = fmaf(p, x2, PM_TANH_A9);
@@ -97,7 +101,8 @@ __device__ __forceinline__ float pm_tanh(float x) {
     q = fmaf(q, x2, PM_TANH_B0);
     float r = __builtin_amdgcn_rcpf(q);
     r = fmaf(fmaf(-q, r, 1.0f), r, r);                     // one Newton step: 1/q to ~0.5 ulp
-    return x * (p * r);                                     // P/Q ~ 1 first, then times x: no denormal intermediates
+    const float t = x * (p * r);                            // P/Q ~ 1 first, then times x: no denormal intermediates
+    return x0 != x0 ? x0 : t;
 }
 __device__ __forceinline__ f32x2 pm_tanh2(f32x2 x) {
 #define PM_S2(v) ((f32x2){(v), (v)})

@@ -397,18 +397,23 @@ __global__ __launch_bounds__(256) void rms_partial_kernel(const float* __restric
     part[((size_t)blockIdx.y * D + col) * 2] = s;
     part[((size_t)blockIdx.y * D + col) * 2 + 1] = q;
 }
-__global__ __launch_bounds__(256) void rms_finish_kernel(const double* __restrict__ part, int N, int D, int n_new,
-                                                          float* __restrict__ mean, float* __restrict__ S,
-                                                          float* __restrict__ stdv) {
+__global__ __launch_bounds__(256) void rms_finish_kernel(const double* __restrict__ part, int nsplit, double N, int D,
+                                                          int n_new, float* __restrict__ mean, float* __restrict__ S,
+                                                          float* __restrict__ stdv, double* __restrict__ mom_out) {
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= D) return;
     double s = 0.0, q = 0.0;
-    for (int y = 0; y < RMS_ROWSPLIT; ++y) {
+    for (int y = 0; y < nsplit; ++y) {
         s += part[((size_t)y * D + col) * 2];
         q += part[((size_t)y * D + col) * 2 + 1];
     }
-    const double m64 = s / (double)N;
-    double w64 = q / (double)N - m64 * m64;             // mean((x - cur)^2), exact to fp64 round-off
+    if (mom_out) {                                      // moments only (data-parallel: the caller all-reduces them)
+        mom_out[(size_t)col * 2] = s;
+        mom_out[(size_t)col * 2 + 1] = q;
+        return;
+    }
+    const double m64 = s / N;
+    double w64 = q / N - m64 * m64;                     // mean((x - cur)^2), exact to fp64 round-off
     if (w64 < 0.0) w64 = 0.0;
     const float cur = (float)m64, within = (float)w64, prev = mean[col], n = (float)n_new;
     const float d = prev - cur;
@@ -440,8 +445,35 @@ extern "C" int pm_rms_update_f32(const float* x, long ldx, int N, int D, int n_n
     double* part = (double*)workspace;
     hipLaunchKernelGGL(rms_partial_kernel, dim3((D + 255) / 256, RMS_ROWSPLIT), dim3(256), 0, pm_stream(stream), x, ldx, N,
                        D, part);
-    hipLaunchKernelGGL(rms_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, pm_stream(stream), part, N, D, n_new, mean,
-                       S, stdv);
+    hipLaunchKernelGGL(rms_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, pm_stream(stream), part, RMS_ROWSPLIT,
+                       (double)N, D, n_new, mean, S, stdv, (double*)nullptr);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// The same update in two halves for the data-parallel learner (each rank holds an env shard of the batch): column
+// moments {sum x, sum x^2} (fp64, interleaved per column) -> [the caller sums them over ranks] -> the RMS.py:10-18
+// update from moments over `n_rows` rows.  One process calling both halves = pm_rms_update_f32.
+extern "C" int pm_rms_moments_f64(const float* x, long ldx, int N, int D, double* mom, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(x && mom && N > 0 && D > 0 && ldx >= D);
+    if (!workspace || workspace_bytes < pm_rms_update_workspace_bytes(D)) return PM_EWORKSPACE;
+    if (((uintptr_t)workspace & 7) != 0 || ((uintptr_t)mom & 7) != 0) return PM_EALIGN;
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL(rms_partial_kernel, dim3((D + 255) / 256, RMS_ROWSPLIT), dim3(256), 0, pm_stream(stream), x, ldx, N,
+                       D, part);
+    hipLaunchKernelGGL(rms_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, pm_stream(stream), part, RMS_ROWSPLIT,
+                       (double)N, D, 1, (float*)nullptr, (float*)nullptr, (float*)nullptr, mom);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_rms_apply_moments_f32(const double* mom, long n_rows, int D, int n_new, float* mean, float* S,
+                                        float* stdv, void* stream) {
+    PM_REQUIRE(mom && mean && S && stdv && n_rows > 0 && D > 0 && n_new >= 1);
+    if (((uintptr_t)mom & 7) != 0) return PM_EALIGN;
+    hipLaunchKernelGGL(rms_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, pm_stream(stream), mom, 1, (double)n_rows,
+                       D, n_new, mean, S, stdv, (double*)nullptr);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }

@@ -69,9 +69,30 @@ class GradSync:
         self.sum_(mom2)
         return count * self.world
 
+    def broadcast_(self, t, src=0):
+        """Rank `src`'s tensor to every rank (initial parameters / optimiser state: one model, W replicas)."""
+        dist.broadcast(t, src=src, group=self.group)
+        return t
+
     def barrier(self):
         dist.barrier(group=self.group)
 
 
 def maybe_sync():
-    return GradSync() if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+    """GradSync when a process group with more than one rank exists, else None.  PARTMANIP_FORCE_SYNC=1 also returns
+    one for a single-rank group, so that the collective code path (and RCCL itself) can be exercised on a 1-GPU box."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_world_size() > 1 or os.environ.get("PARTMANIP_FORCE_SYNC") == "1":
+        return GradSync()
+    return None
+
+
+def resolve_seed(seed_fn):
+    """Run `seed_fn()` on rank 0 and hand its (picklable) result to every rank: a run started with `seed: -1` must not
+    draw a different seed -- i.e. different initial weights and a different checkpoint directory -- per rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seed_fn()
+    box = [seed_fn() if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]

@@ -114,9 +114,10 @@ def gae_scan(rewards, values, dones, succs, last_values, returns, advantages, ga
     d8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones
     s8 = succs.view(torch.uint8) if succs.dtype == torch.bool else succs
     use = succ_value is not None
-    check(lib.pm_gae_scan_f32(_ptr(rewards), _ptr(values), _ptr(d8), _ptr(s8), _ptr(last_values), _ptr(returns),
-                              _ptr(advantages), T, N, float(gamma), float(gamma * lam), int(use),
-                              float(succ_value) if use else 0.0, _stream()), "pm_gae_scan_f32")
+    with TIMER.bracket("gae_scan"):
+        check(lib.pm_gae_scan_f32(_ptr(rewards), _ptr(values), _ptr(d8), _ptr(s8), _ptr(last_values), _ptr(returns),
+                                  _ptr(advantages), T, N, float(gamma), float(gamma * lam), int(use),
+                                  float(succ_value) if use else 0.0, _stream()), "pm_gae_scan_f32")
 
 
 def moments(x, out2, ws):
@@ -477,8 +478,9 @@ def conv3d_c1_fwd(x5, k, stride, pad, wt, bias, act):
     cout = wt.shape[1]
     y = torch.empty(B * Do * Ho * Wo, cout, dtype=torch.float32, device=x5.device)
     sb, _, sd, sh, sw = x5.stride()
-    check(lib.pm_conv3d_c1_fwd_f32(_ptr(x5), B, D, H, W, k, stride, pad, sb, sd, sh, sw, _ptr(wt), _ptr(bias), cout, int(act),
-                                   _ptr(y), cout, _stream()), "pm_conv3d_c1_fwd_f32")
+    with TIMER.bracket("conv3d_c1_fwd"):
+        check(lib.pm_conv3d_c1_fwd_f32(_ptr(x5), B, D, H, W, k, stride, pad, sb, sd, sh, sw, _ptr(wt), _ptr(bias), cout, int(act),
+                                       _ptr(y), cout, _stream()), "pm_conv3d_c1_fwd_f32")
     return y
 
 
@@ -489,9 +491,10 @@ def conv3d_c1_wgrad(dz, x5, k, stride, pad, dw, db, ws):
     cout = dw.shape[0]
     w = ws.get(lib.pm_conv3d_c1_wgrad_workspace_bytes(cout))
     sb, _, sd, sh, sw = x5.stride()
-    check(lib.pm_conv3d_c1_wgrad_f32(_ptr(dz), _rows(dz, "dz"), _ptr(x5), B, D, H, W, k, stride, pad, sb, sd, sh, sw, cout,
-                                     _ptr(dw), _rows(dw, "dw"), _ptr(db), _ptr(w), w.numel(), _stream()),
-          "pm_conv3d_c1_wgrad_f32")
+    with TIMER.bracket("conv3d_c1_wgrad"):
+        check(lib.pm_conv3d_c1_wgrad_f32(_ptr(dz), _rows(dz, "dz"), _ptr(x5), B, D, H, W, k, stride, pad, sb, sd, sh, sw, cout,
+                                         _ptr(dw), _rows(dw, "dw"), _ptr(db), _ptr(w), w.numel(), _stream()),
+              "pm_conv3d_c1_wgrad_f32")
 
 
 def col2im3d(dcols, dx5, k, stride, pad, y_tanh5=None):
@@ -581,6 +584,18 @@ def rms_update(x, n_new, mean, S, std, ws):
     w = ws.get(lib.pm_rms_update_workspace_bytes(D))
     check(lib.pm_rms_update_f32(_ptr(x), _rows(x, "x"), N, D, int(n_new), _ptr(mean), _ptr(S), _ptr(std), _ptr(w),
                                 w.numel(), _stream()), "pm_rms_update_f32")
+
+
+def rms_update_dp(x, n_new, mean, S, std, ws, mom, sum_over_ranks, world):
+    """The same update when the batch is sharded over `world` ranks: local column moments -> `sum_over_ranks(mom)`
+    (one all-reduce of 2*D doubles) -> RMS.py:10-18 from the global moments over N * world rows."""
+    _req(x, mean, S, std, mom)
+    N, D = x.shape
+    w = ws.get(lib.pm_rms_update_workspace_bytes(D))
+    check(lib.pm_rms_moments_f64(_ptr(x), _rows(x, "x"), N, D, _ptr(mom), _ptr(w), w.numel(), _stream()), "pm_rms_moments_f64")
+    sum_over_ranks(mom)
+    check(lib.pm_rms_apply_moments_f32(_ptr(mom), N * world, D, int(n_new), _ptr(mean), _ptr(S), _ptr(std), _stream()),
+          "pm_rms_apply_moments_f32")
 
 
 def rms_normalize(x, mean, std):

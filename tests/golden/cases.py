@@ -225,6 +225,43 @@ def bc_write_dataset(c, folder):
     return d
 
 
+# ---- mixed BC + on-policy DAgger: offline shards preloaded into the ring (storage.py:58-82, dagger.py:186-187) ------
+# 2 scenes x 8 steps = 16 offline rows, then 3 on-policy env steps of 4 rows: 28 rows through a 20-row ring (wraps;
+# the reference itself crashes when the preload leaves the write index off a multiple of num_envs at the wrap).
+# The student is an MLP on [tsdf(40) | proprio(6)] rows (the loader only flattens `tsdf` and appends `proprio_state`).
+DAGGER_OFFLINE_CASE = dict(stu_net=_MLP_NET, tea_net=_MLP_NET, N=4, buf_size=5, n_fill=3, D=40, proprio=6, O_t=32, A=10,
+                           scenes=2, steps=8, n_minibatches=2, n_updates=2, lr=2e-3, lr_schedule="linear_decay",
+                           sampler="random", seed=701, action_std=0.1, max_iterations=1000, it=7, torch_seed=83)
+
+
+def dagger_offline_rows(c):
+    n = c["scenes"] * c["steps"]
+    return dict(tsdf=det_normal((n, c["D"]), c["seed"]), proprio_state=det_normal((n, c["proprio"]), c["seed"] + 1),
+                tea_obs=det_normal((n, c["O_t"]), c["seed"] + 2))
+
+
+def dagger_offline_write(c, folder):
+    """`folder/scene_XXXXX/step_XXXXX.npy` dict shards ({tsdf, proprio_state, tea_obs}) in (scene, step) order."""
+    import os
+    d = dagger_offline_rows(c)
+    for sc in range(c["scenes"]):
+        scene = os.path.join(folder, f"scene_{str(sc).zfill(5)}")
+        os.makedirs(scene, exist_ok=True)
+        for st in range(c["steps"]):
+            i = sc * c["steps"] + st
+            np.save(os.path.join(scene, f"step_{str(st).zfill(5)}.npy"),
+                    dict(tsdf=d["tsdf"][i].reshape(5, 8), proprio_state=d["proprio_state"][i], tea_obs=d["tea_obs"][i]),
+                    allow_pickle=True)
+    return d
+
+
+def dagger_offline_online(c):
+    """The on-policy rows added after the preload: n_fill env steps of (N, D + proprio) / (N, O_t)."""
+    s = c["seed"] * 1000
+    return dict(stu=[det_normal((c["N"], c["D"] + c["proprio"]), s + 10 * k + 1) for k in range(c["n_fill"])],
+                tea=[det_normal((c["N"], c["O_t"]), s + 10 * k + 3) for k in range(c["n_fill"])])
+
+
 # ---- Conv3D TSDF student (network.py:67-94) -----------------------------------------------------------------------
 CONV3D_CASES = {
     "conv3d_proprio": dict(B=3, res=50, proprio=5, out=10, seed=501),

@@ -256,6 +256,60 @@ def gen_dagger(ref_algos, cases):
         print("wrote", name, "losses", out["loss_trace"])
 
 
+def gen_dagger_offline(ref_algos, cases):
+    """Mixed BC + on-policy DAgger by the reference's own code: `RolloutStorage.add_transitions_offline`
+    (storage.py:58-82, the call `dagger.run` makes first, dagger.py:186-187) on shards written to disk, then
+    `add_transitions_dagger` for the on-policy steps (ring wraps over the offline rows), then `dagger.update`."""
+    from algorithms import ppo, dagger
+    c = cases.DAGGER_OFFLINE_CASE
+    N, A, O_s = c["N"], c["A"], c["D"] + c["proprio"]
+    with tempfile.TemporaryDirectory() as d:
+        cwd = os.getcwd()
+        os.chdir(d)
+        try:
+            np.save("teacher_reward.npy", np.linspace(0, 1, 200).astype(np.float32))
+            cases.dagger_offline_write(c, os.path.join(d, "offline"))
+            tc = dict(net=c["tea_net"], T=1, n_updates=1, n_minibatches=1, tricks=dict(cases.TRICKS_DEFAULT),
+                      sampler="sequential", succ_value=None, lr=1e-3, desired_kl=0.1, lr_schedule="fixed",
+                      gamma=0.99, lam=0.95, epsilon_clip=0.2, action_std=0.5, max_iterations=10)
+            tea_run = ppo(FakeEnv(N, {"normal_state": c["O_t"]}, A), ppo_cfg(tc, N), FakeLogger(d))
+            load_sd(tea_run.actor_critic, cases.actor_critic_state(c["tea_net"], c["O_t"], A, 0.5, c["seed"] + 1))
+            tea_run.save(1)
+            env = FakeEnv(N, {"tsdf": O_s, "normal_state": c["O_t"], "proprio_state": c["proprio"]}, A)
+            cfg = dict(num_envs=N, obs_mode="tsdf",
+                       model=dict(action_std=c["action_std"], action_activate="tanh", clipAction=1.0, network=dict(c["stu_net"])),
+                       max_iterations=c["max_iterations"], n_steps=1, n_updates=c["n_updates"], n_minibatches=c["n_minibatches"],
+                       device="cpu", buf_size=c["buf_size"], reward_reset=True, add_proprio_obs=True,
+                       offline_data_pth=os.path.join(d, "offline"), eval_round=1, eval_frequence=10 ** 9,
+                       save_frequence=10 ** 9, test_only=False, save_pose=False, save_video=False,
+                       lr_schedule=c["lr_schedule"], lr=c["lr"], teacher=os.path.join(d, "model_1.pth"), resume=None,
+                       pretrain=None, sampler=c["sampler"])
+            run = dagger(env, cfg, FakeLogger(d))
+            # the student's first Linear takes [tsdf | proprio]: the reference sizes it from stu_input_obs = num_obs['tsdf']
+            load_sd(run.student, cases.actor_critic_state(c["stu_net"], O_s, A, c["action_std"], c["seed"]))
+            run.storage.add_transitions_offline(run.offline_data_pth, run.device, run.add_proprio_obs)   # dagger.py:186-187
+        finally:
+            os.chdir(cwd)
+    st = run.storage
+    out = dict(off_ring_obs=st.observations.numpy().copy(), off_ring_tea=st.tea_obs.numpy().copy(),
+               off_state=np.array([st.mix_buf_ind, st.cur_buf_size, st.last_episode_buf_ind], dtype=np.int64))
+    on = cases.dagger_offline_online(c)
+    for k in range(c["n_fill"]):
+        st.add_transitions_dagger(torch.from_numpy(on["stu"][k]), torch.from_numpy(on["tea"][k]))
+    out.update(ring_obs=st.observations.numpy().copy(), ring_tea=st.tea_obs.numpy().copy(),
+               state=np.array([st.mix_buf_ind, st.cur_buf_size, st.last_episode_buf_ind], dtype=np.int64))
+    torch.manual_seed(c["torch_seed"])
+    run.log_dict = {}
+    with Trace(lambda: list(run.student.parameters())) as tr:
+        run.update(c["it"])
+    out["loss_trace"] = np.array(tr.losses, dtype=np.float64)
+    out["log_dagger_loss"] = np.float64(float(run.log_dict["Train/dagger_loss"]))
+    out["log_learning_rate"] = np.float64(float(run.log_dict["Train/learning_rate"]))
+    out["final_flat"] = flat_params(run.student.state_dict())
+    np.savez_compressed(os.path.join(HERE, "dagger_offline.npz"), **out)
+    print("wrote dagger_offline", out["off_state"], out["state"], "losses", out["loss_trace"])
+
+
 def gen_bc(ref_algos, cases):
     """The reference's own bc.run() (10 DataLoader workers) on shards written by cases.bc_write_dataset."""
     from algorithms import bc
@@ -385,7 +439,7 @@ def main():
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
     from tests.golden import cases
-    which = sys.argv[1:] or ["gae", "ppo", "dagger", "depth2pc", "bc", "conv3d", "rollout"]
+    which = sys.argv[1:] or ["gae", "ppo", "dagger", "dagger_offline", "depth2pc", "bc", "conv3d", "rollout"]
     if "depth2pc" in which:
         gen_depth2pc(cases)
         which = [w for w in which if w != "depth2pc"]
@@ -398,6 +452,8 @@ def main():
         gen_ppo(ref, cases)
     if "dagger" in which:
         gen_dagger(ref, cases)
+    if "dagger_offline" in which:
+        gen_dagger_offline(ref, cases)
     if "bc" in which:
         gen_bc(ref, cases)
     if "conv3d" in which:

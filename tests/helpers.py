@@ -83,3 +83,39 @@ def assert_params_close(got, want, lr, n_steps, q_tol=2e-5):
     diff = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64))
     assert np.quantile(diff, 0.999) < q_tol, np.quantile(diff, 0.999)
     assert diff.max() < 2.5 * lr * n_steps, diff.max()
+
+
+def per_tensor_update_error(fin_flat, ref_flat, init_sd, stride=1):
+    """For every tensor of the state dict: ||got - ref||_2 / ||ref - init||_2 over the sampled elements (those at flat
+    positions = 0 mod `stride`, the way the fixtures subsample) -- the error RELATIVE TO HOW FAR THE UPDATE MOVED that
+    tensor.  A tensor that moves the wrong way on every step scores >= 1 however small it is (b1, log_std, ...), which
+    a whole-vector quantile or a loose max bound cannot see.  Unmoved tensors report the absolute error instead."""
+    init = np.concatenate([np.asarray(v, dtype=np.float32).reshape(-1) for v in init_sd.values()])
+    got = np.asarray(fin_flat, dtype=np.float64)[::stride]
+    ref = np.asarray(ref_flat, dtype=np.float64)
+    ini = init.astype(np.float64)[::stride]
+    assert got.shape == ref.shape == ini.shape, (got.shape, ref.shape, ini.shape)
+    out, off = {}, 0
+    for k, v in init_sd.items():
+        n = int(np.asarray(v).size)
+        first = (-off) % stride                          # first sampled position inside [off, off + n)
+        cnt = 0 if first >= n else (n - first + stride - 1) // stride
+        lo = (off + first) // stride
+        g, r, i0 = got[lo:lo + cnt], ref[lo:lo + cnt], ini[lo:lo + cnt]
+        off += n
+        if cnt == 0:
+            continue
+        moved, err = np.linalg.norm(r - i0), np.linalg.norm(g - r)
+        out[k] = (err / moved, moved) if moved > 0 else (err, 0.0)
+    return out
+
+
+def assert_update_matches(fin_flat, ref_flat, init_sd, lr, n_steps, stride=1, rel=5e-2):
+    """Whole-vector bounds (99.9 % quantile < 0.05 lr; max < 2.5 lr steps) PLUS the per-tensor relative-L2 bound."""
+    diff = np.abs(np.asarray(fin_flat, dtype=np.float64)[::stride] - np.asarray(ref_flat, dtype=np.float64))
+    assert np.quantile(diff, 0.999) < 5e-2 * lr, (np.quantile(diff, 0.999), lr)
+    assert diff.max() < 2.5 * lr * n_steps, (diff.max(), lr)
+    errs = per_tensor_update_error(fin_flat, ref_flat, init_sd, stride)
+    bad = {k: e for k, (e, moved) in errs.items() if (e > rel if moved > 0 else e > 1e-7)}
+    assert not bad, f"per-tensor update error above {rel}: {bad}"
+    return max((e for e, moved in errs.values() if moved > 0), default=0.0)

@@ -101,3 +101,80 @@ def test_shard_envs_and_env_parsing(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     assert pdist.init_from_env("gloo") == (0, 1, 0)            # single process: no group is created
     assert pdist.maybe_sync() is None
+
+
+# ----------------------------------------------------------------------------------------------- DAgger under DP
+# `dagger.update` has the same single all-reduce per optimiser step (partmanip_amd/algorithms/dagger.py: the flat
+# student gradient with the loss in its tail).  Two ranks with env shards of the ring == one process with the whole
+# ring and twice the mini-batch (sequential sampler; a mini-batch is a whole number of env steps on either side).
+_DAG = dict(N=8, buf=4, O_s=24, O_t=16, A=6, n_minibatches=2, n_updates=2, lr=2e-3, seed=611,
+            net=dict(name="MLP", hid_dim=[32, 32], activation="tanh"))
+
+
+def _dagger_problem():
+    from tests.golden.detgen import det_normal
+    c = _DAG
+    stu = state_dict_t(cases.actor_critic_state(c["net"], c["O_s"], c["A"], 0.1, c["seed"]))
+    tea = state_dict_t(cases.actor_critic_state(c["net"], c["O_t"], c["A"], 0.5, c["seed"] + 1))
+    obs = t(det_normal((c["buf"], c["N"], c["O_s"]), c["seed"] * 7 + 1))
+    tobs = t(det_normal((c["buf"], c["N"], c["O_t"]), c["seed"] * 7 + 2))
+    model = lambda std: dict(action_std=std, action_activate="tanh", clipAction=1.0, network=dict(c["net"]))
+    cfg = dict(model=model(0.1), tea_model=model(0.5), n_updates=c["n_updates"], n_minibatches=c["n_minibatches"],
+               sampler="sequential", lr=c["lr"], lr_schedule="fixed", max_iterations=100, proprio_shape=0)
+    return stu, tea, obs, tobs, cfg
+
+
+def _dagger_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from oracle import ref_cpu as R
+    from partmanip_amd import dist as pdist
+    pdist.init_from_env("gloo")
+    sync = pdist.maybe_sync()
+    stu, tea, obs, tobs, cfg = _dagger_problem()
+    lo, hi = pdist.shard_envs(_DAG["N"], rank, world)
+    ring = obs[:, lo:hi].reshape(-1, obs.shape[-1])              # this rank's ring: (buf * N/W, .) rows, step-major
+    tring = tobs[:, lo:hi].reshape(-1, tobs.shape[-1])
+    out = R.dagger_update(stu, tea, ring, tring, ring.shape[0], cfg, 1, grad_sync=OracleSyncAdapter(sync))
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), flat_state(stu))
+    np.save(os.path.join(out_dir, f"l{rank}.npy"), np.array(out["loss_trace"]))
+    sync.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_dagger_dp_equals_single_process(tmp_path):
+    from oracle import ref_cpu as R
+    mp.spawn(_dagger_rank, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    stu, tea, obs, tobs, cfg = _dagger_problem()
+    ring, tring = obs.reshape(-1, obs.shape[-1]), tobs.reshape(-1, tobs.shape[-1])
+    ref = R.dagger_update(stu, tea, ring, tring, ring.shape[0], cfg, 1)
+    r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
+    assert np.array_equal(r0, r1), "ranks diverged"
+    np.testing.assert_allclose(np.load(tmp_path / "l0.npy"), ref["loss_trace"], rtol=1e-5)
+    assert_params_close(r0, flat_state(stu), _DAG["lr"], len(ref["loss_trace"]))
+
+
+def test_resolve_seed_single_process():
+    from partmanip_amd import dist as pdist
+    assert pdist.resolve_seed(lambda: (7, "x_seed7")) == (7, "x_seed7")
+
+
+def _seed_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from partmanip_amd import dist as pdist
+    pdist.init_from_env("gloo")
+    got = pdist.resolve_seed(lambda: (1000 + rank, f"run_seed{1000 + rank}"))     # every rank would pick its own
+    sync = pdist.maybe_sync()
+    w = torch.full((5,), float(rank + 1))
+    sync.broadcast_(w)
+    np.save(os.path.join(out_dir, f"s{rank}.npy"), np.array([got[0], float(w[0])]))
+    torch.distributed.destroy_process_group()
+
+
+def test_rank0_seed_and_parameters_reach_every_rank(tmp_path):
+    """train.py: `seed: -1` must resolve to ONE seed / run name; the runners broadcast rank 0's parameters."""
+    mp.spawn(_seed_rank, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    s0, s1 = np.load(tmp_path / "s0.npy"), np.load(tmp_path / "s1.npy")
+    assert list(s0) == list(s1) == [1000.0, 1.0]

@@ -1,0 +1,273 @@
+"""End-to-end parity at PRODUCTION shapes (VERDICT r1 "weak" #1): the golden fixtures stop at N <= 8, T <= 16 and
+64-wide layers, so the 2048-row cap (storage.py:127), the 512-wide layers, the split-K weight-gradient path at
+M = 2048 and the hipGraph capture/replay were only covered kernel by kernel.  Here the whole `ppo.update` runs on
+the HIP path and on the CPU oracle (which is pinned to the reference by the small fixtures) on the same tensors:
+
+  * BASELINE cfg 1 exactly: 256 envs x 64 steps, O = 32, A = 10, MLP 512-512-512, 5 epochs x 8 mini-batches of 2048,
+    with hipGraph replay on and off (~10 s of CPU oracle);
+  * one B = 2048 actor step + one B = 2048 critic step of BASELINE cfg 3 (PointNet on 1024-point clouds): the oracle
+    evaluates the batch in sixteen 128-row slices whose mean-loss gradients are averaged (a mean over 2048 rows is
+    the mean of the sixteen slice means), then applies its own clip + Adam;
+  * mixed BC + on-policy DAgger against the fixture the reference's own storage + `dagger.update` produced.
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from tests.golden import cases
+from tests.golden.detgen import det_normal, det_uniform
+from tests.helpers import load_fixture, t, flat_state, FakeEnv, FakeLogger, assert_update_matches, per_tensor_update_error
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+TRICKS = dict(mini_adv_norm=False, whole_adv_norm=False, use_state_norm=False, use_clipped_value_loss=False,
+              use_grad_clip=True, max_grad_norm=0.5)
+
+
+def _cfg(net, N, T, n_mb, n_updates, lr, device, tricks=TRICKS, sampler="sequential"):
+    return dict(num_envs=N, obs_mode="normal_state", succ_value=None,
+                model=dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=dict(net)),
+                max_iterations=200000, n_steps=T, n_updates=n_updates, n_minibatches=n_mb, device=device, eval_round=1,
+                eval_frequence=10 ** 9, save_frequence=10 ** 9, test_only=False, save_pose=False, save_video=False,
+                lr_schedule="fixed", lr=lr, desired_kl=0.1, epsilon_clip=0.2, gamma=0.99, lam=0.95, tricks=dict(tricks),
+                sampler=sampler, resume=None)
+
+
+def _rollout_from_policy(p, model_cfg, obs, seed):
+    """A rollout the way bench.py / the reference produce one: actions sampled from the CURRENT policy (ratio ~ 1,
+    KL ~ 0 at the first step), values from the current critic, on the CPU oracle."""
+    T, N, O = obs.shape
+    A = p["log_std"].numel()
+    with torch.no_grad():
+        flat = obs.reshape(T * N, O)
+        g = torch.Generator().manual_seed(seed)
+        eps = torch.randn(T * N, A, generator=g)
+        act, logp, val, mu, ls = R.random_act_cri(p, model_cfg, flat, eps)
+    rew = t(det_normal((T, N, 1), seed + 1))
+    dones = torch.from_numpy(det_uniform((T, N, 1), seed + 2, 0.0, 1.0) < 0.02)
+    succs = dones & torch.from_numpy(det_uniform((T, N, 1), seed + 3, 0.0, 1.0) < 0.5)
+    last = t(det_normal((N, 1), seed + 4)) * 0.1
+    v = lambda x, d: x.reshape(T, N, d)
+    return dict(observations=obs, actions=v(act, A), rewards=rew, dones=dones, succs=succs, values=v(val, 1),
+                actions_log_prob=v(logp, 1), mu=v(mu, A), sigma=v(ls, A), last_values=last)
+
+
+def _fill(run, st):
+    T = st["observations"].shape[0]
+    for tt in range(T):
+        run.storage.add_transitions(st["observations"][tt].to(DEV), st["actions"][tt].to(DEV), st["rewards"][tt, :, 0].to(DEV),
+                                    st["dones"][tt, :, 0].to(DEV), st["succs"][tt, :, 0].to(DEV), st["values"][tt].to(DEV),
+                                    st["actions_log_prob"][tt, :, 0].to(DEV), st["mu"][tt].to(DEV), st["sigma"][tt].to(DEV))
+
+
+# ------------------------------------------------------------------------------------------------------ cfg 1
+@pytest.fixture(scope="module")
+def cfg1_problem():
+    """BASELINE.json configs[0]: 256 envs x 64 steps, 32-d obs, MLP actor-critic -- and its oracle result."""
+    N, T, O, A, lr = 256, 64, 32, 10, 3e-4
+    net = dict(name="MLP", hid_dim=[512, 512, 512], activation="tanh")
+    sd = cases.actor_critic_state(net, O, A, 0.5, 811)
+    p = {k: t(v.copy()) for k, v in sd.items()}
+    cfg = _cfg(net, N, T, 8, 5, lr, "cpu")
+    obs = t(det_normal((T, N, O), 8110))
+    st = _rollout_from_policy(p, cfg["model"], obs, 8111)
+    ret, adv = R.gae_returns(st["rewards"], st["values"], st["dones"], st["succs"], st["last_values"], 0.99, 0.95, None, False)
+    roll = {k: st[k] for k in ("observations", "actions", "values", "actions_log_prob", "mu", "sigma")}
+    roll["returns"], roll["advantages"] = ret, adv
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    out = R.ppo_update(p, roll, cfg, 1)
+    assert len(out["loss_trace"]) == 80 and R.minibatch_size(N * T, 8) == 2048
+    return dict(N=N, T=T, O=O, A=A, lr=lr, net=net, sd=sd, st=st, ret=ret, adv=adv, ref=p, out=out)
+
+
+@pytest.mark.parametrize("graphs", [True, False])
+def test_cfg1_full_ppo_update_matches_oracle(cfg1_problem, graphs):
+    from partmanip_amd.algorithms import ppo
+    q = cfg1_problem
+    with tempfile.TemporaryDirectory() as d:
+        run = ppo(FakeEnv(q["N"], {"normal_state": q["O"]}, q["A"]), _cfg(q["net"], q["N"], q["T"], 8, 5, q["lr"], DEV), FakeLogger(d))
+    run.actor_critic.load_state_dict({k: t(v.copy()) for k, v in q["sd"].items()})
+    assert run.use_graphs, "MLP + sequential sampler + fixed lr on one GPU: the hipGraph path is the default"
+    run.use_graphs = graphs
+    _fill(run, q["st"])
+    run.log_dict = {}
+    run.curr_iter = 1
+    run.learn(q["st"]["last_values"].to(DEV))
+    torch.cuda.synchronize()
+    if graphs:                                             # epoch 1 eager, epoch 2 captures, epochs 3-5 replay
+        assert sum(1 for k in run._graphs if isinstance(k, tuple)) == 16
+    assert np.array_equal(run.storage.returns.cpu().numpy(), q["ret"].numpy())
+    log, ref = run.log_dict, q["out"]["log"]
+    assert log["Train/kl_update_count"] == ref["Train/kl_update_count"] == 40
+    for k in ("Train/value_function_loss", "Train/surrogate_loss", "Train/kl", "Train/kl_max"):
+        np.testing.assert_allclose(float(log[k]), float(ref[k]), rtol=5e-4, atol=2e-6, err_msg=k)
+    worst = assert_update_matches(flat_state(run.actor_critic.state_dict()), flat_state(q["ref"]), q["sd"], q["lr"], 80)
+    print(f"cfg1 graphs={graphs}: worst per-tensor relative update error {worst:.2e}")
+
+
+# ------------------------------------------------------------------------------------------------------ cfg 3, B = 2048
+def _sliced_grads(p, names, loss_of_slice, n, sl=128):
+    """Gradient of the mean loss over n rows as the average of the slice means (n % sl == 0)."""
+    acc = None
+    total = 0.0
+    for lo in range(0, n, sl):
+        loss = loss_of_slice(lo, lo + sl)
+        g = torch.autograd.grad(loss, [p[k] for k in names])
+        acc = [x.clone() for x in g] if acc is None else [a + x for a, x in zip(acc, g)]
+        total += float(loss.detach())
+    k = n // sl
+    return [a / k for a in acc], total / k
+
+
+def test_cfg3_one_b2048_actor_and_critic_step_matches_oracle():
+    """One actor + one critic optimiser step at the production mini-batch (2048 clouds x 1024 points, PointNet tanh,
+    max+mean pooling, no centring: BASELINE cfg 3) -- forward, fused loss, structured encoder backward at its full
+    launch shape, clip + Adam."""
+    from partmanip_amd.algorithms import ppo
+    B, O, A, lr = 2048, 3072, 10, 5e-5
+    net = dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False)
+    sd = cases.actor_critic_state(net, O, A, 0.5, 821)
+    p = {k: t(v.copy()) for k, v in sd.items()}
+    cfg = _cfg(net, B, 1, 1, 1, lr, "cpu")
+    pts = det_uniform((B, 1024, 3), 8210, -1.0, 1.0) + det_uniform((B, 1, 3), 8211, -0.5, 0.5)
+    obs = t(pts.reshape(1, B, O).astype(np.float32))
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    st = _rollout_from_policy(p, cfg["model"], obs, 8212)
+    st["actions_log_prob"] = st["actions_log_prob"] + 0.05 * t(det_normal((1, B, 1), 8213))      # ratio != 1: the clip is live
+    ret, adv = R.gae_returns(st["rewards"], st["values"], st["dones"], st["succs"], st["last_values"], 0.99, 0.95, None, False)
+
+    with tempfile.TemporaryDirectory() as d:
+        run = ppo(FakeEnv(B, {"normal_state": O}, A), _cfg(net, B, 1, 1, 1, lr, DEV), FakeLogger(d))
+    run.actor_critic.load_state_dict({k: t(v.copy()) for k, v in sd.items()})
+    _fill(run, st)
+    run.log_dict = {}
+    run.curr_iter = 1
+    run.learn(st["last_values"].to(DEV))
+    torch.cuda.synchronize()
+    assert np.array_equal(run.storage.returns.cpu().numpy(), ret.numpy())
+
+    # ---- the same two steps on the oracle, 128 rows at a time
+    for k in p:
+        p[k].requires_grad_(True)
+    ak, ck = R.split_params(p)
+    x, a = obs.reshape(B, O), st["actions"].reshape(B, A)
+    fl = lambda key, d_: st[key].reshape(B, d_)
+    kls = []
+
+    def actor_slice(lo, hi):
+        logp, _, _, mu, ls = R.update_act_cri(p, cfg["model"], x[lo:hi], a[lo:hi])
+        kl, loss = R.actor_loss_terms(logp, mu, ls, fl("actions_log_prob", 1)[lo:hi], adv.reshape(B, 1)[lo:hi], fl("mu", A)[lo:hi],
+                                      fl("sigma", A)[lo:hi], 0.2, False)
+        kls.append(float(kl.detach()))
+        return loss
+    names_a = ak + ["log_std"]
+    g_a, surr = _sliced_grads(p, names_a, actor_slice, B)
+    assert np.mean(kls) < 0.1
+    R.clip_grad_norm(g_a[:-1], 0.5)
+    opt_a = R.Adam([p[k] for k in names_a], lr)
+    opt_a.step(g_a)
+
+    def critic_slice(lo, hi):
+        _, _, value, _, _ = R.update_act_cri(p, cfg["model"], x[lo:hi], a[lo:hi])
+        return R.value_loss_fn(value, ret.reshape(B, 1)[lo:hi], fl("values", 1)[lo:hi], 0.2, False)
+    g_c, vloss = _sliced_grads(p, ck, critic_slice, B)
+    R.clip_grad_norm(g_c, 0.5)
+    opt_c = R.Adam([p[k] for k in ck], lr)
+    opt_c.step(g_c)
+    for k in p:
+        p[k].requires_grad_(False)
+
+    np.testing.assert_allclose(float(run.log_dict["Train/surrogate_loss"]), surr, rtol=5e-4, atol=2e-6)
+    np.testing.assert_allclose(float(run.log_dict["Train/value_function_loss"]), vloss, rtol=5e-4)
+    np.testing.assert_allclose(float(run.log_dict["Train/kl"]), np.mean(kls), rtol=5e-4, atol=1e-7)
+    fin, ref = flat_state(run.actor_critic.state_dict()), flat_state(p)
+    # ONE Adam step moves every element by ~lr * sign(g): a near-zero gradient element may flip (a move of 2 lr) between
+    # two correct fp32 evaluations, and the max-pool arg-max of near-tied channels differs legitimately;
+    # the per-tensor relative-L2 bound is therefore looser than for multi-step updates, the quantile bound is the same
+    errs = per_tensor_update_error(fin, ref, sd)
+    print({k: f"{e:.2e}" for k, (e, m) in errs.items() if m > 0})
+    diff = np.abs(fin.astype(np.float64) - ref.astype(np.float64))
+    assert np.quantile(diff, 0.99) < 5e-2 * lr and diff.max() <= 2.0 * lr * 1.0001, (np.quantile(diff, 0.99), diff.max())
+    bad = {k: e for k, (e, m) in errs.items() if m > 0 and e > 0.15}
+    assert not bad, bad
+
+
+# ------------------------------------------------------------------------------------------------------ DAgger, offline + on-policy
+def test_dagger_offline_plus_on_policy_update_matches_reference(tmp_path, monkeypatch):
+    """A13: `add_transitions_offline` (storage.py:58-82) preloads the ring the way `dagger.run` does (dagger.py:186-187),
+    on-policy rows follow, then `dagger.update` on the HIP path -- ring, counters, loss and final student against the
+    fixture produced by the REFERENCE's own storage and update (tests/golden/dagger_offline.npz)."""
+    from partmanip_amd.algorithms import ppo, dagger
+    from tests.helpers import ppo_cfg
+    c, fx = cases.DAGGER_OFFLINE_CASE, load_fixture("dagger_offline")
+    N, A, O_s = c["N"], c["A"], c["D"] + c["proprio"]
+    monkeypatch.chdir(tmp_path)
+    cases.dagger_offline_write(c, str(tmp_path / "offline"))
+    tc = dict(net=c["tea_net"], N=N, T=1, n_updates=1, n_minibatches=1, tricks=dict(cases.TRICKS_DEFAULT), sampler="sequential",
+              succ_value=None, lr=1e-3, desired_kl=0.1, lr_schedule="fixed", gamma=0.99, lam=0.95, epsilon_clip=0.2,
+              action_std=0.5, max_iterations=10)
+    tea = ppo(FakeEnv(N, {"normal_state": c["O_t"]}, A), ppo_cfg(tc, device=DEV), FakeLogger(str(tmp_path)))
+    tea.actor_critic.load_state_dict({k: t(v.copy()) for k, v in cases.actor_critic_state(c["tea_net"], c["O_t"], A, 0.5, c["seed"] + 1).items()})
+    tea.save(1)
+    env = FakeEnv(N, {"tsdf": O_s, "normal_state": c["O_t"], "proprio_state": c["proprio"]}, A)
+    cfg = dict(num_envs=N, obs_mode="tsdf", model=dict(action_std=c["action_std"], action_activate="tanh", clipAction=1.0,
+                                                        network=dict(c["stu_net"])),
+               max_iterations=c["max_iterations"], n_steps=1, n_updates=c["n_updates"], n_minibatches=c["n_minibatches"], device=DEV,
+               buf_size=c["buf_size"], reward_reset=False, add_proprio_obs=True, offline_data_pth=str(tmp_path / "offline"),
+               eval_round=1, eval_frequence=10 ** 9, save_frequence=10 ** 9, test_only=False, save_pose=False, save_video=False,
+               lr_schedule=c["lr_schedule"], lr=c["lr"], teacher=str(tmp_path / "model_1.pth"), resume=None, pretrain=None,
+               sampler=c["sampler"])
+    run = dagger(env, cfg, FakeLogger(str(tmp_path)))
+    init = cases.actor_critic_state(c["stu_net"], O_s, A, c["action_std"], c["seed"])
+    # the MLP student ignores `proprio_shape` (network.py:27-54 takes the flat obs): load the (O_s)-wide weights
+    run.student.load_state_dict({k: t(v.copy()) for k, v in init.items()})
+    run.storage.add_transitions_offline(run.offline_data_pth, run.device, run.add_proprio_obs)          # dagger.py:186-187
+    st = run.storage
+    assert [st.mix_buf_ind, st.cur_buf_size, st.last_episode_buf_ind] == list(fx["off_state"])
+    assert np.array_equal(st.observations.cpu().numpy(), fx["off_ring_obs"])
+    on = cases.dagger_offline_online(c)
+    for k in range(c["n_fill"]):
+        st.add_transitions_dagger(t(on["stu"][k]).to(DEV), t(on["tea"][k]).to(DEV))
+    assert [st.mix_buf_ind, st.cur_buf_size, st.last_episode_buf_ind] == list(fx["state"])
+    assert np.array_equal(st.observations.cpu().numpy(), fx["ring_obs"]) and np.array_equal(st.tea_obs.cpu().numpy(), fx["ring_tea"])
+    torch.manual_seed(c["torch_seed"])
+    run.log_dict = {}
+    run.update(c["it"])
+    np.testing.assert_allclose(run.log_dict["Train/dagger_loss"], float(fx["log_dagger_loss"]), rtol=5e-4)
+    np.testing.assert_allclose(run.log_dict["Train/learning_rate"], float(fx["log_learning_rate"]), rtol=1e-12)
+    assert_update_matches(flat_state(run.student.state_dict()), fx["final_flat"], init, c["lr"], len(fx["loss_trace"]))
+
+
+def test_dagger_run_loop_with_offline_preload(tmp_path, monkeypatch):
+    """`dagger.run()` itself with `offline_data_pth` set (the mixed BC + on-policy half of BASELINE cfg 5): the preload
+    happens before the first rollout step, the on-policy rows are appended behind it, every update is finite."""
+    from partmanip_amd.algorithms import ppo, dagger
+    from partmanip_amd.feeder import FeederEnv, ScreenLogger
+    from tests.test_gpu_run_loop import _ppo_cfg
+    c = cases.DAGGER_OFFLINE_CASE
+    monkeypatch.chdir(tmp_path)
+    cases.dagger_offline_write(c, str(tmp_path / "offline"))
+    O_s = c["D"] + c["proprio"]
+    env = FeederEnv(4, {"normal_state": c["O_t"], "tsdf": O_s, "proprio_state": c["proprio"]}, 10, DEV, seed=3, max_episode_length=5)
+    tlog = ScreenLogger(str(tmp_path), "t", "n", quiet=True)
+    tea = ppo(env, _ppo_cfg(dict(name="MLP", hid_dim=[64, 64], activation="tanh"), "normal_state", 4, 2, False), tlog)
+    tea.save(1)
+    cfg = dict(num_envs=4, obs_mode="tsdf",
+               model=dict(action_std=0.1, action_activate="tanh", clipAction=1.0, network=dict(name="MLP", hid_dim=[64, 64], activation="tanh")),
+               max_iterations=3, n_steps=1, n_updates=2, n_minibatches=2, device=DEV, buf_size=8, reward_reset=False,
+               add_proprio_obs=True, offline_data_pth=str(tmp_path / "offline"), eval_round=1, eval_frequence=10 ** 9,
+               save_frequence=10 ** 9, test_only=False, save_pose=False, save_video=False, lr_schedule="linear_decay", lr=1e-3,
+               teacher=os.path.join(tlog.save_ckpt_dir, "model_1.pth"), resume=None, pretrain=None, sampler="random")
+    run = dagger(env, cfg, ScreenLogger(str(tmp_path), "d", "n", quiet=True))
+    run.run()
+    assert run.curr_iter == 3
+    assert run.storage.cur_buf_size == 16 + 3 * 4 and run.storage.last_episode_buf_ind == 16       # 16 offline rows, then 12 on-policy
+    rows = cases.dagger_offline_rows(c)
+    want0 = np.concatenate([rows["tsdf"][0], rows["proprio_state"][0]])
+    assert np.array_equal(run.storage.observations[0].cpu().numpy(), want0)
+    assert np.isfinite(float(run.log_dict["Train/dagger_loss"]))

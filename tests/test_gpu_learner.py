@@ -19,7 +19,7 @@ import torch
 
 from oracle import ref_cpu as R
 from tests.golden import cases
-from tests.helpers import load_fixture, t, ppo_cfg, ppo_rollout, flat_state, FakeEnv, FakeLogger
+from tests.helpers import load_fixture, t, ppo_cfg, ppo_rollout, flat_state, FakeEnv, FakeLogger, assert_update_matches
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -51,7 +51,11 @@ def fill_storage(run, c, fx):
     return st
 
 
-def check_params(fin, ref_flat, stride, lr, n_steps):
+def check_params(fin, ref_flat, stride, lr, n_steps, init=None):
+    """init: the initial state dict (name -> array, state_dict order) -> adds the per-tensor relative-L2 bound on the
+    update (tests/helpers.py: a small tensor that moves the wrong way cannot hide in the whole-vector tail)."""
+    if init is not None:
+        return assert_update_matches(fin, ref_flat, init, lr, n_steps, stride)
     diff = np.abs(fin[::stride].astype(np.float64) - ref_flat.astype(np.float64))
     assert np.quantile(diff, 0.999) < 5e-2 * lr, (np.quantile(diff, 0.999), lr)
     assert diff.max() < 2.5 * lr * n_steps, (diff.max(), lr)
@@ -95,7 +99,8 @@ def test_ppo_update_matches_reference(name):
         np.testing.assert_allclose(float(log["Train/" + k]), float(fx["log_" + k]), rtol=5e-4, atol=5e-6, err_msg=k)
     fin = flat_state(run.actor_critic.state_dict())
     n_steps = len(fx["loss_trace"])
-    check_params(fin, fx["final_flat"], int(fx["final_stride"]), c["lr"], n_steps)
+    check_params(fin, fx["final_flat"], int(fx["final_stride"]), c["lr"], n_steps,
+                 init=cases.actor_critic_state(c["net"], c["O"], c["A"], c["action_std"], c["seed"]))
     np.testing.assert_allclose([g["lr"] for g in run.optimizer_actor.param_groups], fx["lr_actor_groups"])
     np.testing.assert_allclose([g["lr"] for g in run.optimizer_critic.param_groups], fx["lr_critic_groups"])
     assert int(run.optimizer_actor.state_dev[0]) == int(fx["adam_step"])
@@ -275,7 +280,8 @@ def test_dagger_update_matches_reference(name, tmp_path, monkeypatch):
     np.testing.assert_allclose(run.log_dict["Train/dagger_loss"], float(fx["log_dagger_loss"]), rtol=5e-4)
     np.testing.assert_allclose(run.log_dict["Train/learning_rate"], float(fx["log_learning_rate"]), rtol=1e-12)
     fin = flat_state(run.student.state_dict())
-    check_params(fin, fx["final_flat"], int(fx["final_stride"]), c["lr"], len(fx["loss_trace"]))
+    check_params(fin, fx["final_flat"], int(fx["final_stride"]), c["lr"], len(fx["loss_trace"]),
+                 init=cases.actor_critic_state(c["stu_net"], c["O_s"], A, c["action_std"], c["seed"], c["proprio"]))
     run.save(2)
     ck = torch.load(str(tmp_path / "model_2.pth"), map_location="cpu", weights_only=False)
     assert set(ck) >= {"iteration", "model_state_dict", "optimizer_state_dict", "total_steps", "obs_mode", "teacher"}

@@ -183,3 +183,26 @@ def test_add_transitions_offline_reads_scene_step_npy(tmp_path):
     np.testing.assert_array_equal(st.observations[1].numpy(), want[5])
     np.testing.assert_array_equal(st.observations[2].numpy(), want[2])
     np.testing.assert_array_equal(st.tea_obs[3].numpy(), rows[3]["tea_obs"])
+
+
+def test_offline_preload_then_on_policy_rows_match_the_reference_ring(tmp_path):
+    """Mixed BC + on-policy DAgger (storage.py:58-82 + :84-91, dagger.py:186-187): the ring contents and the three
+    ring counters after the preload and after the on-policy steps equal what the REFERENCE's own storage produced
+    on the same shards (tests/golden/make_golden.py gen_dagger_offline)."""
+    from partmanip_amd.algo_utils import RolloutStorage
+    from tests.golden import cases
+    from tests.helpers import load_fixture, t
+    c, fx = cases.DAGGER_OFFLINE_CASE, load_fixture("dagger_offline")
+    cases.dagger_offline_write(c, str(tmp_path / "offline"))
+    st = RolloutStorage(c["N"], c["buf_size"], c["D"] + c["proprio"], c["A"], "cpu", sampler=c["sampler"],
+                        tea_obs_shape=c["O_t"], max_length=200)
+    st.add_transitions_offline(str(tmp_path / "offline"), "cpu", add_proprio_obs=True)
+    assert [st.mix_buf_ind, st.cur_buf_size, st.last_episode_buf_ind] == list(fx["off_state"])
+    np.testing.assert_array_equal(st.observations.numpy(), fx["off_ring_obs"])
+    np.testing.assert_array_equal(st.tea_obs.numpy(), fx["off_ring_tea"])
+    on = cases.dagger_offline_online(c)
+    for k in range(c["n_fill"]):
+        st.add_transitions_dagger(t(on["stu"][k]), t(on["tea"][k]))
+    assert [st.mix_buf_ind, st.cur_buf_size, st.last_episode_buf_ind] == list(fx["state"])
+    np.testing.assert_array_equal(st.observations.numpy(), fx["ring_obs"])
+    np.testing.assert_array_equal(st.tea_obs.numpy(), fx["ring_tea"])

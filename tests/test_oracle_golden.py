@@ -258,3 +258,21 @@ def test_rollout_side_restatement_matches_reference():
     np.testing.assert_allclose(act.numpy(), fx["actions"], rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(logp.numpy(), fx["logp"], rtol=2e-5, atol=1e-4)
     assert np.array_equal(ls.numpy(), fx["log_std_rows"])
+
+
+def test_dagger_update_on_offline_plus_on_policy_ring_matches_reference():
+    """`dagger.update` over the ring the reference built from offline shards + on-policy rows (dagger_offline.npz)."""
+    c, fx = cases.DAGGER_OFFLINE_CASE, load_fixture("dagger_offline")
+    A, O_s = c["A"], c["D"] + c["proprio"]
+    stu = state_dict_t(cases.actor_critic_state(c["stu_net"], O_s, A, c["action_std"], c["seed"]))
+    tea = state_dict_t(cases.actor_critic_state(c["tea_net"], c["O_t"], A, 0.5, c["seed"] + 1))
+    model = lambda net, std: dict(action_std=std, action_activate="tanh", clipAction=1.0, network=dict(net))
+    cfg = dict(model=model(c["stu_net"], c["action_std"]), tea_model=model(c["tea_net"], 0.5), n_updates=c["n_updates"],
+               n_minibatches=c["n_minibatches"], sampler=c["sampler"], lr=c["lr"], lr_schedule=c["lr_schedule"],
+               max_iterations=c["max_iterations"], proprio_shape=0)
+    torch.manual_seed(c["torch_seed"])
+    out = R.dagger_update(stu, tea, t(fx["ring_obs"]), t(fx["ring_tea"]), int(fx["state"][1]), cfg, c["it"])
+    np.testing.assert_allclose(out["loss_trace"], fx["loss_trace"], rtol=2e-4, atol=1e-8)
+    np.testing.assert_allclose(out["log"]["Train/dagger_loss"], float(fx["log_dagger_loss"]), rtol=2e-4)
+    np.testing.assert_allclose(out["log"]["Train/learning_rate"], float(fx["log_learning_rate"]), rtol=1e-12)
+    assert_params_close(flat_state(stu), fx["final_flat"], c["lr"], len(fx["loss_trace"]))

@@ -19,8 +19,8 @@ from partmanip_amd.config import process_cfgs, num_actions
 from partmanip_amd.feeder import FeederEnv, ScreenLogger
 
 
-def set_seed(seed, exp_name, resume):
-    """train.py:16-50 minus the CUDA-specific determinism switches."""
+def pick_seed(seed, exp_name, resume):
+    """The seed / run-name resolution of train.py:16-31 (no RNG is seeded yet)."""
     if 'seed' in exp_name:
         seed = int(exp_name.split('seed')[-1])
     elif resume is not None:
@@ -32,6 +32,13 @@ def set_seed(seed, exp_name, resume):
         seed = np.random.randint(0, 10000)
     if 'seed' not in exp_name:
         exp_name = exp_name + f'_seed{seed}'
+    return int(seed), exp_name
+
+
+def set_seed(seed, exp_name, resume):
+    """train.py:16-50 minus the CUDA-specific determinism switches.  Under data parallelism rank 0 resolves the seed
+    (`seed: -1` draws one) and every rank uses it: one model, one run name, one checkpoint directory."""
+    seed, exp_name = pdist.resolve_seed(lambda: pick_seed(seed, exp_name, resume))
     print("Setting seed: {}".format(seed))
     random.seed(seed)
     np.random.seed(seed)
@@ -74,6 +81,7 @@ def main():
                     seed=cfg['seed'] + rank, max_episode_length=cfg['task']['maxEpisodeLength'])
     runner = {'ppo': ppo, 'dagger': dagger, 'bc': bc}[cfg['algo_name']](env, cfg['algo'], logger)
     runner.run()
+    return runner
 
 
 if __name__ == '__main__':
