@@ -78,7 +78,7 @@ def cpu_baseline_ppo(w, rollout_cpu, sd_cpu, cfg):
     from oracle import ref_cpu as R
     ncpu = os.cpu_count() or 1
     vision = w["net"]["name"] in ("PointNet", "PointNet2")
-    mb, n_mb = (512, 3) if vision else (2048, 16)
+    mb, n_mb = (512, 3) if vision else (2048, 128)
     T, N = w["T"], w["N"]
     keys = ("observations", "actions", "values", "returns", "actions_log_prob", "advantages", "mu", "sigma")
 
