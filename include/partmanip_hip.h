@@ -41,7 +41,7 @@ extern "C" {
 #define PM_ACT_TANH 1
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 120 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 121 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -86,6 +86,30 @@ size_t pm_linear_bwd_weight_workspace_bytes(int M, int N, int K);
 int pm_linear_bwd_weight_f32(const float* dY, long lddy, const float* X, long ldx, float* dW, long lddw,
                              float* db, int M, int N, int K, void* workspace, size_t workspace_bytes,
                              void* stream);
+
+/* Grouped forms (new; the reference runs one ATen GEMM per layer per network): up to PM_LINEAR_GROUP_MAX independent
+ * problems of the SAME kind in ONE launch.  The small-step regime (state PPO, ppo.py:315-384: 2560 dependent optimiser
+ * steps per iteration on 2048 x 512 matrices = one MFMA block per SIMD) is bound by per-launch ramp / drain and by
+ * single-wave stalls; the actor's and the critic's layer l are independent (ppo.py:73-74: disjoint parameters), and so
+ * are all weight gradients of a backward pass, so they share a grid.  Each desc has exactly the meaning of the
+ * corresponding single-problem call.
+ * pm_linear_bwd_weight_group_f32 with splits > 1 does NOT reduce: slab z (z = 0..splits-1) of problem i's dW / db is
+ * written at dW + z * slab_stride / db + z * slab_stride (the reduction over M is cut into `splits` equal ranges of
+ * whole 32-row steps); the caller sums the slabs in fixed order -- pm_clip_adam_group_f32 does it while it computes the
+ * gradient norm.  With splits == 1 dW / db are final. */
+#define PM_LINEAR_GROUP_MAX 8
+typedef struct pm_linear_fwd_desc {
+    const float* X; long ldx; const float* W; long ldw; const float* b; float* Y; long ldy; int M, N, K, act;
+} pm_linear_fwd_desc;
+typedef struct pm_linear_bwd_data_desc {
+    const float* dY; long lddy; const float* W; long ldw; const float* H; long ldh; float* dX; long lddx; int M, N, K, act;
+} pm_linear_bwd_data_desc;
+typedef struct pm_linear_bwd_weight_desc {
+    const float* dY; long lddy; const float* X; long ldx; float* dW; long lddw; float* db; long slab_stride; int M, N, K, pad_;
+} pm_linear_bwd_weight_desc;
+int pm_linear_fwd_group_f32(int n, const pm_linear_fwd_desc* d, void* stream);
+int pm_linear_bwd_data_group_f32(int n, const pm_linear_bwd_data_desc* d, void* stream);
+int pm_linear_bwd_weight_group_f32(int n, const pm_linear_bwd_weight_desc* d, int splits, void* stream);
 
 /* ------------------------------------------------------------------ K6/K7  PointNet encoder
  * network.py:147-153,172-181: per-point shared MLP C->128->256->512 (tanh,tanh,none) over
@@ -188,6 +212,16 @@ int pm_action_activation_f32(const float* mu, float* out, long n, float max_acti
  * Adam: betas (b1,b2), eps, bias-corrected exactly as torch (denom = sqrt(v)/sqrt(1-b2^t)+eps,
  * step = lr/(1-b1^t)).  Workspace: pm_clip_adam_workspace_bytes(n). */
 size_t pm_clip_adam_workspace_bytes(long n);
+/* The same step for several optimisers in two launches (ppo.py:353 and :382 are independent: optimizer_actor and
+ * optimizer_critic), each optionally summing split-K gradient slabs first: grads[i] += sum_{s=1..n_extra} extra[(s-1) *
+ * extra_stride + i] for i < n_sum (fixed order; grads is slab 0 of pm_linear_bwd_weight_group_f32), then exactly
+ * pm_clip_adam_step_f32.  workspace: pm_clip_adam_workspace_bytes(n) doubles per desc, 8-byte aligned. */
+typedef struct pm_clip_adam_desc {
+    float* params; float* grads; float* exp_avg; float* exp_avg_sq; long n, n_clip; const float* extra; long extra_stride;
+    long n_sum; int n_extra; float max_norm; double lr, b1, b2, eps; int32_t* state; const float* skip_flag;
+    float* gnorm_out; void* workspace;
+} pm_clip_adam_desc;
+int pm_clip_adam_group_f32(int n, const pm_clip_adam_desc* d, void* stream);
 int pm_clip_adam_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
                           long n_clip, float max_norm, double lr, double b1, double b2, double eps,
                           int32_t* state, const float* skip_flag, float* gnorm_out, void* workspace,

@@ -25,6 +25,10 @@ SIGNATURES = {
     "pm_linear_bwd_data_f32": (I, [P, L, P, L, P, L, P, L, I, I, I, I, P]),
     "pm_linear_bwd_weight_workspace_bytes": (Z, [I, I, I]),
     "pm_linear_bwd_weight_f32": (I, [P, L, P, L, P, L, P, I, I, I, P, Z, P]),
+    "pm_linear_fwd_group_f32": (I, [I, P, P]),
+    "pm_linear_bwd_data_group_f32": (I, [I, P, P]),
+    "pm_linear_bwd_weight_group_f32": (I, [I, P, I, P]),
+    "pm_clip_adam_group_f32": (I, [I, P, P]),
     "pm_pointnet_packed_elems": (Z, []),
     "pm_pointnet_pack_weights_f32": (I, [P, P, P, P]),
     "pm_pointnet_enc_fwd_f32": (I, [P, L, I, I, I, I, P, P, P, P, P, I, P, L, P, P, P]),
@@ -81,6 +85,30 @@ SIGNATURES = {
                           P, P, Z, P]),
 }
 
+
+
+# descriptor records of the grouped entry points (field for field the typedefs of include/partmanip_hip.h)
+class LinearFwdDesc(C.Structure):
+    _fields_ = [("X", P), ("ldx", L), ("W", P), ("ldw", L), ("b", P), ("Y", P), ("ldy", L), ("M", I), ("N", I), ("K", I),
+                ("act", I)]
+
+
+class LinearBwdDataDesc(C.Structure):
+    _fields_ = [("dY", P), ("lddy", L), ("W", P), ("ldw", L), ("H", P), ("ldh", L), ("dX", P), ("lddx", L), ("M", I),
+                ("N", I), ("K", I), ("act", I)]
+
+
+class LinearBwdWeightDesc(C.Structure):
+    _fields_ = [("dY", P), ("lddy", L), ("X", P), ("ldx", L), ("dW", P), ("lddw", L), ("db", P), ("slab_stride", L),
+                ("M", I), ("N", I), ("K", I), ("pad_", I)]
+
+
+class ClipAdamDesc(C.Structure):
+    _fields_ = [("params", P), ("grads", P), ("exp_avg", P), ("exp_avg_sq", P), ("n", L), ("n_clip", L), ("extra", P),
+                ("extra_stride", L), ("n_sum", L), ("n_extra", I), ("max_norm", F), ("lr", D), ("b1", D), ("b2", D),
+                ("eps", D), ("state", P), ("skip_flag", P), ("gnorm_out", P), ("workspace", P)]
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -m partmanip_amd.build` "
@@ -92,7 +120,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 120                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 121                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -17,6 +17,7 @@ from .. import ops
 
 class ActorCritic(nn.Module):
     SCAL_TAIL = 8
+    GRAD_SLABS = 4          # split-K slabs of the weight gradients (slab 0 = the gradient buffer; ops.linear_bwd_weight_group)
 
     def __init__(self, obs_shape, actions_shape, model_cfg, proprio_shape=0):
         super(ActorCritic, self).__init__()
@@ -45,8 +46,14 @@ class ActorCritic(nn.Module):
         flat_c = torch.empty(n_c, device=dev)
         # gradient buffers carry an 8-float tail for the step's scalars (loss, kl, skip flag, ...):
         # a data-parallel step all-reduces gradient and scalars as ONE message (dist.py)
-        grad_a = torch.zeros(n_a + A + self.SCAL_TAIL, device=dev)
-        grad_c = torch.zeros(n_c + self.SCAL_TAIL, device=dev)
+        # ... and is slab 0 of GRAD_SLABS equally spaced slabs: the grouped weight-gradient launch of the small-step path
+        # writes split-K partial sums to slabs 0..S-1 and the optimiser launch adds them up (no separate reduce kernels)
+        stride_a = (n_a + A + self.SCAL_TAIL + 3) // 4 * 4
+        stride_c = (n_c + self.SCAL_TAIL + 3) // 4 * 4
+        slabs_a = torch.zeros(self.GRAD_SLABS * stride_a, device=dev)
+        slabs_c = torch.zeros(self.GRAD_SLABS * stride_c, device=dev)
+        grad_a = slabs_a[:n_a + A + self.SCAL_TAIL]
+        grad_c = slabs_c[:n_c + self.SCAL_TAIL]
 
         def rehome(params, flat, grad):
             views, off = {}, 0
@@ -65,7 +72,8 @@ class ActorCritic(nn.Module):
         self.critic.set_grad_views(vc)
         self._flat = dict(actor=flat_a, critic=flat_c, grad_actor=grad_a, grad_critic=grad_c, n_actor=n_a,
                           n_critic=n_c, grad_log_std=grad_a[n_a:n_a + A], scal_actor=grad_a[n_a + A:],
-                          scal_critic=grad_c[n_c:])
+                          scal_critic=grad_c[n_c:], slab_stride_actor=stride_a, slab_stride_critic=stride_c,
+                          extra_actor=slabs_a[stride_a:], extra_critic=slabs_c[stride_c:])
         return self._flat
 
     def flat(self):

@@ -80,6 +80,60 @@ class _LinearChain:
         return dx_out
 
 
+def chains_forward(chains, xs):
+    """Forward of several _LinearChains with the same depth, ONE grouped launch per layer (ops.linear_fwd_group): the actor's
+    and the critic's layer l are independent problems (ppo.py:73-74) and share a grid.  Same arithmetic as
+    `_LinearChain.forward` per chain."""
+    n = len(chains[0].linears)
+    assert all(len(ch.linears) == n for ch in chains)
+    cur = list(xs)
+    for ch, x in zip(chains, xs):
+        ch.x, ch.h = x, []
+    for i in range(n):
+        last = i == n - 1
+        items = []
+        for ch, c in zip(chains, cur):
+            lin = ch.linears[i]
+            y = torch.empty(c.shape[0], lin.out_features, device=c.device)
+            items.append((c, lin.weight.data, lin.bias.data, y, ch.act if (not last or ch.final_act) else ops.ACT_NONE))
+        ops.linear_fwd_group(items)
+        cur = [it[3] for it in items]
+        if not last:
+            for ch, y in zip(chains, cur):
+                ch.h.append(y)
+    return cur
+
+
+def chains_backward(chains, dys, slab_strides, splits):
+    """Backward of the same chains: one grouped data-gradient launch per layer, then ALL weight gradients of all chains in
+    (at most) two grouped launches.  splits > 1: the reduction over the batch is cut into `splits` slabs written at
+    grad + z * slab_stride (slab 0 = the chain's gradient views); the optimiser launch sums them (ops.clip_adam_group)."""
+    n = len(chains[0].linears)
+    dy = list(dys)
+    dz = [[None] * n for _ in chains]                      # dz[c][i] = d loss / d (pre-activation of layer i)
+    for c, d in enumerate(dy):
+        dz[c][n - 1] = d
+    for i in reversed(range(1, n)):
+        items = []
+        for c, ch in enumerate(chains):
+            inp = ch.h[i - 1]
+            items.append((dz[c][i], ch.linears[i].weight.data, inp, torch.empty_like(inp), ch.act))
+        ops.linear_bwd_data_group(items)
+        for c, it in enumerate(items):
+            dz[c][i - 1] = it[3]
+    vec, rest = [], []
+    for c, ch in enumerate(chains):
+        for i in range(n):
+            inp = ch.h[i - 1] if i > 0 else ch.x
+            dW, db = ch.grads[i]
+            item = (dz[c][i], inp, dW, db, slab_strides[c])
+            ok = dz[c][i].shape[1] % 4 == 0 and inp.shape[1] % 4 == 0 and inp.stride(0) % 4 == 0 and inp.data_ptr() % 16 == 0
+            (vec if ok else rest).append(item)
+    for grp in (vec, rest):                                # 16-byte-loadable problems must not share a launch with the others
+        for lo in range(0, len(grp), 8):
+            ops.linear_bwd_weight_group(grp[lo:lo + 8], splits)
+
+
 class _HipNet(nn.Module):
     """Common plumbing: grad views + scratch workspace."""
 

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from ..algo_utils import RolloutStorage, ActorCritic, Normalization, FusedAdam
+from ..algo_utils.network import chains_forward, chains_backward
 from .. import ops, dist as pdist
 
 try:                                        # simulator-side helper of the reference (utils/img2video.py)
@@ -110,6 +111,13 @@ class ppo:
         self.use_graphs = (gr != "0") and is_mlp and self.overlap and cfg['sampler'] == 'sequential' and \
             self.lr_schedule == 'fixed' and self.sync is None
         self._graphs = {}
+        # small-step regime (MLP backbones), opt-in (PARTMANIP_PAIR=1): actor step k and critic step k as ONE launch chain --
+        # every layer of the two networks is a grouped launch (two problems per grid), all eight weight gradients are two
+        # launches whose split-K slabs the grouped optimiser launch sums: ~15 launches per step PAIR instead of ~48 on two
+        # streams.  Identical arithmetic per network.  Measured at cfg 2 (round 2): 1.66 M env-steps/s against 1.75 M for
+        # the two-stream form -- kernels of DIFFERENT kinds co-scheduled from two streams fill the CUs better than two
+        # problems of the same kind in one grid -- so the two streams stay the default.
+        self.pair = is_mlp and self.sync is None and os.environ.get("PARTMANIP_PAIR", "0") == "1"
         # neighbourhood tables (FPS centres + ball-query indices) once per rollout; PARTMANIP_GEOM_CACHE=0 recomputes
         # them in every forward (A/B; identical results)
         self.cache_geometry = os.environ.get("PARTMANIP_GEOM_CACHE", "1") != "0"
@@ -271,6 +279,39 @@ class ppo:
         ops.ppo_accumulate_stats(self._acc, scal_c, 1)
         self.optimizer_critic.step(n=n_c, n_clip=n_c if clip else 0, max_norm=self.max_grad_norm if clip else 0.0)
 
+    def _pair_step(self, f, views, ia, ic):
+        """Actor mini-batch `ia` (ppo.py:316-357) and critic mini-batch `ic` (ppo.py:360-384) in one grouped launch chain."""
+        ac, tricks = self.actor_critic, self.tricks
+        n_a, n_c, A = f['n_actor'], f['n_critic'], self.num_actions
+        scal_a, scal_c = f['scal_actor'], f['scal_critic']
+        clip = tricks['use_grad_clip']
+        mba = self._minibatch(views, ia, ('obs', 'actions', 'old_logp', 'adv', 'old_mu', 'old_sigma'), self._stage)
+        mbc = self._minibatch(views, ic, ('obs', 'returns', 'values'), self._stage_c)
+        B = mba['obs'].shape[0]
+        chains = [ac.actor._chain, ac.critic._chain]
+        mu, value = chains_forward(chains, [mba['obs'], mbc['obs']])
+        mom, cnt = None, 0.0
+        if tricks['mini_adv_norm']:
+            ops.moments(mba['adv'].reshape(-1), self._mom, self._ws)
+            mom, cnt = self._mom, B
+        dmu = torch.empty(B, A, device=mu.device)
+        ops.ppo_actor_loss(mu, ac.log_std.data, mba['actions'], mba['old_logp'], mba['adv'], mba['old_mu'], mba['old_sigma'],
+                           ac.max_action, ac.action_activate == 'tanh', self.epsilon_clip, self.desired_kl, mom, cnt, scal_a,
+                           dmu, f['grad_log_std'], self._ws_loss)
+        dv = torch.empty(mbc['obs'].shape[0], 1, device=value.device)
+        ops.value_loss(value, mbc['returns'], mbc['values'], tricks['use_clipped_value_loss'], self.epsilon_clip, None, 1.0,
+                       scal_c, dv)
+        S = ac.GRAD_SLABS if B >= 1024 and mbc['obs'].shape[0] == B else 1
+        chains_backward(chains, [dmu, dv], [f['slab_stride_actor'], f['slab_stride_critic']], S)
+        ops.ppo_accumulate_stats(self._acc, scal_a, 0)
+        ops.ppo_accumulate_stats(self._acc, scal_c, 1)
+        mn = self.max_grad_norm if clip else 0.0
+        ops.clip_adam_group([
+            self.optimizer_actor.group_item(n=n_a + A, n_clip=n_a if clip else 0, max_norm=mn, skip_flag=scal_a[2:3],
+                                            extra=f['extra_actor'], extra_stride=f['slab_stride_actor'], n_sum=n_a, n_extra=S - 1),
+            self.optimizer_critic.group_item(n=n_c, n_clip=n_c if clip else 0, max_norm=mn, extra=f['extra_critic'],
+                                             extra_stride=f['slab_stride_critic'], n_sum=n_c, n_extra=S - 1)])
+
     # ---- hipGraph replay of the per-mini-batch launch chains (small-step regime) -----------------
     def _graph_table(self, views):
         """Graphs are valid for one (rollout buffers, learning rates) configuration: every kernel argument of a
@@ -282,7 +323,8 @@ class ppo:
                f['actor'].data_ptr(), f['critic'].data_ptr(), self.optimizer_actor.param_groups[0]['lr'], self.optimizer_critic.param_groups[0]['lr'])
         if self._graphs.get('key') != key:
             self._graphs = {'key': key, 'seen': set(),
-                            'pool': {'a': torch.cuda.graph_pool_handle(), 'c': torch.cuda.graph_pool_handle()}}
+                            'pool': {'a': torch.cuda.graph_pool_handle(), 'c': torch.cuda.graph_pool_handle(),
+                                     'p': torch.cuda.graph_pool_handle()}}
         return self._graphs
 
     def _replay(self, graphs, k, fn, stream):
@@ -336,6 +378,12 @@ class ppo:
         graphs = self._graph_table(views) if self.use_graphs else None
         for ep, (la, lc) in enumerate(zip(lists_a, lists_c)):
             for ia, ic in zip(la, lc):
+                if self.pair:
+                    if graphs is not None:
+                        self._replay(graphs, ('p', ia, ic), lambda: self._pair_step(f, views, ia, ic), main)
+                    else:
+                        self._pair_step(f, views, ia, ic)
+                    continue
                 if graphs is not None:
                     self._replay(graphs, ('a', ia), lambda: self._actor_step(f, views, ia, self._stage), main)
                     self._replay(graphs, ('c', ic), lambda: self._critic_step(f, views, ic, self._stage_c), side)

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpartmanip_hip.so")
-SOURCES = ["gae.hip", "losses.hip", "adam.hip", "gemm_f32.hip", "pointnet_enc.hip", "pointnet_enc_bf3.hip", "pointnet_enc_bf6.hip", "pointops.hip", "sa_fused.hip", "conv3d.hip"]
+SOURCES = ["gae.hip", "losses.hip", "adam.hip", "gemm_f32.hip", "gemm2_f32.hip", "pointnet_enc.hip", "pointnet_enc_bf3.hip", "pointnet_enc_bf6.hip", "pointops.hip", "sa_fused.hip", "conv3d.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"]
 
@@ -25,7 +25,7 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mfma_f32.h"),
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mfma_f32.h"), os.path.join(CSRC, "gemm2.h"),
             os.path.join(HERE, "..", "include", "partmanip_hip.h")]
     objs, rebuilt = [], False
     procs = []

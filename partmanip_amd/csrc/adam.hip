@@ -105,3 +105,115 @@ extern "C" int pm_clip_adam_step_f32(float* params, const float* grads, float* e
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
+
+// ---- several optimisers per launch pair, with the split-K slab sum folded into the norm pass -------------------------
+#define ADAM_GROUP_MAX 4
+struct AdamGroup {
+    int n;
+    int block0[ADAM_GROUP_MAX + 1];
+    pm_clip_adam_desc d[ADAM_GROUP_MAX];
+};
+
+__global__ __launch_bounds__(ADAM_THREADS) void grad_sumsq_group_kernel(AdamGroup G) {
+    __shared__ double red[ADAM_THREADS / 64];
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < ADAM_GROUP_MAX; ++i)
+        if (i < G.n && (int)blockIdx.x >= G.block0[i]) k = i;
+    const pm_clip_adam_desc& d = G.d[k];
+    const int nb = G.block0[k + 1] - G.block0[k], b = (int)blockIdx.x - G.block0[k];
+    const long n_clip = d.max_norm > 0.0f ? d.n_clip : 0;
+    const long n_sum = d.n_extra > 0 ? d.n_sum : 0;
+    const long hi = n_clip > n_sum ? n_clip : n_sum;
+    float* __restrict__ g = d.grads;
+    double s = 0.0;
+    for (long i = (long)b * ADAM_THREADS + threadIdx.x; i < hi; i += (long)nb * ADAM_THREADS) {
+        float gi = g[i];
+        if (i < n_sum) {                                   // slab 0 is `grads` itself: add slabs 1.. in fixed order
+            for (int z = 0; z < d.n_extra; ++z) gi += d.extra[(long)z * d.extra_stride + i];
+            g[i] = gi;
+        }
+        if (i < n_clip) s += (double)gi * (double)gi;
+    }
+    s = block_sum<double, ADAM_THREADS>(s, red);
+    if (threadIdx.x == 0) {
+        ((double*)d.workspace)[b] = s;
+        if (b == 0) {
+            const bool skip = d.skip_flag && d.skip_flag[0] != 0.0f;
+            if (!skip) d.state[0] += 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(ADAM_THREADS) void clip_adam_group_kernel(AdamGroup G) {
+    __shared__ double red[ADAM_THREADS / 64];
+    __shared__ float s_coef, s_step_size, s_bc2_sqrt;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < ADAM_GROUP_MAX; ++i)
+        if (i < G.n && (int)blockIdx.x >= G.block0[i]) k = i;
+    const pm_clip_adam_desc& d = G.d[k];
+    const int nb = G.block0[k + 1] - G.block0[k], b = (int)blockIdx.x - G.block0[k];
+    const bool skip = d.skip_flag && d.skip_flag[0] != 0.0f;
+    const double* part = (const double*)d.workspace;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += ADAM_THREADS) s += part[i];
+    s = block_sum<double, ADAM_THREADS>(s, red);
+    if (threadIdx.x == 0) {                                // identical arithmetic to clip_adam_kernel above
+        const float total = (float)sqrt(s);
+        float coef = 1.0f;
+        if (d.max_norm > 0.0f) {
+            coef = d.max_norm / (total + 1e-6f);
+            if (coef > 1.0f) coef = 1.0f;
+        }
+        s_coef = coef;
+        const int t = d.state[0];
+        const double bc1 = 1.0 - pow(d.b1, (double)t);
+        const double bc2 = 1.0 - pow(d.b2, (double)t);
+        s_step_size = (float)(d.lr / bc1);
+        s_bc2_sqrt = (float)sqrt(bc2);
+        if (b == 0 && d.gnorm_out) d.gnorm_out[0] = total;
+    }
+    __syncthreads();
+    if (skip) return;
+    const float coef = s_coef, step_size = s_step_size, bc2s = s_bc2_sqrt;
+    const float fb2 = (float)d.b2, feps = (float)d.eps;
+    const float omb1 = (float)(1.0 - d.b1), omb2 = (float)(1.0 - d.b2);
+    float* __restrict__ p = d.params;
+    const float* __restrict__ g = d.grads;
+    float* __restrict__ m = d.exp_avg;
+    float* __restrict__ v = d.exp_avg_sq;
+    const long n = d.n, n_clip = d.n_clip;
+    for (long i = (long)b * ADAM_THREADS + threadIdx.x; i < n; i += (long)nb * ADAM_THREADS) {
+        float gi = g[i];
+        if (i < n_clip) gi = gi * coef;
+        const float mi = m[i] + omb1 * (gi - m[i]);
+        const float vi = v[i] * fb2 + omb2 * gi * gi;
+        const float denom = sqrtf(vi) / bc2s + feps;
+        p[i] = p[i] - step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+extern "C" int pm_clip_adam_group_f32(int n, const pm_clip_adam_desc* d, void* stream) {
+    PM_REQUIRE(d && n >= 1 && n <= ADAM_GROUP_MAX);
+    AdamGroup G{};
+    G.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const pm_clip_adam_desc& q = d[i];
+        PM_REQUIRE(q.params && q.grads && q.exp_avg && q.exp_avg_sq && q.state && q.workspace && q.n > 0 && q.n_clip >= 0 &&
+                   q.n_clip <= q.n && q.n_extra >= 0 && (q.n_extra == 0 || (q.extra && q.n_sum >= 0 && q.n_sum <= q.n)));
+        if (((uintptr_t)q.workspace & 7) != 0) return PM_EALIGN;
+        G.d[i] = q;
+        G.block0[i] = blocks;
+        blocks += adam_blocks(q.n);
+    }
+    G.block0[n] = blocks;
+    for (int i = n + 1; i <= ADAM_GROUP_MAX; ++i) G.block0[i] = blocks;
+    hipLaunchKernelGGL(grad_sumsq_group_kernel, dim3(blocks), dim3(ADAM_THREADS), 0, pm_stream(stream), G);
+    hipLaunchKernelGGL(clip_adam_group_kernel, dim3(blocks), dim3(ADAM_THREADS), 0, pm_stream(stream), G);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}

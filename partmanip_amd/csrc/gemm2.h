@@ -1,0 +1,37 @@
+// Grouped fp32-MFMA GEMM (gemm2_f32.hip): up to GEMM2_MAXP independent problems of one operand orientation in ONE
+// launch -- the Linear layers of the small-step regime (state PPO: 2560 dependent optimiser steps of ~12 launches)
+// are launch- and ramp-bound, so the actor's and the critic's layer, or all weight gradients of a network, share a
+// grid.  Internal to libpartmanip_hip.so; the C ABI on top is in gemm_f32.hip.
+#pragma once
+#include "common.h"
+
+#define GEMM2_MAXP 8
+
+enum { G2_EPI_BIAS_ACT = 0, G2_EPI_MUL_DACT = 1, G2_EPI_PLAIN = 2 };
+
+struct Gemm2Prob {
+    const float* A; long lda;     // k-contiguous: A[row*lda + k]; k-major: A[k*lda + row]
+    const float* B; long ldb;     // k-contiguous: B[col*ldb + k]; k-major: B[k*ldb + col]
+    float* C; long ldc;           // C[row*ldc + col] (+ z*slab for split-K slab z)
+    const float* bias;            // G2_EPI_BIAS_ACT: per column (may be null)
+    const float* H; long ldh;     // G2_EPI_MUL_DACT: C *= 1 - H[row][col]^2
+    float* dbias; long bslab;     // G2_EPI_PLAIN with a k-major A: column sums of A (= bias gradient) (+ z*bslab), or null
+    long slab;                    // split-K: C offset per slab (elements)
+    int M, N, K;                  // rows, cols, reduction
+    int epi, act;
+    int vecA, vecB;               // 16-byte global loads allowed for that operand
+    int splits, kchunk;           // split-K: number of slabs, reduction range per slab (multiple of 32)
+    int vecC;                     // 16-byte stores of C (and loads of bias / H) allowed (filled by the launcher)
+    int tiles_m, tiles_n;         // filled by the launcher
+    int block0;                   // first work-group of this problem in the grid (filled by the launcher)
+};
+
+struct Gemm2Group {
+    int n;
+    unsigned long long* prof;     // -DG2_PROFILE builds: 4 s_memtime stamps per work-group (tools/g2_profile.py)
+    Gemm2Prob p[GEMM2_MAXP];
+};
+
+// Launches the group (all problems share the orientation); big = 128x128 work-group tiles (for M*N >> chip), else 64x64.
+// Returns PM_OK / PM_E*.  `tag` only names the launch for profiling purposes.
+int gemm2_launch(Gemm2Group& g, bool a_kmajor, bool b_kmajor, void* stream);

@@ -1,0 +1,560 @@
+// Grouped, software-pipelined fp32-MFMA GEMM (v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation, bitwise an
+// fmaf chain per output element) behind the Linear entry points of gemm_f32.hip.
+//
+// Why a second GEMM kernel: the Linear layers of the small-step regime are 2048 x 512 x 512 -- 1024 MFMA blocks, one
+// per SIMD.  The first kernel (gemm_f32_kernel: 8 waves in lock-step on a 64 x 64 tile, two barriers per K-step, every
+// wave staging at the same time and multiplying at the same time) reaches 57 TFLOP/s there, the library (hipBLASLt)
+// the same.  This one keeps the matrix pipe of a SIMD fed from ONE wave:
+//   * a work-group is 4 waves (2 x 2) -- one per SIMD -- on a (64 WM) x (64 WN) tile, each wave WM x WN blocks of 32 x 32;
+//   * K-step 32, LDS double-buffered, ONE barrier per K-step.  A K-step is two half-steps of 8 k-values per lane half;
+//     the fragments of a half-step live in two fixed register sets X / Y:
+//         [barrier]  read X(k+1) <- LDS[next] | MFMA Y(k)  ||  read Y(k+1) .. | MFMA X(k+1) | staging -> LDS | global loads
+//     so every LDS read, the LDS write of tile k+1 and the global loads of tile k+2 are issued between MFMAs of a
+//     half-step whose operands are already in registers, and no LDS latency follows the barrier;
+//   * global -> register -> LDS staging (T14: issue early, write late); out-of-range k is zero-filled by a select on
+//     the loaded value, addresses are clamped instead of predicated (a predicated load makes hipcc branch around it and
+//     drain the whole queue);
+//   * k-major operands (the weight gradient's dY^T and X, the data gradient's W) stay k-major in LDS [k][row]; with two
+//     blocks per wave the tile rows are interleaved (row = 2 i + block) so that one ds_read_b64 feeds both blocks;
+//   * several problems per launch (Gemm2Group): block -> (problem, split-K slab, tile), XCD-aware (T1) inside a problem.
+// Split-K slabs are written to slab z of C; the caller reduces them in fixed order (or hands them to the optimiser
+// kernels, which sum the slabs while they compute the gradient norm: adam.hip).
+#include "gemm2.h"
+
+#ifndef G2_ABLATE
+#define G2_ABLATE 0                     // profiling builds only: 1 = no global loads, 2 = no LDS writes in the K loop
+#endif
+#define G2_TK 32
+#define G2_LDK 36                       // k-contiguous LDS row stride (floats): 16 lanes of a ds_read_b128 group hit 16 distinct 4-bank slots
+#define G2_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+template <int W>
+struct G2Frag {
+    float v[W][8];
+};
+template <int T>
+struct G2Stage {
+    float s[T / 8];                     // T x 32 floats over 256 threads
+};
+
+// (The zero fill of k >= kend is applied when the registers are WRITTEN to LDS, one K-step after the load was issued:
+// a select next to the load makes the compiler wait for the load right there.)
+// ---- global -> registers --------------------------------------------------------------------------------------------
+template <bool KM, int T, bool VEC>
+__device__ __forceinline__ void g2_stage_load(const float* __restrict__ P, long ld, int r0, int nrows, int k0, int kend, int Kfull,
+                                              G2Stage<T>& st) {
+    const int tid = threadIdx.x;
+    if (VEC) {
+#pragma unroll
+        for (int j = 0; j < T / 32; ++j) {
+            const int id = tid + 256 * j;
+            int row, k;
+            if (KM) { k = id / (T / 4); row = (id % (T / 4)) * 4; } else { row = id >> 3; k = (id & 7) * 4; }
+            const int gk = k0 + k;
+            float4 v;
+            if (KM) v = *(const float4*)(P + (long)min(gk, Kfull - 1) * ld + min(r0 + row, nrows - 4));
+            else v = *(const float4*)(P + (long)min(r0 + row, nrows - 1) * ld + min(gk, Kfull - 4));
+            st.s[4 * j] = v.x; st.s[4 * j + 1] = v.y; st.s[4 * j + 2] = v.z; st.s[4 * j + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < T / 8; ++j) {
+            const int id = tid + 256 * j;
+            int row, k;
+            if (KM) { k = id / T; row = id % T; } else { row = id >> 5; k = id & 31; }
+            const int gk = k0 + k;
+            const int gr = min(r0 + row, nrows - 1), gkc = min(gk, Kfull - 1);
+            st.s[j] = KM ? P[(long)gkc * ld + gr] : P[(long)gr * ld + gkc];
+        }
+    }
+}
+// ---- registers -> LDS -----------------------------------------------------------------------------------------------
+template <bool KM, int T, bool VEC>
+__device__ __forceinline__ void g2_stage_store(float* __restrict__ S, const G2Stage<T>& st, int k0, int kend) {
+    const int tid = threadIdx.x;
+    if (VEC) {
+#pragma unroll
+        for (int j = 0; j < T / 32; ++j) {
+            const int id = tid + 256 * j;
+            const bool ok = k0 + (KM ? id / (T / 4) : (id & 7) * 4) < kend;
+            const float4 v = make_float4(ok ? st.s[4 * j] : 0.f, ok ? st.s[4 * j + 1] : 0.f, ok ? st.s[4 * j + 2] : 0.f,
+                                         ok ? st.s[4 * j + 3] : 0.f);
+            if (KM) *(float4*)(S + (id / (T / 4)) * T + (id % (T / 4)) * 4) = v;
+            else *(float4*)(S + (id >> 3) * G2_LDK + (id & 7) * 4) = v;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < T / 8; ++j) {
+            const int id = tid + 256 * j;
+            const float v = (k0 + (KM ? id / T : (id & 31)) < kend) ? st.s[j] : 0.f;
+            if (KM) S[(id / T) * T + (id % T)] = v;
+            else S[(id >> 5) * G2_LDK + (id & 31)] = v;
+        }
+    }
+}
+// ---- LDS -> fragments of half-step h: lane (li, lh) holds k = 16 h + 8 lh + s, s = 0..7, of its row in each block ----
+template <bool KM, int W, int T>
+__device__ __forceinline__ void g2_read_frag(const float* __restrict__ S, int woff, int li, int lh, int h, G2Frag<W>& f) {
+    if (KM) {
+        const float* p = S + (h * 16 + lh * 8) * T + woff + li * W;      // rows interleaved: tile row = woff + W * i + block
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (W == 1) {
+                f.v[0][s] = p[s * T];
+            } else {
+                const float2 v = *(const float2*)(p + s * T);
+                f.v[0][s] = v.x;
+                f.v[W - 1][s] = v.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < W; ++b) {
+            const float* p = S + (woff + b * 32 + li) * G2_LDK + h * 16 + lh * 8;
+            const float4 v0 = *(const float4*)p, v1 = *(const float4*)(p + 4);
+            f.v[b][0] = v0.x; f.v[b][1] = v0.y; f.v[b][2] = v0.z; f.v[b][3] = v0.w;
+            f.v[b][4] = v1.x; f.v[b][5] = v1.y; f.v[b][6] = v1.z; f.v[b][7] = v1.w;
+        }
+    }
+}
+template <int WM, int WN, int S0, int S1>
+__device__ __forceinline__ void g2_mfma_part(const G2Frag<WM>& a, const G2Frag<WN>& b, f32x16 (&acc)[WM][WN]) {
+#pragma unroll
+    for (int s = S0; s < S1; ++s)
+#pragma unroll
+        for (int bn = 0; bn < WN; ++bn)
+#pragma unroll
+            for (int bm = 0; bm < WM; ++bm) acc[bm][bn] = G2_MFMA(a.v[bm][s], b.v[bn][s], acc[bm][bn]);
+}
+template <int WM, int WN>
+__device__ __forceinline__ void g2_mfma_half(const G2Frag<WM>& a, const G2Frag<WN>& b, f32x16 (&acc)[WM][WN]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int bn = 0; bn < WN; ++bn)
+#pragma unroll
+            for (int bm = 0; bm < WM; ++bm) acc[bm][bn] = G2_MFMA(a.v[bm][s], b.v[bn][s], acc[bm][bn]);
+}
+
+// ---- epilogue (shared by the register-staged and the LDS-DMA kernel) ------------------------------------------------
+template <bool A_KM, bool B_KM, int WM, int WN, int NT>
+__device__ __forceinline__ void g2_epilogue(const Gemm2Prob& g, f32x16 (&acc)[WM][WN], float* __restrict__ lds, int m0, int n0, int z,
+                                            int wmo, int wno, int li, int lh, bool writer) {
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    const int tid = threadIdx.x;
+    // ---- epilogue: acc[bm][bn][r] is block row i = (r&3) + 8 (r>>2) + 4 lh, block column li.  Written straight from the
+    // accumulators a wave stores 16 x (2 rows x 128 B) per block -- store-issue-bound: 8.7 k cycles for a 64 x 64 tile, as long
+    // as half its K loop.  The tile goes through LDS instead (the operand buffers are free now) and leaves as 16-byte stores of
+    // whole rows; bias / activation / (1 - h^2) are applied on the way out, four columns at a time.
+    constexpr int LDC = TN + 4;
+    __syncthreads();                                                       // every wave is done with the operand buffers
+    if (writer)
+#pragma unroll
+    for (int bn = 0; bn < WN; ++bn)
+#pragma unroll
+        for (int bm = 0; bm < WM; ++bm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                lds[(wmo + (A_KM ? i * WM + bm : bm * 32 + i)) * LDC + wno + (B_KM ? li * WN + bn : bn * 32 + li)] = acc[bm][bn][r];
+            }
+    __syncthreads();
+    float* C = g.C + (long)z * g.slab;
+    const int epi = g.epi, act = g.act;
+    if (g.vecC) {
+#pragma unroll
+        for (int j = 0; j < TM * TN / 4 / NT; ++j) {
+            const int id = tid + NT * j, row = id / (TN / 4), c4 = (id % (TN / 4)) * 4;
+            const int grow = m0 + row, gcol = n0 + c4;
+            if (grow < g.M && gcol < g.N) {                                // N % 4 == 0: a float4 is inside or outside as a whole
+                float4 v = *(const float4*)(lds + row * LDC + c4);
+                if (epi == G2_EPI_BIAS_ACT) {
+                    if (g.bias) {
+                        const float4 bb = *(const float4*)(g.bias + gcol);
+                        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                    }
+                    if (act == PM_ACT_TANH) { v.x = pm_tanh(v.x); v.y = pm_tanh(v.y); v.z = pm_tanh(v.z); v.w = pm_tanh(v.w); }
+                } else if (epi == G2_EPI_MUL_DACT && act == PM_ACT_TANH) {
+                    const float4 hh = *(const float4*)(g.H + (long)grow * g.ldh + gcol);
+                    v.x *= 1.0f - hh.x * hh.x; v.y *= 1.0f - hh.y * hh.y; v.z *= 1.0f - hh.z * hh.z; v.w *= 1.0f - hh.w * hh.w;
+                }
+                *(float4*)(C + (long)grow * g.ldc + gcol) = v;
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int j = 0; j < TM * TN / NT; ++j) {
+            const int id = tid + NT * j, row = id / TN, col = id % TN;
+            const int grow = m0 + row, gcol = n0 + col;
+            if (grow < g.M && gcol < g.N) {
+                float v = lds[row * LDC + col];
+                if (epi == G2_EPI_BIAS_ACT) {
+                    if (g.bias) v += g.bias[gcol];
+                    if (act == PM_ACT_TANH) v = pm_tanh(v);
+                } else if (epi == G2_EPI_MUL_DACT && act == PM_ACT_TANH) {
+                    const float hh = g.H[(long)grow * g.ldh + gcol];
+                    v *= 1.0f - hh * hh;
+                }
+                C[(long)grow * g.ldc + gcol] = v;
+            }
+        }
+    }
+}
+
+template <bool A_KM, bool B_KM, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void gemm2_kernel(Gemm2Group gg) {
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    constexpr int ABUF = TM * G2_LDK, BBUF = TN * G2_LDK;              // >= 32 * T floats of the k-major layout
+    __shared__ __attribute__((aligned(16))) float lds[2 * ABUF + 2 * BBUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+#ifdef G2_PROFILE
+    const unsigned long long t_start = __builtin_readcyclecounter();
+#define G2_STAMP(i) if (gg.prof && tid == 0) gg.prof[(size_t)blockIdx.x * 4 + (i)] = __builtin_readcyclecounter()
+    if (gg.prof && tid == 0) gg.prof[(size_t)blockIdx.x * 4] = t_start;
+#define G2_KSTAMP(i) if (gg.prof && tid == 0 && k == 4) gg.prof[(size_t)(65536 + blockIdx.x) * 4 * 2 + (i) - 4] = __builtin_readcyclecounter()
+#else
+#define G2_STAMP(i)
+#define G2_KSTAMP(i)
+#endif
+    // ---- block -> (problem, slab, tile) ----
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM2_MAXP; ++i)
+        if (i < gg.n && (int)blockIdx.x >= gg.p[i].block0) pi = i;
+    const Gemm2Prob& g = gg.p[pi];
+    const int tiles = g.tiles_m * g.tiles_n, nblk = tiles * g.splits;
+    int local = (int)blockIdx.x - g.block0;
+    if (local >= nblk) return;                                              // padding block behind a problem (launcher)
+    if ((nblk & 7) == 0) local = (local & 7) * (nblk >> 3) + (local >> 3);   // T1: an XCD (blocks = x mod 8) owns contiguous tiles
+    const int z = local / tiles, t = local - z * tiles;
+    const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int kbeg = z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (kend - kbeg + G2_TK - 1) / G2_TK;
+    const int wmo = (wave >> 1) * 32 * WM, wno = (wave & 1) * 32 * WN;     // this wave's first tile row / column
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int bm = 0; bm < WM; ++bm)
+#pragma unroll
+        for (int bn = 0; bn < WN; ++bn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bm][bn][r] = 0.f;
+
+    const bool do_bias = A_KM && g.epi == G2_EPI_PLAIN && g.dbias != nullptr && tn == 0;
+    constexpr int BQ = 256 / TM, BK = G2_TK / BQ;                          // bias sums: k-groups per step, k-values per thread
+    float bsum = 0.f;
+
+    float* As = lds;
+    float* Bs = lds + 2 * ABUF;
+    G2Stage<TM> sa0, sa1;                                                  // staging ring, two tiles in flight: a load has two
+    G2Stage<TN> sb0, sb1;                                                  // K-steps (~2000 cycles) to land before its LDS write
+    G2Frag<WM> xa, ya;
+    G2Frag<WN> xb, yb;
+    // tile index -> first k of the global load (clamped to the last tile: a redundant reload is cheaper than a conditional
+    // load) and of the zero fill (NOT clamped: a tile behind the last one is written as zeros, so the spare iteration of
+    // the two-fold unrolled loop multiplies by zero)
+    auto kload = [&](int tile) { return kbeg + min(tile, nk - 1) * G2_TK; };
+    auto kfill = [&](int tile) { return kbeg + tile * G2_TK; };
+
+    g2_stage_load<A_KM, TM, VEC>(g.A, g.lda, m0, g.M, kbeg, kend, g.K, sa0);
+    g2_stage_load<B_KM, TN, VEC>(g.B, g.ldb, n0, g.N, kbeg, kend, g.K, sb0);
+    g2_stage_store<A_KM, TM, VEC>(As, sa0, kbeg, kend);
+    g2_stage_store<B_KM, TN, VEC>(Bs, sb0, kbeg, kend);
+    g2_stage_load<A_KM, TM, VEC>(g.A, g.lda, m0, g.M, kload(1), kend, g.K, sa0);
+    g2_stage_load<B_KM, TN, VEC>(g.B, g.ldb, n0, g.N, kload(1), kend, g.K, sb0);
+    g2_stage_load<A_KM, TM, VEC>(g.A, g.lda, m0, g.M, kload(2), kend, g.K, sa1);
+    g2_stage_load<B_KM, TN, VEC>(g.B, g.ldb, n0, g.N, kload(2), kend, g.K, sb1);
+    __syncthreads();
+    g2_read_frag<A_KM, WM, TM>(As, wmo, li, lh, 0, xa);
+    g2_read_frag<B_KM, WN, TN>(Bs, wno, li, lh, 0, xb);
+
+    G2_STAMP(1);
+    // one K-step: tile k sits in LDS buffer c, X holds its half 0; (sa, sb) hold tile k+1 (loaded two K-steps ago)
+    auto kstep = [&](int k, int c, G2Stage<TM>& sa, G2Stage<TN>& sb) __attribute__((always_inline)) {
+        const float* Ac = As + c * ABUF;
+        const float* Bc = Bs + c * BBUF;
+        g2_read_frag<A_KM, WM, TM>(Ac, wmo, li, lh, 1, ya);                // half 1 -> Y while half 0 (X) multiplies
+        g2_read_frag<B_KM, WN, TN>(Bc, wno, li, lh, 1, yb);
+        if (do_bias) {
+            const float* col = Ac + (tid / TM) * BK * TM + (tid % TM);
+#pragma unroll
+            for (int s = 0; s < BK; ++s) bsum += col[s * TM];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        G2_KSTAMP(4);
+        g2_mfma_half<WM, WN>(xa, xb, acc);
+        G2_KSTAMP(5);
+        // tile k+1: staging registers -> the other LDS buffer (its last readers finished before the previous barrier),
+        // then the global loads of tile k+3 into the same registers
+#if !(G2_ABLATE & 2)
+        g2_stage_store<A_KM, TM, VEC>(As + (c ^ 1) * ABUF, sa, kfill(k + 1), kend);
+        g2_stage_store<B_KM, TN, VEC>(Bs + (c ^ 1) * BBUF, sb, kfill(k + 1), kend);
+#endif
+#if !(G2_ABLATE & 1)
+        g2_stage_load<A_KM, TM, VEC>(g.A, g.lda, m0, g.M, kload(k + 3), kend, g.K, sa);
+        g2_stage_load<B_KM, TN, VEC>(g.B, g.ldb, n0, g.N, kload(k + 3), kend, g.K, sb);
+#endif
+        G2_KSTAMP(6);
+        __syncthreads();
+        G2_KSTAMP(7);
+        g2_read_frag<A_KM, WM, TM>(As + (c ^ 1) * ABUF, wmo, li, lh, 0, xa);    // half 0 of tile k+1 -> X while Y multiplies
+        g2_read_frag<B_KM, WN, TN>(Bs + (c ^ 1) * BBUF, wno, li, lh, 0, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        g2_mfma_half<WM, WN>(ya, yb, acc);
+        G2_KSTAMP(8);
+    };
+#pragma unroll 1
+    for (int k = 0; k < nk; k += 2) {
+        kstep(k, 0, sa0, sb0);
+        kstep(k + 1, 1, sa1, sb1);
+    }
+
+    G2_STAMP(2);
+    if (do_bias) {                                                         // fixed-order sum of the BQ k-group partials
+        __syncthreads();
+        lds[tid] = bsum;
+        __syncthreads();
+        if (tid < TM && m0 + tid < g.M) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < BQ; ++q) s += lds[q * TM + tid];
+            g.dbias[(long)z * g.bslab + m0 + tid] = s;
+        }
+    }
+
+    g2_epilogue<A_KM, B_KM, WM, WN, 256>(g, acc, lds, m0, n0, z, wmo, wno, li, lh, true);
+    G2_STAMP(3);
+}
+
+// =====================================================================================================================
+// LDS-DMA variant (16-byte-loadable operands, K a multiple of 32).  Profiling the register-staged kernel above at
+// 2048 x 512 x 512 (tools/g2_profile.py: s_memtime stamps inside one K-step) showed where its time goes: MFMA 2 x 540
+// cycles, barrier 100, and ~420 cycles in which the wave sits in its four ds_write_b128 (the LDS store path is shared by
+// the SIMD pairs and every wave of the CU stores at the same moment) -- without the LDS writes the K loop drops from
+// 10.9 to 7.5 us.  `global_load_lds_dwordx4` (one wave instruction = 1 KiB, LDS image lane-linear) has no store pass
+// and no staging registers:
+//   * k-contiguous operand: LDS rows of 32 floats (128 B, 8 chunks of 16 B), chunk c of row r holds global chunk
+//     c ^ ((r >> 1) & 7) -- the swizzle is applied to the per-lane SOURCE address; a ds_read_b128 lane group (16 rows,
+//     one logical chunk) then covers all 16 four-bank slots;
+//   * k-major operand: LDS [k][T], lane-linear as it is, read with ds_read_b32 / b64 of consecutive lanes;
+//   * NBUF LDS buffers, tile k+NBUF-1 is issued at the top of K-step k, `s_waitcnt vmcnt((NBUF-2) * IPT)` + a raw
+//     s_barrier before tile k+1 is first read (counted wait: the youngest tile stays in flight across the barrier --
+//     `__syncthreads()` would drain it).
+template <bool KM, int W, int T>
+__device__ __forceinline__ void g2_read_frag_dma(const float* __restrict__ S, int woff, int li, int lh, int h, G2Frag<W>& f) {
+    if (KM) {
+        g2_read_frag<true, W, T>(S, woff, li, lh, h, f);                   // [k][T] image: same as the register-staged layout
+    } else {
+#pragma unroll
+        for (int b = 0; b < W; ++b) {
+            const int row = woff + b * 32 + li, sw = (row >> 1) & 7, q = h * 4 + lh * 2;
+            const float4 v0 = *(const float4*)(S + row * 32 + ((q ^ sw) << 2));
+            const float4 v1 = *(const float4*)(S + row * 32 + (((q + 1) ^ sw) << 2));
+            f.v[b][0] = v0.x; f.v[b][1] = v0.y; f.v[b][2] = v0.z; f.v[b][3] = v0.w;
+            f.v[b][4] = v1.x; f.v[b][5] = v1.y; f.v[b][6] = v1.z; f.v[b][7] = v1.w;
+        }
+    }
+}
+typedef __attribute__((address_space(3))) void* g2_lds_ptr;
+// one operand tile (T rows x 32 k) global -> LDS: T / 32 wave instructions per wave
+template <bool KM, int T>
+__device__ __forceinline__ void g2_dma_tile(const float* __restrict__ P, long ld, int r0, int nrows, int k0, float* __restrict__ S,
+                                            int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < T / 32; ++j) {
+        const int piece = j * 4 + wave;                                    // 1 KiB piece of the tile image
+        const float* src;
+        if (KM) {
+            const int k = piece * (256 / T) + lane / (T / 4), c = lane % (T / 4);
+            src = P + (long)(k0 + k) * ld + min(r0 + c * 4, nrows - 4);
+        } else {
+            const int row = piece * 8 + (lane >> 3), c = lane & 7;
+            src = P + (long)min(r0 + row, nrows - 1) * ld + k0 + ((c ^ ((row >> 1) & 7)) << 2);
+        }
+        __builtin_amdgcn_global_load_lds(src, (g2_lds_ptr)(S + piece * 256), 16, 0, 0);
+    }
+}
+
+template <bool A_KM, bool B_KM, int WM, int WN>
+__global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
+    // 8 waves: waves 0-3 multiply (2 x 2 over the tile, one per SIMD), waves 4-7 only feed the LDS ring.  Issuing one
+    // 1 KiB LDS-DMA costs the issuing wave ~90 cycles (measured: 4 of them in front of a half-step's MFMAs stretched it from
+    // 512 to 885 cycles) and an in-order wave cannot issue MFMAs meanwhile -- a second wave on the SIMD can.
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    constexpr int NBUF = 3;
+    constexpr int ABUF = TM * 32, BBUF = TN * 32;
+    constexpr int IPT = (TM + TN) / 32;                                    // DMA instructions per tile per loader wave
+    constexpr int EPI = TM * (TN + 4);                                     // the epilogue's staging image
+    constexpr int LDSF = NBUF * (ABUF + BBUF) > EPI ? NBUF * (ABUF + BBUF) : EPI;
+    __shared__ __attribute__((aligned(1024))) float lds[LDSF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+    const bool loader = tid >= 256;
+    const int li = lane & 31, lh = lane >> 5;
+#ifdef G2_PROFILE
+    if (gg.prof && tid == 0) gg.prof[(size_t)blockIdx.x * 4] = __builtin_readcyclecounter();
+#endif
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM2_MAXP; ++i)
+        if (i < gg.n && (int)blockIdx.x >= gg.p[i].block0) pi = i;
+    const Gemm2Prob& g = gg.p[pi];
+    const int tiles = g.tiles_m * g.tiles_n, nblk = tiles * g.splits;
+    int local = (int)blockIdx.x - g.block0;
+    if (local >= nblk) return;
+    if ((nblk & 7) == 0) local = (local & 7) * (nblk >> 3) + (local >> 3);
+    const int z = local / tiles, t = local - z * tiles;
+    const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int kbeg = z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (kend - kbeg) / G2_TK;                                  // K and kchunk are multiples of 32 on this path
+    const int wmo = (wave >> 1) * 32 * WM, wno = (wave & 1) * 32 * WN;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int bm = 0; bm < WM; ++bm)
+#pragma unroll
+        for (int bn = 0; bn < WN; ++bn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bm][bn][r] = 0.f;
+    const bool do_bias = A_KM && g.epi == G2_EPI_PLAIN && g.dbias != nullptr && tn == 0;
+    constexpr int BQ = 256 / TM, BK = G2_TK / BQ;
+    float bsum = 0.f;
+    float* As = lds;
+    float* Bs = lds + NBUF * ABUF;
+
+    if (loader) {
+        // tile index clamped: the redundant reloads of the last tile keep the outstanding-load count uniform (they land in
+        // buffers nobody reads any more)
+        auto issue = [&](int tile) __attribute__((always_inline)) {
+            const int tt = min(tile, nk - 1), buf = tile % NBUF;
+            g2_dma_tile<A_KM, TM>(g.A, g.lda, m0, g.M, kbeg + tt * G2_TK, As + buf * ABUF, wave, lane);
+            g2_dma_tile<B_KM, TN>(g.B, g.ldb, n0, g.N, kbeg + tt * G2_TK, Bs + buf * BBUF, wave, lane);
+        };
+        issue(0);
+        issue(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");         // tile 0 has landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();                                      // ... and every other loader's
+#pragma unroll 1
+        for (int k = 0; k < nk; ++k) {
+            issue(k + 2);                                                  // into the buffer whose readers passed the last barrier
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");     // tile k+1 landed, tile k+2 stays in flight
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the tail loads must not land in the epilogue's image
+    } else {
+        G2Frag<WM> xa, ya;
+        G2Frag<WN> xb, yb;
+        __builtin_amdgcn_s_barrier();
+        g2_read_frag_dma<A_KM, WM, TM>(As, wmo, li, lh, 0, xa);
+        g2_read_frag_dma<B_KM, WN, TN>(Bs, wno, li, lh, 0, xb);
+        G2_STAMP(1);
+#pragma unroll 1
+        for (int k = 0; k < nk; ++k) {
+            const int c = k % NBUF, c1 = (k + 1) % NBUF;
+            const float* Ac = As + c * ABUF;
+            const float* Bc = Bs + c * BBUF;
+            G2_KSTAMP(4);
+            g2_mfma_part<WM, WN, 0, 4>(xa, xb, acc);                       // X was read a half-step ago: nothing to wait for
+            __builtin_amdgcn_sched_barrier(0);
+            g2_read_frag_dma<A_KM, WM, TM>(Ac, wmo, li, lh, 1, ya);        // Y lands under the second half of the X MFMAs
+            g2_read_frag_dma<B_KM, WN, TN>(Bc, wno, li, lh, 1, yb);
+            if (do_bias) {
+                const float* col = Ac + (tid / TM) * BK * TM + (tid % TM);
+#pragma unroll
+                for (int s = 0; s < BK; ++s) bsum += col[s * TM];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            g2_mfma_part<WM, WN, 4, 8>(xa, xb, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            G2_KSTAMP(5);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // my reads of tile k are retired (its buffer is refilled next)
+            G2_KSTAMP(6);
+            __builtin_amdgcn_s_barrier();
+            G2_KSTAMP(7);
+            __builtin_amdgcn_sched_barrier(0);
+            g2_mfma_part<WM, WN, 0, 4>(ya, yb, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            g2_read_frag_dma<A_KM, WM, TM>(As + c1 * ABUF, wmo, li, lh, 0, xa);
+            g2_read_frag_dma<B_KM, WN, TN>(Bs + c1 * BBUF, wno, li, lh, 0, xb);
+            __builtin_amdgcn_sched_barrier(0);
+            g2_mfma_part<WM, WN, 4, 8>(ya, yb, acc);
+            G2_KSTAMP(8);
+        }
+        G2_STAMP(2);
+    }
+    if (do_bias) {
+        __syncthreads();
+        if (!loader) lds[tid] = bsum;
+        __syncthreads();
+        if (tid < TM && m0 + tid < g.M) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < BQ; ++q) s += lds[q * TM + tid];
+            g.dbias[(long)z * g.bslab + m0 + tid] = s;
+        }
+    }
+    g2_epilogue<A_KM, B_KM, WM, WN, 512>(g, acc, lds, m0, n0, z, wmo, wno, li, lh, !loader);
+    G2_STAMP(3);
+}
+
+template <bool A_KM, bool B_KM>
+static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
+    const int TM = big ? 128 : 64, TN = big ? 128 : 64;
+    int blocks = 0;
+    for (int i = 0; i < g.n; ++i) {
+        Gemm2Prob& p = g.p[i];
+        p.vecC = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.slab % 4 == 0) && (((uintptr_t)p.C & 15) == 0) &&
+                 (p.epi != G2_EPI_BIAS_ACT || !p.bias || ((uintptr_t)p.bias & 15) == 0) &&
+                 (p.epi != G2_EPI_MUL_DACT || p.act != PM_ACT_TANH || (p.ldh % 4 == 0 && ((uintptr_t)p.H & 15) == 0));
+        p.tiles_m = (p.M + TM - 1) / TM;
+        p.tiles_n = (p.N + TN - 1) / TN;
+        p.block0 = blocks;
+        blocks += p.tiles_m * p.tiles_n * p.splits;
+        blocks = (blocks + 7) & ~7;                                        // problems start on an XCD-0 block
+    }
+    bool vec = true;                                                       // 16-byte loads only if every operand of every problem allows them
+    for (int i = 0; i < g.n; ++i) vec = vec && g.p[i].vecA && g.p[i].vecB;
+    bool dma = vec;
+    for (int i = 0; i < g.n; ++i) dma = dma && (g.p[i].K % G2_TK == 0) && (g.p[i].kchunk % G2_TK == 0);
+    const dim3 grid(blocks), blk(256);
+    if (dma && big) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 2>), grid, dim3(512), 0, pm_stream(stream), g);
+    else if (dma) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 1>), grid, dim3(512), 0, pm_stream(stream), g);
+    else if (big && vec) hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 2, 2, true>), grid, blk, 0, pm_stream(stream), g);
+    else if (big) hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 2, 2, false>), grid, blk, 0, pm_stream(stream), g);
+    else if (vec) hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 1, 1, true>), grid, blk, 0, pm_stream(stream), g);
+    else hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 1, 1, false>), grid, blk, 0, pm_stream(stream), g);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+#ifdef G2_PROFILE
+static unsigned long long* g2_prof_buf = nullptr;                          // A/B builds only (tools/g2_profile.py)
+extern "C" void pm_debug_set_gemm_prof(void* p) { g2_prof_buf = (unsigned long long*)p; }
+#endif
+
+int gemm2_launch(Gemm2Group& g, bool a_kmajor, bool b_kmajor, void* stream) {
+    if (g.n < 1 || g.n > GEMM2_MAXP) return PM_EINVAL;
+#ifdef G2_PROFILE
+    g.prof = g2_prof_buf;
+#else
+    g.prof = nullptr;
+#endif
+    long big_tiles = 0;
+    for (int i = 0; i < g.n; ++i) {
+        Gemm2Prob& p = g.p[i];
+        if (p.splits < 1) p.splits = 1;
+        if (p.splits == 1) p.kchunk = ((p.K + G2_TK - 1) / G2_TK) * G2_TK;
+        if (p.kchunk <= 0 || p.kchunk % G2_TK != 0 || (long)(p.splits - 1) * p.kchunk >= p.K) return PM_EINVAL;
+        // 16-byte loads: k-contiguous needs K % 4 == 0 (and >= 4), k-major needs rows % 4 == 0 (and >= 4); the callers
+        // have already checked pointer / leading-dimension alignment
+        big_tiles += (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.splits;
+    }
+    const bool big = big_tiles >= 512;                                     // >= 2 work-groups of 128 x 128 per CU
+    if (!a_kmajor && !b_kmajor) return g2_launch_o<false, false>(g, big, stream);
+    if (!a_kmajor && b_kmajor) return g2_launch_o<false, true>(g, big, stream);
+    if (a_kmajor && b_kmajor) return g2_launch_o<true, true>(g, big, stream);
+    return PM_EUNSUPPORTED;
+}

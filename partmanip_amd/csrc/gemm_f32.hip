@@ -15,6 +15,7 @@
 // Lane l of a wave feeds MFMA row/col (l&31); lanes 0-31 own k in [0,32) of the K-step and
 // lanes 32-63 own k in [32,64), so a k-contiguous lane reads its 32 k-values as 8 x 16 B.
 #include "common.h"
+#include "gemm2.h"
 
 #define GB_M 64
 #define GB_N 64
@@ -228,15 +229,14 @@ extern "C" int pm_linear_fwd_f32(const float* X, long ldx, const float* W, long 
                                  long ldy, int M, int N, int K, int act, void* stream) {
     PM_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N);
     PM_REQUIRE(act == PM_ACT_NONE || act == PM_ACT_TANH);
-    GemmArgs g{};
+    Gemm2Group gg{};
+    gg.n = 1;
+    Gemm2Prob& g = gg.p[0];
     g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.bias = b;
-    g.M = M; g.N = N; g.K = K; g.act = act; g.kchunk = K; g.slab = 0;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.epi = G2_EPI_BIAS_ACT; g.splits = 1;
     g.vecA = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
     g.vecB = (K % 4 == 0) && (ldw % 4 == 0) && aligned16(W);
-    dim3 grid((N + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_BIAS_ACT>), grid, dim3(GB_T), 0, pm_stream(stream), g);
-    PM_CHECK_LAUNCH();
-    return PM_OK;
+    return gemm2_launch(gg, false, false, stream);
 }
 
 extern "C" int pm_linear_bwd_data_f32(const float* dY, long lddy, const float* W, long ldw, const float* H,
@@ -244,16 +244,15 @@ extern "C" int pm_linear_bwd_data_f32(const float* dY, long lddy, const float* W
                                       void* stream) {
     PM_REQUIRE(dY && W && dX && M > 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K);
     PM_REQUIRE(act == PM_ACT_NONE || (act == PM_ACT_TANH && H && ldh >= K));
-    GemmArgs g{};
+    Gemm2Group gg{};
+    gg.n = 1;
+    Gemm2Prob& g = gg.p[0];
     // C[M x K] = dY[M x N] * W[N x K]: reduction over N; A = dY (k-contiguous), B = W (k-major)
     g.A = dY; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = lddx; g.H = H; g.ldh = ldh;
-    g.M = M; g.N = K; g.K = N; g.act = act; g.kchunk = N; g.slab = 0;
+    g.M = M; g.N = K; g.K = N; g.act = act; g.epi = G2_EPI_MUL_DACT; g.splits = 1;
     g.vecA = (N % 4 == 0) && (lddy % 4 == 0) && aligned16(dY);
     g.vecB = (K % 4 == 0) && (ldw % 4 == 0) && aligned16(W);
-    dim3 grid((K + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M, 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<false, true, EPI_MUL_DACT>), grid, dim3(GB_T), 0, pm_stream(stream), g);
-    PM_CHECK_LAUNCH();
-    return PM_OK;
+    return gemm2_launch(gg, false, true, stream);
 }
 
 // ---- weight gradient: split-K over the batch, slab reduction, bias column sums -----------
@@ -269,6 +268,13 @@ static inline int bww_splits(int M, int N, int K) {
     // work-groups at 0.66 TB/s (6.8 ms)
     if (s > (M >= 262144 ? 256 : 32)) s = (M >= 262144 ? 256 : 32);
     if (s < 1) s = 1;
+    // every slab must own at least one row of the reduction once the chunk is rounded up to the K-step
+    while (s > 1) {
+        long kc = (M + s - 1) / s;
+        kc = ((kc + GB_K - 1) / GB_K) * GB_K;
+        if ((s - 1) * kc < M) break;
+        --s;
+    }
     return (int)s;
 }
 
@@ -302,24 +308,29 @@ extern "C" int pm_linear_bwd_weight_f32(const float* dY, long lddy, const float*
     PM_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K);
     const int S = bww_splits(M, N, K);
     if (S > 1 && (!workspace || workspace_bytes < pm_linear_bwd_weight_workspace_bytes(M, N, K))) return PM_EWORKSPACE;
-    GemmArgs g{};
+    Gemm2Group gg{};
+    gg.n = 1;
+    Gemm2Prob& g = gg.p[0];
     // C[N x K] = dY^T[N x M] * X[M x K]: reduction over M; both operands k-major
     g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx;
-    g.M = N; g.N = K; g.K = M; g.act = 0;
+    g.M = N; g.N = K; g.K = M; g.act = 0; g.epi = G2_EPI_PLAIN;
     g.vecA = (N % 4 == 0) && (lddy % 4 == 0) && aligned16(dY);
     g.vecB = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
     float* bslabs = (float*)workspace + (size_t)S * N * K;
     if (S > 1) {
         int kchunk = (M + S - 1) / S;
         kchunk = ((kchunk + GB_K - 1) / GB_K) * GB_K;
-        g.C = (float*)workspace; g.ldc = K; g.kchunk = kchunk; g.slab = (long)N * K;
-        g.dbias = db ? bslabs : nullptr;
+        g.C = (float*)workspace; g.ldc = K; g.kchunk = kchunk; g.slab = (long)N * K; g.splits = S;
+        g.dbias = db ? bslabs : nullptr; g.bslab = N;
+        if ((long)(S - 1) * kchunk >= M) return PM_EINVAL;
     } else {
-        g.C = dW; g.ldc = lddw; g.kchunk = M; g.slab = 0;
-        g.dbias = db;                                  // single slab: the column sums ARE the bias gradient
+        g.C = dW; g.ldc = lddw; g.splits = 1; g.slab = 0;
+        g.dbias = db; g.bslab = 0;                     // single slab: the column sums ARE the bias gradient
     }
-    dim3 grid((K + GB_N - 1) / GB_N, (N + GB_M - 1) / GB_M, S);
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI_PLAIN>), grid, dim3(GB_T), 0, pm_stream(stream), g);
+    {
+        const int rc = gemm2_launch(gg, true, true, stream);
+        if (rc != PM_OK) return rc;
+    }
     if (S > 1) {
         const long ne = (long)N * K + (db ? N : 0);
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, pm_stream(stream),
@@ -327,4 +338,63 @@ extern "C" int pm_linear_bwd_weight_f32(const float* dY, long lddy, const float*
     }
     PM_CHECK_LAUNCH();
     return PM_OK;
+}
+
+// ---- grouped forms: several problems of one kind in ONE launch (include/partmanip_hip.h) -----------------------------
+extern "C" int pm_linear_fwd_group_f32(int n, const pm_linear_fwd_desc* d, void* stream) {
+    PM_REQUIRE(d && n >= 1 && n <= PM_LINEAR_GROUP_MAX);
+    Gemm2Group gg{};
+    gg.n = n;
+    for (int i = 0; i < n; ++i) {
+        const pm_linear_fwd_desc& q = d[i];
+        PM_REQUIRE(q.X && q.W && q.Y && q.M > 0 && q.N > 0 && q.K > 0 && q.ldx >= q.K && q.ldw >= q.K && q.ldy >= q.N);
+        PM_REQUIRE(q.act == PM_ACT_NONE || q.act == PM_ACT_TANH);
+        Gemm2Prob& g = gg.p[i];
+        g.A = q.X; g.lda = q.ldx; g.B = q.W; g.ldb = q.ldw; g.C = q.Y; g.ldc = q.ldy; g.bias = q.b;
+        g.M = q.M; g.N = q.N; g.K = q.K; g.act = q.act; g.epi = G2_EPI_BIAS_ACT; g.splits = 1;
+        g.vecA = (q.K % 4 == 0) && (q.ldx % 4 == 0) && aligned16(q.X);
+        g.vecB = (q.K % 4 == 0) && (q.ldw % 4 == 0) && aligned16(q.W);
+    }
+    return gemm2_launch(gg, false, false, stream);
+}
+
+extern "C" int pm_linear_bwd_data_group_f32(int n, const pm_linear_bwd_data_desc* d, void* stream) {
+    PM_REQUIRE(d && n >= 1 && n <= PM_LINEAR_GROUP_MAX);
+    Gemm2Group gg{};
+    gg.n = n;
+    for (int i = 0; i < n; ++i) {
+        const pm_linear_bwd_data_desc& q = d[i];
+        PM_REQUIRE(q.dY && q.W && q.dX && q.M > 0 && q.N > 0 && q.K > 0 && q.lddy >= q.N && q.ldw >= q.K && q.lddx >= q.K);
+        PM_REQUIRE(q.act == PM_ACT_NONE || (q.act == PM_ACT_TANH && q.H && q.ldh >= q.K));
+        Gemm2Prob& g = gg.p[i];
+        g.A = q.dY; g.lda = q.lddy; g.B = q.W; g.ldb = q.ldw; g.C = q.dX; g.ldc = q.lddx; g.H = q.H; g.ldh = q.ldh;
+        g.M = q.M; g.N = q.K; g.K = q.N; g.act = q.act; g.epi = G2_EPI_MUL_DACT; g.splits = 1;
+        g.vecA = (q.N % 4 == 0) && (q.lddy % 4 == 0) && aligned16(q.dY);
+        g.vecB = (q.K % 4 == 0) && (q.ldw % 4 == 0) && aligned16(q.W);
+    }
+    return gemm2_launch(gg, false, true, stream);
+}
+
+extern "C" int pm_linear_bwd_weight_group_f32(int n, const pm_linear_bwd_weight_desc* d, int splits, void* stream) {
+    PM_REQUIRE(d && n >= 1 && n <= PM_LINEAR_GROUP_MAX && splits >= 1);
+    Gemm2Group gg{};
+    gg.n = n;
+    for (int i = 0; i < n; ++i) {
+        const pm_linear_bwd_weight_desc& q = d[i];
+        PM_REQUIRE(q.dY && q.X && q.dW && q.M > 0 && q.N > 0 && q.K > 0 && q.lddy >= q.N && q.ldx >= q.K && q.lddw >= q.K);
+        Gemm2Prob& g = gg.p[i];
+        g.A = q.dY; g.lda = q.lddy; g.B = q.X; g.ldb = q.ldx; g.C = q.dW; g.ldc = q.lddw;
+        g.M = q.N; g.N = q.K; g.K = q.M; g.act = 0; g.epi = G2_EPI_PLAIN;
+        g.vecA = (q.N % 4 == 0) && (q.lddy % 4 == 0) && aligned16(q.dY);
+        g.vecB = (q.K % 4 == 0) && (q.ldx % 4 == 0) && aligned16(q.X);
+        g.dbias = q.db;
+        g.splits = splits;
+        if (splits > 1) {
+            int kchunk = (q.M + splits - 1) / splits;
+            kchunk = ((kchunk + 31) / 32) * 32;
+            PM_REQUIRE((long)(splits - 1) * kchunk < q.M && q.slab_stride > 0);
+            g.kchunk = kchunk; g.slab = q.slab_stride; g.bslab = q.slab_stride;
+        }
+    }
+    return gemm2_launch(gg, true, true, stream);
 }

@@ -171,6 +171,61 @@ def linear_bwd_weight(dy, x, dw, db, ws):
                                        _ptr(db), M, N, K, _ptr(w), w.numel(), _stream()), "pm_linear_bwd_weight_f32")
 
 
+# ---- grouped forms: several independent problems of one kind in ONE launch (the actor's and the critic's layer l; all
+# weight gradients of a backward pass).  Each item is the argument tuple of the single-problem op.
+def linear_fwd_group(items):
+    """items: [(x, w, b, y, act), ...]"""
+    from ._lib import LinearFwdDesc
+    arr = (LinearFwdDesc * len(items))()
+    for d, (x, w, b, y, act) in zip(arr, items):
+        _req(x, w, b, y)
+        d.X, d.ldx, d.W, d.ldw, d.b, d.Y, d.ldy = _ptr(x), _rows(x, "x"), _ptr(w), _rows(w, "w"), _ptr(b), _ptr(y), _rows(y, "y")
+        d.M, d.K, d.N, d.act = x.shape[0], x.shape[1], w.shape[0], act
+    check(lib.pm_linear_fwd_group_f32(len(items), arr, _stream()), "pm_linear_fwd_group_f32")
+
+
+def linear_bwd_data_group(items):
+    """items: [(dy, w, h, dx, act), ...]"""
+    from ._lib import LinearBwdDataDesc
+    arr = (LinearBwdDataDesc * len(items))()
+    for d, (dy, w, h, dx, act) in zip(arr, items):
+        _req(dy, w, h, dx)
+        d.dY, d.lddy, d.W, d.ldw, d.dX, d.lddx = _ptr(dy), _rows(dy, "dy"), _ptr(w), _rows(w, "w"), _ptr(dx), _rows(dx, "dx")
+        d.H, d.ldh = _ptr(h), (_rows(h, "h") if h is not None else 0)
+        d.M, d.N, d.K, d.act = dy.shape[0], dy.shape[1], w.shape[1], act
+    check(lib.pm_linear_bwd_data_group_f32(len(items), arr, _stream()), "pm_linear_bwd_data_group_f32")
+
+
+def linear_bwd_weight_group(items, splits=1):
+    """items: [(dy, x, dw, db, slab_stride), ...]; splits > 1: slab z of dw / db lands at + z * slab_stride elements and the
+    caller sums the slabs (clip_adam_group does)."""
+    from ._lib import LinearBwdWeightDesc
+    arr = (LinearBwdWeightDesc * len(items))()
+    for d, (dy, x, dw, db, stride) in zip(arr, items):
+        _req(dy, x, dw, db)
+        d.dY, d.lddy, d.X, d.ldx, d.dW, d.lddw, d.db = _ptr(dy), _rows(dy, "dy"), _ptr(x), _rows(x, "x"), _ptr(dw), _rows(dw, "dw"), _ptr(db)
+        d.slab_stride, d.M, d.N, d.K = int(stride), dy.shape[0], dy.shape[1], x.shape[1]
+    check(lib.pm_linear_bwd_weight_group_f32(len(items), arr, int(splits), _stream()), "pm_linear_bwd_weight_group_f32")
+
+
+def clip_adam_group(items):
+    """items: [dict(p, g, m, v, n_clip, max_norm, lr, b1, b2, eps, state, skip_flag, gnorm, ws, extra, extra_stride, n_sum,
+    n_extra)]: pm_clip_adam_step_f32 for several optimisers in two launches; `extra` = split-K slabs 1.. of g[:n_sum]."""
+    from ._lib import ClipAdamDesc
+    arr = (ClipAdamDesc * len(items))()
+    for d, it in zip(arr, items):
+        p, g = it["p"], it["g"]
+        _req(p, g, it["m"], it["v"], it["state"], it.get("skip_flag"), it.get("gnorm"), it.get("extra"))
+        n = p.numel()
+        w = it["ws"].get(lib.pm_clip_adam_workspace_bytes(n) + 8)
+        base = w.data_ptr()
+        d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.n, d.n_clip = _ptr(p), _ptr(g), _ptr(it["m"]), _ptr(it["v"]), n, int(it["n_clip"])
+        d.extra, d.extra_stride, d.n_sum, d.n_extra = _ptr(it.get("extra")), int(it.get("extra_stride", 0)), int(it.get("n_sum", 0)), int(it.get("n_extra", 0))
+        d.max_norm, d.lr, d.b1, d.b2, d.eps = float(it["max_norm"]), float(it["lr"]), float(it["b1"]), float(it["b2"]), float(it["eps"])
+        d.state, d.skip_flag, d.gnorm_out, d.workspace = _ptr(it["state"]), _ptr(it.get("skip_flag")), _ptr(it.get("gnorm")), base + (-base) % 8
+    check(lib.pm_clip_adam_group_f32(len(items), arr, _stream()), "pm_clip_adam_group_f32")
+
+
 # ----------------------------------------------------------------------------- K6/K7
 def pointnet_packed_elems():
     return int(lib.pm_pointnet_packed_elems())

@@ -462,3 +462,72 @@ def test_sa_kernels_are_invariant_to_neighbour_order_at_bench_size(dims, P, S, c
         dyd = (y0 - y1).abs()                                  # a tie flip moves one row's gradient to another source point
         assert float((dyd > 1e-4 * float(y0.abs().max())).float().mean()) < 1e-4
         assert float((y0 - y2).abs().max()) < 1e-5 * float(y0.abs().max())      # global fp32 atomics: order varies
+
+
+def test_grouped_linear_ops_equal_the_single_problem_ops():
+    """pm_linear_*_group_f32: several problems per launch, each bit-identical to its own single-problem launch; the
+    split-K slabs of the grouped weight gradient add up (in slab order) to the single call's result to fp32 round-off."""
+    from partmanip_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    ws = ops.Workspace(DEV)
+    probs = [(2048, 512, 512), (2048, 512, 256), (1024, 53, 512), (2048, 512, 10)]
+    xs = [r(M, K) for M, K, N in probs]
+    wts = [r(N, K) / K ** 0.5 for M, K, N in probs]
+    bs = [r(N) for M, K, N in probs]
+    y1 = [torch.empty(M, N, device=DEV) for M, K, N in probs]
+    y2 = [torch.empty(M, N, device=DEV) for M, K, N in probs]
+    for x, w, b, y in zip(xs, wts, bs, y1):
+        ops.linear_fwd(x, w, b, y, ops.ACT_TANH)
+    ops.linear_fwd_group([(x, w, b, y, ops.ACT_TANH) for x, w, b, y in zip(xs, wts, bs, y2)][:2])
+    ops.linear_fwd_group([(x, w, b, y, ops.ACT_TANH) for x, w, b, y in zip(xs, wts, bs, y2)][2:])
+    for a, b_ in zip(y1, y2):
+        assert torch.equal(a, b_)
+    dys = [r(M, N) for M, K, N in probs]
+    dx1 = [torch.empty(M, K, device=DEV) for M, K, N in probs]
+    dx2 = [torch.empty(M, K, device=DEV) for M, K, N in probs]
+    for dy, w, x, dx in zip(dys, wts, xs, dx1):
+        ops.linear_bwd_data(dy, w, x, dx, ops.ACT_TANH)
+    ops.linear_bwd_data_group([(dy, w, x, dx, ops.ACT_TANH) for dy, w, x, dx in zip(dys, wts, xs, dx2)])
+    for a, b_ in zip(dx1, dx2):
+        assert torch.equal(a, b_)
+    # weight gradients: 4 slabs per problem, summed in slab order
+    S = 4
+    for (M, K, N), dy, x in zip(probs, dys, xs):
+        dw1, db1 = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+        ops.linear_bwd_weight(dy, x, dw1, db1, ws)
+        stride = (N * K + N + 3) // 4 * 4
+        slabs = torch.zeros(S * stride, device=DEV)
+        ops.linear_bwd_weight_group([(dy, x, slabs[:N * K].view(N, K), slabs[N * K:N * K + N], stride)], S)
+        tot = slabs.view(S, stride).sum(0)
+        ref = (dy.double().t() @ x.double())
+        assert float((tot[:N * K].view(N, K).double() - ref).abs().max() / ref.abs().max()) < 2e-6
+        assert float((dw1.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+        np.testing.assert_allclose(tot[N * K:N * K + N].cpu().numpy(), dy.double().sum(0).float().cpu().numpy(), rtol=2e-5, atol=2e-4)
+        np.testing.assert_allclose(db1.cpu().numpy(), dy.double().sum(0).float().cpu().numpy(), rtol=2e-5, atol=2e-4)
+
+
+def test_grouped_clip_adam_equals_two_single_steps():
+    from partmanip_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(6)
+    items1, items2, ref = [], [], []
+    for n, n_clip, S in ((10007, 9000, 3), (5000, 5000, 0)):
+        p = torch.randn(n, device=DEV, generator=g)
+        gr = torch.randn(n, device=DEV, generator=g)
+        extra = torch.randn(max(S, 1) * n, device=DEV, generator=g)
+        gsum = gr.clone()
+        for z in range(S):
+            gsum[:n_clip] += extra[z * n:z * n + n_clip]
+        a = dict(p=p.clone(), g=gsum.clone(), m=torch.zeros(n, device=DEV), v=torch.zeros(n, device=DEV),
+                 state=torch.zeros(4, dtype=torch.int32, device=DEV), gnorm=torch.zeros(1, device=DEV), ws=ops.Workspace(DEV))
+        ops.clip_adam_step(a["p"], a["g"], a["m"], a["v"], n_clip, 0.5, 1e-3, 0.9, 0.999, 1e-8, a["state"], None, a["gnorm"], a["ws"])
+        ref.append(a)
+        b = dict(p=p.clone(), g=gr.clone(), m=torch.zeros(n, device=DEV), v=torch.zeros(n, device=DEV),
+                 state=torch.zeros(4, dtype=torch.int32, device=DEV), gnorm=torch.zeros(1, device=DEV), ws=ops.Workspace(DEV),
+                 n_clip=n_clip, max_norm=0.5, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, skip_flag=None, extra=extra, extra_stride=n,
+                 n_sum=n_clip, n_extra=S)
+        items2.append(b)
+    ops.clip_adam_group(items2)
+    for a, b in zip(ref, items2):
+        assert torch.equal(a["g"], b["g"]) and torch.equal(a["p"], b["p"]) and torch.equal(a["m"], b["m"])
+        assert torch.equal(a["v"], b["v"]) and int(b["state"][0]) == 1 and torch.equal(a["gnorm"], b["gnorm"])
