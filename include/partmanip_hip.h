@@ -39,9 +39,19 @@ extern "C" {
 
 #define PM_ACT_NONE 0
 #define PM_ACT_TANH 1
+/* network.py:7-24 `get_activation`: the other activations a cfg may name (Linear epilogues only: the fused point-cloud /
+ * voxel encoders are tanh kernels).  Each derivative is a function of the activation OUTPUT h, which is what the
+ * backward kernels are handed: relu 1[h>0]; lrelu (slope 0.01) h>0 ? 1 : 0.01; elu (alpha 1) h>0 ? 1 : h+1;
+ * selu h>0 ? lambda : h + lambda*alpha; sigmoid h(1-h). */
+#define PM_ACT_RELU 2
+#define PM_ACT_LRELU 3
+#define PM_ACT_ELU 4
+#define PM_ACT_SELU 5
+#define PM_ACT_SIGMOID 6
+#define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 121 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 122 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -75,7 +85,8 @@ int pm_gather_rows_f32(const float* src, const int64_t* idx, float* dst, long n_
  * autograd backward ppo.py:348,378 / dagger.py:318 triggers for them.
  *   fwd : Y[M,N]  = act(X[M,K] * W[N,K]^T + b[N])
  *   bwd_data  : dX[M,K] = (dY[M,N] * W[N,K]) .* act'(H[M,K])   (H = the layer input, i.e. the previous
- *               layer's activation OUTPUT; act' for tanh is 1-H^2; H may be NULL with PM_ACT_NONE)
+ *               layer's activation OUTPUT; act' for tanh is 1-H^2, the others as listed at PM_ACT_*; H may be NULL with
+ *               PM_ACT_NONE)
  *   bwd_weight: dW[N,K] = dY^T * X ; db[N] = column sums of dY (db may be NULL)
  * v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate. */
 int pm_linear_fwd_f32(const float* X, long ldx, const float* W, long ldw, const float* b, float* Y, long ldy,
@@ -201,6 +212,16 @@ int pm_mse_tanh_loss_fwd_bwd_f32(const float* stu_mu, long lds, const float* tea
                                  float* dstu_mu, long ldd, void* stream);
 /* actor_critic.py:84-91 */
 int pm_action_activation_f32(const float* mu, float* out, long n, float max_action, int act_tanh, void* stream);
+/* Backward halves of pm_gaussian_logp_f32 / pm_action_activation_f32 for callers that differentiate through
+ * ActorCritic.update_act_cri / update_act with torch autograd, the way the reference's own update() does
+ * (ppo.py:326,347-348; dagger.py:312-318; partmanip_amd/autograd.py wraps them in torch.autograd.Function):
+ * dmu (B, A) = dlogp[i] * (x - mu) / s^2 and dlog_std (A) = sum_i dlogp[i] (2 z^2 - 2) + 2 dent[i], with s = exp(log_std)^2,
+ * z = (x - mu) / s, x = atanh(clamp(a / max_action)) -- dlogp / dent (B) are the incoming gradients (either may be NULL). */
+int pm_gaussian_logp_bwd_f32(const float* mu, long ldmu, const float* log_std, const float* actions, long lda, int B, int A,
+                             float max_action, int act_tanh, const float* dlogp, const float* dent, float* dmu, long lddm,
+                             float* dlog_std, void* stream);
+int pm_action_activation_bwd_f32(const float* out, const float* dout, float* dmu, long n, float max_action, int act_tanh,
+                                 void* stream);
 
 /* ------------------------------------------------------------------ K10 clip + Adam
  * nn.utils.clip_grad_norm_ (ppo.py:351,381) fused with torch.optim.Adam.step (ppo.py:353,382,
@@ -237,7 +258,8 @@ int pm_ppo_accumulate_stats_f32(float* acc, const float* scal, int which, void* 
  * K12: utils/depth2tsdf.py:113,160 call pytorch3d.ops.sample_farthest_points(points, K)
  * (un-vendored; defaults: start index 0, no lengths).  idx_out (B,K) int32; squared-L2
  * running-min distance; next = argmax, lowest index on ties.  PARITY UNPINNED (no reference
- * implementation in tree) -- checked against oracle/pointops_ref.c.
+ * implementation in tree) -- checked against the restatement `oracle/ref_cpu.py::fps` / `ball_query` / `group_points`
+ * (tests/test_gpu_kernels.py, tests/test_gpu_fuzz.py: indices bit-exact).
  * K13/K14: PointNet++ ball query / grouping -- absent from the reference (README.md:23,30),
  * mandated by BASELINE.json.north_star; first `nsample` in-radius indices in ascending
  * order, padded with the first hit, all-zero row when the ball is empty. */

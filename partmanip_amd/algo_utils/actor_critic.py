@@ -32,6 +32,10 @@ class ActorCritic(nn.Module):
             raise NotImplementedError
         self.actions_shape = actions_shape
         self._flat = None
+        # True: update_act_cri / update_act return tensors that carry a torch autograd graph whose backward is the HIP
+        # backward (partmanip_amd/autograd.py) -- for callers that differentiate through them like the reference's own
+        # update() (ppo.py:326,347-348).  The runners of this package leave it off and call the HIP backward directly.
+        self.autograd = False
 
     # ------------------------------------------------------------------ flat buffers
     def flatten(self):
@@ -70,6 +74,8 @@ class ActorCritic(nn.Module):
         vc, _ = rehome(c_params, flat_c, grad_c)
         self.actor.set_grad_views(va)
         self.critic.set_grad_views(vc)
+        object.__setattr__(self.actor, "_grad_list", [va[n] for n, _ in a_params])     # parameter order (autograd bridge)
+        object.__setattr__(self.critic, "_grad_list", [vc[n] for n, _ in c_params])
         self._flat = dict(actor=flat_a, critic=flat_c, grad_actor=grad_a, grad_critic=grad_c, n_actor=n_a,
                           n_critic=n_c, grad_log_std=grad_a[n_a:n_a + A], scal_actor=grad_a[n_a + A:],
                           scal_critic=grad_c[n_c:], slab_stride_actor=stride_a, slab_stride_critic=stride_c,
@@ -131,13 +137,24 @@ class ActorCritic(nn.Module):
 
     def update_act(self, observations):
         self.flat()
+        if self.autograd and torch.is_grad_enabled():                    # dagger.py:312: graph back to the student actor
+            from ..autograd import backbone_apply, ActionActivationFn
+            mu = backbone_apply(self.actor, observations)
+            return ActionActivationFn.apply(mu, self.max_action) if self.action_activate == 'tanh' else mu
         return self.action_activation(self.actor(observations))
 
     def update_act_cri(self, observations, actions):
         """actor_critic.py:71-82 -> (log_prob (B,), entropy (B,), value (B,1), mu (B,A), log_std rows (B,A)).
-        Values only (no autograd graph): the training step differentiates through the explicit
-        HIP backward in `algorithms/ppo.py`, not through this method."""
+        Default: values only (the runners of this package differentiate through the explicit HIP backward in
+        `algorithms/ppo.py`).  With `self.autograd = True` the five tensors carry an autograd graph to the parameters
+        whose backward is that same HIP backward -- `loss.backward()` + `torch.optim.Adam`, as ppo.py:347-353, work."""
         self.flat()
+        if self.autograd and torch.is_grad_enabled():
+            from ..autograd import backbone_apply, GaussianLogpFn
+            mu = backbone_apply(self.actor, observations)
+            logp, ent = GaussianLogpFn.apply(mu, self.log_std, actions, self.max_action, self.action_activate == 'tanh')
+            value = backbone_apply(self.critic, observations)
+            return logp, ent, value, mu, self.log_std.repeat(mu.shape[0], 1)
         mu = self.actor(observations)
         logp, ent = self._logp_entropy(mu, actions, squashed=True)
         value = self.critic(observations)

@@ -16,6 +16,10 @@ import torch.nn as nn
 
 from .. import ops
 
+# network.py:7-24: every activation the reference's `get_activation` knows, as epilogues of the Linear kernels.  The fused
+# point-cloud / voxel encoders (PointNet, PointNet2, Conv3DNet) are tanh kernels -- every shipped cfg's activation.
+_LINEAR_ACT = {"tanh": ops.ACT_TANH, "relu": ops.ACT_RELU, "crelu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "elu": ops.ACT_ELU,
+               "selu": ops.ACT_SELU, "sigmoid": ops.ACT_SIGMOID}
 _SUPPORTED_ACT = {"tanh": ops.ACT_TANH}
 
 
@@ -29,10 +33,14 @@ def get_activation(act_name):
     return table[act_name]()
 
 
-def _act_code(name):
-    if name not in _SUPPORTED_ACT:
-        raise NotImplementedError(f"activation '{name}': the HIP path implements tanh (every shipped cfg); no fallback")
-    return _SUPPORTED_ACT[name]
+def _act_code(name, linear_only=False):
+    """PM_ACT_* code of a cfg's `activation`.  linear_only: the backbone is a chain of Linear kernels (MLP), which take
+    the whole set; the fused encoders implement tanh."""
+    table = _LINEAR_ACT if linear_only else _SUPPORTED_ACT
+    if name not in table:
+        raise NotImplementedError(f"activation '{name}': the fused encoder kernels of this backbone implement tanh (every "
+                                  f"shipped cfg); the MLP backbone takes {sorted(_LINEAR_ACT)}; there is no fallback")
+    return table[name]
 
 
 class _LinearChain:
@@ -173,7 +181,7 @@ class MLP(_HipNet):
         lins = [m for m in self.model if isinstance(m, nn.Linear)]
         for g, m in zip(gains, lins):
             torch.nn.init.orthogonal_(m.weight, gain=g)
-        object.__setattr__(self, "_chain", _LinearChain(lins, _act_code(net_cfg['activation'])))
+        object.__setattr__(self, "_chain", _LinearChain(lins, _act_code(net_cfg['activation'], linear_only=True)))
 
     def set_grad_views(self, views):
         idx = [i for i, m in enumerate(self.model) if isinstance(m, nn.Linear)]

@@ -126,3 +126,30 @@ __device__ __forceinline__ f32x2 pm_tanh2(f32x2 x) {
 #undef PM_S2
 }
 __device__ __forceinline__ f32x2 pm_tanh2(float a, float b) { return pm_tanh2((f32x2){a, b}); }
+
+// ---- the activation set of network.py:7-24 (Linear epilogues) ------------------------------------------------------------
+#define PM_SELU_L 1.0507009873554804934193349852946f
+#define PM_SELU_A 1.6732632423543772848170429916717f
+__device__ __forceinline__ float pm_act(float z, int act) {
+    switch (act) {
+        case PM_ACT_TANH: return pm_tanh(z);
+        case PM_ACT_RELU: return fmaxf(z, 0.0f);
+        case PM_ACT_LRELU: return z > 0.0f ? z : 0.01f * z;
+        case PM_ACT_ELU: return z > 0.0f ? z : expm1f(z);
+        case PM_ACT_SELU: return PM_SELU_L * (z > 0.0f ? z : PM_SELU_A * expm1f(z));
+        case PM_ACT_SIGMOID: return 1.0f / (1.0f + expf(-z));
+        default: return z;
+    }
+}
+// derivative of the activation expressed through its OUTPUT h
+__device__ __forceinline__ float pm_dact(float h, int act) {
+    switch (act) {
+        case PM_ACT_TANH: return 1.0f - h * h;
+        case PM_ACT_RELU: return h > 0.0f ? 1.0f : 0.0f;
+        case PM_ACT_LRELU: return h > 0.0f ? 1.0f : 0.01f;
+        case PM_ACT_ELU: return h > 0.0f ? 1.0f : h + 1.0f;
+        case PM_ACT_SELU: return h > 0.0f ? PM_SELU_L : h + PM_SELU_L * PM_SELU_A;
+        case PM_ACT_SIGMOID: return h * (1.0f - h);
+        default: return 1.0f;
+    }
+}

@@ -174,9 +174,14 @@ __device__ __forceinline__ void g2_epilogue(const Gemm2Prob& g, f32x16 (&acc)[WM
                         v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
                     }
                     if (act == PM_ACT_TANH) { v.x = pm_tanh(v.x); v.y = pm_tanh(v.y); v.z = pm_tanh(v.z); v.w = pm_tanh(v.w); }
-                } else if (epi == G2_EPI_MUL_DACT && act == PM_ACT_TANH) {
+                    else if (act != PM_ACT_NONE) { v.x = pm_act(v.x, act); v.y = pm_act(v.y, act); v.z = pm_act(v.z, act); v.w = pm_act(v.w, act); }
+                } else if (epi == G2_EPI_MUL_DACT && act != PM_ACT_NONE) {
                     const float4 hh = *(const float4*)(g.H + (long)grow * g.ldh + gcol);
-                    v.x *= 1.0f - hh.x * hh.x; v.y *= 1.0f - hh.y * hh.y; v.z *= 1.0f - hh.z * hh.z; v.w *= 1.0f - hh.w * hh.w;
+                    if (act == PM_ACT_TANH) {
+                        v.x *= 1.0f - hh.x * hh.x; v.y *= 1.0f - hh.y * hh.y; v.z *= 1.0f - hh.z * hh.z; v.w *= 1.0f - hh.w * hh.w;
+                    } else {
+                        v.x *= pm_dact(hh.x, act); v.y *= pm_dact(hh.y, act); v.z *= pm_dact(hh.z, act); v.w *= pm_dact(hh.w, act);
+                    }
                 }
                 *(float4*)(C + (long)grow * g.ldc + gcol) = v;
             }
@@ -190,10 +195,9 @@ __device__ __forceinline__ void g2_epilogue(const Gemm2Prob& g, f32x16 (&acc)[WM
                 float v = lds[row * LDC + col];
                 if (epi == G2_EPI_BIAS_ACT) {
                     if (g.bias) v += g.bias[gcol];
-                    if (act == PM_ACT_TANH) v = pm_tanh(v);
-                } else if (epi == G2_EPI_MUL_DACT && act == PM_ACT_TANH) {
-                    const float hh = g.H[(long)grow * g.ldh + gcol];
-                    v *= 1.0f - hh * hh;
+                    v = pm_act(v, act);
+                } else if (epi == G2_EPI_MUL_DACT && act != PM_ACT_NONE) {
+                    v *= pm_dact(g.H[(long)grow * g.ldh + gcol], act);
                 }
                 C[(long)grow * g.ldc + gcol] = v;
             }
@@ -508,7 +512,7 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
         Gemm2Prob& p = g.p[i];
         p.vecC = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.slab % 4 == 0) && (((uintptr_t)p.C & 15) == 0) &&
                  (p.epi != G2_EPI_BIAS_ACT || !p.bias || ((uintptr_t)p.bias & 15) == 0) &&
-                 (p.epi != G2_EPI_MUL_DACT || p.act != PM_ACT_TANH || (p.ldh % 4 == 0 && ((uintptr_t)p.H & 15) == 0));
+                 (p.epi != G2_EPI_MUL_DACT || p.act == PM_ACT_NONE || (p.ldh % 4 == 0 && ((uintptr_t)p.H & 15) == 0));
         p.tiles_m = (p.M + TM - 1) / TM;
         p.tiles_n = (p.N + TN - 1) / TN;
         p.block0 = blocks;

@@ -1,234 +1,24 @@
-// K4/K5: Linear forward / backward as LDS-tiled fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32:
-// exact fp32 products, fp32 accumulate -- bitwise an fmaf chain per output, so results are
-// fp32-roundoff-class against the reference's CPU sgemm).
-//
-// One work-group = 8 waves on a 64x64 tile, K-step 64: waves 0-3 (2x2 blocks of 32x32) take
-// k in [0,32) of every K-step and waves 4-7 the same blocks with k in [32,64) (intra-work-group
-// split-K, combined through LDS at the end).  The output of these layers (2048 x 512) is only 1024
-// MFMA blocks -- one per SIMD -- so without the split every SIMD holds a single wave and nothing
-// hides the LDS staging; with it two waves per SIMD alternate staging and MFMA.  Operand tiles are staged in LDS in
-// their natural global orientation:
-//   "k-contiguous" operand (row r, k fastest):   LDS [64][68]  -> fragments by ds_read_b128;
-//        row stride 68 floats: (68*r) mod 64 hits 16 distinct 4-bank slots -> conflict-free.
-//   "k-major" operand (k slowest, r fastest):    LDS [64][64]  -> fragments by ds_read_b32,
-//        lanes read consecutive floats -> conflict-free.
-// Lane l of a wave feeds MFMA row/col (l&31); lanes 0-31 own k in [0,32) of the K-step and
-// lanes 32-63 own k in [32,64), so a k-contiguous lane reads its 32 k-values as 8 x 16 B.
+// K4/K5: Linear forward / backward entry points (C ABI).  The GEMMs run on the grouped fp32-MFMA kernels of gemm2_f32.hip
+// (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate -- bitwise an fmaf chain per output, so results are
+// fp32-roundoff-class against the reference's CPU sgemm):
+//   fwd        Y  = act(X W^T + b)          A = X (k-contiguous), B = W (k-contiguous), bias + activation epilogue
+//   bwd_data   dX = (dY W) .* act'(H)       A = dY (k-contiguous), B = W (k-major), derivative-of-activation epilogue
+//   bwd_weight dW = dY^T X, db = colsum dY  A = dY, B = X (both k-major), split-K over the batch into slabs, bias
+//              gradient from the staged dY tiles; slabs are summed here in fixed order (single-problem call) or by the
+//              optimiser launch (grouped call, adam.hip).
 #include "common.h"
 #include "gemm2.h"
 
-#define GB_M 64
+#define GB_M 64                       // tile / K-step granularity the split-K heuristic below counts in
 #define GB_N 64
 #define GB_K 64
-#define LDK (GB_K + 4)   // k-contiguous LDS row stride (floats)
-#define LDR 64           // k-major LDS row stride (floats)
-#define GB_T 512                      // threads per work-group
-#define NV4 (GB_M * GB_K / 4 / GB_T)  // float4 loads per thread per operand tile
-#define NSC (GB_M * GB_K / GB_T)      // scalar loads per thread per operand tile
-#define KH (GB_K / 4)                 // k-values per lane half per wave k-group (16)
-
-enum { EPI_BIAS_ACT = 0, EPI_MUL_DACT = 1, EPI_PLAIN = 2 };
-
-struct GemmArgs {
-    const float* A; long lda;     // k-contig: A[row*lda + k] ; k-major: A[k*lda + row]
-    const float* B; long ldb;     // k-contig: B[col*ldb + k] ; k-major: B[k*ldb + col]
-    float* C; long ldc;           // C[row*ldc + col]
-    const float* bias;            // EPI_BIAS_ACT: per col (may be null)
-    const float* H; long ldh;     // EPI_MUL_DACT: C *= 1 - H[row][col]^2
-    int M, N, K;                  // GEMM dims (rows, cols, reduction)
-    int act;
-    int kchunk;                   // split-K: reduction range per blockIdx.z
-    long slab;                    // split-K: C offset per blockIdx.z (elements)
-    int vecA, vecB;               // 16 B global loads allowed
-    float* dbias;                 // EPI_PLAIN (weight gradient): column sums of the k-major A operand
-                                  // (= bias gradient), written by the blockIdx.x == 0 tiles per z-slab
-};
-
-// ---- global -> register tile loads ------------------------------------------------------
-// k-contiguous tile: 64 rows x 32 k.  vec: 2 float4 per thread; scalar: 8 floats per thread.
-__device__ __forceinline__ void load_kcontig(const float* __restrict__ P, long ld, int row0, int nrows, int k0,
-                                             int kend, int vec, float (&r)[NSC]) {
-    const int tid = threadIdx.x;
-    if (vec) {
-#pragma unroll
-        for (int j = 0; j < NV4; ++j) {
-            const int idx = tid + GB_T * j, row = idx / (GB_K / 4), k = k0 + ((idx % (GB_K / 4)) << 2);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + row < nrows && k < kend) v = *(const float4*)(P + (long)(row0 + row) * ld + k);
-            r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NSC; ++j) {
-            const int idx = tid + GB_T * j, row = idx / GB_K, k = k0 + (idx % GB_K);
-            r[j] = (row0 + row < nrows && k < kend) ? P[(long)(row0 + row) * ld + k] : 0.f;
-        }
-    }
-}
-__device__ __forceinline__ void store_kcontig(float* __restrict__ S, int vec, const float (&r)[NSC]) {
-    const int tid = threadIdx.x;
-    if (vec) {
-#pragma unroll
-        for (int j = 0; j < NV4; ++j) {
-            const int idx = tid + GB_T * j, row = idx / (GB_K / 4), k = (idx % (GB_K / 4)) << 2;
-            *(float4*)(S + row * LDK + k) = make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NSC; ++j) {
-            const int idx = tid + GB_T * j;
-            S[(idx / GB_K) * LDK + (idx % GB_K)] = r[j];
-        }
-    }
-}
-// k-major tile: GB_K k x 64 rows(cols).
-__device__ __forceinline__ void load_kmajor(const float* __restrict__ P, long ld, int row0, int nrows, int k0,
-                                            int kend, int vec, float (&r)[NSC]) {
-    const int tid = threadIdx.x;
-    if (vec) {
-#pragma unroll
-        for (int j = 0; j < NV4; ++j) {
-            const int idx = tid + GB_T * j, k = k0 + (idx >> 4), row = row0 + ((idx & 15) << 2);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < kend && row < nrows) v = *(const float4*)(P + (long)k * ld + row);
-            r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NSC; ++j) {
-            const int idx = tid + GB_T * j, k = k0 + (idx >> 6), row = row0 + (idx & 63);
-            r[j] = (k < kend && row < nrows) ? P[(long)k * ld + row] : 0.f;
-        }
-    }
-}
-__device__ __forceinline__ void store_kmajor(float* __restrict__ S, int vec, const float (&r)[NSC]) {
-    const int tid = threadIdx.x;
-    if (vec) {
-#pragma unroll
-        for (int j = 0; j < NV4; ++j) {
-            const int idx = tid + GB_T * j;
-            *(float4*)(S + (idx >> 4) * LDR + ((idx & 15) << 2)) =
-                make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NSC; ++j) {
-            const int idx = tid + GB_T * j;
-            S[(idx >> 6) * LDR + (idx & 63)] = r[j];
-        }
-    }
-}
-
-template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
-__global__ __launch_bounds__(GB_T) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[GB_M * LDK];   // 64*68 >= 64*64
-    __shared__ __attribute__((aligned(16))) float Bs[GB_N * LDK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int kg = wave >> 2, wq = wave & 3;                  // k-group (intra-WG split-K), output quadrant
-    const int wm = (wq >> 1) * 32, wn = (wq & 1) * 32;
-    const int kofs = kg * (GB_K / 2) + lh * KH;               // this lane's first k inside a K-step
-    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
-    const int kbeg = blockIdx.z * g.kchunk;
-    const int kend = min(g.K, kbeg + g.kchunk);
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool do_bias = (EPI == EPI_PLAIN) && g.dbias != nullptr && blockIdx.x == 0;
-    float bsum = 0.f;
-
-    float ra[NSC], rb[NSC];
-    if (kbeg < kend) {
-        if (A_KMAJOR) load_kmajor(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
-        else load_kcontig(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
-        if (B_KMAJOR) load_kmajor(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
-        else load_kcontig(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
-    }
-    for (int k0 = kbeg; k0 < kend; k0 += GB_K) {
-        __syncthreads();                       // previous tile's fragment reads done
-        if (A_KMAJOR) store_kmajor(As, g.vecA, ra); else store_kcontig(As, g.vecA, ra);
-        if (B_KMAJOR) store_kmajor(Bs, g.vecB, rb); else store_kcontig(Bs, g.vecB, rb);
-        __syncthreads();
-        if (EPI == EPI_PLAIN && A_KMAJOR && do_bias && tid < GB_M) {   // db += column sums of this dY tile
-#pragma unroll 8
-            for (int k = 0; k < GB_K; ++k) bsum += As[k * LDR + tid];
-        }
-        if (k0 + GB_K < kend) {                // prefetch next tile while this one is multiplied
-            if (A_KMAJOR) load_kmajor(g.A, g.lda, m0, g.M, k0 + GB_K, kend, g.vecA, ra);
-            else load_kcontig(g.A, g.lda, m0, g.M, k0 + GB_K, kend, g.vecA, ra);
-            if (B_KMAJOR) load_kmajor(g.B, g.ldb, n0, g.N, k0 + GB_K, kend, g.vecB, rb);
-            else load_kcontig(g.B, g.ldb, n0, g.N, k0 + GB_K, kend, g.vecB, rb);
-        }
-        float fa[KH], fb[KH];
-        if (A_KMAJOR) {
-#pragma unroll
-            for (int s = 0; s < KH; ++s) fa[s] = As[(kofs + s) * LDR + wm + li];
-        } else {
-#pragma unroll
-            for (int q = 0; q < KH / 4; ++q) {
-                const float4 v = *(const float4*)(As + (wm + li) * LDK + kofs + 4 * q);
-                fa[4 * q] = v.x; fa[4 * q + 1] = v.y; fa[4 * q + 2] = v.z; fa[4 * q + 3] = v.w;
-            }
-        }
-        if (B_KMAJOR) {
-#pragma unroll
-            for (int s = 0; s < KH; ++s) fb[s] = Bs[(kofs + s) * LDR + wn + li];
-        } else {
-#pragma unroll
-            for (int q = 0; q < KH / 4; ++q) {
-                const float4 v = *(const float4*)(Bs + (wn + li) * LDK + kofs + 4 * q);
-                fb[4 * q] = v.x; fb[4 * q + 1] = v.y; fb[4 * q + 2] = v.z; fb[4 * q + 3] = v.w;
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
-    }
-
-    if (EPI == EPI_PLAIN && A_KMAJOR && do_bias && tid < GB_M && m0 + tid < g.M)
-        g.dbias[(long)blockIdx.z * g.M + m0 + tid] = bsum;
-    // combine the two k-groups: waves 4-7 park their accumulators in LDS, waves 0-3 add them
-    __syncthreads();
-    float* red = As;                                           // 4 quadrants x 64 lanes x 16 floats = 16 KB
-    if (kg == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wq * 16 + r) * 64 + lane] = acc[r];
-    }
-    __syncthreads();
-    if (kg == 1) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += red[(wq * 16 + r) * 64 + lane];
-    // epilogue: acc[r] is C[row = wm + (r&3) + 8*(r>>2) + 4*lh][col = wn + li]
-    float* C = g.C + (long)blockIdx.z * g.slab;
-    const int col = n0 + wn + li;
-    if (col >= g.N) return;
-    float bias = 0.f;
-    if (EPI == EPI_BIAS_ACT && g.bias) bias = g.bias[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < g.M) {
-            float v = acc[r];
-            if (EPI == EPI_BIAS_ACT) {
-                v += bias;
-                if (g.act == PM_ACT_TANH) v = pm_tanh(v);
-            } else if (EPI == EPI_MUL_DACT) {
-                if (g.act == PM_ACT_TANH) {
-                    const float h = g.H[(long)row * g.ldh + col];
-                    v *= (1.0f - h * h);
-                }
-            }
-            C[(long)row * g.ldc + col] = v;
-        }
-    }
-}
 
 static inline int aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int pm_linear_fwd_f32(const float* X, long ldx, const float* W, long ldw, const float* b, float* Y,
                                  long ldy, int M, int N, int K, int act, void* stream) {
     PM_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N);
-    PM_REQUIRE(act == PM_ACT_NONE || act == PM_ACT_TANH);
+    PM_REQUIRE(act >= PM_ACT_NONE && act <= PM_ACT_MAX);
     Gemm2Group gg{};
     gg.n = 1;
     Gemm2Prob& g = gg.p[0];
@@ -243,7 +33,7 @@ extern "C" int pm_linear_bwd_data_f32(const float* dY, long lddy, const float* W
                                       long ldh, float* dX, long lddx, int M, int N, int K, int act,
                                       void* stream) {
     PM_REQUIRE(dY && W && dX && M > 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K);
-    PM_REQUIRE(act == PM_ACT_NONE || (act == PM_ACT_TANH && H && ldh >= K));
+    PM_REQUIRE(act == PM_ACT_NONE || (act > PM_ACT_NONE && act <= PM_ACT_MAX && H && ldh >= K));
     Gemm2Group gg{};
     gg.n = 1;
     Gemm2Prob& g = gg.p[0];
@@ -348,7 +138,7 @@ extern "C" int pm_linear_fwd_group_f32(int n, const pm_linear_fwd_desc* d, void*
     for (int i = 0; i < n; ++i) {
         const pm_linear_fwd_desc& q = d[i];
         PM_REQUIRE(q.X && q.W && q.Y && q.M > 0 && q.N > 0 && q.K > 0 && q.ldx >= q.K && q.ldw >= q.K && q.ldy >= q.N);
-        PM_REQUIRE(q.act == PM_ACT_NONE || q.act == PM_ACT_TANH);
+        PM_REQUIRE(q.act >= PM_ACT_NONE && q.act <= PM_ACT_MAX);
         Gemm2Prob& g = gg.p[i];
         g.A = q.X; g.lda = q.ldx; g.B = q.W; g.ldb = q.ldw; g.C = q.Y; g.ldc = q.ldy; g.bias = q.b;
         g.M = q.M; g.N = q.N; g.K = q.K; g.act = q.act; g.epi = G2_EPI_BIAS_ACT; g.splits = 1;
@@ -365,7 +155,7 @@ extern "C" int pm_linear_bwd_data_group_f32(int n, const pm_linear_bwd_data_desc
     for (int i = 0; i < n; ++i) {
         const pm_linear_bwd_data_desc& q = d[i];
         PM_REQUIRE(q.dY && q.W && q.dX && q.M > 0 && q.N > 0 && q.K > 0 && q.lddy >= q.N && q.ldw >= q.K && q.lddx >= q.K);
-        PM_REQUIRE(q.act == PM_ACT_NONE || (q.act == PM_ACT_TANH && q.H && q.ldh >= q.K));
+        PM_REQUIRE(q.act == PM_ACT_NONE || (q.act > PM_ACT_NONE && q.act <= PM_ACT_MAX && q.H && q.ldh >= q.K));
         Gemm2Prob& g = gg.p[i];
         g.A = q.dY; g.lda = q.lddy; g.B = q.W; g.ldb = q.ldw; g.C = q.dX; g.ldc = q.lddx; g.H = q.H; g.ldh = q.ldh;
         g.M = q.M; g.N = q.K; g.K = q.N; g.act = q.act; g.epi = G2_EPI_MUL_DACT; g.splits = 1;

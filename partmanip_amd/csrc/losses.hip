@@ -205,6 +205,68 @@ extern "C" int pm_gaussian_logp_f32(const float* mu, long ldmu, const float* log
     return PM_OK;
 }
 
+// Backward of the two rows above for the autograd bridge (partmanip_amd/autograd.py: the reference's own `update()`
+// differentiates through ActorCritic.update_act_cri with torch autograd, ppo.py:326,347-348):
+//   dmu[i][a]  = dlogp[i] * (x - mu) / s^2,  s = exp(log_std)^2 (the covariance factor of actor_critic.py:74-75)
+//   dlog_std[a] = sum_i dlogp[i] * (2 z^2 - 2) + dent[i] * 2,  z = (x - mu) / s
+// dlog_std: one work-group, fixed-order fp64 sums (deterministic).
+__global__ __launch_bounds__(LOSS_THREADS) void gaussian_logp_bwd_kernel(const float* __restrict__ mu, long ldmu,
+                                                                          const float* __restrict__ log_std,
+                                                                          const float* __restrict__ actions, long lda,
+                                                                          int B, int A, float max_action, int act_tanh,
+                                                                          const float* __restrict__ dlogp,
+                                                                          const float* __restrict__ dent,
+                                                                          float* __restrict__ dmu, long lddm,
+                                                                          float* __restrict__ dlog_std) {
+    __shared__ double red[LOSS_WAVES];
+    for (int a = 0; a < A; ++a) {
+        const float e = expf(log_std[a]);
+        const float s = e * e;
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < B; i += LOSS_THREADS) {
+            const float gl = dlogp ? dlogp[i] : 0.f;
+            const float x = deactivate(actions[i * lda + a], max_action, act_tanh);
+            const float z = (x - mu[i * ldmu + a]) / s;
+            if (dmu) dmu[i * lddm + a] = gl * z / s;
+            acc += (double)(gl * (2.0f * z * z - 2.0f)) + (dent ? (double)(2.0f * dent[i]) : 0.0);
+        }
+        acc = block_sum<double, LOSS_THREADS>(acc, red);
+        if (threadIdx.x == 0 && dlog_std) dlog_std[a] = (float)acc;
+        __syncthreads();
+    }
+}
+
+extern "C" int pm_gaussian_logp_bwd_f32(const float* mu, long ldmu, const float* log_std, const float* actions, long lda,
+                                        int B, int A, float max_action, int act_tanh, const float* dlogp,
+                                        const float* dent, float* dmu, long lddm, float* dlog_std, void* stream) {
+    PM_REQUIRE(mu && log_std && actions && B > 0 && A > 0 && (dmu || dlog_std) && max_action > 0.f);
+    hipLaunchKernelGGL(gaussian_logp_bwd_kernel, dim3(1), dim3(LOSS_THREADS), 0, pm_stream(stream), mu, ldmu, log_std,
+                       actions, lda, B, A, max_action, act_tanh, dlogp, dent, dmu, lddm, dlog_std);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// d/d(mu) of actor_critic.py:84-91: out = tanh(mu) * max_action  ->  dmu = dout * max_action * (1 - (out / max_action)^2)
+__global__ __launch_bounds__(256) void action_activation_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                                     float* __restrict__ dmu, long n, float max_action,
+                                                                     int act_tanh) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float t = out[i] / max_action;
+        dmu[i] = act_tanh ? dout[i] * max_action * (1.0f - t * t) : dout[i];
+    }
+}
+
+extern "C" int pm_action_activation_bwd_f32(const float* out, const float* dout, float* dmu, long n, float max_action,
+                                            int act_tanh, void* stream) {
+    PM_REQUIRE(out && dout && dmu && n > 0 && max_action > 0.f);
+    long b = (n + 255) / 256;
+    if (b > 1024) b = 1024;
+    hipLaunchKernelGGL(action_activation_bwd_kernel, dim3((int)b), dim3(256), 0, pm_stream(stream), out, dout, dmu, n,
+                       max_action, act_tanh);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
 // ---------------------------------------------------------------------------------- K9
 __global__ __launch_bounds__(LOSS_THREADS) void value_loss_kernel(const float* __restrict__ V,
                                                                    const float* __restrict__ returns,

@@ -8,7 +8,7 @@
 //   feat    (B, ldf)      [max(512) | mean(512)]   argmax (B,512) int32
 //   never materialised: the (B,P,128/256/512) activations (4.3 GB per net at B=2048).
 //
-// Forward: one work-group (4 waves) owns one cloud and walks it in tiles of 64 points
+// Forward: one work-group (8 waves: PN_FWD_NW) owns one cloud and walks it in tiles of 64 points
 // (the backward uses 32-point tiles so that two work-groups fit one CU, see below):
 //   layer 1 (K=C<=8)  VALU          -> H1 tile in LDS  [64][132]
 //   layer 2 (K=128)   fp32 MFMA     -> H2 tile in LDS  [64][260]   (aliases H1 after a barrier)

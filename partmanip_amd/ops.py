@@ -7,7 +7,7 @@ import torch
 
 from ._lib import lib, check
 
-ACT_NONE, ACT_TANH = 0, 1
+ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_ELU, ACT_SELU, ACT_SIGMOID = range(7)      # PM_ACT_* of the header
 
 
 def _ptr(t):
@@ -310,6 +310,23 @@ def gaussian_logp(mu, log_std, actions, max_action, act_tanh, logp, entropy):
     check(lib.pm_gaussian_logp_f32(_ptr(mu), _rows(mu, "mu"), _ptr(log_std), _ptr(actions), _rows(actions, "actions"),
                                    B, A, float(max_action), int(act_tanh), _ptr(logp), _ptr(entropy), _stream()),
           "pm_gaussian_logp_f32")
+
+
+def gaussian_logp_bwd(mu, log_std, actions, max_action, act_tanh, dlogp, dent, dmu, dlog_std):
+    _req(mu, log_std, actions, dlogp, dent, dmu, dlog_std)
+    B, A = mu.shape
+    check(lib.pm_gaussian_logp_bwd_f32(_ptr(mu), _rows(mu, "mu"), _ptr(log_std), _ptr(actions), _rows(actions, "actions"), B, A,
+                                       float(max_action), int(act_tanh), _ptr(dlogp), _ptr(dent), _ptr(dmu),
+                                       _rows(dmu, "dmu") if dmu is not None else 0, _ptr(dlog_std), _stream()),
+          "pm_gaussian_logp_bwd_f32")
+
+
+def action_activation_bwd(out, dout, dmu, max_action, act_tanh):
+    _req(out, dout, dmu)
+    for t_, n_ in ((out, "out"), (dout, "dout"), (dmu, "dmu")):
+        _f32c(t_, n_)
+    check(lib.pm_action_activation_bwd_f32(_ptr(out), _ptr(dout), _ptr(dmu), out.numel(), float(max_action), int(act_tanh),
+                                           _stream()), "pm_action_activation_bwd_f32")
 
 
 def value_loss(v, returns, old_values, clipped, eps_clip, clip_mean_extern, grad_scale, scal, dv):
