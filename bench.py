@@ -110,12 +110,11 @@ def cpu_baseline_ppo(w, rollout_cpu, sd_cpu, cfg):
                        f"{T * N} samples per loop; {used} torch threads (fastest of {sorted(tried)} on {ncpu} host CPUs)")
 
 
-def cpu_baseline_dagger(d, net, ring_obs, ring_tea, stu_sd, tea_sd, tea_net, rows_total, proprio):
+def cpu_baseline_dagger(d, net, ring_obs, ring_tea, stu_sd, tea_sd, tea_net, rows_total, proprio, mb=128):
     """Oracle `dagger_update` (frozen teacher forward + student forward/backward + Adam) on 3 mini-batches of `mb`
     ring rows, warmed; extrapolated by the row count of one update (n_updates passes over the ring)."""
     from oracle import ref_cpu as R
     ncpu = os.cpu_count() or 1
-    mb = 128
     model = lambda n, std: dict(action_std=std, action_activate="tanh", clipAction=1.0, network=dict(n))
     cfg = dict(model=model(net, 0.1), tea_model=model(tea_net, 0.5), n_updates=1, n_minibatches=3, sampler="sequential",
                lr=5e-5, lr_schedule="fixed", max_iterations=10000, proprio_shape=proprio)
@@ -127,7 +126,7 @@ def cpu_baseline_dagger(d, net, ring_obs, ring_tea, stu_sd, tea_sd, tea_net, row
         R.dagger_update(stu, tea_sd, ring_obs[: mb_ * n_], ring_tea[: mb_ * n_], mb_ * n_, c, 1)
         return time.perf_counter() - t0
 
-    used, tried = _pick_threads(lambda: run(16, 1), ncpu)
+    used, tried = _pick_threads(lambda: run(min(16, mb), 1), ncpu)
     t = run(mb, 3)
     per_row = t / (3 * mb)
     t_upd = per_row * rows_total
@@ -152,6 +151,10 @@ def run_dagger(args, device, rank, world):
         # a 50^3 TSDF + proprio = 12.8 GB, resident in HBM), Conv3DNet student, 16 mini-batches (-> 1600 rows), 2 passes
         d = dict(DAGGER, N=16, buf=1600, O_s=50 ** 3 + 25, proprio=25, name="dagger_conv3dnet_student_16env_x_1600buf_x_50cube_tsdf")
         obs_mode = "mesh_tsdf"
+    elif args.student == "sparse_unet":
+        # BASELINE cfg 5 as written: a 3D sparse-voxel U-Net student on 4096-point 'depth_sparse' clouds (x, y, z, tsdf rows)
+        d = dict(DAGGER, O_s=4 * args.points, proprio=0, name=f"dagger_sparse_unet_student_4096env_x_16buf_x_{args.points}pt")
+        obs_mode = "depth_sparse"
     else:
         d = dict(DAGGER, O_s=3 * args.points, proprio=0, name=DAGGER["name"].format(P=args.points))
         obs_mode = "depth_pc"
@@ -164,7 +167,9 @@ def run_dagger(args, device, rank, world):
     tea = ppo(env, tcfg, ScreenLogger(tmp, f"tea{rank}", "n", quiet=True))
     tea.sync = None                                      # every rank writes its own (identical) teacher checkpoint
     tea.save(1)
+    sparse = args.student == "sparse_unet"
     net = (dict(name="Conv3DNet", activation="tanh") if conv else
+           dict(name="SparseUNet", activation="tanh", point_num=args.points, grid=50) if sparse else
            dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False, point_num=args.points))
     cfg = dict(num_envs=d["N"], obs_mode=obs_mode,
                model=dict(action_std=0.1, action_activate="tanh", clipAction=1.0, network=net),
@@ -185,7 +190,8 @@ def run_dagger(args, device, rank, world):
             torch.cuda.synchronize()
     for _ in range(args.warmup):
         run.update(1)
-    timed = ("conv3d_c1_wgrad", "conv3d_c1_fwd") if conv else ("pointnet_enc_fwd", "pointnet_enc_bwd")
+    timed = ("conv3d_c1_wgrad", "conv3d_c1_fwd") if conv else ("sparse_unet_fwd", "sparse_unet_bwd") if sparse else \
+        ("pointnet_enc_fwd", "pointnet_enc_bwd")
     ops.TIMER.enable(*timed)
     fence()
     t0 = time.perf_counter()
@@ -219,6 +225,25 @@ def run_dagger(args, device, rank, world):
             if f:
                 out["roofline"]["conv1_fwd_mean_ms"] = f[0]
                 out["roofline"]["conv1_fwd_gbs"] = nbytes / (f[0] * 1e-3) / 1e9
+    elif sparse:
+        # whole backbone forward / backward (gathers + Linear GEMMs); flops = the GEMMs the launch executes, from the level
+        # sizes of the last mini-batch: fwd sum_l rows_l * K_l * N_l * 2, bwd twice that minus conv0's absent data gradient
+        t, b = ops.TIMER.mean_ms("sparse_unet_fwd"), ops.TIMER.mean_ms("sparse_unet_bwd")
+        g = run.student.actor._saved["g"]
+        c0, c1, c2 = run.student.actor.channels
+        R0, R1, R2 = g["rows"]
+        macs = {"conv0": R0 * 108 * c0, "down0": R1 * 8 * c0 * c1, "conv1": R1 * 27 * c1 * c1, "down1": R2 * 8 * c1 * c2,
+                "conv2": R2 * 27 * c2 * c2, "up1": R1 * (c2 + c1) * c1, "up0": R0 * (c1 + c0) * c0}
+        ffl = 2.0 * sum(macs.values())
+        bfl = 2.0 * ffl - 2.0 * macs["conv0"]
+        if t and b:
+            tf = (ffl + bfl) / ((t[0] + b[0]) * 1e-3) / 1e12
+            out["roofline"] = dict(bound="mfma", kernel="SparseUNet forward + backward (row gathers + gemm2 Linear kernels)",
+                                   achieved=tf, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                                   launches=t[1], fwd_mean_ms=t[0], bwd_mean_ms=b[0], level_rows=[R0, R1, R2],
+                                   flops_fwd=ffl, flops_bwd=bfl,
+                                   note="unfused first version: every sparse convolution materialises its gathered (rows x J*C) "
+                                        "operand in HBM; the GEMMs run at the Linear kernels' rate, the gathers are HBM-bound")
     else:
         t = ops.TIMER.mean_ms("pointnet_enc_fwd")
         if t:
@@ -234,11 +259,12 @@ def run_dagger(args, device, rank, world):
                                        enc_bwd_frac=bflops / (b[0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = lambda t: t.detach().cpu()
-        n_rows = 3 * 128
+        cmb = 8 if sparse else 128            # the sparse restatement builds its voxel tables in Python: a smaller sample
+        n_rows = 3 * cmb
         out["cpu_baseline"] = cpu_baseline_dagger(
             d, net, cpu(run.storage.observations.view(-1, d["O_s"])[:n_rows]), cpu(run.storage.tea_obs.view(-1, d["O_t"])[:n_rows]),
             {k: cpu(v).clone() for k, v in run.student.state_dict().items()},
-            {k: cpu(v).clone() for k, v in run.teacher.state_dict().items()}, WORKLOADS["state"]["net"], rows, d["proprio"])
+            {k: cpu(v).clone() for k, v in run.teacher.state_dict().items()}, WORKLOADS["state"]["net"], rows, d["proprio"], cmb)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     return out
 
@@ -578,7 +604,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optional", action="store_true", help="vision workload: skip the opt-in paths (profiling runs)")
     ap.add_argument("--n-steps", type=int, default=0, help="override the rollout length T (e.g. 128 for the vision workload)")
-    ap.add_argument("--student", default="pointnet", choices=["pointnet", "conv3d"],
+    ap.add_argument("--student", default="pointnet", choices=["pointnet", "conv3d", "sparse_unet"],
                     help="dagger workload: PointNet on --points clouds (cfg 5 analogue) or the reference's shipped Conv3DNet config")
     ap.add_argument("--points", type=int, default=4096, help="dagger workload: points per student cloud (BASELINE cfg 5: 4096)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x6"],

@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 122 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 123 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -399,6 +399,37 @@ int pm_rms_moments_f64(const float* x, long ldx, int N, int D, double* mom, void
                        void* stream);
 int pm_rms_apply_moments_f32(const double* mom, long n_rows, int D, int n_new, float* mean, float* S, float* std,
                              void* stream);
+
+/* ------------------------------------------------------------------ sparse-voxel U-Net building blocks
+ * `network.name: SparseUNet` -- the "3D Sparse-UNet" backbone README.md:30 names; its code is NOT in the reference
+ * snapshot (README.md:23): PARITY UNPINNED, restated in oracle/ref_cpu.py.  Input rows are the reference's 'depth_sparse'
+ * observation (tasks/hand_base.py:335-336; utils/depth2tsdf.py:88-120): (x, y, z, f) with integer voxel coordinates.
+ * Geometry: dense per-cloud index grids (R^3 int32; empty = 0x7fffffff), duplicates resolve to the lowest row.
+ *   pm_voxel_grid0_f32: x (B, ldx) rows of P points x C floats -> grid (B * R^3) = lowest row b*P+i at that coordinate,
+ *     coords (B*P, 4) int32 (b, x, y, z) clamped to [0, R), feat (B*P, 4) = (f, x/R, y/R, z/R) (may be NULL).
+ *   pm_voxel_nbr27_i32: nbr (rows, 27) = row at coords + (dx,dy,dz), o = (dx+1)*9 + (dy+1)*3 + (dz+1), or -1.
+ *   pm_voxel_down_count_i32 / _build_i32: the 2x strided level.  count: grid_c (B * Rc^3, Rc = ceil(Rf/2)) marks the parent
+ *     cells, counts[b] = occupied cells of cloud b.  The caller prefix-sums counts into base (and sizes the level:
+ *     rows_c = sum), then build numbers the cells in cell order from base[b] (grid_c <- global row; coords_c (rows_c, 4)),
+ *     child (rows_c, 8) = fine row in slot (x&1)*4 + (y&1)*2 + (z&1) or -1, and per fine row parent / parent_canon (-1 for a
+ *     duplicate coordinate: only the lowest row is its parent's child) / slot.
+ * Arithmetic: a sparse convolution = pm_rows_gather_f32 + the Linear kernels on (rows x J*C).
+ *   pm_rows_gather_f32: dst[r][j*C + c] = idx[r][j] >= 0 ? src[idx[r][j]][c] : 0      (C % 4 == 0, 16-byte rows)
+ *   pm_rows_gather_bwd_f32: dsrc[r][c] (=, or += if accumulate) (sum_j dcols[t][blk*C + c]) * (y_tanh ? 1 - y_tanh[r][c]^2 : 1)
+ *     with t = tidx[r][reverse ? J-1-j : j] (skipped when < 0) and blk = j (mode 0), tslot[r][j] (mode 1) or 0 (mode 2);
+ *     self_col >= 0: rows with tidx[r][self_col] != r get 0 (duplicates are nobody's neighbour).  Fixed summation order. */
+int pm_voxel_grid0_f32(const float* x, long ldx, int B, int P, int C, int R, int32_t* grid, int32_t* coords, float* feat,
+                       void* stream);
+int pm_voxel_nbr27_i32(const int32_t* coords, long rows, const int32_t* grid, int R, int32_t* nbr, void* stream);
+int pm_voxel_down_count_i32(const int32_t* coords_f, long rows_f, int B, int Rc, int32_t* grid_c, int32_t* counts, void* stream);
+int pm_voxel_down_build_i32(const int32_t* coords_f, long rows_f, const int32_t* grid_f, int Rf, int B, int Rc,
+                            const int32_t* base, int32_t* grid_c, long rows_c, int32_t* coords_c, int32_t* child,
+                            int32_t* parent, int32_t* parent_canon, int32_t* slot, void* stream);
+int pm_rows_gather_f32(const float* src, long lds, const int32_t* idx, long rows, int J, int C, float* dst, long ldd,
+                       void* stream);
+int pm_rows_gather_bwd_f32(const float* dcols, long ldc, const int32_t* tidx, const int32_t* tslot, int mode, int reverse,
+                           int self_col, long rows, int J, int C, const float* y_tanh, long ldy, int accumulate, float* dsrc,
+                           long lds, void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .network import MLP, Conv3DNet, PoolConv3DNet, PointNet, PointNet2, ResNet, depthResNet  # noqa: F401 (eval() namespace)
+from .network import MLP, Conv3DNet, PoolConv3DNet, PointNet, PointNet2, SparseUNet, ResNet, depthResNet  # noqa: F401 (eval() namespace)
 from .. import ops
 
 

@@ -532,6 +532,156 @@ class PointNet2(_HipNet):
                 dpooled = ops.group_concat_bwd(drows, idx_g, B, P_l, cf, ldo).view(B * P_l, cf)
 
 
+class SparseUNet(_HipNet):
+    """3D sparse-voxel U-Net encoder as a backbone plug-in (`network.name: SparseUNet`).
+
+    The reference's README names a "3D Sparse-UNet" as the paper's vision backbone (README.md:30) but its code moved to an
+    unmounted branch (README.md:23); BASELINE.json's north_star / config 5 ask for it, so this follows the published sparse
+    U-Net structure (submanifold 3^3 convolutions, 2x strided levels, skip connections) with the reference's conventions
+    (no BatchNorm, `net_cfg['activation']` = tanh, the PointNet head 128-32-out, proprio appended before the head) --
+    PARITY UNPINNED, restated in oracle/ref_cpu.py::sparse_unet_forward.
+
+    Input: the reference's 'depth_sparse' observation (tasks/hand_base.py:335-336, utils/depth2tsdf.py:88-120): `point_num`
+    rows (x, y, z, f) per env with integer voxel coordinates in [0, grid), flattened (+ proprio tail).  Levels (channels
+    c0, c1, c2; default 32, 64, 128; every Linear is followed by tanh):
+        F0 = (f, x/grid, y/grid, z/grid)
+        H0 = conv0(F0)  3^3 submanifold            D1 = down0(H0)  2^3 stride 2          H1 = conv1(D1)
+        D2 = down1(H1)                              H2 = conv2(D2)
+        E1 = up1([unpool(H2) | H1])                 E0 = up0([unpool(E1) | H0])            feat = max over the cloud's rows of E0
+    A sparse convolution runs as a neighbour-row gather (pm_rows_gather_f32) + the fp32-MFMA Linear kernel on the
+    (rows x J*C_in) matrix; geometry (dense index grids, neighbour / parent / child tables) is csrc/sparse_voxel.hip."""
+
+    def __init__(self, input_dim, output_dim, net_cfg, proprio_shape):
+        super().__init__()
+        self.point_num = int(net_cfg.get('point_num', 1024))
+        self.in_channels = input_dim // self.point_num
+        if self.in_channels < 3:
+            raise ValueError("SparseUNet needs rows (x, y, z[, f]) per point")
+        self.grid = int(net_cfg.get('grid', 50))
+        c0, c1, c2 = (int(c) for c in net_cfg.get('channels', [32, 64, 128]))
+        if any(c % 4 for c in (c0, c1, c2)):
+            raise ValueError("SparseUNet channels must be multiples of 4 (16-byte feature rows)")
+        self.channels = (c0, c1, c2)
+        self.proprio_shape = proprio_shape
+        act = net_cfg['activation']
+        code = _act_code(act)
+        self.conv0, self.down0 = nn.Linear(27 * 4, c0), nn.Linear(8 * c0, c1)
+        self.conv1, self.down1 = nn.Linear(27 * c1, c1), nn.Linear(8 * c1, c2)
+        self.conv2 = nn.Linear(27 * c2, c2)
+        self.up1, self.up0 = nn.Linear(c2 + c1, c1), nn.Linear(c1 + c0, c0)
+        self.feat_dim = c0
+        self.final_mlp = nn.Sequential(nn.Linear(c0 + proprio_shape, 128), get_activation(act), nn.Linear(128, 32),
+                                       get_activation(act), nn.Linear(32, output_dim))
+        object.__setattr__(self, "_act", code)
+        object.__setattr__(self, "_head", _LinearChain([self.final_mlp[0], self.final_mlp[2], self.final_mlp[4]], code))
+        object.__setattr__(self, "_g", None)
+
+    _LAYERS = ("conv0", "down0", "conv1", "down1", "conv2", "up1", "up0")
+
+    def set_grad_views(self, views):
+        self._head.grads = [(views[f"final_mlp.{i}.weight"], views[f"final_mlp.{i}.bias"]) for i in (0, 2, 4)]
+        object.__setattr__(self, "_g", {n: (views[f"{n}.weight"], views[f"{n}.bias"]) for n in self._LAYERS})
+
+    def geometry(self, x):
+        """Index grids and tables of the three levels for the clouds in x (coordinates only: no parameters involved)."""
+        B, P, C, R = x.shape[0], self.point_num, self.in_channels, self.grid
+        grid0, coords0, feat0 = ops.voxel_grid0(x, P, C, R)
+        l1 = ops.voxel_down(coords0, grid0, R, B)
+        l2 = ops.voxel_down(l1["coords"], l1["grid"], l1["R"], B)
+        return dict(feat0=feat0, nbr0=ops.voxel_nbr27(coords0, grid0, R), nbr1=ops.voxel_nbr27(l1["coords"], l1["grid"], l1["R"]),
+                    nbr2=ops.voxel_nbr27(l2["coords"], l2["grid"], l2["R"]), l1=l1, l2=l2, rows=(B * P, l1["rows"], l2["rows"]))
+
+    def _lin(self, name, x, y):
+        lin = getattr(self, name)
+        ops.linear_fwd(x, lin.weight.data, lin.bias.data, y, self._act)
+        return y
+
+    def forward(self, x):
+        with torch.no_grad():
+            return self.hip_forward(x)
+
+    def hip_forward(self, x, out=None):
+        with ops.TIMER.bracket("sparse_unet_fwd"):
+            return self._hip_forward(x, out)
+
+    def hip_backward(self, dy):
+        with ops.TIMER.bracket("sparse_unet_bwd"):
+            self._hip_backward(dy)
+
+    def _hip_forward(self, x, out=None):
+        B, P = x.shape[0], self.point_num
+        c0, c1, c2 = self.channels
+        dev = x.device
+        g = self.geometry(x)
+        R0, R1, R2 = g["rows"]
+        e = lambda r, c: torch.empty(r, c, device=dev)
+        cols0 = ops.rows_gather(g["feat0"], g["nbr0"], 4, e(R0, 27 * 4))
+        cat0 = e(R0, c1 + c0)                                   # [unpool(E1) | H0]
+        H0 = self._lin("conv0", cols0, cat0[:, c1:])
+        colsd0 = ops.rows_gather(H0, g["l1"]["child"], c0, e(R1, 8 * c0))
+        D1 = self._lin("down0", colsd0, e(R1, c1))
+        cols1 = ops.rows_gather(D1, g["nbr1"], c1, e(R1, 27 * c1))
+        cat1 = e(R1, c2 + c1)                                   # [unpool(H2) | H1]
+        H1 = self._lin("conv1", cols1, cat1[:, c2:])
+        colsd1 = ops.rows_gather(H1, g["l2"]["child"], c1, e(R2, 8 * c1))
+        D2 = self._lin("down1", colsd1, e(R2, c2))
+        cols2 = ops.rows_gather(D2, g["nbr2"], c2, e(R2, 27 * c2))
+        H2 = self._lin("conv2", cols2, e(R2, c2))
+        ops.rows_gather(H2, g["l2"]["parent"].view(-1, 1), c2, cat1[:, :c2])
+        E1 = self._lin("up1", cat1, e(R1, c1))
+        ops.rows_gather(E1, g["l1"]["parent"].view(-1, 1), c1, cat0[:, :c1])
+        E0 = self._lin("up0", cat0, e(R0, c0))
+        fbuf = torch.empty(B, c0 + self.proprio_shape, device=dev)
+        arg = ops.maxpool_rows(E0, B, P, fbuf[:, :c0])
+        if self.proprio_shape != 0:
+            fbuf[:, c0:].copy_(x[:, -self.proprio_shape:])
+        object.__setattr__(self, "_saved", dict(g=g, cols0=cols0, cat0=cat0, colsd0=colsd0, D1=D1, cols1=cols1, cat1=cat1,
+                                                colsd1=colsd1, D2=D2, cols2=cols2, E0=E0, arg=arg, B=B))
+        return self._head.forward(fbuf, out)
+
+    def _hip_backward(self, dy):
+        s, g = self._saved, self._saved["g"]
+        c0, c1, c2 = self.channels
+        P, B = self.point_num, s["B"]
+        ws = self._workspace(dy.device)
+        W = lambda n: getattr(self, n).weight.data
+        dfbuf = torch.empty(B, c0 + self.proprio_shape, device=dy.device)
+        self._head.backward(dy, ws, dx_out=dfbuf)
+        dzE0 = ops.maxpool_rows_bwd(dfbuf[:, :c0], s["arg"], P, y_tanh=s["E0"])            # pre-activation gradient of up0
+        cat0, cat1 = s["cat0"], s["cat1"]
+        ops.linear_bwd_weight(dzE0, cat0, *self._g["up0"], ws)
+        dcat0 = torch.empty_like(cat0)
+        ops.linear_bwd_data(dzE0, W("up0"), cat0, dcat0, ops.ACT_TANH)                     # tanh' of both halves folded in
+        dzE1 = ops.rows_gather_bwd(dcat0[:, :c1], g["l1"]["child"], c1, torch.empty_like(s["D1"]), mode=2)
+        ops.linear_bwd_weight(dzE1, cat1, *self._g["up1"], ws)
+        dcat1 = torch.empty_like(cat1)
+        ops.linear_bwd_data(dzE1, W("up1"), cat1, dcat1, ops.ACT_TANH)
+        dzH2 = ops.rows_gather_bwd(dcat1[:, :c2], g["l2"]["child"], c2, torch.empty_like(s["D2"]), mode=2)
+        ops.linear_bwd_weight(dzH2, s["cols2"], *self._g["conv2"], ws)
+        dcols2 = torch.empty_like(s["cols2"])
+        ops.linear_bwd_data(dzH2, W("conv2"), None, dcols2, ops.ACT_NONE)
+        dzD2 = ops.rows_gather_bwd(dcols2, g["nbr2"], c2, torch.empty_like(s["D2"]), reverse=True, self_col=13, y_tanh=s["D2"])
+        del dcols2
+        ops.linear_bwd_weight(dzD2, s["colsd1"], *self._g["down1"], ws)
+        dcolsd1 = torch.empty_like(s["colsd1"])
+        ops.linear_bwd_data(dzD2, W("down1"), None, dcolsd1, ops.ACT_NONE)
+        dzH1 = dcat1[:, c2:]                                                                # skip part (already pre-activation)
+        ops.rows_gather_bwd(dcolsd1, g["l2"]["parent_canon"].view(-1, 1), c1, dzH1, tslot=g["l2"]["slot"].view(-1, 1), mode=1,
+                            y_tanh=cat1[:, c2:], accumulate=True)
+        ops.linear_bwd_weight(dzH1, s["cols1"], *self._g["conv1"], ws)
+        dcols1 = torch.empty_like(s["cols1"])
+        ops.linear_bwd_data(dzH1, W("conv1"), None, dcols1, ops.ACT_NONE)
+        dzD1 = ops.rows_gather_bwd(dcols1, g["nbr1"], c1, torch.empty_like(s["D1"]), reverse=True, self_col=13, y_tanh=s["D1"])
+        del dcols1
+        ops.linear_bwd_weight(dzD1, s["colsd0"], *self._g["down0"], ws)
+        dcolsd0 = torch.empty_like(s["colsd0"])
+        ops.linear_bwd_data(dzD1, W("down0"), None, dcolsd0, ops.ACT_NONE)
+        dzH0 = dcat0[:, c1:]
+        ops.rows_gather_bwd(dcolsd0, g["l1"]["parent_canon"].view(-1, 1), c0, dzH0, tslot=g["l1"]["slot"].view(-1, 1), mode=1,
+                            y_tanh=cat0[:, c1:], accumulate=True)
+        ops.linear_bwd_weight(dzH0, s["cols0"], *self._g["conv0"], ws)                      # the input features are data
+
+
 class _ConvEncoder(nn.Module):
     """Parameter container with the reference's names (network.py:116-139 `Encoder`: conv1..conv3)."""
 

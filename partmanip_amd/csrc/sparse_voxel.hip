@@ -1,0 +1,264 @@
+// Sparse-voxel U-Net building blocks (`network.name: SparseUNet`, the "3D Sparse-UNet" backbone the reference's README
+// names -- README.md:30 -- whose code is NOT in the snapshot, README.md:23: parity unpinned, own restatement in
+// oracle/ref_cpu.py).  The observation is the reference's 'depth_sparse' format (tasks/hand_base.py:335-336,
+// utils/depth2tsdf.py:88-120): P rows (x, y, z, f) per env with integer voxel coordinates in [0, R).
+//
+// MI355X-shaped design: geometry and arithmetic are separated.
+//   * Geometry (integer work, HBM-bound, once per forward): a DENSE index grid per cloud and level (R^3 int32: 0.5 MB
+//     per cloud at R = 50 -- 1 GB for a 2048-cloud mini-batch is small change next to 288 GB of HBM and makes every
+//     neighbour / parent / child lookup one load instead of a hash probe), the 27-neighbour table of a submanifold
+//     convolution, and the 2x2x2 parent / child tables of the strided levels.  Duplicate coordinates (the padding rows of
+//     `sparse_voxel` all read voxel (0,0,0)) resolve to the LOWEST row index (atomicMin), everything is deterministic.
+//   * Arithmetic: a sparse convolution is "gather the neighbour rows side by side" (pm_rows_gather_f32: a row of
+//     J x C floats per output voxel, zeros for absent neighbours) followed by the fp32-MFMA Linear kernels of
+//     gemm2_f32.hip on (rows x J C) x (J C x C_out) -- one big GEMM per layer instead of J small ones, bias + tanh in its
+//     epilogue; the backward is the Linear backward kernels plus pm_rows_gather_bwd_f32, which routes the column
+//     blocks back through the MIRRORED table as a gather (no atomics: fixed summation order), folds tanh' and can
+//     accumulate a second contribution (skip connections).
+#include "common.h"
+
+#define VX_EMPTY 0x7fffffff
+
+__global__ __launch_bounds__(256) void vx_fill_kernel(int32_t* __restrict__ p, long n, int32_t v) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
+}
+static inline int vx_blocks(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// level 0: rows -> coords (b, x, y, z) and grid[b][cell] = lowest row with that coordinate
+__global__ __launch_bounds__(256) void vx_grid0_kernel(const float* __restrict__ x, long ldx, int P, int C, int R, long rows,
+                                                        int32_t* __restrict__ grid, int32_t* __restrict__ coords) {
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        const long b = r / P;
+        const float* q = x + b * ldx + (r - b * P) * C;
+        int c[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            int v = (int)floorf(q[d]);
+            c[d] = v < 0 ? 0 : (v >= R ? R - 1 : v);
+        }
+        coords[r * 4] = (int)b; coords[r * 4 + 1] = c[0]; coords[r * 4 + 2] = c[1]; coords[r * 4 + 3] = c[2];
+        atomicMin(&grid[b * R * R * R + ((long)c[0] * R + c[1]) * R + c[2]], (int)r);
+    }
+}
+
+// 27 neighbours of every row: nbr[r][o], o = (dx+1)*9 + (dy+1)*3 + (dz+1); offset 26 - o is the mirrored one
+__global__ __launch_bounds__(256) void vx_nbr27_kernel(const int32_t* __restrict__ coords, long rows, const int32_t* __restrict__ grid,
+                                                        int R, int32_t* __restrict__ nbr) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < rows * 27; e += (long)gridDim.x * 256) {
+        const long r = e / 27;
+        const int o = (int)(e - r * 27);
+        const int dx = o / 9 - 1, dy = (o / 3) % 3 - 1, dz = o % 3 - 1;
+        const int b = coords[r * 4], X = coords[r * 4 + 1] + dx, Y = coords[r * 4 + 2] + dy, Z = coords[r * 4 + 3] + dz;
+        int v = -1;
+        if (X >= 0 && X < R && Y >= 0 && Y < R && Z >= 0 && Z < R) {
+            const int g = grid[(long)b * R * R * R + ((long)X * R + Y) * R + Z];
+            v = g == VX_EMPTY ? -1 : g;
+        }
+        nbr[e] = v;
+    }
+}
+
+// strided level: mark the parent cells of the fine rows, then count them per cloud (cell order)
+__global__ __launch_bounds__(256) void vx_mark_kernel(const int32_t* __restrict__ coords, long rows, int Rc, int32_t* __restrict__ gridc) {
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        const int b = coords[r * 4], X = coords[r * 4 + 1] >> 1, Y = coords[r * 4 + 2] >> 1, Z = coords[r * 4 + 3] >> 1;
+        gridc[(long)b * Rc * Rc * Rc + ((long)X * Rc + Y) * Rc + Z] = 0;          // occupied (every writer stores the same value)
+    }
+}
+// one work-group per cloud walks its Rc^3 cells in order: pass 0 counts the occupied ones, pass 1 numbers them from
+// base[b] on (grid <- global row, VX_EMPTY stays) and writes their coords
+__global__ __launch_bounds__(1024) void vx_number_kernel(int32_t* __restrict__ gridc, int Rc, const int32_t* __restrict__ base,
+                                                          int32_t* __restrict__ counts, int32_t* __restrict__ coordsc, int pass) {
+    __shared__ int wcnt[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = Rc * Rc * Rc;
+    int32_t* g = gridc + (long)b * V;
+    int run = pass ? base[b] : 0;
+    for (int v0 = 0; v0 < V; v0 += 1024) {
+        const int v = v0 + tid;
+        const bool occ = v < V && g[v] != VX_EMPTY;
+        const unsigned long long m = __ballot(occ);
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = wcnt[w];
+            before += (w < wave) ? c : 0;
+            total += c;
+        }
+        if (pass && occ) {
+            const int row = run + before + __popcll(m & ((1ull << lane) - 1ull));
+            g[v] = row;
+            coordsc[(long)row * 4] = b; coordsc[(long)row * 4 + 1] = v / (Rc * Rc);
+            coordsc[(long)row * 4 + 2] = (v / Rc) % Rc; coordsc[(long)row * 4 + 3] = v % Rc;
+        }
+        run += total;
+        __syncthreads();
+    }
+    if (!pass && tid == 0) counts[b] = run;
+}
+// child table of the coarse rows (8 slots, slot = (x&1)*4 + (y&1)*2 + (z&1), canonical fine rows only) and parent / slot
+// of the fine rows
+__global__ __launch_bounds__(256) void vx_child_kernel(const int32_t* __restrict__ coordsc, long rowsc, const int32_t* __restrict__ gridf,
+                                                        int Rf, int32_t* __restrict__ child) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < rowsc * 8; e += (long)gridDim.x * 256) {
+        const long r = e >> 3;
+        const int s = (int)(e & 7);
+        const int b = coordsc[r * 4], X = 2 * coordsc[r * 4 + 1] + (s >> 2), Y = 2 * coordsc[r * 4 + 2] + ((s >> 1) & 1),
+                  Z = 2 * coordsc[r * 4 + 3] + (s & 1);
+        int v = -1;
+        if (X < Rf && Y < Rf && Z < Rf) {
+            const int g = gridf[(long)b * Rf * Rf * Rf + ((long)X * Rf + Y) * Rf + Z];
+            v = g == VX_EMPTY ? -1 : g;
+        }
+        child[e] = v;
+    }
+}
+__global__ __launch_bounds__(256) void vx_parent_kernel(const int32_t* __restrict__ coordsf, long rowsf, const int32_t* __restrict__ gridc,
+                                                         int Rc, const int32_t* __restrict__ gridf, int Rf,
+                                                         int32_t* __restrict__ parent, int32_t* __restrict__ parent_canon,
+                                                         int32_t* __restrict__ slot) {
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rowsf; r += (long)gridDim.x * 256) {
+        const int b = coordsf[r * 4], x = coordsf[r * 4 + 1], y = coordsf[r * 4 + 2], z = coordsf[r * 4 + 3];
+        const int p = gridc[(long)b * Rc * Rc * Rc + ((long)(x >> 1) * Rc + (y >> 1)) * Rc + (z >> 1)];
+        parent[r] = p;                                    // every row (a duplicate coordinate still reads its parent's features)
+        // ... but only the canonical row of a coordinate is a child of that parent (it alone receives gradient from it)
+        parent_canon[r] = gridf[(long)b * Rf * Rf * Rf + ((long)x * Rf + y) * Rf + z] == (int)r ? p : -1;
+        slot[r] = (x & 1) * 4 + (y & 1) * 2 + (z & 1);
+    }
+}
+
+// dst[r][j*C + c] = idx[r][j] >= 0 ? src[idx[r][j]][c] : 0        (C % 4 == 0: one float4 per thread)
+__global__ __launch_bounds__(256) void rows_gather_kernel(const float* __restrict__ src, long lds, const int32_t* __restrict__ idx,
+                                                           long rows, int J, int C, float* __restrict__ dst, long ldd) {
+    const int c4 = C >> 2;
+    const long total = rows * J * c4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long rj = e / c4;
+        const int q = (int)(e - rj * c4);
+        const long r = rj / J;
+        const int j = (int)(rj - r * J);
+        const int i = idx[rj];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i >= 0) v = *(const float4*)(src + (long)i * lds + 4 * q);
+        *(float4*)(dst + r * ldd + (long)j * C + 4 * q) = v;
+    }
+}
+// dsrc[r][c] (= or +=) (sum_j tidx[r][j] >= 0 ? dcols[tidx[r][j]][slot(r,j)*C + c] : 0) * (y ? 1 - y[r][c]^2 : 1)
+// slot(r, j) = tslot ? tslot[r*J + j] : (mirror ? J - 1 - j ... see host) -- the host passes explicit conventions:
+//   mode 0: block = j (table already arranged per block), mode 1: block = tslot[r*J + j], mode 2: block = 0 (plain rows)
+__global__ __launch_bounds__(256) void rows_gather_bwd_kernel(const float* __restrict__ dcols, long ldc, const int32_t* __restrict__ tidx,
+                                                               const int32_t* __restrict__ tslot, int mode, int reverse, int self_col,
+                                                               long rows, int J, int C, const float* __restrict__ y, long ldy,
+                                                               int accumulate, float* __restrict__ dsrc, long lds) {
+    const int c4 = C >> 2;
+    const long total = rows * c4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / c4;
+        const int q = (int)(e - r * c4);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        // self_col >= 0: the row only has consumers if the table's own-cell entry points back at it (a duplicate coordinate
+        // is never anybody's neighbour: its gradient is zero, not its canonical twin's)
+        const bool live = self_col < 0 || tidx[r * J + self_col] == (int)r;
+        for (int j = 0; live && j < J; ++j) {
+            const int i = tidx[r * J + (reverse ? J - 1 - j : j)];
+            if (i >= 0) {
+                const int blk = mode == 0 ? j : (mode == 1 ? tslot[r * J + j] : 0);
+                const float4 v = *(const float4*)(dcols + (long)i * ldc + (long)blk * C + 4 * q);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        if (y) {
+            const float4 h = *(const float4*)(y + r * ldy + 4 * q);
+            s.x *= 1.0f - h.x * h.x; s.y *= 1.0f - h.y * h.y; s.z *= 1.0f - h.z * h.z; s.w *= 1.0f - h.w * h.w;
+        }
+        float4* o = (float4*)(dsrc + r * lds + 4 * q);
+        if (accumulate) {
+            const float4 p = *o;
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        *o = s;
+    }
+}
+
+// level-0 input features: [f, x / R, y / R, z / R] per row (4 columns)
+__global__ __launch_bounds__(256) void vx_features0_kernel(const float* __restrict__ x, long ldx, int P, int C, int R, long rows,
+                                                            const int32_t* __restrict__ coords, float* __restrict__ feat) {
+    const float Rf = (float)R;                        // a true division per coordinate: bit-identical to the restatement's x / R
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        const long b = r / P;
+        const float f = C > 3 ? x[b * ldx + (r - b * P) * C + 3] : 1.0f;
+        *(float4*)(feat + r * 4) = make_float4(f, __fdiv_rn((float)coords[r * 4 + 1], Rf), __fdiv_rn((float)coords[r * 4 + 2], Rf),
+                                               __fdiv_rn((float)coords[r * 4 + 3], Rf));
+    }
+}
+
+#define VX_LAUNCH(kern, n, ...) hipLaunchKernelGGL(kern, dim3(vx_blocks(n)), dim3(256), 0, pm_stream(stream), __VA_ARGS__)
+
+extern "C" int pm_voxel_grid0_f32(const float* x, long ldx, int B, int P, int C, int R, int32_t* grid, int32_t* coords,
+                                  float* feat, void* stream) {
+    PM_REQUIRE(x && grid && coords && B > 0 && P > 0 && C >= 3 && R > 0 && R <= 256 && ldx >= (long)P * C);
+    const long cells = (long)B * R * R * R, rows = (long)B * P;
+    VX_LAUNCH(vx_fill_kernel, cells, grid, cells, VX_EMPTY);
+    VX_LAUNCH(vx_grid0_kernel, rows, x, ldx, P, C, R, rows, grid, coords);
+    if (feat) VX_LAUNCH(vx_features0_kernel, rows, x, ldx, P, C, R, rows, (const int32_t*)coords, feat);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_voxel_nbr27_i32(const int32_t* coords, long rows, const int32_t* grid, int R, int32_t* nbr, void* stream) {
+    PM_REQUIRE(coords && grid && nbr && rows > 0 && R > 0);
+    VX_LAUNCH(vx_nbr27_kernel, rows * 27, coords, rows, grid, R, nbr);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_voxel_down_count_i32(const int32_t* coords_f, long rows_f, int B, int Rc, int32_t* grid_c, int32_t* counts,
+                                       void* stream) {
+    PM_REQUIRE(coords_f && grid_c && counts && rows_f > 0 && B > 0 && Rc > 0);
+    const long cells = (long)B * Rc * Rc * Rc;
+    VX_LAUNCH(vx_fill_kernel, cells, grid_c, cells, VX_EMPTY);
+    VX_LAUNCH(vx_mark_kernel, rows_f, coords_f, rows_f, Rc, grid_c);
+    hipLaunchKernelGGL(vx_number_kernel, dim3(B), dim3(1024), 0, pm_stream(stream), grid_c, Rc, (const int32_t*)nullptr, counts,
+                       (int32_t*)nullptr, 0);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_voxel_down_build_i32(const int32_t* coords_f, long rows_f, const int32_t* grid_f, int Rf, int B, int Rc,
+                                       const int32_t* base, int32_t* grid_c, long rows_c, int32_t* coords_c, int32_t* child,
+                                       int32_t* parent, int32_t* parent_canon, int32_t* slot, void* stream) {
+    PM_REQUIRE(coords_f && grid_f && base && grid_c && coords_c && child && parent && parent_canon && slot && rows_f > 0 &&
+               rows_c > 0 && B > 0);
+    hipLaunchKernelGGL(vx_number_kernel, dim3(B), dim3(1024), 0, pm_stream(stream), grid_c, Rc, base, (int32_t*)nullptr, coords_c, 1);
+    VX_LAUNCH(vx_child_kernel, rows_c * 8, (const int32_t*)coords_c, rows_c, grid_f, Rf, child);
+    VX_LAUNCH(vx_parent_kernel, rows_f, coords_f, rows_f, (const int32_t*)grid_c, Rc, grid_f, Rf, parent, parent_canon, slot);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_rows_gather_f32(const float* src, long lds, const int32_t* idx, long rows, int J, int C, float* dst, long ldd,
+                                  void* stream) {
+    PM_REQUIRE(src && idx && dst && rows > 0 && J > 0 && C > 0 && C % 4 == 0 && lds >= C && ldd >= (long)J * C);
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) != 0 || lds % 4 != 0 || ldd % 4 != 0) return PM_EALIGN;
+    VX_LAUNCH(rows_gather_kernel, rows * J * (C / 4), src, lds, idx, rows, J, C, dst, ldd);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_rows_gather_bwd_f32(const float* dcols, long ldc, const int32_t* tidx, const int32_t* tslot, int mode, int reverse,
+                                      int self_col, long rows, int J, int C, const float* y_tanh, long ldy, int accumulate,
+                                      float* dsrc, long lds, void* stream) {
+    PM_REQUIRE(dcols && tidx && dsrc && rows > 0 && J > 0 && C > 0 && C % 4 == 0 && mode >= 0 && mode <= 2 && (mode != 1 || tslot) &&
+               self_col < J);
+    if ((((uintptr_t)dcols | (uintptr_t)dsrc | (uintptr_t)y_tanh) & 15) != 0 || ldc % 4 != 0 || lds % 4 != 0 || (y_tanh && ldy % 4 != 0))
+        return PM_EALIGN;
+    VX_LAUNCH(rows_gather_bwd_kernel, rows * (C / 4), dcols, ldc, tidx, tslot, mode, reverse, self_col, rows, J, C, y_tanh, ldy,
+              accumulate, dsrc, lds);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}

@@ -33,6 +33,8 @@ class FeederEnv:
         for mode, dim in self.num_obs.items():
             if dim == 0:
                 out[mode] = torch.zeros(N, 0, device=self.device)
+            elif mode == 'depth_sparse' and dim >= self.point_num * 4:
+                out[mode] = self._sparse_voxels(dim)
             elif dim >= self.point_num * 3 and (dim % self.point_num) < 64 and mode != 'normal_state':
                 c, tail = dim // self.point_num, dim % self.point_num
                 pts = torch.rand(N, self.point_num, c, device=self.device, generator=self.gen) * 2 - 1
@@ -44,6 +46,26 @@ class FeederEnv:
             else:
                 out[mode] = torch.randn(N, dim, device=self.device, generator=self.gen)
         return out
+
+    def _sparse_voxels(self, dim, grid=50):
+        """The 'depth_sparse' observation (tasks/hand_base.py:335-336; utils/depth2tsdf.py:88-120): `point_num` rows
+        (x, y, z, tsdf) with integer voxel coordinates -- here the cells of a two-voxel-thick band around a random tilted
+        plane through the grid (distinct cells, like a surface seen by the depth cameras), tsdf in (-0.2, 0.2)."""
+        N, P, g = self.num_envs, self.point_num, self.gen
+        layers = max(2, -(-P // (grid * grid)) + 1)
+        score = torch.rand(N, grid * grid * layers, device=self.device, generator=g)
+        pick = score.topk(P, dim=1).indices                              # P distinct (column, layer) pairs per env
+        col, lay = pick % (grid * grid), pick // (grid * grid)
+        xs, ys = col // grid, col % grid
+        ab = torch.rand(N, 3, device=self.device, generator=g)
+        z = (0.5 * ab[:, :1] * xs + 0.5 * ab[:, 1:2] * ys + ab[:, 2:3] * (grid / 4)).floor().long() + lay
+        z = z.clamp_(0, grid - 1)
+        f = torch.rand(N, P, device=self.device, generator=g) * 0.4 - 0.2
+        rows = torch.stack([xs.float(), ys.float(), z.float(), f], dim=-1).reshape(N, P * 4)
+        tail = dim - P * 4
+        if tail:
+            rows = torch.cat([rows, torch.randn(N, tail, device=self.device, generator=g)], dim=1)
+        return rows.contiguous()
 
     def reset(self):
         self.progress_buf.zero_()

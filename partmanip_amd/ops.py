@@ -502,6 +502,72 @@ def sa_bwd(xyz, centers, idx, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpoo
                                 _ptr(h2_saved), _ptr(w), w.numel(), _stream()), "pm_sa_bwd_f32")
 
 
+# ----------------------------------------------------------------------------- sparse-voxel U-Net blocks
+def voxel_grid0(x, P, C, R):
+    """x (B, >= P*C) rows of P points (x, y, z, f...) -> (grid (B*R^3) i32, coords (B*P, 4) i32, feat (B*P, 4) f32)."""
+    _req(x)
+    B = x.shape[0]
+    grid = torch.empty(B * R ** 3, dtype=torch.int32, device=x.device)
+    coords = torch.empty(B * P, 4, dtype=torch.int32, device=x.device)
+    feat = torch.empty(B * P, 4, dtype=torch.float32, device=x.device)
+    check(lib.pm_voxel_grid0_f32(_ptr(x), _rows(x, "x"), B, P, C, R, _ptr(grid), _ptr(coords), _ptr(feat), _stream()),
+          "pm_voxel_grid0_f32")
+    return grid, coords, feat
+
+
+def voxel_nbr27(coords, grid, R):
+    _req(coords, grid)
+    rows = coords.shape[0]
+    nbr = torch.empty(rows, 27, dtype=torch.int32, device=coords.device)
+    check(lib.pm_voxel_nbr27_i32(_ptr(coords), rows, _ptr(grid), R, _ptr(nbr), _stream()), "pm_voxel_nbr27_i32")
+    return nbr
+
+
+def voxel_down(coords_f, grid_f, Rf, B):
+    """The 2x strided level of a fine level: dict(R, rows, grid, coords, child (rows, 8), parent / parent_canon / slot (rows_f)).
+    One host read (the level's row count sizes its buffers and GEMMs)."""
+    _req(coords_f, grid_f)
+    dev = coords_f.device
+    Rc = (Rf + 1) // 2
+    rows_f = coords_f.shape[0]
+    grid_c = torch.empty(B * Rc ** 3, dtype=torch.int32, device=dev)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    check(lib.pm_voxel_down_count_i32(_ptr(coords_f), rows_f, B, Rc, _ptr(grid_c), _ptr(counts), _stream()),
+          "pm_voxel_down_count_i32")
+    ends = torch.cumsum(counts, 0, dtype=torch.int32)                   # index bookkeeping (B integers)
+    base = (ends - counts).contiguous()
+    rows_c = int(ends[-1].item())
+    coords_c = torch.empty(rows_c, 4, dtype=torch.int32, device=dev)
+    child = torch.empty(rows_c, 8, dtype=torch.int32, device=dev)
+    parent = torch.empty(rows_f, dtype=torch.int32, device=dev)
+    parent_canon = torch.empty(rows_f, dtype=torch.int32, device=dev)
+    slot = torch.empty(rows_f, dtype=torch.int32, device=dev)
+    check(lib.pm_voxel_down_build_i32(_ptr(coords_f), rows_f, _ptr(grid_f), Rf, B, Rc, _ptr(base), _ptr(grid_c), rows_c,
+                                      _ptr(coords_c), _ptr(child), _ptr(parent), _ptr(parent_canon), _ptr(slot), _stream()),
+          "pm_voxel_down_build_i32")
+    return dict(R=Rc, rows=rows_c, grid=grid_c, coords=coords_c, child=child, parent=parent, parent_canon=parent_canon, slot=slot)
+
+
+def rows_gather(src, idx, C, dst):
+    """dst[r][j*C:(j+1)*C] = src[idx[r][j]][:C] (zeros where idx < 0); src / dst are 2-D views with unit inner stride."""
+    _req(src, idx, dst)
+    rows = idx.shape[0]
+    J = idx.shape[1] if idx.dim() == 2 else 1
+    check(lib.pm_rows_gather_f32(_ptr(src), _rows(src, "src"), _ptr(idx), rows, J, C, _ptr(dst), _rows(dst, "dst"), _stream()),
+          "pm_rows_gather_f32")
+    return dst
+
+
+def rows_gather_bwd(dcols, tidx, C, dsrc, tslot=None, mode=0, reverse=False, self_col=-1, y_tanh=None, accumulate=False):
+    _req(dcols, tidx, dsrc, tslot, y_tanh)
+    rows = tidx.shape[0]
+    J = tidx.shape[1] if tidx.dim() == 2 else 1
+    check(lib.pm_rows_gather_bwd_f32(_ptr(dcols), _rows(dcols, "dcols"), _ptr(tidx), _ptr(tslot), int(mode), int(reverse),
+                                     int(self_col), rows, J, C, _ptr(y_tanh), _rows(y_tanh, "y") if y_tanh is not None else 0,
+                                     int(accumulate), _ptr(dsrc), _rows(dsrc, "dsrc"), _stream()), "pm_rows_gather_bwd_f32")
+    return dsrc
+
+
 # ----------------------------------------------------------------------------- depth -> cloud
 def depth_backproject(depth, cam_pose, fx, fy, cx, cy, lo, hi):
     """depth (B,M,H,W), cam_pose (M,4,4) device -> world cloud (B, M*H*W, 3), out-of-box points zeroed."""

@@ -8,7 +8,7 @@ cfg/algos/dagger_tsdf.yaml:1-38).
 import copy
 import numpy as np
 
-from .detgen import det_uniform, det_normal, det_bernoulli, linear_init
+from .detgen import det_uniform, det_normal, det_bernoulli, det_u01, linear_init
 
 TRICKS_DEFAULT = dict(mini_adv_norm=False, whole_adv_norm=False, use_state_norm=False,
                       use_clipped_value_loss=False, use_grad_clip=True, max_grad_norm=0.5)
@@ -102,7 +102,36 @@ def net_param_shapes(net, in_dim, out_dim, proprio=0):
         feat = 512 * (2 if net["max_mean"] else 1) + proprio
         return [("mlp.0", (128, c)), ("mlp.2", (256, 128)), ("mlp.4", (512, 256)),
                 ("final_mlp.0", (128, feat)), ("final_mlp.2", (32, 128)), ("final_mlp.4", (out_dim, 32))]
+    if net["name"] == "SparseUNet":
+        c0, c1, c2 = net.get("channels", [32, 64, 128])
+        return [("conv0", (c0, 27 * 4)), ("down0", (c1, 8 * c0)), ("conv1", (c1, 27 * c1)), ("down1", (c2, 8 * c1)),
+                ("conv2", (c2, 27 * c2)), ("up1", (c1, c2 + c1)), ("up0", (c0, c1 + c0)),
+                ("final_mlp.0", (128, c0 + proprio)), ("final_mlp.2", (32, 128)), ("final_mlp.4", (out_dim, 32))]
     raise KeyError(net["name"])
+
+
+def sparse_clouds(B, P, R, seed, n_distinct=None, pad_tail=0):
+    """'depth_sparse'-style rows (x, y, z, f): integer voxel coordinates as floats + a feature in (-0.2, 0.2) per VOXEL; the
+    last `pad_tail` rows of every cloud repeat voxel (0, 0, 0) the way `TSDFVolume.sparse_voxel` pads short clouds
+    (utils/depth2tsdf.py:116-119); n_distinct < P makes further rows repeat earlier voxels."""
+    out = np.zeros((B, P, 4), dtype=np.float32)
+    n = min(n_distinct or P, P)
+    assert n < R * R
+    for b in range(B):
+        s = seed * 1000 + b * 10
+        order = np.argsort(det_u01((R * R,), s), kind="stable")
+        order = order[order != 0][:n]                                        # n distinct (x, y) columns; (0, 0) is the padding voxel's
+        xs, ys = order // R, order % R
+        zs = np.clip((0.4 * xs + 0.3 * ys + 3.0 * det_u01((n,), s + 1)).astype(np.int64), 0, R - 1)   # a noisy tilted surface
+        vox = np.stack([xs, ys, zs], 1).astype(np.float32)
+        fv = det_uniform((n,), s + 2, -0.2, 0.2)
+        idx = np.concatenate([np.arange(n), (det_u01((P - n,), s + 3) * n).astype(np.int64) % n]) if n < P else np.arange(P)
+        out[b, :, :3] = vox[idx]
+        out[b, :, 3] = fv[idx]
+        if pad_tail:
+            out[b, P - pad_tail:, :3] = 0.0
+            out[b, P - pad_tail:, 3] = 0.125
+    return out.reshape(B, P * 4)
 
 
 def actor_critic_state(net, in_dim, A, action_std, seed, proprio=0):
