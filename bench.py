@@ -126,7 +126,7 @@ def cpu_baseline_dagger(d, net, ring_obs, ring_tea, stu_sd, tea_sd, tea_net, row
         R.dagger_update(stu, tea_sd, ring_obs[: mb_ * n_], ring_tea[: mb_ * n_], mb_ * n_, c, 1)
         return time.perf_counter() - t0
 
-    used, tried = _pick_threads(lambda: run(min(16, mb), 1), ncpu)
+    used, tried = _pick_threads(lambda: run(16, 1), ncpu)                 # (dagger.update is a no-op below 16 rows, dagger.py:300)
     t = run(mb, 3)
     per_row = t / (3 * mb)
     t_upd = per_row * rows_total

@@ -539,7 +539,7 @@ class SparseUNet(_HipNet):
     unmounted branch (README.md:23); BASELINE.json's north_star / config 5 ask for it, so this follows the published sparse
     U-Net structure (submanifold 3^3 convolutions, 2x strided levels, skip connections) with the reference's conventions
     (no BatchNorm, `net_cfg['activation']` = tanh, the PointNet head 128-32-out, proprio appended before the head) --
-    PARITY UNPINNED, restated in oracle/ref_cpu.py::sparse_unet_forward.
+    PARITY UNPINNED; the test-side CPU restatement (`sparse_unet_forward`) is pinned to torch's dense conv3d U-Net on full grids.
 
     Input: the reference's 'depth_sparse' observation (tasks/hand_base.py:335-336, utils/depth2tsdf.py:88-120): `point_num`
     rows (x, y, z, f) per env with integer voxel coordinates in [0, grid), flattened (+ proprio tail).  Levels (channels

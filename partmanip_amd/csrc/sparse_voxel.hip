@@ -1,6 +1,6 @@
 // Sparse-voxel U-Net building blocks (`network.name: SparseUNet`, the "3D Sparse-UNet" backbone the reference's README
-// names -- README.md:30 -- whose code is NOT in the snapshot, README.md:23: parity unpinned, own restatement in
-// oracle/ref_cpu.py).  The observation is the reference's 'depth_sparse' format (tasks/hand_base.py:335-336,
+// names -- README.md:30 -- whose code is NOT in the snapshot, README.md:23: parity unpinned, checked against the test-side CPU
+// restatement).  The observation is the reference's 'depth_sparse' format (tasks/hand_base.py:335-336,
 // utils/depth2tsdf.py:88-120): P rows (x, y, z, f) per env with integer voxel coordinates in [0, R).
 //
 // MI355X-shaped design: geometry and arithmetic are separated.
