@@ -697,6 +697,66 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
 #ifndef PN_BWD16
 #define PN_BWD16 1
 #endif
+// ---- per-cloud arg-max bookkeeping of pn_bwd16_kernel, hoisted into its own launch ---------------------------------------
+// Inside the 16-wave kernel the 512-key bitonic sort is 45 barrier-separated stages in which 256 of 1024 threads work
+// while the matrix pipe idles (0.2 ms of a 2.95 ms launch, tools/time_enc.py ablation).  It depends on the forward's
+// arg-max only, so one small work-group per cloud does it up front -- 2048 of them fill the chip -- and the backward kernel
+// just loads the results: keys (slot<<22 | point<<9 | channel, ascending), the first key of every 2-point row block
+// (`offs`), and slotmap[b][c] = index of channel c's arg-max point among the cloud's distinct arg-max points.
+__global__ __launch_bounds__(256) void pn_bwd_prep_kernel(const int32_t* __restrict__ argmax, int P, int32_t* __restrict__ keys_g,
+                                                           unsigned short* __restrict__ offs_g, int32_t* __restrict__ slotmap) {
+    __shared__ int keys[PN_C3];
+    __shared__ int wtot[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
+    keys[tid] = (argmax[(long)b * PN_C3 + tid] << 9) | tid;
+    keys[tid + 256] = (argmax[(long)b * PN_C3 + tid + 256] << 9) | (tid + 256);
+#pragma unroll 1
+    for (int k = 2; k <= 512; k <<= 1) {
+#pragma unroll 1
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
+            const int ixj = i | j;
+            const int a = keys[i], c = keys[ixj];
+            if ((a > c) == ((i & k) == 0)) {
+                keys[i] = c;
+                keys[ixj] = a;
+            }
+        }
+    }
+    __syncthreads();
+    const int nblk = P / 2;                                      // row blocks of 2 points (RPW of the 16-wave kernel)
+    for (int p = tid; p <= nblk; p += 256) {                     // offs[i] = #keys with point < 2 i
+        int lo = 0, hi = PN_C3;
+        const int target = (p * 2) << 9;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        offs_g[(long)b * (nblk + 1) + p] = (unsigned short)lo;
+    }
+    // slot[e] = number of distinct arg-max points before sorted entry e
+    const int e0 = 2 * tid, e1 = e0 + 1;
+    const int q0 = keys[e0] >> 9, q1 = keys[e1] >> 9, qm = (e0 > 0) ? (keys[e0 - 1] >> 9) : -1;
+    const int f1 = (q1 != q0);
+    int v = (q0 != qm) + f1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane0 >= o) v += t;
+    }
+    if (lane0 == 63) wtot[wave] = v;
+    __syncthreads();
+    int base = 0;
+    for (int w2 = 0; w2 < wave; ++w2) base += wtot[w2];
+    const int s1 = base + v - 1, s0 = s1 - f1;
+    const int k0 = keys[e0] | (s0 << 22), k1 = keys[e1] | (s1 << 22);
+    keys_g[(long)b * PN_C3 + e0] = k0;
+    keys_g[(long)b * PN_C3 + e1] = k1;
+    slotmap[(long)b * PN_C3 + (k0 & 511)] = s0;
+    slotmap[(long)b * PN_C3 + (k1 & 511)] = s1;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 template <int CT>
@@ -704,8 +764,8 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
     const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
     const float* __restrict__ b1, const float* __restrict__ W3, const float* __restrict__ packed, int max_mean,
     const float* __restrict__ dfeat, long ldf, const int32_t* __restrict__ argmax, const float* __restrict__ U,
-    float* __restrict__ H2sum, float* __restrict__ Hg, int32_t* __restrict__ slotmap, PnBwdPart* __restrict__ parts,
-    const float* __restrict__ h2_saved) {
+    float* __restrict__ H2sum, float* __restrict__ Hg, const int32_t* __restrict__ keys_g,
+    const unsigned short* __restrict__ offs_g, PnBwdPart* __restrict__ parts, const float* __restrict__ h2_saved) {
     constexpr int BT = 32, NT = 1024, NW = 16, RPW = BT / NW, PPT = BT * PN_C1 / NT;
     constexpr int NXC = (CT == 3 || CT == 4) ? 4 : PN_MAXC;      // point coordinates that can be non-zero
     constexpr int XSZ = BT * PN_MAXC, H1SZ = BT * PN_LD1, H2SZ = BT * PN_LD2;
@@ -744,66 +804,14 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
         float cen[3] = {0.f, 0.f, 0.f};
         __syncthreads();
         if (sub_mean) cloud_centroid<NT>(xb, P, C, red, cen);
-        // ---- per-cloud setup: u/P, dmax, CSR of argmax by point (see pn_bwd_kernel) -------------------------
+        // ---- per-cloud setup: u/P, dmax; the sorted arg-max keys and their row-block offsets come from pn_bwd_prep_kernel --
         if (tid < PN_C2) Us[tid] = max_mean ? U[(long)b * PN_C2 + tid] * invP : 0.f;
         if (tid < PN_C3) {
             Gm[tid] = dfeat[(long)b * ldf + tid];
-            keys[tid] = (argmax[(long)b * PN_C3 + tid] << 9) | tid;
+            keys[tid] = keys_g[(long)b * PN_C3 + tid];
         }
-#pragma unroll 1
-        for (int k = 2; k <= ((PN_ABLATE & 16) ? 0 : 512); k <<= 1) {   // bitonic sort of the 512 keys by threads 0-255
-#pragma unroll 1
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                __syncthreads();
-                if (tid < 256) {
-                    const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
-                    const int ixj = i | j;
-                    const int a = keys[i], c = keys[ixj];
-                    if ((a > c) == ((i & k) == 0)) {
-                        keys[i] = c;
-                        keys[ixj] = a;
-                    }
-                }
-            }
-        }
+        for (int p = tid; p <= P / RPW; p += NT) offs[p] = offs_g[(long)b * (P / RPW + 1) + p];
         __syncthreads();
-        for (int p = tid; p <= P / RPW; p += NT) {       // offs[i] = #keys with point < i * RPW
-            int lo = 0, hi = PN_C3;
-            const int target = (p * RPW) << 9;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (keys[mid] < target) lo = mid + 1; else hi = mid;
-            }
-            offs[p] = (unsigned short)lo;
-        }
-        {   // slot[e] = number of distinct arg-max points before sorted entry e; each distinct point's h2 row is
-            // stored once (Hg[b, slot, :]) and found through slotmap[b, c]
-            int* wtot = (int*)red;
-            int v = 0, f1 = 0;
-            const int e0 = 2 * tid, e1 = e0 + 1;
-            if (tid < 256) {
-                const int q0 = keys[e0] >> 9, q1 = keys[e1] >> 9, qm = (e0 > 0) ? (keys[e0 - 1] >> 9) : -1;
-                f1 = (q1 != q0);
-                v = (q0 != qm) + f1;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int t = __shfl_up(v, o, 64);
-                    if (lane0 >= o) v += t;
-                }
-            }
-            __syncthreads();                                   // every neighbour key has been read
-            if (tid < 256 && lane0 == 63) wtot[wave] = v;
-            __syncthreads();
-            if (tid < 256) {
-                int base = 0;
-                for (int w2 = 0; w2 < wave; ++w2) base += wtot[w2];
-                const int s1 = base + v - 1, s0 = s1 - f1;
-                keys[e0] |= s0 << 22;
-                keys[e1] |= s1 << 22;
-                slotmap[(long)b * PN_C3 + (keys[e0] & 511)] = s0;
-                slotmap[(long)b * PN_C3 + (keys[e1] & 511)] = s1;
-            }
-        }
         float4 h2s = make_float4(0.f, 0.f, 0.f, 0.f);    // sum_p h2[p][4*lane..] over this wave's rows
 
         // ---- VALU stage of tile tt, in two parts.  valu_issue: everything that waits on HBM / L2 is REQUESTED (this
@@ -1159,7 +1167,7 @@ static int pn_cu_count() {
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct PnBwdWs {
-    size_t off_U, off_H2sum, off_Hg, off_slot, off_parts, off_dw3, off_gemm, total;
+    size_t off_U, off_H2sum, off_Hg, off_slot, off_parts, off_dw3, off_gemm, off_keys, off_offs, total;
 };
 static PnBwdWs pn_bwd_layout(int B) {
     PnBwdWs w;
@@ -1171,6 +1179,8 @@ static PnBwdWs pn_bwd_layout(int B) {
     w.off_parts = o;  o += align256((size_t)(pn_bwd_grid(B) + PN_RED_SPLIT) * sizeof(PnBwdPart));
     w.off_dw3 = o;    o += align256((size_t)PN_DW3_SPLIT * PN_C3 * PN_C2 * 4);
     w.off_gemm = o;   o += align256(pm_linear_bwd_weight_workspace_bytes(B, PN_C3, PN_C2));
+    w.off_keys = o;   o += align256((size_t)B * PN_C3 * 4);               // pn_bwd_prep_kernel: sorted arg-max keys
+    w.off_offs = o;   o += align256((size_t)B * (4096 / 2 + 1) * 2);      // ... and their row-block offsets (P <= 4096)
     w.total = o;
     return w;
 }
@@ -1210,9 +1220,13 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
     if (PN_BWD16 && h2_saved) {                   // saved layer 2: one 16-wave work-group per CU
         const int ncu = pn_cu_count();
         G = B < ncu ? B : ncu;
+        int32_t* keys_g = (int32_t*)(ws + w.off_keys);
+        unsigned short* offs_g = (unsigned short*)(ws + w.off_offs);
+        hipLaunchKernelGGL(pn_bwd_prep_kernel, dim3(B), dim3(256), 0, pm_stream(stream), argmax, P, keys_g, offs_g, slotmap);
 #define PN_BWD16_LAUNCH(CT)                                                                                            \
     hipLaunchKernelGGL((pn_bwd16_kernel<CT>), dim3(G), dim3(1024), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, \
-                       W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, slotmap, parts, h2_saved)
+                       W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, (const int32_t*)keys_g,                    \
+                       (const unsigned short*)offs_g, parts, h2_saved)
         if (C == 3) PN_BWD16_LAUNCH(3);
         else if (C == 4) PN_BWD16_LAUNCH(4);
         else PN_BWD16_LAUNCH(0);

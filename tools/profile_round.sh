@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round profile set (run ON the GPU box from the repo root, inside ONE gpurun call):  tools/profile_round.sh <tag>
+# rocprofv3 --kernel-trace --stats summaries of the bench workloads (+ per-grid tables) and the PMC passes of the encoder
+# kernels; everything lands under gpurun_out/<tag>/ -- copy what should be judged into profiles/.
+tag=${1:-round}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/$tag
+mkdir -p $out
+prof() {   # name, bench args...
+  name=$1; shift
+  timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name -o p -- python bench.py "$@" > $out/$name.json 2> $out/$name.err < /dev/null
+  python tools/trace_summary.py $out/$name/p_kernel_trace.csv $out/${name}_kernel_by_grid.csv 40 < /dev/null
+  cp $out/$name/p_kernel_stats.csv $out/${name}_kernel_stats.csv
+  rm -rf $out/$name
+}
+prof bench_default --no-optional --steps 2 --warmup 1
+prof bench_state --workload state --steps 2 --warmup 1 --no-cpu-baseline
+prof bench_dagger_sparse_unet --workload dagger --student sparse_unet --steps 1 --warmup 1 --no-cpu-baseline
+# un-profiled bench lines (the numbers to quote: a profiled run clocks lower)
+timeout 400 python bench.py > $out/line_default.json 2> $out/line_default.err < /dev/null
+timeout 300 python bench.py --workload state > $out/line_state.json 2>> $out/line_default.err < /dev/null
+timeout 400 python bench.py --workload vision_pn2 > $out/line_vision_pn2.json 2>> $out/line_default.err < /dev/null
+timeout 400 python bench.py --workload dagger > $out/line_dagger_pointnet.json 2>> $out/line_default.err < /dev/null
+timeout 300 python bench.py --workload dagger --student conv3d > $out/line_dagger_conv3d.json 2>> $out/line_default.err < /dev/null
+timeout 300 python bench.py --workload depth2pc > $out/line_depth2pc.json 2>> $out/line_default.err < /dev/null
+# PMC passes (separate runs, counters only) on the short encoder-only command
+PMC_PASS_TIMEOUT=150 bash tools/pmc_run.sh $out/pmc_enc python tools/time_enc.py < /dev/null
+ls $out
