@@ -531,3 +531,29 @@ def test_grouped_clip_adam_equals_two_single_steps():
     for a, b in zip(ref, items2):
         assert torch.equal(a["g"], b["g"]) and torch.equal(a["p"], b["p"]) and torch.equal(a["m"], b["m"])
         assert torch.equal(a["v"], b["v"]) and int(b["state"][0]) == 1 and torch.equal(a["gnorm"], b["gnorm"])
+
+
+@pytest.mark.parametrize("M,K,N,act", [(2048, 512, 10, 0), (2048, 512, 1, 0), (2048, 32, 10, 1), (300, 128, 16, 1), (4096, 1028, 7, 0)])
+def test_skinny_linear_layers(M, K, N, act):
+    """Layers with <= 16 outputs (policy / value heads) run as row-wise VALU kernels instead of 64-wide GEMM tiles: forward,
+    data gradient (with the activation derivative of the layer input) and weight / bias gradient against fp64."""
+    from partmanip_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    x = torch.tanh(torch.randn(M, K, device=DEV, generator=g))
+    w = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    y = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(x, w, b, y, ops.ACT_TANH if act else ops.ACT_NONE)
+    ref = x.double() @ w.double().t() + b.double()
+    ref = torch.tanh(ref) if act else ref
+    assert float((y.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    dy = torch.randn(M, N, device=DEV, generator=g)
+    dx = torch.empty(M, K, device=DEV)
+    ops.linear_bwd_data(dy, w, x, dx, ops.ACT_TANH)
+    rdx = (dy.double() @ w.double()) * (1 - x.double() ** 2)
+    assert float((dx.double() - rdx).abs().max()) < 2e-5 * max(1.0, float(rdx.abs().max()))
+    dw, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+    ops.linear_bwd_weight(dy, x, dw, db, ops.Workspace(DEV))
+    rdw, rdb = dy.double().t() @ x.double(), dy.double().sum(0)
+    assert float((dw.double() - rdw).abs().max()) < 3e-5 * max(1.0, float(rdw.abs().max()))
+    assert float((db.double() - rdb).abs().max()) < 3e-5 * max(1.0, float(rdb.abs().max()))
