@@ -14,16 +14,14 @@
 #define GB_K 64
 
 static inline int aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-#define SK_WGRAD_ROWS 32                 // rows per work-group of the skinny weight-gradient kernel (below)
-static inline size_t skinny_wgrad_ws(int M, int N, int K) {
-    return (size_t)((M + SK_WGRAD_ROWS - 1) / SK_WGRAD_ROWS) * (size_t)(((long)N * K + N + 3) & ~3L) * sizeof(float);
-}
+
 
 // ---- skinny layers (N <= 16 outputs: the policy / value heads, 512 -> 10 and 512 -> 1) ----------------------------------
-// As GEMMs these are a 64-wide tile with 10 (or 1) live columns on 32 work-groups walking a 16-step K loop: 10-17 us per
-// launch in the state-PPO step, where the whole network step should take ~45.  They are row-wise dot products (forward),
-// a rank-N update per row (data gradient) and an N x K reduction over the batch (weight gradient): memory-bound VALU
-// kernels over all CUs.  fp32 FMA chains with a fixed (deterministic) summation order.
+// As GEMMs these are a 64-wide tile with 10 (or 1) live columns on 32 work-groups walking a 16-step K loop: 17 / 8.4 us per
+// forward / data-gradient launch in the state-PPO step, where the whole network step should take ~45.  They are row-wise dot
+// products (forward: 8.3 us) and a rank-N update per row (data gradient: 5.8 us): memory-bound VALU kernels over all CUs,
+// fp32 FMA chains with a fixed (deterministic) summation order.  (The weight gradient, an N x K reduction over the batch,
+// stays on the split-K GEMM: a per-work-group-partials VALU version measured 25 us against its 10 + 5.)
 #define SK_MAXN 16
 #define SK_T 256
 // Y[i][n] = act(sum_k X[i][k] W[n][k] + b[n]); one wave per row, lanes over k (float4 per lane per 256-wide chunk)
@@ -88,51 +86,6 @@ __global__ __launch_bounds__(SK_T) void skinny_dgrad_kernel(const float* __restr
         *(float4*)(dX + i * lddx + k) = s;
     }
 }
-// partial[g][n][k] = sum over work-group g's rows of dY[i][n] X[i][k]; thread = one float4 of k for one row subset
-__global__ __launch_bounds__(SK_T) void skinny_wgrad_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx,
-                                                            int M, int N, int K, int rows_per_wg, float* __restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];                  // [rows_per_wg][N] dY rows, then the subset partials
-    const int r0 = blockIdx.x * rows_per_wg, nr = min(rows_per_wg, M - r0);
-    for (int e = threadIdx.x; e < nr * N; e += SK_T) sm[e] = dY[(long)(r0 + e / N) * lddy + (e % N)];
-    __syncthreads();
-    const int k4 = K >> 2;
-    float* out = part + (long)blockIdx.x * ((N * K + N + 3) & ~3);               // 16-byte aligned partial rows
-    for (int c0 = 0; c0 < k4; c0 += SK_T) {                                     // K > 1024: several passes
-        const int c = c0 + threadIdx.x;
-        if (c < k4) {
-            float4 acc[SK_MAXN];
-#pragma unroll
-            for (int n = 0; n < SK_MAXN; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int r = 0; r < nr; ++r) {
-                const float4 x = *(const float4*)(X + (long)(r0 + r) * ldx + c * 4);
-#pragma unroll
-                for (int n = 0; n < SK_MAXN; ++n)
-                    if (n < N) {
-                        const float g = sm[r * N + n];
-                        acc[n].x = fmaf(g, x.x, acc[n].x); acc[n].y = fmaf(g, x.y, acc[n].y);
-                        acc[n].z = fmaf(g, x.z, acc[n].z); acc[n].w = fmaf(g, x.w, acc[n].w);
-                    }
-            }
-#pragma unroll
-            for (int n = 0; n < SK_MAXN; ++n)
-                if (n < N) *(float4*)(out + n * K + c * 4) = acc[n];
-        }
-    }
-    if (threadIdx.x < N) {                                                      // bias gradient partial
-        float s = 0.f;
-        for (int r = 0; r < nr; ++r) s += sm[r * N + threadIdx.x];
-        out[N * K + threadIdx.x] = s;
-    }
-}
-__global__ __launch_bounds__(256) void skinny_wgrad_reduce_kernel(const float* __restrict__ part, int G, int N, int K,
-                                                                   float* __restrict__ dW, long lddw, float* __restrict__ db) {
-    const int e = blockIdx.x * 256 + threadIdx.x, nk = N * K;
-    if (e >= nk + N) return;
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += part[(long)g * ((nk + N + 3) & ~3) + e];
-    if (e < nk) dW[(long)(e / K) * lddw + (e % K)] = s;
-    else if (db) db[e - nk] = s;
-}
 static inline bool skinny_ok(int N, int K, const void* a, long lda, const void* b, long ldb) {
     return N <= SK_MAXN && K % 4 == 0 && (long)N * K * 4 <= 64 * 1024 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(a) && aligned16(b);
 }
@@ -143,7 +96,7 @@ extern "C" int pm_linear_fwd_f32(const float* X, long ldx, const float* W, long 
     PM_REQUIRE(X && W && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N);
     PM_REQUIRE(act >= PM_ACT_NONE && act <= PM_ACT_MAX);
     if (M >= 256 && skinny_ok(N, K, X, ldx, W, ldw)) {
-        int nb = (M + 3) / 4;
+        int nb = (M + 3) / 4;                                        // one row per wave (8 rows per work-group measured slower)
         if (nb > 1024) nb = 1024;
         hipLaunchKernelGGL(skinny_fwd_kernel, dim3(nb), dim3(SK_T), (size_t)N * K * 4, pm_stream(stream), X, ldx, W, ldw, b, Y, ldy, M,
                            N, K, act);
@@ -209,12 +162,7 @@ static inline int bww_splits(int M, int N, int K) {
 
 extern "C" size_t pm_linear_bwd_weight_workspace_bytes(int M, int N, int K) {
     const int s = bww_splits(M, N, K);
-    size_t b = s > 1 ? (size_t)s * ((size_t)N * K + N) * sizeof(float) : 16;     // dW slabs + db slabs
-    if (N <= 16 && M >= 256 && M <= 65536) {                                     // skinny path: per-work-group partials
-        const size_t sk = skinny_wgrad_ws(M, N, K);
-        if (sk > b) b = sk;
-    }
-    return b;
+    return s > 1 ? (size_t)s * ((size_t)N * K + N) * sizeof(float) : 16;     // dW slabs + db slabs
 }
 
 // dW = sum_z slab_z (fixed order); the trailing N "elements" reduce the bias-gradient slabs.
@@ -240,17 +188,6 @@ extern "C" int pm_linear_bwd_weight_f32(const float* dY, long lddy, const float*
                                         long lddw, float* db, int M, int N, int K, void* workspace,
                                         size_t workspace_bytes, void* stream) {
     PM_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K);
-    if (M >= 256 && M <= 65536 && skinny_ok(N, K, X, ldx, X, ldx) && workspace &&
-        workspace_bytes >= skinny_wgrad_ws(M, N, K) && aligned16(workspace)) {
-        const int G = (M + SK_WGRAD_ROWS - 1) / SK_WGRAD_ROWS;
-        float* part = (float*)workspace;
-        hipLaunchKernelGGL(skinny_wgrad_kernel, dim3(G), dim3(SK_T), (size_t)SK_WGRAD_ROWS * N * 4, pm_stream(stream), dY, lddy, X, ldx,
-                           M, N, K, SK_WGRAD_ROWS, part);
-        hipLaunchKernelGGL(skinny_wgrad_reduce_kernel, dim3((N * K + N + 255) / 256), dim3(256), 0, pm_stream(stream),
-                           (const float*)part, G, N, K, dW, lddw, db);
-        PM_CHECK_LAUNCH();
-        return PM_OK;
-    }
     const int S = bww_splits(M, N, K);
     if (S > 1 && (!workspace || workspace_bytes < pm_linear_bwd_weight_workspace_bytes(M, N, K))) return PM_EWORKSPACE;
     Gemm2Group gg{};

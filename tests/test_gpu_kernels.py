@@ -481,16 +481,16 @@ def test_grouped_linear_ops_equal_the_single_problem_ops():
         ops.linear_fwd(x, w, b, y, ops.ACT_TANH)
     ops.linear_fwd_group([(x, w, b, y, ops.ACT_TANH) for x, w, b, y in zip(xs, wts, bs, y2)][:2])
     ops.linear_fwd_group([(x, w, b, y, ops.ACT_TANH) for x, w, b, y in zip(xs, wts, bs, y2)][2:])
-    for a, b_ in zip(y1, y2):
-        assert torch.equal(a, b_)
+    for (M, K, N), a, b_ in zip(probs, y1, y2):              # <= 16 outputs: the single call runs the skinny VALU kernel
+        assert torch.equal(a, b_) if N > 16 else float((a - b_).abs().max()) < 2e-5
     dys = [r(M, N) for M, K, N in probs]
     dx1 = [torch.empty(M, K, device=DEV) for M, K, N in probs]
     dx2 = [torch.empty(M, K, device=DEV) for M, K, N in probs]
     for dy, w, x, dx in zip(dys, wts, xs, dx1):
         ops.linear_bwd_data(dy, w, x, dx, ops.ACT_TANH)
     ops.linear_bwd_data_group([(dy, w, x, dx, ops.ACT_TANH) for dy, w, x, dx in zip(dys, wts, xs, dx2)])
-    for a, b_ in zip(dx1, dx2):
-        assert torch.equal(a, b_)
+    for (M, K, N), a, b_ in zip(probs, dx1, dx2):
+        assert torch.equal(a, b_) if N > 16 else float((a - b_).abs().max()) < 2e-5 * max(1.0, float(a.abs().max()))
     # weight gradients: 4 slabs per problem, summed in slab order
     S = 4
     for (M, K, N), dy, x in zip(probs, dys, xs):
