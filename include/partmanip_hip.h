@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 123 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 124 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -427,6 +427,16 @@ int pm_voxel_down_build_i32(const int32_t* coords_f, long rows_f, const int32_t*
                             int32_t* parent, int32_t* parent_canon, int32_t* slot, void* stream);
 int pm_rows_gather_f32(const float* src, long lds, const int32_t* idx, long rows, int J, int C, float* dst, long ldd,
                        void* stream);
+/* Fused forms: the gather happens inside the GEMM's LDS-DMA loader, the (rows x J*C) operand never exists in HBM
+ * (J*C % 32 == 0; `zero`: >= C zeros, 16-byte aligned, read for absent neighbours).
+ *   fwd:        Y[r][n] = act(sum_{j,c} src[idx[r][j]][c] * W[n][j*C + c] + b[n])
+ *   bwd_weight: dW[n][j*C + c] = sum_r dY[r][n] * src[idx[r][j]][c],  db[n] = sum_r dY[r][n]   (db may be NULL) */
+int pm_sparse_conv_fwd_f32(const float* src, long lds, const int32_t* idx, long rows, int J, int C, const float* W, long ldw,
+                           const float* b, float* Y, long ldy, int N, int act, const float* zero, void* stream);
+size_t pm_sparse_conv_bwd_weight_workspace_bytes(long rows, int N, int J, int C);
+int pm_sparse_conv_bwd_weight_f32(const float* dY, long lddy, const float* src, long lds, const int32_t* idx, long rows, int J,
+                                  int C, float* dW, long lddw, float* db, int N, const float* zero, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 int pm_rows_gather_bwd_f32(const float* dcols, long ldc, const int32_t* tidx, const int32_t* tslot, int mode, int reverse,
                            int self_col, long rows, int J, int C, const float* y_tanh, long ldy, int accumulate, float* dsrc,
                            long lds, void* stream);

@@ -575,6 +575,7 @@ class SparseUNet(_HipNet):
         object.__setattr__(self, "_act", code)
         object.__setattr__(self, "_head", _LinearChain([self.final_mlp[0], self.final_mlp[2], self.final_mlp[4]], code))
         object.__setattr__(self, "_g", None)
+        self.fused_gather = bool(net_cfg.get('fused_gather', True))          # False: materialise every gathered operand (A/B)
 
     _LAYERS = ("conv0", "down0", "conv1", "down1", "conv2", "up1", "up0")
 
@@ -596,6 +597,32 @@ class SparseUNet(_HipNet):
         ops.linear_fwd(x, lin.weight.data, lin.bias.data, y, self._act)
         return y
 
+    def _conv(self, name, src, idx, C, y):
+        """Sparse convolution `name` of the rows of `src` through the neighbour table `idx` (rows, J): fused -- the gather runs
+        inside the GEMM's LDS-DMA loader and the (rows x J*C) operand never reaches HBM -- when J*C is a multiple of the K-step
+        (every layer but conv0, whose 108-wide operand is small); returns the materialised operand or None."""
+        lin = getattr(self, name)
+        if self.fused_gather and (idx.shape[1] * C) % 32 == 0:
+            ops.sparse_conv_fwd(src, idx, C, lin.weight.data, lin.bias.data, y, self._act, self._zero(src.device))
+            return None
+        cols = ops.rows_gather(src, idx, C, torch.empty(idx.shape[0], idx.shape[1] * C, device=src.device))
+        self._lin(name, cols, y)
+        return cols
+
+    def _conv_wgrad(self, name, dz, src, idx, C, cols, ws):
+        dW, db = self._g[name]
+        if cols is None:
+            ops.sparse_conv_bwd_weight(dz, src, idx, C, dW, db, self._zero(src.device), ws)
+        else:
+            ops.linear_bwd_weight(dz, cols, dW, db, ws)
+
+    def _zero(self, device):
+        z = getattr(self, "_zero_row", None)
+        if z is None or z.device != device:
+            z = torch.zeros(max(self.channels) + 64, device=device)
+            object.__setattr__(self, "_zero_row", z)
+        return z
+
     def forward(self, x):
         with torch.no_grad():
             return self.hip_forward(x)
@@ -615,18 +642,18 @@ class SparseUNet(_HipNet):
         g = self.geometry(x)
         R0, R1, R2 = g["rows"]
         e = lambda r, c: torch.empty(r, c, device=dev)
-        cols0 = ops.rows_gather(g["feat0"], g["nbr0"], 4, e(R0, 27 * 4))
         cat0 = e(R0, c1 + c0)                                   # [unpool(E1) | H0]
-        H0 = self._lin("conv0", cols0, cat0[:, c1:])
-        colsd0 = ops.rows_gather(H0, g["l1"]["child"], c0, e(R1, 8 * c0))
-        D1 = self._lin("down0", colsd0, e(R1, c1))
-        cols1 = ops.rows_gather(D1, g["nbr1"], c1, e(R1, 27 * c1))
+        H0 = cat0[:, c1:]
+        cols0 = self._conv("conv0", g["feat0"], g["nbr0"], 4, H0)
+        D1 = e(R1, c1)
+        colsd0 = self._conv("down0", H0, g["l1"]["child"], c0, D1)
         cat1 = e(R1, c2 + c1)                                   # [unpool(H2) | H1]
-        H1 = self._lin("conv1", cols1, cat1[:, c2:])
-        colsd1 = ops.rows_gather(H1, g["l2"]["child"], c1, e(R2, 8 * c1))
-        D2 = self._lin("down1", colsd1, e(R2, c2))
-        cols2 = ops.rows_gather(D2, g["nbr2"], c2, e(R2, 27 * c2))
-        H2 = self._lin("conv2", cols2, e(R2, c2))
+        H1 = cat1[:, c2:]
+        cols1 = self._conv("conv1", D1, g["nbr1"], c1, H1)
+        D2 = e(R2, c2)
+        colsd1 = self._conv("down1", H1, g["l2"]["child"], c1, D2)
+        H2 = e(R2, c2)
+        cols2 = self._conv("conv2", D2, g["nbr2"], c2, H2)
         ops.rows_gather(H2, g["l2"]["parent"].view(-1, 1), c2, cat1[:, :c2])
         E1 = self._lin("up1", cat1, e(R1, c1))
         ops.rows_gather(E1, g["l1"]["parent"].view(-1, 1), c1, cat0[:, :c1])
@@ -636,7 +663,7 @@ class SparseUNet(_HipNet):
         if self.proprio_shape != 0:
             fbuf[:, c0:].copy_(x[:, -self.proprio_shape:])
         object.__setattr__(self, "_saved", dict(g=g, cols0=cols0, cat0=cat0, colsd0=colsd0, D1=D1, cols1=cols1, cat1=cat1,
-                                                colsd1=colsd1, D2=D2, cols2=cols2, E0=E0, arg=arg, B=B))
+                                                colsd1=colsd1, D2=D2, cols2=cols2, H2=H2, E0=E0, arg=arg, B=B))
         return self._head.forward(fbuf, out)
 
     def _hip_backward(self, dy):
@@ -657,29 +684,29 @@ class SparseUNet(_HipNet):
         dcat1 = torch.empty_like(cat1)
         ops.linear_bwd_data(dzE1, W("up1"), cat1, dcat1, ops.ACT_TANH)
         dzH2 = ops.rows_gather_bwd(dcat1[:, :c2], g["l2"]["child"], c2, torch.empty_like(s["D2"]), mode=2)
-        ops.linear_bwd_weight(dzH2, s["cols2"], *self._g["conv2"], ws)
-        dcols2 = torch.empty_like(s["cols2"])
+        self._conv_wgrad("conv2", dzH2, s["D2"], g["nbr2"], c2, s["cols2"], ws)
+        dcols2 = torch.empty(dzH2.shape[0], 27 * c2, device=dy.device)
         ops.linear_bwd_data(dzH2, W("conv2"), None, dcols2, ops.ACT_NONE)
         dzD2 = ops.rows_gather_bwd(dcols2, g["nbr2"], c2, torch.empty_like(s["D2"]), reverse=True, self_col=13, y_tanh=s["D2"])
         del dcols2
-        ops.linear_bwd_weight(dzD2, s["colsd1"], *self._g["down1"], ws)
-        dcolsd1 = torch.empty_like(s["colsd1"])
+        self._conv_wgrad("down1", dzD2, cat1[:, c2:], g["l2"]["child"], c1, s["colsd1"], ws)
+        dcolsd1 = torch.empty(dzD2.shape[0], 8 * c1, device=dy.device)
         ops.linear_bwd_data(dzD2, W("down1"), None, dcolsd1, ops.ACT_NONE)
         dzH1 = dcat1[:, c2:]                                                                # skip part (already pre-activation)
         ops.rows_gather_bwd(dcolsd1, g["l2"]["parent_canon"].view(-1, 1), c1, dzH1, tslot=g["l2"]["slot"].view(-1, 1), mode=1,
                             y_tanh=cat1[:, c2:], accumulate=True)
-        ops.linear_bwd_weight(dzH1, s["cols1"], *self._g["conv1"], ws)
-        dcols1 = torch.empty_like(s["cols1"])
+        self._conv_wgrad("conv1", dzH1, s["D1"], g["nbr1"], c1, s["cols1"], ws)
+        dcols1 = torch.empty(dzH1.shape[0], 27 * c1, device=dy.device)
         ops.linear_bwd_data(dzH1, W("conv1"), None, dcols1, ops.ACT_NONE)
         dzD1 = ops.rows_gather_bwd(dcols1, g["nbr1"], c1, torch.empty_like(s["D1"]), reverse=True, self_col=13, y_tanh=s["D1"])
         del dcols1
-        ops.linear_bwd_weight(dzD1, s["colsd0"], *self._g["down0"], ws)
-        dcolsd0 = torch.empty_like(s["colsd0"])
+        self._conv_wgrad("down0", dzD1, cat0[:, c1:], g["l1"]["child"], c0, s["colsd0"], ws)
+        dcolsd0 = torch.empty(dzD1.shape[0], 8 * c0, device=dy.device)
         ops.linear_bwd_data(dzD1, W("down0"), None, dcolsd0, ops.ACT_NONE)
         dzH0 = dcat0[:, c1:]
         ops.rows_gather_bwd(dcolsd0, g["l1"]["parent_canon"].view(-1, 1), c0, dzH0, tslot=g["l1"]["slot"].view(-1, 1), mode=1,
                             y_tanh=cat0[:, c1:], accumulate=True)
-        ops.linear_bwd_weight(dzH0, s["cols0"], *self._g["conv0"], ws)                      # the input features are data
+        self._conv_wgrad("conv0", dzH0, g["feat0"], g["nbr0"], 4, s["cols0"], ws)           # the input features are data
 
 
 class _ConvEncoder(nn.Module):

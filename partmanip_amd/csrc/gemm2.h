@@ -21,6 +21,11 @@ struct Gemm2Prob {
     int epi, act;
     int vecA, vecB;               // 16-byte global loads allowed for that operand
     int splits, kchunk;           // split-K: number of slabs, reduction range per slab (multiple of 32)
+    // gathered operand (sparse convolutions, sparse_voxel.hip): the k-contiguous A of a forward problem / the k-major B of a
+    // weight-gradient problem is VIRTUAL -- element (row r, column q) is gsrc-row gidx[r*gJ + q/gC], column q%gC of the matrix
+    // at A (resp. B) with its leading dimension, or 0 where the index is negative (read from gzero, >= gC zeros).  The
+    // (rows x gJ*gC) operand never exists in HBM.  LDS-DMA path only (gC % 4 == 0, K resp. N = gJ*gC).
+    const int32_t* gidx; const float* gzero; int gJ, gC;
     int vecC;                     // 16-byte stores of C (and loads of bias / H) allowed (filled by the launcher)
     int tiles_m, tiles_n;         // filled by the launcher
     int block0;                   // first work-group of this problem in the grid (filled by the launcher)

@@ -366,14 +366,14 @@ typedef __attribute__((address_space(3))) void* g2_lds_ptr;
 // one operand tile (T rows x 32 k) global -> LDS: T / 32 wave instructions per wave
 template <bool KM, int T>
 __device__ __forceinline__ void g2_dma_tile(const float* __restrict__ P, long ld, int r0, int nrows, int k0, float* __restrict__ S,
-                                            int wave, int lane) {
+                                            int wave, int lane, int kmax = 0x7fffffff) {
 #pragma unroll
     for (int j = 0; j < T / 32; ++j) {
         const int piece = j * 4 + wave;                                    // 1 KiB piece of the tile image
         const float* src;
         if (KM) {
             const int k = piece * (256 / T) + lane / (T / 4), c = lane % (T / 4);
-            src = P + (long)(k0 + k) * ld + min(r0 + c * 4, nrows - 4);
+            src = P + (long)min(k0 + k, kmax) * ld + min(r0 + c * 4, nrows - 4);      // kmax: ragged reduction tail (gathered B is 0 there)
         } else {
             const int row = piece * 8 + (lane >> 3), c = lane & 7;
             src = P + (long)min(r0 + row, nrows - 1) * ld + k0 + ((c ^ ((row >> 1) & 7)) << 2);
@@ -382,7 +382,50 @@ __device__ __forceinline__ void g2_dma_tile(const float* __restrict__ P, long ld
     }
 }
 
-template <bool A_KM, bool B_KM, int WM, int WN>
+// The same for a GATHERED operand (see Gemm2Prob::gidx).  The neighbour indices of a tile are ordinary loads; VMEM returns in
+// order, so waiting for them would also drain every LDS-DMA issued before -- they are therefore fetched one K-step ahead
+// (`gi`: this tile's indices, loaded while the previous tile was issued; refilled here for the next tile `k0n`).
+template <bool KM, int T>
+__device__ __forceinline__ void g2_dma_tile_gather(const Gemm2Prob& g, const float* __restrict__ P, long ld, int r0, int nrows, int k0,
+                                                   int k0n, float* __restrict__ S, int wave, int lane, int (&gi)[T / 32]) {
+#pragma unroll
+    for (int j = 0; j < T / 32; ++j) {
+        const int piece = j * 4 + wave;
+        int q, qn, rr;                                                     // column inside the virtual operand, its row
+        if (KM) {                                                          // B of a weight gradient: rows = reduction index
+            const int k = piece * (256 / T) + lane / (T / 4), c = lane % (T / 4);
+            q = qn = min(r0 + c * 4, nrows - 4);
+            rr = k0 + k;
+            const float* src = gi[j] >= 0 ? P + (long)gi[j] * ld + (q % g.gC) : g.gzero + (q % g.gC);
+            __builtin_amdgcn_global_load_lds(src, (g2_lds_ptr)(S + piece * 256), 16, 0, 0);
+            gi[j] = k0n + k < g.K ? g.gidx[(long)(k0n + k) * g.gJ + qn / g.gC] : -1;     // rows behind the reduction's end: zeros
+        } else {                                                           // A of a forward: rows = output rows
+            const int row = piece * 8 + (lane >> 3), c = lane & 7;
+            rr = min(r0 + row, nrows - 1);
+            q = k0 + ((c ^ ((row >> 1) & 7)) << 2);
+            qn = k0n + ((c ^ ((row >> 1) & 7)) << 2);
+            const float* src = gi[j] >= 0 ? P + (long)gi[j] * ld + (q % g.gC) : g.gzero + (q % g.gC);
+            __builtin_amdgcn_global_load_lds(src, (g2_lds_ptr)(S + piece * 256), 16, 0, 0);
+            gi[j] = g.gidx[(long)rr * g.gJ + qn / g.gC];
+        }
+    }
+}
+template <bool KM, int T>
+__device__ __forceinline__ void g2_gather_first(const Gemm2Prob& g, int r0, int nrows, int k0, int wave, int lane, int (&gi)[T / 32]) {
+#pragma unroll
+    for (int j = 0; j < T / 32; ++j) {
+        const int piece = j * 4 + wave;
+        if (KM) {
+            const int k = piece * (256 / T) + lane / (T / 4), c = lane % (T / 4);
+            gi[j] = k0 + k < g.K ? g.gidx[(long)(k0 + k) * g.gJ + min(r0 + c * 4, nrows - 4) / g.gC] : -1;
+        } else {
+            const int row = piece * 8 + (lane >> 3), c = lane & 7;
+            gi[j] = g.gidx[(long)min(r0 + row, nrows - 1) * g.gJ + (k0 + ((c ^ ((row >> 1) & 7)) << 2)) / g.gC];
+        }
+    }
+}
+
+template <bool A_KM, bool B_KM, int WM, int WN, bool GATHER = false>
 __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
     // 8 waves: waves 0-3 multiply (2 x 2 over the tile, one per SIMD), waves 4-7 only feed the LDS ring.  Issuing one
     // 1 KiB LDS-DMA costs the issuing wave ~90 cycles (measured: 4 of them in front of a half-step's MFMAs stretched it from
@@ -413,7 +456,7 @@ __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
     const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
     const int m0 = tm * TM, n0 = tn * TN;
     const int kbeg = z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    const int nk = (kend - kbeg) / G2_TK;                                  // K and kchunk are multiples of 32 on this path
+    const int nk = (kend - kbeg + G2_TK - 1) / G2_TK;                      // whole steps, except the ragged row tail of a gathered weight gradient
     const int wmo = (wave >> 1) * 32 * WM, wno = (wave & 1) * 32 * WN;
 
     f32x16 acc[WM][WN];
@@ -432,19 +475,32 @@ __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
     if (loader) {
         // tile index clamped: the redundant reloads of the last tile keep the outstanding-load count uniform (they land in
         // buffers nobody reads any more)
+        constexpr int NGI = GATHER ? (A_KM ? TN : TM) / 32 : 1;
+        int gi[NGI];                                                       // GATHER: this lane's neighbour indices of the next tile
         auto issue = [&](int tile) __attribute__((always_inline)) {
             const int tt = min(tile, nk - 1), buf = tile % NBUF;
-            g2_dma_tile<A_KM, TM>(g.A, g.lda, m0, g.M, kbeg + tt * G2_TK, As + buf * ABUF, wave, lane);
-            g2_dma_tile<B_KM, TN>(g.B, g.ldb, n0, g.N, kbeg + tt * G2_TK, Bs + buf * BBUF, wave, lane);
+            const int kt = kbeg + tt * G2_TK, ktn = kbeg + min(tile + 1, nk - 1) * G2_TK;
+            if constexpr (GATHER && !A_KM) g2_dma_tile_gather<false, TM>(g, g.A, g.lda, m0, g.M, kt, ktn, As + buf * ABUF, wave, lane, gi);
+            else g2_dma_tile<A_KM, TM>(g.A, g.lda, m0, g.M, kt, As + buf * ABUF, wave, lane, g.K - 1);
+            if constexpr (GATHER && A_KM) g2_dma_tile_gather<true, TN>(g, g.B, g.ldb, n0, g.N, kt, ktn, Bs + buf * BBUF, wave, lane, gi);
+            else g2_dma_tile<B_KM, TN>(g.B, g.ldb, n0, g.N, kt, Bs + buf * BBUF, wave, lane);
         };
+        if constexpr (GATHER) {
+            if constexpr (A_KM) g2_gather_first<true, TN>(g, n0, g.N, kbeg, wave, lane, gi);
+            else g2_gather_first<false, TM>(g, m0, g.M, kbeg, wave, lane, gi);
+        }
+        // GATHER: an issue() ends with NGI index loads for the following tile; VMEM returns in order, so (a) the counted
+        // waits allow for them and (b) the next issue() -- which consumes them -- implicitly waits for everything older too:
+        // one tile (not two) stays in flight across the consumers' K-step.
+        constexpr int NW1 = IPT + (GATHER ? NGI : 0);
         issue(0);
         issue(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");         // tile 0 has landed (this wave's pieces)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW1) : "memory");         // tile 0 has landed (this wave's pieces)
         __builtin_amdgcn_s_barrier();                                      // ... and every other loader's
 #pragma unroll 1
         for (int k = 0; k < nk; ++k) {
             issue(k + 2);                                                  // into the buffer whose readers passed the last barrier
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");     // tile k+1 landed, tile k+2 stays in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW1) : "memory");     // tile k+1 landed, tile k+2 stays in flight
             __builtin_amdgcn_s_barrier();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the tail loads must not land in the epilogue's image
@@ -467,8 +523,9 @@ __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
             g2_read_frag_dma<B_KM, WN, TN>(Bc, wno, li, lh, 1, yb);
             if (do_bias) {
                 const float* col = Ac + (tid / TM) * BK * TM + (tid % TM);
+                const int kk = kbeg + k * G2_TK + (tid / TM) * BK;         // (the clamped rows of a ragged reduction tail do not count)
 #pragma unroll
-                for (int s = 0; s < BK; ++s) bsum += col[s * TM];
+                for (int s = 0; s < BK; ++s) bsum += kk + s < kend ? col[s * TM] : 0.f;
             }
             __builtin_amdgcn_sched_barrier(0);
             g2_mfma_part<WM, WN, 4, 8>(xa, xb, acc);
@@ -521,8 +578,29 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
     }
     bool vec = true;                                                       // 16-byte loads only if every operand of every problem allows them
     for (int i = 0; i < g.n; ++i) vec = vec && g.p[i].vecA && g.p[i].vecB;
-    bool dma = vec;
-    for (int i = 0; i < g.n; ++i) dma = dma && (g.p[i].K % G2_TK == 0) && (g.p[i].kchunk % G2_TK == 0);
+    bool dma = vec, gather = false;
+    for (int i = 0; i < g.n; ++i) {
+        dma = dma && (g.p[i].K % G2_TK == 0) && (g.p[i].kchunk % G2_TK == 0);
+        gather = gather || g.p[i].gidx != nullptr;
+    }
+    if (gather) {                                                          // virtual (gathered) operand: LDS-DMA kernels only
+        for (int i = 0; i < g.n; ++i) {
+            const Gemm2Prob& q = g.p[i];
+            const bool kok = A_KM ? (q.kchunk % G2_TK == 0) : (q.K % G2_TK == 0 && q.kchunk % G2_TK == 0);
+            if (!q.gidx || !q.gzero || !vec || !kok || q.gC % 4 != 0 || q.gJ < 1 || (long)q.gJ * q.gC != (A_KM ? q.N : q.K)) return PM_EINVAL;
+        }
+        if (!A_KM && !B_KM) {
+            if (big) hipLaunchKernelGGL((gemm2_dma_kernel<false, false, 2, 2, true>), dim3(blocks), dim3(512), 0, pm_stream(stream), g);
+            else hipLaunchKernelGGL((gemm2_dma_kernel<false, false, 1, 1, true>), dim3(blocks), dim3(512), 0, pm_stream(stream), g);
+        } else if (A_KM && B_KM) {
+            if (big) hipLaunchKernelGGL((gemm2_dma_kernel<true, true, 2, 2, true>), dim3(blocks), dim3(512), 0, pm_stream(stream), g);
+            else hipLaunchKernelGGL((gemm2_dma_kernel<true, true, 1, 1, true>), dim3(blocks), dim3(512), 0, pm_stream(stream), g);
+        } else {
+            return PM_EUNSUPPORTED;
+        }
+        PM_CHECK_LAUNCH();
+        return PM_OK;
+    }
     const dim3 grid(blocks), blk(256);
     if (dma && big) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 2>), grid, dim3(512), 0, pm_stream(stream), g);
     else if (dma) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 1>), grid, dim3(512), 0, pm_stream(stream), g);

@@ -280,3 +280,65 @@ extern "C" int pm_linear_bwd_weight_group_f32(int n, const pm_linear_bwd_weight_
     }
     return gemm2_launch(gg, true, true, stream);
 }
+
+// ---- sparse convolution = gathered-operand GEMM (sparse_voxel.hip builds the tables) -----------------------------------
+// forward:  Y[r][n] = act(sum_{j,c} src[idx[r][j]][c] * W[n][j*C + c] + b[n])        (absent neighbours, idx < 0, contribute 0)
+// weight:   dW[n][j*C + c] = sum_r dY[r][n] * src[idx[r][j]][c],  db[n] = sum_r dY[r][n]
+// The (rows x J*C) operand is gathered by the GEMM's LDS-DMA loader and never exists in HBM.
+extern "C" int pm_sparse_conv_fwd_f32(const float* src, long lds, const int32_t* idx, long rows, int J, int C, const float* W,
+                                      long ldw, const float* b, float* Y, long ldy, int N, int act, const float* zero, void* stream) {
+    PM_REQUIRE(src && idx && W && Y && zero && rows > 0 && rows < 0x7fffffffL && J > 0 && C > 0 && N > 0 && lds >= C && ldw >= (long)J * C &&
+               ldy >= N && act >= PM_ACT_NONE && act <= PM_ACT_MAX);
+    PM_REQUIRE(C % 4 == 0 && (J * C) % 32 == 0 && lds % 4 == 0 && ldw % 4 == 0);
+    if (!aligned16(src) || !aligned16(W) || !aligned16(zero)) return PM_EALIGN;
+    Gemm2Group gg{};
+    gg.n = 1;
+    Gemm2Prob& g = gg.p[0];
+    g.A = src; g.lda = lds; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.bias = b;
+    g.M = (int)rows; g.N = N; g.K = J * C; g.act = act; g.epi = G2_EPI_BIAS_ACT; g.splits = 1;
+    g.vecA = g.vecB = 1;
+    g.gidx = idx; g.gzero = zero; g.gJ = J; g.gC = C;
+    return gemm2_launch(gg, false, false, stream);
+}
+
+extern "C" size_t pm_sparse_conv_bwd_weight_workspace_bytes(long rows, int N, int J, int C) {
+    return pm_linear_bwd_weight_workspace_bytes((int)rows, N, J * C);
+}
+
+extern "C" int pm_sparse_conv_bwd_weight_f32(const float* dY, long lddy, const float* src, long lds, const int32_t* idx, long rows,
+                                             int J, int C, float* dW, long lddw, float* db, int N, const float* zero,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(dY && src && idx && dW && zero && rows > 0 && rows < 0x7fffffffL && J > 0 && C > 0 && N > 0 && lds >= C && lddy >= N &&
+               lddw >= (long)J * C);
+    PM_REQUIRE(C % 4 == 0 && N % 4 == 0 && lds % 4 == 0 && lddy % 4 == 0);
+    if (!aligned16(src) || !aligned16(dY) || !aligned16(zero)) return PM_EALIGN;
+    const int M = (int)rows, K = J * C;
+    const int S = bww_splits(M, N, K);
+    if (S > 1 && (!workspace || workspace_bytes < pm_linear_bwd_weight_workspace_bytes(M, N, K))) return PM_EWORKSPACE;
+    Gemm2Group gg{};
+    gg.n = 1;
+    Gemm2Prob& g = gg.p[0];
+    g.A = dY; g.lda = lddy; g.B = src; g.ldb = lds;
+    g.M = N; g.N = K; g.K = M; g.act = 0; g.epi = G2_EPI_PLAIN;
+    g.vecA = g.vecB = 1;
+    g.gidx = idx; g.gzero = zero; g.gJ = J; g.gC = C;
+    float* bslabs = (float*)workspace + (size_t)S * N * K;
+    if (S > 1) {
+        int kchunk = (M + S - 1) / S;
+        kchunk = ((kchunk + GB_K - 1) / GB_K) * GB_K;
+        g.C = (float*)workspace; g.ldc = K; g.kchunk = kchunk; g.slab = (long)N * K; g.splits = S;
+        g.dbias = db ? bslabs : nullptr; g.bslab = N;
+    } else {
+        g.C = dW; g.ldc = lddw; g.splits = 1; g.kchunk = ((M + 31) / 32) * 32; g.slab = 0;
+        g.dbias = db; g.bslab = 0;
+    }
+    const int rc = gemm2_launch(gg, true, true, stream);
+    if (rc != PM_OK) return rc;
+    if (S > 1) {
+        const long ne = (long)N * K + (db ? N : 0);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, pm_stream(stream),
+                           (const float*)workspace, S, (long)N * K, dW, lddw, N, K, (const float*)bslabs, db);
+        PM_CHECK_LAUNCH();
+    }
+    return PM_OK;
+}

@@ -558,6 +558,27 @@ def rows_gather(src, idx, C, dst):
     return dst
 
 
+def sparse_conv_fwd(src, idx, C, w, b, y, act, zero):
+    """y = act(gather(src, idx) @ w.T + b) with the gather inside the GEMM loader (J*C % 32 == 0)."""
+    _req(src, idx, w, b, y, zero)
+    rows, J = idx.shape
+    check(lib.pm_sparse_conv_fwd_f32(_ptr(src), _rows(src, "src"), _ptr(idx), rows, J, C, _ptr(w), _rows(w, "w"), _ptr(b), _ptr(y),
+                                     _rows(y, "y"), w.shape[0], int(act), _ptr(zero), _stream()), "pm_sparse_conv_fwd_f32")
+    return y
+
+
+def sparse_conv_bwd_weight(dy, src, idx, C, dw, db, zero, ws):
+    _req(dy, src, idx, dw, db, zero)
+    rows, J = idx.shape
+    N = dy.shape[1]
+    w = ws.get(lib.pm_sparse_conv_bwd_weight_workspace_bytes(rows, N, J, C) + 256)
+    base = w.data_ptr()
+    al = (-base) % 256
+    check(lib.pm_sparse_conv_bwd_weight_f32(_ptr(dy), _rows(dy, "dy"), _ptr(src), _rows(src, "src"), _ptr(idx), rows, J, C, _ptr(dw),
+                                            _rows(dw, "dw"), _ptr(db), N, _ptr(zero), base + al, w.numel() - al, _stream()),
+          "pm_sparse_conv_bwd_weight_f32")
+
+
 def rows_gather_bwd(dcols, tidx, C, dsrc, tslot=None, mode=0, reverse=False, self_col=-1, y_tanh=None, accumulate=False):
     _req(dcols, tidx, dsrc, tslot, y_tanh)
     rows = tidx.shape[0]

@@ -39,8 +39,11 @@ def test_geometry_tables_equal_the_restatement(dups):
         np.testing.assert_array_equal(g[lv]["coords"][:, 1:].cpu().numpy(), np.concatenate(ref[lv]["coords"]))
 
 
-@pytest.mark.parametrize("proprio,dups", [(0, False), (5, True)])
-def test_forward_and_parameter_gradients_match_the_restatement(proprio, dups):
+NET_WIDE = dict(NET, channels=[32, 64, 64])        # every layer but conv0 has J*C % 32 == 0: all gathers fused into the GEMM loader
+
+
+@pytest.mark.parametrize("proprio,dups,NET", [(0, False, NET), (5, True, NET), (0, True, NET_WIDE), (3, False, dict(NET_WIDE, fused_gather=False))])
+def test_forward_and_parameter_gradients_match_the_restatement(proprio, dups, NET):
     from partmanip_amd.algo_utils import ActorCritic
     from partmanip_amd.autograd import backbone_apply
     P, Rg, A, B = NET["point_num"], NET["grid"], 6, 7
@@ -104,3 +107,25 @@ def test_dagger_update_with_sparse_unet_student_matches_the_restatement(tmp_path
                           ocfg, 1)
     np.testing.assert_allclose(run.log_dict["Train/dagger_loss"], ref["log"]["Train/dagger_loss"], rtol=5e-4)
     assert_update_matches(flat_state(run.student.state_dict()), flat_state(stu), init, lr, len(ref["loss_trace"]))
+
+
+def test_fused_and_materialised_gathers_agree_bit_for_bit():
+    """`fused_gather`: the neighbour rows are gathered by the GEMM's LDS-DMA loader instead of being written to HBM first; the
+    MFMA k-order is the same, so outputs and gradients are identical."""
+    from partmanip_amd.algo_utils import ActorCritic
+    from partmanip_amd.autograd import backbone_apply
+    P, Rg, A, B = NET_WIDE["point_num"], NET_WIDE["grid"], 4, 9
+    sd = cases.actor_critic_state(NET_WIDE, 4 * P, A, 0.5, 43)
+    x = t(cases.sparse_clouds(B, P, Rg, 14, n_distinct=75, pad_tail=4)).to(DEV)
+    w = torch.randn(B, A, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    res = []
+    for fused in (True, False):
+        ac = ActorCritic(4 * P, A, _model(dict(NET_WIDE, fused_gather=fused))).to(DEV)
+        ac.load_state_dict({k: t(v.copy()) for k, v in sd.items()})
+        ac.flat()
+        out = backbone_apply(ac.actor, x)
+        (out * w).sum().backward()
+        res.append((out.detach().clone(), [p.grad.clone() for p in ac.actor.parameters()]))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
