@@ -684,18 +684,32 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
 // The 4-wave kernel above keeps the whole 256x128 dW2 accumulator in 4 waves (128 VGPRs each), which caps a CU at
 // two waves per SIMD, and its VALU / memory phases wait for HBM and L2 round trips between barriers.  Here
 //   * 16 waves share the dW2 accumulator (two 32x32 blocks = 32 registers each): four waves per SIMD feed the pipe;
-//   * dh1 = dz2 * W2 (32 points x 128 channels) runs on v_mfma_f32_16x16x4_f32: 16 blocks of 16x16, one per wave,
-//     full K = 256 (no K-split exchange), finished in registers: dz1 = dh1 .* (1 - h1^2) feeds dW1 / db1 directly;
+//   * dh1 = dz2 * W2 (32 points x 128 channels) runs on v_mfma_f32_16x16x4_f32 over the full K = 256 (no K-split
+//     exchange) on EIGHT of the waves, each owning 16 channels of both 16-point blocks so that one W2 fragment from L2
+//     feeds eight MFMAs; it is finished in registers: dz1 = dh1 .* (1 - h1^2) feeds dW1 / db1 directly;
 //   * the H1 / H2 tiles are double-buffered in LDS and the tile loop is software-pipelined by one tile: the memory
-//     requests of tile t+1's VALU stage (saved h2 rows, key run, first W3 row) are issued BEFORE the MFMA stage of
-//     tile t and consumed after it, so their round trips run under the MFMAs.  One barrier per 32-point tile.
-// Measured (2048 clouds): kernel 3.27 -> 2.95 ms; alone: MFMA stage 2.1 ms (ideal 1.75), VALU stage 0.65, per-cloud
-// setup 0.2.  Tried on this skeleton and dropped: splitting the waves into a VALU-first and an MFMA-first half so
-// the two stages overlap inside a SIMD (three variants, 3.7-4.8 ms: with two waves per SIMD in the MFMA stage its
-// operand streams are no longer covered, and the second code path costs registers); 64-point tiles with the VALU
-// results held in registers across the stage (24 VGPRs: spills, 5.6 ms).
+//     requests of tile t+1's VALU stage (saved h2 rows, the finished dh2 rows of its arg-max points) are issued BEFORE the
+//     MFMA stage of tile t and consumed after it, so their round trips run under the MFMAs.  One barrier per 32-point tile.
+// Round-2 timeline work (s_memtime stamps per wave and tile, -DPN_PROFILE + tools/pn_profile.py; 2048 clouds):
+//   3.00 ms  round-1 structure: each wave walked the arg-max keys of its two points itself (one dependent L2 round trip
+//            per key; a point that wins 10+ channels held all 16 waves at the tile barrier: slowest wave 6.9 k cycles of
+//            VALU stage against a mean of 3.3 k)
+//   2.74 ms  the per-point sums S = sum_c dmax[c] W3[c,:] come finished from pn_bwd_prep_kernel (one row load per point)
+//   2.62 ms  dh1 on eight waves with shared B fragments: the loop ran at 39 cycles per 32-cycle MFMA because every
+//            global_load_dwordx4 costs its SIMD ~27 issue cycles (the same with every wave reading ONE L1-resident block;
+//            with the loads removed the loop runs at 32.1) -- the dW2 loop, LDS-fed, runs at 99 % of the matrix rate
+// What the stamps also showed: a SIMD serves its waves strictly oldest-first, so waves 0-3 run ahead and 12-15 trail;
+// that is harmless here because fp32 MFMA and VALU share the issue port and the pipe has work whenever ANY
+// wave has.  Measured without effect or slower on this skeleton, all removed: the VALU stage before the MFMA stage (all
+// waves, or only the younger half via a barrier placed mid-iteration), s_setprio by stage / by progress / by wave group,
+// three LDS operand sets in rotation for the dW2 loop, two accumulator chains in dh1, the dh1 prologue loads hoisted
+// above the dW2 loop, layer-1 weights requested before the MFMA stage.  Round 1 (kept for the record): 64-point tiles
+// with the VALU results held in registers across the stage (spills, 5.6 ms).
 #ifndef PN_BWD16
 #define PN_BWD16 1
+#endif
+#ifndef PN_DH1_GROUP
+#define PN_DH1_GROUP 0           // which half of the 16 waves runs the dh1 GEMM (0: waves 0-7, 1: waves 8-15)
 #endif
 // ---- per-cloud arg-max bookkeeping of pn_bwd16_kernel, hoisted into its own launch ---------------------------------------
 // Inside the 16-wave kernel the 512-key bitonic sort is 45 barrier-separated stages in which 256 of 1024 threads work
@@ -704,9 +718,14 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
 // just loads the results: keys (slot<<22 | point<<9 | channel, ascending), the first key of every 2-point row block
 // (`offs`), and slotmap[b][c] = index of channel c's arg-max point among the cloud's distinct arg-max points.
 __global__ __launch_bounds__(256) void pn_bwd_prep_kernel(const int32_t* __restrict__ argmax, int P, int32_t* __restrict__ keys_g,
-                                                           unsigned short* __restrict__ offs_g, int32_t* __restrict__ slotmap) {
+                                                           unsigned short* __restrict__ offs_g, int32_t* __restrict__ slotmap,
+                                                           const float* __restrict__ dfeat, long ldf,
+                                                           const float* __restrict__ W3, float* __restrict__ Sg) {
     __shared__ int keys[PN_C3];
     __shared__ int wtot[4];
+    __shared__ float Gm[PN_C3];                     // dmax[b,:]
+    __shared__ unsigned short start[PN_C3 + 1];     // first sorted entry of every distinct arg-max point (slot)
+    __shared__ int nd_s;
     const int b = blockIdx.x, tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
     keys[tid] = (argmax[(long)b * PN_C3 + tid] << 9) | tid;
     keys[tid + 256] = (argmax[(long)b * PN_C3 + tid + 256] << 9) | (tid + 256);
@@ -755,18 +774,64 @@ __global__ __launch_bounds__(256) void pn_bwd_prep_kernel(const int32_t* __restr
     keys_g[(long)b * PN_C3 + e1] = k1;
     slotmap[(long)b * PN_C3 + (k0 & 511)] = s0;
     slotmap[(long)b * PN_C3 + (k1 & 511)] = s1;
+    // ---- S[slot,:] = sum over the channels c that picked this point of dmax[b,c] * W3[c,:], channels ascending (the
+    // order of the sorted keys).  The 16-wave kernel used to walk these runs itself, one dependent L2 round trip per key,
+    // and a point that wins many channels (a few extreme points always do) held its whole work-group at the tile
+    // barrier; here 2048 small work-groups walk them side by side and the big kernel loads ONE finished row per arg-max
+    // point.  (All reads of keys[] above are in front of the wtot barrier.)
+    Gm[tid] = dfeat[(long)b * ldf + tid];
+    Gm[tid + 256] = dfeat[(long)b * ldf + tid + 256];
+    keys[e0] = k0;
+    keys[e1] = k1;
+    if (q0 != qm) start[s0] = (unsigned short)e0;
+    if (f1) start[s1] = (unsigned short)e1;
+    if (tid == 255) {
+        start[s1 + 1] = (unsigned short)PN_C3;
+        nd_s = s1 + 1;
+    }
+    __syncthreads();
+    const int nd = nd_s;
+    for (int sl = wave; sl < nd; sl += 4) {
+        const int a = start[sl], z = start[sl + 1];
+        float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+        int c_next = keys[a] & 511;
+        float4 w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane0);
+        for (int e = a; e < z; ++e) {
+            const int c = c_next;
+            const float4 w3 = w_next;
+            if (e + 1 < z) {
+                c_next = keys[e + 1] & 511;
+                w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane0);
+            }
+            const float g = Gm[c];
+            S.x += g * w3.x; S.y += g * w3.y; S.z += g * w3.z; S.w += g * w3.w;
+        }
+        *(float4*)(Sg + ((long)b * PN_C3 + sl) * PN_C2 + 4 * lane0) = S;
+    }
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#ifdef PN_PROFILE   // A/B builds only (tools/pn_profile.py): s_memtime stamps of work-groups 0-3, first cloud, tiles 0-15, every wave
+__device__ unsigned long long pn_prof[4 * 16 * 16 * 8];
+extern "C" int pm_debug_pn_prof_read(void* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pn_prof), sizeof(unsigned long long) * 4 * 16 * 16 * 8) == hipSuccess ? 0 : 1;
+}
+#define PN_STAMP(i)                                                                                         \
+    if (prof_tile >= 0 && lane0 == 0) pn_prof[((blockIdx.x * 16 + prof_tile) * 16 + wave) * 8 + (i)] = __builtin_readcyclecounter()
+#else
+#define PN_STAMP(i)
+#endif
 template <int CT>
 __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
     const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
     const float* __restrict__ b1, const float* __restrict__ W3, const float* __restrict__ packed, int max_mean,
     const float* __restrict__ dfeat, long ldf, const int32_t* __restrict__ argmax, const float* __restrict__ U,
     float* __restrict__ H2sum, float* __restrict__ Hg, const int32_t* __restrict__ keys_g,
-    const unsigned short* __restrict__ offs_g, PnBwdPart* __restrict__ parts, const float* __restrict__ h2_saved) {
+    const unsigned short* __restrict__ offs_g, PnBwdPart* __restrict__ parts, const float* __restrict__ h2_saved,
+    const float* __restrict__ Sg) {
     constexpr int BT = 32, NT = 1024, NW = 16, RPW = BT / NW, PPT = BT * PN_C1 / NT;
+    static_assert(RPW == 2, "the row-owner pass finds its two rows' slots at the ends of the wave's key run");
     constexpr int NXC = (CT == 3 || CT == 4) ? 4 : PN_MAXC;      // point coordinates that can be non-zero
     constexpr int XSZ = BT * PN_MAXC, H1SZ = BT * PN_LD1, H2SZ = BT * PN_LD2;
     __shared__ __attribute__((aligned(16))) float smem[2 * H1SZ + 2 * H2SZ + 3 * XSZ + PN_C2 + PN_C3 + PN_C3 + 1028 + 32];
@@ -787,7 +852,8 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
     const float invP = 1.0f / (float)P;
 
     const int w2_m = wave & 7, w2_n0 = (wave >> 3) * 2;  // dW2[out = w2_m*32 + row][in = (w2_n0 + j)*32 + li]
-    const int hmb = wave & 1, hnb = wave >> 1;           // dh1 block: points hmb*16.., channels hnb*16..
+    const int hnb = wave & 7;                            // dh1: channels hnb*16.. (both 16-point blocks), by one wave group
+    const bool dh_on = (wave >> 3) == PN_DH1_GROUP;
     f32x16 accW2[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
@@ -806,10 +872,7 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
         if (sub_mean) cloud_centroid<NT>(xb, P, C, red, cen);
         // ---- per-cloud setup: u/P, dmax; the sorted arg-max keys and their row-block offsets come from pn_bwd_prep_kernel --
         if (tid < PN_C2) Us[tid] = max_mean ? U[(long)b * PN_C2 + tid] * invP : 0.f;
-        if (tid < PN_C3) {
-            Gm[tid] = dfeat[(long)b * ldf + tid];
-            keys[tid] = keys_g[(long)b * PN_C3 + tid];
-        }
+        if (tid < PN_C3) keys[tid] = keys_g[(long)b * PN_C3 + tid];
         for (int p = tid; p <= P / RPW; p += NT) offs[p] = offs_g[(long)b * (P / RPW + 1) + p];
         __syncthreads();
         float4 h2s = make_float4(0.f, 0.f, 0.f, 0.f);    // sum_p h2[p][4*lane..] over this wave's rows
@@ -818,23 +881,31 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
         // wave's two saved-h2 rows, its run of sorted keys, the W3 row of the first key); valu_finish: layer 1 -> H1n and
         // the row-owner pass (wave w owns rows 2w, 2w+1) h2 -> dz2 -> H2n.  The MFMA stage of the previous tile runs
         // between the two, so the round trips are over when valu_finish starts.
-        float4 hrows[RPW], w_next, u4;
-        int e, e_end, pj, c_next;
+        float4 hrows[RPW], srow[RPW];
+        int slot[RPW];                                   // >= 0: this row's point is an arg-max (its Hg / Sg slot)
+#ifdef PN_PROFILE
+        int prof_tile = -1;
+#endif
         auto valu_issue = [&](int tt, int tl) __attribute__((always_inline)) {
             const int lane = tl & 63;
 #pragma unroll
             for (int rr = 0; rr < RPW; ++rr)
                 hrows[rr] = *(const float4*)(h2_saved + ((long)b * P + tt * BT + wave * RPW + rr) * PN_C2 + 4 * lane);
             const int p0 = tt * BT + wave * RPW;
-            u4 = *(const float4*)(Us + 4 * lane);
-            e_end = offs[p0 / RPW + 1];
-            e = offs[p0 / RPW];
-            pj = (lane < e_end - e) ? ((keys[e + lane] >> 9) & 0x1FFF) : 0x7FFFFFFF;
-            c_next = 0;
-            w_next = make_float4(0.f, 0.f, 0.f, 0.f);
+            // the wave's key run [e, e_end) covers its two points: the first key belongs to row 0 iff its point is p0,
+            // the last to row 1 iff its point is p0 + 1 (keys are sorted by point)
+            const int e = __builtin_amdgcn_readfirstlane((int)offs[p0 / RPW]);
+            const int e_end = __builtin_amdgcn_readfirstlane((int)offs[p0 / RPW + 1]);
+            slot[0] = slot[1] = -1;
+            srow[0] = srow[1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < e_end) {
-                c_next = keys[e] & 511;
-                w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
+                const int kf = __builtin_amdgcn_readfirstlane(keys[e]);
+                const int kl = __builtin_amdgcn_readfirstlane(keys[e_end - 1]);
+                if (((kf >> 9) & 0x1FFF) == p0) slot[0] = kf >> 22;
+                if (((kl >> 9) & 0x1FFF) == p0 + 1) slot[1] = kl >> 22;
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr)
+                    if (slot[rr] >= 0) srow[rr] = *(const float4*)(Sg + ((long)b * PN_C3 + slot[rr]) * PN_C2 + 4 * lane);
             }
         };
         auto valu_finish = [&](int tt, const float* Xs, float* H1n, float* H2n, int tl) __attribute__((always_inline)) {
@@ -868,37 +939,13 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
                 }
             }
             if (!(PN_ABLATE & 8)) {
-                const int p0 = tt * BT + wave * RPW;
-                const int e0 = e, span = e_end - e0;
+                const float4 u4 = *(const float4*)(Us + 4 * lane);
 #pragma unroll
                 for (int rr = 0; rr < RPW; ++rr) {
-                    const float4 h = hrows[rr];
+                    const float4 h = hrows[rr], S = srow[rr];
                     h2s.x += h.x; h2s.y += h.y; h2s.z += h.z; h2s.w += h.w;
-                    float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
-                    int row_end;
-                    if (span <= 64) {
-                        row_end = e0 + __popcll(__ballot(pj <= p0 + rr));
-                    } else {
-                        int lo = e, hi = e_end;
-                        const int target = (p0 + rr + 1) << 9;
-                        while (lo < hi) {
-                            const int mid = (lo + hi) >> 1;
-                            if ((keys[mid] & 0x3FFFFF) < target) lo = mid + 1; else hi = mid;
-                        }
-                        row_end = lo;
-                    }
-                    if (e < row_end)                                  // this point is some channel's arg-max
-                        *(float4*)(Hg + ((long)b * PN_C3 + (keys[e] >> 22)) * PN_C2 + 4 * lane) = h;
-                    for (; e < row_end; ++e) {
-                        const int c = c_next;
-                        const float4 w3 = w_next;
-                        if (e + 1 < e_end) {
-                            c_next = keys[e + 1] & 511;
-                            w_next = *(const float4*)(W3 + (long)c_next * PN_C2 + 4 * lane);
-                        }
-                        const float g = Gm[c];
-                        S.x += g * w3.x; S.y += g * w3.y; S.z += g * w3.z; S.w += g * w3.w;
-                    }
+                    if (slot[rr] >= 0)                                 // this point is some channel's arg-max
+                        *(float4*)(Hg + ((long)b * PN_C3 + slot[rr]) * PN_C2 + 4 * lane) = h;
                     float4 dz;
                     dz.x = (u4.x + S.x) * (1.0f - h.x * h.x);
                     dz.y = (u4.y + S.y) * (1.0f - h.y * h.y);
@@ -932,43 +979,56 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
 #undef DW2_LOAD
 #undef DW2_MMA
             }
-            {   // dh1 = dz2 * W2 on 16x16x4: lane (l16 = lane&15, q = lane>>4) holds A[row l16][k = 64q + 4g + e],
-                // B[k][col l16] and the results of rows 4q..4q+3, column l16 of this wave's block
+            PN_STAMP(2);
+            if (dh_on) {
+                // dh1 = dz2 * W2 on 16x16x4, by HALF of the waves: wave (hnb) owns channels hnb*16.. of BOTH 16-point
+                // blocks, so one B fragment from L2 feeds eight MFMAs instead of four.  (With one block per wave every
+                // fragment was fetched twice and the loop ran at 39 cycles per 32-cycle MFMA: each global_load_dwordx4
+                // costs its SIMD ~27 issue cycles whatever the L1 / L2 hit rate -- tools/pn_profile.py, A/B probes.)  The
+                // other eight waves go straight from the dW2 loop to their VALU stage, which then runs beside these MFMAs.
+                // Lane (l16 = lane&15, q = lane>>4) holds A[row l16][k = 64q + 4g + e], B[k][col l16] and the results of rows
+                // 4q..4q+3 (acc0) / 16+4q..16+4q+3 (acc1), column l16.
                 const int l16 = lane & 15, q = lane >> 4;
-                const float* Ap = H2c + (hmb * 16 + l16) * PN_LD2 + q * 64;
+                const float* Ap = H2c + l16 * PN_LD2 + q * 64;
                 const float4* Bp = P2T16 + (size_t)hnb * 16 * 64 + lane;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 // the B stream comes from L2 (~700 clk): four groups in flight (b0..b3); A from LDS: one group ahead
-                float4 a0 = *(const float4*)Ap, a1;
+                float4 a0 = *(const float4*)Ap, c0 = *(const float4*)(Ap + 16 * PN_LD2), a1, c1;
                 float4 b0 = Bp[0], b1v = Bp[64], b2v = Bp[128], b3v = Bp[192];
-#define DH_MMA(a_, b_)                    \
-    acc = MFMA16(a_.x, b_.x, acc);        \
-    acc = MFMA16(a_.y, b_.y, acc);        \
-    acc = MFMA16(a_.z, b_.z, acc);        \
-    acc = MFMA16(a_.w, b_.w, acc);
-#define DH_STEP(acur, anext, bcur, g_)                                                        \
-    anext = *(const float4*)(Ap + ((g_) + 1) * 4);                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                        \
-    DH_MMA(acur, bcur)                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                        \
+#define DH_MMA(a_, c_, b_)                  \
+    acc0 = MFMA16(a_.x, b_.x, acc0);        \
+    acc1 = MFMA16(c_.x, b_.x, acc1);        \
+    acc0 = MFMA16(a_.y, b_.y, acc0);        \
+    acc1 = MFMA16(c_.y, b_.y, acc1);        \
+    acc0 = MFMA16(a_.z, b_.z, acc0);        \
+    acc1 = MFMA16(c_.z, b_.z, acc1);        \
+    acc0 = MFMA16(a_.w, b_.w, acc0);        \
+    acc1 = MFMA16(c_.w, b_.w, acc1);
+#define DH_STEP(acur, ccur, anext, cnext, bcur, g_)                                                                      \
+    anext = *(const float4*)(Ap + ((g_) + 1) * 4);                                                                       \
+    cnext = *(const float4*)(Ap + 16 * PN_LD2 + ((g_) + 1) * 4);                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    DH_MMA(acur, ccur, bcur)                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
     bcur = Bp[(size_t)((g_) + 4) * 64];        /* unconditional: up to 4 groups past the end (next block / tail pad) */ \
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
                 for (int g = 0; g < ((PN_ABLATE & 64) ? 0 : 16); g += 4) {
-                    DH_STEP(a0, a1, b0, g)
-                    DH_STEP(a1, a0, b1v, g + 1)
-                    DH_STEP(a0, a1, b2v, g + 2)
-                    DH_STEP(a1, a0, b3v, g + 3)
+                    DH_STEP(a0, c0, a1, c1, b0, g)
+                    DH_STEP(a1, c1, a0, c0, b1v, g + 1)
+                    DH_STEP(a0, c0, a1, c1, b2v, g + 2)
+                    DH_STEP(a1, c1, a0, c0, b3v, g + 3)
                 }
 #undef DH_STEP
 #undef DH_MMA
+                PN_STAMP(3);
                 // dz1 = dh1 .* (1 - h1^2); dW1 / db1 straight from the accumulator registers
                 const int col = hnb * 16 + l16;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = hmb * 16 + 4 * q + r;
+                for (int r = 0; r < 8; ++r) {
+                    const int row = (r >> 2) * 16 + 4 * q + (r & 3);
                     const float h = H1c[row * PN_LD1 + col];
-                    const float dz = acc[r] * (1.0f - h * h);
+                    const float dz = (r < 4 ? acc0[r & 3] : acc1[r & 3]) * (1.0f - h * h);
                     const float4 x0 = *(const float4*)(Xs + row * PN_MAXC);
                     db1acc += dz;
                     dW1acc[0] = fmaf(dz, x0.x, dW1acc[0]);
@@ -1012,11 +1072,19 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
                 xnext = xb[((tile + 2) * BT + (tl >> 3)) * C + (tl & 7)];
                 if (sub_mean && (tl & 7) < 3) xnext -= cen[tl & 7];
             }
+#ifdef PN_PROFILE
+            prof_tile = (blockIdx.x < 4 && b == (int)blockIdx.x && tile < 16) ? tile : -1;
+#endif
+            PN_STAMP(0);
             if (more) valu_issue(tile + 1, tl);
+            PN_STAMP(1);
             mfma_stage(H1b + cur * H1SZ, H2b + cur * H2SZ, Xs0 + ix * XSZ, tl);
+            PN_STAMP(4);
             if (more) valu_finish(tile + 1, Xs0 + ix1 * XSZ, H1b + (cur ^ 1) * H1SZ, H2b + (cur ^ 1) * H2SZ, tl);
             if (stage2) Xs0[ix2 * XSZ + tl] = xnext;
+            PN_STAMP(5);
             __syncthreads();                               // tile t's buffers are free, tile t+1's complete
+            PN_STAMP(6);
             ix = ix1;
         }
         *(float4*)(wred + wave * PN_C2 + 4 * lane0) = h2s;
@@ -1045,7 +1113,7 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
     *(float4*)(wred + wave * PN_C2 + 4 * lane0) = db2acc;
     float* t1 = H2b + NW * PN_C2;                       // dW1/db1: the 8 row subsets (point half, lane quarter) of a channel
     {                                                   // meet in LDS: [8][128][9] floats behind the wave partials
-        const int c = hnb * 16 + (lane0 & 15), part_i = hmb * 4 + (lane0 >> 4);
+        const int c = hnb * 16 + (lane0 & 15), part_i = (wave >> 3) * 4 + (lane0 >> 4);   // the idle group adds zeros
 #pragma unroll
         for (int d = 0; d < PN_MAXC; ++d) t1[(part_i * 128 + c) * (PN_MAXC + 1) + d] = d < NXC ? dW1acc[d % NXC] : 0.f;
         t1[(part_i * 128 + c) * (PN_MAXC + 1) + PN_MAXC] = db1acc;
@@ -1167,7 +1235,7 @@ static int pn_cu_count() {
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct PnBwdWs {
-    size_t off_U, off_H2sum, off_Hg, off_slot, off_parts, off_dw3, off_gemm, off_keys, off_offs, total;
+    size_t off_U, off_H2sum, off_Hg, off_slot, off_parts, off_dw3, off_gemm, off_keys, off_offs, off_Sg, total;
 };
 static PnBwdWs pn_bwd_layout(int B) {
     PnBwdWs w;
@@ -1181,6 +1249,7 @@ static PnBwdWs pn_bwd_layout(int B) {
     w.off_gemm = o;   o += align256(pm_linear_bwd_weight_workspace_bytes(B, PN_C3, PN_C2));
     w.off_keys = o;   o += align256((size_t)B * PN_C3 * 4);               // pn_bwd_prep_kernel: sorted arg-max keys
     w.off_offs = o;   o += align256((size_t)B * (4096 / 2 + 1) * 2);      // ... and their row-block offsets (P <= 4096)
+    w.off_Sg = o;     o += align256((size_t)B * PN_C3 * PN_C2 * 4);       // ... and the dh2 contribution of every arg-max point
     w.total = o;
     return w;
 }
@@ -1222,11 +1291,13 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
         G = B < ncu ? B : ncu;
         int32_t* keys_g = (int32_t*)(ws + w.off_keys);
         unsigned short* offs_g = (unsigned short*)(ws + w.off_offs);
-        hipLaunchKernelGGL(pn_bwd_prep_kernel, dim3(B), dim3(256), 0, pm_stream(stream), argmax, P, keys_g, offs_g, slotmap);
+        float* Sg = (float*)(ws + w.off_Sg);
+        hipLaunchKernelGGL(pn_bwd_prep_kernel, dim3(B), dim3(256), 0, pm_stream(stream), argmax, P, keys_g, offs_g, slotmap,
+                           dfeat, ldf, W3, Sg);
 #define PN_BWD16_LAUNCH(CT)                                                                                            \
     hipLaunchKernelGGL((pn_bwd16_kernel<CT>), dim3(G), dim3(1024), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, \
                        W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, (const int32_t*)keys_g,                    \
-                       (const unsigned short*)offs_g, parts, h2_saved)
+                       (const unsigned short*)offs_g, parts, h2_saved, (const float*)Sg)
         if (C == 3) PN_BWD16_LAUNCH(3);
         else if (C == 4) PN_BWD16_LAUNCH(4);
         else PN_BWD16_LAUNCH(0);
