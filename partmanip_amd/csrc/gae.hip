@@ -1,60 +1,90 @@
-// K1 GAE return scan, K2 advantage normalisation, K3 row gather.  HBM / latency bound
-// scans: one lane per env, N contiguous => every wave load is a coalesced 256 B row.
+// K1 GAE return scan, K2 advantage normalisation, K3 row gather.  HBM / latency bound.
 #include "common.h"
 
 // ---------------------------------------------------------------------------------- K1
-// storage.py:96-112.  Thread n walks t = T-1 .. 0 keeping the running advantage in a
-// register; loads of the next UNROLL steps are independent of the recurrence and are
-// issued ahead of it.  All arithmetic uses explicit round-to-nearest ops (no FMA
-// contraction) so the result is bit-identical to the reference's op-by-op tensors.
-template <int UNROLL>
-__global__ __launch_bounds__(64) void gae_scan_kernel(const float* __restrict__ rewards,
-                                                       const float* __restrict__ values,
-                                                       const uint8_t* __restrict__ dones,
-                                                       const uint8_t* __restrict__ succs,
-                                                       const float* __restrict__ last_values,
-                                                       float* __restrict__ returns, float* __restrict__ advantages,
-                                                       int T, int N, float gamma, float gamma_lam, int use_succ,
-                                                       float succ_value) {
-    const int n = blockIdx.x * 64 + threadIdx.x;
-    if (n >= N) return;
-    float adv = 0.0f;
-    float nv = last_values[n];
-    int t = T - 1;
-    while (t >= 0) {
-        const int cnt = (t + 1 < UNROLL) ? (t + 1) : UNROLL;
-        float r[UNROLL], v[UNROLL];
-        uint8_t d[UNROLL], s[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            if (u < cnt) {
-                const long o = (long)(t - u) * N + n;
-                r[u] = rewards[o];
-                v[u] = values[o];
-                d[u] = dones[o];
-                s[u] = use_succ ? succs[o] : (uint8_t)0;
+// storage.py:96-112.  The recurrence  adv_t = notdone_t * (delta_t + gamma*lam * adv_{t+1})  is the only serial part of
+// the scan: delta_t = r_t + gamma * V_{t+1} - V_t and the two outputs are element-wise.  A work-group owns GAE_E
+// consecutive envs and walks T in chunks of GAE_TC steps from the end:
+//   phase 1 (256 threads): coalesced loads of r, V, V_next, done -> delta, notdone, V into LDS;
+//   phase 2 (GAE_E lanes): the dependent chain over the chunk, three dependent fp32 ops per step, operands from LDS;
+//   phase 3 (256 threads): returns / advantages from the chain's values, coalesced stores.
+// Round 1 ran the whole scan as one lane per env (loads, stores and twelve ops inside the chain, 64 single-wave
+// work-groups on 64 CUs): 40-55 us for 4096 x 128.  With 16 envs per work-group every CU takes part in the
+// element-wise phases.  All arithmetic is the reference's op-by-op sequence in explicit round-to-nearest ops (no FMA
+// contraction), evaluated per element exactly as before: the result stays bit-identical to the reference's tensors.
+#define GAE_E 16
+#define GAE_TC 128
+__global__ __launch_bounds__(256) void gae_scan_kernel(const float* __restrict__ rewards,
+                                                        const float* __restrict__ values,
+                                                        const uint8_t* __restrict__ dones,
+                                                        const uint8_t* __restrict__ succs,
+                                                        const float* __restrict__ last_values,
+                                                        float* __restrict__ returns, float* __restrict__ advantages,
+                                                        int T, int N, float gamma, float gamma_lam, int use_succ,
+                                                        float succ_value) {
+    __shared__ float D[GAE_TC * GAE_E];      // delta, then adv
+    __shared__ float ND[GAE_TC * GAE_E];     // 1 - done
+    __shared__ float V[GAE_TC * GAE_E];
+    const int tid = threadIdx.x, n0 = blockIdx.x * GAE_E;
+    const int e = tid % GAE_E, r0 = tid / GAE_E;           // phases 1 / 3: rows r0, r0 + 16, ... of the chunk
+    const int n = n0 + e;
+    const bool live = n < N;
+    float adv = 0.0f;                                       // chain state of lane e (tid < GAE_E), carried over chunks
+    for (int t_hi = T; t_hi > 0; t_hi -= GAE_TC) {
+        const int t_lo = t_hi > GAE_TC ? t_hi - GAE_TC : 0, nt = t_hi - t_lo;
+        if (live) {
+#pragma unroll 8
+            for (int tl = r0; tl < nt; tl += 256 / GAE_E) {
+                const int t = t_lo + tl;
+                const long o = (long)t * N + n;
+                const float r = rewards[o], v = values[o];
+                const float nv = (t + 1 < T) ? values[o + N] : last_values[n];
+                const float notdone = dones[o] ? 0.0f : 1.0f;
+                D[tl * GAE_E + e] = sub_rn(add_rn(r, mul_rn(gamma, nv)), v);
+                ND[tl * GAE_E + e] = notdone;
+                V[tl * GAE_E + e] = v;
             }
         }
+        __syncthreads();
+        if (tid < GAE_E && live) {
+            int tl = nt - 1;
+            for (; tl >= 7; tl -= 8) {                      // operands of eight steps requested together, then the chain
+                float d8[8], n8[8];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            if (u < cnt) {
-                const long o = (long)(t - u) * N + n;
-                const float notdone = d[u] ? 0.0f : 1.0f;
-                const float delta = sub_rn(add_rn(r[u], mul_rn(gamma, nv)), v[u]);
-                adv = mul_rn(notdone, add_rn(delta, mul_rn(gamma_lam, adv)));
+                for (int u = 0; u < 8; ++u) {
+                    d8[u] = D[(tl - u) * GAE_E + tid];
+                    n8[u] = ND[(tl - u) * GAE_E + tid];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    adv = mul_rn(n8[u], add_rn(d8[u], mul_rn(gamma_lam, adv)));
+                    D[(tl - u) * GAE_E + tid] = adv;
+                }
+            }
+            for (; tl >= 0; --tl) {
+                adv = mul_rn(ND[tl * GAE_E + tid], add_rn(D[tl * GAE_E + tid], mul_rn(gamma_lam, adv)));
+                D[tl * GAE_E + tid] = adv;
+            }
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll 8
+            for (int tl = r0; tl < nt; tl += 256 / GAE_E) {
+                const long o = (long)(t_lo + tl) * N + n;
+                const float a = D[tl * GAE_E + e], v = V[tl * GAE_E + e];
                 float ret;
                 if (use_succ) {
-                    const float sf = s[u] ? 1.0f : 0.0f, nsf = s[u] ? 0.0f : 1.0f;
-                    ret = add_rn(mul_rn(nsf, add_rn(adv, v[u])), mul_rn(sf, succ_value));
+                    const uint8_t sb = succs[o];
+                    const float sf = sb ? 1.0f : 0.0f, nsf = sb ? 0.0f : 1.0f;
+                    ret = add_rn(mul_rn(nsf, add_rn(a, v)), mul_rn(sf, succ_value));
                 } else {
-                    ret = add_rn(adv, v[u]);
+                    ret = add_rn(a, v);
                 }
                 returns[o] = ret;
-                advantages[o] = sub_rn(ret, v[u]);
-                nv = v[u];
+                advantages[o] = sub_rn(ret, v);
             }
         }
-        t -= cnt;
+        __syncthreads();                                    // the next chunk overwrites the tiles
     }
 }
 
@@ -65,7 +95,7 @@ extern "C" int pm_gae_scan_f32(const float* rewards, const float* values, const 
     PM_REQUIRE(rewards && values && dones && last_values && returns && advantages);
     PM_REQUIRE(T > 0 && N > 0);
     PM_REQUIRE(!use_succ || succs);
-    hipLaunchKernelGGL(gae_scan_kernel<8>, dim3((N + 63) / 64), dim3(64), 0, pm_stream(stream), rewards, values,
+    hipLaunchKernelGGL(gae_scan_kernel, dim3((N + GAE_E - 1) / GAE_E), dim3(256), 0, pm_stream(stream), rewards, values,
                        dones, succs, last_values, returns, advantages, T, N, gamma, gamma_lam, use_succ,
                        succ_value);
     PM_CHECK_LAUNCH();

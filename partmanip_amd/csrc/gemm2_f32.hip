@@ -561,9 +561,36 @@ __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
     G2_STAMP(3);
 }
 
+// (WM, WN) of a launch: 64 x 64 work-group tiles for small grids; for big ones 128 rows / columns only along a dimension some
+// problem actually extends past 64 -- a 128 x 128 tile on an N = 64 problem (the 64-channel sparse convolutions: 2.7 M rows,
+// K = 1728) spends half of its MFMAs on columns that do not exist.
+template <bool A_KM, bool B_KM, bool GATHER>
+static void g2_launch_dma(const Gemm2Group& g, int wm, int wn, int blocks, void* stream) {
+    const dim3 grid(blocks), blk(512);
+    if (wm == 2 && wn == 2) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 2, GATHER>), grid, blk, 0, pm_stream(stream), g);
+    else if (wm == 2) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 1, GATHER>), grid, blk, 0, pm_stream(stream), g);
+    else if (wn == 2) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 2, GATHER>), grid, blk, 0, pm_stream(stream), g);
+    else hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 1, GATHER>), grid, blk, 0, pm_stream(stream), g);
+}
+
 template <bool A_KM, bool B_KM>
 static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
-    const int TM = big ? 128 : 64, TN = big ? 128 : 64;
+    bool vec = true;                                                       // 16-byte loads only if every operand of every problem allows them
+    for (int i = 0; i < g.n; ++i) vec = vec && g.p[i].vecA && g.p[i].vecB;
+    bool dma = vec, gather = false;
+    int maxM = 0, maxN = 0;
+    for (int i = 0; i < g.n; ++i) {
+        dma = dma && (g.p[i].K % G2_TK == 0) && (g.p[i].kchunk % G2_TK == 0);
+        gather = gather || g.p[i].gidx != nullptr;
+        maxM = g.p[i].M > maxM ? g.p[i].M : maxM;
+        maxN = g.p[i].N > maxN ? g.p[i].N : maxN;
+    }
+    int wm = big ? 2 : 1, wn = big ? 2 : 1;
+    if (big && (dma || gather)) {                                          // the register-staged kernel keeps its two square shapes
+        if (maxM <= 64) wm = 1;
+        if (maxN <= 64) wn = 1;
+    }
+    const int TM = 64 * wm, TN = 64 * wn;
     int blocks = 0;
     for (int i = 0; i < g.n; ++i) {
         Gemm2Prob& p = g.p[i];
@@ -576,34 +603,19 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
         blocks += p.tiles_m * p.tiles_n * p.splits;
         blocks = (blocks + 7) & ~7;                                        // problems start on an XCD-0 block
     }
-    bool vec = true;                                                       // 16-byte loads only if every operand of every problem allows them
-    for (int i = 0; i < g.n; ++i) vec = vec && g.p[i].vecA && g.p[i].vecB;
-    bool dma = vec, gather = false;
-    for (int i = 0; i < g.n; ++i) {
-        dma = dma && (g.p[i].K % G2_TK == 0) && (g.p[i].kchunk % G2_TK == 0);
-        gather = gather || g.p[i].gidx != nullptr;
-    }
     if (gather) {                                                          // virtual (gathered) operand: LDS-DMA kernels only
         for (int i = 0; i < g.n; ++i) {
             const Gemm2Prob& q = g.p[i];
             const bool kok = A_KM ? (q.kchunk % G2_TK == 0) : (q.K % G2_TK == 0 && q.kchunk % G2_TK == 0);
             if (!q.gidx || !q.gzero || !vec || !kok || q.gC % 4 != 0 || q.gJ < 1 || (long)q.gJ * q.gC != (A_KM ? q.N : q.K)) return PM_EINVAL;
         }
-        if (!A_KM && !B_KM) {
-            if (big) hipLaunchKernelGGL((gemm2_dma_kernel<false, false, 2, 2, true>), dim3(blocks), dim3(512), 0, pm_stream(stream), g);
-            else hipLaunchKernelGGL((gemm2_dma_kernel<false, false, 1, 1, true>), dim3(blocks), dim3(512), 0, pm_stream(stream), g);
-        } else if (A_KM && B_KM) {
-            if (big) hipLaunchKernelGGL((gemm2_dma_kernel<true, true, 2, 2, true>), dim3(blocks), dim3(512), 0, pm_stream(stream), g);
-            else hipLaunchKernelGGL((gemm2_dma_kernel<true, true, 1, 1, true>), dim3(blocks), dim3(512), 0, pm_stream(stream), g);
-        } else {
-            return PM_EUNSUPPORTED;
-        }
+        if constexpr (A_KM == B_KM) g2_launch_dma<A_KM, B_KM, true>(g, wm, wn, blocks, stream);
+        else return PM_EUNSUPPORTED;
         PM_CHECK_LAUNCH();
         return PM_OK;
     }
     const dim3 grid(blocks), blk(256);
-    if (dma && big) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 2>), grid, dim3(512), 0, pm_stream(stream), g);
-    else if (dma) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 1>), grid, dim3(512), 0, pm_stream(stream), g);
+    if (dma) g2_launch_dma<A_KM, B_KM, false>(g, wm, wn, blocks, stream);
     else if (big && vec) hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 2, 2, true>), grid, blk, 0, pm_stream(stream), g);
     else if (big) hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 2, 2, false>), grid, blk, 0, pm_stream(stream), g);
     else if (vec) hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 1, 1, true>), grid, blk, 0, pm_stream(stream), g);

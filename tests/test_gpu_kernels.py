@@ -52,7 +52,10 @@ def test_gae_golden_bit_exact(name):
         assert np.array_equal(st.advantages.cpu().numpy(), fx["advantages"])
 
 
-@pytest.mark.parametrize("T,N,succ", [(128, 4096, None), (8, 4096, 500.0), (64, 256, 0), (3, 1, None), (5, 67, 2.5)])
+# (300, 37) / (129, 16) / (257, 4100): several 128-step chunks with the chain state carried across them, ragged last chunk,
+# env counts that are not a multiple of the 16 envs a work-group owns
+@pytest.mark.parametrize("T,N,succ", [(128, 4096, None), (8, 4096, 500.0), (64, 256, 0), (3, 1, None), (5, 67, 2.5),
+                                      (300, 37, None), (129, 16, 3.0), (257, 4100, None), (1, 5, 1.0)])
 def test_gae_full_size_vs_oracle(T, N, succ):
     g = torch.Generator().manual_seed(T * 1000 + N)
     rewards, values = torch.randn(T, N, 1, generator=g), torch.randn(T, N, 1, generator=g)
