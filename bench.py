@@ -238,12 +238,14 @@ def run_dagger(args, device, rank, world):
         bfl = 2.0 * ffl - 2.0 * macs["conv0"]
         if t and b:
             tf = (ffl + bfl) / ((t[0] + b[0]) * 1e-3) / 1e12
-            out["roofline"] = dict(bound="mfma", kernel="SparseUNet forward + backward (row gathers + gemm2 Linear kernels)",
+            out["roofline"] = dict(bound="mfma", kernel="SparseUNet forward + backward (gemm2_dma_kernel with fused neighbour gathers)",
                                    achieved=tf, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS, traffic=None,
                                    launches=t[1], fwd_mean_ms=t[0], bwd_mean_ms=b[0], level_rows=[R0, R1, R2],
                                    flops_fwd=ffl, flops_bwd=bfl,
-                                   note="unfused first version: every sparse convolution materialises its gathered (rows x J*C) "
-                                        "operand in HBM; the GEMMs run at the Linear kernels' rate, the gathers are HBM-bound")
+                                   note="3^3 / strided convolutions gather their neighbour rows inside the GEMM's LDS-DMA loader "
+                                        "(forward, weight gradient and the 3^3 data gradient through the mirrored table): no column "
+                                        "matrix in HBM except conv0's 108-wide one and the strided layers' data gradients; "
+                                        "kernel = gemm2_dma_kernel<..., GATHER>, 128 x 64 tiles on the 64-channel levels")
     else:
         t = ops.TIMER.mean_ms("pointnet_enc_fwd")
         if t:

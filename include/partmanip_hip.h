@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 124 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 125 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -433,6 +433,13 @@ int pm_rows_gather_f32(const float* src, long lds, const int32_t* idx, long rows
  *   bwd_weight: dW[n][j*C + c] = sum_r dY[r][n] * src[idx[r][j]][c],  db[n] = sum_r dY[r][n]   (db may be NULL) */
 int pm_sparse_conv_fwd_f32(const float* src, long lds, const int32_t* idx, long rows, int J, int C, const float* W, long ldw,
                            const float* b, float* Y, long ldy, int N, int act, const float* zero, void* stream);
+/* Data gradient of a submanifold convolution as a gathered GEMM (no column matrix in HBM):
+ *   dX[s][ci] = (sum_{j,co} dY[idxT[s][j]][co] * Wt[ci][j*Cout + co]) * act'(H[s][ci])
+ * idxT = the mirrored neighbour table (idxT[s][j] = idx[s][J-1-j], all -1 for rows that are nobody's neighbour),
+ * Wt[ci][j*Cout + co] = W[co][j*Cin + ci] (row idxT[s][j] read s through ITS tap j); H = the activation the layer read (NULL: no factor).  (J*Cout) % 32 == 0. */
+int pm_sparse_conv_bwd_data_f32(const float* dY, long lddy, const int32_t* idxT, long rows, int J, int Cout, const float* Wt,
+                                long ldwt, const float* H, long ldh, float* dX, long lddx, int Cin, int act, const float* zero,
+                                void* stream);
 size_t pm_sparse_conv_bwd_weight_workspace_bytes(long rows, int N, int J, int C);
 int pm_sparse_conv_bwd_weight_f32(const float* dY, long lddy, const float* src, long lds, const int32_t* idx, long rows, int J,
                                   int C, float* dW, long lddw, float* db, int N, const float* zero, void* workspace,

@@ -84,6 +84,7 @@ SIGNATURES = {
     "pm_voxel_down_build_i32": (I, [P, L, P, I, I, I, P, P, L, P, P, P, P, P, P]),
     "pm_rows_gather_f32": (I, [P, L, P, L, I, I, P, L, P]),
     "pm_sparse_conv_fwd_f32": (I, [P, L, P, L, I, I, P, L, P, P, L, I, I, P, P]),
+    "pm_sparse_conv_bwd_data_f32": (I, [P, L, P, L, I, I, P, L, P, L, P, L, I, I, P, P]),
     "pm_sparse_conv_bwd_weight_workspace_bytes": (Z, [L, I, I, I]),
     "pm_sparse_conv_bwd_weight_f32": (I, [P, L, P, L, P, L, I, I, P, L, P, I, P, P, Z, P]),
     "pm_rows_gather_bwd_f32": (I, [P, L, P, P, I, I, I, L, I, I, P, L, I, P, L, P]),
@@ -131,7 +132,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 124                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 125                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -592,6 +592,27 @@ class SparseUNet(_HipNet):
         return dict(feat0=feat0, nbr0=ops.voxel_nbr27(coords0, grid0, R), nbr1=ops.voxel_nbr27(l1["coords"], l1["grid"], l1["R"]),
                     nbr2=ops.voxel_nbr27(l2["coords"], l2["grid"], l2["R"]), l1=l1, l2=l2, rows=(B * P, l1["rows"], l2["rows"]))
 
+    @staticmethod
+    def _mirror(nbr):
+        """Mirrored neighbour table for the data gradient: row r reads s as neighbour j  <=>  s reads r as neighbour 26 - j,
+        so the rows whose output used s are nbr[s].flip.  A row that is nobody's neighbour (a duplicate coordinate: its centre
+        tap points at the canonical row, not at itself) gets -1 everywhere and a gradient of exactly zero."""
+        canon = nbr[:, 13] == torch.arange(nbr.shape[0], device=nbr.device, dtype=nbr.dtype)
+        return torch.where(canon[:, None], nbr.flip(1), torch.full_like(nbr, -1)).contiguous()
+
+    def _conv_dgrad(self, name, dz, nbr, y_in, dx):
+        """dx = d loss / d (pre-activation of the layer that produced y_in) of the 3^3 convolution `name`, dz its output
+        gradient: fused -- a gathered GEMM through the mirrored table, the (rows x 27*C_in) column gradient never exists --
+        or, with fused_gather off, the Linear data gradient + the mirrored column gather."""
+        lin = getattr(self, name)
+        cout, cin = lin.weight.shape[0], lin.weight.shape[1] // 27
+        if self.fused_gather and (27 * cout) % 32 == 0:
+            wt = lin.weight.data.view(cout, 27, cin).permute(2, 1, 0).reshape(cin, 27 * cout).contiguous()
+            return ops.sparse_conv_bwd_data(dz, self._mirror(nbr), wt, y_in, dx, self._act, self._zero(dz.device))
+        dcols = torch.empty(dz.shape[0], 27 * cin, device=dz.device)
+        ops.linear_bwd_data(dz, lin.weight.data, None, dcols, ops.ACT_NONE)
+        return ops.rows_gather_bwd(dcols, nbr, cin, dx, reverse=True, self_col=13, y_tanh=y_in)
+
     def _lin(self, name, x, y):
         lin = getattr(self, name)
         ops.linear_fwd(x, lin.weight.data, lin.bias.data, y, self._act)
@@ -685,10 +706,7 @@ class SparseUNet(_HipNet):
         ops.linear_bwd_data(dzE1, W("up1"), cat1, dcat1, ops.ACT_TANH)
         dzH2 = ops.rows_gather_bwd(dcat1[:, :c2], g["l2"]["child"], c2, torch.empty_like(s["D2"]), mode=2)
         self._conv_wgrad("conv2", dzH2, s["D2"], g["nbr2"], c2, s["cols2"], ws)
-        dcols2 = torch.empty(dzH2.shape[0], 27 * c2, device=dy.device)
-        ops.linear_bwd_data(dzH2, W("conv2"), None, dcols2, ops.ACT_NONE)
-        dzD2 = ops.rows_gather_bwd(dcols2, g["nbr2"], c2, torch.empty_like(s["D2"]), reverse=True, self_col=13, y_tanh=s["D2"])
-        del dcols2
+        dzD2 = self._conv_dgrad("conv2", dzH2, g["nbr2"], s["D2"], torch.empty_like(s["D2"]))
         self._conv_wgrad("down1", dzD2, cat1[:, c2:], g["l2"]["child"], c1, s["colsd1"], ws)
         dcolsd1 = torch.empty(dzD2.shape[0], 8 * c1, device=dy.device)
         ops.linear_bwd_data(dzD2, W("down1"), None, dcolsd1, ops.ACT_NONE)
@@ -696,10 +714,7 @@ class SparseUNet(_HipNet):
         ops.rows_gather_bwd(dcolsd1, g["l2"]["parent_canon"].view(-1, 1), c1, dzH1, tslot=g["l2"]["slot"].view(-1, 1), mode=1,
                             y_tanh=cat1[:, c2:], accumulate=True)
         self._conv_wgrad("conv1", dzH1, s["D1"], g["nbr1"], c1, s["cols1"], ws)
-        dcols1 = torch.empty(dzH1.shape[0], 27 * c1, device=dy.device)
-        ops.linear_bwd_data(dzH1, W("conv1"), None, dcols1, ops.ACT_NONE)
-        dzD1 = ops.rows_gather_bwd(dcols1, g["nbr1"], c1, torch.empty_like(s["D1"]), reverse=True, self_col=13, y_tanh=s["D1"])
-        del dcols1
+        dzD1 = self._conv_dgrad("conv1", dzH1, g["nbr1"], s["D1"], torch.empty_like(s["D1"]))
         self._conv_wgrad("down0", dzD1, cat0[:, c1:], g["l1"]["child"], c0, s["colsd0"], ws)
         dcolsd0 = torch.empty(dzD1.shape[0], 8 * c0, device=dy.device)
         ops.linear_bwd_data(dzD1, W("down0"), None, dcolsd0, ops.ACT_NONE)

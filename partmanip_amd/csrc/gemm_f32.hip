@@ -301,6 +301,32 @@ extern "C" int pm_sparse_conv_fwd_f32(const float* src, long lds, const int32_t*
     return gemm2_launch(gg, false, false, stream);
 }
 
+// data gradient of a submanifold convolution as a gathered GEMM of its own (no (rows x J*C_in) column matrix in HBM):
+//   dX[s][ci] = (sum_{j,co} dY[idxT[s][j]][co] * Wt[ci][j*Cout + co]) * act'(H[s][ci])
+// with the MIRRORED neighbour table idxT[s][j] = idx[s][J-1-j] (row r reads s as its neighbour j  <=>  s reads r as its
+// neighbour J-1-j; rows that are nobody's neighbour -- duplicates -- carry -1 everywhere) and the per-tap transposed weight
+// view Wt[ci][j*Cout + co] = W[co][j*Cin + ci] (row idxT[s][j] read s through ITS tap j), both built by the caller.  H = the layer input's activation (NULL / act
+// NONE: no factor).
+extern "C" int pm_sparse_conv_bwd_data_f32(const float* dY, long lddy, const int32_t* idxT, long rows, int J, int Cout,
+                                           const float* Wt, long ldwt, const float* H, long ldh, float* dX, long lddx, int Cin,
+                                           int act, const float* zero, void* stream) {
+    PM_REQUIRE(dY && idxT && Wt && dX && zero && rows > 0 && rows < 0x7fffffffL && J > 0 && Cout > 0 && Cin > 0 && lddy >= Cout &&
+               ldwt >= (long)J * Cout && lddx >= Cin && act >= PM_ACT_NONE && act <= PM_ACT_MAX);
+    PM_REQUIRE(Cout % 4 == 0 && (J * Cout) % 32 == 0 && lddy % 4 == 0 && ldwt % 4 == 0);
+    PM_REQUIRE(!H || ldh >= Cin);
+    if (!aligned16(dY) || !aligned16(Wt) || !aligned16(zero)) return PM_EALIGN;
+    Gemm2Group gg{};
+    gg.n = 1;
+    Gemm2Prob& g = gg.p[0];
+    g.A = dY; g.lda = lddy; g.B = Wt; g.ldb = ldwt; g.C = dX; g.ldc = lddx;
+    g.M = (int)rows; g.N = Cin; g.K = J * Cout; g.splits = 1;
+    g.epi = (H && act != PM_ACT_NONE) ? G2_EPI_MUL_DACT : G2_EPI_PLAIN;
+    g.act = act; g.H = H; g.ldh = ldh;
+    g.vecA = g.vecB = 1;
+    g.gidx = idxT; g.gzero = zero; g.gJ = J; g.gC = Cout;
+    return gemm2_launch(gg, false, false, stream);
+}
+
 extern "C" size_t pm_sparse_conv_bwd_weight_workspace_bytes(long rows, int N, int J, int C) {
     return pm_linear_bwd_weight_workspace_bytes((int)rows, N, J * C);
 }

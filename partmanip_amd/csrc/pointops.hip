@@ -415,9 +415,52 @@ __global__ __launch_bounds__(256) void maxpool_rows_kernel(const float* __restri
     }
 }
 
+// Long groups (a whole cloud's rows: the SparseUNet's feature pooling, ns = 4096): one work-group per group, thread
+// (chunk = t / C, c = t % C) scans rows chunk, chunk + 256/C, ... -- a wave reads whole consecutive rows -- and the 256/C
+// candidates of a channel meet in LDS.  Same result as the serial scan: the greatest value, the lowest row among equals.
+__global__ __launch_bounds__(256) void maxpool_rows_long_kernel(const float* __restrict__ x, int ns, int C,
+                                                                 float* __restrict__ out, long ldo, int32_t* __restrict__ arg) {
+    __shared__ float sm[256];
+    __shared__ int sa[256];
+    const long g = blockIdx.x;
+    const int t = threadIdx.x, tpc = 256 / C, chunk = t / C, c = t - chunk * C;
+    const float* p = x + g * ns * C + c;
+    float m = -INFINITY;
+    int am = 0x7fffffff;
+    int j = chunk;
+    for (; j + 3 * tpc < ns; j += 4 * tpc) {
+        const float v0 = p[(long)j * C], v1 = p[(long)(j + tpc) * C], v2 = p[(long)(j + 2 * tpc) * C], v3 = p[(long)(j + 3 * tpc) * C];
+        if (v0 > m || am == 0x7fffffff) { m = v0; am = j; }
+        if (v1 > m) { m = v1; am = j + tpc; }
+        if (v2 > m) { m = v2; am = j + 2 * tpc; }
+        if (v3 > m) { m = v3; am = j + 3 * tpc; }
+    }
+    for (; j < ns; j += tpc) {
+        const float v = p[(long)j * C];
+        if (v > m || am == 0x7fffffff) { m = v; am = j; }
+    }
+    sm[t] = m;
+    sa[t] = am;
+    __syncthreads();
+    if (t < C) {
+        for (int k = 1; k < tpc; ++k) {
+            const float v = sm[k * C + t];
+            const int a = sa[k * C + t];
+            if (a != 0x7fffffff && (am == 0x7fffffff || v > m || (v == m && a < am))) { m = v; am = a; }
+        }
+        out[g * ldo + t] = m;
+        arg[g * C + t] = am;
+    }
+}
+
 extern "C" int pm_maxpool_rows_f32(const float* x, long G, int nsample, int C, float* out, long ldo, int32_t* arg,
                                    void* stream) {
     PM_REQUIRE(x && out && arg && G > 0 && nsample > 0 && C > 0 && ldo >= C);
+    if (nsample >= 256 && C <= 256 && 256 % C == 0 && G < 0x7fffffffL) {
+        hipLaunchKernelGGL(maxpool_rows_long_kernel, dim3((unsigned)G), dim3(256), 0, pm_stream(stream), x, nsample, C, out, ldo, arg);
+        PM_CHECK_LAUNCH();
+        return PM_OK;
+    }
     long nb = (G * C + 255) / 256;
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(maxpool_rows_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), x, G, nsample, C, out,

@@ -567,6 +567,18 @@ def sparse_conv_fwd(src, idx, C, w, b, y, act, zero):
     return y
 
 
+def sparse_conv_bwd_data(dy, idx_t, wt, h, dx, act, zero):
+    """dx = (gather(dy, idx_t) @ wt.T) * act'(h): the data gradient of a submanifold convolution through the mirrored table
+    `idx_t` and the transposed weight view `wt` (C_in, J*C_out), wt[ci, j*C_out + co] = w[co, j*C_in + ci] -- see pm_sparse_conv_bwd_data_f32."""
+    _req(dy, idx_t, wt, h, dx, zero)
+    rows, J = idx_t.shape
+    Cout = dy.shape[1]
+    check(lib.pm_sparse_conv_bwd_data_f32(_ptr(dy), _rows(dy, "dy"), _ptr(idx_t), rows, J, Cout, _ptr(wt), _rows(wt, "wt"), _ptr(h),
+                                          _rows(h, "h") if h is not None else 0, _ptr(dx), _rows(dx, "dx"), wt.shape[0], int(act),
+                                          _ptr(zero), _stream()), "pm_sparse_conv_bwd_data_f32")
+    return dx
+
+
 def sparse_conv_bwd_weight(dy, src, idx, C, dw, db, zero, ws):
     _req(dy, src, idx, dw, db, zero)
     rows, J = idx.shape

@@ -560,3 +560,16 @@ def test_skinny_linear_layers(M, K, N, act):
     rdw, rdb = dy.double().t() @ x.double(), dy.double().sum(0)
     assert float((dw.double() - rdw).abs().max()) < 3e-5 * max(1.0, float(rdw.abs().max()))
     assert float((db.double() - rdb).abs().max()) < 3e-5 * max(1.0, float(rdb.abs().max()))
+
+
+@pytest.mark.parametrize("G,ns,C", [(5, 4096, 32), (3, 300, 64), (2, 257, 256), (7, 1024, 16), (4, 32, 32), (3, 700, 24)])
+def test_maxpool_rows_value_and_lowest_arg(G, ns, C):
+    """Pooling over a group's rows (long groups: one work-group per group, chunked scan + LDS merge; short ones / channel counts
+    that do not divide 256: the serial scan): the greatest value and the LOWEST row attaining it (values quantised -> many ties)."""
+    g = torch.Generator().manual_seed(G * 31 + ns)
+    x = (torch.randn(G * ns, C, generator=g) * 4).round() / 4
+    out = torch.empty(G, C + 3, device=DEV)[:, :C]
+    arg = ops().maxpool_rows(x.to(DEV), G, ns, out)
+    xr = x.view(G, ns, C).numpy()
+    np.testing.assert_array_equal(out.cpu().numpy(), xr.max(1))
+    np.testing.assert_array_equal(arg.cpu().numpy(), xr.argmax(1).astype(np.int32))
