@@ -626,6 +626,16 @@ class SparseUNet(_HipNet):
         if self.fused_gather and (idx.shape[1] * C) % 32 == 0:
             ops.sparse_conv_fwd(src, idx, C, lin.weight.data, lin.bias.data, y, self._act, self._zero(src.device))
             return None
+        pad = (-idx.shape[1] * C) % 32
+        if self.fused_gather and pad % C == 0:
+            # conv0: 27 taps x 4 input channels = 108 columns; five absent taps (index -1 -> zero rows) and zero weight columns
+            # make it 128 = four K-steps, and the layer runs fused like the others.  Returns the padded table for the
+            # weight gradient.
+            idx_p = torch.nn.functional.pad(idx, (0, pad // C), value=-1)
+            w_p = torch.zeros(lin.weight.shape[0], idx_p.shape[1] * C, device=src.device)
+            w_p[:, :lin.weight.shape[1]].copy_(lin.weight.data)
+            ops.sparse_conv_fwd(src, idx_p, C, w_p, lin.bias.data, y, self._act, self._zero(src.device))
+            return idx_p
         cols = ops.rows_gather(src, idx, C, torch.empty(idx.shape[0], idx.shape[1] * C, device=src.device))
         self._lin(name, cols, y)
         return cols
@@ -634,6 +644,10 @@ class SparseUNet(_HipNet):
         dW, db = self._g[name]
         if cols is None:
             ops.sparse_conv_bwd_weight(dz, src, idx, C, dW, db, self._zero(src.device), ws)
+        elif cols.dtype == torch.int32:                       # the padded table of a fused layer with a ragged K (conv0)
+            dW_p = torch.empty(dW.shape[0], cols.shape[1] * C, device=src.device)
+            ops.sparse_conv_bwd_weight(dz, src, cols, C, dW_p, db, self._zero(src.device), ws)
+            dW.copy_(dW_p[:, :dW.shape[1]])
         else:
             ops.linear_bwd_weight(dz, cols, dW, db, ws)
 
