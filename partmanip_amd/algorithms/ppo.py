@@ -118,6 +118,11 @@ class ppo:
         # the two-stream form -- kernels of DIFFERENT kinds co-scheduled from two streams fill the CUs better than two
         # problems of the same kind in one grid -- so the two streams stay the default.
         self.pair = is_mlp and self.sync is None and os.environ.get("PARTMANIP_PAIR", "0") == "1"
+        # ... and the same grouping WITHOUT pairing the networks (PARTMANIP_SOLO_GROUP, default on for MLP backbones without a
+        # collective in the step): each network keeps its stream, but its four weight gradients are one or two grouped launches
+        # whose split-K slabs the grouped optimiser launch sums -- no slab-reduce launches (4 per step, 12 % of the kernel time
+        # at cfg 2), no separate norm pass.
+        self.solo_group = is_mlp and self.sync is None and os.environ.get("PARTMANIP_SOLO_GROUP", "1") == "1"
         # neighbourhood tables (FPS centres + ball-query indices) once per rollout; PARTMANIP_GEOM_CACHE=0 recomputes
         # them in every forward (A/B; identical results)
         self.cache_geometry = os.environ.get("PARTMANIP_GEOM_CACHE", "1") != "0"
@@ -248,6 +253,14 @@ class ppo:
         ops.ppo_actor_loss(mu, ac.log_std.data, mb['actions'], mb['old_logp'], mb['adv'], mb['old_mu'],
                            mb['old_sigma'], ac.max_action, ac.action_activate == 'tanh', self.epsilon_clip,
                            self.desired_kl, mom, cnt, scal_a, dmu, f['grad_log_std'], self._ws_loss)
+        if self.solo_group:
+            S = ac.GRAD_SLABS if B >= 1024 else 1
+            chains_backward([ac.actor._chain], [dmu], [f['slab_stride_actor']], S)
+            ops.ppo_accumulate_stats(self._acc, scal_a, 0)
+            ops.clip_adam_group([self.optimizer_actor.group_item(
+                n=n_a + A, n_clip=n_a if clip else 0, max_norm=self.max_grad_norm if clip else 0.0, skip_flag=scal_a[2:3],
+                extra=f['extra_actor'], extra_stride=f['slab_stride_actor'], n_sum=n_a, n_extra=S - 1)])
+            return
         ac.actor.hip_backward(dmu)
         if sync:                                              # ONE all-reduce: grads + loss/kl in the tail
             sync.mean_(f['grad_actor'])
@@ -273,6 +286,14 @@ class ppo:
         dv = torch.empty(B, 1, device=value.device)
         ops.value_loss(value, mb['returns'], mb['values'], tricks['use_clipped_value_loss'], self.epsilon_clip,
                        clip_mean, 1.0, scal_c, dv)
+        if self.solo_group:
+            S = ac.GRAD_SLABS if B >= 1024 else 1
+            chains_backward([ac.critic._chain], [dv], [f['slab_stride_critic']], S)
+            ops.ppo_accumulate_stats(self._acc, scal_c, 1)
+            ops.clip_adam_group([self.optimizer_critic.group_item(
+                n=n_c, n_clip=n_c if clip else 0, max_norm=self.max_grad_norm if clip else 0.0, extra=f['extra_critic'],
+                extra_stride=f['slab_stride_critic'], n_sum=n_c, n_extra=S - 1)])
+            return
         ac.critic.hip_backward(dv)
         if sync:
             sync.mean_(f['grad_critic'])
