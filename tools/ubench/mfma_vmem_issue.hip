@@ -8,7 +8,8 @@
 // Measured (MI355X, 256 work-groups): 32.5 / 64.0 cycles per bare 16x16x4 / 32x32x2 MFMA per SIMD; one global_load_dwordx4 per
 // four MFMAs adds 32-39 cycles per load, of which its VALU companions are 11-18: the load instruction itself takes ~21-23
 // cycles out of the SIMD's MFMA issue; a ds_read_b128 ~17.  Neither waits for data.  (pn_bwd16_kernel's dh1 loop: 27 per
-// B-fragment load with its 64-bit address add -- DESIGN.md 3.2.)
+// B-fragment load with its 64-bit address add -- DESIGN.md 3.2.)  By width (net of the companions): ds_read_b32 5.6, b64 10.8,
+// b128 15.5; global_load_dword 7.1, x2 14.5, x4 21.3 -- about 4-5 cycles per VGPR a load writes, whichever path it takes.
 // Build: hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tools/ubench/mfma_vmem_issue.hip -o gpurun_ab/mfma_vmem_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -54,6 +55,10 @@ __global__ __launch_bounds__(1024, 1) void k(int iters, const float4* __restrict
                 if (LOAD == 1) dst[j] = gp[ctr & 4095];
                 if (LOAD == 2) dst[j] = lds[ctr & 4095];
                 if (LOAD == 3) dst[j].x = __builtin_bit_cast(float, ctr & 4095);      // the companions alone: no load
+                if (LOAD == 4) dst[j].x = ((const float*)lds)[ctr & 16383];            // ds_read_b32
+                if (LOAD == 5) *(float2*)&dst[j] = ((const float2*)lds)[ctr & 8191];   // ds_read_b64
+                if (LOAD == 6) dst[j].x = ((const float*)gp)[ctr & 16383];             // global_load_dword
+                if (LOAD == 7) *(float2*)&dst[j] = ((const float2*)gp)[ctr & 8191];    // global_load_dwordx2
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -109,5 +114,12 @@ int main() {
     }
     ROW(0)
     ROW(1)
+    {   // width sweep beside 32x32x2 MFMAs, two loads per four MFMAs, companions subtracted: cycles per load by bytes per lane
+        const double b = run<1, 3, 2>(iters, g, out, cyc, nblk);
+        printf("per load, net of the VALU companions: ds_read_b32 %.1f  b64 %.1f  b128 %.1f | global_load_dword %.1f  x2 %.1f  x4 %.1f\n",
+               (run<1, 4, 2>(iters, g, out, cyc, nblk) - b) * 2, (run<1, 5, 2>(iters, g, out, cyc, nblk) - b) * 2,
+               (run<1, 2, 2>(iters, g, out, cyc, nblk) - b) * 2, (run<1, 6, 2>(iters, g, out, cyc, nblk) - b) * 2,
+               (run<1, 7, 2>(iters, g, out, cyc, nblk) - b) * 2, (run<1, 1, 2>(iters, g, out, cyc, nblk) - b) * 2);
+    }
     return 0;
 }
