@@ -573,3 +573,44 @@ def test_maxpool_rows_value_and_lowest_arg(G, ns, C):
     xr = x.view(G, ns, C).numpy()
     np.testing.assert_array_equal(out.cpu().numpy(), xr.max(1))
     np.testing.assert_array_equal(arg.cpu().numpy(), xr.argmax(1).astype(np.int32))
+
+
+@pytest.mark.parametrize("rows,J,C,N", [(1000, 27, 32, 32), (333, 8, 32, 64), (4097, 27, 64, 64), (700, 32, 4, 32), (129, 27, 32, 128)])
+def test_sparse_conv_entry_points_against_torch(rows, J, C, N):
+    """The three gathered-GEMM entry points (the (rows x J*C) operand exists only inside the LDS-DMA loader) against a plain
+    torch fp32 gather + matmul of the same op: random neighbour tables with ~30 % absent neighbours (-1 -> zero rows),
+    row counts that do not fill the 128 / 64-row tiles."""
+    o = ops()
+    g = torch.Generator().manual_seed(rows + J)
+    nsrc = rows + 17
+    src = torch.randn(nsrc, C, generator=g)
+    idx = torch.randint(0, nsrc, (rows, J), generator=g, dtype=torch.int32)
+    idx[torch.rand(rows, J, generator=g) < 0.3] = -1
+    w = torch.randn(N, J * C, generator=g) / (J * C) ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    zero = torch.zeros(256, device=DEV)
+    srcp = torch.cat([src, torch.zeros(1, C)])                       # index -1 -> the appended zero row
+    cols = srcp[idx.long()].reshape(rows, J * C)
+    # forward (+ bias + tanh)
+    y = torch.empty(rows, N, device=DEV)
+    o.sparse_conv_fwd(src.to(DEV), idx.to(DEV), C, w.to(DEV), b.to(DEV), y, o.ACT_TANH, zero)
+    # (reference in fp64: the fp32 round-off of a K = J*C reduction, ~1e-6 at K = 1728, is the only difference)
+    np.testing.assert_allclose(y.cpu().numpy(), torch.tanh(cols.double() @ w.double().t() + b.double()).numpy(), rtol=2e-5, atol=1e-5)
+    # weight gradient
+    dy = torch.randn(rows, N, generator=g)
+    dw, db = torch.empty(N, J * C, device=DEV), torch.empty(N, device=DEV)
+    o.sparse_conv_bwd_weight(dy.to(DEV), src.to(DEV), idx.to(DEV), C, dw, db, zero, o.Workspace(DEV))
+    ref = dy.double().t() @ cols.double()
+    assert rel_err(dw, ref) < 2e-5 and rel_err(db, dy.double().sum(0)) < 2e-5
+    # data-gradient form: dx = (gather(dy, idx_t) @ wt.T) * (1 - h^2), dy rows N wide, output C wide
+    idx_t = torch.randint(0, rows, (rows, J), generator=g, dtype=torch.int32)
+    idx_t[torch.rand(rows, J, generator=g) < 0.3] = -1
+    idx_t[5] = -1                                                     # a row that is nobody's neighbour: exactly zero
+    wt = torch.randn(C, J * N, generator=g) / (J * N) ** 0.5
+    h = torch.tanh(torch.randn(rows, C, generator=g))
+    dx = torch.empty(rows, C, device=DEV)
+    o.sparse_conv_bwd_data(dy.to(DEV), idx_t.to(DEV), wt.to(DEV), h.to(DEV), dx, o.ACT_TANH, zero)
+    dyp = torch.cat([dy, torch.zeros(1, N)])
+    refx = (dyp[idx_t.long()].reshape(rows, J * N).double() @ wt.double().t()) * (1 - h.double() ** 2)
+    assert rel_err(dx, refx) < 2e-5
+    assert float(dx[5].abs().max()) == 0.0
