@@ -780,9 +780,55 @@ class Conv3DNet(_HipNet):
         object.__setattr__(self, "_head", _LinearChain([self.final_mlp[0], self.final_mlp[2]], code))
         object.__setattr__(self, "_conv_grads", None)
         object.__setattr__(self, "_w1p", None)
+        self.fused_gather = bool(net_cfg.get('fused_gather', True))         # False: im2col + Linear for layers 2-3 (A/B)
 
     def _convs(self):
         return [self.encoder.conv1, self.encoder.conv2, self.encoder.conv3]
+
+    def _zero(self, device):
+        z = getattr(self, "_zero_row", None)
+        if z is None or z.device != device:
+            z = torch.zeros(128, device=device)
+            object.__setattr__(self, "_zero_row", z)
+        return z
+
+    def _patch_table(self, B, n, k, stride, pad, cin, device):
+        """(B*no^3, J) int32: row of the channels-last input (b, d, h, w) under tap (kd, kh, kw) of output (b, od, oh, ow), -1
+        in the padding; J = k^3 rounded up so that J*cin is whole K-steps of 32 (extra taps are -1).  Depends on the batch
+        size and the geometry only: cached."""
+        key = (B, n, k, stride, pad, cin, str(device))
+        cache = getattr(self, "_tables", None)
+        if cache is None:
+            cache = {}
+            object.__setattr__(self, "_tables", cache)
+        if key not in cache:
+            no = ops.conv3d_out(n, k, stride, pad)
+            o = torch.arange(no, device=device) * stride - pad
+            t = torch.arange(k, device=device)
+            p = o[:, None] + t[None, :]                                       # (no, k) input coordinate per (output, tap)
+            ok = (p >= 0) & (p < n)
+            d, h, w = p[:, None, None, :, None, None], p[None, :, None, None, :, None], p[None, None, :, None, None, :]
+            okk = ok[:, None, None, :, None, None] & ok[None, :, None, None, :, None] & ok[None, None, :, None, None, :]
+            lin = ((d * n + h) * n + w).expand(no, no, no, k, k, k)
+            lin = torch.where(okk, lin, torch.full_like(lin, -1)).reshape(no ** 3, k ** 3)
+            b = torch.arange(B, device=device)[:, None, None] * n ** 3
+            idx = torch.where(lin[None] >= 0, lin[None] + b, lin[None]).reshape(B * no ** 3, k ** 3)
+            jp = k ** 3
+            while (jp * cin) % 32:
+                jp += 1
+            if jp > k ** 3:
+                idx = torch.nn.functional.pad(idx, (0, jp - k ** 3), value=-1)
+            cache[key] = (idx.to(torch.int32).contiguous(), jp)
+        return cache[key]
+
+    @staticmethod
+    def _tap_major(conv, jp):
+        """conv.weight (Cout, Cin, k, k, k) as (Cout, jp*Cin) with columns (tap, c), zero columns for the padding taps."""
+        co, ci = conv.out_channels, conv.in_channels
+        k3 = conv.weight[0, 0].numel()
+        wp = torch.zeros(co, jp * ci, device=conv.weight.device)
+        wp[:, :k3 * ci].view(co, k3, ci).copy_(conv.weight.data.view(co, ci, k3).transpose(1, 2))
+        return wp
 
     def set_grad_views(self, views):
         self._head.grads = [(views[f"final_mlp.{i}.weight"], views[f"final_mlp.{i}.bias"]) for i in (0, 2)]
@@ -810,6 +856,17 @@ class Conv3DNet(_HipNet):
                 # the single-channel input layer runs as a direct stencil: no 4 GB patch matrix (csrc/conv3d.hip)
                 y = ops.conv3d_c1_fwd(cur, k, st, k // 2, w1.t().contiguous(), conv.bias.data, self._act)
                 saved.append((cur, None, y))
+                cur = y.view(B, e, e, e, conv.out_channels).permute(0, 4, 1, 2, 3)
+                continue
+            if i > 0 and self.fused_gather and conv.in_channels % 4 == 0:
+                # layers 2-3 read channels-last rows of the previous layer: the patch gather runs inside the GEMM's LDS-DMA
+                # loader (the same gathered operand as the sparse convolutions), no patch matrix in HBM
+                idx, jp = self._patch_table(B, ext[i], k, st, k // 2, conv.in_channels, x.device)
+                wp = self._tap_major(conv, jp)
+                src = saved[i - 1][2]
+                y = torch.empty(idx.shape[0], conv.out_channels, device=x.device)
+                ops.sparse_conv_fwd(src, idx, conv.in_channels, wp, conv.bias.data, y, self._act, self._zero(x.device))
+                saved.append((cur, idx, y))
                 cur = y.view(B, e, e, e, conv.out_channels).permute(0, 4, 1, 2, 3)
                 continue
             w = self._w1p if i == 0 else conv.weight.data.view(conv.out_channels, -1)
@@ -845,8 +902,15 @@ class Conv3DNet(_HipNet):
                 ops.linear_bwd_weight(dz, cols, dwp, db, ws)
                 dW.view(conv.out_channels, -1).copy_(dwp[:, :dW[0].numel()])
                 break                                                        # the volume is data: no gradient to it
-            ops.linear_bwd_weight(dz, cols, dW.view(conv.out_channels, -1), db, ws)
-            dcols = torch.empty_like(cols)
+            if cols.dtype == torch.int32:                                    # fused layer: `cols` is its patch table
+                cin, k3 = conv.in_channels, k ** 3
+                dwp = torch.empty(conv.out_channels, cols.shape[1] * cin, device=dy.device)
+                ops.sparse_conv_bwd_weight(dz, saved[i - 1][2], cols, cin, dwp, db, self._zero(dy.device), ws)
+                dW.view(conv.out_channels, cin, k3).copy_(dwp[:, :k3 * cin].view(conv.out_channels, k3, cin).transpose(1, 2))
+                dcols = torch.empty(cols.shape[0], cin * k3, device=dy.device)
+            else:
+                ops.linear_bwd_weight(dz, cols, dW.view(conv.out_channels, -1), db, ws)
+                dcols = torch.empty_like(cols)
             ops.linear_bwd_data(dz, conv.weight.data.view(conv.out_channels, -1), None, dcols, ops.ACT_NONE)
             y_prev = saved[i - 1][2]                                          # this layer's input = previous tanh output
             dz = torch.empty_like(y_prev)
