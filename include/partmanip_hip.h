@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 125 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 128 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -320,14 +320,17 @@ int pm_tsdf_sparse_gather_f32(const float* coords, const int32_t* idx, const flo
  * wt = conv.weight viewed (Cout, k^3) TRANSPOSED to (k^3, Cout); y (B*Do*Ho*Wo, ldy) rows of Cout = act(conv + bias)
  * (channels-last, what the next layer's pm_im2col3d_f32 reads through strides).  pm_conv3d_c1_wgrad_f32: dW (Cout, lddw
  * >= k^3) and db (Cout, may be NULL) from dz (rows, lddz) = the gradient at this layer's pre-activation.  Instantiated
- * for k = 5, Cout = 16 (pm_conv3d_c1_supported); other shapes return PM_EUNSUPPORTED: use im2col + the Linear kernels. */
+ * for k = 5, Cout = 16 (pm_conv3d_c1_supported); other shapes return PM_EUNSUPPORTED: use im2col + the Linear kernels.
+ * batch_index (may be NULL): volume b of the batch is row batch_index[b] (stride sb) of a larger store -- DAgger's
+ * mini-batches are random rows of the ring (dagger.py:305-306): the 0.8 GB gathered copy of 1600 volumes is not made. */
 int pm_conv3d_c1_supported(int k, int Cout);
 size_t pm_conv3d_c1_wgrad_workspace_bytes(int Cout);
 int pm_conv3d_c1_fwd_f32(const float* x, int B, int D, int H, int W, int k, int stride, int pad, long sb, long sd, long sh,
-                         long sw, const float* wt, const float* bias, int Cout, int act, float* y, long ldy, void* stream);
+                         long sw, const float* wt, const float* bias, int Cout, int act, float* y, long ldy,
+                         const int64_t* batch_index, void* stream);
 int pm_conv3d_c1_wgrad_f32(const float* dz, long lddz, const float* x, int B, int D, int H, int W, int k, int stride,
                            int pad, long sb, long sd, long sh, long sw, int Cout, float* dW, long lddw, float* db,
-                           void* workspace, size_t workspace_bytes, void* stream);
+                           const int64_t* batch_index, void* workspace, size_t workspace_bytes, void* stream);
 /* ------------------------------------------------------------------ Conv3D students: patch gather / scatter
  * network.py:56-94 (`Conv3DNet` / `Encoder`: nn.Conv3d(k, stride, padding = k/2)).  A convolution runs as
  * cols = im2col(x) -> pm_linear_fwd_f32 with conv.weight viewed (Cout, Cin*k^3) -> rows (b, od, oh, ow) x Cout;
@@ -440,6 +443,12 @@ int pm_sparse_conv_fwd_f32(const float* src, long lds, const int32_t* idx, long 
 int pm_sparse_conv_bwd_data_f32(const float* dY, long lddy, const int32_t* idxT, long rows, int J, int Cout, const float* Wt,
                                 long ldwt, const float* H, long ldh, float* dX, long lddx, int Cin, int act, const float* zero,
                                 void* stream);
+/* Data gradient by scatter, for convolutions whose patches do not overlap (stride == kernel size): every input row is
+ * idx[r][j] for at most one (r, j), so  dX[idx[r][j]][c] = (sum_co dY[r][co] * W[co][j*C + c]) * act'(H[idx[r][j]][c])
+ * is one GEMM whose epilogue stores each 16-byte piece at its destination row (idx < 0: dropped; rows nobody maps to keep
+ * their contents).  W = the tap-major weight (Cout x J*C) of the forward. */
+int pm_sparse_conv_bwd_data_scatter_f32(const float* dY, long lddy, const float* W, long ldw, const int32_t* idx, long rows,
+                                        int J, int C, int Cout, const float* H, float* dX, int act, void* stream);
 size_t pm_sparse_conv_bwd_weight_workspace_bytes(long rows, int N, int J, int C);
 int pm_sparse_conv_bwd_weight_f32(const float* dY, long lddy, const float* src, long lds, const int32_t* idx, long rows, int J,
                                   int C, float* dW, long lddw, float* db, int N, const float* zero, void* workspace,

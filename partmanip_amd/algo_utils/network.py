@@ -835,8 +835,16 @@ class Conv3DNet(_HipNet):
         object.__setattr__(self, "_conv_grads", [(views[f"encoder.conv{i}.weight"], views[f"encoder.conv{i}.bias"])
                                                  for i in (1, 2, 3)])
 
-    def hip_forward(self, x, out=None):
-        B, r = x.shape[0], self.res
+    supports_row_index = True        # hip_forward(store, rows=idx): the batch is rows idx of `store`, read in place
+
+    def hip_forward(self, x, out=None, rows=None):
+        """rows (int64 device tensor, optional): the mini-batch is x[rows] -- DAgger draws random rows of its ring -- and the
+        input layer's kernels read those volumes where they lie (no 0.8 GB gathered copy per 1600-row mini-batch)."""
+        r = self.res
+        if rows is not None and not (self._act in (ops.ACT_NONE, ops.ACT_TANH) and r <= 64
+                                     and ops.conv3d_c1_supported(self.KERNELS[0], self.FILTERS[0])):
+            x, rows = x.index_select(0, rows), None
+        B = x.shape[0] if rows is None else rows.numel()
         vol = x[:, :r ** 3].unflatten(1, (1, r, r, r))                   # 5-D view (row stride = the obs width)
         convs, ext = self._convs(), self._ext
         # conv1's K = 125 is not a multiple of 4: a (16,128) zero-padded copy of the weight lets the GEMM use 16-B loads
@@ -854,7 +862,7 @@ class Conv3DNet(_HipNet):
             if (i == 0 and self._act in (ops.ACT_NONE, ops.ACT_TANH) and self.res <= 64
                     and ops.conv3d_c1_supported(k, conv.out_channels)):
                 # the single-channel input layer runs as a direct stencil: no 4 GB patch matrix (csrc/conv3d.hip)
-                y = ops.conv3d_c1_fwd(cur, k, st, k // 2, w1.t().contiguous(), conv.bias.data, self._act)
+                y = ops.conv3d_c1_fwd(cur, k, st, k // 2, w1.t().contiguous(), conv.bias.data, self._act, rows)
                 saved.append((cur, None, y))
                 cur = y.view(B, e, e, e, conv.out_channels).permute(0, 4, 1, 2, 3)
                 continue
@@ -878,8 +886,10 @@ class Conv3DNet(_HipNet):
         fbuf = torch.empty(B, 32 * 27 + self.proprio_shape, device=x.device)
         fbuf[:, :32 * 27].view(B, 32, 27).copy_(cur.reshape(B, 32, 27))           # channels-first flatten (network.py:88,90)
         if self.proprio_shape != 0:
-            fbuf[:, 32 * 27:].copy_(x[:, -self.proprio_shape:])
+            tail = x[:, -self.proprio_shape:]
+            fbuf[:, 32 * 27:].copy_(tail if rows is None else tail.index_select(0, rows))
         object.__setattr__(self, "_saved", saved)
+        object.__setattr__(self, "_rows_idx", rows)
         return self._head.forward(fbuf, out)
 
     def hip_backward(self, dy):
@@ -895,7 +905,7 @@ class Conv3DNet(_HipNet):
             k, st = self.KERNELS[i], self.STRIDES[i]
             dW, db = self._conv_grads[i]
             if i == 0 and cols is None:
-                ops.conv3d_c1_wgrad(dz, x5, k, st, k // 2, dW.view(conv.out_channels, -1), db, ws)
+                ops.conv3d_c1_wgrad(dz, x5, k, st, k // 2, dW.view(conv.out_channels, -1), db, ws, self._rows_idx)
                 break
             if i == 0:
                 dwp = torch.empty_like(self._w1p)
@@ -907,6 +917,16 @@ class Conv3DNet(_HipNet):
                 dwp = torch.empty(conv.out_channels, cols.shape[1] * cin, device=dy.device)
                 ops.sparse_conv_bwd_weight(dz, saved[i - 1][2], cols, cin, dwp, db, self._zero(dy.device), ws)
                 dW.view(conv.out_channels, cin, k3).copy_(dwp[:, :k3 * cin].view(conv.out_channels, k3, cin).transpose(1, 2))
+                if st == k:
+                    # stride == k: the patches do not overlap, every input voxel is idx[r, j] for at most one (r, j): the data
+                    # gradient is one GEMM whose epilogue scatters to the input rows -- no column gradients, no col2im
+                    y_prev = saved[i - 1][2]
+                    n_in, no = ext[i], ext[i + 1]
+                    covered = no * k >= n_in + k // 2
+                    dzp = torch.empty_like(y_prev) if covered else torch.zeros_like(y_prev)
+                    ops.sparse_conv_bwd_data_scatter(dz, self._tap_major(conv, cols.shape[1]), cols, cin, y_prev, dzp, self._act)
+                    dz = dzp
+                    continue
                 dcols = torch.empty(cols.shape[0], cin * k3, device=dy.device)
             else:
                 ops.linear_bwd_weight(dz, cols, dW.view(conv.out_channels, -1), db, ws)

@@ -164,14 +164,19 @@ class dagger:
         for _ in range(self.n_updates):
             batch = self.storage.mini_batch_generator(self.num_mini_batches)   # fresh sampler per epoch (dagger.py:305)
             for indices in batch:
-                stu_obs = self._rows('stu', obs_all, indices)
+                in_place = getattr(stu.actor, 'supports_row_index', False) and self.storage.sampler != "sequential"
+                stu_obs = None if in_place else self._rows('stu', obs_all, indices)
                 tea_obs = self._rows('tea', tea_all, indices)
                 with torch.no_grad():
                     tea_mu = tea.actor.hip_forward(tea_obs)                  # teacher.act, squashing fused into K11
                     if not same_squash:
                         tea_mu = tea_mu.contiguous()
                         ops.action_activation(tea_mu, tea_mu, tea.max_action, tea_tanh)
-                stu_mu = stu.actor.hip_forward(stu_obs)
+                if in_place:           # the backbone reads its rows of the ring where they lie (Conv3DNet: 0.8 GB per batch)
+                    idx = torch.tensor(indices, dtype=torch.int64).to(obs_all.device, non_blocking=True)
+                    stu_mu = stu.actor.hip_forward(obs_all, rows=idx)
+                else:
+                    stu_mu = stu.actor.hip_forward(stu_obs)
                 dstu = torch.empty_like(stu_mu)
                 ops.mse_tanh_loss(stu_mu, tea_mu, stu.max_action, mode, 1.0, scal, dstu)
                 stu.actor.hip_backward(dstu)

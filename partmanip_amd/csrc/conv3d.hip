@@ -148,7 +148,8 @@ template <int K, int CO>
 __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restrict__ x, Conv3dGeom g,
                                                              const float* __restrict__ wt,
                                                              const float* __restrict__ bias, int act_tanh, long nrows,
-                                                             float* __restrict__ y, long ldy) {
+                                                             float* __restrict__ y, long ldy,
+                                                             const int64_t* __restrict__ bidx) {
     // one row per thread, no grid-stride loop: inside a loop the 125 x CO wave-uniform weight loads are loop-invariant
     // and hipcc hoists all of them (2010 spilled SGPRs)
     {
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restr
         const int od = (int)(r % g.Do);
         const long b = r / g.Do;
         const int d0 = od * g.stride - g.pad, h0 = oh * g.stride - g.pad, w0 = ow * g.stride - g.pad;
-        const float* xb = x + b * g.sb;
+        const float* xb = x + (bidx ? bidx[b] : b) * g.sb;        // bidx: batch row b is row bidx[b] of a larger store (ring)
         float acc[CO];
 #pragma unroll
         for (int o = 0; o < CO; ++o) acc[o] = bias ? bias[o] : 0.f;
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restr
 template <int K, int CO>
 __global__ __launch_bounds__(128) void conv3d_c1_wgrad_kernel(const float* __restrict__ dz, long lddz,
                                                                const float* __restrict__ x, Conv3dGeom g, long nlines,
-                                                               long lines_per_wg, float* __restrict__ slabs) {
+                                                               long lines_per_wg, float* __restrict__ slabs,
+                                                               const int64_t* __restrict__ bidx) {
     constexpr int K3 = K * K * K;
     static_assert(K3 < 128, "one lane per tap plus the bias lane");
     __shared__ float slab[2][K * K][C1_MAXW + 2 * K];      // [buffer][kd*K+kh][pad + w], double-buffered over lines
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(128) void conv3d_c1_wgrad_kernel(const float* __res
     auto stage_load = [&](long bb, int odd, int ohh) __attribute__((always_inline)) {
         const int d = odd * g.stride - g.pad + srow / K, h = ohh * g.stride - g.pad + srow % K;
         const bool ok = srow < K * K && d >= 0 && d < g.D && h >= 0 && h < g.H;
-        const float* src = x + bb * g.sb + (long)d * g.sd + (long)h * g.sh;
+        const float* src = x + (bidx ? bidx[bb] : bb) * g.sb + (long)d * g.sd + (long)h * g.sh;
 #pragma unroll
         for (int j = 0; j < SMAX; ++j) {
             const int w = spart + j * K - g.pad;
@@ -301,7 +303,7 @@ extern "C" size_t pm_conv3d_c1_wgrad_workspace_bytes(int Cout) { return (size_t)
 
 extern "C" int pm_conv3d_c1_fwd_f32(const float* x, int B, int D, int H, int W, int k, int stride, int pad, long sb,
                                     long sd, long sh, long sw, const float* wt, const float* bias, int Cout, int act,
-                                    float* y, long ldy, void* stream) {
+                                    float* y, long ldy, const int64_t* batch_index, void* stream) {
     PM_REQUIRE(x && wt && y && B > 0 && ldy >= Cout);
     if (!pm_conv3d_c1_supported(k, Cout)) return PM_EUNSUPPORTED;
     if (act != PM_ACT_NONE && act != PM_ACT_TANH) return PM_EUNSUPPORTED;
@@ -312,14 +314,15 @@ extern "C" int pm_conv3d_c1_fwd_f32(const float* x, int B, int D, int H, int W, 
     const long nb = (nrows + 255) / 256;
     if (nb > 0x7fffffffL) return PM_EINVAL;
     hipLaunchKernelGGL((conv3d_c1_fwd_kernel<5, 16>), dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), x, g, wt, bias,
-                       act == PM_ACT_TANH, nrows, y, ldy);
+                       act == PM_ACT_TANH, nrows, y, ldy, batch_index);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
 
 extern "C" int pm_conv3d_c1_wgrad_f32(const float* dz, long lddz, const float* x, int B, int D, int H, int W, int k,
                                       int stride, int pad, long sb, long sd, long sh, long sw, int Cout, float* dW,
-                                      long lddw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+                                      long lddw, float* db, const int64_t* batch_index, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
     PM_REQUIRE(dz && x && dW && B > 0 && lddz >= Cout && lddw >= k * k * k);
     if (!pm_conv3d_c1_supported(k, Cout)) return PM_EUNSUPPORTED;
     if (!workspace || workspace_bytes < pm_conv3d_c1_wgrad_workspace_bytes(Cout)) return PM_EWORKSPACE;
@@ -332,7 +335,7 @@ extern "C" int pm_conv3d_c1_wgrad_f32(const float* dz, long lddz, const float* x
     if (per < 4) per = 4;
     const int nwg = (int)((nlines + per - 1) / per);
     hipLaunchKernelGGL((conv3d_c1_wgrad_kernel<5, 16>), dim3(nwg), dim3(128), 0, pm_stream(stream), dz, lddz, x, g, nlines,
-                       per, (float*)workspace);
+                       per, (float*)workspace, batch_index);
     hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(Cout), dim3(128), 0, pm_stream(stream),
                        (const float*)workspace, nwg, Cout, k * k * k, dW, lddw, db);
     PM_CHECK_LAUNCH();

@@ -26,6 +26,10 @@ struct Gemm2Prob {
     // at A (resp. B) with its leading dimension, or 0 where the index is negative (read from gzero, >= gC zeros).  The
     // (rows x gJ*gC) operand never exists in HBM.  LDS-DMA path only (gC % 4 == 0, K resp. N = gJ*gC).
     const int32_t* gidx; const float* gzero; int gJ, gC;
+    // scattered result (the input gradient of a convolution whose patches do not overlap): element (row r, column q) goes to
+    // row sidx[r*sJ + q/sC], column q%sC of the matrix at C (row stride sC), and is dropped where the index is negative; H
+    // (G2_EPI_MUL_DACT) is read at the same place.  sC % 4 == 0.  Rows no element maps to keep their contents.
+    const int32_t* sidx; int sJ, sC;
     int vecC;                     // 16-byte stores of C (and loads of bias / H) allowed (filled by the launcher)
     int tiles_m, tiles_n;         // filled by the launcher
     int block0;                   // first work-group of this problem in the grid (filled by the launcher)

@@ -167,6 +167,13 @@ __device__ __forceinline__ void g2_epilogue(const Gemm2Prob& g, f32x16 (&acc)[WM
             const int id = tid + NT * j, row = id / (TN / 4), c4 = (id % (TN / 4)) * 4;
             const int grow = m0 + row, gcol = n0 + c4;
             if (grow < g.M && gcol < g.N) {                                // N % 4 == 0: a float4 is inside or outside as a whole
+                long coff = (long)grow * g.ldc + gcol, hoff = (long)grow * g.ldh + gcol;
+                if (g.sidx) {                                              // scattered rows (sC % 4 == 0: a float4 stays inside one)
+                    const int t = gcol / g.sC;
+                    const int dst = g.sidx[(long)grow * g.sJ + t];
+                    if (dst < 0) continue;
+                    coff = hoff = (long)dst * g.sC + (gcol - t * g.sC);
+                }
                 float4 v = *(const float4*)(lds + row * LDC + c4);
                 if (epi == G2_EPI_BIAS_ACT) {
                     if (g.bias) {
@@ -176,14 +183,14 @@ __device__ __forceinline__ void g2_epilogue(const Gemm2Prob& g, f32x16 (&acc)[WM
                     if (act == PM_ACT_TANH) { v.x = pm_tanh(v.x); v.y = pm_tanh(v.y); v.z = pm_tanh(v.z); v.w = pm_tanh(v.w); }
                     else if (act != PM_ACT_NONE) { v.x = pm_act(v.x, act); v.y = pm_act(v.y, act); v.z = pm_act(v.z, act); v.w = pm_act(v.w, act); }
                 } else if (epi == G2_EPI_MUL_DACT && act != PM_ACT_NONE) {
-                    const float4 hh = *(const float4*)(g.H + (long)grow * g.ldh + gcol);
+                    const float4 hh = *(const float4*)(g.H + hoff);
                     if (act == PM_ACT_TANH) {
                         v.x *= 1.0f - hh.x * hh.x; v.y *= 1.0f - hh.y * hh.y; v.z *= 1.0f - hh.z * hh.z; v.w *= 1.0f - hh.w * hh.w;
                     } else {
                         v.x *= pm_dact(hh.x, act); v.y *= pm_dact(hh.y, act); v.z *= pm_dact(hh.z, act); v.w *= pm_dact(hh.w, act);
                     }
                 }
-                *(float4*)(C + (long)grow * g.ldc + gcol) = v;
+                *(float4*)(C + coff) = v;
             }
         }
     } else {
@@ -597,6 +604,8 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
         p.vecC = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.slab % 4 == 0) && (((uintptr_t)p.C & 15) == 0) &&
                  (p.epi != G2_EPI_BIAS_ACT || !p.bias || ((uintptr_t)p.bias & 15) == 0) &&
                  (p.epi != G2_EPI_MUL_DACT || p.act == PM_ACT_NONE || (p.ldh % 4 == 0 && ((uintptr_t)p.H & 15) == 0));
+        if (p.sidx && (!p.vecC && !(p.N % 4 == 0 && p.sC % 4 == 0 && ((uintptr_t)p.C & 15) == 0))) return PM_EINVAL;
+        if (p.sidx) p.vecC = 1;                                            // scattered rows: the 16-byte path only (sC % 4 == 0)
         p.tiles_m = (p.M + TM - 1) / TM;
         p.tiles_n = (p.N + TN - 1) / TN;
         p.block0 = blocks;

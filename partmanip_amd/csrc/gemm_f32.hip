@@ -327,6 +327,31 @@ extern "C" int pm_sparse_conv_bwd_data_f32(const float* dY, long lddy, const int
     return gemm2_launch(gg, false, false, stream);
 }
 
+// data gradient of a convolution whose patches do not overlap (stride == kernel size), by SCATTER: output row r wrote to /
+// read from input row idx[r][j] through tap j and nobody else did, so
+//   dX[idx[r][j]][c] = (sum_co dY[r][co] * W[co][j*C + c]) * act'(H[idx[r][j]][c])         (idx < 0: dropped)
+// is one plain GEMM (K = Cout) whose epilogue stores each 16-byte piece at its destination row -- no column-gradient matrix,
+// no col2im pass.  W is the layer's tap-major weight (Cout x J*C), the forward's B operand as it is.  Destination rows that
+// no (r, j) maps to keep their contents (the caller zero-fills when the geometry leaves any).
+extern "C" int pm_sparse_conv_bwd_data_scatter_f32(const float* dY, long lddy, const float* W, long ldw, const int32_t* idx,
+                                                   long rows, int J, int C, int Cout, const float* H, float* dX, int act,
+                                                   void* stream) {
+    PM_REQUIRE(dY && W && idx && dX && rows > 0 && rows < 0x7fffffffL && J > 0 && C > 0 && Cout > 0 && lddy >= Cout &&
+               ldw >= (long)J * C && act >= PM_ACT_NONE && act <= PM_ACT_MAX);
+    PM_REQUIRE(C % 4 == 0 && Cout % 4 == 0 && lddy % 4 == 0 && ldw % 4 == 0);
+    if (!aligned16(dY) || !aligned16(W) || !aligned16(dX) || (H && !aligned16(H))) return PM_EALIGN;
+    Gemm2Group gg{};
+    gg.n = 1;
+    Gemm2Prob& g = gg.p[0];
+    g.A = dY; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = C;
+    g.M = (int)rows; g.N = J * C; g.K = Cout; g.splits = 1;
+    g.epi = (H && act != PM_ACT_NONE) ? G2_EPI_MUL_DACT : G2_EPI_PLAIN;
+    g.act = act; g.H = H; g.ldh = C;
+    g.vecA = g.vecB = 1;
+    g.sidx = idx; g.sJ = J; g.sC = C;
+    return gemm2_launch(gg, false, true, stream);
+}
+
 extern "C" size_t pm_sparse_conv_bwd_weight_workspace_bytes(long rows, int N, int J, int C) {
     return pm_linear_bwd_weight_workspace_bytes((int)rows, N, J * C);
 }

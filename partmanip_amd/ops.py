@@ -579,6 +579,18 @@ def sparse_conv_bwd_data(dy, idx_t, wt, h, dx, act, zero):
     return dx
 
 
+def sparse_conv_bwd_data_scatter(dy, w, idx, C, h, dx, act):
+    """dx[idx[r, j]] = (dy[r] @ w[:, j*C:(j+1)*C]) * act'(h[idx[r, j]]) for convolutions with non-overlapping patches
+    (pm_sparse_conv_bwd_data_scatter_f32); w = the forward's tap-major weight (Cout, J*C)."""
+    _req(dy, w, idx, h, dx)
+    _f32c(dx, "dx")
+    rows, J = idx.shape
+    check(lib.pm_sparse_conv_bwd_data_scatter_f32(_ptr(dy), _rows(dy, "dy"), _ptr(w), _rows(w, "w"), _ptr(idx), rows, J, C,
+                                                  dy.shape[1], _ptr(h), _ptr(dx), int(act), _stream()),
+          "pm_sparse_conv_bwd_data_scatter_f32")
+    return dx
+
+
 def sparse_conv_bwd_weight(dy, src, idx, C, dw, db, zero, ws):
     _req(dy, src, idx, dw, db, zero)
     rows, J = idx.shape
@@ -638,10 +650,13 @@ def conv3d_c1_supported(k, cout):
     return bool(lib.pm_conv3d_c1_supported(int(k), int(cout)))
 
 
-def conv3d_c1_fwd(x5, k, stride, pad, wt, bias, act):
-    """Direct conv of a single-channel 5-D VIEW (B, 1, D, H, W) with wt (k^3, Cout) -> y (B*Do*Ho*Wo, Cout) = act(conv + b)."""
-    _req(x5, wt, bias)
+def conv3d_c1_fwd(x5, k, stride, pad, wt, bias, act, rows=None):
+    """Direct conv of a single-channel 5-D VIEW (B, 1, D, H, W) with wt (k^3, Cout) -> y (B*Do*Ho*Wo, Cout) = act(conv + b).
+    rows (int64, optional): the batch is rows[b] of x5's first dimension (no gathered copy)."""
+    _req(x5, wt, bias, rows)
     B, Cc, D, H, W = x5.shape
+    if rows is not None:
+        B = rows.numel()
     if Cc != 1:
         raise ValueError("conv3d_c1_fwd: one input channel")
     _f32c(wt, "wt")
@@ -651,20 +666,22 @@ def conv3d_c1_fwd(x5, k, stride, pad, wt, bias, act):
     sb, _, sd, sh, sw = x5.stride()
     with TIMER.bracket("conv3d_c1_fwd"):
         check(lib.pm_conv3d_c1_fwd_f32(_ptr(x5), B, D, H, W, k, stride, pad, sb, sd, sh, sw, _ptr(wt), _ptr(bias), cout, int(act),
-                                       _ptr(y), cout, _stream()), "pm_conv3d_c1_fwd_f32")
+                                       _ptr(y), cout, _ptr(rows), _stream()), "pm_conv3d_c1_fwd_f32")
     return y
 
 
-def conv3d_c1_wgrad(dz, x5, k, stride, pad, dw, db, ws):
-    """dw (Cout, k^3) / db (Cout) of the direct input-layer conv from dz (rows, Cout)."""
-    _req(dz, x5, dw, db)
+def conv3d_c1_wgrad(dz, x5, k, stride, pad, dw, db, ws, rows=None):
+    """dw (Cout, k^3) / db (Cout) of the direct input-layer conv from dz (rows, Cout); `rows` as in conv3d_c1_fwd."""
+    _req(dz, x5, dw, db, rows)
     B, Cc, D, H, W = x5.shape
+    if rows is not None:
+        B = rows.numel()
     cout = dw.shape[0]
     w = ws.get(lib.pm_conv3d_c1_wgrad_workspace_bytes(cout))
     sb, _, sd, sh, sw = x5.stride()
     with TIMER.bracket("conv3d_c1_wgrad"):
         check(lib.pm_conv3d_c1_wgrad_f32(_ptr(dz), _rows(dz, "dz"), _ptr(x5), B, D, H, W, k, stride, pad, sb, sd, sh, sw, cout,
-                                         _ptr(dw), _rows(dw, "dw"), _ptr(db), _ptr(w), w.numel(), _stream()),
+                                         _ptr(dw), _rows(dw, "dw"), _ptr(db), _ptr(rows), _ptr(w), w.numel(), _stream()),
               "pm_conv3d_c1_wgrad_f32")
 
 

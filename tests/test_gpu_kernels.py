@@ -614,3 +614,24 @@ def test_sparse_conv_entry_points_against_torch(rows, J, C, N):
     refx = (dyp[idx_t.long()].reshape(rows, J * N).double() @ wt.double().t()) * (1 - h.double() ** 2)
     assert rel_err(dx, refx) < 2e-5
     assert float(dx[5].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,J,C,N", [(700, 28, 16, 32), (129, 8, 32, 64), (2050, 27, 32, 32)])
+def test_sparse_conv_bwd_data_scatter_against_torch(rows, J, C, N):
+    """Data gradient by scatter (non-overlapping patches: every destination row has at most one (r, j)): against a torch
+    matmul + index_put; destination rows nobody maps to keep their contents, absent taps (-1) are dropped."""
+    o = ops()
+    g = torch.Generator().manual_seed(rows * 7 + J)
+    ndst = rows * J + 11
+    perm = torch.randperm(ndst, generator=g)[: rows * J].reshape(rows, J).to(torch.int32)
+    perm[torch.rand(rows, J, generator=g) < 0.2] = -1
+    dy = torch.randn(rows, N, generator=g)
+    w = torch.randn(N, J * C, generator=g) / N ** 0.5
+    h = torch.tanh(torch.randn(ndst, C, generator=g))
+    dx = torch.full((ndst, C), 7.0, device=DEV)
+    o.sparse_conv_bwd_data_scatter(dy.to(DEV), w.to(DEV), perm.to(DEV), C, h.to(DEV), dx, o.ACT_TANH)
+    full = (dy.double() @ w.double()).reshape(rows, J, C)
+    ref = torch.full((ndst, C), 7.0, dtype=torch.float64)
+    m = perm >= 0
+    ref[perm[m].long()] = full[m] * (1 - h.double()[perm[m].long()] ** 2)
+    np.testing.assert_allclose(dx.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=1e-5)
