@@ -218,7 +218,7 @@ def run_dagger(args, device, rank, world):
         if t:
             nbytes = mb * (50 ** 3 + 17 ** 3 * 16) * 4.0
             gbs = nbytes / (t[0] * 1e-3) / 1e9
-            out["roofline"] = dict(bound="hbm", kernel="conv3d_c1_wgrad_kernel", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
+            out["roofline"] = dict(bound="hbm", kernel="conv3d_c1_wgrad_mfma_kernel", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
                                    frac=gbs / PEAK_HBM_GBS, traffic=None, launches=t[1], mean_launch_ms=t[0],
                                    bytes_per_launch=nbytes)
             f = ops.TIMER.mean_ms("conv3d_c1_fwd")

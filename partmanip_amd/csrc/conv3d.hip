@@ -201,91 +201,138 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restr
 
 #define C1_WG_SLABS 2048
 #define C1_MAXW 64                                           // widest volume row the LDS slab holds
-// Work-groups own contiguous runs of output LINES (fixed b, od, oh; ow = 0..Wo-1).  A line's patches all lie in the K x K
-// input rows x[d0..d0+K)[h0..h0+K)[*]: they are staged in LDS by coalesced row loads (zero-filled outside the volume),
-// then lane = tap gathers its value for each ow from LDS -- the first version gathered from global memory, 25-50 cache
-// lines per wave load, and was bound by the texture addresser (2.5 ms).
-template <int K, int CO>
-__global__ __launch_bounds__(128) void conv3d_c1_wgrad_kernel(const float* __restrict__ dz, long lddz,
-                                                               const float* __restrict__ x, Conv3dGeom g, long nlines,
-                                                               long lines_per_wg, float* __restrict__ slabs,
-                                                               const int64_t* __restrict__ bidx) {
-    constexpr int K3 = K * K * K;
-    static_assert(K3 < 128, "one lane per tap plus the bias lane");
-    __shared__ float slab[2][K * K][C1_MAXW + 2 * K];      // [buffer][kd*K+kh][pad + w], double-buffered over lines
-    const int tap = threadIdx.x;
-    const int kd = tap / (K * K), kh = (tap / K) % K, kw = tap % K;
-    const int WP = g.W + 2 * g.pad;                         // padded row length actually used
+// Weight gradient of the input layer on the matrix pipe: dW^T (128 taps x 16 filters) += patch^T (128 x 4 rows) * dz (4 rows
+// x 16) is exactly v_mfma_f32_16x16x4_f32 -- four consecutive output positions of a LINE (fixed b, od, oh; ow = 0..Wo-1) per
+// instruction, the tap axis in eight 16-row blocks (125 taps, tap 125 = the constant 1 that collects the bias gradient, two
+// idle).  Work-groups own contiguous runs of lines.  A line's patches all lie in the K x K input rows
+// x[d0..d0+K)[h0..h0+K)[*]: they are staged in LDS by coalesced loads (zero-filled outside the volume), lane (tap, position)
+// reads its value from there -- gathering from global memory, 25-50 cache lines per wave load, was bound by the texture
+// addresser.  4 waves share the slab, wave w owns tap blocks 2w, 2w+1 (two accumulators of 4 registers); lines are padded to
+// NG groups of 4 positions (the dz of positions >= Wo is 0).  Per-work-group partial sums are added in fixed order.
+// History (1600 volumes of 50^3, tools/time_conv3d.py): the round-1 FMA form (lane = tap, 16 FMAs per row and lane with the
+// row's dz as ONE wave-uniform scalar load from HBM per row, next line's rows one iteration ahead) 1.49 ms; this kernel with
+// the same one-line look-ahead 1.46 (an iteration is ~320 cycles of MFMA per wave, far shorter than an HBM round trip: both ran
+// at load latency); two lines ahead 1.17.  Ablations of that: volume loads + LDS stores 0.51, dz loads 0.27 (every wave
+// fetches the line's dz), MFMAs + LDS reads 0.31, the rest 0.11 -- they add up: issue-bound.  Measured slower: whole slab rows
+// per wave with wave-uniform row arithmetic (1.64: 54 of 64 lanes, twice the load slots), whole rounds of resident groups (no
+// change).
+typedef float c1_f32x4 __attribute__((ext_vector_type(4)));
+#ifndef C1_ABLATE
+#define C1_ABLATE 0              // timing probes (wrong results): 1 = no volume loads, 2 = no dz loads, 4 = no MFMAs / LDS reads, 8 = no LDS stores
+#endif
+template <int K, int CO, int NG>
+__global__ __launch_bounds__(256) void conv3d_c1_wgrad_mfma_kernel(const float* __restrict__ dz, long lddz,
+                                                                    const float* __restrict__ x, Conv3dGeom g, long nlines,
+                                                                    long lines_per_wg, float* __restrict__ slabs,
+                                                                    const int64_t* __restrict__ bidx) {
+    constexpr int K3 = K * K * K, SW = C1_MAXW + 2 * K;      // NG groups of 4 output positions per line
+    constexpr int NST = (K * K * SW + 255) / 256;
+    static_assert(CO == 16 && K3 <= 125, "one 16-column MFMA block of filters, taps + bias lane within 128");
+    __shared__ float slab[3][K * K][SW];                    // line L lives in buffer L % 3
+    const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int WP = g.W + 2 * g.pad;
+    // staging map: which (slab row, padded column) this thread copies in slot j (fixed for the whole kernel)
+    int srow[NST], scol[NST];
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+        const int e = tid + 256 * j;
+        srow[j] = e < K * K * WP ? e / WP : -1;
+        scol[j] = e - (e / WP) * WP;
+    }
+    // this lane's two taps and their slab offsets
+    int aoff[2];
+    float aconst[2];                                        // tap 125: 1 (bias), 126 / 127: 0
+    bool areal[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int tap = (wave * 2 + i) * 16 + l16;
+        areal[i] = tap < K3;
+        aconst[i] = tap == K3 ? 1.0f : 0.0f;
+        const int t = areal[i] ? tap : 0;
+        aoff[i] = ((t / (K * K)) * K + (t / K) % K) * SW + t % K;
+    }
     const long l0 = (long)blockIdx.x * lines_per_wg;
     long l1 = l0 + lines_per_wg;
     if (l1 > nlines) l1 = nlines;
-    float acc[CO];
-#pragma unroll
-    for (int o = 0; o < CO; ++o) acc[o] = 0.f;
-    long rr = l0;                                           // wave-uniform line counters, advanced by carry
+    c1_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // (b, od, oh) of the line whose loads are issued next, advanced by carry (wave-uniform, no divisions in the loop)
+    long rr = l0;
     int oh = (int)(rr % g.Ho); rr /= g.Ho;
     int od = (int)(rr % g.Do);
     long b = rr / g.Do;
-    // staging: K threads per input row (kd, kh) = tap / K, each copies every K-th padded column -- no runtime divisions.
-    // The next line's values are REQUESTED into registers before the current line is consumed and stored to LDS after it:
-    // a load -> ds_write loop in front of the FMA loop exposed ~11 dependent HBM/L2 round trips per line.
-    constexpr int SMAX = (C1_MAXW + 2 * K + K - 1) / K;
-    const int srow = tap / K, spart = tap % K;
-    float st[SMAX];
-    auto stage_load = [&](long bb, int odd, int ohh) __attribute__((always_inline)) {
-        const int d = odd * g.stride - g.pad + srow / K, h = ohh * g.stride - g.pad + srow % K;
-        const bool ok = srow < K * K && d >= 0 && d < g.D && h >= 0 && h < g.H;
-        const float* src = x + (bidx ? bidx[bb] : bb) * g.sb + (long)d * g.sd + (long)h * g.sh;
-#pragma unroll
-        for (int j = 0; j < SMAX; ++j) {
-            const int w = spart + j * K - g.pad;
-            st[j] = (ok && w >= 0 && w < g.W) ? src[(long)w * g.sw] : 0.f;
-        }
-    };
-    auto stage_store = [&](int buf) __attribute__((always_inline)) {
-        if (srow >= K * K) return;
-#pragma unroll
-        for (int j = 0; j < SMAX; ++j)
-            if (spart + j * K < WP) slab[buf][srow][spart + j * K] = st[j];
-    };
-    if (l0 < l1) {
-        stage_load(b, od, oh);
-        stage_store(0);
-    }
-    __syncthreads();
-    for (long line = l0; line < l1; ++line) {
-        const int buf = (int)((line - l0) & 1);
-        // next line's counters; its rows are requested now and land in the other buffer after this line's FMA loop
-        int oh2 = oh + 1, od2 = od;
-        long b2 = b;
-        if (oh2 == g.Ho) {
-            oh2 = 0;
-            if (++od2 == g.Do) {
-                od2 = 0;
-                ++b2;
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (++oh == g.Ho) {
+            oh = 0;
+            if (++od == g.Do) {
+                od = 0;
+                ++b;
             }
         }
-        const bool more = line + 1 < l1;
-        if (more) stage_load(b2, od2, oh2);
-        const float* sp = &slab[buf][kd * K + kh][kw];
-        const float* dzl = dz + line * g.Wo * lddz;
-#pragma unroll 4
-        for (int ow = 0; ow < g.Wo; ++ow) {
-            float v = 0.f;
-            if (tap < K3) v = sp[ow * g.stride];
-            else if (tap == K3) v = 1.0f;                   // bias lane
-            const float* dzr = dzl + (long)ow * lddz;       // wave-uniform: scalar loads
+    };
+    // Two lines in flight: line L's volume rows and dz are REQUESTED at the top of iteration L-2 (register set L % 2), the rows
+    // go to LDS at the end of iteration L-1 and are consumed in iteration L.  (One line ahead, an iteration -- 320 cycles of
+    // MFMA per wave -- is far shorter than an HBM round trip: both this kernel and the FMA form then run at load latency.)
+    float st[2][NST], bz[3][NG];
+    auto loads = [&](long line, float (&sx)[NST], float (&sz)[NG]) __attribute__((always_inline)) {
+        const float* xb = x + (bidx ? bidx[b] : b) * g.sb;
 #pragma unroll
-            for (int o = 0; o < CO; ++o) acc[o] = fmaf(dzr[o], v, acc[o]);
+        for (int j = 0; j < NST; ++j) {
+            const int d = od * g.stride - g.pad + srow[j] / K, h = oh * g.stride - g.pad + srow[j] % K, w = scol[j] - g.pad;
+            const bool ok = srow[j] >= 0 && d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W;
+            sx[j] = (ok && !(C1_ABLATE & 1)) ? xb[(long)d * g.sd + (long)h * g.sh + (long)w * g.sw] : 0.f;
         }
-        if (more) stage_store(buf ^ 1);
-        oh = oh2; od = od2; b = b2;
-        __syncthreads();
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            const int ow = 4 * gq + q;
+            sz[gq] = (ow < g.Wo && !(C1_ABLATE & 2)) ? dz[(line * g.Wo + ow) * lddz + l16] : 0.f;
+        }
+        advance();
+    };
+    auto stage_store = [&](int buf, const float (&sx)[NST]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NST; ++j)
+            if (srow[j] >= 0 && !(C1_ABLATE & 8)) slab[buf][srow[j]][scol[j]] = sx[j];
+    };
+    // prologue: line l0 loaded and stored, line l0+1 loaded
+    if (l0 < l1) {
+        loads(l0, st[0], bz[0]);
+        stage_store(0, st[0]);
+        if (l0 + 1 < l1) loads(l0 + 1, st[1], bz[1]);
     }
+    __syncthreads();
+    // the loop is unrolled by 6 = lcm(2 register sets, 3 buffers) so that every set / buffer index is a constant
+    long line = l0;
+    while (line < l1) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            if (line < l1) {                                // wave-uniform
+                if (line + 2 < l1) loads(line + 2, st[u % 2], bz[(u + 2) % 3]);
+                const float* sp = &slab[u % 3][0][0];
+#pragma unroll
+                for (int gq = 0; gq < ((C1_ABLATE & 4) ? 0 : NG); ++gq) {
+                    int ow = 4 * gq + q;
+                    if (ow >= g.Wo) ow = g.Wo - 1;          // padded positions: dz is 0, any finite patch value will do
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float a = areal[i] ? sp[aoff[i] + ow * g.stride] : aconst[i];
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bz[u % 3][gq], acc[i], 0, 0, 0);
+                    }
+                }
+                if (line + 1 < l1) stage_store((u + 1) % 3, st[(u + 1) % 2]);
+                __syncthreads();
+                ++line;
+            }
+        }
+    }
+    // D block i: rows (taps) (2 wave + i) 16 + 4 q + r, column (filter) l16
     float* out = slabs + (size_t)blockIdx.x * CO * 128;
 #pragma unroll
-    for (int o = 0; o < CO; ++o) out[o * 128 + tap] = acc[o];
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[l16 * 128 + (wave * 2 + i) * 16 + 4 * q + r] = acc[i][r];
 }
+
 // dW[o][tap] = sum_slabs (fixed order), db[o] from lane K^3
 __global__ __launch_bounds__(128) void conv3d_c1_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslabs, int CO,
                                                                       int K3, float* __restrict__ dW, long lddw,
@@ -334,8 +381,14 @@ extern "C" int pm_conv3d_c1_wgrad_f32(const float* dz, long lddz, const float* x
     long per = (nlines + C1_WG_SLABS - 1) / C1_WG_SLABS;
     if (per < 4) per = 4;
     const int nwg = (int)((nlines + per - 1) / per);
-    hipLaunchKernelGGL((conv3d_c1_wgrad_kernel<5, 16>), dim3(nwg), dim3(128), 0, pm_stream(stream), dz, lddz, x, g, nlines,
-                       per, (float*)workspace, batch_index);
+#define C1_WGRAD_LAUNCH(NG_)                                                                                             \
+    hipLaunchKernelGGL((conv3d_c1_wgrad_mfma_kernel<5, 16, NG_>), dim3(nwg), dim3(256), 0, pm_stream(stream), dz, lddz, x, g, \
+                       nlines, per, (float*)workspace, batch_index)
+    if (g.Wo <= 20) C1_WGRAD_LAUNCH(5);                     // the shipped geometry: 17 positions per line
+    else if (g.Wo <= 32) C1_WGRAD_LAUNCH(8);
+    else if (g.Wo <= 64) C1_WGRAD_LAUNCH(16);
+    else return PM_EUNSUPPORTED;
+#undef C1_WGRAD_LAUNCH
     hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(Cout), dim3(128), 0, pm_stream(stream),
                        (const float*)workspace, nwg, Cout, k * k * k, dW, lddw, db);
     PM_CHECK_LAUNCH();
