@@ -27,26 +27,31 @@ struct ActorLossPart {
     float dls[MAX_A];
 };
 
+// One lane per (row, action) element, AP = 16 or 64 lanes per row (A <= AP): the first version walked a row's A actions in
+// one thread -- A dependent rounds of four loads, an atanh, an exp -- and took 19 us for 2048 x 10, a sixth of a state-PPO
+// actor step's dependent chain.  Row sums (M, kl) are butterfly sums inside the AP-lane group; the per-action dlog_std terms
+// stay in their lane across the work-group's rows and meet in LDS at the end (fixed order).
+template <int AP>
 __global__ __launch_bounds__(AL_THREADS) void ppo_actor_loss_part_kernel(
     const float* __restrict__ mu, long ldmu, const float* __restrict__ log_std, const float* __restrict__ actions,
     long lda, const float* __restrict__ old_logp, const float* __restrict__ adv, const float* __restrict__ old_mu,
     long ldom, const float* __restrict__ old_sigma, long ldos, int B, int A, float max_action, int act_tanh,
     float eps_clip, const double* __restrict__ adv_moments, double adv_count, float* __restrict__ dmu, long lddmu,
     ActorLossPart* __restrict__ parts) {
+    constexpr int RPB = AL_THREADS / AP;                   // rows per work-group pass
     __shared__ float s_ls[MAX_A], s_s[MAX_A];
     __shared__ double red[AL_THREADS / 64];
-    __shared__ float red_a[AL_THREADS / 64][MAX_A];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ float red_a[RPB][AP];
+    const int tid = threadIdx.x, r = tid / AP, a = tid % AP;
     if (tid < A) {
         const float ls = log_std[tid];
         const float e = expf(ls);
         s_ls[tid] = ls;
         s_s[tid] = e * e;                 // effective std (actor_critic.py:74) == square(sigma.exp()) of ppo.py:333
     }
-    for (int a = lane; a < A; a += 64) red_a[w][a] = 0.f;
     __syncthreads();
     float sum_logs = 0.f;
-    for (int a = 0; a < A; ++a) sum_logs += logf(s_s[a]);
+    for (int k = 0; k < A; ++k) sum_logs += logf(s_s[k]);
     const float k_log2pi = (float)A * 1.8378770664093453f;
 
     float a_mean = 0.f, a_den = 1.f;
@@ -58,55 +63,58 @@ __global__ __launch_bounds__(AL_THREADS) void ppo_actor_loss_part_kernel(
         a_den = (float)sqrt(var) + 1e-8f;
     }
     const float invB = 1.0f / (float)B;
+    const bool on_a = a < A;
+    const float sa = on_a ? s_s[a] : 1.f, lsa = on_a ? s_ls[a] : 0.f;
     double loss_acc = 0.0, kl_acc = 0.0;
-    for (int base = blockIdx.x * AL_THREADS; base < B; base += gridDim.x * AL_THREADS) {   // uniform trip count per block
-        const int i = base + tid;
-        const bool on = i < B;
-        float M = 0.f, kl = 0.f;
+    float cacc = 0.f;                                       // this lane's action: sum over its rows of d loss / d log_std[a]
+    for (int base = blockIdx.x * RPB; base < B; base += gridDim.x * RPB) {   // uniform trip count per block
+        const int i = base + r;
+        const bool row = i < B, on = row && on_a;
+        float z = 0.f, klt = 0.f;
         if (on) {
-            for (int a = 0; a < A; ++a) {
-                const float m = mu[i * ldmu + a];
-                const float x = deactivate(actions[i * lda + a], max_action, act_tanh);
-                const float z = (x - m) / s_s[a];
-                M += z * z;
-                const float eo = expf(old_sigma[i * ldos + a]);
-                const float dm = old_mu[i * ldom + a] - m;
-                kl += s_ls[a] - old_sigma[i * ldos + a] + (eo * eo + dm * dm) / (2.0f * s_s[a]) - 0.5f;
-            }
+            const float m = mu[i * ldmu + a];
+            const float x = deactivate(actions[i * lda + a], max_action, act_tanh);
+            const float os = old_sigma[i * ldos + a];
+            z = (x - m) / sa;
+            const float eo = expf(os);
+            const float dm = old_mu[i * ldom + a] - m;
+            klt = lsa - os + (eo * eo + dm * dm) / (2.0f * sa) - 0.5f;
+        }
+        float M = z * z, kl = klt;
+#pragma unroll
+        for (int o = AP / 2; o > 0; o >>= 1) {
+            M += __shfl_xor(M, o, 64);
+            kl += __shfl_xor(kl, o, 64);
         }
         float g = 0.f;
-        if (on) {
+        if (row) {
             const float logp = -0.5f * (k_log2pi + M) - sum_logs;
             const float ratio = expf(logp - old_logp[i]);
             float ad = adv[i];
             if (adv_moments) ad = (ad - a_mean) / a_den;
             const float s1 = -ad * ratio;
             const float s2 = -ad * fminf(fmaxf(ratio, 1.0f - eps_clip), 1.0f + eps_clip);
-            loss_acc += (double)fmaxf(s1, s2);
-            kl_acc += (double)kl;
+            if (a == 0) {
+                loss_acc += (double)fmaxf(s1, s2);
+                kl_acc += (double)kl;
+            }
             // d max(s1,s2)/d ratio: -ad through the unclipped branch (incl. the tie inside the clip
             // range, where torch splits the gradient in two halves that re-add); 0 when clipped.
             g = (s1 >= s2 ? -ad : 0.0f) * ratio * invB;       // d loss / d logp_i
         }
-        for (int a = 0; a < A; ++a) {
-            float c = 0.f;
-            if (on) {
-                const float x = deactivate(actions[i * lda + a], max_action, act_tanh);
-                const float z = (x - mu[i * ldmu + a]) / s_s[a];
-                dmu[i * lddmu + a] = g * z / s_s[a];          // d logp / d mu = z / s
-                c = g * (2.0f * z * z - 2.0f);                 // d logp / d log_std (s = exp(2 ls))
-            }
-            c = wave_sum(c);
-            if (lane == 0) red_a[w][a] += c;
+        if (on) {
+            dmu[i * lddmu + a] = g * z / sa;                  // d logp / d mu = z / s
+            cacc += g * (2.0f * z * z - 2.0f);                // d logp / d log_std (s = exp(2 ls))
         }
     }
     const double loss_sum = block_sum<double, AL_THREADS>(loss_acc, red);
     const double kl_sum = block_sum<double, AL_THREADS>(kl_acc, red);
+    red_a[r][a] = cacc;
     __syncthreads();
     ActorLossPart* part = parts + blockIdx.x;
     if (tid < A) {
         float t = 0.f;
-        for (int k = 0; k < AL_THREADS / 64; ++k) t += red_a[k][tid];
+        for (int k = 0; k < RPB; ++k) t += red_a[k][tid];
         part->dls[tid] = t;
     }
     if (tid == 0) {
@@ -119,18 +127,20 @@ __global__ __launch_bounds__(64) void ppo_actor_loss_final_kernel(const ActorLos
                                                                    int A, const float* __restrict__ log_std,
                                                                    float desired_kl, float* __restrict__ scal_out,
                                                                    float* __restrict__ dlog_std) {
+    // lane g holds work-group g's partial (G <= 64 = one wave): butterfly sums instead of G dependent loads in one lane
     const int tid = threadIdx.x;
-    if (tid < A) {
-        float t = 0.f;
-        for (int g = 0; g < G; ++g) t += parts[g].dls[tid];
-        dlog_std[tid] = t;
+    const bool has = tid < G;
+    double ls = has ? parts[tid].loss : 0.0, ks = has ? parts[tid].kl : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ls += __shfl_xor(ls, o, 64);
+        ks += __shfl_xor(ks, o, 64);
+    }
+    for (int a = 0; a < A; ++a) {
+        const float t = wave_sum(has ? parts[tid].dls[a] : 0.f);
+        if (tid == 0) dlog_std[a] = t;
     }
     if (tid == 0) {
-        double ls = 0.0, ks = 0.0;
-        for (int g = 0; g < G; ++g) {
-            ls += parts[g].loss;
-            ks += parts[g].kl;
-        }
         float sum_logs = 0.f;
         for (int a = 0; a < A; ++a) {
             const float e = expf(log_std[a]);
@@ -144,8 +154,8 @@ __global__ __launch_bounds__(64) void ppo_actor_loss_final_kernel(const ActorLos
     }
 }
 
-static inline int actor_loss_blocks(int B) {
-    int g = (B + AL_THREADS - 1) / AL_THREADS;
+static inline int actor_loss_blocks(int B) {           // sized for the 16-lanes-per-row form (16 rows per work-group pass)
+    int g = (B + AL_THREADS / 16 - 1) / (AL_THREADS / 16);
     return g < 1 ? 1 : (g > AL_MAXG ? AL_MAXG : g);
 }
 
@@ -165,9 +175,14 @@ extern "C" int pm_ppo_actor_loss_fwd_bwd_f32(const float* mu, long ldmu, const f
     const int G = actor_loss_blocks(B);
     if (!workspace || workspace_bytes < (size_t)G * sizeof(ActorLossPart) || ((uintptr_t)workspace & 7)) return PM_EWORKSPACE;
     ActorLossPart* parts = (ActorLossPart*)workspace;
-    hipLaunchKernelGGL(ppo_actor_loss_part_kernel, dim3(G), dim3(AL_THREADS), 0, pm_stream(stream), mu, ldmu, log_std,
-                       actions, lda, old_logp, adv, old_mu, ldom, old_sigma, ldos, B, A, max_action, act_tanh, eps_clip,
-                       adv_moments, adv_count, dmu, lddmu, parts);
+    if (A <= 16)
+        hipLaunchKernelGGL(ppo_actor_loss_part_kernel<16>, dim3(G), dim3(AL_THREADS), 0, pm_stream(stream), mu, ldmu, log_std,
+                           actions, lda, old_logp, adv, old_mu, ldom, old_sigma, ldos, B, A, max_action, act_tanh, eps_clip,
+                           adv_moments, adv_count, dmu, lddmu, parts);
+    else
+        hipLaunchKernelGGL(ppo_actor_loss_part_kernel<64>, dim3(G), dim3(AL_THREADS), 0, pm_stream(stream), mu, ldmu, log_std,
+                           actions, lda, old_logp, adv, old_mu, ldom, old_sigma, ldos, B, A, max_action, act_tanh, eps_clip,
+                           adv_moments, adv_count, dmu, lddmu, parts);
     hipLaunchKernelGGL(ppo_actor_loss_final_kernel, dim3(1), dim3(64), 0, pm_stream(stream), parts, G, B, A, log_std,
                        desired_kl, scal_out, dlog_std);
     PM_CHECK_LAUNCH();
