@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 128 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 129 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -241,6 +241,8 @@ typedef struct pm_clip_adam_desc {
     float* params; float* grads; float* exp_avg; float* exp_avg_sq; long n, n_clip; const float* extra; long extra_stride;
     long n_sum; int n_extra; float max_norm; double lr, b1, b2, eps; int32_t* state; const float* skip_flag;
     float* gnorm_out; void* workspace;
+    /* optional (stats_acc != NULL): pm_ppo_accumulate_stats_f32(stats_acc, stats_scal, stats_which) folded into the norm pass */
+    float* stats_acc; const float* stats_scal; int stats_which;
 } pm_clip_adam_desc;
 int pm_clip_adam_group_f32(int n, const pm_clip_adam_desc* d, void* stream);
 int pm_clip_adam_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,

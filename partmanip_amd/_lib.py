@@ -119,7 +119,8 @@ class LinearBwdWeightDesc(C.Structure):
 class ClipAdamDesc(C.Structure):
     _fields_ = [("params", P), ("grads", P), ("exp_avg", P), ("exp_avg_sq", P), ("n", L), ("n_clip", L), ("extra", P),
                 ("extra_stride", L), ("n_sum", L), ("n_extra", I), ("max_norm", F), ("lr", D), ("b1", D), ("b2", D),
-                ("eps", D), ("state", P), ("skip_flag", P), ("gnorm_out", P), ("workspace", P)]
+                ("eps", D), ("state", P), ("skip_flag", P), ("gnorm_out", P), ("workspace", P), ("stats_acc", P), ("stats_scal", P),
+                ("stats_which", I)]
 
 
 if not os.path.exists(LIB_PATH):
@@ -133,7 +134,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 128                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 129                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -256,10 +256,10 @@ class ppo:
         if self.solo_group:
             S = ac.GRAD_SLABS if B >= 1024 else 1
             chains_backward([ac.actor._chain], [dmu], [f['slab_stride_actor']], S)
-            ops.ppo_accumulate_stats(self._acc, scal_a, 0)
             ops.clip_adam_group([self.optimizer_actor.group_item(
                 n=n_a + A, n_clip=n_a if clip else 0, max_norm=self.max_grad_norm if clip else 0.0, skip_flag=scal_a[2:3],
-                extra=f['extra_actor'], extra_stride=f['slab_stride_actor'], n_sum=n_a, n_extra=S - 1)])
+                extra=f['extra_actor'], extra_stride=f['slab_stride_actor'], n_sum=n_a, n_extra=S - 1,
+                stats=(self._acc, scal_a, 0))])             # the step's running sums ride in the norm pass (one launch less)
             return
         ac.actor.hip_backward(dmu)
         if sync:                                              # ONE all-reduce: grads + loss/kl in the tail
@@ -289,10 +289,9 @@ class ppo:
         if self.solo_group:
             S = ac.GRAD_SLABS if B >= 1024 else 1
             chains_backward([ac.critic._chain], [dv], [f['slab_stride_critic']], S)
-            ops.ppo_accumulate_stats(self._acc, scal_c, 1)
             ops.clip_adam_group([self.optimizer_critic.group_item(
                 n=n_c, n_clip=n_c if clip else 0, max_norm=self.max_grad_norm if clip else 0.0, extra=f['extra_critic'],
-                extra_stride=f['slab_stride_critic'], n_sum=n_c, n_extra=S - 1)])
+                extra_stride=f['slab_stride_critic'], n_sum=n_c, n_extra=S - 1, stats=(self._acc, scal_c, 1))])
             return
         ac.critic.hip_backward(dv)
         if sync:

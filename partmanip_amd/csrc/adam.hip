@@ -127,9 +127,25 @@ __global__ __launch_bounds__(ADAM_THREADS) void grad_sumsq_group_kernel(AdamGrou
     const long hi = n_clip > n_sum ? n_clip : n_sum;
     float* __restrict__ g = d.grads;
     double s = 0.0;
-    for (long i = (long)b * ADAM_THREADS + threadIdx.x; i < hi; i += (long)nb * ADAM_THREADS) {
+    // 16-byte body (4 elements per thread and trip, the common prefix of the two ranges rounded down), scalar tail
+    const bool al = (((uintptr_t)g | (uintptr_t)d.extra) & 15) == 0 && (d.extra_stride & 3) == 0;
+    const long lo = n_clip < n_sum ? n_clip : n_sum;
+    const long nv = al ? ((n_sum > 0 && n_clip > 0 ? lo : hi) & ~3L) : 0;
+    const bool vs = n_sum > 0, vc = n_clip > 0;             // inside [0, nv) an element is in every non-empty range
+    for (long i = ((long)b * ADAM_THREADS + threadIdx.x) * 4; i < nv; i += (long)nb * ADAM_THREADS * 4) {
+        float4 gv = *(const float4*)(g + i);
+        if (vs) {                                          // slab 0 is `grads` itself: add slabs 1.. in fixed order
+            for (int z = 0; z < d.n_extra; ++z) {
+                const float4 e = *(const float4*)(d.extra + (long)z * d.extra_stride + i);
+                gv.x += e.x; gv.y += e.y; gv.z += e.z; gv.w += e.w;
+            }
+            *(float4*)(g + i) = gv;
+        }
+        if (vc) s += (double)gv.x * (double)gv.x + (double)gv.y * (double)gv.y + (double)gv.z * (double)gv.z + (double)gv.w * (double)gv.w;
+    }
+    for (long i = nv + (long)b * ADAM_THREADS + threadIdx.x; i < hi; i += (long)nb * ADAM_THREADS) {
         float gi = g[i];
-        if (i < n_sum) {                                   // slab 0 is `grads` itself: add slabs 1.. in fixed order
+        if (i < n_sum) {
             for (int z = 0; z < d.n_extra; ++z) gi += d.extra[(long)z * d.extra_stride + i];
             g[i] = gi;
         }
@@ -141,6 +157,22 @@ __global__ __launch_bounds__(ADAM_THREADS) void grad_sumsq_group_kernel(AdamGrou
         if (b == 0) {
             const bool skip = d.skip_flag && d.skip_flag[0] != 0.0f;
             if (!skip) d.state[0] += 1;
+            if (d.stats_acc) {                             // pm_ppo_accumulate_stats_f32 (losses.hip), same arithmetic
+                float* acc = d.stats_acc;
+                const float* scal = d.stats_scal;
+                if (d.stats_which == 0) {
+                    const float loss = scal[0], kl = scal[1], sk = scal[2];
+                    if (kl > acc[2]) acc[2] = kl;
+                    if (sk == 0.0f) {
+                        acc[0] += loss;
+                        acc[1] += kl;
+                        acc[3] += 1.0f;
+                    }
+                } else {
+                    acc[4] += scal[0];
+                    acc[5] += 1.0f;
+                }
+            }
         }
     }
 }
@@ -184,13 +216,31 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adam_group_kernel(AdamGroup
     float* __restrict__ m = d.exp_avg;
     float* __restrict__ v = d.exp_avg_sq;
     const long n = d.n, n_clip = d.n_clip;
-    for (long i = (long)b * ADAM_THREADS + threadIdx.x; i < n; i += (long)nb * ADAM_THREADS) {
-        float gi = g[i];
-        if (i < n_clip) gi = gi * coef;
-        const float mi = m[i] + omb1 * (gi - m[i]);
-        const float vi = v[i] * fb2 + omb2 * gi * gi;
+    auto upd = [&](float gi, bool clipped, float& pi, float& mi, float& vi) __attribute__((always_inline)) {
+        if (clipped) gi = gi * coef;
+        mi = mi + omb1 * (gi - mi);
+        vi = vi * fb2 + omb2 * gi * gi;
         const float denom = sqrtf(vi) / bc2s + feps;
-        p[i] = p[i] - step_size * (mi / denom);
+        pi = pi - step_size * (mi / denom);
+    };
+    // 16-byte body, scalar tail (element-wise the same arithmetic)
+    const bool al = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    const long nv = al ? (n & ~3L) : 0;
+    for (long i = ((long)b * ADAM_THREADS + threadIdx.x) * 4; i < nv; i += (long)nb * ADAM_THREADS * 4) {
+        const float4 gv = *(const float4*)(g + i);
+        float4 pv = *(const float4*)(p + i), mv = *(const float4*)(m + i), vv = *(const float4*)(v + i);
+        upd(gv.x, i < n_clip, pv.x, mv.x, vv.x);
+        upd(gv.y, i + 1 < n_clip, pv.y, mv.y, vv.y);
+        upd(gv.z, i + 2 < n_clip, pv.z, mv.z, vv.z);
+        upd(gv.w, i + 3 < n_clip, pv.w, mv.w, vv.w);
+        *(float4*)(p + i) = pv;
+        *(float4*)(m + i) = mv;
+        *(float4*)(v + i) = vv;
+    }
+    for (long i = nv + (long)b * ADAM_THREADS + threadIdx.x; i < n; i += (long)nb * ADAM_THREADS) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        upd(g[i], i < n_clip, pi, mi, vi);
+        p[i] = pi;
         m[i] = mi;
         v[i] = vi;
     }

@@ -223,6 +223,10 @@ def clip_adam_group(items):
         d.extra, d.extra_stride, d.n_sum, d.n_extra = _ptr(it.get("extra")), int(it.get("extra_stride", 0)), int(it.get("n_sum", 0)), int(it.get("n_extra", 0))
         d.max_norm, d.lr, d.b1, d.b2, d.eps = float(it["max_norm"]), float(it["lr"]), float(it["b1"]), float(it["b2"]), float(it["eps"])
         d.state, d.skip_flag, d.gnorm_out, d.workspace = _ptr(it["state"]), _ptr(it.get("skip_flag")), _ptr(it.get("gnorm")), base + (-base) % 8
+        st = it.get("stats")                               # (acc, scal, which): ppo_accumulate_stats inside the norm pass
+        if st is not None:
+            _req(st[0], st[1])
+            d.stats_acc, d.stats_scal, d.stats_which = _ptr(st[0]), _ptr(st[1]), int(st[2])
     check(lib.pm_clip_adam_group_f32(len(items), arr, _stream()), "pm_clip_adam_group_f32")
 
 
