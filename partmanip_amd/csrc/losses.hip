@@ -136,9 +136,15 @@ __global__ __launch_bounds__(64) void ppo_actor_loss_final_kernel(const ActorLos
         ls += __shfl_xor(ls, o, 64);
         ks += __shfl_xor(ks, o, 64);
     }
-    for (int a = 0; a < A; ++a) {
-        const float t = wave_sum(has ? parts[tid].dls[a] : 0.f);
-        if (tid == 0) dlog_std[a] = t;
+    for (int a0 = 0; a0 < A; a0 += 16) {                   // sixteen independent loads in flight, then their butterflies
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = (has && a0 + j < A) ? parts[tid].dls[a0 + j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = wave_sum(t[j]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (tid == j && a0 + j < A) dlog_std[a0 + j] = t[j];
     }
     if (tid == 0) {
         float sum_logs = 0.f;
