@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restr
                                                              const float* __restrict__ wt,
                                                              const float* __restrict__ bias, int act_tanh, long nrows,
                                                              float* __restrict__ y, long ldy,
-                                                             const int64_t* __restrict__ bidx) {
+                                                             const int64_t* __restrict__ bidx, int vec4) {
     // one row per thread, no grid-stride loop: inside a loop the 125 x CO wave-uniform weight loads are loop-invariant
     // and hipcc hoists all of them (2010 spilled SGPRs)
     {
@@ -185,16 +185,20 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float* __restr
             }
         }
         float* yr = y + row * ldy;
+        if (act_tanh) {
 #pragma unroll
-        for (int o = 0; o < CO; o += 2) {
-            if (act_tanh) {
+            for (int o = 0; o < CO; o += 2) {
                 const f32x2 t = pm_tanh2(acc[o], acc[o + 1]);
-                yr[o] = t.x;
-                yr[o + 1] = t.y;
-            } else {
-                yr[o] = acc[o];
-                yr[o + 1] = acc[o + 1];
+                acc[o] = t.x;
+                acc[o + 1] = t.y;
             }
+        }
+        if (vec4) {                                         // the row's 64 bytes as four 16-byte stores instead of sixteen
+#pragma unroll
+            for (int o = 0; o < CO; o += 4) *(float4*)(yr + o) = make_float4(acc[o], acc[o + 1], acc[o + 2], acc[o + 3]);
+        } else {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) yr[o] = acc[o];
         }
     }
 }
@@ -361,7 +365,7 @@ extern "C" int pm_conv3d_c1_fwd_f32(const float* x, int B, int D, int H, int W, 
     const long nb = (nrows + 255) / 256;
     if (nb > 0x7fffffffL) return PM_EINVAL;
     hipLaunchKernelGGL((conv3d_c1_fwd_kernel<5, 16>), dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), x, g, wt, bias,
-                       act == PM_ACT_TANH, nrows, y, ldy, batch_index);
+                       act == PM_ACT_TANH, nrows, y, ldy, batch_index, (int)(ldy % 4 == 0 && ((uintptr_t)y & 15) == 0));
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
