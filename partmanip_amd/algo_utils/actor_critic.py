@@ -7,6 +7,8 @@ Added for the MI355X path: `flatten()` re-homes all parameters into two contiguo
 buffers -- [actor params | log_std] and [critic params] -- matching the reference's two
 optimisers (ppo.py:73-74), with same-layout gradient buffers the HIP backward writes into.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -17,7 +19,9 @@ from .. import ops
 
 class ActorCritic(nn.Module):
     SCAL_TAIL = 8
-    GRAD_SLABS = int(__import__("os").environ.get("PARTMANIP_GRAD_SLABS", "8"))   # split-K slabs of the grouped weight gradients (slab 0 = the gradient buffer); cfg 2: 4 -> 1.85 M, 8 -> 1.89 M, 16 -> 1.84 M env-steps/s
+    # split-K slabs of the grouped weight gradients of the small-step path (slab 0 = the gradient buffer itself, the optimiser's
+    # norm pass sums the rest).  cfg 2: 4 slabs 1.85 M env-steps/s, 8 -> 1.89 M, 16 -> 1.84 M, 32 -> 1.63 M.
+    GRAD_SLABS = int(os.environ.get("PARTMANIP_GRAD_SLABS", "8"))
 
     def __init__(self, obs_shape, actions_shape, model_cfg, proprio_shape=0):
         super(ActorCritic, self).__init__()
