@@ -85,8 +85,8 @@ def cfg1_problem():
     return dict(N=N, T=T, O=O, A=A, lr=lr, net=net, sd=sd, st=st, ret=ret, adv=adv, ref=p, out=out)
 
 
-@pytest.mark.parametrize("graphs,pair", [(True, False), (False, False), (True, True)])
-def test_cfg1_full_ppo_update_matches_oracle(cfg1_problem, graphs, pair):
+@pytest.mark.parametrize("graphs,pair,steps", [(True, False, 16), (True, False, 3), (True, False, 1), (False, False, 1), (True, True, 1)])
+def test_cfg1_full_ppo_update_matches_oracle(cfg1_problem, graphs, pair, steps):
     from partmanip_amd.algorithms import ppo
     q = cfg1_problem
     with tempfile.TemporaryDirectory() as d:
@@ -95,13 +95,14 @@ def test_cfg1_full_ppo_update_matches_oracle(cfg1_problem, graphs, pair):
     assert run.use_graphs, "MLP + sequential sampler + fixed lr on one GPU: the hipGraph path is the default"
     run.use_graphs = graphs
     run.pair = pair                                        # opt-in grouped actor+critic launch chain (PARTMANIP_PAIR=1)
+    run.graph_steps = steps                                # consecutive mini-batch steps per graph (3: a ragged last chunk)
     _fill(run, q["st"])
     run.log_dict = {}
     run.curr_iter = 1
     run.learn(q["st"]["last_values"].to(DEV))
     torch.cuda.synchronize()
     if graphs:                                             # epoch 1 eager, epoch 2 captures, epochs 3-5 replay
-        assert sum(1 for k in run._graphs if isinstance(k, tuple)) == (8 if run.pair else 16)
+        assert sum(1 for k in run._graphs if isinstance(k, tuple)) == (8 if run.pair else 2 * -(-8 // steps))
     assert np.array_equal(run.storage.returns.cpu().numpy(), q["ret"].numpy())
     log, ref = run.log_dict, q["out"]["log"]
     assert log["Train/kl_update_count"] == ref["Train/kl_update_count"] == 40
