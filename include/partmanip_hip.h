@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 129 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 130 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -190,6 +190,20 @@ int pm_ppo_actor_loss_fwd_bwd_f32(const float* mu, long ldmu, const float* log_s
                                   double adv_count, float* scal_out, float* dmu, long lddmu, float* dlog_std,
                                   void* workspace, size_t workspace_bytes, void* stream);
 size_t pm_ppo_actor_loss_workspace_bytes(int B);
+/* The policy head and its loss as ONE launch (small-step regime; ppo.py:322-347 from the last hidden activation on):
+ * mu = H W^T + bias (H: B x K last hidden activations, W: A x K, the head of network.py:40) -> the loss rows of
+ * pm_ppo_actor_loss_fwd_bwd_f32 -> dmu -> dH = (dmu W) .* act'(H) (hidden_act: PM_ACT_* of the hidden layers) -> the last
+ * work-group to finish reduces the partials.  Same arithmetic and summation order as pm_linear_fwd_f32 (row-wise form) +
+ * pm_ppo_actor_loss_fwd_bwd_f32 + pm_linear_bwd_data_f32: bit-identical outputs.  mu_out: NULL or B x A.  counter: one
+ * device uint32, zero before the first launch (the kernel leaves it zero).  Shapes: A <= 16, K % 4 == 0, A * K * 4 <= 64 KiB,
+ * 16-byte aligned rows (pm_ppo_actor_head_supported); otherwise PM_EUNSUPPORTED: use the three entry points separately. */
+int pm_ppo_actor_head_supported(const float* H, long ldh, const float* W, long ldw, int A, int K, const float* dH, long lddh);
+int pm_ppo_actor_head_f32(const float* H, long ldh, const float* W, long ldw, const float* bias, int K, int hidden_act,
+                          const float* log_std, const float* actions, long lda, const float* old_logp, const float* adv,
+                          const float* old_mu, long ldom, const float* old_sigma, long ldos, int B, int A, float max_action,
+                          int act_tanh, float eps_clip, float desired_kl, const double* adv_moments, double adv_count,
+                          float* scal_out, float* mu_out, long ldmu, float* dmu, long lddmu, float* dH, long lddh,
+                          float* dlog_std, void* workspace, size_t workspace_bytes, unsigned int* counter, void* stream);
 /* forward-only: log-prob/entropy rows, actor_critic.py:71-82 (used by rollout + tests). */
 int pm_gaussian_logp_f32(const float* mu, long ldmu, const float* log_std, const float* actions, long lda,
                          int B, int A, float max_action, int act_tanh, float* logp, float* entropy,

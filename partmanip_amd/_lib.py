@@ -42,6 +42,8 @@ SIGNATURES = {
     "pm_pointnet_enc_bwd_f32": (I, [P, L, I, I, I, I, P, P, P, P, P, I, P, L, P, P, P, P, P, P, P, P, P, Z, P]),
     "pm_ppo_actor_loss_fwd_bwd_f32": (I, [P, L, P, P, L, P, P, P, L, P, L, I, I, F, I, F, F, P, D, P, P, L, P, P, Z, P]),
     "pm_ppo_actor_loss_workspace_bytes": (Z, [I]),
+    "pm_ppo_actor_head_supported": (I, [P, L, P, L, I, I, P, L]),
+    "pm_ppo_actor_head_f32": (I, [P, L, P, L, P, I, I, P, P, L, P, P, P, L, P, L, I, I, F, I, F, F, P, D, P, P, L, P, L, P, L, P, P, Z, P, P]),
     "pm_gaussian_logp_f32": (I, [P, L, P, P, L, I, I, F, I, P, P, P]),
     "pm_gaussian_logp_bwd_f32": (I, [P, L, P, P, L, I, I, F, I, P, P, P, L, P, P]),
     "pm_action_activation_bwd_f32": (I, [P, P, P, L, F, I, P]),
@@ -134,7 +136,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 129                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 130                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -69,6 +69,18 @@ class _LinearChain:
             cur = y
         return cur
 
+    def forward_hidden(self, x):
+        """All layers but the last (the head runs fused with its loss: ops.ppo_actor_head); returns the last hidden activation."""
+        self.x = x
+        self.h = []
+        cur = x
+        for lin in self.linears[:-1]:
+            y = torch.empty(cur.shape[0], lin.out_features, device=cur.device)
+            ops.linear_fwd(cur, lin.weight.data, lin.bias.data, y, self.act)
+            self.h.append(y)
+            cur = y
+        return cur
+
     def backward(self, dy, ws, dx_out=None, x_is_activation=False):
         """dy: d loss / d output.  Fills self.grads; returns d loss / d input if dx_out is given
         (x_is_activation: the chain input is itself a tanh output whose derivative must be applied)."""
@@ -112,16 +124,23 @@ def chains_forward(chains, xs):
     return cur
 
 
-def chains_backward(chains, dys, slab_strides, splits):
+def chains_backward(chains, dys, slab_strides, splits, head_dz=None):
     """Backward of the same chains: one grouped data-gradient launch per layer, then ALL weight gradients of all chains in
     (at most) two grouped launches.  splits > 1: the reduction over the batch is cut into `splits` slabs written at
-    grad + z * slab_stride (slab 0 = the chain's gradient views); the optimiser launch sums them (ops.clip_adam_group)."""
+    grad + z * slab_stride (slab 0 = the chain's gradient views); the optimiser launch sums them (ops.clip_adam_group).
+    head_dz: the heads' data gradients (d loss / d pre-activation of the last hidden layer) when the caller's fused head
+    launch has already produced them."""
     n = len(chains[0].linears)
     dy = list(dys)
     dz = [[None] * n for _ in chains]                      # dz[c][i] = d loss / d (pre-activation of layer i)
     for c, d in enumerate(dy):
         dz[c][n - 1] = d
-    for i in reversed(range(1, n)):
+    top = n
+    if head_dz is not None:
+        for c, d in enumerate(head_dz):
+            dz[c][n - 2] = d
+        top = n - 1
+    for i in reversed(range(1, top)):
         items = []
         for c, ch in enumerate(chains):
             inp = ch.h[i - 1]

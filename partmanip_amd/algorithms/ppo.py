@@ -111,6 +111,7 @@ class ppo:
         self.use_graphs = (gr != "0") and is_mlp and self.overlap and cfg['sampler'] == 'sequential' and \
             self.lr_schedule == 'fixed' and self.sync is None
         self._graphs = {}
+        self.fused_head = os.environ.get("PARTMANIP_FUSED_HEAD", "1") == "1"
         # mini-batch steps per graph: 16 consecutive steps of a network replay as one graph (cfg 2: 1 -> 1.88 M env-steps/s,
         # 4 -> 1.916 M, 16 -> 1.919 M, 64 -> 1.922 M: the boundary between two graphs costs little more than a kernel boundary)
         self.graph_steps = max(1, int(os.environ.get("PARTMANIP_GRAPH_STEPS", "16")))
@@ -246,12 +247,33 @@ class ppo:
         B = mb['obs'].shape[0]
         if self._geom is not None:
             ac.actor.use_geometry(self._geom, indices)
-        mu = ac.actor.hip_forward(mb['obs'])
         mom, cnt = None, 0.0
         if tricks['mini_adv_norm']:                          # ppo.py:329
             ops.moments(mb['adv'].reshape(-1), self._mom, self._ws)
             cnt = sync.moments_sync(self._mom, B) if sync else B
             mom = self._mom
+        chain = getattr(ac.actor, '_chain', None) if (self.solo_group and self.fused_head) else None
+        if chain is not None and len(chain.linears) >= 2:
+            # small-step regime: policy head + loss + head data gradient as one launch (bit-identical to the separate ones)
+            h = chain.forward_hidden(mb['obs'])
+            lin = chain.linears[-1]
+            dh = torch.empty_like(h)
+            if ops.ppo_actor_head_supported(h, lin.weight.data, dh):
+                dmu = torch.empty(B, A, device=h.device)
+                ops.ppo_actor_head(h, lin.weight.data, lin.bias.data, chain.act, ac.log_std.data, mb['actions'], mb['old_logp'],
+                                   mb['adv'], mb['old_mu'], mb['old_sigma'], ac.max_action, ac.action_activate == 'tanh',
+                                   self.epsilon_clip, self.desired_kl, mom, cnt, scal_a, dmu, dh, f['grad_log_std'], self._ws_loss)
+                S = ac.GRAD_SLABS if B >= 1024 else 1
+                chains_backward([chain], [dmu], [f['slab_stride_actor']], S, head_dz=[dh])
+                ops.clip_adam_group([self.optimizer_actor.group_item(
+                    n=n_a + A, n_clip=n_a if clip else 0, max_norm=self.max_grad_norm if clip else 0.0, skip_flag=scal_a[2:3],
+                    extra=f['extra_actor'], extra_stride=f['slab_stride_actor'], n_sum=n_a, n_extra=S - 1,
+                    stats=(self._acc, scal_a, 0))])
+                return
+            mu = torch.empty(B, A, device=h.device)          # (shape outside the fused kernel: finish the forward separately)
+            ops.linear_fwd(h, lin.weight.data, lin.bias.data, mu, ops.ACT_NONE)
+        else:
+            mu = ac.actor.hip_forward(mb['obs'])
         dmu = torch.empty(B, A, device=mu.device)
         ops.ppo_actor_loss(mu, ac.log_std.data, mb['actions'], mb['old_logp'], mb['adv'], mb['old_mu'],
                            mb['old_sigma'], ac.max_action, ac.action_activate == 'tanh', self.epsilon_clip,

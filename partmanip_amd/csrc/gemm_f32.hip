@@ -8,6 +8,7 @@
 //              optimiser launch (grouped call, adam.hip).
 #include "common.h"
 #include "gemm2.h"
+#include "skinny.h"
 
 #define GB_M 64                       // tile / K-step granularity the split-K heuristic below counts in
 #define GB_N 64
@@ -22,32 +23,17 @@ static inline int aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // products (forward: 8.3 us) and a rank-N update per row (data gradient: 5.8 us): memory-bound VALU kernels over all CUs,
 // fp32 FMA chains with a fixed (deterministic) summation order.  (The weight gradient, an N x K reduction over the batch,
 // stays on the split-K GEMM: a per-work-group-partials VALU version measured 25 us against its 10 + 5.)
-#define SK_MAXN 16
-#define SK_T 256
 // Y[i][n] = act(sum_k X[i][k] W[n][k] + b[n]); one wave per row, lanes over k (float4 per lane per 256-wide chunk)
 __global__ __launch_bounds__(SK_T) void skinny_fwd_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ W, long ldw,
                                                           const float* __restrict__ b, float* __restrict__ Y, long ldy, int M, int N,
                                                           int K, int act) {
     extern __shared__ __attribute__((aligned(16))) float sW[];                  // [N][K]
-    for (int e = threadIdx.x * 4; e < N * K; e += SK_T * 4) {
-        const int n = e / K, k = e - n * K;
-        *(float4*)(sW + e) = *(const float4*)(W + (long)n * ldw + k);
-    }
+    sk_fill_w(sW, W, ldw, N, K);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = blockIdx.x * 4 + wave; i < M; i += gridDim.x * 4) {
         float acc[SK_MAXN];
-#pragma unroll
-        for (int n = 0; n < SK_MAXN; ++n) acc[n] = 0.f;
-        for (int k = lane * 4; k < K; k += 256) {
-            const float4 x = *(const float4*)(X + (long)i * ldx + k);
-#pragma unroll
-            for (int n = 0; n < SK_MAXN; ++n)
-                if (n < N) {
-                    const float4 w = *(const float4*)(sW + n * K + k);
-                    acc[n] = fmaf(x.w, w.w, fmaf(x.z, w.z, fmaf(x.y, w.y, fmaf(x.x, w.x, acc[n]))));
-                }
-        }
+        sk_row_dot(X + (long)i * ldx, sW, N, K, lane, acc);
 #pragma unroll
         for (int n = 0; n < SK_MAXN; ++n)
             if (n < N) {
@@ -61,33 +47,16 @@ __global__ __launch_bounds__(SK_T) void skinny_dgrad_kernel(const float* __restr
                                                             const float* __restrict__ H, long ldh, float* __restrict__ dX, long lddx,
                                                             int M, int N, int K, int act) {
     extern __shared__ __attribute__((aligned(16))) float sW[];                  // [N][K]
-    for (int e = threadIdx.x * 4; e < N * K; e += SK_T * 4) {
-        const int n = e / K, k = e - n * K;
-        *(float4*)(sW + e) = *(const float4*)(W + (long)n * ldw + k);
-    }
+    sk_fill_w(sW, W, ldw, N, K);
     __syncthreads();
     const int k4 = K >> 2;
     const long total = (long)M * k4;
     for (long e = (long)blockIdx.x * SK_T + threadIdx.x; e < total; e += (long)gridDim.x * SK_T) {
         const long i = e / k4;
         const int k = (int)(e - i * k4) * 4;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int n = 0; n < SK_MAXN; ++n)
-            if (n < N) {
-                const float g = dY[i * lddy + n];
-                const float4 w = *(const float4*)(sW + n * K + k);
-                s.x = fmaf(g, w.x, s.x); s.y = fmaf(g, w.y, s.y); s.z = fmaf(g, w.z, s.z); s.w = fmaf(g, w.w, s.w);
-            }
-        if (act != PM_ACT_NONE) {
-            const float4 h = *(const float4*)(H + i * ldh + k);
-            s.x *= pm_dact(h.x, act); s.y *= pm_dact(h.y, act); s.z *= pm_dact(h.z, act); s.w *= pm_dact(h.w, act);
-        }
-        *(float4*)(dX + i * lddx + k) = s;
+        const float* dyrow = dY + i * lddy;
+        *(float4*)(dX + i * lddx + k) = sk_dgrad4([&](int n) { return dyrow[n]; }, sW, N, K, k, H + i * ldh, act);
     }
-}
-static inline bool skinny_ok(int N, int K, const void* a, long lda, const void* b, long ldb) {
-    return N <= SK_MAXN && K % 4 == 0 && (long)N * K * 4 <= 64 * 1024 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(a) && aligned16(b);
 }
 
 

@@ -3,6 +3,7 @@
 // traffic per call; the point of fusing is to remove ~40 tiny ATen launches and two host
 // syncs per mini-batch (ppo.py:326-357), not bandwidth.
 #include "common.h"
+#include "skinny.h"
 
 #define LOSS_THREADS 1024
 #define LOSS_WAVES (LOSS_THREADS / 64)
@@ -17,11 +18,11 @@ __device__ __forceinline__ float deactivate(float a, float max_action, int act_t
 }
 
 // ---------------------------------------------------------------------------------- K8
-// Stage 1: up to 64 work-groups of 256 rows each write dmu and a partial {loss, kl, dlog_std[A]};
+// Stage 1: up to 128 work-groups of 256 threads each write dmu and a partial {loss, kl, dlog_std[A]};
 // stage 2 (one wave) sums the partials in fixed order.  (A single 1024-thread work-group took
 // 63 us for 2048 rows -- 12 % of a state-PPO optimiser step; the row math is atanh/exp/log heavy.)
 #define AL_THREADS 256
-#define AL_MAXG 64
+#define AL_MAXG 128
 struct ActorLossPart {
     double loss, kl;
     float dls[MAX_A];
@@ -123,23 +124,32 @@ __global__ __launch_bounds__(AL_THREADS) void ppo_actor_loss_part_kernel(
     }
 }
 
-__global__ __launch_bounds__(64) void ppo_actor_loss_final_kernel(const ActorLossPart* __restrict__ parts, int G, int B,
-                                                                   int A, const float* __restrict__ log_std,
-                                                                   float desired_kl, float* __restrict__ scal_out,
-                                                                   float* __restrict__ dlog_std) {
-    // lane g holds work-group g's partial (G <= 64 = one wave): butterfly sums instead of G dependent loads in one lane
-    const int tid = threadIdx.x;
-    const bool has = tid < G;
-    double ls = has ? parts[tid].loss : 0.0, ks = has ? parts[tid].kl : 0.0;
+// final stage (one wave): butterfly sums over the work-groups' partials instead of G dependent loads in one lane
+template <bool COHERENT = false>                           // true: the partials were written by other work-groups of THIS launch
+__device__ __forceinline__ void actor_loss_final(const ActorLossPart* parts, int G, int B, int A,
+                                                 const float* __restrict__ log_std, float desired_kl, float* __restrict__ scal_out,
+                                                 float* __restrict__ dlog_std, int tid, const float* sum_logs_known = nullptr) {
+    const bool has = tid < G, has2 = tid + 64 < G;         // G <= 128: lane g holds partials g and g + 64
+    auto ldd = [&](const double* p) { return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
+    auto ldf = [&](const float* p) { return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
+    double ls = has ? ldd(&parts[tid].loss) : 0.0, ks = has ? ldd(&parts[tid].kl) : 0.0;
+    if (has2) {
+        ls += ldd(&parts[tid + 64].loss);
+        ks += ldd(&parts[tid + 64].kl);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         ls += __shfl_xor(ls, o, 64);
         ks += __shfl_xor(ks, o, 64);
     }
     for (int a0 = 0; a0 < A; a0 += 16) {                   // sixteen independent loads in flight, then their butterflies
-        float t[16];
+        float t[16], u[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) t[j] = (has && a0 + j < A) ? parts[tid].dls[a0 + j] : 0.f;
+        for (int j = 0; j < 16; ++j) t[j] = (has && a0 + j < A) ? ldf(&parts[tid].dls[a0 + j]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) u[j] = (has2 && a0 + j < A) ? ldf(&parts[tid + 64].dls[a0 + j]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] += u[j];
 #pragma unroll
         for (int j = 0; j < 16; ++j) t[j] = wave_sum(t[j]);
 #pragma unroll
@@ -148,15 +158,186 @@ __global__ __launch_bounds__(64) void ppo_actor_loss_final_kernel(const ActorLos
     }
     if (tid == 0) {
         float sum_logs = 0.f;
-        for (int a = 0; a < A; ++a) {
-            const float e = expf(log_std[a]);
-            sum_logs += logf(e * e);
+        if (sum_logs_known) {                              // (the caller has this very sum already)
+            sum_logs = *sum_logs_known;
+        } else {
+            for (int a = 0; a < A; ++a) {
+                const float e = expf(log_std[a]);
+                sum_logs += logf(e * e);
+            }
         }
         const float klm = (float)(ks / (double)B);
         scal_out[0] = (float)(ls / (double)B);
         scal_out[1] = klm;
         scal_out[2] = (klm > desired_kl) ? 1.0f : 0.0f;
         scal_out[3] = 0.5f * (float)A * (1.0f + 1.8378770664093453f) + sum_logs;   // entropy (same every row)
+    }
+}
+__global__ __launch_bounds__(64) void ppo_actor_loss_final_kernel(const ActorLossPart* __restrict__ parts, int G, int B,
+                                                                   int A, const float* __restrict__ log_std,
+                                                                   float desired_kl, float* __restrict__ scal_out,
+                                                                   float* __restrict__ dlog_std) {
+    actor_loss_final(parts, G, B, A, log_std, desired_kl, scal_out, dlog_std, threadIdx.x);
+}
+
+// ---- the policy head and its loss as ONE launch (small-step regime) ------------------------------------------------------
+// mu = H W^T + b (row-wise, skinny.h) -> the loss rows above -> dmu -> dH = (dmu W) .* act'(H) -> the last work-group to
+// finish sums the partials.  Replaces four dependent launches of a state-PPO actor step (head forward 9 us, loss 9.7, final
+// 8, head data gradient 5.7 of a ~200 us chain) by one; every stage keeps the arithmetic and the summation order of the
+// separate kernels (same work-group partition as ppo_actor_loss_part_kernel<16>), so the results are bit-identical.
+#define AH_ROWS 16
+#define AH_THREADS 1024
+__global__ __launch_bounds__(AH_THREADS) void ppo_actor_head_kernel(
+    const float* __restrict__ H, long ldh, const float* __restrict__ W, long ldw, const float* __restrict__ bias, int K, int hact,
+    const float* __restrict__ log_std, const float* __restrict__ actions, long lda, const float* __restrict__ old_logp,
+    const float* __restrict__ adv, const float* __restrict__ old_mu, long ldom, const float* __restrict__ old_sigma, long ldos,
+    int B, int A, float max_action, int act_tanh, float eps_clip, float desired_kl, const double* __restrict__ adv_moments,
+    double adv_count, float* __restrict__ mu_out, long ldmu, float* __restrict__ dmu, long lddmu, float* __restrict__ dH, long lddh,
+    ActorLossPart* __restrict__ parts, unsigned int* __restrict__ counter, float* __restrict__ scal_out,
+    float* __restrict__ dlog_std) {
+    constexpr int AP = 16, RPB = AH_ROWS;
+    extern __shared__ __attribute__((aligned(16))) float sW[];                  // [A][K]
+    __shared__ float s_ls[MAX_A], s_s[MAX_A];
+    __shared__ double red[AH_THREADS / 64];
+    __shared__ float red_a[RPB][AP];
+    __shared__ float s_mu[RPB][AP], s_dmu[RPB][AP];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool lt = tid < AL_THREADS;                      // the loss rows run on the first 256 threads (16 lanes per row)
+    const int r = lt ? tid / AP : 0, a = tid % AP;
+    sk_fill_w<AH_THREADS>(sW, W, ldw, A, K);
+    if (tid < A) {
+        const float ls = log_std[tid];
+        const float e = expf(ls);
+        s_ls[tid] = ls;
+        s_s[tid] = e * e;
+    }
+    __syncthreads();
+    float sum_logs = 0.f;
+    for (int k = 0; k < A; ++k) sum_logs += logf(s_s[k]);
+    const float k_log2pi = (float)A * 1.8378770664093453f;
+    float a_mean = 0.f, a_den = 1.f;
+    if (adv_moments) {
+        const double m = adv_moments[0] / adv_count;
+        double var = (adv_moments[1] - adv_moments[0] * m) / (adv_count - 1.0);
+        if (var < 0.0) var = 0.0;
+        a_mean = (float)m;
+        a_den = (float)sqrt(var) + 1e-8f;
+    }
+    const float invB = 1.0f / (float)B;
+    const bool on_a = a < A;
+    const float sa = on_a ? s_s[a] : 1.f, lsa = on_a ? s_ls[a] : 0.f;
+    double loss_acc = 0.0, kl_acc = 0.0;
+    float cacc = 0.f;
+    const int k4 = K >> 2;
+    for (int base = blockIdx.x * RPB; base < B; base += gridDim.x * RPB) {
+        // the loss rows' inputs do not depend on mu: request them now, they land under the head forward
+        const int i = base + r;
+        const bool row = lt && i < B, on = row && on_a;
+        float in_act = 0.f, in_os = 0.f, in_om = 0.f, in_olp = 0.f, in_adv = 0.f;
+        if (on) {
+            in_act = actions[i * lda + a];
+            in_os = old_sigma[i * ldos + a];
+            in_om = old_mu[i * ldom + a];
+        }
+        if (row) {
+            in_olp = old_logp[i];
+            in_adv = adv[i];
+        }
+        // ---- head forward: one row of the pass per wave
+        {
+            const int rr = wave, i = base + rr;
+            if (i < B) {                                    // wave-uniform
+                float acc[SK_MAXN];
+                sk_row_dot(H + (long)i * ldh, sW, A, K, lane, acc);
+#pragma unroll
+                for (int n = 0; n < SK_MAXN; ++n)
+                    if (n < A) {
+                        const float s = wave_sum(acc[n]);
+                        if (lane == n) {
+                            const float m = s + (bias ? bias[n] : 0.f);
+                            s_mu[rr][n] = m;
+                            if (mu_out) mu_out[(long)i * ldmu + n] = m;
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+        // ---- loss rows (ppo_actor_loss_part_kernel<16>, mu from LDS)
+        float z = 0.f, klt = 0.f;
+        if (on) {
+            const float m = s_mu[r][a];
+            const float x = deactivate(in_act, max_action, act_tanh);
+            const float os = in_os;
+            z = (x - m) / sa;
+            const float eo = expf(os);
+            const float dm = in_om - m;
+            klt = lsa - os + (eo * eo + dm * dm) / (2.0f * sa) - 0.5f;
+        }
+        float M = z * z, kl = klt;
+#pragma unroll
+        for (int o = AP / 2; o > 0; o >>= 1) {
+            M += __shfl_xor(M, o, 64);
+            kl += __shfl_xor(kl, o, 64);
+        }
+        float g = 0.f;
+        if (row) {
+            const float logp = -0.5f * (k_log2pi + M) - sum_logs;
+            const float ratio = expf(logp - in_olp);
+            float ad = in_adv;
+            if (adv_moments) ad = (ad - a_mean) / a_den;
+            const float s1 = -ad * ratio;
+            const float s2 = -ad * fminf(fmaxf(ratio, 1.0f - eps_clip), 1.0f + eps_clip);
+            if (a == 0) {
+                loss_acc += (double)fmaxf(s1, s2);
+                kl_acc += (double)kl;
+            }
+            g = (s1 >= s2 ? -ad : 0.0f) * ratio * invB;
+        }
+        float dm_out = 0.f;
+        if (on) {
+            dm_out = g * z / sa;
+            dmu[i * lddmu + a] = dm_out;
+            cacc += g * (2.0f * z * z - 2.0f);
+        }
+        if (lt) s_dmu[r][a] = dm_out;
+        __syncthreads();
+        // ---- head data gradient: (row, 4 columns) items of the pass over the work-group
+        for (int e = tid; e < RPB * k4; e += AH_THREADS) {
+            const int rr = e / k4, k = (e - rr * k4) * 4;
+            const long ii = base + rr;
+            if (ii < B)
+                *(float4*)(dH + ii * lddh + k) = sk_dgrad4([&](int n) { return s_dmu[rr][n]; }, sW, A, K, k, H + ii * ldh, hact);
+        }
+        __syncthreads();                                   // s_mu / s_dmu are rewritten by the next pass
+    }
+    // (threads 256.. carry zeros: the same sums, in the same order, as the 256-thread loss kernel's)
+    const double loss_sum = block_sum<double, AH_THREADS>(loss_acc, red);
+    const double kl_sum = block_sum<double, AH_THREADS>(kl_acc, red);
+    if (lt) red_a[r][a] = cacc;
+    __syncthreads();
+    // The partials cross work-groups (and XCDs, whose L2s are not coherent with each other) INSIDE the launch.  A device-scope
+    // fence would do it -- and writes back every dirty L2 line first, the 4 MB of dH included: the kernel took 49 us with
+    // __threadfence() against 13 without.  Instead the partials themselves travel as device-scope atomic stores / loads
+    // (write-through, sc1) and the ordinary stores are left to the end-of-kernel release.
+    ActorLossPart* part = parts + blockIdx.x;
+    if (lt && tid < A) {
+        float t = 0.f;
+        for (int k = 0; k < RPB; ++k) t += red_a[k][tid];
+        __hip_atomic_store(&part->dls[tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+        __hip_atomic_store(&part->loss, loss_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&part->kl, kl_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my partials have reached memory ...
+    __syncthreads();                                       // ... and so have this work-group's
+    // ---- the last work-group to get here sums the partials (fixed order: the result does not depend on which one it is)
+    if (tid == 0) s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (s_last && tid < 64) {
+        actor_loss_final<true>(parts, (int)gridDim.x, B, A, log_std, desired_kl, scal_out, dlog_std, tid, &sum_logs);
+        if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
 }
 
@@ -191,6 +372,34 @@ extern "C" int pm_ppo_actor_loss_fwd_bwd_f32(const float* mu, long ldmu, const f
                            adv_moments, adv_count, dmu, lddmu, parts);
     hipLaunchKernelGGL(ppo_actor_loss_final_kernel, dim3(1), dim3(64), 0, pm_stream(stream), parts, G, B, A, log_std,
                        desired_kl, scal_out, dlog_std);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_ppo_actor_head_supported(const float* H, long ldh, const float* W, long ldw, int A, int K, const float* dH,
+                                           long lddh) {
+    return A <= 16 && skinny_ok(A, K, H, ldh, W, ldw) && lddh % 4 == 0 && sk_aligned16(dH);
+}
+
+extern "C" int pm_ppo_actor_head_f32(const float* H, long ldh, const float* W, long ldw, const float* bias, int K, int hidden_act,
+                                     const float* log_std, const float* actions, long lda, const float* old_logp,
+                                     const float* adv, const float* old_mu, long ldom, const float* old_sigma, long ldos, int B,
+                                     int A, float max_action, int act_tanh, float eps_clip, float desired_kl,
+                                     const double* adv_moments, double adv_count, float* scal_out, float* mu_out, long ldmu,
+                                     float* dmu, long lddmu, float* dH, long lddh, float* dlog_std, void* workspace,
+                                     size_t workspace_bytes, unsigned int* counter, void* stream) {
+    PM_REQUIRE(H && W && log_std && actions && old_logp && adv && old_mu && old_sigma && scal_out && dmu && dH && dlog_std && counter);
+    PM_REQUIRE(B > 0 && A > 0 && K > 0 && max_action > 0.f && ldh >= K && ldw >= K && lddh >= K && lddmu >= A);
+    PM_REQUIRE(hidden_act >= PM_ACT_NONE && hidden_act <= PM_ACT_MAX);
+    PM_REQUIRE(!adv_moments || adv_count > 1.0);
+    PM_REQUIRE(!mu_out || ldmu >= A);
+    if (!pm_ppo_actor_head_supported(H, ldh, W, ldw, A, K, dH, lddh)) return PM_EUNSUPPORTED;
+    const int G = actor_loss_blocks(B);
+    if (!workspace || workspace_bytes < (size_t)G * sizeof(ActorLossPart) || ((uintptr_t)workspace & 7)) return PM_EWORKSPACE;
+    hipLaunchKernelGGL(ppo_actor_head_kernel, dim3(G), dim3(AH_THREADS), (size_t)A * K * 4, pm_stream(stream), H, ldh, W, ldw, bias, K,
+                       hidden_act, log_std, actions, lda, old_logp, adv, old_mu, ldom, old_sigma, ldos, B, A, max_action, act_tanh,
+                       eps_clip, desired_kl, adv_moments, adv_count, mu_out, ldmu, dmu, lddmu, dH, lddh, (ActorLossPart*)workspace,
+                       counter, scal_out, dlog_std);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }

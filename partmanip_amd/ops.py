@@ -308,6 +308,31 @@ def ppo_actor_loss(mu, log_std, actions, old_logp, adv, old_mu, old_sigma, max_a
           "pm_ppo_actor_loss_fwd_bwd_f32")
 
 
+def ppo_actor_head_supported(h, w, dh):
+    return bool(lib.pm_ppo_actor_head_supported(_ptr(h), _rows(h, "h"), _ptr(w), _rows(w, "w"), w.shape[0], w.shape[1], _ptr(dh),
+                                                _rows(dh, "dh")))
+
+
+def ppo_actor_head(h, w, b, hidden_act, log_std, actions, old_logp, adv, old_mu, old_sigma, max_action, act_tanh, eps_clip,
+                   desired_kl, adv_moments, adv_count, scal, dmu, dh, dlog_std, ws, mu_out=None):
+    """Policy head forward + PPO actor loss + dmu + head data gradient in one launch (pm_ppo_actor_head_f32); `ws` also keeps
+    the launch's self-resetting work-group counter."""
+    _req(h, w, b, log_std, actions, old_logp, adv, old_mu, old_sigma, scal, dmu, dh, dlog_std, mu_out)
+    B, K = h.shape
+    A = w.shape[0]
+    buf = ws.get(lib.pm_ppo_actor_loss_workspace_bytes(B))
+    ctr = getattr(ws, "counter", None)
+    if ctr is None:
+        ctr = ws.counter = torch.zeros(4, dtype=torch.int32, device=h.device)
+    check(lib.pm_ppo_actor_head_f32(_ptr(h), _rows(h, "h"), _ptr(w), _rows(w, "w"), _ptr(b), K, int(hidden_act), _ptr(log_std),
+                                    _ptr(actions), _rows(actions, "actions"), _ptr(old_logp), _ptr(adv), _ptr(old_mu),
+                                    _rows(old_mu, "old_mu"), _ptr(old_sigma), _rows(old_sigma, "old_sigma"), B, A,
+                                    float(max_action), int(act_tanh), float(eps_clip), float(desired_kl), _ptr(adv_moments),
+                                    float(adv_count), _ptr(scal), _ptr(mu_out), _rows(mu_out, "mu_out") if mu_out is not None else 0,
+                                    _ptr(dmu), _rows(dmu, "dmu"), _ptr(dh), _rows(dh, "dh"), _ptr(dlog_std), _ptr(buf), buf.numel(),
+                                    _ptr(ctr), _stream()), "pm_ppo_actor_head_f32")
+
+
 def gaussian_logp(mu, log_std, actions, max_action, act_tanh, logp, entropy):
     _req(mu, log_std, actions, logp, entropy)
     B, A = mu.shape

@@ -112,6 +112,31 @@ def test_cfg1_full_ppo_update_matches_oracle(cfg1_problem, graphs, pair, steps):
     print(f"cfg1 graphs={graphs}: worst per-tensor relative update error {worst:.2e}")
 
 
+def test_cfg1_fused_policy_head_is_bit_identical(cfg1_problem):
+    """cfg 1 whole update with the policy head + loss + head data gradient as ONE launch (default) and as four
+    (PARTMANIP_FUSED_HEAD=0's path): the same arithmetic in the same order -> identical parameters and scalars."""
+    from partmanip_amd.algorithms import ppo
+    q = cfg1_problem
+    res = []
+    for fused in (True, False):
+        with tempfile.TemporaryDirectory() as d:
+            run = ppo(FakeEnv(q["N"], {"normal_state": q["O"]}, q["A"]), _cfg(q["net"], q["N"], q["T"], 8, 5, q["lr"], DEV), FakeLogger(d))
+        run.actor_critic.load_state_dict({k: t(v.copy()) for k, v in q["sd"].items()})
+        assert run.fused_head and run.solo_group
+        run.fused_head = fused
+        _fill(run, q["st"])
+        run.log_dict = {}
+        run.curr_iter = 1
+        run.learn(q["st"]["last_values"].to(DEV))
+        torch.cuda.synchronize()
+        res.append(({k: v.clone() for k, v in run.actor_critic.state_dict().items()}, dict(run.log_dict)))
+    (sa, la), (sb, lb) = res
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for k in ("Train/surrogate_loss", "Train/kl", "Train/kl_max", "Train/value_function_loss"):
+        assert float(la[k]) == float(lb[k]), k
+
+
 # ------------------------------------------------------------------------------------------------------ cfg 3, B = 2048
 def _sliced_grads(p, names, loss_of_slice, n, sl=128):
     """Gradient of the mean loss over n rows as the average of the slice means (n % sl == 0)."""
