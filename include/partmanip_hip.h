@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 130 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 131 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -116,7 +116,11 @@ typedef struct pm_linear_bwd_data_desc {
     const float* dY; long lddy; const float* W; long ldw; const float* H; long ldh; float* dX; long lddx; int M, N, K, act;
 } pm_linear_bwd_data_desc;
 typedef struct pm_linear_bwd_weight_desc {
-    const float* dY; long lddy; const float* X; long ldx; float* dW; long lddw; float* db; long slab_stride; int M, N, K, pad_;
+    const float* dY; long lddy; const float* X; long ldx; float* dW; long lddw; float* db; long slab_stride; int M, N, K;
+    int dy_cols, x_cols; /* 0, or the number of columns of a dY / X row that may be READ (>= N / K, <= the row stride): rows of 10 or 53
+                          * floats inside 16- / 56-float strides take the 16-byte loaders with dy_cols = 16 / x_cols = 56; the extra
+                          * columns' contents do not reach dW / db */
+    int pad_;
 } pm_linear_bwd_weight_desc;
 int pm_linear_fwd_group_f32(int n, const pm_linear_fwd_desc* d, void* stream);
 int pm_linear_bwd_data_group_f32(int n, const pm_linear_bwd_data_desc* d, void* stream);
@@ -212,10 +216,10 @@ int pm_gaussian_logp_f32(const float* mu, long ldmu, const float* log_std, const
 /* ------------------------------------------------------------------ K9  value loss
  * ppo.py:368-374: mean((ret-V)^2), or the clipped variant with the batch-mean clip width.
  * clip_mean_extern: NULL or device float = all-reduced mean(|eps*V_old|) (data parallel).
- * scal_out[0] = loss.  dV (B) = d loss / dV * grad_scale. */
+ * scal_out[0] = loss.  dV (B rows of stride lddv >= 1) = d loss / dV * grad_scale. */
 int pm_value_loss_fwd_bwd_f32(const float* V, const float* returns, const float* old_values, int B,
                               int clipped, float eps_clip, const float* clip_mean_extern, float grad_scale,
-                              float* scal_out, float* dV, void* stream);
+                              float* scal_out, float* dV, long lddv, void* stream);
 
 /* ------------------------------------------------------------------ K11 DAgger loss
  * dagger.py:310-314: mean((tanh(tea_mu)*max_a - tanh(stu_mu)*max_a)^2) over B*A and

@@ -52,11 +52,12 @@ class _LinearChain:
         self.final_act = final_act        # activation after the last Linear too (PointNet++ shared MLPs); the
                                           # caller then folds act' of the chain OUTPUT into the dy it passes back
         self.h = []                        # saved activation outputs of the hidden layers
+        self.x_w = None                    # the chain input again, in rows padded for 16-byte loads (ops.padded_cols): weight gradient only
         self.grads = None                  # list[(dW view, db view)] set by ActorCritic.flatten()
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, x_w=None):
         n = len(self.linears)
-        self.x = x
+        self.x, self.x_w = x, x_w
         self.h = []
         cur = x
         for i, lin in enumerate(self.linears):
@@ -69,9 +70,9 @@ class _LinearChain:
             cur = y
         return cur
 
-    def forward_hidden(self, x):
+    def forward_hidden(self, x, x_w=None):
         """All layers but the last (the head runs fused with its loss: ops.ppo_actor_head); returns the last hidden activation."""
-        self.x = x
+        self.x, self.x_w = x, x_w
         self.h = []
         cur = x
         for lin in self.linears[:-1]:
@@ -108,7 +109,7 @@ def chains_forward(chains, xs):
     assert all(len(ch.linears) == n for ch in chains)
     cur = list(xs)
     for ch, x in zip(chains, xs):
-        ch.x, ch.h = x, []
+        ch.x, ch.x_w, ch.h = x, None, []
     for i in range(n):
         last = i == n - 1
         items = []
@@ -157,10 +158,13 @@ def chains_backward(chains, dys, slab_strides, splits, head_dz=None):
     vec, rest = [], []
     for c, ch in enumerate(chains):
         for i in range(n):
-            inp = ch.h[i - 1] if i > 0 else ch.x
+            inp = ch.h[i - 1] if i > 0 else (ch.x_w if ch.x_w is not None else ch.x)
             dW, db = ch.grads[i]
             item = (dz[c][i], inp, dW, db, slab_strides[c])
-            ok = dz[c][i].shape[1] % 4 == 0 and inp.shape[1] % 4 == 0 and inp.stride(0) % 4 == 0 and inp.data_ptr() % 16 == 0
+            # 16-byte loads: whole float4s per row, counting the readable padding of ops.padded_cols buffers
+            ncol, kcol = getattr(dz[c][i], "_pm_cols", dz[c][i].shape[1]), getattr(inp, "_pm_cols", inp.shape[1])
+            ok = ncol % 4 == 0 and kcol % 4 == 0 and inp.stride(0) % 4 == 0 and inp.data_ptr() % 16 == 0 and \
+                dz[c][i].stride(0) % 4 == 0 and dz[c][i].data_ptr() % 16 == 0
             (vec if ok else rest).append(item)
     for grp in (vec, rest):                                # 16-byte-loadable problems must not share a launch with the others
         for lo in range(0, len(grp), 8):
@@ -212,8 +216,8 @@ class MLP(_HipNet):
         idx = [i for i, m in enumerate(self.model) if isinstance(m, nn.Linear)]
         self._chain.grads = [(views[f"model.{i}.weight"], views[f"model.{i}.bias"]) for i in idx]
 
-    def hip_forward(self, x, out=None):
-        return self._chain.forward(x, out)
+    def hip_forward(self, x, out=None, x_w=None):
+        return self._chain.forward(x, out, x_w)
 
     def hip_backward(self, dy):
         self._chain.backward(dy, self._workspace(dy.device))

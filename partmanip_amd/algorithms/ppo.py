@@ -111,6 +111,7 @@ class ppo:
         self.use_graphs = (gr != "0") and is_mlp and self.overlap and cfg['sampler'] == 'sequential' and \
             self.lr_schedule == 'fixed' and self.sync is None
         self._graphs = {}
+        self._obs_pad = None
         self.fused_head = os.environ.get("PARTMANIP_FUSED_HEAD", "1") == "1"
         # mini-batch steps per graph: 16 consecutive steps of a network replay as one graph (cfg 2: 1 -> 1.88 M env-steps/s,
         # 4 -> 1.916 M, 16 -> 1.919 M, 64 -> 1.922 M: the boundary between two graphs costs little more than a kernel boundary)
@@ -223,7 +224,13 @@ class ppo:
         """Sequential sampler -> contiguous slices (zero copy); random -> HIP row gather (K3)."""
         if isinstance(indices, tuple):
             lo, n = indices
-            return {k: views[k][lo:lo + n] for k in keys}
+            mb = {k: views[k][lo:lo + n] for k in keys}
+            pad = views.get('obs_pad')
+            if pad is not None and 'obs' in keys:          # the same rows inside 16-byte-padded strides (weight gradient of layer 0)
+                xw = pad[lo:lo + n]
+                xw._pm_cols = pad._pm_cols
+                mb['obs_pad'] = xw
+            return mb
         n = len(indices)
         dev = views['obs'].device
         idx = indices.to(dev, non_blocking=True)
@@ -255,11 +262,11 @@ class ppo:
         chain = getattr(ac.actor, '_chain', None) if (self.solo_group and self.fused_head) else None
         if chain is not None and len(chain.linears) >= 2:
             # small-step regime: policy head + loss + head data gradient as one launch (bit-identical to the separate ones)
-            h = chain.forward_hidden(mb['obs'])
+            h = chain.forward_hidden(mb['obs'], mb.get('obs_pad'))
             lin = chain.linears[-1]
             dh = torch.empty_like(h)
             if ops.ppo_actor_head_supported(h, lin.weight.data, dh):
-                dmu = torch.empty(B, A, device=h.device)
+                dmu = ops.padded_cols(B, A, h.device)     # (B, A) inside 16-byte rows: the head's weight gradient loads float4s
                 ops.ppo_actor_head(h, lin.weight.data, lin.bias.data, chain.act, ac.log_std.data, mb['actions'], mb['old_logp'],
                                    mb['adv'], mb['old_mu'], mb['old_sigma'], ac.max_action, ac.action_activate == 'tanh',
                                    self.epsilon_clip, self.desired_kl, mom, cnt, scal_a, dmu, dh, f['grad_log_std'], self._ws_loss)
@@ -304,11 +311,12 @@ class ppo:
         B = mb['obs'].shape[0]
         if self._geom is not None:
             ac.critic.use_geometry(self._geom, indices)
-        value = ac.critic.hip_forward(mb['obs'])
+        cchain = getattr(ac.critic, '_chain', None) if self.solo_group else None
+        value = ac.critic.hip_forward(mb['obs'], x_w=mb.get('obs_pad')) if cchain is not None else ac.critic.hip_forward(mb['obs'])
         clip_mean = None
         if tricks['use_clipped_value_loss'] and sync:
             clip_mean = sync.mean_((self.epsilon_clip * mb['values']).abs().mean().reshape(1))
-        dv = torch.empty(B, 1, device=value.device)
+        dv = ops.padded_cols(B, 1, value.device) if cchain is not None else torch.empty(B, 1, device=value.device)
         ops.value_loss(value, mb['returns'], mb['values'], tricks['use_clipped_value_loss'], self.epsilon_clip,
                        clip_mean, 1.0, scal_c, dv)
         if self.solo_group:
@@ -364,7 +372,7 @@ class ppo:
         hyper-parameters -- while everything that changes between steps (parameters, Adam moments and step
         counter, the KL skip flag, the running sums) lives in device memory."""
         f = self.actor_critic.flat()
-        key = (views['obs'].data_ptr(), views['adv'].data_ptr(), views['returns'].data_ptr(),
+        key = (views['obs'].data_ptr(), views['obs_pad'].data_ptr() if 'obs_pad' in views else 0, views['adv'].data_ptr(), views['returns'].data_ptr(),
                f['actor'].data_ptr(), f['critic'].data_ptr(), self.optimizer_actor.param_groups[0]['lr'], self.optimizer_critic.param_groups[0]['lr'])
         if self._graphs.get('key') != key:
             self._graphs = {'key': key, 'seen': set(),
@@ -405,6 +413,14 @@ class ppo:
         if not self.optimizer_critic.bound_to(f['critic']):
             self.optimizer_critic.rebind(f['critic'], f['grad_critic'][:f['n_critic']])
         views = self._views()
+        if self.solo_group and views['obs'].shape[1] % 4 != 0 and self.storage.sampler == "sequential":
+            # small-step regime: the rollout's observations once more in rows padded to 16 bytes (53 -> 56 floats), so that the
+            # input layer's weight gradient joins the other layers' LDS-DMA launch (one copy per rollout, 128 of 0.28 ms at cfg 2)
+            o = views['obs']
+            if self._obs_pad is None or self._obs_pad.shape != o.shape or self._obs_pad.device != o.device:
+                self._obs_pad = ops.padded_cols(o.shape[0], o.shape[1], o.device, zero=True)
+            self._obs_pad.copy_(o)
+            views['obs_pad'] = self._obs_pad
         self._acc.zero_()
         # backbones whose sampling / grouping depends on the coordinates only (PointNet2) build their
         # neighbourhood tables once per rollout; every epoch of both networks then reuses them

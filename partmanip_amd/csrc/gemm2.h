@@ -18,6 +18,9 @@ struct Gemm2Prob {
     float* dbias; long bslab;     // G2_EPI_PLAIN with a k-major A: column sums of A (= bias gradient) (+ z*bslab), or null
     long slab;                    // split-K: C offset per slab (elements)
     int M, N, K;                  // rows, cols, reduction
+    int Mld, Nld;                 // k-major operands: rows of A / B that may be LOADED (>= M / N, 0 = M / N): a weight gradient whose
+                                  // dY or X has 10 or 53 columns inside 16- / 56-float rows takes the 16-byte loaders with Mld = 16 /
+                                  // Nld = 56; what the extra columns hold only reaches result rows / columns >= M / N, which are not stored
     int epi, act;
     int vecA, vecB;               // 16-byte global loads allowed for that operand
     int splits, kchunk;           // split-K: number of slabs, reduction range per slab (multiple of 32)

@@ -270,14 +270,14 @@ __global__ __launch_bounds__(256) void gemm2_kernel(Gemm2Group gg) {
     auto kload = [&](int tile) { return kbeg + min(tile, nk - 1) * G2_TK; };
     auto kfill = [&](int tile) { return kbeg + tile * G2_TK; };
 
-    g2_stage_load<A_KM, TM, VEC>(g.A, g.lda, m0, g.M, kbeg, kend, g.K, sa0);
-    g2_stage_load<B_KM, TN, VEC>(g.B, g.ldb, n0, g.N, kbeg, kend, g.K, sb0);
+    g2_stage_load<A_KM, TM, VEC>(g.A, g.lda, m0, A_KM ? g.Mld : g.M, kbeg, kend, g.K, sa0);
+    g2_stage_load<B_KM, TN, VEC>(g.B, g.ldb, n0, B_KM ? g.Nld : g.N, kbeg, kend, g.K, sb0);
     g2_stage_store<A_KM, TM, VEC>(As, sa0, kbeg, kend);
     g2_stage_store<B_KM, TN, VEC>(Bs, sb0, kbeg, kend);
-    g2_stage_load<A_KM, TM, VEC>(g.A, g.lda, m0, g.M, kload(1), kend, g.K, sa0);
-    g2_stage_load<B_KM, TN, VEC>(g.B, g.ldb, n0, g.N, kload(1), kend, g.K, sb0);
-    g2_stage_load<A_KM, TM, VEC>(g.A, g.lda, m0, g.M, kload(2), kend, g.K, sa1);
-    g2_stage_load<B_KM, TN, VEC>(g.B, g.ldb, n0, g.N, kload(2), kend, g.K, sb1);
+    g2_stage_load<A_KM, TM, VEC>(g.A, g.lda, m0, A_KM ? g.Mld : g.M, kload(1), kend, g.K, sa0);
+    g2_stage_load<B_KM, TN, VEC>(g.B, g.ldb, n0, B_KM ? g.Nld : g.N, kload(1), kend, g.K, sb0);
+    g2_stage_load<A_KM, TM, VEC>(g.A, g.lda, m0, A_KM ? g.Mld : g.M, kload(2), kend, g.K, sa1);
+    g2_stage_load<B_KM, TN, VEC>(g.B, g.ldb, n0, B_KM ? g.Nld : g.N, kload(2), kend, g.K, sb1);
     __syncthreads();
     g2_read_frag<A_KM, WM, TM>(As, wmo, li, lh, 0, xa);
     g2_read_frag<B_KM, WN, TN>(Bs, wno, li, lh, 0, xb);
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(256) void gemm2_kernel(Gemm2Group gg) {
         g2_stage_store<B_KM, TN, VEC>(Bs + (c ^ 1) * BBUF, sb, kfill(k + 1), kend);
 #endif
 #if !(G2_ABLATE & 1)
-        g2_stage_load<A_KM, TM, VEC>(g.A, g.lda, m0, g.M, kload(k + 3), kend, g.K, sa);
-        g2_stage_load<B_KM, TN, VEC>(g.B, g.ldb, n0, g.N, kload(k + 3), kend, g.K, sb);
+        g2_stage_load<A_KM, TM, VEC>(g.A, g.lda, m0, A_KM ? g.Mld : g.M, kload(k + 3), kend, g.K, sa);
+        g2_stage_load<B_KM, TN, VEC>(g.B, g.ldb, n0, B_KM ? g.Nld : g.N, kload(k + 3), kend, g.K, sb);
 #endif
         G2_KSTAMP(6);
         __syncthreads();
@@ -488,9 +488,9 @@ __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
             const int tt = min(tile, nk - 1), buf = tile % NBUF;
             const int kt = kbeg + tt * G2_TK, ktn = kbeg + min(tile + 1, nk - 1) * G2_TK;
             if constexpr (GATHER && !A_KM) g2_dma_tile_gather<false, TM>(g, g.A, g.lda, m0, g.M, kt, ktn, As + buf * ABUF, wave, lane, gi);
-            else g2_dma_tile<A_KM, TM>(g.A, g.lda, m0, g.M, kt, As + buf * ABUF, wave, lane, g.K - 1);
+            else g2_dma_tile<A_KM, TM>(g.A, g.lda, m0, A_KM ? g.Mld : g.M, kt, As + buf * ABUF, wave, lane, g.K - 1);
             if constexpr (GATHER && A_KM) g2_dma_tile_gather<true, TN>(g, g.B, g.ldb, n0, g.N, kt, ktn, Bs + buf * BBUF, wave, lane, gi);
-            else g2_dma_tile<B_KM, TN>(g.B, g.ldb, n0, g.N, kt, Bs + buf * BBUF, wave, lane);
+            else g2_dma_tile<B_KM, TN>(g.B, g.ldb, n0, B_KM ? g.Nld : g.N, kt, Bs + buf * BBUF, wave, lane);
         };
         if constexpr (GATHER) {
             if constexpr (A_KM) g2_gather_first<true, TN>(g, n0, g.N, kbeg, wave, lane, gi);
@@ -649,6 +649,8 @@ int gemm2_launch(Gemm2Group& g, bool a_kmajor, bool b_kmajor, void* stream) {
     for (int i = 0; i < g.n; ++i) {
         Gemm2Prob& p = g.p[i];
         if (p.splits < 1) p.splits = 1;
+        if (p.Mld < p.M) p.Mld = p.M;
+        if (p.Nld < p.N) p.Nld = p.N;
         if (p.splits == 1) p.kchunk = ((p.K + G2_TK - 1) / G2_TK) * G2_TK;
         if (p.kchunk <= 0 || p.kchunk % G2_TK != 0 || (long)(p.splits - 1) * p.kchunk >= p.K) return PM_EINVAL;
         // 16-byte loads: k-contiguous needs K % 4 == 0 (and >= 4), k-major needs rows % 4 == 0 (and >= 4); the callers

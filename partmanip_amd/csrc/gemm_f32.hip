@@ -236,8 +236,12 @@ extern "C" int pm_linear_bwd_weight_group_f32(int n, const pm_linear_bwd_weight_
         Gemm2Prob& g = gg.p[i];
         g.A = q.dY; g.lda = q.lddy; g.B = q.X; g.ldb = q.ldx; g.C = q.dW; g.ldc = q.lddw;
         g.M = q.N; g.N = q.K; g.K = q.M; g.act = 0; g.epi = G2_EPI_PLAIN;
-        g.vecA = (q.N % 4 == 0) && (q.lddy % 4 == 0) && aligned16(q.dY);
-        g.vecB = (q.K % 4 == 0) && (q.ldx % 4 == 0) && aligned16(q.X);
+        // loadable columns of the dY / X rows (0 = N / K): see Gemm2Prob::Mld
+        const int ncols = q.dy_cols ? q.dy_cols : q.N, kcols = q.x_cols ? q.x_cols : q.K;
+        PM_REQUIRE(ncols >= q.N && q.lddy >= ncols && kcols >= q.K && q.ldx >= kcols);
+        g.Mld = ncols; g.Nld = kcols;
+        g.vecA = (ncols % 4 == 0) && (q.lddy % 4 == 0) && aligned16(q.dY);
+        g.vecB = (kcols % 4 == 0) && (q.ldx % 4 == 0) && aligned16(q.X);
         g.dbias = q.db;
         g.splits = splits;
         if (splits > 1) {

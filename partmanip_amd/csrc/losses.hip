@@ -504,7 +504,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void value_loss_kernel(const float* _
                                                                    int clipped, float eps_clip,
                                                                    const float* __restrict__ clip_mean_extern,
                                                                    float grad_scale, float* __restrict__ scal_out,
-                                                                   float* __restrict__ dV) {
+                                                                   float* __restrict__ dV, long lddv) {
     __shared__ double red[LOSS_WAVES];
     const int tid = threadIdx.x;
     float d = 0.f;
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void value_loss_kernel(const float* _
         }
         const float e = V[i] - tgt;
         acc += (double)(e * e);
-        dV[i] = k * e;
+        dV[i * lddv] = k * e;
     }
     acc = block_sum<double, LOSS_THREADS>(acc, red);
     if (tid == 0) {
@@ -539,11 +539,11 @@ __global__ __launch_bounds__(LOSS_THREADS) void value_loss_kernel(const float* _
 
 extern "C" int pm_value_loss_fwd_bwd_f32(const float* V, const float* returns, const float* old_values, int B,
                                          int clipped, float eps_clip, const float* clip_mean_extern,
-                                         float grad_scale, float* scal_out, float* dV, void* stream) {
-    PM_REQUIRE(V && returns && scal_out && dV && B > 0);
+                                         float grad_scale, float* scal_out, float* dV, long lddv, void* stream) {
+    PM_REQUIRE(V && returns && scal_out && dV && B > 0 && lddv >= 1);
     PM_REQUIRE(!clipped || old_values);
     hipLaunchKernelGGL(value_loss_kernel, dim3(1), dim3(LOSS_THREADS), 0, pm_stream(stream), V, returns, old_values,
-                       B, clipped, eps_clip, clip_mean_extern, grad_scale, scal_out, dV);
+                       B, clipped, eps_clip, clip_mean_extern, grad_scale, scal_out, dV, lddv);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }

@@ -196,6 +196,17 @@ def linear_bwd_data_group(items):
     check(lib.pm_linear_bwd_data_group_f32(len(items), arr, _stream()), "pm_linear_bwd_data_group_f32")
 
 
+def padded_cols(rows, cols, device, zero=False):
+    """(rows, cols) fp32 view of a buffer whose rows are padded to a multiple of 4 floats; the view carries `_pm_cols` (the
+    readable row width), which `linear_bwd_weight_group` hands to the kernels so that a 10- or 53-column operand takes the
+    16-byte loaders."""
+    w = (cols + 3) // 4 * 4
+    buf = (torch.zeros if zero else torch.empty)(rows, w, device=device)
+    v = buf[:, :cols]
+    v._pm_cols = w
+    return v
+
+
 def linear_bwd_weight_group(items, splits=1):
     """items: [(dy, x, dw, db, slab_stride), ...]; splits > 1: slab z of dw / db lands at + z * slab_stride elements and the
     caller sums the slabs (clip_adam_group does)."""
@@ -203,6 +214,8 @@ def linear_bwd_weight_group(items, splits=1):
     arr = (LinearBwdWeightDesc * len(items))()
     for d, (dy, x, dw, db, stride) in zip(arr, items):
         _req(dy, x, dw, db)
+        # tensors whose allocator marked their rows as readable past the last column (`padded_cols`): 16-byte loaders
+        d.dy_cols, d.x_cols = int(getattr(dy, "_pm_cols", 0)), int(getattr(x, "_pm_cols", 0))
         d.dY, d.lddy, d.X, d.ldx, d.dW, d.lddw, d.db = _ptr(dy), _rows(dy, "dy"), _ptr(x), _rows(x, "x"), _ptr(dw), _rows(dw, "dw"), _ptr(db)
         d.slab_stride, d.M, d.N, d.K = int(stride), dy.shape[0], dy.shape[1], x.shape[1]
     check(lib.pm_linear_bwd_weight_group_f32(len(items), arr, int(splits), _stream()), "pm_linear_bwd_weight_group_f32")
@@ -362,7 +375,7 @@ def value_loss(v, returns, old_values, clipped, eps_clip, clip_mean_extern, grad
     _req(v, returns, old_values, clip_mean_extern, scal, dv)
     check(lib.pm_value_loss_fwd_bwd_f32(_ptr(v), _ptr(returns), _ptr(old_values), v.numel(), int(clipped),
                                         float(eps_clip), _ptr(clip_mean_extern), float(grad_scale), _ptr(scal), _ptr(dv),
-                                        _stream()), "pm_value_loss_fwd_bwd_f32")
+                                        dv.stride(0) if dv.dim() == 2 else 1, _stream()), "pm_value_loss_fwd_bwd_f32")
 
 
 def mse_tanh_loss(stu_mu, tea_mu, max_action, act_tanh, grad_scale, scal, dstu):
