@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 131 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 132 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -220,6 +220,19 @@ int pm_gaussian_logp_f32(const float* mu, long ldmu, const float* log_std, const
 int pm_value_loss_fwd_bwd_f32(const float* V, const float* returns, const float* old_values, int B,
                               int clipped, float eps_clip, const float* clip_mean_extern, float grad_scale,
                               float* scal_out, float* dV, long lddv, void* stream);
+
+/* The value head and its loss as ONE launch (small-step regime; ppo.py:362-377 from the last hidden activation on):
+ * V = H w + bias (H: B x K, w: the (1 x K) head of network.py:40) -> the loss above -> dV (rows of stride lddv) ->
+ * dH = (dV w) .* act'(H) -> the last work-group to finish sums the loss partials.  V, dV, dH: the bits of pm_linear_fwd_f32
+ * (row-wise form) + pm_value_loss_fwd_bwd_f32 + pm_linear_bwd_data_f32; scal_out[0]: the same sum in another association
+ * (double precision).  V_out: NULL or B.  counter: one device uint32, zero before the first launch (left zero).  K % 4 == 0,
+ * K * 4 <= 64 KiB, 16-byte aligned rows (pm_value_head_supported), otherwise PM_EUNSUPPORTED. */
+size_t pm_value_head_workspace_bytes(void);
+int pm_value_head_supported(const float* H, long ldh, const float* W, int K, const float* dH, long lddh);
+int pm_value_head_f32(const float* H, long ldh, const float* W, const float* bias, int K, int hidden_act, const float* returns,
+                      const float* old_values, int B, int clipped, float eps_clip, const float* clip_mean_extern,
+                      float grad_scale, float* scal_out, float* V_out, float* dV, long lddv, float* dH, long lddh,
+                      void* workspace, size_t workspace_bytes, unsigned int* counter, void* stream);
 
 /* ------------------------------------------------------------------ K11 DAgger loss
  * dagger.py:310-314: mean((tanh(tea_mu)*max_a - tanh(stu_mu)*max_a)^2) over B*A and

@@ -48,6 +48,9 @@ SIGNATURES = {
     "pm_gaussian_logp_bwd_f32": (I, [P, L, P, P, L, I, I, F, I, P, P, P, L, P, P]),
     "pm_action_activation_bwd_f32": (I, [P, P, P, L, F, I, P]),
     "pm_value_loss_fwd_bwd_f32": (I, [P, P, P, I, I, F, P, F, P, P, L, P]),
+    "pm_value_head_workspace_bytes": (Z, []),
+    "pm_value_head_supported": (I, [P, L, P, I, P, L]),
+    "pm_value_head_f32": (I, [P, L, P, P, I, I, P, P, I, I, F, P, F, P, P, P, L, P, L, P, Z, P, P]),
     "pm_mse_tanh_loss_fwd_bwd_f32": (I, [P, L, P, L, I, I, F, I, F, P, P, L, P]),
     "pm_action_activation_f32": (I, [P, P, L, F, I, P]),
     "pm_clip_adam_workspace_bytes": (Z, [L]),
@@ -136,7 +139,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 131                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 132                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

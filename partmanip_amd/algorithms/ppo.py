@@ -95,6 +95,7 @@ class ppo:
         self._mom = torch.zeros(2, dtype=torch.float64, device=dev)
         self._ws = ops.Workspace(dev)
         self._ws_loss = ops.Workspace(dev)
+        self._ws_vloss = ops.Workspace(dev)
         self._stage, self._stage_c = {}, {}
         self._pending_critic = []
         self._side = None
@@ -312,7 +313,25 @@ class ppo:
         if self._geom is not None:
             ac.critic.use_geometry(self._geom, indices)
         cchain = getattr(ac.critic, '_chain', None) if self.solo_group else None
-        value = ac.critic.hip_forward(mb['obs'], x_w=mb.get('obs_pad')) if cchain is not None else ac.critic.hip_forward(mb['obs'])
+        if cchain is not None and self.fused_head and len(cchain.linears) >= 2 and not (tricks['use_clipped_value_loss'] and sync):
+            # small-step regime: value head + loss + head data gradient as one launch (as the actor's, _actor_step)
+            h = cchain.forward_hidden(mb['obs'], mb.get('obs_pad'))
+            lin = cchain.linears[-1]
+            dh = torch.empty_like(h)
+            if ops.value_head_supported(h, lin.weight.data, dh):
+                dv = ops.padded_cols(B, 1, h.device)
+                ops.value_head(h, lin.weight.data, lin.bias.data, cchain.act, mb['returns'], mb['values'],
+                               tricks['use_clipped_value_loss'], self.epsilon_clip, None, 1.0, scal_c, dv, dh, self._ws_vloss)
+                S = ac.GRAD_SLABS if B >= 1024 else 1
+                chains_backward([cchain], [dv], [f['slab_stride_critic']], S, head_dz=[dh])
+                ops.clip_adam_group([self.optimizer_critic.group_item(
+                    n=n_c, n_clip=n_c if clip else 0, max_norm=self.max_grad_norm if clip else 0.0, extra=f['extra_critic'],
+                    extra_stride=f['slab_stride_critic'], n_sum=n_c, n_extra=S - 1, stats=(self._acc, scal_c, 1))])
+                return
+            value = torch.empty(B, 1, device=h.device)
+            ops.linear_fwd(h, lin.weight.data, lin.bias.data, value, ops.ACT_NONE)
+        else:
+            value = ac.critic.hip_forward(mb['obs'], x_w=mb.get('obs_pad')) if cchain is not None else ac.critic.hip_forward(mb['obs'])
         clip_mean = None
         if tricks['use_clipped_value_loss'] and sync:
             clip_mean = sync.mean_((self.epsilon_clip * mb['values']).abs().mean().reshape(1))

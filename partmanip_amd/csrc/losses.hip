@@ -548,6 +548,109 @@ extern "C" int pm_value_loss_fwd_bwd_f32(const float* V, const float* returns, c
     return PM_OK;
 }
 
+// ---- the value head and its loss as ONE launch (small-step regime), the critic's counterpart of ppo_actor_head_kernel:
+// V = H w + b (row-wise, skinny.h) -> value_loss_kernel's rows -> dV -> dH = (dV w) .* act'(H) -> the last work-group sums the
+// loss partials.  V, dV and dH carry the bits of the three separate launches (the clip width d is summed in value_loss_kernel's
+// order by every work-group); the loss SCALAR is the same sum of squares in a different association (double precision).
+#define VH_MAXG 128
+__global__ __launch_bounds__(AH_THREADS) void value_head_kernel(
+    const float* __restrict__ H, long ldh, const float* __restrict__ W, const float* __restrict__ bias, int K, int hact,
+    const float* __restrict__ returns, const float* __restrict__ old_values, int B, int clipped, float eps_clip,
+    const float* __restrict__ clip_mean_extern, float grad_scale, float* __restrict__ V_out, float* __restrict__ dV, long lddv,
+    float* __restrict__ dH, long lddh, double* __restrict__ parts, unsigned int* __restrict__ counter, float* __restrict__ scal_out) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];                  // [K]
+    __shared__ double red[AH_THREADS / 64];
+    __shared__ float s_dv[AH_ROWS];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    sk_fill_w<AH_THREADS>(sW, W, K, 1, K);
+    float d = 0.f;
+    if (clipped) {                       // ppo.py:370: delta = mean(|eps * V_old|) over the mini-batch (value_loss_kernel's order)
+        if (clip_mean_extern) {
+            d = clip_mean_extern[0];
+        } else {
+            double acc = 0.0;
+            for (int i = tid; i < B; i += LOSS_THREADS) acc += (double)fabsf(eps_clip * old_values[i]);
+            acc = block_sum<double, AH_THREADS>(acc, red);
+            d = (float)(acc / (double)B);
+        }
+    }
+    __syncthreads();
+    const float kq = 2.0f / (float)B * grad_scale;
+    const int k4 = K >> 2;
+    double acc = 0.0;
+    for (int base = blockIdx.x * AH_ROWS; base < B; base += gridDim.x * AH_ROWS) {
+        const int i = base + wave;                             // one row per wave
+        if (i < B) {
+            float a[SK_MAXN];
+            sk_row_dot(H + (long)i * ldh, sW, 1, K, lane, a);
+            const float s = wave_sum(a[0]);
+            if (lane == 0) {
+                const float v = s + (bias ? bias[0] : 0.f);
+                float tgt = returns[i];
+                if (clipped) {
+                    const float ov = old_values[i];
+                    tgt = ov + fminf(fmaxf(returns[i] - ov, -d), d);
+                }
+                const float e = v - tgt;
+                acc += (double)(e * e);
+                const float g = kq * e;
+                dV[(long)i * lddv] = g;
+                s_dv[wave] = g;
+                if (V_out) V_out[i] = v;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < AH_ROWS * k4; e += AH_THREADS) {
+            const int rr = e / k4, k = (e - rr * k4) * 4;
+            const long ii = base + rr;
+            if (ii < B)
+                *(float4*)(dH + ii * lddh + k) = sk_dgrad4([&](int) { return s_dv[rr]; }, sW, 1, K, k, H + ii * ldh, hact);
+        }
+        __syncthreads();
+    }
+    acc = block_sum<double, AH_THREADS>(acc, red);
+    if (tid == 0) {
+        __hip_atomic_store(parts + blockIdx.x, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (see ppo_actor_head_kernel)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last && tid < 64) {
+        const int G = (int)gridDim.x;
+        double s = tid < G ? __hip_atomic_load(parts + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        if (tid + 64 < G) s += __hip_atomic_load(parts + tid + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s = wave_sum(s);
+        if (tid == 0) {
+            scal_out[0] = (float)(s / (double)B);
+            scal_out[1] = d;
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+extern "C" size_t pm_value_head_workspace_bytes(void) { return VH_MAXG * sizeof(double); }
+extern "C" int pm_value_head_supported(const float* H, long ldh, const float* W, int K, const float* dH, long lddh) {
+    return skinny_ok(1, K, H, ldh, W, K) && lddh % 4 == 0 && sk_aligned16(dH);
+}
+extern "C" int pm_value_head_f32(const float* H, long ldh, const float* W, const float* bias, int K, int hidden_act,
+                                 const float* returns, const float* old_values, int B, int clipped, float eps_clip,
+                                 const float* clip_mean_extern, float grad_scale, float* scal_out, float* V_out, float* dV, long lddv,
+                                 float* dH, long lddh, void* workspace, size_t workspace_bytes, unsigned int* counter, void* stream) {
+    PM_REQUIRE(H && W && returns && scal_out && dV && dH && counter && B > 0 && K > 0 && ldh >= K && lddh >= K && lddv >= 1);
+    PM_REQUIRE(!clipped || old_values);
+    PM_REQUIRE(hidden_act >= PM_ACT_NONE && hidden_act <= PM_ACT_MAX);
+    if (!pm_value_head_supported(H, ldh, W, K, dH, lddh)) return PM_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < pm_value_head_workspace_bytes() || ((uintptr_t)workspace & 7)) return PM_EWORKSPACE;
+    int G = (B + AH_ROWS - 1) / AH_ROWS;
+    if (G > VH_MAXG) G = VH_MAXG;
+    hipLaunchKernelGGL(value_head_kernel, dim3(G), dim3(AH_THREADS), (size_t)K * 4, pm_stream(stream), H, ldh, W, bias, K, hidden_act,
+                       returns, old_values, B, clipped, eps_clip, clip_mean_extern, grad_scale, V_out, dV, lddv, dH, lddh,
+                       (double*)workspace, counter, scal_out);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
 // ---------------------------------------------------------------------------------- K11
 __global__ __launch_bounds__(LOSS_THREADS) void mse_tanh_loss_kernel(const float* __restrict__ stu_mu, long lds,
                                                                       const float* __restrict__ tea_mu, long ldt,

@@ -378,6 +378,25 @@ def value_loss(v, returns, old_values, clipped, eps_clip, clip_mean_extern, grad
                                         dv.stride(0) if dv.dim() == 2 else 1, _stream()), "pm_value_loss_fwd_bwd_f32")
 
 
+def value_head_supported(h, w, dh):
+    return w.shape[0] == 1 and w.is_contiguous() and bool(lib.pm_value_head_supported(_ptr(h), _rows(h, "h"), _ptr(w), w.shape[1], _ptr(dh),
+                                                                                      _rows(dh, "dh")))
+
+
+def value_head(h, w, b, hidden_act, returns, old_values, clipped, eps_clip, clip_mean_extern, grad_scale, scal, dv, dh, ws, v_out=None):
+    """Value head forward + value loss + dV + head data gradient in one launch (pm_value_head_f32)."""
+    _req(h, w, b, returns, old_values, clip_mean_extern, scal, dv, dh, v_out)
+    B, K = h.shape
+    buf = ws.get(lib.pm_value_head_workspace_bytes())
+    ctr = getattr(ws, "counter", None)
+    if ctr is None:
+        ctr = ws.counter = torch.zeros(4, dtype=torch.int32, device=h.device)
+    check(lib.pm_value_head_f32(_ptr(h), _rows(h, "h"), _ptr(w), _ptr(b), K, int(hidden_act), _ptr(returns), _ptr(old_values), B,
+                                int(clipped), float(eps_clip), _ptr(clip_mean_extern), float(grad_scale), _ptr(scal), _ptr(v_out),
+                                _ptr(dv), dv.stride(0) if dv.dim() == 2 else 1, _ptr(dh), _rows(dh, "dh"), _ptr(buf), buf.numel(),
+                                _ptr(ctr), _stream()), "pm_value_head_f32")
+
+
 def mse_tanh_loss(stu_mu, tea_mu, max_action, act_tanh, grad_scale, scal, dstu):
     _req(stu_mu, tea_mu, scal, dstu)
     B, A = stu_mu.shape

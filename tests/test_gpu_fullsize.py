@@ -113,7 +113,7 @@ def test_cfg1_full_ppo_update_matches_oracle(cfg1_problem, graphs, pair, steps):
 
 
 def test_cfg1_fused_policy_head_is_bit_identical(cfg1_problem):
-    """cfg 1 whole update with the policy head + loss + head data gradient as ONE launch (default) and as four
+    """cfg 1 whole update with each head + its loss + the head data gradient as ONE launch (default) and as three / four
     (PARTMANIP_FUSED_HEAD=0's path): the same arithmetic in the same order -> identical parameters and scalars."""
     from partmanip_amd.algorithms import ppo
     q = cfg1_problem
@@ -133,8 +133,10 @@ def test_cfg1_fused_policy_head_is_bit_identical(cfg1_problem):
     (sa, la), (sb, lb) = res
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
-    for k in ("Train/surrogate_loss", "Train/kl", "Train/kl_max", "Train/value_function_loss"):
+    for k in ("Train/surrogate_loss", "Train/kl", "Train/kl_max"):
         assert float(la[k]) == float(lb[k]), k
+    # (the value loss SCALAR is one double-precision sum in two associations; its gradient is bit-identical: the parameters above)
+    np.testing.assert_allclose(float(la["Train/value_function_loss"]), float(lb["Train/value_function_loss"]), rtol=1e-6)
 
 
 # ------------------------------------------------------------------------------------------------------ cfg 3, B = 2048

@@ -210,6 +210,33 @@ def test_ppo_actor_head_equals_the_separate_launches(B, K, A, mini_norm):
     assert not o.ppo_actor_head_supported(h[:, :K - 2], W[:, :K - 2], dh2[:, :K - 2])       # K % 4 != 0: the separate kernels
 
 
+@pytest.mark.parametrize("B,K,clipped", [(2048, 512, False), (2048, 512, True), (300, 64, True), (4100, 128, False), (256, 1024, True)])
+def test_value_head_equals_the_separate_launches(B, K, clipped):
+    """pm_value_head_f32 against pm_linear_fwd_f32 -> pm_value_loss_fwd_bwd_f32 -> pm_linear_bwd_data_f32 (pinned to the oracle by
+    test_value_loss / test_linear_*): V, dV, dH and the clip width bit for bit, the loss scalar to double-precision rounding."""
+    o = ops()
+    g = torch.Generator().manual_seed(B + K)
+    d = lambda v: v.to(DEV).contiguous()
+    h = d(torch.tanh(torch.randn(B, K, generator=g)))
+    W, b = d(torch.randn(1, K, generator=g) * 0.05), d(torch.randn(1, generator=g) * 0.1)
+    ret, old = d(torch.randn(B, 1, generator=g)), d(torch.randn(B, 1, generator=g))
+    v, dv, dh, scal = torch.empty(B, 1, device=DEV), torch.empty(B, 1, device=DEV), torch.empty_like(h), torch.zeros(8, device=DEV)
+    o.linear_fwd(h, W, b, v, o.ACT_NONE)
+    o.value_loss(v, ret, old, clipped, 0.2, None, 1.0, scal, dv)
+    o.linear_bwd_data(dv, W, h, dh, o.ACT_TANH)
+    v2, dh2, scal2 = torch.empty(B, device=DEV), torch.empty_like(h), torch.zeros(8, device=DEV)
+    dv2 = o.padded_cols(B, 1, torch.device(DEV))                               # (B, 1) rows of stride 4, as the learner passes
+    assert o.value_head_supported(h, W, dh2)
+    ws = o.Workspace(torch.device(DEV))
+    for _ in range(3):
+        dh2.fill_(float("nan"))
+        o.value_head(h, W, b, o.ACT_TANH, ret, old, clipped, 0.2, None, 1.0, scal2, dv2, dh2, ws, v_out=v2)
+        assert int(ws.counter[0]) == 0
+        assert torch.equal(v.view(-1), v2) and torch.equal(dv, dv2) and torch.equal(dh, dh2)
+        assert float(scal[1]) == float(scal2[1])
+        np.testing.assert_allclose(float(scal2[0]), float(scal[0]), rtol=1e-6)
+
+
 @pytest.mark.parametrize("B,clipped", [(2048, False), (2048, True), (15, True)])
 def test_value_loss(B, clipped):
     o = ops()
