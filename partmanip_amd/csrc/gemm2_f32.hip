@@ -137,10 +137,9 @@ __device__ __forceinline__ void g2_mfma_half(const G2Frag<WM>& a, const G2Frag<W
 }
 
 // ---- epilogue (shared by the register-staged and the LDS-DMA kernel) ------------------------------------------------
-template <bool A_KM, bool B_KM, int WM, int WN, int NT>
+template <bool A_KM, bool B_KM, int WM, int WN, int NT, int TM = 64 * WM, int TN = 64 * WN>
 __device__ __forceinline__ void g2_epilogue(const Gemm2Prob& g, f32x16 (&acc)[WM][WN], float* __restrict__ lds, int m0, int n0, int z,
                                             int wmo, int wno, int li, int lh, bool writer) {
-    constexpr int TM = 64 * WM, TN = 64 * WN;
     const int tid = threadIdx.x;
     // ---- epilogue: acc[bm][bn][r] is block row i = (r&3) + 8 (r>>2) + 4 lh, block column li.  Written straight from the
     // accumulators a wave stores 16 x (2 rows x 128 B) per block -- store-issue-bound: 8.7 k cycles for a 64 x 64 tile, as long
@@ -432,12 +431,15 @@ __device__ __forceinline__ void g2_gather_first(const Gemm2Prob& g, int r0, int 
     }
 }
 
-template <bool A_KM, bool B_KM, int WM, int WN, bool GATHER = false>
+// LAY: how the four multiplying waves cover the work-group tile -- 0: 2 x 2 (tile 64 WM x 64 WN); 1: 1 x 4 (tile 32 WM x 128 WN)
+// for problems with at most 32 rows (the weight gradient of a 32-channel convolution over millions of rows: on the 2 x 2 layout
+// half of every MFMA multiplies rows that do not exist -- 6.5 ms per launch at 142 TFLOP/s of ISSUED work, 71 of useful).
+template <bool A_KM, bool B_KM, int WM, int WN, bool GATHER = false, int LAY = 0>
 __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
-    // 8 waves: waves 0-3 multiply (2 x 2 over the tile, one per SIMD), waves 4-7 only feed the LDS ring.  Issuing one
+    // 8 waves: waves 0-3 multiply (one per SIMD), waves 4-7 only feed the LDS ring.  Issuing one
     // 1 KiB LDS-DMA costs the issuing wave ~90 cycles (measured: 4 of them in front of a half-step's MFMAs stretched it from
     // 512 to 885 cycles) and an in-order wave cannot issue MFMAs meanwhile -- a second wave on the SIMD can.
-    constexpr int TM = 64 * WM, TN = 64 * WN;
+    constexpr int TM = LAY ? 32 * WM : 64 * WM, TN = LAY ? 128 * WN : 64 * WN;
     constexpr int NBUF = 3;
     constexpr int ABUF = TM * 32, BBUF = TN * 32;
     constexpr int IPT = (TM + TN) / 32;                                    // DMA instructions per tile per loader wave
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
     const int m0 = tm * TM, n0 = tn * TN;
     const int kbeg = z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     const int nk = (kend - kbeg + G2_TK - 1) / G2_TK;                      // whole steps, except the ragged row tail of a gathered weight gradient
-    const int wmo = (wave >> 1) * 32 * WM, wno = (wave & 1) * 32 * WN;
+    const int wmo = LAY ? 0 : (wave >> 1) * 32 * WM, wno = LAY ? wave * 32 * WN : (wave & 1) * 32 * WN;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
             g.dbias[(long)z * g.bslab + m0 + tid] = s;
         }
     }
-    g2_epilogue<A_KM, B_KM, WM, WN, 512>(g, acc, lds, m0, n0, z, wmo, wno, li, lh, !loader);
+    g2_epilogue<A_KM, B_KM, WM, WN, 512, TM, TN>(g, acc, lds, m0, n0, z, wmo, wno, li, lh, !loader);
     G2_STAMP(3);
 }
 
@@ -572,8 +574,14 @@ __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
 // problem actually extends past 64 -- a 128 x 128 tile on an N = 64 problem (the 64-channel sparse convolutions: 2.7 M rows,
 // K = 1728) spends half of its MFMAs on columns that do not exist.
 template <bool A_KM, bool B_KM, bool GATHER>
-static void g2_launch_dma(const Gemm2Group& g, int wm, int wn, int blocks, void* stream) {
+static void g2_launch_dma(const Gemm2Group& g, int wm, int wn, int blocks, void* stream, bool lay1 = false) {
     const dim3 grid(blocks), blk(512);
+    if constexpr (A_KM && B_KM) {
+        if (lay1) {
+            hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 1, GATHER, 1>), grid, blk, 0, pm_stream(stream), g);
+            return;
+        }
+    }
     if (wm == 2 && wn == 2) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 2, GATHER>), grid, blk, 0, pm_stream(stream), g);
     else if (wm == 2) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 1, GATHER>), grid, blk, 0, pm_stream(stream), g);
     else if (wn == 2) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 2, GATHER>), grid, blk, 0, pm_stream(stream), g);
@@ -597,7 +605,10 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
         if (maxM <= 64) wm = 1;
         if (maxN <= 64) wn = 1;
     }
-    const int TM = 64 * wm, TN = 64 * wn;
+    // weight gradients of <= 32 output rows: the 32 x 128 tile (1 x 4 waves) of the LDS-DMA kernels
+    const bool lay1 = A_KM && B_KM && (dma || gather) && vec && maxM <= 32 && maxN > 64;
+    if (lay1) wm = wn = 1;
+    const int TM = lay1 ? 32 : 64 * wm, TN = lay1 ? 128 : 64 * wn;
     int blocks = 0;
     for (int i = 0; i < g.n; ++i) {
         Gemm2Prob& p = g.p[i];
@@ -618,13 +629,13 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
             const bool kok = A_KM ? (q.kchunk % G2_TK == 0) : (q.K % G2_TK == 0 && q.kchunk % G2_TK == 0);
             if (!q.gidx || !q.gzero || !vec || !kok || q.gC % 4 != 0 || q.gJ < 1 || (long)q.gJ * q.gC != (A_KM ? q.N : q.K)) return PM_EINVAL;
         }
-        if constexpr (A_KM == B_KM) g2_launch_dma<A_KM, B_KM, true>(g, wm, wn, blocks, stream);
+        if constexpr (A_KM == B_KM) g2_launch_dma<A_KM, B_KM, true>(g, wm, wn, blocks, stream, lay1);
         else return PM_EUNSUPPORTED;
         PM_CHECK_LAUNCH();
         return PM_OK;
     }
     const dim3 grid(blocks), blk(256);
-    if (dma) g2_launch_dma<A_KM, B_KM, false>(g, wm, wn, blocks, stream);
+    if (dma) g2_launch_dma<A_KM, B_KM, false>(g, wm, wn, blocks, stream, lay1);
     else if (big && vec) hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 2, 2, true>), grid, blk, 0, pm_stream(stream), g);
     else if (big) hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 2, 2, false>), grid, blk, 0, pm_stream(stream), g);
     else if (vec) hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 1, 1, true>), grid, blk, 0, pm_stream(stream), g);

@@ -108,7 +108,8 @@ extern "C" int pm_linear_bwd_data_f32(const float* dY, long lddy, const float* W
 
 // ---- weight gradient: split-K over the batch, slab reduction, bias column sums -----------
 static inline int bww_splits(int M, int N, int K) {
-    const long tiles = (long)((N + GB_M - 1) / GB_M) * ((K + GB_N - 1) / GB_N);
+    // (<= 32 output rows: the LDS-DMA kernels' 32 x 128 tile, gemm2_f32.hip LAY = 1)
+    const long tiles = (N <= 32 && K > 64) ? (K + 127) / 128 : (long)((N + GB_M - 1) / GB_M) * ((K + GB_N - 1) / GB_N);
     // target work-group count of the split-K weight-gradient GEMM: one per CU for the mini-batch-sized reductions
     // (M <= 4096: 512 measured -2 %, 128 -12 % on state PPO), two per CU for the long reductions of the point-cloud glue
     long s = (M <= 4096 ? 256 : 512) / tiles;

@@ -91,7 +91,9 @@ def test_moments_normalize_and_gather():
 
 # ------------------------------------------------------------------------------- Linear
 @pytest.mark.parametrize("M,N,K,act", [(2048, 512, 53, 1), (2048, 512, 512, 1), (2048, 10, 512, 0), (2048, 1, 512, 0),
-                                       (63, 33, 19, 1), (15, 64, 64, 1), (2048, 128, 1031, 1), (300, 32, 128, 0)])
+                                       (63, 33, 19, 1), (15, 64, 64, 1), (2048, 128, 1031, 1), (300, 32, 128, 0),
+                                       # weight gradients of <= 32 rows: the LDS-DMA kernel's 32 x 128 tile (ragged in N, K, M)
+                                       (4096, 32, 864, 0), (2048, 16, 200, 1), (70000, 32, 1728, 0), (1000, 28, 132, 0), (2048, 32, 64, 0)])
 def test_linear_fwd_bwd(M, N, K, act):
     o = ops()
     g = torch.Generator().manual_seed(M + N + K)
@@ -643,7 +645,8 @@ def test_maxpool_rows_value_and_lowest_arg(G, ns, C):
     np.testing.assert_array_equal(arg.cpu().numpy(), xr.argmax(1).astype(np.int32))
 
 
-@pytest.mark.parametrize("rows,J,C,N", [(1000, 27, 32, 32), (333, 8, 32, 64), (4097, 27, 64, 64), (700, 32, 4, 32), (129, 27, 32, 128)])
+@pytest.mark.parametrize("rows,J,C,N", [(1000, 27, 32, 32), (333, 8, 32, 64), (4097, 27, 64, 64), (700, 32, 4, 32), (129, 27, 32, 128),
+                                        (50001, 27, 64, 32), (3000, 32, 32, 16), (2049, 8, 64, 32)])
 def test_sparse_conv_entry_points_against_torch(rows, J, C, N):
     """The three gathered-GEMM entry points (the (rows x J*C) operand exists only inside the LDS-DMA loader) against a plain
     torch fp32 gather + matmul of the same op: random neighbour tables with ~30 % absent neighbours (-1 -> zero rows),
