@@ -20,8 +20,10 @@ from .. import ops
 class ActorCritic(nn.Module):
     SCAL_TAIL = 8
     # split-K slabs of the grouped weight gradients of the small-step path (slab 0 = the gradient buffer itself, the optimiser's
-    # norm pass sums the rest).  cfg 2: 4 slabs 1.85 M env-steps/s, 8 -> 1.89 M, 16 -> 1.84 M, 32 -> 1.63 M.
-    GRAD_SLABS = int(os.environ.get("PARTMANIP_GRAD_SLABS", "8"))
+    # norm pass sums the rest).  cfg 2, all four weight gradients of a network in one LDS-DMA launch: 2 slabs 2.13 M env-steps/s,
+    # 3 -> 2.26 M, 4 -> 2.23 M, 5 -> 2.19 M, 8 -> 2.20 M (while the unaligned first-layer / head problems still ran as a launch of
+    # their own on the register-staged kernel, 8 was best: 1.89 M against 1.85 M with 4).
+    GRAD_SLABS = int(os.environ.get("PARTMANIP_GRAD_SLABS", "3"))
 
     def __init__(self, obs_shape, actions_shape, model_cfg, proprio_shape=0):
         super(ActorCritic, self).__init__()
