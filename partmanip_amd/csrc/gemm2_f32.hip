@@ -20,6 +20,7 @@
 // Split-K slabs are written to slab z of C; the caller reduces them in fixed order (or hands them to the optimiser
 // kernels, which sum the slabs while they compute the gradient norm: adam.hip).
 #include "gemm2.h"
+#include <cstdlib>
 
 #ifndef G2_ABLATE
 #define G2_ABLATE 0                     // profiling builds only: 1 = no global loads, 2 = no LDS writes in the K loop
@@ -605,6 +606,9 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
         if (maxM <= 64) wm = 1;
         if (maxN <= 64) wn = 1;
     }
+#ifdef G2_TILE_ENV                                         // A/B builds only: PM_G2_TILE=21 / 12 / 22 forces the (wm, wn) of forward / data-gradient launches
+    if (const char* e = getenv("PM_G2_TILE"); e && dma && !(A_KM && B_KM)) { wm = e[0] - '0'; wn = e[1] - '0'; }
+#endif
     // weight gradients of <= 32 output rows: the 32 x 128 tile (1 x 4 waves) of the LDS-DMA kernels
     const bool lay1 = A_KM && B_KM && (dma || gather) && vec && maxM <= 32 && maxN > 64;
     if (lay1) wm = wn = 1;
