@@ -245,6 +245,24 @@ class ppo:
             out[k] = buf
         return out
 
+    def _solo_adam(self, f, which, S):
+        """Grouped optimiser launch of one network on its own stream (small-step regime): the norm pass sums the S split-K slabs of
+        the weight gradients and carries the step's running sums (one launch less), then clip + Adam.  log_std belongs to the
+        actor's optimiser but is outside the clipped norm (ppo.py:351); the actor's KL predicate is the skip flag (ppo.py:337-338)."""
+        clip = self.tricks['use_grad_clip']
+        mn = self.max_grad_norm if clip else 0.0
+        if which == 'actor':
+            n_a, A, scal = f['n_actor'], self.num_actions, f['scal_actor']
+            item = self.optimizer_actor.group_item(n=n_a + A, n_clip=n_a if clip else 0, max_norm=mn, skip_flag=scal[2:3],
+                                                   extra=f['extra_actor'], extra_stride=f['slab_stride_actor'], n_sum=n_a, n_extra=S - 1,
+                                                   stats=(self._acc, scal, 0))
+        else:
+            n_c = f['n_critic']
+            item = self.optimizer_critic.group_item(n=n_c, n_clip=n_c if clip else 0, max_norm=mn, extra=f['extra_critic'],
+                                                    extra_stride=f['slab_stride_critic'], n_sum=n_c, n_extra=S - 1,
+                                                    stats=(self._acc, f['scal_critic'], 1))
+        ops.clip_adam_group([item])
+
     def _actor_step(self, f, views, indices, stage):
         """One mini-batch of ppo.py:316-357 (forward, loss fwd+bwd, backward, [all-reduce], clip+Adam)."""
         ac, tricks, sync = self.actor_critic, self.tricks, self.sync
@@ -273,10 +291,7 @@ class ppo:
                                    self.epsilon_clip, self.desired_kl, mom, cnt, scal_a, dmu, dh, f['grad_log_std'], self._ws_loss)
                 S = ac.GRAD_SLABS if B >= 1024 else 1
                 chains_backward([chain], [dmu], [f['slab_stride_actor']], S, head_dz=[dh])
-                ops.clip_adam_group([self.optimizer_actor.group_item(
-                    n=n_a + A, n_clip=n_a if clip else 0, max_norm=self.max_grad_norm if clip else 0.0, skip_flag=scal_a[2:3],
-                    extra=f['extra_actor'], extra_stride=f['slab_stride_actor'], n_sum=n_a, n_extra=S - 1,
-                    stats=(self._acc, scal_a, 0))])
+                self._solo_adam(f, 'actor', S)
                 return
             mu = torch.empty(B, A, device=h.device)          # (shape outside the fused kernel: finish the forward separately)
             ops.linear_fwd(h, lin.weight.data, lin.bias.data, mu, ops.ACT_NONE)
@@ -289,10 +304,7 @@ class ppo:
         if self.solo_group:
             S = ac.GRAD_SLABS if B >= 1024 else 1
             chains_backward([ac.actor._chain], [dmu], [f['slab_stride_actor']], S)
-            ops.clip_adam_group([self.optimizer_actor.group_item(
-                n=n_a + A, n_clip=n_a if clip else 0, max_norm=self.max_grad_norm if clip else 0.0, skip_flag=scal_a[2:3],
-                extra=f['extra_actor'], extra_stride=f['slab_stride_actor'], n_sum=n_a, n_extra=S - 1,
-                stats=(self._acc, scal_a, 0))])             # the step's running sums ride in the norm pass (one launch less)
+            self._solo_adam(f, 'actor', S)
             return
         ac.actor.hip_backward(dmu)
         if sync:                                              # ONE all-reduce: grads + loss/kl in the tail
@@ -324,9 +336,7 @@ class ppo:
                                tricks['use_clipped_value_loss'], self.epsilon_clip, None, 1.0, scal_c, dv, dh, self._ws_vloss)
                 S = ac.GRAD_SLABS if B >= 1024 else 1
                 chains_backward([cchain], [dv], [f['slab_stride_critic']], S, head_dz=[dh])
-                ops.clip_adam_group([self.optimizer_critic.group_item(
-                    n=n_c, n_clip=n_c if clip else 0, max_norm=self.max_grad_norm if clip else 0.0, extra=f['extra_critic'],
-                    extra_stride=f['slab_stride_critic'], n_sum=n_c, n_extra=S - 1, stats=(self._acc, scal_c, 1))])
+                self._solo_adam(f, 'critic', S)
                 return
             value = torch.empty(B, 1, device=h.device)
             ops.linear_fwd(h, lin.weight.data, lin.bias.data, value, ops.ACT_NONE)
@@ -341,9 +351,7 @@ class ppo:
         if self.solo_group:
             S = ac.GRAD_SLABS if B >= 1024 else 1
             chains_backward([ac.critic._chain], [dv], [f['slab_stride_critic']], S)
-            ops.clip_adam_group([self.optimizer_critic.group_item(
-                n=n_c, n_clip=n_c if clip else 0, max_norm=self.max_grad_norm if clip else 0.0, extra=f['extra_critic'],
-                extra_stride=f['slab_stride_critic'], n_sum=n_c, n_extra=S - 1, stats=(self._acc, scal_c, 1))])
+            self._solo_adam(f, 'critic', S)
             return
         ac.critic.hip_backward(dv)
         if sync:
