@@ -245,6 +245,14 @@ class ppo:
             out[k] = buf
         return out
 
+    def _slabs(self, B):
+        """Split-K slabs of the weight gradients of a B-row mini-batch (ActorCritic.GRAD_SLABS, lowered until every slab owns
+        rows once its range is rounded up to the kernels' K-step of 32; small mini-batches are not split)."""
+        S = self.actor_critic.GRAD_SLABS if B >= 1024 else 1
+        while S > 1 and (S - 1) * ((-(-B // S) + 31) // 32 * 32) >= B:
+            S -= 1
+        return S
+
     def _solo_adam(self, f, which, S):
         """Grouped optimiser launch of one network on its own stream (small-step regime): the norm pass sums the S split-K slabs of
         the weight gradients and carries the step's running sums (one launch less), then clip + Adam.  log_std belongs to the
@@ -289,7 +297,7 @@ class ppo:
                 ops.ppo_actor_head(h, lin.weight.data, lin.bias.data, chain.act, ac.log_std.data, mb['actions'], mb['old_logp'],
                                    mb['adv'], mb['old_mu'], mb['old_sigma'], ac.max_action, ac.action_activate == 'tanh',
                                    self.epsilon_clip, self.desired_kl, mom, cnt, scal_a, dmu, dh, f['grad_log_std'], self._ws_loss)
-                S = ac.GRAD_SLABS if B >= 1024 else 1
+                S = self._slabs(B)
                 chains_backward([chain], [dmu], [f['slab_stride_actor']], S, head_dz=[dh])
                 self._solo_adam(f, 'actor', S)
                 return
@@ -302,7 +310,7 @@ class ppo:
                            mb['old_sigma'], ac.max_action, ac.action_activate == 'tanh', self.epsilon_clip,
                            self.desired_kl, mom, cnt, scal_a, dmu, f['grad_log_std'], self._ws_loss)
         if self.solo_group:
-            S = ac.GRAD_SLABS if B >= 1024 else 1
+            S = self._slabs(B)
             chains_backward([ac.actor._chain], [dmu], [f['slab_stride_actor']], S)
             self._solo_adam(f, 'actor', S)
             return
@@ -334,7 +342,7 @@ class ppo:
                 dv = ops.padded_cols(B, 1, h.device)
                 ops.value_head(h, lin.weight.data, lin.bias.data, cchain.act, mb['returns'], mb['values'],
                                tricks['use_clipped_value_loss'], self.epsilon_clip, None, 1.0, scal_c, dv, dh, self._ws_vloss)
-                S = ac.GRAD_SLABS if B >= 1024 else 1
+                S = self._slabs(B)
                 chains_backward([cchain], [dv], [f['slab_stride_critic']], S, head_dz=[dh])
                 self._solo_adam(f, 'critic', S)
                 return
@@ -349,7 +357,7 @@ class ppo:
         ops.value_loss(value, mb['returns'], mb['values'], tricks['use_clipped_value_loss'], self.epsilon_clip,
                        clip_mean, 1.0, scal_c, dv)
         if self.solo_group:
-            S = ac.GRAD_SLABS if B >= 1024 else 1
+            S = self._slabs(B)
             chains_backward([ac.critic._chain], [dv], [f['slab_stride_critic']], S)
             self._solo_adam(f, 'critic', S)
             return
@@ -381,7 +389,7 @@ class ppo:
         dv = torch.empty(mbc['obs'].shape[0], 1, device=value.device)
         ops.value_loss(value, mbc['returns'], mbc['values'], tricks['use_clipped_value_loss'], self.epsilon_clip, None, 1.0,
                        scal_c, dv)
-        S = ac.GRAD_SLABS if B >= 1024 and mbc['obs'].shape[0] == B else 1
+        S = self._slabs(B) if mbc['obs'].shape[0] == B else 1
         chains_backward(chains, [dmu, dv], [f['slab_stride_actor'], f['slab_stride_critic']], S)
         ops.ppo_accumulate_stats(self._acc, scal_a, 0)
         ops.ppo_accumulate_stats(self._acc, scal_c, 1)
