@@ -171,9 +171,9 @@ def test_ppo_actor_loss(B, A, mini_norm):
     np.testing.assert_allclose(lp.cpu().numpy(), logp.detach().numpy(), rtol=2e-5, atol=2e-4)
 
 
-@pytest.mark.parametrize("B,K,A,mini_norm", [(2048, 512, 10, False), (2048, 512, 10, True), (300, 64, 3, False), (4100, 128, 16, True),
-                                             (2048, 512, 1, False), (256, 1024, 16, False)])
-def test_ppo_actor_head_equals_the_separate_launches(B, K, A, mini_norm):
+@pytest.mark.parametrize("B,K,A,mini_norm,hact", [(2048, 512, 10, False, "tanh"), (2048, 512, 10, True, "tanh"), (300, 64, 3, False, "elu"),
+                                                  (4100, 128, 16, True, "tanh"), (2048, 512, 1, False, "relu"), (256, 1024, 16, False, "selu")])
+def test_ppo_actor_head_equals_the_separate_launches(B, K, A, mini_norm, hact):
     """pm_ppo_actor_head_f32 (head forward + loss + dmu + head data gradient + last-work-group reduction in one launch) against
     pm_linear_fwd_f32 -> pm_ppo_actor_loss_fwd_bwd_f32 -> pm_linear_bwd_data_f32, which test_ppo_actor_loss / test_linear_* pin
     to the oracle: every output bit for bit (B >= 256: the row-wise Linear kernels on both sides), run three times on one
@@ -181,6 +181,7 @@ def test_ppo_actor_head_equals_the_separate_launches(B, K, A, mini_norm):
     o = ops()
     g = torch.Generator().manual_seed(B + K + A)
     d = lambda v: v.to(DEV).contiguous()
+    HACT = {"tanh": o.ACT_TANH, "relu": o.ACT_RELU, "elu": o.ACT_ELU, "selu": o.ACT_SELU}[hact]     # hidden activation: dH's epilogue
     h = d(torch.tanh(torch.randn(B, K, generator=g)))
     W, b = d(torch.randn(A, K, generator=g) * 0.05), d(torch.randn(A, generator=g) * 0.1)
     ls = d(torch.full((A,), math.log(0.5)) + 0.1 * torch.randn(A, generator=g))
@@ -197,14 +198,14 @@ def test_ppo_actor_head_equals_the_separate_launches(B, K, A, mini_norm):
     scal, dls = torch.zeros(8, device=DEV), torch.empty(A, device=DEV)
     o.linear_fwd(h, W, b, mu, o.ACT_NONE)
     o.ppo_actor_loss(mu, ls, act, olp, adv, om, osg, 1.0, True, 0.2, 0.016, mom, cnt, scal, dmu, dls, o.Workspace(torch.device(DEV)))
-    o.linear_bwd_data(dmu, W, h, dh, o.ACT_TANH)
+    o.linear_bwd_data(dmu, W, h, dh, HACT)
     mu2, dmu2, dh2 = torch.empty_like(mu), torch.empty_like(dmu), torch.empty_like(dh)
     scal2, dls2 = torch.zeros(8, device=DEV), torch.empty(A, device=DEV)
     assert o.ppo_actor_head_supported(h, W, dh2)
     ws = o.Workspace(torch.device(DEV))
     for _ in range(3):
         dh2.fill_(float("nan"))
-        o.ppo_actor_head(h, W, b, o.ACT_TANH, ls, act, olp, adv, om, osg, 1.0, True, 0.2, 0.016, mom, cnt, scal2, dmu2, dh2, dls2, ws,
+        o.ppo_actor_head(h, W, b, HACT, ls, act, olp, adv, om, osg, 1.0, True, 0.2, 0.016, mom, cnt, scal2, dmu2, dh2, dls2, ws,
                          mu_out=mu2)
         assert int(ws.counter[0]) == 0
         for name, x, y in (("mu", mu, mu2), ("dmu", dmu, dmu2), ("dh", dh, dh2), ("scal", scal, scal2), ("dlog_std", dls, dls2)):
