@@ -7,6 +7,7 @@
 //              gradient from the staged dY tiles; slabs are summed here in fixed order (single-problem call) or by the
 //              optimiser launch (grouped call, adam.hip).
 #include "common.h"
+#include <cstdlib>
 #include "gemm2.h"
 #include "skinny.h"
 
@@ -120,6 +121,21 @@ static inline int bww_splits(int M, int N, int K) {
     // work-groups at 0.66 TB/s (6.8 ms)
     if (s > (M >= 262144 ? 256 : 32)) s = (M >= 262144 ? 256 : 32);
     if (s < 1) s = 1;
+    // long reductions are MFMA-bound and two or three of their work-groups share a CU: the launch takes as long as the fullest
+    // CU, i.e. ceil(work-groups / 256) rounds -- pick the slab count near the target that fills its last round best (108 tiles:
+    // 4 slabs = 432 work-groups = 2 rounds at 84 %; 7 slabs = 756 = 3 rounds at 98 %)
+    if (M >= 262144 && tiles < 256) {
+        const long s0 = s;
+        double best = 0.0;
+        for (long c = (s0 + 1) / 2; c <= 2 * s0 && c <= 256 && c <= maxs; ++c) {
+            const long w = tiles * c;
+            const double eff = (double)w / (256.0 * ((w + 255) / 256));
+            if (eff > best + 0.02 || (eff > best - 1e-9 && labs(c - s0) < labs(s - s0))) {
+                if (eff > best) best = eff;
+                s = c;
+            }
+        }
+    }
     // every slab must own at least one row of the reduction once the chunk is rounded up to the K-step
     while (s > 1) {
         long kc = (M + s - 1) / s;
