@@ -446,6 +446,37 @@ def _gae_kernel_ms(st, n=32):
     return e0.elapsed_time(e1) / n
 
 
+def _linear_kernel_us(M, K, N, n=32):
+    """Mean duration (us, launch boundary included) of the hidden-layer GEMM of the small-step regime -- forward, data gradient
+    and weight gradient at (M x K) -> N -- each over `n` dependent launches replayed from one hipGraph."""
+    from partmanip_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    x, w, b = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) / K ** 0.5, torch.zeros(N, device=dev)
+    y, dy, dx = torch.empty(M, N, device=dev), torch.randn(M, N, device=dev), torch.empty(M, K, device=dev)
+    dw, db, ws = torch.empty(N, K, device=dev), torch.empty(N, device=dev), ops.Workspace(dev)
+    ws.get(ops.lib.pm_linear_bwd_weight_workspace_bytes(M, N, K))
+    out = {}
+    for name, call in (("fwd", lambda: ops.linear_fwd(x, w, b, y, ops.ACT_TANH)),
+                       ("bwd_data", lambda: ops.linear_bwd_data(dy, w, x, dx, ops.ACT_TANH)),
+                       ("bwd_weight", lambda: ops.linear_bwd_weight(dy, x, dw, db, ws))):
+        call()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(n):
+                call()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) / n * 1e3
+    return out
+
+
 def run_ppo(args, device, rank, world):
     from partmanip_amd import ops
     w = dict(WORKLOADS[args.workload])
@@ -554,6 +585,17 @@ def run_ppo(args, device, rank, world):
                                achieved=tf, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
                                traffic=None, flops_per_env_step=per_env_step,
                                note="algorithmic flops of the iteration / its wall time: every launch gap is inside")
+        if rank == 0:
+            # the dominant kernel on its own: a hidden layer (mini-batch x 512 x 512) on gemm2_dma_kernel, 32 dependent launches
+            # replayed from a graph on the otherwise idle chip (in the iteration two networks' chains share it)
+            Bm, H = 2048, hid[0]
+            us = _linear_kernel_us(Bm, H, H)
+            fl = 2.0 * Bm * H * H
+            out["roofline"]["hidden_layer_gemm"] = dict(
+                kernel="gemm2_dma_kernel (LDS-DMA fed v_mfma_f32_32x32x2_f32)", shape=[Bm, H, H], launches=32,
+                us_per_launch=us, tflops={k: fl / (v * 1e-6) / 1e12 for k, v in us.items()},
+                frac={k: fl / (v * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS for k, v in us.items()},
+                note="launch boundary included; bwd_weight = split-K GEMM + slab reduction as the single-problem entry point runs it")
     if gae_blk:
         out.setdefault("roofline", {})["gae_scan"] = gae_blk
     if args.workload == "vision" and args.precision == "f32" and world == 1 and not args.no_optional:
