@@ -206,3 +206,22 @@ def test_offline_preload_then_on_policy_rows_match_the_reference_ring(tmp_path):
     assert [st.mix_buf_ind, st.cur_buf_size, st.last_episode_buf_ind] == list(fx["state"])
     np.testing.assert_array_equal(st.observations.numpy(), fx["ring_obs"])
     np.testing.assert_array_equal(st.tea_obs.numpy(), fx["ring_tea"])
+
+
+def test_padded_cols_and_slab_count_host_side():
+    """Host pieces of the small-step path: rows padded to 16 bytes carry their readable width for the weight-gradient
+    launch, and the split-K slab count is lowered until every slab owns rows after rounding to the kernels' K-step of 32."""
+    from types import SimpleNamespace
+    from partmanip_amd import ops
+    from partmanip_amd.algorithms.ppo import ppo
+    v = ops.padded_cols(7, 53, torch.device("cpu"), zero=True)
+    assert tuple(v.shape) == (7, 53) and v.stride(0) == 56 and v._pm_cols == 56 and float(v.abs().sum()) == 0.0
+    w = ops.padded_cols(5, 1, torch.device("cpu"))
+    assert w.stride(0) == 4 and w._pm_cols == 4 and ops.padded_cols(3, 64, torch.device("cpu")).stride(0) == 64
+    for slabs in (1, 3, 8, 12, 64):
+        me = SimpleNamespace(actor_critic=SimpleNamespace(GRAD_SLABS=slabs))
+        for B in (8, 1023, 1024, 2048, 4100):
+            S = ppo._slabs(me, B)
+            chunk = (-(-B // S) + 31) // 32 * 32
+            assert 1 <= S <= slabs and (S == 1 or (S - 1) * chunk < B) and (B >= 1024 or S == 1)
+    assert ppo._slabs(SimpleNamespace(actor_critic=SimpleNamespace(GRAD_SLABS=3)), 2048) == 3
