@@ -16,6 +16,7 @@ prof() {   # name, bench args...
 prof bench_default --no-optional --steps 2 --warmup 1
 prof bench_state --workload state --steps 2 --warmup 1 --no-cpu-baseline
 prof bench_dagger_sparse_unet --workload dagger --student sparse_unet --steps 1 --warmup 1 --no-cpu-baseline
+prof bench_vision_pn2 --workload vision_pn2 --steps 1 --warmup 1 --no-cpu-baseline
 # un-profiled bench lines (the numbers to quote: a profiled run clocks lower)
 timeout 400 python bench.py > $out/line_default.json 2> $out/line_default.err < /dev/null
 timeout 300 python bench.py --workload state > $out/line_state.json 2>> $out/line_default.err < /dev/null
