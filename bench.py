@@ -595,7 +595,11 @@ def run_ppo(args, device, rank, world):
                 kernel="gemm2_dma_kernel (LDS-DMA fed v_mfma_f32_32x32x2_f32)", shape=[Bm, H, H], launches=32,
                 us_per_launch=us, tflops={k: fl / (v * 1e-6) / 1e12 for k, v in us.items()},
                 frac={k: fl / (v * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS for k, v in us.items()},
-                note="launch boundary included; bwd_weight = split-K GEMM + slab reduction as the single-problem entry point runs it")
+                traffic={k: _hbm_traffic(f"linear_2048x512x512_{k}_bytes_per_launch")[0] for k in us} if (Bm, H) == (2048, 512) else None,
+                algorithmic_bytes=(2 * Bm * H + H * H) * 4,
+                note="launch boundary included; bwd_weight = split-K GEMM + slab reduction as the single-problem entry point runs it; "
+                     "traffic: HBM bytes per launch of the GEMM kernel from the committed PMC pass (profiles/hbm_traffic.json, "
+                     "round2_l_pmc_linear.json) -- every XCD fetches the whole weight matrix into its own L2")
     if gae_blk:
         out.setdefault("roofline", {})["gae_scan"] = gae_blk
     if args.workload == "vision" and args.precision == "f32" and world == 1 and not args.no_optional:
