@@ -559,6 +559,22 @@ def run_ppo(args, device, rank, world):
             bflops = 2.0 * 2 * 256 * 128 * 1024 * 2048
             out["roofline"]["enc_bwd_executed_tflops"] = bflops / (bwd[0] * 1e-3) / 1e12
             out["roofline"]["enc_bwd_frac"] = out["roofline"]["enc_bwd_executed_tflops"] / PEAK_F32_MFMA_TFLOPS
+            # whole iteration: the MFMA flops the two encoder calls EXECUTE per network step (forward 688.8 G + backward
+            # 274.9 G, the latter = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 of pn_bwd16_kernel, profiles/hbm_traffic.json) x the
+            # network steps of the iteration, over the iteration's wall time -- every launch gap, head, loss and optimiser inside
+            net_steps = 2 * cfg["n_updates"] * (w["N"] * w["T"] // 2048)
+            it_flops = net_steps * (flops + bflops)
+            it_tf = it_flops / (ms_per_step * 1e-3) / 1e12
+            enc_ms = net_steps * (mean_ms + bwd[0])
+            out["roofline"]["iteration"] = dict(
+                executed_flops=it_flops, network_steps=net_steps, executed_tflops=it_tf, frac=it_tf / PEAK_F32_MFMA_TFLOPS,
+                encoder_calls_ms=enc_ms, outside_encoder_calls_ms=ms_per_step - enc_ms,
+                survey_30F_useful_tflops=30.0 * 2.0 * (ENC_MAC_PER_POINT * 1024 + 135488) * w["N"] * w["T"] / (ms_per_step * 1e-3) / 1e12,
+                note="SURVEY 8d / BASELINE.md 4 price an env-step at 30 F (fwd + 2 x bwd per net and epoch, F = 336.6 MFLOP) "
+                     "-> a 15.6 k env-steps/s ceiling at 157.3 TFLOP/s.  That ceiling no longer applies: the structured backward "
+                     "(DESIGN.md 3.2) eliminates the 256->512 layer's two backward GEMMs algebraically (max-pool gradient = one row "
+                     "per channel, layer 3 linear), so a backward EXECUTES 0.4 F instead of 2 F.  `frac` here is executed flops "
+                     "/ wall / peak; survey_30F_useful_tflops (> peak) is the same wall time priced the survey's way")
     if args.workload == "vision_pn2":
         # the four fused set-abstraction kernels; `achieved` counts the MFMA flops each launch EXECUTES
         # (fwd: layers 2-3; bwd: dW2 + dH1 [+ dH2 where it is dense] -- layer 2 is loaded from what the forward saved)
@@ -650,6 +666,52 @@ def optional_paths(run, ac, w, step, fence):
     return res
 
 
+def _brief(line):
+    """The part of a workload's line that the default line carries as a `secondary` entry."""
+    r = line.get("roofline") or {}
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "fwd_mean_ms", "bwd_mean_ms", "level_rows", "flops_per_env_step")
+    out = dict(metric=line["metric"], value=line["value"], unit=line["unit"], steps=line["steps"], warmup=line["warmup"],
+               ms_per_step=line["ms_per_step"], dtype=line["dtype"], workload=line["config"]["workload"],
+               roofline={k: r[k] for k in keep if k in r})
+    for k in ("hidden_layer_gemm", "gae_scan"):
+        if k in r:
+            out["roofline"][k] = r[k]
+    if "cpu_baseline" in line:
+        out["cpu_baseline"] = {k: line["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample")}
+        out["gpu_over_cpu"] = line.get("gpu_over_cpu")
+    if "train_scalars" in line["config"]:
+        out["train_scalars"] = line["config"]["train_scalars"]
+    if "dagger_loss" in line["config"]:
+        out["dagger_loss"] = line["config"]["dagger_loss"]
+    return out
+
+
+def secondary_lines(args, device):
+    """The other single-GPU BASELINE configs, timed by the SAME process right after the headline workload so that the driver's
+    clock witnesses them too: cfg 2 (state PPO) and cfg 5 as written (DAgger, SparseUNet student on 4096-voxel clouds).  Fixed
+    3 timed steps + 1 warm-up each (their own `steps` / `warmup` fields say so), each with its roofline and CPU baseline."""
+    import copy
+    import gc
+    res = {}
+    for key, kw in (("state", dict(workload="state")), ("dagger_sparse_unet", dict(workload="dagger", student="sparse_unet", points=4096))):
+        a = copy.copy(args)
+        a.steps, a.warmup, a.n_steps, a.precision = 3, 1, 0, "f32"
+        for k, v in kw.items():
+            setattr(a, k, v)
+        gc.collect()
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        try:
+            line = run_dagger(a, device, 0, 1) if a.workload == "dagger" else run_ppo(a, device, 0, 1)
+            res[key] = _brief(line)
+            res[key]["wall_s_incl_setup_and_cpu_baseline"] = time.perf_counter() - t0
+        except Exception as e:                             # the headline line must survive a secondary's failure -- and say so
+            res[key] = dict(error=f"{type(e).__name__}: {e}")
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) of this same command line under
     torch.distributed.run on this node and pass rank 0's ONE JSON line through.  Exits non-zero when fewer than N
@@ -680,6 +742,8 @@ def main():
     ap.add_argument("--workload", default="vision", choices=list(WORKLOADS) + ["dagger", "depth2pc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optional", action="store_true", help="vision workload: skip the opt-in paths (profiling runs)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default (vision) line on one GPU: skip the cfg 2 / cfg 5 sub-lines that the same run otherwise times")
     ap.add_argument("--n-steps", type=int, default=0, help="override the rollout length T (e.g. 128 for the vision workload)")
     ap.add_argument("--student", default="pointnet", choices=["pointnet", "conv3d", "sparse_unet"],
                     help="dagger workload: PointNet on --points clouds (cfg 5 analogue) or the reference's shipped Conv3DNet config")
@@ -705,6 +769,8 @@ def main():
             out = run_dagger(args, device, rank, world)
         else:
             out = run_ppo(args, device, rank, world)
+            if args.workload == "vision" and world == 1 and args.precision == "f32" and not args.n_steps and not args.no_secondary:
+                out["secondary"] = secondary_lines(args, device)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -307,7 +307,7 @@ def split_params(p):
     return actor, critic
 
 
-def ppo_update(p, st, cfg, it, opt=None, grad_sync=None):
+def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic")):
     """ppo.py:307-411 on explicit tensors.
 
     p   : dict name -> leaf tensor (ActorCritic.state_dict() layout), updated in place.
@@ -318,6 +318,7 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None):
     opt : optional (adam_actor, adam_critic) to continue from; created if None.
     grad_sync : optional callable(list_of_grads, list_of_scalars)->None used by the
           multi-process parity tests to average grads/scalars across ranks.
+    loops : which of the two loops to run (tests that need an fp64 evaluation of the actor's trajectory alone).
     Returns dict(log=..., loss_trace=[...], opt=(adam_actor, adam_critic)).
     """
     tricks, model_cfg = cfg["tricks"], cfg["model"]
@@ -333,7 +334,7 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None):
     seq_lists = minibatch_index_lists(n, cfg["n_minibatches"], "sequential") if sampler == "sequential" else None
     trace, sum_surr, sum_kl, kl_max, count, sum_v, n_v = [], 0.0, 0.0, 0.0, 0, 0.0, 0
 
-    for _ in range(cfg["n_updates"]):
+    for _ in range(cfg["n_updates"] if "actor" in loops else 0):
         lists = seq_lists if seq_lists is not None else minibatch_index_lists(n, cfg["n_minibatches"], sampler)
         for idx in lists:
             logp, _, _, mu, ls = update_act_cri(p, model_cfg, flat["observations"][idx], flat["actions"][idx],
@@ -360,7 +361,7 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None):
             sum_kl += float(kl_mean)
             count += 1
 
-    for _ in range(cfg["n_updates"]):
+    for _ in range(cfg["n_updates"] if "critic" in loops else 0):
         lists = seq_lists if seq_lists is not None else minibatch_index_lists(n, cfg["n_minibatches"], sampler)
         for idx in lists:
             # ppo.py:366: the critic loop also calls update_act_cri, i.e. runs BOTH networks forward
@@ -388,9 +389,9 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None):
         "Train/value_gt_return_mean": float(st["returns"].mean()),
         "Train/value_gt_return_max": float(st["returns"].max()),
         "Train/learning_rate": lr_now,
-        "Train/value_function_loss": sum_v / n_v,
-        "Train/surrogate_loss": sum_surr / count,        # ZeroDivisionError if every mb was skipped, as ppo.py:387
-        "Train/kl": sum_kl / count,
+        "Train/value_function_loss": sum_v / n_v if "critic" in loops else float("nan"),
+        "Train/surrogate_loss": sum_surr / count if "actor" in loops else float("nan"),   # ZeroDivisionError if every mb was skipped, as ppo.py:387
+        "Train/kl": sum_kl / count if "actor" in loops else float("nan"),
         "Train/kl_max": kl_max,
         "Train/kl_update_count": count,
     }

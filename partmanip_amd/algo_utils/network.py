@@ -742,11 +742,11 @@ class SparseUNet(_HipNet):
         cat0, cat1 = s["cat0"], s["cat1"]
         ops.linear_bwd_weight(dzE0, cat0, *self._g["up0"], ws)
         dcat0 = torch.empty_like(cat0)
-        ops.linear_bwd_data(dzE0, W("up0"), cat0, dcat0, ops.ACT_TANH)                     # tanh' of both halves folded in
+        ops.linear_bwd_data(dzE0, W("up0"), cat0, dcat0, self._act)                        # tanh' of both halves folded in
         dzE1 = ops.rows_gather_bwd(dcat0[:, :c1], g["l1"]["child"], c1, torch.empty_like(s["D1"]), mode=2)
         ops.linear_bwd_weight(dzE1, cat1, *self._g["up1"], ws)
         dcat1 = torch.empty_like(cat1)
-        ops.linear_bwd_data(dzE1, W("up1"), cat1, dcat1, ops.ACT_TANH)
+        ops.linear_bwd_data(dzE1, W("up1"), cat1, dcat1, self._act)
         dzH2 = ops.rows_gather_bwd(dcat1[:, :c2], g["l2"]["child"], c2, torch.empty_like(s["D2"]), mode=2)
         self._conv_wgrad("conv2", dzH2, s["D2"], g["nbr2"], c2, s["cols2"], ws)
         dzD2 = self._conv_dgrad("conv2", dzH2, g["nbr2"], s["D2"], torch.empty_like(s["D2"]))

@@ -474,7 +474,8 @@ class ppo:
         graphs = self._graph_table(views) if self.use_graphs else None
         chunk_a, chunk_c = [], []
         for ep, (la, lc) in enumerate(zip(lists_a, lists_c)):
-            for ia, ic in zip(la, lc):
+            assert len(la) == len(lc)
+            for k, (ia, ic) in enumerate(zip(la, lc)):
                 if self.pair:
                     if graphs is not None:
                         self._replay(graphs, ('p', ia, ic), lambda: self._pair_step(f, views, ia, ic), main)
@@ -485,7 +486,7 @@ class ppo:
                     if self.graph_steps > 1:
                         chunk_a.append(ia)
                         chunk_c.append(ic)
-                        if len(chunk_a) == self.graph_steps or ia is la[-1]:
+                        if len(chunk_a) == self.graph_steps or k == len(la) - 1:       # a chunk never crosses an epoch
                             ca, cc = tuple(chunk_a), tuple(chunk_c)
                             self._replay(graphs, ('a',) + ca, lambda: [self._actor_step(f, views, i, self._stage) for i in ca], main)
                             self._replay(graphs, ('c',) + cc, lambda: [self._critic_step(f, views, i, self._stage_c) for i in cc], side)
@@ -500,6 +501,7 @@ class ppo:
                         self._critic_step(f, views, ic, self._stage_c)
                 else:
                     self._pending_critic.append(ic)
+            assert not chunk_a and not chunk_c, "a mini-batch chunk was left unissued at the end of the epoch"
         if self.overlap:
             main.wait_stream(side)
         else:                                                            # reference order: critic loop afterwards

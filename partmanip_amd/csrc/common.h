@@ -83,10 +83,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PM_TANH_B4 1.18534705686654e-04f
 #define PM_TANH_B2 2.26843463243900e-03f
 #define PM_TANH_B0 4.89352518554385e-03f
-// v_med3_f32 drops a NaN operand (a NaN pre-activation would come out as -1): the scalar form selects the input back
-// when it is NaN so that a diverged network / a NaN observation stays visible in the losses, as with torch.tanh; the
-// packed form in the encoders' inner loops does not pay for the test (NaN WEIGHTS still surface through the last,
-// activation-free Linear of every backbone, and the runners check the loss scalars they read back).
+// v_med3_f32 drops a NaN operand (a NaN pre-activation would come out as -1): both forms select the input back when it
+// is NaN so that a NaN observation / a diverged network stays visible in the features and losses, as with torch.tanh
+// (two more VALU instructions per value; the encoder forward's pooling then turns a channel whose column holds a NaN
+// into NaN, as torch.max does -- pn_fwd_kernel's epilogue).
 __device__ __forceinline__ float pm_tanh(float x0) {
     float x = __builtin_amdgcn_fmed3f(x0, -PM_TANH_CLAMP, PM_TANH_CLAMP);
     const float x2 = x * x;
@@ -104,10 +104,11 @@ __device__ __forceinline__ float pm_tanh(float x0) {
     const float t = x * (p * r);                            // P/Q ~ 1 first, then times x: no denormal intermediates
     return x0 != x0 ? x0 : t;
 }
-__device__ __forceinline__ f32x2 pm_tanh2(f32x2 x) {
+__device__ __forceinline__ f32x2 pm_tanh2(f32x2 x0) {
 #define PM_S2(v) ((f32x2){(v), (v)})
-    x.x = __builtin_amdgcn_fmed3f(x.x, -PM_TANH_CLAMP, PM_TANH_CLAMP);
-    x.y = __builtin_amdgcn_fmed3f(x.y, -PM_TANH_CLAMP, PM_TANH_CLAMP);
+    f32x2 x;
+    x.x = __builtin_amdgcn_fmed3f(x0.x, -PM_TANH_CLAMP, PM_TANH_CLAMP);
+    x.y = __builtin_amdgcn_fmed3f(x0.y, -PM_TANH_CLAMP, PM_TANH_CLAMP);
     const f32x2 x2 = x * x;
     f32x2 p = __builtin_elementwise_fma(PM_S2(PM_TANH_A13), x2, PM_S2(PM_TANH_A11));
     p = __builtin_elementwise_fma(p, x2, PM_S2(PM_TANH_A9));
@@ -122,7 +123,12 @@ __device__ __forceinline__ f32x2 pm_tanh2(f32x2 x) {
     r.x = __builtin_amdgcn_rcpf(q.x);
     r.y = __builtin_amdgcn_rcpf(q.y);
     r = __builtin_elementwise_fma(__builtin_elementwise_fma(-q, r, PM_S2(1.0f)), r, r);
-    return x * (p * r);
+    f32x2 t = x * (p * r);
+#ifndef PM_TANH2_DROPS_NAN                                   // A/B builds only: what the two selects cost
+    t.x = x0.x != x0.x ? x0.x : t.x;                        // NaN in -> NaN out, as torch.tanh (v_cmp_u_f32 + v_cndmask_b32 per value)
+    t.y = x0.y != x0.y ? x0.y : t.y;
+#endif
+    return t;
 #undef PM_S2
 }
 __device__ __forceinline__ f32x2 pm_tanh2(float a, float b) { return pm_tanh2((f32x2){a, b}); }

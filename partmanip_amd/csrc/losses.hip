@@ -187,6 +187,11 @@ __global__ __launch_bounds__(64) void ppo_actor_loss_final_kernel(const ActorLos
 // separate kernels (same work-group partition as ppo_actor_loss_part_kernel<16>), so the results are bit-identical.
 #define AH_ROWS 16
 #define AH_THREADS 1024
+// dynamic LDS (the head's A x K weights) the fused head kernels accept.  Their static arrays add < 8 KB; a gfx950 work-group
+// may allocate up to 160 KB (MI355X_MICROARCH.md, LDS: "a single workgroup may declare all 160 KiB"), and this library is built
+// for gfx950 only -- 64 KB + 8 KB can therefore never fail at launch (tests run A = 16, K = 1024 = exactly 64 KB).
+#define AH_MAX_DYN_LDS (64 * 1024)
+static_assert(AH_MAX_DYN_LDS + 8 * 1024 <= 160 * 1024, "fused head kernels: weights + static arrays must fit a gfx950 work-group's LDS");
 __global__ __launch_bounds__(AH_THREADS) void ppo_actor_head_kernel(
     const float* __restrict__ H, long ldh, const float* __restrict__ W, long ldw, const float* __restrict__ bias, int K, int hact,
     const float* __restrict__ log_std, const float* __restrict__ actions, long lda, const float* __restrict__ old_logp,
@@ -382,7 +387,8 @@ extern "C" int pm_ppo_actor_loss_fwd_bwd_f32(const float* mu, long ldmu, const f
 
 extern "C" int pm_ppo_actor_head_supported(const float* H, long ldh, const float* W, long ldw, int A, int K, const float* dH,
                                            long lddh) {
-    return A <= 16 && skinny_ok(A, K, H, ldh, W, ldw) && lddh % 4 == 0 && sk_aligned16(dH);
+    // the kernel adds ~4.5 KB of static LDS (red, red_a, s_mu, s_dmu, ...) to the A*K*4 bytes of weights (AH_MAX_DYN_LDS above)
+    return A <= 16 && skinny_ok(A, K, H, ldh, W, ldw) && (long)A * K * 4 <= AH_MAX_DYN_LDS && lddh % 4 == 0 && sk_aligned16(dH);
 }
 
 extern "C" int pm_ppo_actor_head_f32(const float* H, long ldh, const float* W, long ldw, const float* bias, int K, int hidden_act,
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(AH_THREADS) void value_head_kernel(
             d = clip_mean_extern[0];
         } else {
             double acc = 0.0;
-            for (int i = tid; i < B; i += LOSS_THREADS) acc += (double)fabsf(eps_clip * old_values[i]);
+            for (int i = tid; i < B; i += AH_THREADS) acc += (double)fabsf(eps_clip * old_values[i]);
             acc = block_sum<double, AH_THREADS>(acc, red);
             d = (float)(acc / (double)B);
         }
@@ -635,7 +641,7 @@ __global__ __launch_bounds__(AH_THREADS) void value_head_kernel(
 
 extern "C" size_t pm_value_head_workspace_bytes(void) { return VH_MAXG * sizeof(double); }
 extern "C" int pm_value_head_supported(const float* H, long ldh, const float* W, int K, const float* dH, long lddh) {
-    return skinny_ok(1, K, H, ldh, W, K) && lddh % 4 == 0 && sk_aligned16(dH);
+    return skinny_ok(1, K, H, ldh, W, K) && (long)K * 4 <= AH_MAX_DYN_LDS && lddh % 4 == 0 && sk_aligned16(dH);
 }
 extern "C" int pm_value_head_f32(const float* H, long ldh, const float* W, const float* bias, int K, int hidden_act,
                                  const float* returns, const float* old_values, int B, int clipped, float eps_clip,

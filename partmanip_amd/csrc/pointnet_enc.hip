@@ -307,8 +307,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
         }
         if (lh == 0) {
             const int ch = (wave * NB3 + nb) * 32 + li;
+            const float sm = vsum[nb] + os;
+            if (sm != sm) v = sm;                 // a NaN anywhere in the channel's column: torch.max returns NaN (the strict > above skips it)
             feat[(long)b * ldf + ch] = v;
-            if (max_mean) feat[(long)b * ldf + PN_C3 + ch] = (vsum[nb] + os) / (float)P;
+            if (max_mean) feat[(long)b * ldf + PN_C3 + ch] = sm / (float)P;
             argmax[(long)b * PN_C3 + ch] = i;
         }
     }

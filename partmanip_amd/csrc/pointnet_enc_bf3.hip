@@ -288,8 +288,10 @@ __global__ __launch_bounds__(B3_NT, 2) void pn_fwd_bf3_kernel(const float* __res
         }
         if (lq == 0) {
             const int ch = (wave * 2 + nb) * 32 + li;
+            const float sm = vsum[nb] + os;
+            if (sm != sm) v = sm;                 // a NaN anywhere in the channel's column: torch.max returns NaN (the strict > above skips it)
             feat[(long)b * ldf + ch] = v;
-            if (max_mean) feat[(long)b * ldf + B3_C3 + ch] = (vsum[nb] + os) / (float)P;
+            if (max_mean) feat[(long)b * ldf + B3_C3 + ch] = sm / (float)P;
             argmax[(long)b * B3_C3 + ch] = i;
         }
     }

@@ -20,3 +20,14 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _record_parity_margins(request, monkeypatch):
+    """GPU tests: every np.testing.assert_allclose also appends what it OBSERVED to gpurun_out/parity_margins.jsonl
+    (tests/helpers.py; folded into profiles/parity_margins.json by tools/margins_summary.py)."""
+    if "gpu" in request.keywords:
+        import numpy as np
+        from tests import helpers
+        monkeypatch.setattr(np.testing, "assert_allclose", helpers.recording_allclose)
+    yield

@@ -7,6 +7,61 @@ import torch
 from tests.golden import cases
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------------------------- observed parity margins
+def margins_path():
+    """Where the GPU tests append what they OBSERVED next to what they tolerate (one JSON object per line; gpurun merges
+    gpurun_out/ back, tools/margins_summary.py folds the lines into profiles/parity_margins.json)."""
+    return os.environ.get("PARTMANIP_MARGINS", os.path.join(ROOT, "gpurun_out", "parity_margins.jsonl"))
+
+
+def record_margin(name, observed, tol, **extra):
+    """observed / tol in the same unit (a relative error, an absolute error, a count ...); never raises."""
+    import json
+    try:
+        path = margins_path()
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(test=test, name=name, observed=float(observed), tol=float(tol), **extra)) + "\n")
+    except Exception:
+        pass
+
+
+def assert_close_rec(name, got, want, rtol, atol=0.0):
+    """np.testing.assert_allclose that also records the worst element as a fraction of its tolerance."""
+    g, w = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    err = np.abs(g - w)
+    bound = atol + rtol * np.abs(w)
+    frac = float((err / np.maximum(bound, 1e-300)).max()) if err.size else 0.0
+    rel = float((err / np.maximum(np.abs(w), 1e-300)).max()) if err.size else 0.0
+    record_margin(name, frac, 1.0, unit="fraction of (atol + rtol*|want|)", rtol=rtol, atol=atol, worst_abs=float(err.max()) if err.size else 0.0,
+                  worst_rel=rel)
+    _ORIG_ALLCLOSE(g, w, rtol=rtol, atol=atol, err_msg=name)
+
+
+_ORIG_ALLCLOSE = np.testing.assert_allclose                 # (tests/conftest.py wraps np.testing.assert_allclose for the GPU tests)
+
+
+def recording_allclose(actual, desired, rtol=1e-7, atol=0, *args, **kw):
+    """np.testing.assert_allclose + the observed margin of EVERY such assertion of a GPU test (named by its call site)."""
+    import inspect
+    try:
+        fr = inspect.stack()[1]
+        where = f"{os.path.basename(fr.filename)}:{fr.lineno}"
+        g, w = np.asarray(actual, dtype=np.float64), np.asarray(desired, dtype=np.float64)
+        g, w = np.broadcast_arrays(g, w)
+        err = np.abs(g - w)
+        bound = atol + rtol * np.abs(w)
+        if err.size and np.all(np.isfinite(err)):
+            frac = float((err / np.maximum(bound, 1e-300)).max())
+            record_margin(f"assert_allclose @ {where}" + (f" [{kw['err_msg']}]" if kw.get("err_msg") else ""), frac, 1.0,
+                          unit="fraction of (atol + rtol*|want|)", rtol=float(rtol), atol=float(atol), worst_abs=float(err.max()))
+    except Exception:
+        pass
+    return _ORIG_ALLCLOSE(actual, desired, rtol, atol, *args, **kw)
 
 
 def load_fixture(name):
@@ -110,12 +165,31 @@ def per_tensor_update_error(fin_flat, ref_flat, init_sd, stride=1):
     return out
 
 
-def assert_update_matches(fin_flat, ref_flat, init_sd, lr, n_steps, stride=1, rel=5e-2):
-    """Whole-vector bounds (99.9 % quantile < 0.05 lr; max < 2.5 lr steps) PLUS the per-tensor relative-L2 bound."""
+def assert_update_matches(fin_flat, ref_flat, init_sd, lr, n_steps, stride=1, rel=1.2e-2, q_lr=5e-3, max_lr_steps=0.35):
+    """Whole-vector bounds (99.9 % quantile < q_lr * lr; max < max_lr_steps * lr * steps) PLUS the per-tensor relative-L2
+    bound; what was observed is recorded beside each bound (profiles/parity_margins.json).  Defaults = 4x the worst value
+    observed over the golden / autograd-bridge / SparseUNet cases on the MI355X box (round 3: 3.2e-3, 1.3e-3 lr, 0.085 lr
+    steps; rounds 1-2 asserted 5e-2, 5e-2, 2.5)."""
     diff = np.abs(np.asarray(fin_flat, dtype=np.float64)[::stride] - np.asarray(ref_flat, dtype=np.float64))
-    assert np.quantile(diff, 0.999) < 5e-2 * lr, (np.quantile(diff, 0.999), lr)
-    assert diff.max() < 2.5 * lr * n_steps, (diff.max(), lr)
+    q999 = float(np.quantile(diff, 0.999))
     errs = per_tensor_update_error(fin_flat, ref_flat, init_sd, stride)
+    worst = max((e for e, moved in errs.values() if moved > 0), default=0.0)
+    worst_k = max(((e, k) for k, (e, moved) in errs.items() if moved > 0), default=(0.0, ""))[1]
+    record_margin("update: 99.9% quantile of |param - ref| / lr", q999 / lr, q_lr, lr=lr, steps=n_steps)
+    record_margin("update: max |param - ref| / (lr * steps)", float(diff.max()) / (lr * n_steps), max_lr_steps, lr=lr, steps=n_steps)
+    record_margin("update: worst per-tensor ||got - ref|| / ||ref - init||", worst, rel, tensor=worst_k)
+    assert q999 < q_lr * lr, (q999, lr)
+    assert diff.max() < max_lr_steps * lr * n_steps, (diff.max(), lr)
     bad = {k: e for k, (e, moved) in errs.items() if (e > rel if moved > 0 else e > 1e-7)}
     assert not bad, f"per-tensor update error above {rel}: {bad}"
-    return max((e for e, moved in errs.values() if moved > 0), default=0.0)
+    return worst
+
+
+def assert_flat_params_close(name, got, ref, lr, n_steps, q_lr=5e-2, max_lr_steps=2.5):
+    """Two flat parameter vectors of the same run done two ways (ranks vs one process, ...): 99.9 % quantile and max bounds,
+    observed values recorded."""
+    diff = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64))
+    q = float(np.quantile(diff, 0.999))
+    record_margin(f"{name}: 99.9% quantile of |a - b| / lr", q / lr, q_lr)
+    record_margin(f"{name}: max |a - b| / (lr * steps)", float(diff.max()) / (lr * n_steps), max_lr_steps)
+    assert q < q_lr * lr and diff.max() < max_lr_steps * lr * n_steps, (q, diff.max(), lr)

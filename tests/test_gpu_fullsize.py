@@ -20,7 +20,8 @@ import torch
 from oracle import ref_cpu as R
 from tests.golden import cases
 from tests.golden.detgen import det_normal, det_uniform
-from tests.helpers import load_fixture, t, flat_state, FakeEnv, FakeLogger, assert_update_matches, per_tensor_update_error
+from tests.helpers import (load_fixture, t, flat_state, FakeEnv, FakeLogger, assert_update_matches, per_tensor_update_error,
+                           assert_close_rec, record_margin)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -106,10 +107,128 @@ def test_cfg1_full_ppo_update_matches_oracle(cfg1_problem, graphs, pair, steps):
     assert np.array_equal(run.storage.returns.cpu().numpy(), q["ret"].numpy())
     log, ref = run.log_dict, q["out"]["log"]
     assert log["Train/kl_update_count"] == ref["Train/kl_update_count"] == 40
-    for k in ("Train/value_function_loss", "Train/surrogate_loss", "Train/kl", "Train/kl_max"):
-        np.testing.assert_allclose(float(log[k]), float(ref[k]), rtol=5e-4, atol=2e-6, err_msg=k)
-    worst = assert_update_matches(flat_state(run.actor_critic.state_dict()), flat_state(q["ref"]), q["sd"], q["lr"], 80)
+    # observed on the box (round 3): kl 8e-6, kl_max 7e-8, surrogate 4e-6, value loss 4e-8 relative; parameters 1.1e-4 lr at the
+    # 99.9 % quantile, 3.6e-5 of the update per tensor -- the bounds are ~4x that (rounds 1-2: 5e-4, 5e-2 lr, 5e-2)
+    for k, rtol in (("Train/value_function_loss", 1e-6), ("Train/surrogate_loss", 2e-5), ("Train/kl", 4e-5), ("Train/kl_max", 1e-6)):
+        assert_close_rec(k, float(log[k]), float(ref[k]), rtol=rtol, atol=1e-9)
+    worst = assert_update_matches(flat_state(run.actor_critic.state_dict()), flat_state(q["ref"]), q["sd"], q["lr"], 80,
+                                  rel=2e-4, q_lr=5e-4, max_lr_steps=2e-3)
     print(f"cfg1 graphs={graphs}: worst per-tensor relative update error {worst:.2e}")
+
+
+# ------------------------------------------------------------------------------------------------------ cfg 2
+def _cfg2_inputs():
+    N, T, O, A, lr = 4096, 128, 53, 10, 5e-5
+    net = dict(name="MLP", hid_dim=[512, 512, 512], activation="tanh")
+    sd = cases.actor_critic_state(net, O, A, 0.5, 831)
+    p = {k: t(v.copy()) for k, v in sd.items()}
+    cfg = _cfg(net, N, T, 8, 5, lr, "cpu")
+    obs = t(det_normal((T, N, O), 8310))
+    st = _rollout_from_policy(p, cfg["model"], obs, 8311)
+    ret, adv = R.gae_returns(st["rewards"], st["values"], st["dones"], st["succs"], st["last_values"], 0.99, 0.95, None, False)
+    roll = {k: st[k] for k in ("observations", "actions", "values", "actions_log_prob", "mu", "sigma")}
+    roll["returns"], roll["advantages"] = ret, adv
+    return dict(N=N, T=T, O=O, A=A, lr=lr, net=net, sd=sd, st=st, ret=ret, adv=adv, cfg=cfg, roll=roll, p=p)
+
+
+def _cfg2_actor_fp64(threads):
+    """The actor loop of cfg 2 on the SAME oracle in fp64 (runs in a spawned child process beside the fp32 oracle)."""
+    torch.set_num_threads(threads)
+    q = _cfg2_inputs()
+    p64 = {k: v.double() for k, v in q["p"].items()}
+    out = R.ppo_update(p64, {k: v.double() for k, v in q["roll"].items()}, q["cfg"], 1, loops=("actor",))
+    return {k: v.numpy() for k, v in p64.items()}, {k: out["log"][k] for k in ("Train/surrogate_loss", "Train/kl", "Train/kl_max")}
+
+
+@pytest.fixture(scope="module")
+def cfg2_problem():
+    """BASELINE.json configs[1]: open_drawer state PPO, 4096 envs x 128 steps, O = 53 (open_drawer.yaml:9), A = 10, MLP
+    512-512-512 tanh, ppo.yaml hyper-parameters (lr 5e-5, 5 epochs, 8 -> 2048-row mini-batches: 256 per epoch, 2 x 1280
+    dependent optimiser steps) -- the oracle's fp32 `ppo_update` on the same rollout (~60 s of host cores) and, beside it
+    in a child process, the oracle's actor loop in fp64.
+
+    Why the fp64 run: after 1280 Adam steps on a surrogate whose gradient is ~0 at ratio = 1 the ACTOR's parameter trajectory
+    is chaotic at fp32 round-off -- the fp32 oracle itself ends 4e-2 (relative to the update) away from its own fp64
+    evaluation, 2.3 lr at the 99.9 % quantile (tools/probe_cfg2.py; the critic, driven by a large regression loss, stays at
+    1e-5).  No fp32 implementation can be closer to the fp32 reference than that, so the actor is bracketed: the HIP path
+    must be as close to the fp64 trajectory as the fp32 oracle is (x 2), and the critic is compared tightly."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    ncpu = os.cpu_count() or 1
+    th = max(1, min(32, ncpu // 2))
+    with ProcessPoolExecutor(1, mp_context=mp.get_context("spawn")) as ex:
+        fut = ex.submit(_cfg2_actor_fp64, th)
+        torch.set_num_threads(th)
+        q = _cfg2_inputs()
+        out = R.ppo_update(q["p"], q["roll"], q["cfg"], 1)
+        p64, log64 = fut.result()
+    assert len(out["loss_trace"]) == 2560 and R.minibatch_size(q["N"] * q["T"], 8) == 2048
+    q.update(ref=q["p"], out=out, p64=p64, log64=log64)
+    return q
+
+
+def test_cfg2_full_ppo_update_matches_oracle(cfg2_problem):
+    """cfg 2 exactly, whole `learn` window on the HIP path: O = 53 takes the 16-byte padded-observation path of the small-step
+    regime (ppo.py `obs_pad`: 53 -> 56-float rows feeding the input layer's LDS-DMA weight gradient), and 256 mini-batches
+    per epoch are sixteen 16-step hipGraphs per network, captured in epoch 2 and replayed in epochs 3-5.  Graph replay on and
+    off must agree bit for bit; against the oracle: returns bit-exact, the same 1280 un-skipped actor steps, loss scalars,
+    critic parameters tightly, actor parameters inside the fp32 oracle's own distance to fp64 (see the fixture)."""
+    from partmanip_amd.algorithms import ppo
+    q = cfg2_problem
+    fin = {}
+    for graphs in (True, False):
+        with tempfile.TemporaryDirectory() as d:
+            run = ppo(FakeEnv(q["N"], {"normal_state": q["O"]}, q["A"]), _cfg(q["net"], q["N"], q["T"], 8, 5, q["lr"], DEV), FakeLogger(d))
+        run.actor_critic.load_state_dict({k: t(v.copy()) for k, v in q["sd"].items()})
+        assert run.use_graphs and run.solo_group and run.fused_head and run.graph_steps == 16
+        run.use_graphs = graphs
+        _fill(run, q["st"])
+        run.log_dict = {}
+        run.curr_iter = 1
+        run.learn(q["st"]["last_values"].to(DEV))
+        torch.cuda.synchronize()
+        assert run._obs_pad is not None and tuple(run._obs_pad.shape) == (q["N"] * q["T"], q["O"]) and run._obs_pad.stride(0) == 56
+        if graphs:
+            assert sum(1 for k in run._graphs if isinstance(k, tuple)) == 2 * 256 // 16
+        assert np.array_equal(run.storage.returns.cpu().numpy(), q["ret"].numpy())
+        fin[graphs] = (flat_state(run.actor_critic.state_dict()), dict(run.log_dict))
+        del run
+    assert np.array_equal(fin[True][0], fin[False][0]), "hipGraph replay changed the result"
+    got, log = fin[True]
+    ref, l64 = q["out"]["log"], q["log64"]
+    assert log["Train/kl_update_count"] == ref["Train/kl_update_count"] == 1280
+    # scalars are means over all 1280 steps: value loss and KL to fp32 round-off; the surrogate is a mean of O(1) terms that
+    # cancel to ~1e-3, so its error is absolute (5e-6 observed between the fp32 and the fp64 oracle)
+    assert_close_rec("Train/value_function_loss", float(log["Train/value_function_loss"]), float(ref["Train/value_function_loss"]), rtol=2e-6)
+    assert_close_rec("Train/kl", float(log["Train/kl"]), float(ref["Train/kl"]), rtol=5e-4)
+    assert_close_rec("Train/kl_max", float(log["Train/kl_max"]), float(ref["Train/kl_max"]), rtol=1e-5)
+    assert_close_rec("Train/surrogate_loss", float(log["Train/surrogate_loss"]), float(ref["Train/surrogate_loss"]), rtol=0, atol=2e-5)
+    # ---- parameters
+    o32 = flat_state(q["ref"])
+    names = list(q["sd"].keys())
+    e_hip32 = per_tensor_update_error(got, o32, q["sd"])
+    f64 = np.concatenate([np.asarray(q["p64"][k], dtype=np.float64).reshape(-1) for k in names])
+    e_hip64, e_o32_64 = per_tensor_update_error(got, f64, q["sd"]), per_tensor_update_error(o32, f64, q["sd"])
+    for k in names:
+        if k.startswith("critic."):
+            record_margin(f"cfg 2 critic: ||hip - oracle32|| / ||oracle32 - init|| [{k}]", e_hip32[k][0], 1e-4)
+            assert e_hip32[k][0] < 1e-4, (k, e_hip32[k])           # observed 2e-6 ... 2.6e-5 (the 1-element head bias)
+        else:
+            record_margin(f"cfg 2 actor: hip-to-fp64 distance / oracle32-to-fp64 distance [{k}]", e_hip64[k][0] / e_o32_64[k][0], 2.0,
+                          hip_to_fp64=e_hip64[k][0], oracle32_to_fp64=e_o32_64[k][0], hip_to_oracle32=e_hip32[k][0])
+            assert e_hip64[k][0] < 2.0 * e_o32_64[k][0], (k, e_hip64[k], e_o32_64[k])
+    n_c = sum(int(np.asarray(v).size) for k, v in q["sd"].items() if k.startswith("critic."))
+    d_hip = np.abs(got[:-n_c].astype(np.float64) - f64[:-n_c])
+    d_o32 = np.abs(o32[:-n_c].astype(np.float64) - f64[:-n_c])
+    for name, qq in (("median", 0.5), ("99.9 % quantile", 0.999)):
+        a, b = float(np.quantile(d_hip, qq)), float(np.quantile(d_o32, qq))
+        record_margin(f"cfg 2 actor: {name} of |param - fp64|, hip / oracle32", a / b, 2.0, hip_over_lr=a / q["lr"], oracle32_over_lr=b / q["lr"])
+        assert a < 2.0 * b, (name, a, b)
+    d_c = np.abs(got[-n_c:].astype(np.float64) - o32[-n_c:].astype(np.float64))
+    record_margin("cfg 2 critic: 99.9 % quantile of |param - oracle32| / lr", float(np.quantile(d_c, 0.999)) / q["lr"], 3e-3)
+    assert np.quantile(d_c, 0.999) < 3e-3 * q["lr"]                  # observed 6.7e-4 lr
+    for k in ("Train/surrogate_loss", "Train/kl"):
+        record_margin(f"cfg 2 {k}: |hip - fp64| / |oracle32 - fp64|", abs(float(log[k]) - l64[k]) / max(abs(float(ref[k]) - l64[k]), 1e-300), 4.0)
 
 
 def test_cfg1_fused_policy_head_is_bit_identical(cfg1_problem):
@@ -211,9 +330,9 @@ def test_cfg3_one_b2048_actor_and_critic_step_matches_oracle():
     for k in p:
         p[k].requires_grad_(False)
 
-    np.testing.assert_allclose(float(run.log_dict["Train/surrogate_loss"]), surr, rtol=5e-4, atol=2e-6)
-    np.testing.assert_allclose(float(run.log_dict["Train/value_function_loss"]), vloss, rtol=5e-4)
-    np.testing.assert_allclose(float(run.log_dict["Train/kl"]), np.mean(kls), rtol=5e-4, atol=1e-7)
+    assert_close_rec("Train/surrogate_loss", float(run.log_dict["Train/surrogate_loss"]), surr, rtol=5e-4, atol=2e-6)
+    assert_close_rec("Train/value_function_loss", float(run.log_dict["Train/value_function_loss"]), vloss, rtol=5e-4)
+    assert_close_rec("Train/kl", float(run.log_dict["Train/kl"]), np.mean(kls), rtol=5e-4, atol=1e-7)
     fin, ref = flat_state(run.actor_critic.state_dict()), flat_state(p)
     # ONE Adam step moves every element by ~lr * sign(g): a near-zero gradient element may flip (a move of 2 lr) between
     # two correct fp32 evaluations, and the max-pool arg-max of near-tied channels differs legitimately;
@@ -221,8 +340,10 @@ def test_cfg3_one_b2048_actor_and_critic_step_matches_oracle():
     errs = per_tensor_update_error(fin, ref, sd)
     print({k: f"{e:.2e}" for k, (e, m) in errs.items() if m > 0})
     diff = np.abs(fin.astype(np.float64) - ref.astype(np.float64))
-    assert np.quantile(diff, 0.99) < 5e-2 * lr and diff.max() <= 2.0 * lr * 1.0001, (np.quantile(diff, 0.99), diff.max())
-    bad = {k: e for k, (e, m) in errs.items() if m > 0 and e > 0.15}
+    record_margin("one B=2048 step: 99% quantile of |param - ref| / lr", float(np.quantile(diff, 0.99)) / lr, 1e-3)
+    record_margin("one B=2048 step: worst per-tensor ||got - ref|| / ||ref - init||", max(e for e, m in errs.values() if m > 0), 0.1)
+    assert np.quantile(diff, 0.99) < 1e-3 * lr and diff.max() <= 2.0 * lr * 1.0001, (np.quantile(diff, 0.99), diff.max())
+    bad = {k: e for k, (e, m) in errs.items() if m > 0 and e > 0.1}                # observed 2.6e-2 (sign flips of ~0 gradients)
     assert not bad, bad
 
 
@@ -267,7 +388,7 @@ def test_dagger_offline_plus_on_policy_update_matches_reference(tmp_path, monkey
     torch.manual_seed(c["torch_seed"])
     run.log_dict = {}
     run.update(c["it"])
-    np.testing.assert_allclose(run.log_dict["Train/dagger_loss"], float(fx["log_dagger_loss"]), rtol=5e-4)
+    np.testing.assert_allclose(run.log_dict["Train/dagger_loss"], float(fx["log_dagger_loss"]), rtol=1e-5)
     np.testing.assert_allclose(run.log_dict["Train/learning_rate"], float(fx["log_learning_rate"]), rtol=1e-12)
     assert_update_matches(flat_state(run.student.state_dict()), fx["final_flat"], init, c["lr"], len(fx["loss_trace"]))
 

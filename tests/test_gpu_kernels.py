@@ -47,7 +47,7 @@ def test_gae_golden_bit_exact(name):
     st.compute_returns(t(inp["last_values"]).to(DEV), 0.99, 0.95)
     assert np.array_equal(st.returns.cpu().numpy(), fx["returns"])
     if c["whole_adv_norm"]:
-        np.testing.assert_allclose(st.advantages.cpu().numpy(), fx["advantages"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(st.advantages.cpu().numpy(), fx["advantages"], rtol=2e-6, atol=2e-7)
     else:
         assert np.array_equal(st.advantages.cpu().numpy(), fx["advantages"])
 
@@ -159,16 +159,16 @@ def test_ppo_actor_loss(B, A, mini_norm):
     o.ppo_actor_loss(d(mu), d(log_std), d(actions), d(old_logp), d(adv), d(old_mu), d(old_sigma), 1.0, True, 0.2, 0.1,
                      mom, cnt, scal, dmu, dls, o.Workspace(torch.device(DEV)))
     s = scal.cpu()
-    np.testing.assert_allclose(float(s[0]), float(loss_ref.detach()), rtol=2e-5, atol=3e-5)   # mean of +-O(1) terms
-    np.testing.assert_allclose(float(s[1]), float(kl_ref), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(float(s[0]), float(loss_ref.detach()), rtol=5e-6, atol=5e-6)   # mean of +-O(1) terms
+    np.testing.assert_allclose(float(s[1]), float(kl_ref), rtol=1e-5, atol=2e-7)
     assert float(s[2]) == float(float(kl_ref) > 0.1)
-    np.testing.assert_allclose(float(s[3]), float(ent[0]), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(float(s[3]), float(ent[0]), rtol=5e-6, atol=5e-6)
     # saturated actions give |logp| ~ 1e2: one fp32 ulp there is ~1e-5 in the exponent of ratio = exp(logp - old)
     assert rel_err(dmu, gmu) < 2e-4
     assert rel_err(dls, gls) < 2e-4
     lp, en = torch.empty(B, device=DEV), torch.empty(B, device=DEV)
     o.gaussian_logp(d(mu), d(log_std), d(actions), 1.0, True, lp, en)
-    np.testing.assert_allclose(lp.cpu().numpy(), logp.detach().numpy(), rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(lp.cpu().numpy(), logp.detach().numpy(), rtol=5e-6, atol=5e-5)
 
 
 @pytest.mark.parametrize("B,K,A,mini_norm,hact", [(2048, 512, 10, False, "tanh"), (2048, 512, 10, True, "tanh"), (300, 64, 3, False, "elu"),
@@ -240,6 +240,57 @@ def test_value_head_equals_the_separate_launches(B, K, clipped):
         np.testing.assert_allclose(float(scal2[0]), float(scal[0]), rtol=1e-6)
 
 
+def test_fused_heads_last_work_group_reduction_under_uneven_load():
+    """The fused head launches hand their per-work-group partials to the LAST work-group to arrive INSIDE the launch (relaxed
+    agent-scope atomic stores -> s_waitcnt vmcnt(0) -> a relaxed agent-scope counter RMW -> agent-scope atomic loads: the
+    '8-byte agent atomics on both sides' form of MI355X_MICROARCH.md, which bypasses the non-coherent L1 / per-XCD L2 without a
+    fence).  That relies on how gfx950 lowers sc1 atomics, so it is stressed here the way the guide asks: the full 128-work-group
+    grid, 200 launches whose inputs CHANGE every launch (a stale partial of the previous launch would be a wrong sum), a second
+    stream keeping part of the chip busy with a copy (uneven load), every scalar and log_std gradient bit for bit against the
+    two-launch path each time."""
+    o = ops()
+    B, K, A = 2048, 512, 10
+    g = torch.Generator().manual_seed(77)
+    d = lambda v: v.to(DEV).contiguous()
+    h = d(torch.tanh(torch.randn(B, K, generator=g)))
+    W, b = d(torch.randn(A, K, generator=g) * 0.05), d(torch.randn(A, generator=g) * 0.1)
+    Wv, bv = d(torch.randn(1, K, generator=g) * 0.05), d(torch.randn(1, generator=g) * 0.1)
+    ls = d(torch.full((A,), math.log(0.5)) + 0.1 * torch.randn(A, generator=g))
+    act = d(torch.rand(B, A, generator=g) * 1.998 - 0.999)
+    olp, adv0 = d(torch.randn(B, generator=g) * 0.3 - 4.0), d(torch.randn(B, generator=g))
+    om, osg = d(torch.randn(B, A, generator=g) * 0.1), d(ls.cpu().repeat(B, 1) + 0.02 * torch.randn(B, A, generator=g))
+    ret0, old = d(torch.randn(B, 1, generator=g)), d(torch.randn(B, 1, generator=g))
+    dev = torch.device(DEV)
+    mu, dmu, dh = torch.empty(B, A, device=DEV), torch.empty(B, A, device=DEV), torch.empty_like(h)
+    scal, dls = torch.zeros(8, device=DEV), torch.empty(A, device=DEV)
+    dmu2, dh2, scal2, dls2 = torch.empty_like(dmu), torch.empty_like(dh), torch.zeros(8, device=DEV), torch.empty(A, device=DEV)
+    v, dv, dhv, scv = torch.empty(B, 1, device=DEV), torch.empty(B, 1, device=DEV), torch.empty_like(h), torch.zeros(8, device=DEV)
+    dv2, dhv2, scv2 = o.padded_cols(B, 1, dev), torch.empty_like(h), torch.zeros(8, device=DEV)
+    ws_ref, ws_a, ws_v = o.Workspace(dev), o.Workspace(dev), o.Workspace(dev)
+    side = torch.cuda.Stream()
+    big_a, big_b = torch.empty(64 << 20, device=DEV), torch.empty(64 << 20, device=DEV)
+    bad = 0
+    for it in range(200):
+        adv = adv0 * (1.0 + 0.01 * it) + 0.001 * it
+        ret = ret0 + 0.01 * it
+        o.linear_fwd(h, W, b, mu, o.ACT_NONE)
+        o.ppo_actor_loss(mu, ls, act, olp, adv, om, osg, 1.0, True, 0.2, 0.016, None, 0, scal, dmu, dls, ws_ref)
+        o.linear_fwd(h, Wv, bv, v, o.ACT_NONE)
+        o.value_loss(v, ret, old, True, 0.2, None, 1.0, scv, dv)
+        if it % 3 != 2:                                       # two launches in three run next to a 256 MB copy on another stream
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                big_b.copy_(big_a)
+        o.ppo_actor_head(h, W, b, o.ACT_TANH, ls, act, olp, adv, om, osg, 1.0, True, 0.2, 0.016, None, 0, scal2, dmu2, dh2, dls2, ws_a)
+        o.value_head(h, Wv, bv, o.ACT_TANH, ret, old, True, 0.2, None, 1.0, scv2, dv2, dhv2, ws_v)
+        ok = torch.equal(scal, scal2) and torch.equal(dls, dls2) and torch.equal(dmu, dmu2) and float(scv[1]) == float(scv2[1]) \
+            and abs(float(scv2[0]) - float(scv[0])) <= 1e-6 * abs(float(scv[0])) and torch.equal(dv, dv2)
+        bad += 0 if ok else 1
+        torch.cuda.current_stream().wait_stream(side)
+    assert bad == 0, f"{bad} of 200 launches read stale / partial sums"
+    assert int(ws_a.counter[0]) == 0 and int(ws_v.counter[0]) == 0
+
+
 @pytest.mark.parametrize("B,clipped", [(2048, False), (2048, True), (15, True)])
 def test_value_loss(B, clipped):
     o = ops()
@@ -250,7 +301,7 @@ def test_value_loss(B, clipped):
     gv, = torch.autograd.grad(loss, [v])
     scal, dv = torch.zeros(8, device=DEV), torch.empty(B, 1, device=DEV)
     o.value_loss(v.detach().to(DEV), ret.to(DEV), old.to(DEV), clipped, 0.2, None, 1.0, scal, dv)
-    np.testing.assert_allclose(float(scal[0]), float(loss), rtol=1e-5)
+    np.testing.assert_allclose(float(scal[0]), float(loss), rtol=2e-6)
     assert rel_err(dv, gv) < 1e-5
 
 
@@ -264,11 +315,11 @@ def test_mse_tanh_loss(B, A):
     gs, = torch.autograd.grad(loss, [sm])
     scal, ds = torch.zeros(8, device=DEV), torch.empty(B, A, device=DEV)
     o.mse_tanh_loss(sm.detach().to(DEV), tm.to(DEV), 1.0, True, 1.0, scal, ds)
-    np.testing.assert_allclose(float(scal[0]), float(loss), rtol=1e-5)
+    np.testing.assert_allclose(float(scal[0]), float(loss), rtol=2e-6)
     assert rel_err(ds, gs) < 1e-5
     out = torch.empty(B, A, device=DEV)
     o.action_activation(tm.to(DEV), out, 1.0, True)
-    np.testing.assert_allclose(out.cpu().numpy(), torch.tanh(tm).numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(out.cpu().numpy(), torch.tanh(tm).numpy(), rtol=2e-6, atol=2e-7)
 
 
 # ------------------------------------------------------------------------------- clip + Adam
@@ -299,7 +350,7 @@ def test_clip_adam_steps(n, n_clip, max_norm):
                 np.testing.assert_allclose(float(gn), float(total), rtol=1e-5)
             adam.step([gr])
     assert int(state[0]) == 5
-    np.testing.assert_allclose(pd.cpu().numpy(), pr.numpy(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(pd.cpu().numpy(), pr.numpy(), rtol=0, atol=1e-6)
     assert rel_err(m, adam.m[0]) < 1e-5 and rel_err(v, adam.v[0]) < 1e-5
 
 
@@ -577,8 +628,8 @@ def test_grouped_linear_ops_equal_the_single_problem_ops():
         ref = (dy.double().t() @ x.double())
         assert float((tot[:N * K].view(N, K).double() - ref).abs().max() / ref.abs().max()) < 2e-6
         assert float((dw1.double() - ref).abs().max() / ref.abs().max()) < 2e-6
-        np.testing.assert_allclose(tot[N * K:N * K + N].cpu().numpy(), dy.double().sum(0).float().cpu().numpy(), rtol=2e-5, atol=2e-4)
-        np.testing.assert_allclose(db1.cpu().numpy(), dy.double().sum(0).float().cpu().numpy(), rtol=2e-5, atol=2e-4)
+        np.testing.assert_allclose(tot[N * K:N * K + N].cpu().numpy(), dy.double().sum(0).float().cpu().numpy(), rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(db1.cpu().numpy(), dy.double().sum(0).float().cpu().numpy(), rtol=1e-5, atol=1e-4)
 
 
 def test_grouped_clip_adam_equals_two_single_steps():
@@ -706,4 +757,4 @@ def test_sparse_conv_bwd_data_scatter_against_torch(rows, J, C, N):
     ref = torch.full((ndst, C), 7.0, dtype=torch.float64)
     m = perm >= 0
     ref[perm[m].long()] = full[m] * (1 - h.double()[perm[m].long()] ** 2)
-    np.testing.assert_allclose(dx.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(dx.cpu().numpy(), ref.numpy(), rtol=5e-6, atol=2e-6)

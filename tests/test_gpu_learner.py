@@ -19,10 +19,18 @@ import torch
 
 from oracle import ref_cpu as R
 from tests.golden import cases
-from tests.helpers import load_fixture, t, ppo_cfg, ppo_rollout, flat_state, FakeEnv, FakeLogger, assert_update_matches
+from tests.helpers import (load_fixture, t, ppo_cfg, ppo_rollout, flat_state, FakeEnv, FakeLogger, assert_update_matches, assert_close_rec,
+                           record_margin)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+# (rtol, atol) of the Train/* scalars against the reference's own values: 4x what the MI355X path was observed at (round 3,
+# profiles/parity_margins.json; rounds 1-2 asserted rtol 5e-4 for all of them).  The surrogate of the golden cases is a mean
+# of terms with |logp| ~ 1e2 in the exponent: one ulp there is 1e-5 relative in the ratio.
+SCALAR_TOL = {"value_function_loss": (2e-6, 0.0), "surrogate_loss": (4e-4, 5e-6), "kl": (2e-5, 1e-7), "kl_max": (4e-5, 1e-7),
+              "learning_rate": (1e-12, 0.0), "value_gt_return_mean": (2e-6, 2e-7), "value_gt_return_max": (1e-7, 0.0)}
 
 
 def rel_err(got, ref):
@@ -69,10 +77,10 @@ def test_update_act_cri_matches_reference(name):
     st = ppo_rollout(c, fx)
     logp, ent, val, mu, sig = run.actor_critic.update_act_cri(st["observations"].view(-1, c["O"]).to(DEV),
                                                               st["actions"].view(-1, c["A"]).to(DEV))
-    np.testing.assert_allclose(mu.cpu().numpy(), fx["fwd_mu"], rtol=2e-5, atol=3e-6)
-    np.testing.assert_allclose(val.cpu().numpy(), fx["fwd_value"], rtol=2e-5, atol=3e-6)
-    np.testing.assert_allclose(logp.cpu().numpy(), fx["fwd_logp"], rtol=3e-5, atol=3e-4)
-    np.testing.assert_allclose(ent.cpu().numpy(), fx["fwd_entropy"], rtol=1e-6)
+    assert_close_rec("mu", mu.cpu().numpy(), fx["fwd_mu"], rtol=2e-5, atol=3e-6)
+    assert_close_rec("value", val.cpu().numpy(), fx["fwd_value"], rtol=2e-5, atol=3e-6)
+    assert_close_rec("log_prob", logp.cpu().numpy(), fx["fwd_logp"], rtol=3e-5, atol=3e-4)
+    assert_close_rec("entropy", ent.cpu().numpy(), fx["fwd_entropy"], rtol=1e-6)
     assert sig.shape == mu.shape
 
 
@@ -85,7 +93,7 @@ def test_ppo_update_matches_reference(name):
     run.storage.compute_returns(t(fx["last_values"]).to(DEV), c["gamma"], c["lam"])
     assert np.array_equal(run.storage.returns.cpu().numpy(), fx["returns"])
     if c["tricks"]["whole_adv_norm"]:
-        np.testing.assert_allclose(run.storage.advantages.cpu().numpy(), fx["advantages"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(run.storage.advantages.cpu().numpy(), fx["advantages"], rtol=2e-6, atol=5e-7)
     else:
         assert np.array_equal(run.storage.advantages.cpu().numpy(), fx["advantages"])
     if c["sampler"] == "random":
@@ -96,7 +104,7 @@ def test_ppo_update_matches_reference(name):
     assert log["Train/kl_update_count"] == int(fx["log_kl_update_count"])
     for k in ("value_function_loss", "surrogate_loss", "kl", "kl_max", "learning_rate", "value_gt_return_mean",
               "value_gt_return_max"):
-        np.testing.assert_allclose(float(log["Train/" + k]), float(fx["log_" + k]), rtol=5e-4, atol=5e-6, err_msg=k)
+        assert_close_rec("Train/" + k, float(log["Train/" + k]), float(fx["log_" + k]), *SCALAR_TOL[k])
     fin = flat_state(run.actor_critic.state_dict())
     n_steps = len(fx["loss_trace"])
     check_params(fin, fx["final_flat"], int(fx["final_stride"]), c["lr"], n_steps,
@@ -179,6 +187,7 @@ def test_pointnet_forward_backward(B, C, max_mean, sub_mean, proprio, P):
 
     xd = x.to(DEV)
     out = ac.actor.hip_forward(xd)
+    record_margin("encoder output (max abs / max|ref|)", rel_err(out, out_ref.detach()), 2e-5)
     assert rel_err(out, out_ref.detach()) < 2e-5
     # gradient reference with the pooling index pinned to the kernel's (checked against torch.max's below
     # wherever the top-2 gap is resolvable in fp32): see oracle.pointnet_forward's docstring
@@ -204,6 +213,13 @@ def test_pointnet_forward_backward(B, C, max_mean, sub_mean, proprio, P):
     am = argmax.cpu().long()
     clear = gap > 1e-5
     assert torch.equal(am[clear], imax[clear])
+    # how many (cloud, channel) pairs the equality above could NOT check (top-2 gap inside fp32 round-off), and how many of
+    # those the kernel resolved differently from torch.max: a silent arg-max bug cannot hide in "near-tie" if this stays ~0
+    n_sub, n_diff = int((~clear).sum()), int((am[~clear] != imax[~clear]).sum())
+    print(f"arg-max: {n_sub} of {clear.numel()} (cloud, channel) pairs under the 1e-5 gap, {n_diff} of them resolved differently")
+    record_margin("arg-max pairs under the 1e-5 top-2 gap / all pairs", n_sub / clear.numel(), 5e-2, differing=n_diff, pairs=int(clear.numel()))
+    record_margin("arg-max pairs under the gap that differ from torch.max / all pairs", n_diff / clear.numel(), 2e-3)
+    assert n_sub <= 5e-2 * clear.numel() and n_diff <= 2e-3 * clear.numel()
     if B <= 8:   # exact ties (duplicated point 7/100): the lower index must win, as torch.max does
         tie = (am == 100)
         assert not tie.any()
@@ -213,8 +229,12 @@ def test_pointnet_forward_backward(B, C, max_mean, sub_mean, proprio, P):
     for k, v in ac.actor.named_parameters():
         views["actor." + k] = f["grad_actor"][off:off + v.numel()].view(v.shape)
         off += v.numel()
+    worst = 0.0
     for k, gr in zip(names, grads_ref):
-        assert rel_err(views[k], gr) < 1e-4, k
+        e = rel_err(views[k], gr)
+        worst = max(worst, e)
+        assert e < 1e-4, k
+    record_margin("encoder parameter gradients (max abs / max|ref|)", worst, 1e-4)
 
 
 def test_pointnet_full_batch_properties():
@@ -239,6 +259,45 @@ def test_pointnet_full_batch_properties():
     # equal unless two different points tie EXACTLY for a channel's max (then each ordering keeps its lowest index)
     assert float((perm[a2.long()] != a1.long()).float().mean()) < 2e-3
     assert torch.isfinite(f1).all()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
+def test_pointnet_nan_point_poisons_its_cloud_like_torch(precision):
+    """A NaN coordinate: torch.tanh propagates it through the shared MLP, `x.max(dim=1)` and `x.mean(dim=1)` return NaN for
+    every channel of THAT cloud (network.py:175-181) -- the packed tanh of the fused encoders used to clamp it to -1 and the
+    pooling's strict `>` skipped it.  The other clouds of the batch must not change by a bit."""
+    from partmanip_amd.algo_utils import ActorCritic
+    net = dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False, precision=precision)
+    torch.manual_seed(3)
+    ac = ActorCritic(3072, 10, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net)).to(DEV)
+    ac.flat()
+    g = torch.Generator().manual_seed(9)
+    x = (torch.rand(6, 1024, 3, generator=g) * 2 - 1)
+    clean = ac.actor.hip_forward(x.reshape(6, -1).to(DEV)).clone()
+    feat_clean = ac.actor._saved[1].clone()
+    x[2, 517, 1] = float("nan")
+    x[4, 1023, 0] = float("nan")
+    out = ac.actor.hip_forward(x.reshape(6, -1).to(DEV))
+    feat = ac.actor._saved[1]
+    p = {k: v.detach().cpu() for k, v in ac.state_dict().items()}
+    ref = R.pointnet_forward(p, "actor", dict(net, precision="f32"), x.reshape(6, -1), 0)
+    for b in range(6):
+        if b in (2, 4):
+            assert torch.isnan(feat[b]).all() and torch.isnan(out[b]).all() and torch.isnan(ref[b]).all(), b
+        else:
+            assert torch.equal(feat[b], feat_clean[b]) and torch.equal(out[b], clean[b]) and torch.isfinite(ref[b]).all(), b
+
+
+def test_mlp_nan_observation_propagates_like_torch():
+    from partmanip_amd.algo_utils import ActorCritic
+    net = dict(name="MLP", hid_dim=[64, 64], activation="tanh")
+    torch.manual_seed(4)
+    ac = ActorCritic(20, 5, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net)).to(DEV)
+    ac.flat()
+    x = torch.randn(300, 20)
+    x[7, 3] = float("nan")
+    out = ac.actor.hip_forward(x.to(DEV)).cpu()
+    assert torch.isnan(out[7]).all() and torch.isfinite(out[torch.arange(300) != 7]).all()
 
 
 # ------------------------------------------------------------------------------- DAgger vs golden
@@ -272,12 +331,12 @@ def test_dagger_update_matches_reference(name, tmp_path, monkeypatch):
         run.storage.add_transitions_dagger(t(raw["stu"][k]).to(DEV), t(raw["tea"][k]).to(DEV))
     assert (run.storage.mix_buf_ind, run.storage.cur_buf_size) == (int(fx["mix_buf_ind"]), int(fx["cur_buf_size"]))
     assert np.array_equal(run.storage.tea_obs.cpu().numpy(), fx["ring_tea"])
-    np.testing.assert_allclose(run.teacher.act(run.storage.tea_obs).cpu().numpy(), fx["tea_act"], rtol=2e-5, atol=3e-6)
-    np.testing.assert_allclose(run.student.act(run.storage.observations).cpu().numpy(), fx["stu_act0"], rtol=2e-5, atol=3e-6)
+    np.testing.assert_allclose(run.teacher.act(run.storage.tea_obs).cpu().numpy(), fx["tea_act"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(run.student.act(run.storage.observations).cpu().numpy(), fx["stu_act0"], rtol=2e-5, atol=2e-6)
     torch.manual_seed(c["torch_seed"])
     run.log_dict = {}
     run.update(c["it"])
-    np.testing.assert_allclose(run.log_dict["Train/dagger_loss"], float(fx["log_dagger_loss"]), rtol=5e-4)
+    np.testing.assert_allclose(run.log_dict["Train/dagger_loss"], float(fx["log_dagger_loss"]), rtol=1e-5)
     np.testing.assert_allclose(run.log_dict["Train/learning_rate"], float(fx["log_learning_rate"]), rtol=1e-12)
     fin = flat_state(run.student.state_dict())
     check_params(fin, fx["final_flat"], int(fx["final_stride"]), c["lr"], len(fx["loss_trace"]),
@@ -311,7 +370,7 @@ def test_bc_run_matches_reference(tmp_path):
     run.student.load_state_dict({k: t(v.copy()) for k, v in sd.items()})
     torch.manual_seed(c["torch_seed"])
     run.run()
-    np.testing.assert_allclose([x[0] for x in trace], fx["loss_trace"], rtol=2e-5)
+    np.testing.assert_allclose([x[0] for x in trace], fx["loss_trace"], rtol=2e-6)
     np.testing.assert_allclose([x[1] for x in trace], fx["lr_trace"], rtol=1e-12)
     n_steps = c["max_iterations"] * 5
     check_params(flat_state(run.student.state_dict()), fx["final_flat"], 1, c["lr"], n_steps)
@@ -520,7 +579,7 @@ def test_ppo_update_pointnet2_follows_the_cpu_restatement(sampler):
     out = R.ppo_update(p, {k: st[k] for k in keys}, ppo_cfg(c), c["it"])
     assert run.log_dict["Train/kl_update_count"] == out["log"]["Train/kl_update_count"]
     for k in ("value_function_loss", "surrogate_loss", "kl", "kl_max"):
-        np.testing.assert_allclose(float(run.log_dict["Train/" + k]), float(out["log"]["Train/" + k]), rtol=5e-4,
+        np.testing.assert_allclose(float(run.log_dict["Train/" + k]), float(out["log"]["Train/" + k]), rtol=1e-5,
                                    atol=5e-6, err_msg=k)
     check_params(flat_state(run.actor_critic.state_dict()), flat_state(p), 1, c["lr"], len(out["loss_trace"]))
 
@@ -610,7 +669,7 @@ def test_ppo_update_bf16x3_forward_within_reference_tolerances(name):
     log = run.log_dict
     assert log["Train/kl_update_count"] == int(fx["log_kl_update_count"])
     for k in ("value_function_loss", "surrogate_loss", "kl", "kl_max"):
-        np.testing.assert_allclose(float(log["Train/" + k]), float(fx["log_" + k]), rtol=5e-4, atol=5e-6, err_msg=k)
+        np.testing.assert_allclose(float(log["Train/" + k]), float(fx["log_" + k]), rtol=2e-4, atol=2e-6, err_msg=k)
     check_params(flat_state(run.actor_critic.state_dict()), fx["final_flat"], int(fx["final_stride"]), c["lr"],
                  len(fx["loss_trace"]))
 
@@ -671,7 +730,7 @@ def test_ppo_update_bf16x6_forward_within_reference_tolerances(name):
     log = run.log_dict
     assert log["Train/kl_update_count"] == int(fx["log_kl_update_count"])
     for k in ("value_function_loss", "surrogate_loss", "kl", "kl_max"):
-        np.testing.assert_allclose(float(log["Train/" + k]), float(fx["log_" + k]), rtol=5e-4, atol=5e-6, err_msg=k)
+        np.testing.assert_allclose(float(log["Train/" + k]), float(fx["log_" + k]), rtol=5e-5, atol=5e-7, err_msg=k)
     check_params(flat_state(run.actor_critic.state_dict()), fx["final_flat"], int(fx["final_stride"]), c["lr"],
                  len(fx["loss_trace"]))
 
@@ -690,10 +749,10 @@ def test_rollout_side_matches_reference():
         out = norm(t(x).to(DEV))
         st = np.stack([norm.running_ms.mean.cpu().numpy()[0], norm.running_ms.std.cpu().numpy()[0],
                        norm.running_ms.S.cpu().numpy()[0]])
-        np.testing.assert_allclose(st, fx["norm_stats"][i], rtol=2e-6, atol=1e-6)
-        np.testing.assert_allclose(out.cpu().numpy(), fx["norm_out"][i], rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(st, fx["norm_stats"][i], rtol=2e-6, atol=5e-7)
+        np.testing.assert_allclose(out.cpu().numpy(), fx["norm_out"][i], rtol=5e-6, atol=2e-6)
     assert norm.running_ms.n == int(fx["n"]) and tuple(norm.running_ms.mean.shape) == (1, c["O"])
-    np.testing.assert_allclose(norm(t(xs[2]).to(DEV), update=False).cpu().numpy(), fx["norm_frozen"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(norm(t(xs[2]).to(DEV), update=False).cpu().numpy(), fx["norm_frozen"], rtol=2e-6, atol=5e-7)
     assert norm.running_ms.n == int(fx["n"])                       # update=False leaves the statistics alone
     # save() / load() round trip keeps the kernels usable (RMS.py:20-34)
     norm2 = Normalization(c["O"], DEV)
@@ -713,10 +772,10 @@ def test_rollout_side_matches_reference():
         act_only = ac.random_act(t(obs).to(DEV))
     finally:
         torch.normal = real_normal
-    np.testing.assert_allclose(mu.cpu().numpy(), fx["mu"], rtol=2e-5, atol=3e-6)
-    np.testing.assert_allclose(val.cpu().numpy(), fx["value"], rtol=2e-5, atol=3e-6)
-    np.testing.assert_allclose(act.cpu().numpy(), fx["actions"], rtol=2e-5, atol=5e-6)
-    np.testing.assert_allclose(logp.cpu().numpy(), fx["logp"], rtol=3e-5, atol=3e-4)
+    np.testing.assert_allclose(mu.cpu().numpy(), fx["mu"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(val.cpu().numpy(), fx["value"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(act.cpu().numpy(), fx["actions"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(logp.cpu().numpy(), fx["logp"], rtol=2e-6, atol=1e-5)
     assert np.array_equal(ls.cpu().numpy(), fx["log_std_rows"])
     assert torch.equal(act_only, act)
 
@@ -732,6 +791,6 @@ def test_rms_kernels_against_restatement(N, D):
         x = torch.randn(N, D, generator=g) * (0.5 + i) + 3.0 * i + torch.linspace(-5, 5, D)
         out = norm(x.to(DEV))
         want = ref.normalize(x)
-        np.testing.assert_allclose(norm.running_ms.mean.cpu().numpy(), ref.mean.numpy(), rtol=3e-6, atol=3e-6)
-        np.testing.assert_allclose(norm.running_ms.S.cpu().numpy(), ref.S.numpy(), rtol=2e-5, atol=1e-6)
-        np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=3e-5, atol=3e-5)
+        np.testing.assert_allclose(norm.running_ms.mean.cpu().numpy(), ref.mean.numpy(), rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(norm.running_ms.S.cpu().numpy(), ref.S.numpy(), rtol=5e-6, atol=2e-7)
+        np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)

@@ -62,7 +62,7 @@ def test_forward_and_parameter_gradients_match_the_restatement(proprio, dups, NE
     p = {k: torch.from_numpy(v.copy()).double().requires_grad_(True) for k, v in sd.items()}
     ref = R.sparse_unet_forward(p, "actor", NET, t(x).double(), proprio)
     (ref * t(w).double()).sum().backward()
-    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-7)
     for name, par in ac.actor.named_parameters():
         gr = p["actor." + name].grad
         err = float((par.grad.double().cpu() - gr).abs().max() / (gr.abs().max() + 1e-30))
@@ -105,7 +105,7 @@ def test_dagger_update_with_sparse_unet_student_matches_the_restatement(tmp_path
                 lr_schedule="fixed", max_iterations=100, proprio_shape=0)
     ref = R.dagger_update(stu, {k: t(v.copy()) for k, v in tsd.items()}, t(np.concatenate(obs)), t(np.concatenate(tob)), N * n_fill,
                           ocfg, 1)
-    np.testing.assert_allclose(run.log_dict["Train/dagger_loss"], ref["log"]["Train/dagger_loss"], rtol=5e-4)
+    np.testing.assert_allclose(run.log_dict["Train/dagger_loss"], ref["log"]["Train/dagger_loss"], rtol=1e-5)
     assert_update_matches(flat_state(run.student.state_dict()), flat_state(stu), init, lr, len(ref["loss_trace"]))
 
 
@@ -129,3 +129,228 @@ def test_fused_and_materialised_gathers_agree_bit_for_bit():
     assert torch.equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1], res[1][1]):
         assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+
+
+# =========================================================================================================== cfg 5 at its own size
+# BASELINE.json configs[4] as `bench.py --workload dagger --student sparse_unet` runs it: 4096-voxel clouds on a 50^3 grid, the
+# backbone's default channels (32, 64, 128).  256 clouds are 1.05 M / ~0.34 M / ~0.08 M level rows: the 128 x 64 / 32 x 128 tile
+# instantiations, multi-slab split-K weight gradients and row * 27 * C index products that the 96-voxel cases above never reach.
+NET_FULL = dict(name="SparseUNet", activation="tanh", point_num=4096, grid=50)
+
+
+def _full_size_clouds(B, seed):
+    """The feeder's 'depth_sparse' rows (a two-voxel band around a tilted plane, distinct cells) + what `TSDFVolume.sparse_voxel`
+    does to short clouds: a few clouds end in padding rows of voxel (0, 0, 0) (utils/depth2tsdf.py:116-119), one repeats voxels."""
+    from partmanip_amd.feeder import FeederEnv
+    P = NET_FULL["point_num"]
+    env = FeederEnv(B, {"depth_sparse": 4 * P}, 10, DEV, seed=seed, point_num=P)
+    x = env.reset()["depth_sparse"].view(B, P, 4).clone()
+    for b, pad in ((1, 37), (B // 2, 900), (B - 1, 5)):
+        x[b, P - pad:, :3] = 0.0
+        x[b, P - pad:, 3] = 0.125
+    x[2, 3000:] = x[2, :P - 3000]                               # duplicates of earlier voxels: resolve to the lowest row
+    return x.reshape(B, 4 * P).contiguous()
+
+
+def test_full_size_geometry_tables_equal_the_restatement():
+    """Whole-batch tables (256 clouds) against the numpy restatement on the first four and the last four clouds (rows are
+    numbered cloud by cloud, so the last clouds' tables are the restatement's plus the rows in front of them)."""
+    from partmanip_amd.algo_utils import ActorCritic
+    B, P, Rg = 256, NET_FULL["point_num"], NET_FULL["grid"]
+    x = _full_size_clouds(B, 770)
+    ac = ActorCritic(4 * P, 10, _model(NET_FULL)).to(DEV)
+    g = ac.actor.geometry(x)
+    R0, R1, R2 = g["rows"]
+    assert R0 == B * P and 0 < R2 < R1 < R0
+    cl1, cl2 = g["l1"]["coords"][:, 0].cpu().numpy(), g["l2"]["coords"][:, 0].cpu().numpy()       # cloud of every coarse row
+    assert np.all(np.diff(cl1) >= 0) and np.all(np.diff(cl2) >= 0)
+    for lo in (0, B - 4):
+        ref = R.sparse_unet_geometry(x[lo:lo + 4].cpu().numpy(), P, 4, Rg)
+        b0, b1, b2 = lo * P, int((cl1 < lo).sum()), int((cl2 < lo).sum())
+        n0, n1, n2 = ref["rows"]
+        assert n1 == int(((cl1 >= lo) & (cl1 < lo + 4)).sum()) and n2 == int(((cl2 >= lo) & (cl2 < lo + 4)).sum())
+        sh = lambda tab, base: np.where(tab >= 0, tab + base, -1)                # restatement numbering -> whole-batch numbering
+        np.testing.assert_array_equal(g["feat0"][b0:b0 + n0].cpu().numpy(), ref["feat0"])
+        np.testing.assert_array_equal(g["nbr0"][b0:b0 + n0].cpu().numpy(), sh(ref["nbr0"], b0))
+        np.testing.assert_array_equal(g["nbr1"][b1:b1 + n1].cpu().numpy(), sh(ref["nbr1"], b1))
+        np.testing.assert_array_equal(g["nbr2"][b2:b2 + n2].cpu().numpy(), sh(ref["nbr2"], b2))
+        for lv, (fb, fn, cb, cn) in (("l1", (b0, n0, b1, n1)), ("l2", (b1, n1, b2, n2))):
+            got, want = g[lv], ref[lv]
+            np.testing.assert_array_equal(got["child"].cpu().numpy().reshape(-1, 8)[cb:cb + cn], sh(want["child"], fb), err_msg=lv)
+            np.testing.assert_array_equal(got["parent"].cpu().numpy().reshape(-1)[fb:fb + fn], sh(want["parent"], cb), err_msg=lv)
+            np.testing.assert_array_equal(got["parent_canon"].cpu().numpy().reshape(-1)[fb:fb + fn], sh(want["parent_canon"], cb), err_msg=lv)
+            np.testing.assert_array_equal(got["slot"].cpu().numpy().reshape(-1)[fb:fb + fn], want["slot"], err_msg=lv)
+            np.testing.assert_array_equal(got["coords"][cb:cb + cn, 1:].cpu().numpy(), np.concatenate(want["coords"]))
+
+
+def test_full_size_forward_and_gradients_fused_vs_materialised_and_vs_restatement():
+    """256 clouds x 4096 voxels through the cfg 5 network: (a) gathers fused into the GEMM loaders vs materialised operands on the
+    WHOLE batch -- outputs bit for bit, parameter gradients to 1e-6; (b) four clouds spread over the batch (first, two inner,
+    last) against the restatement in fp64: outputs, and parameter gradients of a loss that weighs only those clouds (their rows
+    sit at the start, inside and at the end of every level's row range); everything finite."""
+    from partmanip_amd.algo_utils import ActorCritic
+    from partmanip_amd.autograd import backbone_apply
+    from tests.helpers import record_margin
+    B, P, A = 256, NET_FULL["point_num"], 10
+    pick = [0, 85, 170, B - 1]
+    sd = cases.actor_critic_state(NET_FULL, 4 * P, A, 0.5, 47)
+    x = _full_size_clouds(B, 771)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    w_all = torch.randn(B, A, device=DEV, generator=gen)
+    w_pick = torch.zeros(B, A, device=DEV)
+    w_pick[pick] = w_all[pick]
+    res = {}
+    for fused in (True, False):
+        ac = ActorCritic(4 * P, A, _model(dict(NET_FULL, fused_gather=fused))).to(DEV)
+        ac.load_state_dict({k: t(v.copy()) for k, v in sd.items()})
+        ac.flat()
+        out = backbone_apply(ac.actor, x)
+        (out * w_all).sum().backward()
+        res[fused] = (out.detach().clone(), {n: p.grad.clone() for n, p in ac.actor.named_parameters()})
+        if fused:
+            for p in ac.actor.parameters():
+                p.grad = None
+            out2 = backbone_apply(ac.actor, x)
+            (out2 * w_pick).sum().backward()
+            g_pick = {n: p.grad.clone() for n, p in ac.actor.named_parameters()}
+            assert torch.equal(out2.detach(), out.detach())
+        del ac
+    assert torch.isfinite(res[True][0]).all() and all(torch.isfinite(v).all() for v in res[True][1].values())
+    assert torch.equal(res[True][0], res[False][0])
+    worst = 0.0
+    for n in res[True][1]:
+        a, b = res[True][1][n], res[False][1][n]
+        e = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+        worst = max(worst, e)
+        assert e <= 1e-6, (n, e)
+    record_margin("full size: fused vs materialised parameter gradients (max abs / max(1, max|ref|))", worst, 1e-6)
+    # ---- the four picked clouds on the restatement (fp64)
+    xs = x[pick].cpu()
+    p = {k: torch.from_numpy(v.copy()).double().requires_grad_(True) for k, v in sd.items()}
+    ref = R.sparse_unet_forward(p, "actor", NET_FULL, xs.double(), 0)
+    (ref * w_all[pick].cpu().double()).sum().backward()
+    got = res[True][0][pick].cpu().numpy()
+    err_o = float(np.abs(got - ref.detach().numpy()).max() / (np.abs(ref.detach().numpy()).max() + 1e-30))
+    record_margin("full size: outputs vs restatement (max abs / max|ref|)", err_o, 2e-5)
+    np.testing.assert_allclose(got, ref.detach().numpy(), rtol=2e-6, atol=2e-7)
+    worst = 0.0
+    for n, gr in g_pick.items():
+        r = p["actor." + n].grad
+        e = float((gr.double().cpu() - r).abs().max() / (r.abs().max() + 1e-30))
+        worst = max(worst, e)
+        assert e < 2e-4, (n, e)
+    record_margin("full size: parameter gradients vs restatement (max abs / max|ref|)", worst, 2e-4)
+
+
+# =========================================================================================================== cfg 5's three ingredients together
+_MIX = dict(N=8, P=96, grid=14, A=6, O_t=20, buf=6, n_steps_online=4, n_minibatches=3, n_updates=2, lr=1e-3, seed=913,
+            net=dict(NET), tnet=dict(name="MLP", hid_dim=[32, 32], activation="tanh"))
+
+
+def _mix_offline_rows(scene):
+    """Eight offline shards of one scene: `tsdf` holds the student's 'depth_sparse' rows (storage.py:58-82 flattens it)."""
+    c = _MIX
+    return (cases.sparse_clouds(8, c["P"], c["grid"], 300 + scene, n_distinct=70, pad_tail=4),
+            np.random.default_rng(400 + scene).standard_normal((8, c["O_t"])).astype(np.float32))
+
+
+def _mix_write_offline(folder, scenes):
+    import os
+    for k, sc in enumerate(scenes):
+        d = os.path.join(folder, f"scene_{str(k).zfill(5)}")
+        os.makedirs(d, exist_ok=True)
+        stu, tea = _mix_offline_rows(sc)
+        for s in range(8):
+            np.save(os.path.join(d, f"step_{str(s).zfill(5)}.npy"), dict(tsdf=stu[s].reshape(_MIX["P"], 4), proprio_state=np.zeros(0, np.float32),
+                                                                         tea_obs=tea[s]), allow_pickle=True)
+
+
+def _mix_online(step):
+    c = _MIX
+    return (cases.sparse_clouds(c["N"], c["P"], c["grid"], 500 + step, n_distinct=80, pad_tail=2),
+            np.random.default_rng(600 + step).standard_normal((c["N"], c["O_t"])).astype(np.float32))
+
+
+def _mix_run(lo, hi, scenes, teacher, work):
+    """`dagger` with a SparseUNet student: preload `scenes` (add_transitions_offline), append the env shard [lo, hi) of four
+    on-policy steps, one `update`."""
+    import os
+    from partmanip_amd.algorithms import dagger
+    c = _MIX
+    n = hi - lo
+    off = os.path.join(work, f"offline_{lo}_{hi}")
+    _mix_write_offline(off, scenes)
+    cfg = dict(num_envs=n, obs_mode="depth_sparse", model=_model(c["net"], 0.1), max_iterations=100, n_steps=1, n_updates=c["n_updates"],
+               n_minibatches=c["n_minibatches"], device=DEV, buf_size=c["buf"], reward_reset=False, add_proprio_obs=False,
+               offline_data_pth=off, eval_round=1, eval_frequence=10 ** 9, save_frequence=10 ** 9, test_only=False, save_pose=False,
+               save_video=False, lr_schedule="fixed", lr=c["lr"], teacher=teacher, resume=None, pretrain=None, sampler="sequential")
+    env = FakeEnv(n, {"depth_sparse": 4 * c["P"], "normal_state": c["O_t"], "proprio_state": 0}, c["A"])
+    run = dagger(env, cfg, FakeLogger(work))
+    run.student.load_state_dict({k: t(v.copy()) for k, v in cases.actor_critic_state(c["net"], 4 * c["P"], c["A"], 0.1, c["seed"]).items()})
+    run.storage.add_transitions_offline(run.offline_data_pth, run.device, run.add_proprio_obs)               # dagger.py:186-187
+    for s in range(c["n_steps_online"]):
+        stu, tea = _mix_online(s)
+        run.storage.add_transitions_dagger(t(stu[lo:hi]).to(DEV), t(tea[lo:hi]).to(DEV))
+    run.log_dict = {}
+    run.update(1)
+    torch.cuda.synchronize()
+    return run
+
+
+def _mix_rank(rank, world, port, teacher, out_dir):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from partmanip_amd import dist as pdist
+    pdist.init_from_env("gloo")
+    lo, hi = pdist.shard_envs(_MIX["N"], rank, world)
+    run = _mix_run(lo, hi, [rank], teacher, out_dir)                     # rank r preloads scene r: its half of the offline rows
+    assert run.sync is not None and run.sync.world == world
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), flat_state(run.student.state_dict()))
+    np.save(os.path.join(out_dir, f"l{rank}.npy"), np.array([run.log_dict["Train/dagger_loss"]]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_sparse_unet_student_mixed_offline_and_on_policy_ring_two_ranks(tmp_path, monkeypatch):
+    """BASELINE cfg 5's three ingredients in ONE `dagger.update`: SparseUNet student + a ring that holds offline (BC) rows in
+    front of on-policy rows (storage.py:58-91, dagger.py:186-187) + data parallelism (two ranks sharing the GPU over gloo, each
+    with its env shard and its half of the offline scenes).  With the sequential sampler mini-batch k of the two ranks together
+    is mini-batch k of one process that owns everything, so three results must agree: the two ranks (bit for bit with each
+    other), the single HIP process, and the CPU restatement `dagger_update` on the single process's ring."""
+    import torch.multiprocessing as mp
+    from partmanip_amd.algorithms import ppo
+    from tests.test_gpu_dp import _free_port
+    c = _MIX
+    monkeypatch.chdir(tmp_path)
+    tc = dict(net=c["tnet"], N=c["N"], T=1, n_updates=1, n_minibatches=1, tricks=dict(cases.TRICKS_DEFAULT), sampler="sequential",
+              succ_value=None, lr=1e-3, desired_kl=0.1, lr_schedule="fixed", gamma=0.99, lam=0.95, epsilon_clip=0.2, action_std=0.5,
+              max_iterations=10)
+    tea = ppo(FakeEnv(c["N"], {"normal_state": c["O_t"]}, c["A"]), ppo_cfg(tc, device=DEV), FakeLogger(str(tmp_path)))
+    tsd = cases.actor_critic_state(c["tnet"], c["O_t"], c["A"], 0.5, c["seed"] + 1)
+    tea.actor_critic.load_state_dict({k: t(v.copy()) for k, v in tsd.items()})
+    tea.save(1)
+    teacher = str(tmp_path / "model_1.pth")
+    mp.spawn(_mix_rank, args=(2, _free_port(), teacher, str(tmp_path)), nprocs=2, join=True)
+    run = _mix_run(0, c["N"], [0, 1], teacher, str(tmp_path))
+    st = run.storage
+    assert st.cur_buf_size == 16 + c["n_steps_online"] * c["N"] == c["buf"] * c["N"] and st.last_episode_buf_ind == 16
+    single = flat_state(run.student.state_dict())
+    r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
+    assert np.array_equal(r0, r1), "ranks diverged"
+    for k in (0, 1):
+        np.testing.assert_allclose(np.load(tmp_path / f"l{k}.npy")[0], run.log_dict["Train/dagger_loss"], rtol=2e-6)
+    from tests.helpers import assert_flat_params_close
+    assert_flat_params_close("SparseUNet dagger: two ranks vs one process", r0, single, c["lr"], 6)
+    # ---- the restatement on the single process's ring
+    init = cases.actor_critic_state(c["net"], 4 * c["P"], c["A"], 0.1, c["seed"])
+    stu = {k: t(v.copy()) for k, v in init.items()}
+    ocfg = dict(model=_model(c["net"], 0.1), tea_model=_model(c["tnet"]), n_updates=c["n_updates"], n_minibatches=c["n_minibatches"],
+                sampler="sequential", lr=c["lr"], lr_schedule="fixed", max_iterations=100, proprio_shape=0)
+    ring_obs = st.observations.view(-1, 4 * c["P"]).cpu()
+    want0 = np.concatenate([_mix_offline_rows(0)[0], _mix_offline_rows(1)[0]])
+    assert np.array_equal(ring_obs[:16].numpy(), want0)                       # the BC half of the ring, in (scene, step) order
+    ref = R.dagger_update(stu, {k: t(v.copy()) for k, v in tsd.items()}, ring_obs, st.tea_obs.view(-1, c["O_t"]).cpu(), st.cur_buf_size,
+                          ocfg, 1)
+    np.testing.assert_allclose(run.log_dict["Train/dagger_loss"], ref["log"]["Train/dagger_loss"], rtol=1e-5)
+    assert_update_matches(single, flat_state(stu), init, c["lr"], len(ref["loss_trace"]))
+    assert_update_matches(r0, flat_state(stu), init, c["lr"], len(ref["loss_trace"]))

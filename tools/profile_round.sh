@@ -13,7 +13,7 @@ prof() {   # name, bench args...
   cp $out/$name/p_kernel_stats.csv $out/${name}_kernel_stats.csv
   rm -rf $out/$name
 }
-prof bench_default --no-optional --steps 2 --warmup 1
+prof bench_default --no-optional --no-secondary --steps 2 --warmup 1
 prof bench_state --workload state --steps 2 --warmup 1 --no-cpu-baseline
 prof bench_dagger_sparse_unet --workload dagger --student sparse_unet --steps 1 --warmup 1 --no-cpu-baseline
 prof bench_vision_pn2 --workload vision_pn2 --steps 1 --warmup 1 --no-cpu-baseline
