@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 132 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 133 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -274,8 +274,20 @@ typedef struct pm_clip_adam_desc {
     float* gnorm_out; void* workspace;
     /* optional (stats_acc != NULL): pm_ppo_accumulate_stats_f32(stats_acc, stats_scal, stats_which) folded into the norm pass */
     float* stats_acc; const float* stats_scal; int stats_which;
+    /* data-parallel step (new: the reference has no collective): `grads` and the step's scalars arrive as the
+     * all-reduce SUM over W ranks.  The form is on when dp_scal != NULL or grad_scale is neither 0 nor 1; it requires n_extra == 0
+     * (fold the slabs with pm_grad_slab_sum_f32 BEFORE the reduce).  grad_scale = 1/W: the norm pass first rewrites grads[0..n) *= grad_scale
+     * (mean gradient; clip + Adam then see exactly what a single process with the W-fold mini-batch computes).  dp_scal
+     * (NULL = off): the step's scalar record {loss, kl, skip}: [0], [1] *= grad_scale, and when dp_kl_desired > 0 the KL
+     * early-stop predicate of ppo.py:337-338 is re-taken from the REDUCED kl ([2] = kl > dp_kl_desired) before skip_flag /
+     * stats are read -- every rank takes the same branch without a host round trip or an extra launch. */
+    float grad_scale; float dp_kl_desired; float* dp_scal;
 } pm_clip_adam_desc;
 int pm_clip_adam_group_f32(int n, const pm_clip_adam_desc* d, void* stream);
+/* grads[i] += sum_{s=1..n_extra} extra[(s-1) * extra_stride + i] for i < n_sum, in the order pm_clip_adam_group_f32's norm
+ * pass uses (bit-identical): the split-K slabs of pm_linear_bwd_weight_group_f32 folded BEFORE a gradient all-reduce, so
+ * that the message is one slab and not n_extra + 1. */
+int pm_grad_slab_sum_f32(float* grads, const float* extra, long extra_stride, long n_sum, int n_extra, void* stream);
 int pm_clip_adam_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
                           long n_clip, float max_norm, double lr, double b1, double b2, double eps,
                           int32_t* state, const float* skip_flag, float* gnorm_out, void* workspace,

@@ -29,6 +29,7 @@ SIGNATURES = {
     "pm_linear_bwd_data_group_f32": (I, [I, P, P]),
     "pm_linear_bwd_weight_group_f32": (I, [I, P, I, P]),
     "pm_clip_adam_group_f32": (I, [I, P, P]),
+    "pm_grad_slab_sum_f32": (I, [P, P, L, L, I, P]),
     "pm_pointnet_packed_elems": (Z, []),
     "pm_pointnet_pack_weights_f32": (I, [P, P, P, P]),
     "pm_pointnet_enc_fwd_f32": (I, [P, L, I, I, I, I, P, P, P, P, P, I, P, L, P, P, P]),
@@ -125,7 +126,7 @@ class ClipAdamDesc(C.Structure):
     _fields_ = [("params", P), ("grads", P), ("exp_avg", P), ("exp_avg_sq", P), ("n", L), ("n_clip", L), ("extra", P),
                 ("extra_stride", L), ("n_sum", L), ("n_extra", I), ("max_norm", F), ("lr", D), ("b1", D), ("b2", D),
                 ("eps", D), ("state", P), ("skip_flag", P), ("gnorm_out", P), ("workspace", P), ("stats_acc", P), ("stats_scal", P),
-                ("stats_which", I)]
+                ("stats_which", I), ("grad_scale", F), ("dp_kl_desired", F), ("dp_scal", P)]
 
 
 if not os.path.exists(LIB_PATH):
@@ -139,7 +140,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 132                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 133                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -51,14 +51,17 @@ class FusedAdam:
         ops.clip_adam_step(self.p[:n], self.g[:n], self.m[:n], self.v[:n], n_clip, max_norm, g0['lr'], g0['betas'][0],
                            g0['betas'][1], g0['eps'], self.state_dev, skip_flag, self.gnorm, self.ws)
 
-    def group_item(self, n=None, n_clip=0, max_norm=0.0, skip_flag=None, extra=None, extra_stride=0, n_sum=0, n_extra=0, stats=None):
+    def group_item(self, n=None, n_clip=0, max_norm=0.0, skip_flag=None, extra=None, extra_stride=0, n_sum=0, n_extra=0, stats=None,
+                   dp=None):
         """The arguments of `step` as one record of ops.clip_adam_group (several optimisers per launch pair; `extra`: the
-        split-K gradient slabs 1.. that the norm pass adds onto g[:n_sum] first)."""
+        split-K gradient slabs 1.. that the norm pass adds onto g[:n_sum] first; `dp` = (1 / world, scalar record or None,
+        desired_kl or 0): the data-parallel form after an all-reduce SUM, pm_clip_adam_desc in include/partmanip_hip.h)."""
         g0 = self.param_groups[0]
         n = self.p.numel() if n is None else n
         return dict(p=self.p[:n], g=self.g[:n], m=self.m[:n], v=self.v[:n], n_clip=n_clip, max_norm=max_norm, lr=g0['lr'],
                     b1=g0['betas'][0], b2=g0['betas'][1], eps=g0['eps'], state=self.state_dev, skip_flag=skip_flag,
-                    gnorm=self.gnorm, ws=self.ws, extra=extra, extra_stride=extra_stride, n_sum=n_sum, n_extra=n_extra, stats=stats)
+                    gnorm=self.gnorm, ws=self.ws, extra=extra, extra_stride=extra_stride, n_sum=n_sum, n_extra=n_extra, stats=stats,
+                    dp=dp)
 
     # ---- torch.optim.Adam-compatible (de)serialisation ---------------------------------------
     def _param_slices(self):

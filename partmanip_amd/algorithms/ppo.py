@@ -110,7 +110,20 @@ class ppo:
         # sampler (slices of persistent storage), a fixed learning rate, no collective inside the chain.
         gr = os.environ.get("PARTMANIP_GRAPHS")
         self.use_graphs = (gr != "0") and is_mlp and self.overlap and cfg['sampler'] == 'sequential' and \
-            self.lr_schedule == 'fixed' and self.sync is None
+            self.lr_schedule == 'fixed'
+        # Under data parallelism a gradient all-reduce sits inside every step.  "capture": RCCL collectives are stream-ordered
+        # device work and are captured INTO the multi-step graphs like any kernel (backend nccl); "split": each step replays as
+        # two graphs with the collective issued between them (any backend -- gloo on the 1-GPU test box).  Steps that need a
+        # further collective BEFORE their loss (mini_adv_norm moments, the clipped value loss's batch-mean width) run eagerly.
+        self.dp_graph_mode = None
+        if self.sync is not None:
+            be = torch.distributed.get_backend()
+            self.dp_graph_mode = os.environ.get("PARTMANIP_DP_GRAPHS") or ("capture" if be == "nccl" else "split")
+            if self.dp_graph_mode not in ("capture", "split") or self.tricks['mini_adv_norm'] or self.tricks['use_clipped_value_loss']:
+                self.use_graphs, self.dp_graph_mode = False, None
+            # actor and critic steps run on two streams: give the critic's all-reduces their own communicator, so that two
+            # concurrently replayed graphs never interleave collectives of ONE communicator in rank-dependent order
+            self.sync_c = pdist.GradSync(group=torch.distributed.new_group()) if self.overlap else self.sync
         self._graphs = {}
         self._obs_pad = None
         self.fused_head = os.environ.get("PARTMANIP_FUSED_HEAD", "1") == "1"
@@ -128,7 +141,7 @@ class ppo:
         # collective in the step): each network keeps its stream, but its four weight gradients are one or two grouped launches
         # whose split-K slabs the grouped optimiser launch sums -- no slab-reduce launches (4 per step, 12 % of the kernel time
         # at cfg 2), no separate norm pass.
-        self.solo_group = is_mlp and self.sync is None and os.environ.get("PARTMANIP_SOLO_GROUP", "1") == "1"
+        self.solo_group = is_mlp and os.environ.get("PARTMANIP_SOLO_GROUP", "1") == "1"
         # neighbourhood tables (FPS centres + ball-query indices) once per rollout; PARTMANIP_GEOM_CACHE=0 recomputes
         # them in every forward (A/B; identical results)
         self.cache_geometry = os.environ.get("PARTMANIP_GEOM_CACHE", "1") != "0"
@@ -253,30 +266,50 @@ class ppo:
             S -= 1
         return S
 
-    def _solo_adam(self, f, which, S):
+    def _solo_adam(self, f, which, S, phase=None):
         """Grouped optimiser launch of one network on its own stream (small-step regime): the norm pass sums the S split-K slabs of
         the weight gradients and carries the step's running sums (one launch less), then clip + Adam.  log_std belongs to the
-        actor's optimiser but is outside the clipped norm (ppo.py:351); the actor's KL predicate is the skip flag (ppo.py:337-338)."""
+        actor's optimiser but is outside the clipped norm (ppo.py:351); the actor's KL predicate is the skip flag (ppo.py:337-338).
+
+        Data parallel (self.sync): the slabs are folded first (one small launch), ONE all-reduce SUM carries the gradient and
+        the step's scalars in its tail, and the optimiser's norm pass turns the sum into the mean, re-takes the KL predicate
+        from the reduced KL and accumulates the reduced scalars (pm_clip_adam_desc.grad_scale / dp_scal): no separate scale /
+        flag / statistics launches.  phase 'pre' / 'post': the part before / after the collective (split graphs)."""
         clip = self.tricks['use_grad_clip']
         mn = self.max_grad_norm if clip else 0.0
+        sync = self.sync if which == 'actor' else getattr(self, 'sync_c', self.sync)
+        n_a, n_c, A = f['n_actor'], f['n_critic'], self.num_actions
+        if sync is not None:
+            if phase in (None, 'pre') and S > 1:
+                ops.grad_slab_sum(f[f'grad_{which}'], f[f'extra_{which}'], f[f'slab_stride_{which}'], n_a if which == 'actor' else n_c, S - 1)
+            if phase is None:
+                sync.sum_(f[f'grad_{which}'])
+            if phase == 'pre':
+                return
+            S, dp = 1, (1.0 / sync.world, f[f'scal_{which}'], self.desired_kl if which == 'actor' else 0.0)
+        else:
+            dp = None
         if which == 'actor':
-            n_a, A, scal = f['n_actor'], self.num_actions, f['scal_actor']
+            scal = f['scal_actor']
             item = self.optimizer_actor.group_item(n=n_a + A, n_clip=n_a if clip else 0, max_norm=mn, skip_flag=scal[2:3],
                                                    extra=f['extra_actor'], extra_stride=f['slab_stride_actor'], n_sum=n_a, n_extra=S - 1,
-                                                   stats=(self._acc, scal, 0))
+                                                   stats=(self._acc, scal, 0), dp=dp)
         else:
-            n_c = f['n_critic']
             item = self.optimizer_critic.group_item(n=n_c, n_clip=n_c if clip else 0, max_norm=mn, extra=f['extra_critic'],
                                                     extra_stride=f['slab_stride_critic'], n_sum=n_c, n_extra=S - 1,
-                                                    stats=(self._acc, f['scal_critic'], 1))
+                                                    stats=(self._acc, f['scal_critic'], 1), dp=dp)
         ops.clip_adam_group([item])
 
-    def _actor_step(self, f, views, indices, stage):
-        """One mini-batch of ppo.py:316-357 (forward, loss fwd+bwd, backward, [all-reduce], clip+Adam)."""
+    def _actor_step(self, f, views, indices, stage, phase=None):
+        """One mini-batch of ppo.py:316-357 (forward, loss fwd+bwd, backward, [all-reduce], clip+Adam).  phase 'pre' / 'post':
+        the part in front of / behind the data-parallel all-reduce (small-step path only: the two halves replay as graphs)."""
         ac, tricks, sync = self.actor_critic, self.tricks, self.sync
         n_a, A = f['n_actor'], self.num_actions
         scal_a = f['scal_actor']
         clip = tricks['use_grad_clip']
+        if phase == 'post':
+            self._solo_adam(f, 'actor', self._slabs(indices[1]), phase='post')
+            return
         mb = self._minibatch(views, indices, ('obs', 'actions', 'old_logp', 'adv', 'old_mu', 'old_sigma'), stage)
         B = mb['obs'].shape[0]
         if self._geom is not None:
@@ -299,7 +332,7 @@ class ppo:
                                    self.epsilon_clip, self.desired_kl, mom, cnt, scal_a, dmu, dh, f['grad_log_std'], self._ws_loss)
                 S = self._slabs(B)
                 chains_backward([chain], [dmu], [f['slab_stride_actor']], S, head_dz=[dh])
-                self._solo_adam(f, 'actor', S)
+                self._solo_adam(f, 'actor', S, phase)
                 return
             mu = torch.empty(B, A, device=h.device)          # (shape outside the fused kernel: finish the forward separately)
             ops.linear_fwd(h, lin.weight.data, lin.bias.data, mu, ops.ACT_NONE)
@@ -312,22 +345,27 @@ class ppo:
         if self.solo_group:
             S = self._slabs(B)
             chains_backward([ac.actor._chain], [dmu], [f['slab_stride_actor']], S)
-            self._solo_adam(f, 'actor', S)
+            self._solo_adam(f, 'actor', S, phase)
             return
+        assert phase is None
         ac.actor.hip_backward(dmu)
-        if sync:                                              # ONE all-reduce: grads + loss/kl in the tail
-            sync.mean_(f['grad_actor'])
-            scal_a[2:3].copy_((scal_a[1:2] > self.desired_kl).float())
+        if sync:                                              # ONE all-reduce: grads + loss/kl in the tail; mean, KL predicate,
+            self._solo_adam(f, 'actor', 1)                    # running sums and clip + Adam in the optimiser launch pair
+            return
         ops.ppo_accumulate_stats(self._acc, scal_a, 0)
         # log_std belongs to this optimiser but is outside the clipped norm (ppo.py:351)
         self.optimizer_actor.step(n=n_a + A, n_clip=n_a if clip else 0,
                                   max_norm=self.max_grad_norm if clip else 0.0, skip_flag=scal_a[2:3])
 
-    def _critic_step(self, f, views, indices, stage):
-        """One mini-batch of ppo.py:360-384."""
-        ac, tricks, sync = self.actor_critic, self.tricks, self.sync
+    def _critic_step(self, f, views, indices, stage, phase=None):
+        """One mini-batch of ppo.py:360-384 (phase: as `_actor_step`)."""
+        ac, tricks = self.actor_critic, self.tricks
+        sync = getattr(self, 'sync_c', self.sync)
         n_c, scal_c = f['n_critic'], f['scal_critic']
         clip = tricks['use_grad_clip']
+        if phase == 'post':
+            self._solo_adam(f, 'critic', self._slabs(indices[1]), phase='post')
+            return
         mb = self._minibatch(views, indices, ('obs', 'returns', 'values'), stage)
         B = mb['obs'].shape[0]
         if self._geom is not None:
@@ -344,7 +382,7 @@ class ppo:
                                tricks['use_clipped_value_loss'], self.epsilon_clip, None, 1.0, scal_c, dv, dh, self._ws_vloss)
                 S = self._slabs(B)
                 chains_backward([cchain], [dv], [f['slab_stride_critic']], S, head_dz=[dh])
-                self._solo_adam(f, 'critic', S)
+                self._solo_adam(f, 'critic', S, phase)
                 return
             value = torch.empty(B, 1, device=h.device)
             ops.linear_fwd(h, lin.weight.data, lin.bias.data, value, ops.ACT_NONE)
@@ -359,11 +397,13 @@ class ppo:
         if self.solo_group:
             S = self._slabs(B)
             chains_backward([ac.critic._chain], [dv], [f['slab_stride_critic']], S)
-            self._solo_adam(f, 'critic', S)
+            self._solo_adam(f, 'critic', S, phase)
             return
+        assert phase is None
         ac.critic.hip_backward(dv)
         if sync:
-            sync.mean_(f['grad_critic'])
+            self._solo_adam(f, 'critic', 1)
+            return
         ops.ppo_accumulate_stats(self._acc, scal_c, 1)
         self.optimizer_critic.step(n=n_c, n_clip=n_c if clip else 0, max_norm=self.max_grad_norm if clip else 0.0)
 
@@ -481,6 +521,16 @@ class ppo:
                         self._replay(graphs, ('p', ia, ic), lambda: self._pair_step(f, views, ia, ic), main)
                     else:
                         self._pair_step(f, views, ia, ic)
+                    continue
+                if graphs is not None and self.dp_graph_mode == "split":
+                    # data parallel, any backend: [graph: forward .. backward .. slab fold] -> all-reduce -> [graph: optimiser]
+                    self._replay(graphs, ('a', ia, 'pre'), lambda: self._actor_step(f, views, ia, self._stage, 'pre'), main)
+                    self.sync.sum_(f['grad_actor'])
+                    self._replay(graphs, ('a', ia, 'post'), lambda: self._actor_step(f, views, ia, self._stage, 'post'), main)
+                    self._replay(graphs, ('c', ic, 'pre'), lambda: self._critic_step(f, views, ic, self._stage_c, 'pre'), side)
+                    with torch.cuda.stream(side):
+                        self.sync_c.sum_(f['grad_critic'])
+                    self._replay(graphs, ('c', ic, 'post'), lambda: self._critic_step(f, views, ic, self._stage_c, 'post'), side)
                     continue
                 if graphs is not None:
                     if self.graph_steps > 1:

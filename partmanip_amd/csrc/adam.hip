@@ -114,6 +114,29 @@ struct AdamGroup {
     pm_clip_adam_desc d[ADAM_GROUP_MAX];
 };
 
+// block 0, thread 0 of the norm pass: the step counter (unless the step is skipped) and the step's running sums
+__device__ __forceinline__ void adam_block0_tail(const pm_clip_adam_desc& d) {
+    // (volatile: in the data-parallel form the flag was just rewritten through d.dp_scal, which may alias it)
+    const bool skip = d.skip_flag && ((const volatile float*)d.skip_flag)[0] != 0.0f;
+    if (!skip) d.state[0] += 1;
+    if (d.stats_acc) {                                     // pm_ppo_accumulate_stats_f32 (losses.hip), same arithmetic
+        float* acc = d.stats_acc;
+        const volatile float* scal = d.stats_scal;
+        if (d.stats_which == 0) {
+            const float loss = scal[0], kl = scal[1], sk = scal[2];
+            if (kl > acc[2]) acc[2] = kl;
+            if (sk == 0.0f) {
+                acc[0] += loss;
+                acc[1] += kl;
+                acc[3] += 1.0f;
+            }
+        } else {
+            acc[4] += scal[0];
+            acc[5] += 1.0f;
+        }
+    }
+}
+
 __global__ __launch_bounds__(ADAM_THREADS) void grad_sumsq_group_kernel(AdamGroup G) {
     __shared__ double red[ADAM_THREADS / 64];
     int k = 0;
@@ -127,6 +150,41 @@ __global__ __launch_bounds__(ADAM_THREADS) void grad_sumsq_group_kernel(AdamGrou
     const long hi = n_clip > n_sum ? n_clip : n_sum;
     float* __restrict__ g = d.grads;
     double s = 0.0;
+    if (d.dp_scal != nullptr || (d.grad_scale != 0.0f && d.grad_scale != 1.0f)) {
+        // data-parallel step: grads hold the all-reduce SUM over the ranks -> the mean, in place, then the plain norm pass
+        // (n_extra == 0 by contract: the slabs were folded before the reduce, pm_grad_slab_sum_f32)
+        const float sc = d.grad_scale != 0.0f ? d.grad_scale : 1.0f;       // (a one-rank group: x 1.0f, exact)
+        const long n = d.n;
+        const bool al4 = ((uintptr_t)g & 15) == 0;
+        const long nv4 = al4 ? (n & ~3L) : 0;
+        for (long i = ((long)b * ADAM_THREADS + threadIdx.x) * 4; i < nv4; i += (long)nb * ADAM_THREADS * 4) {
+            float4 gv = *(const float4*)(g + i);
+            gv.x *= sc; gv.y *= sc; gv.z *= sc; gv.w *= sc;
+            *(float4*)(g + i) = gv;
+            if (i < n_clip) {
+                s += (i + 0 < n_clip ? (double)gv.x * (double)gv.x : 0.0) + (i + 1 < n_clip ? (double)gv.y * (double)gv.y : 0.0) +
+                     (i + 2 < n_clip ? (double)gv.z * (double)gv.z : 0.0) + (i + 3 < n_clip ? (double)gv.w * (double)gv.w : 0.0);
+            }
+        }
+        for (long i = nv4 + (long)b * ADAM_THREADS + threadIdx.x; i < n; i += (long)nb * ADAM_THREADS) {
+            const float gi = g[i] * sc;
+            g[i] = gi;
+            if (i < n_clip) s += (double)gi * (double)gi;
+        }
+        s = block_sum<double, ADAM_THREADS>(s, red);
+        if (threadIdx.x == 0) {
+            ((double*)d.workspace)[b] = s;
+            if (b == 0) {
+                if (d.dp_scal) {                               // the reduced scalars -> means; the KL predicate from the REDUCED kl
+                    d.dp_scal[0] *= sc;
+                    d.dp_scal[1] *= sc;
+                    if (d.dp_kl_desired > 0.0f) d.dp_scal[2] = d.dp_scal[1] > d.dp_kl_desired ? 1.0f : 0.0f;
+                }
+                adam_block0_tail(d);
+            }
+        }
+        return;
+    }
     // 16-byte body (4 elements per thread and trip, the common prefix of the two ranges rounded down), scalar tail
     const bool al = (((uintptr_t)g | (uintptr_t)d.extra) & 15) == 0 && (d.extra_stride & 3) == 0;
     const long lo = n_clip < n_sum ? n_clip : n_sum;
@@ -154,26 +212,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void grad_sumsq_group_kernel(AdamGrou
     s = block_sum<double, ADAM_THREADS>(s, red);
     if (threadIdx.x == 0) {
         ((double*)d.workspace)[b] = s;
-        if (b == 0) {
-            const bool skip = d.skip_flag && d.skip_flag[0] != 0.0f;
-            if (!skip) d.state[0] += 1;
-            if (d.stats_acc) {                             // pm_ppo_accumulate_stats_f32 (losses.hip), same arithmetic
-                float* acc = d.stats_acc;
-                const float* scal = d.stats_scal;
-                if (d.stats_which == 0) {
-                    const float loss = scal[0], kl = scal[1], sk = scal[2];
-                    if (kl > acc[2]) acc[2] = kl;
-                    if (sk == 0.0f) {
-                        acc[0] += loss;
-                        acc[1] += kl;
-                        acc[3] += 1.0f;
-                    }
-                } else {
-                    acc[4] += scal[0];
-                    acc[5] += 1.0f;
-                }
-            }
-        }
+        if (b == 0) adam_block0_tail(d);
     }
 }
 
@@ -246,6 +285,34 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adam_group_kernel(AdamGroup
     }
 }
 
+__global__ __launch_bounds__(ADAM_THREADS) void grad_slab_sum_kernel(float* __restrict__ g, const float* __restrict__ extra,
+                                                                      long extra_stride, long n_sum, int n_extra) {
+    const bool al = (((uintptr_t)g | (uintptr_t)extra) & 15) == 0 && (extra_stride & 3) == 0;
+    const long nv = al ? (n_sum & ~3L) : 0;
+    for (long i = ((long)blockIdx.x * ADAM_THREADS + threadIdx.x) * 4; i < nv; i += (long)gridDim.x * ADAM_THREADS * 4) {
+        float4 gv = *(const float4*)(g + i);
+        for (int z = 0; z < n_extra; ++z) {                // the order of grad_sumsq_group_kernel: slab 0, then 1, 2, ...
+            const float4 e = *(const float4*)(extra + (long)z * extra_stride + i);
+            gv.x += e.x; gv.y += e.y; gv.z += e.z; gv.w += e.w;
+        }
+        *(float4*)(g + i) = gv;
+    }
+    for (long i = nv + (long)blockIdx.x * ADAM_THREADS + threadIdx.x; i < n_sum; i += (long)gridDim.x * ADAM_THREADS) {
+        float gi = g[i];
+        for (int z = 0; z < n_extra; ++z) gi += extra[(long)z * extra_stride + i];
+        g[i] = gi;
+    }
+}
+
+extern "C" int pm_grad_slab_sum_f32(float* grads, const float* extra, long extra_stride, long n_sum, int n_extra, void* stream) {
+    PM_REQUIRE(grads && n_sum >= 0 && n_extra >= 0 && (n_extra == 0 || extra));
+    if (n_sum == 0 || n_extra == 0) return PM_OK;
+    hipLaunchKernelGGL(grad_slab_sum_kernel, dim3(adam_blocks(n_sum)), dim3(ADAM_THREADS), 0, pm_stream(stream), grads, extra,
+                       extra_stride, n_sum, n_extra);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
 extern "C" int pm_clip_adam_group_f32(int n, const pm_clip_adam_desc* d, void* stream) {
     PM_REQUIRE(d && n >= 1 && n <= ADAM_GROUP_MAX);
     AdamGroup G{};
@@ -255,6 +322,8 @@ extern "C" int pm_clip_adam_group_f32(int n, const pm_clip_adam_desc* d, void* s
         const pm_clip_adam_desc& q = d[i];
         PM_REQUIRE(q.params && q.grads && q.exp_avg && q.exp_avg_sq && q.state && q.workspace && q.n > 0 && q.n_clip >= 0 &&
                    q.n_clip <= q.n && q.n_extra >= 0 && (q.n_extra == 0 || (q.extra && q.n_sum >= 0 && q.n_sum <= q.n)));
+        const bool dp = q.dp_scal != nullptr || (q.grad_scale != 0.0f && q.grad_scale != 1.0f);
+        PM_REQUIRE(!dp || q.n_extra == 0);                 // data-parallel form: slabs are folded before the all-reduce
         if (((uintptr_t)q.workspace & 7) != 0) return PM_EALIGN;
         G.d[i] = q;
         G.block0[i] = blocks;

@@ -236,11 +236,21 @@ def clip_adam_group(items):
         d.extra, d.extra_stride, d.n_sum, d.n_extra = _ptr(it.get("extra")), int(it.get("extra_stride", 0)), int(it.get("n_sum", 0)), int(it.get("n_extra", 0))
         d.max_norm, d.lr, d.b1, d.b2, d.eps = float(it["max_norm"]), float(it["lr"]), float(it["b1"]), float(it["b2"]), float(it["eps"])
         d.state, d.skip_flag, d.gnorm_out, d.workspace = _ptr(it["state"]), _ptr(it.get("skip_flag")), _ptr(it.get("gnorm")), base + (-base) % 8
+        dp = it.get("dp")                                  # (1/W, scal or None, desired_kl or 0): data-parallel step, see the header
+        if dp is not None:
+            _req(dp[1])
+            d.grad_scale, d.dp_scal, d.dp_kl_desired = float(dp[0]), _ptr(dp[1]), float(dp[2])
         st = it.get("stats")                               # (acc, scal, which): ppo_accumulate_stats inside the norm pass
         if st is not None:
             _req(st[0], st[1])
             d.stats_acc, d.stats_scal, d.stats_which = _ptr(st[0]), _ptr(st[1]), int(st[2])
     check(lib.pm_clip_adam_group_f32(len(items), arr, _stream()), "pm_clip_adam_group_f32")
+
+
+def grad_slab_sum(g, extra, extra_stride, n_sum, n_extra):
+    """g[:n_sum] += the n_extra split-K slabs (pm_grad_slab_sum_f32): before a gradient all-reduce."""
+    _req(g, extra)
+    check(lib.pm_grad_slab_sum_f32(_ptr(g), _ptr(extra), int(extra_stride), int(n_sum), int(n_extra), _stream()), "pm_grad_slab_sum_f32")
 
 
 # ----------------------------------------------------------------------------- K6/K7

@@ -70,6 +70,100 @@ def test_two_ranks_on_one_gpu_match_single_process(name, tmp_path):
     assert_flat_params_close("two ranks vs one process", r0, single, c["lr"], 16)
 
 
+# ----------------------------------------------------------------------------------------------- small-step fast path under DP
+_BIG = dict(N=128, T=64, O=53, A=10, lr=3e-4, n_mb=4, n_up=5, seed=941, net=dict(name="MLP", hid_dim=[256, 256], activation="tanh"))
+
+
+def _big_problem():
+    """A state-PPO rollout large enough for the small-step machinery to be live on every rank: 64 envs x 64 steps per rank ->
+    1024-row mini-batches (split-K slabs > 1), O = 53 (16-byte padded observation rows), 5 epochs (hipGraph capture in epoch
+    2, replay in 3-5).  Rank r's mini-batch k and the single process's mini-batch k cover the same 16 time steps."""
+    from oracle import ref_cpu as R
+    from tests.golden.detgen import det_normal
+    from tests.test_gpu_fullsize import _cfg, _rollout_from_policy
+    c = _BIG
+    sd = cases.actor_critic_state(c["net"], c["O"], c["A"], 0.5, c["seed"])
+    p = {k: t(v.copy()) for k, v in sd.items()}
+    cfg = _cfg(c["net"], c["N"], c["T"], c["n_mb"], c["n_up"], c["lr"], "cpu")
+    st = _rollout_from_policy(p, cfg["model"], t(det_normal((c["T"], c["N"], c["O"]), c["seed"] + 1)), c["seed"] + 2)
+    return sd, st
+
+
+def _run_big(lo, hi, out_path, expect_mode):
+    from partmanip_amd.algorithms import ppo
+    from tests.test_gpu_fullsize import _cfg
+    c = _BIG
+    sd, st = _big_problem()
+    n = hi - lo
+    with tempfile.TemporaryDirectory() as d:
+        run = ppo(FakeEnv(n, {"normal_state": c["O"]}, c["A"]), _cfg(c["net"], n, c["T"], c["n_mb"], c["n_up"], c["lr"], DEV), FakeLogger(d))
+    run.actor_critic.load_state_dict({k: t(v.copy()) for k, v in sd.items()})
+    assert run.use_graphs and run.solo_group and run.fused_head and run.dp_graph_mode == expect_mode, \
+        (run.use_graphs, run.solo_group, run.fused_head, run.dp_graph_mode)
+    for tt in range(c["T"]):
+        s = lambda k: st[k][tt, lo:hi].to(DEV)
+        run.storage.add_transitions(s("observations"), s("actions"), s("rewards")[:, 0], s("dones")[:, 0], s("succs")[:, 0], s("values"),
+                                    s("actions_log_prob")[:, 0], s("mu"), s("sigma"))
+    run.log_dict = {}
+    run.curr_iter = 1
+    run.learn(st["last_values"][lo:hi].to(DEV))
+    torch.cuda.synchronize()
+    n_graphs = sum(1 for k in run._graphs if isinstance(k, tuple))
+    np.save(out_path, flat_state(run.actor_critic.state_dict()))
+    return run, n_graphs
+
+
+def _rank_big(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from partmanip_amd import dist as pdist
+    pdist.init_from_env("gloo")
+    lo, hi = pdist.shard_envs(_BIG["N"], rank, world)
+    run, n_graphs = _run_big(lo, hi, os.path.join(out_dir, f"r{rank}.npy"), "split")
+    assert run.sync is not None and run.sync.world == world and run.sync_c is not run.sync
+    assert n_graphs == 4 * _BIG["n_mb"], n_graphs               # per mini-batch: {actor, critic} x {before, after the all-reduce}
+    np.save(os.path.join(out_dir, f"log{rank}.npy"), np.array([float(run.log_dict[k]) for k in
+                                                                ("Train/surrogate_loss", "Train/kl", "Train/value_function_loss", "Train/kl_update_count")]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_keep_the_small_step_fast_path(tmp_path):
+    """with a process group the MLP learner used to drop hipGraph replay, the grouped weight-gradient /
+    optimiser launches and the fused heads.  Now each rank keeps all three: the split-K slabs are folded before ONE all-reduce
+    SUM per step, the optimiser's norm pass turns it into the mean and re-takes the KL predicate, and every step replays as
+    [graph] -> all-reduce -> [graph] (gloo here; captured inside the graphs under RCCL).  Two ranks == one process."""
+    c = _BIG
+    mp.spawn(_rank_big, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    run, n_graphs = _run_big(0, c["N"], str(tmp_path / "single.npy"), None)
+    assert n_graphs == 2                                           # one 4-step chunk per network
+    r0, r1, single = (np.load(tmp_path / f) for f in ("r0.npy", "r1.npy", "single.npy"))
+    assert np.array_equal(r0, r1), "ranks diverged"
+    l0, l1 = np.load(tmp_path / "log0.npy"), np.load(tmp_path / "log1.npy")
+    assert np.array_equal(l0, l1) and l0[3] == c["n_up"] * c["n_mb"] == run.log_dict["Train/kl_update_count"]
+    want = [float(run.log_dict[k]) for k in ("Train/surrogate_loss", "Train/kl", "Train/value_function_loss")]
+    np.testing.assert_allclose(l0[:3], want, rtol=2e-4, atol=2e-6)
+    assert_flat_params_close("small-step fast path: two ranks vs one process", r0, single, c["lr"], c["n_up"] * c["n_mb"])
+
+
+def _rank_big_rccl(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", PARTMANIP_FORCE_SYNC="1")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    run, n_graphs = _run_big(0, _BIG["N"], os.path.join(out_dir, "rccl.npy"), "capture")
+    assert n_graphs == 2, n_graphs                                  # the all-reduces are INSIDE the two 4-step graphs
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_all_reduce_captured_inside_the_step_graphs(tmp_path):
+    """Backend nccl (= RCCL): the gradient all-reduces are captured into the multi-step hipGraphs (one RCCL rank is all a
+    1-GPU box can host; the collectives still go through librccl and through graph capture / replay)."""
+    mp.spawn(_rank_big_rccl, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    _run_big(0, _BIG["N"], str(tmp_path / "single.npy"), None)
+    got, single = np.load(tmp_path / "rccl.npy"), np.load(tmp_path / "single.npy")
+    assert np.array_equal(got, single), "a one-rank all-reduce SUM with scale 1.0 must not change a bit"
+
+
 # ----------------------------------------------------------------------------------------------- overlap=True under DP
 def _rank_overlap(rank, world, port, name, out_dir):
     os.environ["PARTMANIP_OVERLAP"] = "1"          # actor and critic steps (and their all-reduces) on two HIP streams
