@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 133 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 134 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -125,6 +125,20 @@ typedef struct pm_linear_bwd_weight_desc {
 int pm_linear_fwd_group_f32(int n, const pm_linear_fwd_desc* d, void* stream);
 int pm_linear_bwd_data_group_f32(int n, const pm_linear_bwd_data_desc* d, void* stream);
 int pm_linear_bwd_weight_group_f32(int n, const pm_linear_bwd_weight_desc* d, int splits, void* stream);
+/* Chains: n (2..4) CONSECUTIVE layers of one network in one launch -- d[i + 1].X must be d[i].Y (forward: network.py:53-54
+ * `self.model(x)`), resp. d[i + 1].dY must be d[i].dX (data gradient, top layer first) -- for the small-step regime, where a
+ * kernel boundary between two 15 us layers costs a third of a layer.  A 64-row stripe of layer l + 1 depends on the same 64
+ * rows of layer l only, so the work-groups of a stripe hand their tiles over inside the launch (write-through stores, one
+ * arrival counter per stripe in `workspace`, bounded spins).  Same arithmetic per layer as the single-problem entry points.
+ * Needs equal layer widths N (a multiple of 64), 16-byte-loadable operands with K % 32 == 0 (the FIRST forward layer may
+ * instead have K <= 64 and unaligned rows: the input layer), and ceil(M / 64) * N / 64 <= 256 work-groups; otherwise returns
+ * PM_EUNSUPPORTED (-4) and the caller issues the layers one by one.  workspace: pm_linear_chain_workspace_bytes(M) bytes,
+ * 8-byte aligned, ZEROED ONCE by the caller and then handed only to chains of the same (M, N, n): the arrival counters in it
+ * are monotonic (no memset per launch, graph-replay safe); its LAST 8-byte word is non-zero once a spin has given up
+ * (results of that launch are invalid). */
+size_t pm_linear_chain_workspace_bytes(int M);
+int pm_linear_fwd_chain_f32(int n, const pm_linear_fwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+int pm_linear_bwd_data_chain_f32(int n, const pm_linear_bwd_data_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ K6/K7  PointNet encoder
  * network.py:147-153,172-181: per-point shared MLP C->128->256->512 (tanh,tanh,none) over

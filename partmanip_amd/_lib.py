@@ -27,6 +27,9 @@ SIGNATURES = {
     "pm_linear_bwd_weight_f32": (I, [P, L, P, L, P, L, P, I, I, I, P, Z, P]),
     "pm_linear_fwd_group_f32": (I, [I, P, P]),
     "pm_linear_bwd_data_group_f32": (I, [I, P, P]),
+    "pm_linear_chain_workspace_bytes": (C.c_size_t, [I]),
+    "pm_linear_fwd_chain_f32": (I, [I, P, P, C.c_size_t, P]),
+    "pm_linear_bwd_data_chain_f32": (I, [I, P, P, C.c_size_t, P]),
     "pm_linear_bwd_weight_group_f32": (I, [I, P, I, P]),
     "pm_clip_adam_group_f32": (I, [I, P, P]),
     "pm_grad_slab_sum_f32": (I, [P, P, L, L, I, P]),
@@ -140,7 +143,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 133                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 134                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

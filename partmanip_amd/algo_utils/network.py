@@ -21,6 +21,13 @@ from .. import ops
 _LINEAR_ACT = {"tanh": ops.ACT_TANH, "relu": ops.ACT_RELU, "crelu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "elu": ops.ACT_ELU,
                "selu": ops.ACT_SELU, "sigmoid": ops.ACT_SIGMOID}
 _SUPPORTED_ACT = {"tanh": ops.ACT_TANH}
+# Consecutive hidden layers of an MLP as ONE launch (csrc/gemm2_f32.hip: gemm2_chain_kernel, stripe-local hand-offs instead of
+# kernel boundaries).  OPT-IN (PARTMANIP_CHAIN=1): bit-identical to the layer-by-layer launches and level with them on an idle
+# chip (37.1 vs 37.1 us for the three forward layers of cfg 2, 29.7 vs 30.3 us for the two data gradients), but with the actor's
+# and the critic's chains sharing the chip it LOSES: 1.98 M against 2.29 M env-steps/s at cfg 2 (round 3, alternating runs) --
+# resident work-groups waiting at a stripe counter hold CU slots the other network's short kernels would have filled.
+import os as _os
+CHAIN_LAUNCH = _os.environ.get("PARTMANIP_CHAIN", "0") == "1"
 
 
 def get_activation(act_name):
@@ -54,6 +61,12 @@ class _LinearChain:
         self.h = []                        # saved activation outputs of the hidden layers
         self.x_w = None                    # the chain input again, in rows padded for 16-byte loads (ops.padded_cols): weight gradient only
         self.grads = None                  # list[(dW view, db view)] set by ActorCritic.flatten()
+        self._cws = None                   # stripe counters of the chained launches (one set per network: they run on two streams)
+
+    def _chain_ws(self, device):
+        if self._cws is None or self._cws.device != device:
+            self._cws = ops.Workspace(device)
+        return self._cws
 
     def forward(self, x, out=None, x_w=None):
         n = len(self.linears)
@@ -71,11 +84,22 @@ class _LinearChain:
         return cur
 
     def forward_hidden(self, x, x_w=None):
-        """All layers but the last (the head runs fused with its loss: ops.ppo_actor_head); returns the last hidden activation."""
+        """All layers but the last (the head runs fused with its loss: ops.ppo_actor_head); returns the last hidden activation.
+        Small-step regime: the hidden layers run as ONE launch when their shapes allow (ops.linear_fwd_chain: the stripes of a
+        layer hand their tiles to the next layer inside the launch), else layer by layer."""
         self.x, self.x_w = x, x_w
         self.h = []
+        hidden = self.linears[:-1]
+        if CHAIN_LAUNCH and len(hidden) >= 2 and x.shape[0] >= 256:
+            ys = [torch.empty(x.shape[0], lin.out_features, device=x.device) for lin in hidden]
+            # (the input layer reads the observations in their 16-byte-padded rows when the caller has them: same values)
+            ins = [x_w if (x_w is not None and x_w.shape == x.shape) else x] + ys[:-1]
+            items = [(i_, lin.weight.data, lin.bias.data, y, self.act) for i_, lin, y in zip(ins, hidden, ys)]
+            if ops.linear_fwd_chain(items, self._chain_ws(x.device)):
+                self.h = ys
+                return ys[-1]
         cur = x
-        for lin in self.linears[:-1]:
+        for lin in hidden:
             y = torch.empty(cur.shape[0], lin.out_features, device=cur.device)
             ops.linear_fwd(cur, lin.weight.data, lin.bias.data, y, self.act)
             self.h.append(y)
@@ -141,6 +165,19 @@ def chains_backward(chains, dys, slab_strides, splits, head_dz=None):
         for c, d in enumerate(head_dz):
             dz[c][n - 2] = d
         top = n - 1
+    if CHAIN_LAUNCH and len(chains) == 1 and top - 1 >= 2 and dz[0][top - 1].shape[0] >= 256 and dz[0][top - 1].shape[1] > 16:
+        # one network's hidden-layer data gradients as ONE launch (ops.linear_bwd_data_chain), top layer first
+        ch = chains[0]
+        items, d = [], dz[0][top - 1]
+        for i in reversed(range(1, top)):
+            inp = ch.h[i - 1]
+            dx = torch.empty_like(inp)
+            items.append((d, ch.linears[i].weight.data, inp, dx, ch.act))
+            d = dx
+        if ops.linear_bwd_data_chain(items, ch._chain_ws(d.device)):
+            for i, it in zip(reversed(range(1, top)), items):
+                dz[0][i - 1] = it[3]
+            top = 1
     for i in reversed(range(1, top)):
         items = []
         for c, ch in enumerate(chains):

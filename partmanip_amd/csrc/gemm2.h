@@ -44,6 +44,25 @@ struct Gemm2Group {
     Gemm2Prob p[GEMM2_MAXP];
 };
 
+// ---- a CHAIN of dependent problems in one launch (the hidden layers of an MLP forward, or of its data gradient) --------------
+// Phase p + 1 reads, as its A operand, the C of phase p.  The dependency is row-local: a 64-row stripe of C(p+1) needs the same
+// 64 rows of C(p), all columns -- so the N / 64 work-groups that own a stripe hand their tiles to each other INSIDE the launch
+// (write-through stores, one arrival counter per stripe, sc1 loads: MI355X_MICROARCH.md "inter-workgroup visibility", form R1)
+// and no kernel boundary separates the layers.  Every work-group of the grid must be resident (<= 256, one per CU).
+#define GEMM2_CHAIN_MAX 4
+#define GEMM2_CHAIN_MAX_WG 256
+struct Gemm2Chain {
+    int n;                        // phases
+    int stripes, G;               // 64-row stripes, work-groups (64-column tiles) per stripe -- filled by the launcher
+    int small0;                   // phase 0 has K <= 64 and rows that are not 16-byte loadable (the input layer): staged through registers
+    unsigned long long* bar;      // `stripes` MONOTONIC arrival counters + one error word behind them: zeroed ONCE by the caller, then
+                                  // only ever handed to chains of this (stripes, G, n) -- a launch derives its base from what it finds
+    Gemm2Prob p[GEMM2_CHAIN_MAX];
+};
+// b_kmajor: false = forward chain (A, B k-contiguous), true = data-gradient chain (B = W k-major).  PM_EUNSUPPORTED when the
+// shapes do not fit the scheme (the caller then issues the layers one by one).
+int gemm2_chain_launch(Gemm2Chain& ch, bool b_kmajor, void* stream);
+
 // Launches the group (all problems share the orientation); big = 128x128 work-group tiles (for M*N >> chip), else 64x64.
 // Returns PM_OK / PM_E*.  `tag` only names the launch for profiling purposes.
 int gemm2_launch(Gemm2Group& g, bool a_kmajor, bool b_kmajor, void* stream);

@@ -138,7 +138,9 @@ __device__ __forceinline__ void g2_mfma_half(const G2Frag<WM>& a, const G2Frag<W
 }
 
 // ---- epilogue (shared by the register-staged and the LDS-DMA kernel) ------------------------------------------------
-template <bool A_KM, bool B_KM, int WM, int WN, int NT, int TM = 64 * WM, int TN = 64 * WN>
+typedef unsigned int g2_u32x4 __attribute__((ext_vector_type(4)));
+// SC1: the tile leaves as write-through (sc1) 16-byte stores -- another work-group of the same launch reads it next
+template <bool A_KM, bool B_KM, int WM, int WN, int NT, int TM = 64 * WM, int TN = 64 * WN, bool SC1 = false>
 __device__ __forceinline__ void g2_epilogue(const Gemm2Prob& g, f32x16 (&acc)[WM][WN], float* __restrict__ lds, int m0, int n0, int z,
                                             int wmo, int wno, int li, int lh, bool writer) {
     const int tid = threadIdx.x;
@@ -190,7 +192,14 @@ __device__ __forceinline__ void g2_epilogue(const Gemm2Prob& g, f32x16 (&acc)[WM
                         v.x *= pm_dact(hh.x, act); v.y *= pm_dact(hh.y, act); v.z *= pm_dact(hh.z, act); v.w *= pm_dact(hh.w, act);
                     }
                 }
-                *(float4*)(C + coff) = v;
+                if constexpr (SC1) {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(C, 0, 0x7fffffff, 0x00020000);
+                    g2_u32x4 d;
+                    d.x = __float_as_uint(v.x); d.y = __float_as_uint(v.y); d.z = __float_as_uint(v.z); d.w = __float_as_uint(v.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)(coff * 4), 0, 16);
+                } else {
+                    *(float4*)(C + coff) = v;
+                }
             }
         }
     } else {
@@ -371,7 +380,9 @@ __device__ __forceinline__ void g2_read_frag_dma(const float* __restrict__ S, in
 }
 typedef __attribute__((address_space(3))) void* g2_lds_ptr;
 // one operand tile (T rows x 32 k) global -> LDS: T / 32 wave instructions per wave
-template <bool KM, int T>
+// AUX: cache policy of the loads (0 = default; 16 = sc1: an operand another work-group of the SAME launch has just written
+// with sc1 stores -- gemm2_chain_kernel -- must not come out of this CU's L1)
+template <bool KM, int T, int AUX = 0>
 __device__ __forceinline__ void g2_dma_tile(const float* __restrict__ P, long ld, int r0, int nrows, int k0, float* __restrict__ S,
                                             int wave, int lane, int kmax = 0x7fffffff) {
 #pragma unroll
@@ -385,7 +396,7 @@ __device__ __forceinline__ void g2_dma_tile(const float* __restrict__ P, long ld
             const int row = piece * 8 + (lane >> 3), c = lane & 7;
             src = P + (long)min(r0 + row, nrows - 1) * ld + k0 + ((c ^ ((row >> 1) & 7)) << 2);
         }
-        __builtin_amdgcn_global_load_lds(src, (g2_lds_ptr)(S + piece * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src, (g2_lds_ptr)(S + piece * 256), 16, 0, AUX);
     }
 }
 
@@ -435,35 +446,28 @@ __device__ __forceinline__ void g2_gather_first(const Gemm2Prob& g, int r0, int 
 // LAY: how the four multiplying waves cover the work-group tile -- 0: 2 x 2 (tile 64 WM x 64 WN); 1: 1 x 4 (tile 32 WM x 128 WN)
 // for problems with at most 32 rows (the weight gradient of a 32-channel convolution over millions of rows: on the 2 x 2 layout
 // half of every MFMA multiplies rows that do not exist -- 6.5 ms per launch at 142 TFLOP/s of ISSUED work, 71 of useful).
-template <bool A_KM, bool B_KM, int WM, int WN, bool GATHER = false, int LAY = 0>
-__global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
+template <int WM, int WN, int LAY>
+struct G2DmaShape {
+    static constexpr int TM = LAY ? 32 * WM : 64 * WM, TN = LAY ? 128 * WN : 64 * WN;
+    static constexpr int NBUF = 3;
+    static constexpr int ABUF = TM * 32, BBUF = TN * 32;
+    static constexpr int EPI = TM * (TN + 4);                              // the epilogue's staging image
+    static constexpr int LDSF = NBUF * (ABUF + BBUF) > EPI ? NBUF * (ABUF + BBUF) : EPI;
+};
+
+// One work-group tile (tm, tn, slab z) of problem g: the whole K loop + epilogue.  AUXA: cache policy of the A-operand loads,
+// SC1C: write-through result stores (both for tiles that hand data to / take data from other work-groups of the same launch).
+template <bool A_KM, bool B_KM, int WM, int WN, bool GATHER, int LAY, int AUXA, bool SC1C>
+__device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Prob& g, int tm, int tn, int z, float* __restrict__ lds) {
     // 8 waves: waves 0-3 multiply (one per SIMD), waves 4-7 only feed the LDS ring.  Issuing one
     // 1 KiB LDS-DMA costs the issuing wave ~90 cycles (measured: 4 of them in front of a half-step's MFMAs stretched it from
     // 512 to 885 cycles) and an in-order wave cannot issue MFMAs meanwhile -- a second wave on the SIMD can.
-    constexpr int TM = LAY ? 32 * WM : 64 * WM, TN = LAY ? 128 * WN : 64 * WN;
-    constexpr int NBUF = 3;
-    constexpr int ABUF = TM * 32, BBUF = TN * 32;
+    using SH = G2DmaShape<WM, WN, LAY>;
+    constexpr int TM = SH::TM, TN = SH::TN, NBUF = SH::NBUF, ABUF = SH::ABUF, BBUF = SH::BBUF;
     constexpr int IPT = (TM + TN) / 32;                                    // DMA instructions per tile per loader wave
-    constexpr int EPI = TM * (TN + 4);                                     // the epilogue's staging image
-    constexpr int LDSF = NBUF * (ABUF + BBUF) > EPI ? NBUF * (ABUF + BBUF) : EPI;
-    __shared__ __attribute__((aligned(1024))) float lds[LDSF];
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
     const bool loader = tid >= 256;
     const int li = lane & 31, lh = lane >> 5;
-#ifdef G2_PROFILE
-    if (gg.prof && tid == 0) gg.prof[(size_t)blockIdx.x * 4] = __builtin_readcyclecounter();
-#endif
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < GEMM2_MAXP; ++i)
-        if (i < gg.n && (int)blockIdx.x >= gg.p[i].block0) pi = i;
-    const Gemm2Prob& g = gg.p[pi];
-    const int tiles = g.tiles_m * g.tiles_n, nblk = tiles * g.splits;
-    int local = (int)blockIdx.x - g.block0;
-    if (local >= nblk) return;
-    if ((nblk & 7) == 0) local = (local & 7) * (nblk >> 3) + (local >> 3);
-    const int z = local / tiles, t = local - z * tiles;
-    const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
     const int m0 = tm * TM, n0 = tn * TN;
     const int kbeg = z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     const int nk = (kend - kbeg + G2_TK - 1) / G2_TK;                      // whole steps, except the ragged row tail of a gathered weight gradient
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
             const int tt = min(tile, nk - 1), buf = tile % NBUF;
             const int kt = kbeg + tt * G2_TK, ktn = kbeg + min(tile + 1, nk - 1) * G2_TK;
             if constexpr (GATHER && !A_KM) g2_dma_tile_gather<false, TM>(g, g.A, g.lda, m0, g.M, kt, ktn, As + buf * ABUF, wave, lane, gi);
-            else g2_dma_tile<A_KM, TM>(g.A, g.lda, m0, A_KM ? g.Mld : g.M, kt, As + buf * ABUF, wave, lane, g.K - 1);
+            else g2_dma_tile<A_KM, TM, AUXA>(g.A, g.lda, m0, A_KM ? g.Mld : g.M, kt, As + buf * ABUF, wave, lane, g.K - 1);
             if constexpr (GATHER && A_KM) g2_dma_tile_gather<true, TN>(g, g.B, g.ldb, n0, g.N, kt, ktn, Bs + buf * BBUF, wave, lane, gi);
             else g2_dma_tile<B_KM, TN>(g.B, g.ldb, n0, B_KM ? g.Nld : g.N, kt, Bs + buf * BBUF, wave, lane);
         };
@@ -567,8 +571,176 @@ __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
             g.dbias[(long)z * g.bslab + m0 + tid] = s;
         }
     }
-    g2_epilogue<A_KM, B_KM, WM, WN, 512, TM, TN>(g, acc, lds, m0, n0, z, wmo, wno, li, lh, !loader);
+    g2_epilogue<A_KM, B_KM, WM, WN, 512, TM, TN, SC1C>(g, acc, lds, m0, n0, z, wmo, wno, li, lh, !loader);
     G2_STAMP(3);
+}
+
+template <bool A_KM, bool B_KM, int WM, int WN, bool GATHER = false, int LAY = 0>
+__global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
+    __shared__ __attribute__((aligned(1024))) float lds[G2DmaShape<WM, WN, LAY>::LDSF];
+#ifdef G2_PROFILE
+    if (gg.prof && threadIdx.x == 0) gg.prof[(size_t)blockIdx.x * 4] = __builtin_readcyclecounter();
+#endif
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM2_MAXP; ++i)
+        if (i < gg.n && (int)blockIdx.x >= gg.p[i].block0) pi = i;
+    const Gemm2Prob& g = gg.p[pi];
+    const int tiles = g.tiles_m * g.tiles_n, nblk = tiles * g.splits;
+    int local = (int)blockIdx.x - g.block0;
+    if (local >= nblk) return;
+    if ((nblk & 7) == 0) local = (local & 7) * (nblk >> 3) + (local >> 3);
+    const int z = local / tiles, t = local - z * tiles;
+    const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+    g2_dma_body<A_KM, B_KM, WM, WN, GATHER, LAY, 0, false>(gg, g, tm, tn, z, lds);
+}
+
+// =====================================================================================================================
+// Chain of dependent layers in ONE launch (Gemm2Chain, gemm2.h).  The small-step regime's network step is ~9 dependent launches
+// of 5-20 us; a kernel boundary costs ~5.6 us there while the other network's chain competes for the chip.
+// A layer-to-layer dependency only ties together the N / 64 work-groups of one 64-row stripe, so it is carried by a stripe-local
+// arrival counter instead: tiles leave as write-through (sc1) 16-byte stores, every storing wave drains them (s_waitcnt
+// vmcnt(0)), ONE lane adds to the stripe's counter and polls it (relaxed, agent scope, s_sleep, bounded), and the next phase
+// loads its A operand with sc1 LDS-DMA loads -- nothing depends on dispatch order or on where a work-group runs; blocks of a
+// stripe are numbered so that they land on one XCD when the dispatcher round-robins (speed only).
+// MEASURED (round 3, cfg 2 shapes): bit-identical to the per-layer launches; on an idle chip a stripe hand-off costs what a
+// kernel boundary costs (3 forward layers 37.1 us either way; with a memset node zeroing the counters per launch it was 41.2,
+// hence the monotonic counters); in the two-stream PPO step it is 14 % SLOWER than the boundaries it replaces (1.98 vs 2.29 M
+// env-steps/s) -- MI355X_MICROARCH.md's "cut at every seam" verdict, reproduced.  The learner therefore uses it only on
+// request (PARTMANIP_CHAIN=1, algo_utils/network.py).
+#define G2_SPIN_LIMIT (1u << 18)
+typedef unsigned long long g2_u64;
+__device__ __forceinline__ void g2_stripe_barrier(g2_u64* __restrict__ ctr, g2_u64 target, g2_u64* __restrict__ err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // my write-through stores have left
+    __syncthreads();                                                       // ... and those of every wave of this work-group
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > G2_SPIN_LIMIT) {                                 // a work-group of the stripe is not resident / has died:
+                __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // give up loudly instead of hanging the GPU
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Phase 0 of a forward chain when the input layer's rows are not 16-byte loadable (K <= 64, e.g. 53 observations): both
+// operand tiles go whole through registers into the LDS-DMA image (two 32-wide K-tiles, zero-filled past K), then the four
+// multiplying waves run the same fragment reads / MFMA order as the pipelined body.
+template <bool SC1C>
+__device__ __forceinline__ void g2_smallk_body(const Gemm2Prob& g, int tm, int tn, float* __restrict__ lds) {
+    using SH = G2DmaShape<1, 1, 0>;
+    constexpr int TM = 64, TN = 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+    const bool loader = tid >= 256;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int wmo = (wave >> 1) * 32, wno = (wave & 1) * 32;
+    float* As = lds;                                                       // two K-tiles of A, then two of B
+    float* Bs = lds + 2 * SH::ABUF;
+#pragma unroll
+    for (int j = 0; j < TM * 64 / 512; ++j) {
+        const int e = tid + 512 * j, row = e >> 6, k = e & 63;
+        const int kt = k >> 5, c = (k & 31) >> 2, w = k & 3;
+        const int dst = kt * SH::ABUF + row * 32 + ((c ^ ((row >> 1) & 7)) << 2) + w;
+        const int ga = m0 + row, gb = n0 + row;
+        As[dst] = (k < g.K && ga < g.M) ? g.A[(long)ga * g.lda + k] : 0.f;
+        Bs[dst] = (k < g.K && gb < g.N) ? g.B[(long)gb * g.ldb + k] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    if (!loader) {
+        const int nkt = g.K > 32 ? 2 : 1;
+        for (int kt = 0; kt < nkt; ++kt) {
+            G2Frag<1> xa, xb, ya, yb;
+            g2_read_frag_dma<false, 1, TM>(As + kt * SH::ABUF, wmo, li, lh, 0, xa);
+            g2_read_frag_dma<false, 1, TN>(Bs + kt * SH::BBUF, wno, li, lh, 0, xb);
+            g2_read_frag_dma<false, 1, TM>(As + kt * SH::ABUF, wmo, li, lh, 1, ya);
+            g2_read_frag_dma<false, 1, TN>(Bs + kt * SH::BBUF, wno, li, lh, 1, yb);
+            g2_mfma_half<1, 1>(xa, xb, acc);
+            g2_mfma_half<1, 1>(ya, yb, acc);
+        }
+    }
+    g2_epilogue<false, false, 1, 1, 512, TM, TN, SC1C>(g, acc, lds, m0, n0, 0, wmo, wno, li, lh, !loader);
+}
+
+template <bool B_KM>
+__global__ __launch_bounds__(512) void gemm2_chain_kernel(Gemm2Chain ch) {
+    __shared__ __attribute__((aligned(1024))) float lds[G2DmaShape<1, 1, 0>::LDSF];
+    // block -> (stripe, column tile): blocks b = x (mod 8) land on XCD x when the dispatcher round-robins; a stripe's G
+    // work-groups are consecutive WITHIN an XCD's block list (their tiles then meet in that XCD's L2 -- speed only)
+    const int total = ch.stripes * ch.G;
+    int local = (int)blockIdx.x;
+    if ((total & 7) == 0) local = (local & 7) * (total >> 3) + (local >> 3);
+    const int stripe = local / ch.G, tn = local - stripe * ch.G;
+    g2_u64* ctr = ch.bar + stripe;
+    g2_u64* err = ch.bar + ch.stripes;
+    // The counters are MONOTONIC and never reset (a memset node in front of every launch costs as much as the boundary the
+    // chain removes; a per-launch epoch argument would be frozen by graph replay): a launch adds G arrivals per barrier, i.e.
+    // per_launch = G * (n - 1) in total, and every earlier launch has completed, so what this work-group reads at its start is
+    // (launches so far) * per_launch + (arrivals of THIS launch's first barrier, < G <= per_launch): the launch's base is that
+    // value rounded down to a multiple of per_launch.  (64-bit: no wrap in any run length.)
+    __shared__ g2_u64 s_base;
+    if (threadIdx.x == 0) {
+        const g2_u64 per_launch = (g2_u64)ch.G * (g2_u64)(ch.n - 1);
+        const g2_u64 v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_base = v - v % per_launch;
+    }
+    __syncthreads();
+    const g2_u64 base = s_base;
+    Gemm2Group gg{};                                                       // (profiling hooks of the body: unused here)
+    gg.prof = nullptr;
+    int ph = 0;
+    if (ch.small0) {
+        if constexpr (!B_KM) g2_smallk_body<true>(ch.p[0], stripe, tn, lds);
+        g2_stripe_barrier(ctr, base + (g2_u64)ch.G, err);
+        ph = 1;
+    }
+#pragma unroll 1
+    for (; ph < ch.n; ++ph) {
+        // one instantiation for every phase: sc1 loads of A (exact for data of an earlier launch too) and write-through stores
+        g2_dma_body<false, B_KM, 1, 1, false, 0, 16, true>(gg, ch.p[ph], stripe, tn, 0, lds);
+        if (ph + 1 < ch.n) g2_stripe_barrier(ctr, base + (g2_u64)ch.G * (g2_u64)(ph + 1), err);
+    }
+}
+
+int gemm2_chain_launch(Gemm2Chain& ch, bool b_kmajor, void* stream) {
+    if (ch.n < 2 || ch.n > GEMM2_CHAIN_MAX || !ch.bar) return PM_EINVAL;
+    const int M = ch.p[0].M, N = ch.p[0].N;
+    if (N % 64 != 0) return PM_EUNSUPPORTED;
+    for (int i = 0; i < ch.n; ++i) {
+        Gemm2Prob& p = ch.p[i];
+        if (p.M != M || p.N != N) return PM_EUNSUPPORTED;                  // equal widths: every phase has the same stripes x G grid
+        if (i > 0 && (p.A != ch.p[i - 1].C || p.lda != ch.p[i - 1].ldc || p.K != N)) return PM_EINVAL;
+        p.splits = 1;
+        p.kchunk = ((p.K + G2_TK - 1) / G2_TK) * G2_TK;
+        p.Mld = p.M; p.Nld = p.N;
+        p.tiles_m = (M + 63) / 64; p.tiles_n = N / 64; p.block0 = 0;
+        p.vecC = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) &&
+                 (p.epi != G2_EPI_BIAS_ACT || !p.bias || ((uintptr_t)p.bias & 15) == 0) &&
+                 (p.epi != G2_EPI_MUL_DACT || p.act == PM_ACT_NONE || (p.ldh % 4 == 0 && ((uintptr_t)p.H & 15) == 0));
+        if (!p.vecC || (long)M * p.ldc * 4 >= 0x7fffffffL) return PM_EUNSUPPORTED;      // 16-byte write-through stores, 31-bit buffer offsets
+        const bool small = i == 0 && !b_kmajor && !(p.vecA && p.vecB && p.K % G2_TK == 0);
+        if (small) {
+            if (p.K > 64) return PM_EUNSUPPORTED;
+            ch.small0 = 1;
+        } else if (!(p.vecA && p.vecB && p.K % G2_TK == 0)) {
+            return PM_EUNSUPPORTED;
+        }
+    }
+    ch.stripes = (M + 63) / 64;
+    ch.G = N / 64;
+    const int total = ch.stripes * ch.G;
+    if (total > GEMM2_CHAIN_MAX_WG) return PM_EUNSUPPORTED;               // every work-group must be resident: one per CU
+    if (b_kmajor) hipLaunchKernelGGL((gemm2_chain_kernel<true>), dim3(total), dim3(512), 0, pm_stream(stream), ch);
+    else hipLaunchKernelGGL((gemm2_chain_kernel<false>), dim3(total), dim3(512), 0, pm_stream(stream), ch);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
 }
 
 // (WM, WN) of a launch: 64 x 64 work-group tiles for small grids; for big ones 128 rows / columns only along a dimension some

@@ -243,6 +243,50 @@ extern "C" int pm_linear_bwd_data_group_f32(int n, const pm_linear_bwd_data_desc
     return gemm2_launch(gg, false, true, stream);
 }
 
+// ---- chains: consecutive layers of ONE network in one launch (gemm2.h: Gemm2Chain) ----------------------------------------
+extern "C" size_t pm_linear_chain_workspace_bytes(int M) { return (size_t)((M + 63) / 64 + 1) * sizeof(unsigned long long); }
+
+extern "C" int pm_linear_fwd_chain_f32(int n, const pm_linear_fwd_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(d && n >= 2 && n <= GEMM2_CHAIN_MAX && workspace);
+    if (workspace_bytes < pm_linear_chain_workspace_bytes(d[0].M)) return PM_EWORKSPACE;
+    if (((uintptr_t)workspace & 7) != 0) return PM_EALIGN;
+    Gemm2Chain ch{};
+    ch.n = n;
+    ch.bar = (unsigned long long*)workspace;
+    for (int i = 0; i < n; ++i) {
+        const pm_linear_fwd_desc& q = d[i];
+        PM_REQUIRE(q.X && q.W && q.Y && q.M > 0 && q.N > 0 && q.K > 0 && q.ldx >= q.K && q.ldw >= q.K && q.ldy >= q.N);
+        PM_REQUIRE(q.act >= PM_ACT_NONE && q.act <= PM_ACT_MAX);
+        Gemm2Prob& g = ch.p[i];
+        g.A = q.X; g.lda = q.ldx; g.B = q.W; g.ldb = q.ldw; g.C = q.Y; g.ldc = q.ldy; g.bias = q.b;
+        g.M = q.M; g.N = q.N; g.K = q.K; g.act = q.act; g.epi = G2_EPI_BIAS_ACT;
+        g.vecA = (q.K % 4 == 0) && (q.ldx % 4 == 0) && aligned16(q.X);
+        g.vecB = (q.K % 4 == 0) && (q.ldw % 4 == 0) && aligned16(q.W);
+    }
+    return gemm2_chain_launch(ch, false, stream);
+}
+
+extern "C" int pm_linear_bwd_data_chain_f32(int n, const pm_linear_bwd_data_desc* d, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+    PM_REQUIRE(d && n >= 2 && n <= GEMM2_CHAIN_MAX && workspace);
+    if (workspace_bytes < pm_linear_chain_workspace_bytes(d[0].M)) return PM_EWORKSPACE;
+    if (((uintptr_t)workspace & 7) != 0) return PM_EALIGN;
+    Gemm2Chain ch{};
+    ch.n = n;
+    ch.bar = (unsigned long long*)workspace;
+    for (int i = 0; i < n; ++i) {
+        const pm_linear_bwd_data_desc& q = d[i];
+        PM_REQUIRE(q.dY && q.W && q.dX && q.M > 0 && q.N > 0 && q.K > 0 && q.lddy >= q.N && q.ldw >= q.K && q.lddx >= q.K);
+        PM_REQUIRE(q.act == PM_ACT_NONE || (q.act > PM_ACT_NONE && q.act <= PM_ACT_MAX && q.H && q.ldh >= q.K));
+        Gemm2Prob& g = ch.p[i];
+        g.A = q.dY; g.lda = q.lddy; g.B = q.W; g.ldb = q.ldw; g.C = q.dX; g.ldc = q.lddx; g.H = q.H; g.ldh = q.ldh;
+        g.M = q.M; g.N = q.K; g.K = q.N; g.act = q.act; g.epi = G2_EPI_MUL_DACT;
+        g.vecA = (q.N % 4 == 0) && (q.lddy % 4 == 0) && aligned16(q.dY);
+        g.vecB = (q.K % 4 == 0) && (q.ldw % 4 == 0) && aligned16(q.W);
+    }
+    return gemm2_chain_launch(ch, true, stream);
+}
+
 extern "C" int pm_linear_bwd_weight_group_f32(int n, const pm_linear_bwd_weight_desc* d, int splits, void* stream) {
     PM_REQUIRE(d && n >= 1 && n <= PM_LINEAR_GROUP_MAX && splits >= 1);
     Gemm2Group gg{};

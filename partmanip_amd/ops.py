@@ -196,6 +196,61 @@ def linear_bwd_data_group(items):
     check(lib.pm_linear_bwd_data_group_f32(len(items), arr, _stream()), "pm_linear_bwd_data_group_f32")
 
 
+PM_EUNSUPPORTED = -4
+
+
+def _chain_ws(ws, kind, M, N, n_layers):
+    """The monotonic stripe counters + error word of one chain shape (zeroed once, never shared between shapes / directions)."""
+    n = int(lib.pm_linear_chain_workspace_bytes(M)) // 8
+    tab = getattr(ws, "chain_ctr", None)
+    if tab is None:
+        tab = ws.chain_ctr = {}
+    key = (kind, M, N, n_layers)
+    if key not in tab:
+        tab[key] = torch.zeros(n, dtype=torch.int64, device=ws.device)
+    return tab[key], n
+
+
+def linear_fwd_chain(items, ws):
+    """items: [(x, w, b, y, act), ...] with items[i + 1].x is items[i].y: consecutive layers in ONE launch (pm_linear_fwd_chain_f32).
+    Returns False when the shapes do not fit the scheme (nothing was launched: issue the layers one by one)."""
+    from ._lib import LinearFwdDesc
+    arr = (LinearFwdDesc * len(items))()
+    for d, (x, w, b, y, act) in zip(arr, items):
+        _req(x, w, b, y)
+        d.X, d.ldx, d.W, d.ldw, d.b, d.Y, d.ldy = _ptr(x), _rows(x, "x"), _ptr(w), _rows(w, "w"), _ptr(b), _ptr(y), _rows(y, "y")
+        d.M, d.K, d.N, d.act = x.shape[0], x.shape[1], w.shape[0], act
+    ctr, n = _chain_ws(ws, "fwd", items[0][0].shape[0], items[0][1].shape[0], len(items))
+    rc = lib.pm_linear_fwd_chain_f32(len(items), arr, _ptr(ctr), n * 8, _stream())
+    if rc == PM_EUNSUPPORTED:
+        return False
+    check(rc, "pm_linear_fwd_chain_f32")
+    return True
+
+
+def linear_bwd_data_chain(items, ws):
+    """items: [(dy, w, h, dx, act), ...] top layer first, items[i + 1].dy is items[i].dx (pm_linear_bwd_data_chain_f32)."""
+    from ._lib import LinearBwdDataDesc
+    arr = (LinearBwdDataDesc * len(items))()
+    for d, (dy, w, h, dx, act) in zip(arr, items):
+        _req(dy, w, h, dx)
+        d.dY, d.lddy, d.W, d.ldw, d.dX, d.lddx = _ptr(dy), _rows(dy, "dy"), _ptr(w), _rows(w, "w"), _ptr(dx), _rows(dx, "dx")
+        d.H, d.ldh = _ptr(h), (_rows(h, "h") if h is not None else 0)
+        d.M, d.N, d.K, d.act = dy.shape[0], dy.shape[1], w.shape[1], act
+    ctr, n = _chain_ws(ws, "bwd", items[0][0].shape[0], items[0][1].shape[1], len(items))
+    rc = lib.pm_linear_bwd_data_chain_f32(len(items), arr, _ptr(ctr), n * 8, _stream())
+    if rc == PM_EUNSUPPORTED:
+        return False
+    check(rc, "pm_linear_bwd_data_chain_f32")
+    return True
+
+
+def chain_gave_up(ws):
+    """True when a stripe barrier of the last chain launch on this workspace ran into its spin limit (host sync)."""
+    tab = getattr(ws, "chain_ctr", None) or {}
+    return any(int(t[-1].item()) != 0 for t in tab.values())
+
+
 def padded_cols(rows, cols, device, zero=False):
     """(rows, cols) fp32 view of a buffer whose rows are padded to a multiple of 4 floats; the view carries `_pm_cols` (the
     readable row width), which `linear_bwd_weight_group` hands to the kernels so that a 10- or 53-column operand takes the

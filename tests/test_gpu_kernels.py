@@ -240,6 +240,64 @@ def test_value_head_equals_the_separate_launches(B, K, clipped):
         np.testing.assert_allclose(float(scal2[0]), float(scal[0]), rtol=1e-6)
 
 
+@pytest.mark.parametrize("M,O,H,act", [(2048, 53, 512, "tanh"), (2048, 64, 512, "relu"), (1000, 37, 256, "tanh"), (2048, 53, 128, "elu")])
+def test_chained_hidden_layers_equal_the_layer_by_layer_launches(M, O, H, act):
+    """pm_linear_fwd_chain_f32 / pm_linear_bwd_data_chain_f32 (the hidden layers of one network in ONE launch: the work-groups of
+    a 64-row stripe hand their tiles over inside the launch -- write-through stores, a stripe counter, sc1 loads) against the
+    single-layer entry points, which test_linear_* pin to the oracle: every output BIT FOR BIT (same MFMA order), 40 launches
+    whose inputs change every time (a stale tile of the previous launch would be a wrong sum) beside a copy on another stream
+    (uneven load), no spin ever giving up."""
+    o = ops()
+    ACT = {"tanh": o.ACT_TANH, "relu": o.ACT_RELU, "elu": o.ACT_ELU}[act]
+    g = torch.Generator().manual_seed(M + O + H)
+    d = lambda v: v.to(DEV).contiguous()
+    dev = torch.device(DEV)
+    x0 = d(torch.randn(M, O, generator=g))
+    Ws = [d(torch.randn(H, O, generator=g) / O ** 0.5), d(torch.randn(H, H, generator=g) / H ** 0.5), d(torch.randn(H, H, generator=g) / H ** 0.5)]
+    bs = [d(torch.randn(H, generator=g) * 0.1) for _ in range(3)]
+    dz0 = d(torch.randn(M, H, generator=g))
+    ws = o.Workspace(dev)
+    side = torch.cuda.Stream()
+    big_a, big_b = torch.empty(64 << 20, device=DEV), torch.empty(64 << 20, device=DEV)
+    for it in range(40):
+        x = x0 * (1.0 + 0.02 * it)
+        dz = dz0 * (1.0 - 0.01 * it)
+        ref, cur = [], x
+        for W, b in zip(Ws, bs):
+            y = torch.empty(M, H, device=DEV)
+            o.linear_fwd(cur, W, b, y, ACT)
+            ref.append(y)
+            cur = y
+        dref, dcur = [], dz
+        for i in (2, 1):
+            dx = torch.empty(M, H, device=DEV)
+            o.linear_bwd_data(dcur, Ws[i], ref[i - 1], dx, ACT)
+            dref.append(dx)
+            dcur = dx
+        if it % 3 != 2:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                big_b.copy_(big_a)
+        ys = [torch.full((M, H), float("nan"), device=DEV) for _ in range(3)]
+        ins = [x] + ys[:-1]
+        ok = o.linear_fwd_chain([(i_, W, b, y, ACT) for i_, W, b, y in zip(ins, Ws, bs, ys)], ws)
+        assert ok == (M * H <= 256 * 64 * 64 and H % 64 == 0), "shape support changed"
+        if not ok:
+            return
+        dxs = [torch.full((M, H), float("nan"), device=DEV) for _ in range(2)]
+        items, dcur = [], dz
+        for i, dx in zip((2, 1), dxs):
+            items.append((dcur, Ws[i], ys[i - 1], dx, ACT))
+            dcur = dx
+        assert o.linear_bwd_data_chain(items, ws)
+        for k in range(3):
+            assert torch.equal(ys[k], ref[k]), (it, "forward layer", k)
+        for k in range(2):
+            assert torch.equal(dxs[k], dref[k]), (it, "data gradient", k)
+        torch.cuda.current_stream().wait_stream(side)
+    assert not o.chain_gave_up(ws)
+
+
 def test_fused_heads_last_work_group_reduction_under_uneven_load():
     """The fused head launches hand their per-work-group partials to the LAST work-group to arrive INSIDE the launch (relaxed
     agent-scope atomic stores -> s_waitcnt vmcnt(0) -> a relaxed agent-scope counter RMW -> agent-scope atomic loads: the
