@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 134 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 135 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -141,7 +141,7 @@ int pm_linear_fwd_chain_f32(int n, const pm_linear_fwd_desc* d, void* workspace,
 int pm_linear_bwd_data_chain_f32(int n, const pm_linear_bwd_data_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ K6/K7  PointNet encoder
- * network.py:147-153,172-181: per-point shared MLP C->128->256->512 (tanh,tanh,none) over
+ * network.py:147-153,172-181: per-point shared MLP C->128->256->512 (act,act,none) over
  * (B, P, C) clouds fused with the symmetric max(/mean) pooling; the (B,P,512) activation
  * is never materialised.  feat (B, ldf) receives [max(512) | mean(512) if max_mean];
  * argmax (B,512) int32 is the pooling index (lowest index on ties, as torch.max).
@@ -155,6 +155,8 @@ int pm_pointnet_enc_fwd_f32(const float* x, long ldx, int B, int P, int C, int s
                             const float* b1, const float* b2, const float* b3, const float* packed,
                             int max_mean, float* feat, long ldf, int32_t* argmax,
                             float* h2_save /* NULL, or (B, P, 256): the layer-2 activations for the backward */,
+                            int act /* PM_ACT_* of the two hidden layers (network.py:147-153 takes any of get_activation's
+                                       seven; PM_ACT_TANH -- every shipped cfg -- runs the tuned packed-tanh kernels) */,
                             void* stream);
 /* OPT-IN split-bf16 forward: same contract as pm_pointnet_enc_fwd_f32, but the two big per-point GEMMs run as
  * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on bf16 MFMAs with fp32 accumulation (~1e-5 relative instead of ~1e-7;
@@ -187,7 +189,7 @@ int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, int C, int s
                             int max_mean, const float* dfeat, long ldf, const int32_t* argmax, float* dW1,
                             float* db1, float* dW2, float* db2, float* dW3, float* db3,
                             const float* h2_saved /* NULL = recompute layer 2; else what the forward saved */,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            int act /* as the forward's */, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ K8  PPO actor loss
  * actor_critic.py:74-78,93-100 + ppo.py:327-344 in one pass over a mini-batch of B rows:

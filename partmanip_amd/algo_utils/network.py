@@ -16,8 +16,9 @@ import torch.nn as nn
 
 from .. import ops
 
-# network.py:7-24: every activation the reference's `get_activation` knows, as epilogues of the Linear kernels.  The fused
-# point-cloud / voxel encoders (PointNet, PointNet2, Conv3DNet) are tanh kernels -- every shipped cfg's activation.
+# network.py:7-24: every activation the reference's `get_activation` knows, as epilogues of the Linear kernels and in the fused
+# PointNet encoder (tanh: the tuned kernels; the others: their generic instantiation).  The plug-in backbones that are absent
+# from the reference (PointNet2, SparseUNet) and the Conv3DNet stencil kernels are tanh kernels -- every shipped cfg's activation.
 _LINEAR_ACT = {"tanh": ops.ACT_TANH, "relu": ops.ACT_RELU, "crelu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "elu": ops.ACT_ELU,
                "selu": ops.ACT_SELU, "sigmoid": ops.ACT_SIGMOID}
 _SUPPORTED_ACT = {"tanh": ops.ACT_TANH}
@@ -294,9 +295,13 @@ class PointNet(_HipNet):
         self.save_h2 = bool(net_cfg.get('save_h2', True))
         if self.precision not in ('f32', 'bf16x3', 'bf16x6'):
             raise ValueError(f"PointNet precision '{self.precision}'")
-        _act_code(act)
-        object.__setattr__(self, "_head", _LinearChain([self.final_mlp[0], self.final_mlp[2], self.final_mlp[4]],
-                                                       _act_code(act)))
+        # every activation of get_activation (network.py:7-24): tanh runs the tuned packed-tanh encoder kernels, the others
+        # their generic instantiation (pm_act / pm_dact); the split-bf16 forwards are tanh kernels
+        code = _act_code(act, linear_only=True)
+        if self.precision != 'f32' and code != ops.ACT_TANH:
+            raise NotImplementedError(f"PointNet precision '{self.precision}' is a tanh kernel; activation '{act}' runs on 'f32'")
+        object.__setattr__(self, "_act", code)
+        object.__setattr__(self, "_head", _LinearChain([self.final_mlp[0], self.final_mlp[2], self.final_mlp[4]], code))
         object.__setattr__(self, "_enc_grads", None)
         object.__setattr__(self, "_packed", None)
         object.__setattr__(self, "_packed3", None)
@@ -354,7 +359,7 @@ class PointNet(_HipNet):
         else:
             ops.pointnet_enc_fwd(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
                                  self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].bias.data, packed,
-                                 self.max_mean_concat, feat, argmax, h2)
+                                 self.max_mean_concat, feat, argmax, h2, self._act)
         if self.proprio_shape != 0:
             feat[:, self.feat_dim:].copy_(x[:, -self.proprio_shape:])     # network.py:166-168,193-194
         object.__setattr__(self, "_saved", (x, feat, argmax, h2))
@@ -368,7 +373,7 @@ class PointNet(_HipNet):
         g = self._enc_grads
         ops.pointnet_enc_bwd(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
                              self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].weight.data, self._packed,
-                             self.max_mean_concat, dfeat, argmax, g[0], g[1], g[2], g[3], g[4], g[5], ws, h2)
+                             self.max_mean_concat, dfeat, argmax, g[0], g[1], g[2], g[3], g[4], g[5], ws, h2, self._act)
 
 
 def _pad4(n):

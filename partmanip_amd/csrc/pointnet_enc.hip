@@ -97,6 +97,24 @@ __device__ __forceinline__ void cloud_centroid(const float* __restrict__ xb, int
     cen[2] = (float)(s2 / P);
 }
 
+// ---- activation of the shared per-point MLP (network.py:147-153: `activation` = any of get_activation's seven) -----------
+// TANH = true: the tuned path (packed tanh, 1 - h^2) -- every shipped cfg; false: pm_act / pm_dact with the runtime code.
+template <bool TANH>
+__device__ __forceinline__ f32x2 pn_act2(float a, float b, int act) {
+    if constexpr (TANH) return pm_tanh2(a, b);
+    else return (f32x2){pm_act(a, act), pm_act(b, act)};
+}
+template <bool TANH>
+__device__ __forceinline__ float pn_act1(float a, int act) {
+    if constexpr (TANH) return pm_tanh(a);
+    else return pm_act(a, act);
+}
+template <bool TANH>
+__device__ __forceinline__ float pn_dact(float h, int act) {                  // derivative through the OUTPUT h
+    if constexpr (TANH) return 1.0f - h * h;
+    else return pm_dact(h, act);
+}
+
 // stage one tile of TM points (C floats each) into Xs[TM][PN_MAXC], optionally re-centred
 template <int TM, int NT>
 __device__ __forceinline__ void stage_points(const float* __restrict__ xb, int tile, int C, int sub_mean,
@@ -114,9 +132,9 @@ __device__ __forceinline__ void stage_points(const float* __restrict__ xb, int t
 
 // layer 1: thread (c = tid&127, part = tid>>7) computes tanh(b1[c] + W1[c,:] . x[p,:]) for its PPT points.
 // CT = compile-time channel count (3: xyz clouds, 4: depth_sparse); 0 = generic runtime C <= 8.
-template <int CT, int TM, int NT>
+template <int CT, int TM, int NT, bool TANH = true>
 __device__ __forceinline__ void layer1_tile(const float* __restrict__ Xs, const float* __restrict__ W1,
-                                            const float* __restrict__ b1, int C, float* __restrict__ H1) {
+                                            const float* __restrict__ b1, int C, float* __restrict__ H1, int act = PM_ACT_TANH) {
     constexpr int PPT = TM * 128 / NT;           // points per thread
     const int c = threadIdx.x & 127, p0 = (threadIdx.x >> 7) * PPT;
     const float b1c = b1[c];
@@ -137,7 +155,7 @@ __device__ __forceinline__ void layer1_tile(const float* __restrict__ Xs, const 
                 if (CT == 4) s = fmaf(w[3], xv.w, s);
                 s2[j] = s;
             }
-            const f32x2 t = pm_tanh2(s2[0], s2[1]);
+            const f32x2 t = pn_act2<TANH>(s2[0], s2[1], act);
             H1[p * PN_LD1 + c] = t.x;
             H1[(p + 1) * PN_LD1 + c] = t.y;
         }
@@ -150,7 +168,7 @@ __device__ __forceinline__ void layer1_tile(const float* __restrict__ Xs, const 
             float s = b1c;                     // Xs slots d >= C are zero-filled by stage_points
             s = fmaf(w1[0], x0.x, s); s = fmaf(w1[1], x0.y, s); s = fmaf(w1[2], x0.z, s); s = fmaf(w1[3], x0.w, s);
             s = fmaf(w1[4], x1.x, s); s = fmaf(w1[5], x1.y, s); s = fmaf(w1[6], x1.z, s); s = fmaf(w1[7], x1.w, s);
-            H1[p * PN_LD1 + c] = pm_tanh(s);
+            H1[p * PN_LD1 + c] = pn_act1<TANH>(s, act);
         }
     }
 }
@@ -164,9 +182,9 @@ __device__ __forceinline__ void layer2_mfma(const float* __restrict__ H1, const 
 }
 
 // layer 2 epilogue: H2[row][ch] = tanh(acc + b2[ch])
-template <int MB, int NB>
+template <int MB, int NB, bool TANH = true>
 __device__ __forceinline__ void layer2_store(const f32x16 (&acc)[MB][NB], const float* __restrict__ b2, int wave, int lane,
-                                             float* __restrict__ H2, float* __restrict__ h2_global = nullptr) {
+                                             float* __restrict__ H2, float* __restrict__ h2_global = nullptr, int act = PM_ACT_TANH) {
     const int li = lane & 31, lh = lane >> 5;
     float b2v[NB];
 #pragma unroll
@@ -177,7 +195,7 @@ __device__ __forceinline__ void layer2_store(const f32x16 (&acc)[MB][NB], const 
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const f32x2 v2 = pm_tanh2(acc[mb][nb][r] + b2v[nb], acc[mb][nb][r + 1] + b2v[nb]);
+                const f32x2 v2 = pn_act2<TANH>(acc[mb][nb][r] + b2v[nb], acc[mb][nb][r + 1] + b2v[nb], act);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int row = mb * 32 + ((r + j) & 3) + 8 * ((r + j) >> 2) + 4 * lh;
@@ -193,7 +211,7 @@ __device__ __forceinline__ void layer2_store(const f32x16 (&acc)[MB][NB], const 
 // threads, 64 channels per wave in layer 3, <=128 VGPRs) puts FOUR waves on every SIMD (two
 // work-groups per CU), so VALU / LDS / barrier phases of one wave hide under the MFMA phases of
 // three others; NW = 4 (128 channels per wave, 256 VGPRs, two waves per SIMD) is kept for A/B.
-template <int CT, int NW>
+template <int CT, int NW, bool TANH = true>
 __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __restrict__ x, long ldx, int P, int C,
                                                                   int sub_mean, const float* __restrict__ W1,
                                                                   const float* __restrict__ b1,
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
                                                                   const float* __restrict__ packed, int max_mean,
                                                                   float* __restrict__ feat, long ldf,
                                                                   int32_t* __restrict__ argmax,
-                                                                  float* __restrict__ h2_save) {
+                                                                  float* __restrict__ h2_save, int act) {
     constexpr int NT = NW * 64, NB2 = 8 / NW, NB3 = 16 / NW;
     __shared__ __attribute__((aligned(16))) float smem[PN_TM * PN_LD2 + PN_TM * PN_MAXC + 32];
     float* H = smem;                             // H1 [64][132] then H2 [64][260] (aliased)
@@ -237,7 +255,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
         asm volatile("" : "+v"(lane));
         const int li = lane & 31, lh = lane >> 5;
         __syncthreads();                          // Xs staged; previous tile's layer-3 reads of H are done
-        layer1_tile<CT, PN_TM, NT>(Xs, W1, b1, C, H);
+        layer1_tile<CT, PN_TM, NT, TANH>(Xs, W1, b1, C, H, act);
         __syncthreads();
         {
             f32x16 acc2[2][NB2];
@@ -246,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
             layer2_mfma<2, NB2>(H, P2v, wave, lane, acc2);
 #endif
             __syncthreads();                      // every wave has finished reading H1 (and Xs)
-            layer2_store<2, NB2>(acc2, b2, wave, lane, H);
+            layer2_store<2, NB2, TANH>(acc2, b2, wave, lane, H, nullptr, act);
             if (tile + 1 < ntiles) stage_points<PN_TM, NT>(xb, tile + 1, C, sub_mean, cen, Xs);
         }
         __syncthreads();
@@ -319,20 +337,27 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
 extern "C" int pm_pointnet_enc_fwd_f32(const float* x, long ldx, int B, int P, int C, int sub_mean,
                                        const float* W1, const float* b1, const float* b2, const float* b3,
                                        const float* packed, int max_mean, float* feat, long ldf, int32_t* argmax,
-                                       float* h2_save, void* stream) {
+                                       float* h2_save, int act, void* stream) {
     PM_REQUIRE(x && W1 && b1 && b2 && b3 && packed && feat && argmax);
+    PM_REQUIRE(act > PM_ACT_NONE && act <= PM_ACT_MAX);
     if (h2_save && ((uintptr_t)h2_save & 15) != 0) return PM_EALIGN;
     PM_REQUIRE(B > 0 && P > 0 && P % PN_TM == 0 && C >= 1 && C <= PN_MAXC && ldx >= (long)P * C);
     PM_REQUIRE(ldf >= PN_C3 * (max_mean ? 2 : 1));
     PM_REQUIRE(!sub_mean || C >= 3);
     if (((uintptr_t)packed & 15) != 0) return PM_EALIGN;
-#define PN_FWD_LAUNCH(CT)                                                                                  \
-    hipLaunchKernelGGL((pn_fwd_kernel<CT, PN_FWD_NW>), dim3(B), dim3(PN_FWD_NW * 64), 0, pm_stream(stream), x, ldx, P, \
-                       C, sub_mean, W1, b1, b2, b3, packed, max_mean, feat, ldf, argmax, h2_save)
+#define PN_FWD_LAUNCH_(CT, TH)                                                                             \
+    hipLaunchKernelGGL((pn_fwd_kernel<CT, PN_FWD_NW, TH>), dim3(B), dim3(PN_FWD_NW * 64), 0, pm_stream(stream), x, ldx, P, \
+                       C, sub_mean, W1, b1, b2, b3, packed, max_mean, feat, ldf, argmax, h2_save, act)
+#define PN_FWD_LAUNCH(CT)                        \
+    do {                                         \
+        if (act == PM_ACT_TANH) PN_FWD_LAUNCH_(CT, true); \
+        else PN_FWD_LAUNCH_(CT, false);          \
+    } while (0)
     if (C == 3) PN_FWD_LAUNCH(3);
     else if (C == 4) PN_FWD_LAUNCH(4);
     else PN_FWD_LAUNCH(0);
 #undef PN_FWD_LAUNCH
+#undef PN_FWD_LAUNCH_
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
@@ -413,14 +438,14 @@ __device__ __forceinline__ void bitonic_sort_512(int* keys) {
 // SAVED: h2 comes from HBM (written by the training forward) instead of a layer-2 recompute: one MFMA phase and
 // one barrier less per tile, and the row-owner pass reads its rows straight from global memory (1 KB coalesced
 // rows, issued before the tile's first barrier) -- it no longer waits for other waves' layer-2 output.
-template <int CT, bool SAVED>
+template <int CT, bool SAVED, bool TANH = true>
 __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
     const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
     const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ W3,
     const float* __restrict__ packed, int max_mean, const float* __restrict__ dfeat, long ldf,
     const int32_t* __restrict__ argmax, const float* __restrict__ U, float* __restrict__ H2sum,
     float* __restrict__ Hg, int32_t* __restrict__ slotmap, PnBwdPart* __restrict__ parts,
-    const float* __restrict__ h2_saved) {
+    const float* __restrict__ h2_saved, int act) {
     constexpr int BT = PN_BT;
     __shared__ __attribute__((aligned(16))) float smem[BT * PN_LD1 * 2 + BT * PN_LD2 + 2 * BT * PN_MAXC + PN_C2 + PN_C3 +
                                                         PN_C3 + 520 + 4 * PN_C2 + 16];
@@ -518,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                 h_nx2 = *(const float4*)(hsrc + PN_C2);
             }
             __syncthreads();                               // (A) Xs staged; DZ1 of tile t-1 complete; H1/H2 free
-            layer1_tile<CT, BT, 256>(Xs, W1, b1, C, H1);
+            layer1_tile<CT, BT, 256, TANH>(Xs, W1, b1, C, H1, act);
             if (tile > 0) PN_DW1_ACCUM(Xo)
             if (!SAVED) {
                 __syncthreads();                           // (B)
@@ -527,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
 #if !(PN_ABLATE & 32)
                 layer2_mfma<1, 2>(H1, P2v, wave, lane, acc2);
 #endif
-                layer2_store<1, 2>(acc2, b2, wave, lane, H2);
+                layer2_store<1, 2, TANH>(acc2, b2, wave, lane, H2, nullptr, act);
                 if (tile + 1 < ntiles) stage_points<BT, 256>(xb, tile + 1, C, sub_mean, cen, Xo);
                 __syncthreads();                           // (C)
             }
@@ -588,10 +613,10 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                         S.x += g * w3.x; S.y += g * w3.y; S.z += g * w3.z; S.w += g * w3.w;
                     }
                     float4 dz;
-                    dz.x = (u4.x + S.x) * (1.0f - h.x * h.x);
-                    dz.y = (u4.y + S.y) * (1.0f - h.y * h.y);
-                    dz.z = (u4.z + S.z) * (1.0f - h.z * h.z);
-                    dz.w = (u4.w + S.w) * (1.0f - h.w * h.w);
+                    dz.x = (u4.x + S.x) * pn_dact<TANH>(h.x, act);
+                    dz.y = (u4.y + S.y) * pn_dact<TANH>(h.y, act);
+                    dz.z = (u4.z + S.z) * pn_dact<TANH>(h.z, act);
+                    dz.w = (u4.w + S.w) * pn_dact<TANH>(h.w, act);
                     *(float4*)hrow = dz;
                     db2acc.x += dz.x; db2acc.y += dz.y; db2acc.z += dz.z; db2acc.w += dz.w;
                 }
@@ -636,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void pn_bwd_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * lh, col = wave * 32 + li;
                     const float h = H1[row * PN_LD1 + col];
-                    DZ1[row * PN_LD1 + col] = accH[0][0][r] * (1.0f - h * h);
+                    DZ1[row * PN_LD1 + col] = accH[0][0][r] * pn_dact<TANH>(h, act);
                 }
             }
         }
@@ -824,14 +849,14 @@ extern "C" int pm_debug_pn_prof_read(void* dst) {
 #else
 #define PN_STAMP(i)
 #endif
-template <int CT>
+template <int CT, bool TANH = true>
 __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
     const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
     const float* __restrict__ b1, const float* __restrict__ W3, const float* __restrict__ packed, int max_mean,
     const float* __restrict__ dfeat, long ldf, const int32_t* __restrict__ argmax, const float* __restrict__ U,
     float* __restrict__ H2sum, float* __restrict__ Hg, const int32_t* __restrict__ keys_g,
     const unsigned short* __restrict__ offs_g, PnBwdPart* __restrict__ parts, const float* __restrict__ h2_saved,
-    const float* __restrict__ Sg) {
+    const float* __restrict__ Sg, int act) {
     constexpr int BT = 32, NT = 1024, NW = 16, RPW = BT / NW, PPT = BT * PN_C1 / NT;
     static_assert(RPW == 2, "the row-owner pass finds its two rows' slots at the ends of the wave's key run");
     constexpr int NXC = (CT == 3 || CT == 4) ? 4 : PN_MAXC;      // point coordinates that can be non-zero
@@ -935,7 +960,7 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
                 }
 #pragma unroll
                 for (int i = 0; i < PPT; i += 2) {
-                    const f32x2 t = pm_tanh2(z[i], z[i + 1]);
+                    const f32x2 t = pn_act2<TANH>(z[i], z[i + 1], act);
                     H1n[(p0 + i) * PN_LD1 + c] = t.x;
                     H1n[(p0 + i + 1) * PN_LD1 + c] = t.y;
                 }
@@ -949,10 +974,10 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
                     if (slot[rr] >= 0)                                 // this point is some channel's arg-max
                         *(float4*)(Hg + ((long)b * PN_C3 + slot[rr]) * PN_C2 + 4 * lane) = h;
                     float4 dz;
-                    dz.x = (u4.x + S.x) * (1.0f - h.x * h.x);
-                    dz.y = (u4.y + S.y) * (1.0f - h.y * h.y);
-                    dz.z = (u4.z + S.z) * (1.0f - h.z * h.z);
-                    dz.w = (u4.w + S.w) * (1.0f - h.w * h.w);
+                    dz.x = (u4.x + S.x) * pn_dact<TANH>(h.x, act);
+                    dz.y = (u4.y + S.y) * pn_dact<TANH>(h.y, act);
+                    dz.z = (u4.z + S.z) * pn_dact<TANH>(h.z, act);
+                    dz.w = (u4.w + S.w) * pn_dact<TANH>(h.w, act);
                     *(float4*)(H2n + (wave * RPW + rr) * PN_LD2 + 4 * lane) = dz;
                     db2acc.x += dz.x; db2acc.y += dz.y; db2acc.z += dz.z; db2acc.w += dz.w;
                 }
@@ -1030,7 +1055,7 @@ __global__ __launch_bounds__(1024, 1) void pn_bwd16_kernel(
                 for (int r = 0; r < 8; ++r) {
                     const int row = (r >> 2) * 16 + 4 * q + (r & 3);
                     const float h = H1c[row * PN_LD1 + col];
-                    const float dz = (r < 4 ? acc0[r & 3] : acc1[r & 3]) * (1.0f - h * h);
+                    const float dz = (r < 4 ? acc0[r & 3] : acc1[r & 3]) * pn_dact<TANH>(h, act);
                     const float4 x0 = *(const float4*)(Xs + row * PN_MAXC);
                     db1acc += dz;
                     dW1acc[0] = fmaf(dz, x0.x, dW1acc[0]);
@@ -1265,9 +1290,10 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
                                        const float* W1, const float* b1, const float* b2, const float* W3,
                                        const float* packed, int max_mean, const float* dfeat, long ldf,
                                        const int32_t* argmax, float* dW1, float* db1, float* dW2, float* db2,
-                                       float* dW3, float* db3, const float* h2_saved, void* workspace,
+                                       float* dW3, float* db3, const float* h2_saved, int act, void* workspace,
                                        size_t workspace_bytes, void* stream) {
     PM_REQUIRE(x && W1 && b1 && b2 && W3 && packed && dfeat && argmax && dW1 && db1 && dW2 && db2 && dW3 && db3);
+    PM_REQUIRE(act > PM_ACT_NONE && act <= PM_ACT_MAX);
     if (h2_saved && ((uintptr_t)h2_saved & 15) != 0) return PM_EALIGN;
     PM_REQUIRE(B > 0 && P > 0 && P % PN_TM == 0 && P <= 4096 && C >= 1 && C <= PN_MAXC && ldx >= (long)P * C);
     PM_REQUIRE(ldf >= PN_C3 * (max_mean ? 2 : 1));
@@ -1296,22 +1322,33 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
         float* Sg = (float*)(ws + w.off_Sg);
         hipLaunchKernelGGL(pn_bwd_prep_kernel, dim3(B), dim3(256), 0, pm_stream(stream), argmax, P, keys_g, offs_g, slotmap,
                            dfeat, ldf, W3, Sg);
-#define PN_BWD16_LAUNCH(CT)                                                                                            \
-    hipLaunchKernelGGL((pn_bwd16_kernel<CT>), dim3(G), dim3(1024), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, \
+#define PN_BWD16_LAUNCH_(CT, TH)                                                                                       \
+    hipLaunchKernelGGL((pn_bwd16_kernel<CT, TH>), dim3(G), dim3(1024), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, \
                        W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, (const int32_t*)keys_g,                    \
-                       (const unsigned short*)offs_g, parts, h2_saved, (const float*)Sg)
+                       (const unsigned short*)offs_g, parts, h2_saved, (const float*)Sg, act)
+#define PN_BWD16_LAUNCH(CT)                          \
+    do {                                             \
+        if (act == PM_ACT_TANH) PN_BWD16_LAUNCH_(CT, true); \
+        else PN_BWD16_LAUNCH_(CT, false);            \
+    } while (0)
         if (C == 3) PN_BWD16_LAUNCH(3);
         else if (C == 4) PN_BWD16_LAUNCH(4);
         else PN_BWD16_LAUNCH(0);
 #undef PN_BWD16_LAUNCH
+#undef PN_BWD16_LAUNCH_
     } else {
-#define PN_BWD_LAUNCH_(CT, SV)                                                                                   \
-    hipLaunchKernelGGL((pn_bwd_kernel<CT, SV>), dim3(G), dim3(256), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, \
-                       b1, b2, W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, slotmap, parts, h2_saved)
-#define PN_BWD_LAUNCH(CT)                       \
-    do {                                        \
-        if (h2_saved) PN_BWD_LAUNCH_(CT, true); \
-        else PN_BWD_LAUNCH_(CT, false);         \
+#define PN_BWD_LAUNCH_(CT, SV, TH)                                                                               \
+    hipLaunchKernelGGL((pn_bwd_kernel<CT, SV, TH>), dim3(G), dim3(256), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, \
+                       b1, b2, W3, packed, max_mean, dfeat, ldf, argmax, U, H2sum, Hg, slotmap, parts, h2_saved, act)
+#define PN_BWD_LAUNCH(CT)                                                      \
+    do {                                                                       \
+        if (act == PM_ACT_TANH) {                                              \
+            if (h2_saved) PN_BWD_LAUNCH_(CT, true, true);                      \
+            else PN_BWD_LAUNCH_(CT, false, true);                              \
+        } else {                                                               \
+            if (h2_saved) PN_BWD_LAUNCH_(CT, true, false);                     \
+            else PN_BWD_LAUNCH_(CT, false, false);                             \
+        }                                                                      \
     } while (0)
     if (C == 3) PN_BWD_LAUNCH(3);
     else if (C == 4) PN_BWD_LAUNCH(4);

@@ -318,14 +318,16 @@ def pointnet_pack(w2, w3, packed):
     check(lib.pm_pointnet_pack_weights_f32(_ptr(w2), _ptr(w3), _ptr(packed), _stream()), "pm_pointnet_pack_weights_f32")
 
 
-def pointnet_enc_fwd(x, P, Cc, sub_mean, w1, b1, b2, b3, packed, max_mean, feat, argmax, h2_save=None):
-    """h2_save: optional (B, P, 256) buffer the training forward fills with the layer-2 activations."""
+def pointnet_enc_fwd(x, P, Cc, sub_mean, w1, b1, b2, b3, packed, max_mean, feat, argmax, h2_save=None, act=None):
+    """h2_save: optional (B, P, 256) buffer the training forward fills with the layer-2 activations; act: ACT_* of the
+    two hidden layers (default tanh)."""
     _req(x, w1, b1, b2, b3, packed, feat, argmax, h2_save)
     B = x.shape[0]
     with TIMER.bracket("pointnet_enc_fwd"):
         check(lib.pm_pointnet_enc_fwd_f32(_ptr(x), _rows(x, "x"), B, P, Cc, int(sub_mean), _ptr(w1), _ptr(b1), _ptr(b2),
                                           _ptr(b3), _ptr(packed), int(max_mean), _ptr(feat), _rows(feat, "feat"),
-                                          _ptr(argmax), _ptr(h2_save), _stream()), "pm_pointnet_enc_fwd_f32")
+                                          _ptr(argmax), _ptr(h2_save), int(ACT_TANH if act is None else act), _stream()),
+              "pm_pointnet_enc_fwd_f32")
 
 
 def pointnet_pack_bf3(w2, w3, packed):
@@ -357,7 +359,7 @@ def pointnet_enc_fwd_bf6(x, P, Cc, sub_mean, w1, b1, b2, b3, packed, max_mean, f
 
 
 def pointnet_enc_bwd(x, P, Cc, sub_mean, w1, b1, b2, w3, packed, max_mean, dfeat, argmax, dw1, db1, dw2, db2, dw3, db3,
-                     ws, h2_saved=None):
+                     ws, h2_saved=None, act=None):
     _req(x, w1, b1, b2, w3, packed, dfeat, argmax, dw1, db1, dw2, db2, dw3, db3, h2_saved)
     B = x.shape[0]
     w = ws.get(lib.pm_pointnet_enc_bwd_workspace_bytes(B, P, Cc) + 256)
@@ -367,7 +369,8 @@ def pointnet_enc_bwd(x, P, Cc, sub_mean, w1, b1, b2, w3, packed, max_mean, dfeat
         check(lib.pm_pointnet_enc_bwd_f32(_ptr(x), _rows(x, "x"), B, P, Cc, int(sub_mean), _ptr(w1), _ptr(b1), _ptr(b2),
                                           _ptr(w3), _ptr(packed), int(max_mean), _ptr(dfeat), _rows(dfeat, "dfeat"),
                                           _ptr(argmax), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(dw3),
-                                          _ptr(db3), _ptr(h2_saved), base + al, w.numel() - al, _stream()),
+                                          _ptr(db3), _ptr(h2_saved), int(ACT_TANH if act is None else act), base + al,
+                                          w.numel() - al, _stream()),
               "pm_pointnet_enc_bwd_f32")
 
 

@@ -189,8 +189,15 @@ def test_mlp_activation_set_forward_and_gradients(act):
         assert err < 3e-4, (act, k, err)
 
 
-def test_fused_encoders_reject_other_activations_loudly():
+def test_plug_in_encoders_reject_other_activations_loudly():
+    """The reference's own backbones (MLP, PointNet) take every activation of network.py:7-24; the plug-in backbones that
+    are absent from the reference (PointNet2, SparseUNet), the Conv3DNet stencils and the split-bf16 PointNet forwards are
+    tanh kernels and say so instead of computing something else."""
     from partmanip_amd.algo_utils import ActorCritic
-    with pytest.raises(NotImplementedError, match="tanh"):
-        ActorCritic(3072, 4, dict(action_std=0.5, action_activate="tanh", clipAction=1.0,
-                                  network=dict(name="PointNet", activation="relu", max_mean=True, sub_mean=False)))
+    model = lambda net: dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net)
+    for net, O in ((dict(name="PointNet2", activation="relu"), 3072),
+                   (dict(name="SparseUNet", activation="elu", point_num=96, grid=14), 4 * 96),
+                   (dict(name="PointNet", activation="relu", max_mean=True, sub_mean=False, precision="bf16x6"), 3072)):
+        with pytest.raises(NotImplementedError, match="tanh"):
+            ActorCritic(O, 4, model(net))
+    ActorCritic(3072, 4, model(dict(name="PointNet", activation="relu", max_mean=True, sub_mean=False)))      # fp32 kernels: fine

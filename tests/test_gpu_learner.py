@@ -237,6 +237,46 @@ def test_pointnet_forward_backward(B, C, max_mean, sub_mean, proprio, P):
     record_margin("encoder parameter gradients (max abs / max|ref|)", worst, 1e-4)
 
 
+@pytest.mark.parametrize("act", ["relu", "elu", "selu", "lrelu", "sigmoid", "crelu"])
+@pytest.mark.parametrize("save_h2", [True, False])
+def test_pointnet_other_activations_match_the_oracle(act, save_h2):
+    """network.py:144,147-160 builds PointNet with ANY of get_activation's seven activations (network.py:7-24); the fused
+    encoder kernels' generic instantiation (pm_act / pm_dact instead of the packed tanh) against the oracle: forward, pooled
+    features, arg-max and every parameter gradient, through the saved-layer-2 backward (pn_bwd16_kernel) and the recomputing
+    one (pn_bwd_kernel).  max + mean pooling, per-cloud centring, proprio columns."""
+    from partmanip_amd.algo_utils import ActorCritic
+    B, C, P, proprio = 5, 3, 1024, 6
+    net = dict(name="PointNet", activation=act, max_mean=True, sub_mean=True, save_h2=save_h2)
+    O = P * C + proprio
+    torch.manual_seed(77)
+    ac = ActorCritic(O, 10, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net), proprio).to(DEV)
+    f = ac.flat()
+    g = torch.Generator().manual_seed(5)
+    pts = torch.rand(B, P, C, generator=g) * 2 - 1 + (torch.rand(B, 1, C, generator=g) - 0.5)
+    x = torch.cat([pts.reshape(B, -1), torch.randn(B, proprio, generator=g)], dim=1).contiguous()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in ac.state_dict().items()}
+    out_ref = R.pointnet_forward(p, "actor", net, x.clone(), proprio, point_num=P)
+    dy = torch.randn(B, 10, generator=g)
+    names = [k for k in p if k.startswith("actor.")]
+    out = ac.actor.hip_forward(x.to(DEV))
+    record_margin(f"encoder output, activation {act} (max abs / max|ref|)", rel_err(out, out_ref.detach()), 2e-5)
+    assert rel_err(out, out_ref.detach()) < 2e-5
+    out_pin = R.pointnet_forward(p, "actor", net, x.clone(), proprio, point_num=P, argmax_override=ac.actor._saved[2].cpu().long())
+    assert rel_err(out_pin.detach(), out_ref.detach()) < 1e-6          # the kernel's arg-max is (numerically) torch.max's
+    grads_ref = torch.autograd.grad((out_pin * dy).sum(), [p[k] for k in names])
+    ac.actor.hip_backward(dy.to(DEV))
+    views, off = {}, 0
+    for k, v in ac.actor.named_parameters():
+        views["actor." + k] = f["grad_actor"][off:off + v.numel()].view(v.shape)
+        off += v.numel()
+    worst = 0.0
+    for k, gr in zip(names, grads_ref):
+        e = rel_err(views[k], gr)
+        worst = max(worst, e)
+        assert e < 1e-4, (act, k, e)
+    record_margin(f"encoder parameter gradients, activation {act} (max abs / max|ref|)", worst, 1e-4)
+
+
 def test_pointnet_full_batch_properties():
     """BASELINE size (B=2048 clouds x 1024 pts): permuting the points of every cloud leaves the max
     features bit-identical, the mean features equal to rounding, and maps argmax through the permutation."""
