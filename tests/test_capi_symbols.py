@@ -52,7 +52,7 @@ def test_argument_validation_without_gpu():
     from partmanip_amd._lib import lib
     assert lib.pm_gae_scan_f32(None, None, None, None, None, None, None, 4, 4, 0.99, 0.94, 0, 0.0, None) == -1
     assert lib.pm_linear_fwd_f32(None, 0, None, 0, None, None, 0, 1, 1, 1, 0, None) == -1
-    assert lib.pm_pointnet_enc_fwd_f32(None, 0, 1, 1000, 3, 0, None, None, None, None, None, 1, None, 0, None, None, None) == -1
+    assert lib.pm_pointnet_enc_fwd_f32(None, 0, 1, 1000, 3, 0, None, None, None, None, None, 1, None, 0, None, None, 1, None) == -1
     assert lib.pm_pointnet_packed_elems() == 196608 + 32768 + 1024      # fwd W2|W3, bwd W2^T in two MFMA operand orders, pad
     assert lib.pm_moments_workspace_bytes(10) >= 16
     assert lib.pm_fps_workspace_bytes(2, 1024) == 0 and lib.pm_fps_workspace_bytes(2, 20000) == 160000
