@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 135 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 137 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -484,7 +484,11 @@ int pm_rms_apply_moments_f32(const double* mom, long n_rows, int D, int n_new, f
  *     self_col >= 0: rows with tidx[r][self_col] != r get 0 (duplicates are nobody's neighbour).  Fixed summation order. */
 int pm_voxel_grid0_f32(const float* x, long ldx, int B, int P, int C, int R, int32_t* grid, int32_t* coords, float* feat,
                        void* stream);
-int pm_voxel_nbr27_i32(const int32_t* coords, long rows, const int32_t* grid, int R, int32_t* nbr, void* stream);
+int pm_voxel_nbr27_i32(const int32_t* coords, long rows, const int32_t* grid, int R, int32_t* nbr,
+                       int ld /* row stride of nbr, >= 27; columns 27 .. ld-1 are written as -1 (padding taps) */, void* stream);
+/* out[r][o] = nbr[r][26 - o] where row r is the canonical row of its cell (nbr[r][13] == r), else -1: the table the data
+ * gradient of a 3^3 submanifold convolution gathers through (pm_sparse_conv_bwd_data_f32). */
+int pm_voxel_mirror27_i32(const int32_t* nbr, long rows, int32_t* out, void* stream);
 int pm_voxel_down_count_i32(const int32_t* coords_f, long rows_f, int B, int Rc, int32_t* grid_c, int32_t* counts, void* stream);
 int pm_voxel_down_build_i32(const int32_t* coords_f, long rows_f, const int32_t* grid_f, int Rf, int B, int Rc,
                             const int32_t* base, int32_t* grid_c, long rows_c, int32_t* coords_c, int32_t* child,
@@ -507,7 +511,8 @@ int pm_sparse_conv_bwd_data_f32(const float* dY, long lddy, const int32_t* idxT,
 /* Data gradient by scatter, for convolutions whose patches do not overlap (stride == kernel size): every input row is
  * idx[r][j] for at most one (r, j), so  dX[idx[r][j]][c] = (sum_co dY[r][co] * W[co][j*C + c]) * act'(H[idx[r][j]][c])
  * is one GEMM whose epilogue stores each 16-byte piece at its destination row (idx < 0: dropped; rows nobody maps to keep
- * their contents).  W = the tap-major weight (Cout x J*C) of the forward. */
+ * their contents).  W = the tap-major weight (Cout x J*C) of the forward.  accumulate: 0 = overwrite dsrc; 1 = add the (already multiplied) result to what dsrc holds; 2 = dsrc holds a RAW
+ * contribution that is added to the gathered sum BEFORE the activation derivative ((skip + strided) * act'). */
 int pm_sparse_conv_bwd_data_scatter_f32(const float* dY, long lddy, const float* W, long ldw, const int32_t* idx, long rows,
                                         int J, int C, int Cout, const float* H, float* dX, int act, void* stream);
 size_t pm_sparse_conv_bwd_weight_workspace_bytes(long rows, int N, int J, int C);

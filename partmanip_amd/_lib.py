@@ -88,7 +88,8 @@ SIGNATURES = {
     "pm_col2im3d_f32": (I, [P, I, I, I, I, I, I, I, I, L, L, L, L, L, P, P, I, P]),
     "pm_tsdf_integrate_f32": (I, [P, P, P, I, I, L, L, F, F, P, P]),
     "pm_voxel_grid0_f32": (I, [P, L, I, I, I, I, P, P, P, P]),
-    "pm_voxel_nbr27_i32": (I, [P, L, P, I, P, P]),
+    "pm_voxel_nbr27_i32": (I, [P, L, P, I, P, I, P]),
+    "pm_voxel_mirror27_i32": (I, [P, L, P, P]),
     "pm_voxel_down_count_i32": (I, [P, L, I, I, P, P, P]),
     "pm_voxel_down_build_i32": (I, [P, L, P, I, I, I, P, P, L, P, P, P, P, P, P]),
     "pm_rows_gather_f32": (I, [P, L, P, L, I, I, P, L, P]),
@@ -143,7 +144,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 135                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 137                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

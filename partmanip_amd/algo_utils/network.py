@@ -660,7 +660,11 @@ class SparseUNet(_HipNet):
         grid0, coords0, feat0 = ops.voxel_grid0(x, P, C, R)
         l1 = ops.voxel_down(coords0, grid0, R, B)
         l2 = ops.voxel_down(l1["coords"], l1["grid"], l1["R"], B)
-        return dict(feat0=feat0, nbr0=ops.voxel_nbr27(coords0, grid0, R), nbr1=ops.voxel_nbr27(l1["coords"], l1["grid"], l1["R"]),
+        # conv0's operand is 27 taps x 4 channels = 108 columns: the level-0 table is built 32 taps wide (five absent taps), so
+        # that the layer is four whole K-steps of the gathered GEMM without a padded copy of the table per forward
+        pad0 = 32 if (self.fused_gather and self.in_channels >= 3) else 27
+        nbr0p = ops.voxel_nbr27(coords0, grid0, R, pad0)
+        return dict(feat0=feat0, nbr0=nbr0p[:, :27], nbr0p=nbr0p, nbr1=ops.voxel_nbr27(l1["coords"], l1["grid"], l1["R"]),
                     nbr2=ops.voxel_nbr27(l2["coords"], l2["grid"], l2["R"]), l1=l1, l2=l2, rows=(B * P, l1["rows"], l2["rows"]))
 
     @staticmethod
@@ -668,8 +672,7 @@ class SparseUNet(_HipNet):
         """Mirrored neighbour table for the data gradient: row r reads s as neighbour j  <=>  s reads r as neighbour 26 - j,
         so the rows whose output used s are nbr[s].flip.  A row that is nobody's neighbour (a duplicate coordinate: its centre
         tap points at the canonical row, not at itself) gets -1 everywhere and a gradient of exactly zero."""
-        canon = nbr[:, 13] == torch.arange(nbr.shape[0], device=nbr.device, dtype=nbr.dtype)
-        return torch.where(canon[:, None], nbr.flip(1), torch.full_like(nbr, -1)).contiguous()
+        return ops.voxel_mirror27(nbr)
 
     def _conv_dgrad(self, name, dz, nbr, y_in, dx):
         """dx = d loss / d (pre-activation of the layer that produced y_in) of the 3^3 convolution `name`, dz its output
@@ -689,7 +692,7 @@ class SparseUNet(_HipNet):
         ops.linear_fwd(x, lin.weight.data, lin.bias.data, y, self._act)
         return y
 
-    def _conv(self, name, src, idx, C, y):
+    def _conv(self, name, src, idx, C, y, idx_pad=None):
         """Sparse convolution `name` of the rows of `src` through the neighbour table `idx` (rows, J): fused -- the gather runs
         inside the GEMM's LDS-DMA loader and the (rows x J*C) operand never reaches HBM -- when J*C is a multiple of the K-step
         (every layer but conv0, whose 108-wide operand is small); returns the materialised operand or None."""
@@ -701,8 +704,9 @@ class SparseUNet(_HipNet):
         if self.fused_gather and pad % C == 0:
             # conv0: 27 taps x 4 input channels = 108 columns; five absent taps (index -1 -> zero rows) and zero weight columns
             # make it 128 = four K-steps, and the layer runs fused like the others.  Returns the padded table for the
-            # weight gradient.
-            idx_p = torch.nn.functional.pad(idx, (0, pad // C), value=-1)
+            # weight gradient (geometry() builds the level-0 table that wide: `idx_pad`).
+            idx_p = idx_pad if (idx_pad is not None and idx_pad.shape[1] == idx.shape[1] + pad // C) else \
+                torch.nn.functional.pad(idx, (0, pad // C), value=-1)
             w_p = torch.zeros(lin.weight.shape[0], idx_p.shape[1] * C, device=src.device)
             w_p[:, :lin.weight.shape[1]].copy_(lin.weight.data)
             ops.sparse_conv_fwd(src, idx_p, C, w_p, lin.bias.data, y, self._act, self._zero(src.device))
@@ -741,6 +745,21 @@ class SparseUNet(_HipNet):
         with ops.TIMER.bracket("sparse_unet_bwd"):
             self._hip_backward(dy)
 
+    def _vcat_ok(self):
+        """The concatenated operands of up1 / up0 ([unpool(H2) | H1], [unpool(E1) | H0]) stay VIRTUAL when the coarse width is a
+        multiple of the skip width: both halves then live in one buffer of skip-width rows (the coarse matrix viewed as m rows
+        per voxel, the skip rows behind it) and the GEMM loader gathers (m + 1) 'taps' per output row -- no un-pooling copy, no
+        concatenated matrix in HBM.  fused_gather off, or other widths: the materialised form."""
+        c0, c1, c2 = self.channels
+        return self.fused_gather and c2 % c1 == 0 and c1 % c0 == 0 and (c2 + c1) % 32 == 0 and (c1 + c0) % 32 == 0
+
+    @staticmethod
+    def _vcat_table(parent, m, rows_hi):
+        """(rows, m + 1) gather table of a virtual [unpool | skip] operand: m chunks of the parent's row, then the row's own."""
+        r = torch.arange(parent.shape[0], device=parent.device, dtype=torch.int32)
+        p = parent.view(-1).to(torch.int32) * m
+        return torch.stack([p + k for k in range(m)] + [r + m * rows_hi], dim=1).contiguous()
+
     def _hip_forward(self, x, out=None):
         B, P = x.shape[0], self.point_num
         c0, c1, c2 = self.channels
@@ -748,28 +767,47 @@ class SparseUNet(_HipNet):
         g = self.geometry(x)
         R0, R1, R2 = g["rows"]
         e = lambda r, c: torch.empty(r, c, device=dev)
-        cat0 = e(R0, c1 + c0)                                   # [unpool(E1) | H0]
-        H0 = cat0[:, c1:]
-        cols0 = self._conv("conv0", g["feat0"], g["nbr0"], 4, H0)
+        vcat = self._vcat_ok()
+        if vcat:
+            m1, m0 = c2 // c1, c1 // c0
+            comb1 = e(m1 * R2 + R1, c1)                         # [H2 as m1 rows of c1 per voxel | H1]
+            comb0 = e(m0 * R1 + R0, c0)                         # [E1 as m0 rows of c0 per voxel | H0]
+            H2, H1 = comb1[:m1 * R2].view(R2, c2), comb1[m1 * R2:]
+            E1, H0 = comb0[:m0 * R1].view(R1, c1), comb0[m0 * R1:]
+            cat0 = cat1 = None
+        else:
+            cat0 = e(R0, c1 + c0)                               # [unpool(E1) | H0]
+            H0 = cat0[:, c1:]
+            cat1 = e(R1, c2 + c1)                               # [unpool(H2) | H1]
+            H1 = cat1[:, c2:]
+            H2, E1 = e(R2, c2), e(R1, c1)
+        cols0 = self._conv("conv0", g["feat0"], g["nbr0"], 4, H0, idx_pad=g["nbr0p"])
         D1 = e(R1, c1)
         colsd0 = self._conv("down0", H0, g["l1"]["child"], c0, D1)
-        cat1 = e(R1, c2 + c1)                                   # [unpool(H2) | H1]
-        H1 = cat1[:, c2:]
         cols1 = self._conv("conv1", D1, g["nbr1"], c1, H1)
         D2 = e(R2, c2)
         colsd1 = self._conv("down1", H1, g["l2"]["child"], c1, D2)
-        H2 = e(R2, c2)
         cols2 = self._conv("conv2", D2, g["nbr2"], c2, H2)
-        ops.rows_gather(H2, g["l2"]["parent"].view(-1, 1), c2, cat1[:, :c2])
-        E1 = self._lin("up1", cat1, e(R1, c1))
-        ops.rows_gather(E1, g["l1"]["parent"].view(-1, 1), c1, cat0[:, :c1])
-        E0 = self._lin("up0", cat0, e(R0, c0))
+        E0 = e(R0, c0)
+        if vcat:
+            g["up1_idx"] = self._vcat_table(g["l2"]["parent"], m1, R2)
+            g["up0_idx"] = self._vcat_table(g["l1"]["parent"], m0, R1)
+            lin = self.up1
+            ops.sparse_conv_fwd(comb1, g["up1_idx"], c1, lin.weight.data, lin.bias.data, E1, self._act, self._zero(dev))
+            lin = self.up0
+            ops.sparse_conv_fwd(comb0, g["up0_idx"], c0, lin.weight.data, lin.bias.data, E0, self._act, self._zero(dev))
+        else:
+            ops.rows_gather(H2, g["l2"]["parent"].view(-1, 1), c2, cat1[:, :c2])
+            self._lin("up1", cat1, E1)
+            ops.rows_gather(E1, g["l1"]["parent"].view(-1, 1), c1, cat0[:, :c1])
+            self._lin("up0", cat0, E0)
         fbuf = torch.empty(B, c0 + self.proprio_shape, device=dev)
         arg = ops.maxpool_rows(E0, B, P, fbuf[:, :c0])
         if self.proprio_shape != 0:
             fbuf[:, c0:].copy_(x[:, -self.proprio_shape:])
         object.__setattr__(self, "_saved", dict(g=g, cols0=cols0, cat0=cat0, colsd0=colsd0, D1=D1, cols1=cols1, cat1=cat1,
-                                                colsd1=colsd1, D2=D2, cols2=cols2, H2=H2, E0=E0, arg=arg, B=B))
+                                                colsd1=colsd1, D2=D2, cols2=cols2, H2=H2, E0=E0, arg=arg, B=B, vcat=vcat,
+                                                H0=H0, H1=H1, E1=E1, comb0=comb0 if vcat else None, comb1=comb1 if vcat else None))
         return self._head.forward(fbuf, out)
 
     def _hip_backward(self, dy):
@@ -781,31 +819,51 @@ class SparseUNet(_HipNet):
         dfbuf = torch.empty(B, c0 + self.proprio_shape, device=dy.device)
         self._head.backward(dy, ws, dx_out=dfbuf)
         dzE0 = ops.maxpool_rows_bwd(dfbuf[:, :c0], s["arg"], P, y_tanh=s["E0"])            # pre-activation gradient of up0
-        cat0, cat1 = s["cat0"], s["cat1"]
-        ops.linear_bwd_weight(dzE0, cat0, *self._g["up0"], ws)
-        dcat0 = torch.empty_like(cat0)
-        ops.linear_bwd_data(dzE0, W("up0"), cat0, dcat0, self._act)                        # tanh' of both halves folded in
-        dzE1 = ops.rows_gather_bwd(dcat0[:, :c1], g["l1"]["child"], c1, torch.empty_like(s["D1"]), mode=2)
-        ops.linear_bwd_weight(dzE1, cat1, *self._g["up1"], ws)
-        dcat1 = torch.empty_like(cat1)
-        ops.linear_bwd_data(dzE1, W("up1"), cat1, dcat1, self._act)
-        dzH2 = ops.rows_gather_bwd(dcat1[:, :c2], g["l2"]["child"], c2, torch.empty_like(s["D2"]), mode=2)
+        H0, H1 = s["H0"], s["H1"]
+        if s["vcat"]:
+            # the concatenated operands are virtual (see _vcat_ok): weight gradients gather them again; the data gradients are
+            # taken RAW (no activation derivative: nothing to read back) -- tanh' of the un-pooled half is applied after the sum
+            # over a coarse row's children, tanh' of the skip half after the strided layer's contribution has been added
+            # The un-pooled half by linearity: sum_children (dz[child] W_u) = (sum_children dz[child]) W_u -- the children's
+            # gradient rows are summed FIRST (c_out-wide rows, fixed order) and the GEMM runs on the coarse level's rows, so
+            # the (fine rows x c_hi) block of the data gradient is never formed.
+            zero = self._zero(dy.device)
+            e = lambda r, c: torch.empty(r, c, device=dy.device)
+            ops.sparse_conv_bwd_weight(dzE0, s["comb0"], g["up0_idx"], c0, *self._g["up0"], zero, ws)
+            sum0 = ops.rows_gather_bwd(dzE0, g["l1"]["child"], c0, e(s["D1"].shape[0], c0), mode=2)
+            dzE1 = ops.linear_bwd_data(sum0, W("up0")[:, :c1], s["E1"], e(s["D1"].shape[0], c1), self._act)
+            dzH0 = ops.linear_bwd_data(dzE0, W("up0")[:, c1:], None, e(dzE0.shape[0], c0), ops.ACT_NONE)      # skip half, raw
+            ops.sparse_conv_bwd_weight(dzE1, s["comb1"], g["up1_idx"], c1, *self._g["up1"], zero, ws)
+            sum1 = ops.rows_gather_bwd(dzE1, g["l2"]["child"], c1, e(s["D2"].shape[0], c1), mode=2)
+            dzH2 = ops.linear_bwd_data(sum1, W("up1")[:, :c2], s["H2"], e(s["D2"].shape[0], c2), self._act)
+            dzH1 = ops.linear_bwd_data(dzE1, W("up1")[:, c2:], None, e(dzE1.shape[0], c1), ops.ACT_NONE)
+            acc_mode = 2                                                                    # (skip + strided) * tanh'
+        else:
+            cat0, cat1 = s["cat0"], s["cat1"]
+            ops.linear_bwd_weight(dzE0, cat0, *self._g["up0"], ws)
+            dcat0 = torch.empty_like(cat0)
+            ops.linear_bwd_data(dzE0, W("up0"), cat0, dcat0, self._act)                    # tanh' of both halves folded in
+            dzE1 = ops.rows_gather_bwd(dcat0[:, :c1], g["l1"]["child"], c1, torch.empty_like(s["D1"]), mode=2)
+            ops.linear_bwd_weight(dzE1, cat1, *self._g["up1"], ws)
+            dcat1 = torch.empty_like(cat1)
+            ops.linear_bwd_data(dzE1, W("up1"), cat1, dcat1, self._act)
+            dzH2 = ops.rows_gather_bwd(dcat1[:, :c2], g["l2"]["child"], c2, torch.empty_like(s["D2"]), mode=2)
+            dzH1, dzH0 = dcat1[:, c2:], dcat0[:, c1:]
+            acc_mode = True                                                                 # skip part already pre-activation
         self._conv_wgrad("conv2", dzH2, s["D2"], g["nbr2"], c2, s["cols2"], ws)
         dzD2 = self._conv_dgrad("conv2", dzH2, g["nbr2"], s["D2"], torch.empty_like(s["D2"]))
-        self._conv_wgrad("down1", dzD2, cat1[:, c2:], g["l2"]["child"], c1, s["colsd1"], ws)
+        self._conv_wgrad("down1", dzD2, H1, g["l2"]["child"], c1, s["colsd1"], ws)
         dcolsd1 = torch.empty(dzD2.shape[0], 8 * c1, device=dy.device)
         ops.linear_bwd_data(dzD2, W("down1"), None, dcolsd1, ops.ACT_NONE)
-        dzH1 = dcat1[:, c2:]                                                                # skip part (already pre-activation)
         ops.rows_gather_bwd(dcolsd1, g["l2"]["parent_canon"].view(-1, 1), c1, dzH1, tslot=g["l2"]["slot"].view(-1, 1), mode=1,
-                            y_tanh=cat1[:, c2:], accumulate=True)
+                            y_tanh=H1, accumulate=acc_mode)
         self._conv_wgrad("conv1", dzH1, s["D1"], g["nbr1"], c1, s["cols1"], ws)
         dzD1 = self._conv_dgrad("conv1", dzH1, g["nbr1"], s["D1"], torch.empty_like(s["D1"]))
-        self._conv_wgrad("down0", dzD1, cat0[:, c1:], g["l1"]["child"], c0, s["colsd0"], ws)
+        self._conv_wgrad("down0", dzD1, H0, g["l1"]["child"], c0, s["colsd0"], ws)
         dcolsd0 = torch.empty(dzD1.shape[0], 8 * c0, device=dy.device)
         ops.linear_bwd_data(dzD1, W("down0"), None, dcolsd0, ops.ACT_NONE)
-        dzH0 = dcat0[:, c1:]
         ops.rows_gather_bwd(dcolsd0, g["l1"]["parent_canon"].view(-1, 1), c0, dzH0, tslot=g["l1"]["slot"].view(-1, 1), mode=1,
-                            y_tanh=cat0[:, c1:], accumulate=True)
+                            y_tanh=H0, accumulate=acc_mode)
         self._conv_wgrad("conv0", dzH0, g["feat0"], g["nbr0"], 4, s["cols0"], ws)           # the input features are data
 
 

@@ -443,12 +443,14 @@ __device__ __forceinline__ void g2_gather_first(const Gemm2Prob& g, int r0, int 
     }
 }
 
-// LAY: how the four multiplying waves cover the work-group tile -- 0: 2 x 2 (tile 64 WM x 64 WN); 1: 1 x 4 (tile 32 WM x 128 WN)
+// LAY: how the four multiplying waves cover the work-group tile -- 0: 2 x 2 (tile 64 WM x 64 WN); 2: 4 x 1 (tile 128 WM x 32 WN)
+// for forward problems with at most 32 OUTPUT columns (the 32-channel level of the sparse U-Net: 8.4 M rows -- on a 64-wide
+// tile half of every MFMA multiplies columns that do not exist); 1: 1 x 4 (tile 32 WM x 128 WN)
 // for problems with at most 32 rows (the weight gradient of a 32-channel convolution over millions of rows: on the 2 x 2 layout
 // half of every MFMA multiplies rows that do not exist -- 6.5 ms per launch at 142 TFLOP/s of ISSUED work, 71 of useful).
 template <int WM, int WN, int LAY>
 struct G2DmaShape {
-    static constexpr int TM = LAY ? 32 * WM : 64 * WM, TN = LAY ? 128 * WN : 64 * WN;
+    static constexpr int TM = LAY == 2 ? 128 * WM : (LAY ? 32 * WM : 64 * WM), TN = LAY == 2 ? 32 * WN : (LAY ? 128 * WN : 64 * WN);
     static constexpr int NBUF = 3;
     static constexpr int ABUF = TM * 32, BBUF = TN * 32;
     static constexpr int EPI = TM * (TN + 4);                              // the epilogue's staging image
@@ -471,7 +473,8 @@ __device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Pro
     const int m0 = tm * TM, n0 = tn * TN;
     const int kbeg = z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     const int nk = (kend - kbeg + G2_TK - 1) / G2_TK;                      // whole steps, except the ragged row tail of a gathered weight gradient
-    const int wmo = LAY ? 0 : (wave >> 1) * 32 * WM, wno = LAY ? wave * 32 * WN : (wave & 1) * 32 * WN;
+    const int wmo = LAY == 2 ? wave * 32 * WM : (LAY ? 0 : (wave >> 1) * 32 * WM);
+    const int wno = LAY == 2 ? 0 : (LAY ? wave * 32 * WN : (wave & 1) * 32 * WN);
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -481,7 +484,7 @@ __device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Pro
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[bm][bn][r] = 0.f;
     const bool do_bias = A_KM && g.epi == G2_EPI_PLAIN && g.dbias != nullptr && tn == 0;
-    constexpr int BQ = 256 / TM, BK = G2_TK / BQ;
+    constexpr int BQ = 256 / TM > 0 ? 256 / TM : 1, BK = G2_TK / BQ;
     float bsum = 0.f;
     float* As = lds;
     float* Bs = lds + NBUF * ABUF;
@@ -747,11 +750,17 @@ int gemm2_chain_launch(Gemm2Chain& ch, bool b_kmajor, void* stream) {
 // problem actually extends past 64 -- a 128 x 128 tile on an N = 64 problem (the 64-channel sparse convolutions: 2.7 M rows,
 // K = 1728) spends half of its MFMAs on columns that do not exist.
 template <bool A_KM, bool B_KM, bool GATHER>
-static void g2_launch_dma(const Gemm2Group& g, int wm, int wn, int blocks, void* stream, bool lay1 = false) {
+static void g2_launch_dma(const Gemm2Group& g, int wm, int wn, int blocks, void* stream, bool lay1 = false, bool lay2 = false) {
     const dim3 grid(blocks), blk(512);
     if constexpr (A_KM && B_KM) {
         if (lay1) {
             hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 1, GATHER, 1>), grid, blk, 0, pm_stream(stream), g);
+            return;
+        }
+    }
+    if constexpr (!A_KM && !B_KM) {
+        if (lay2) {
+            hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 1, GATHER, 2>), grid, blk, 0, pm_stream(stream), g);
             return;
         }
     }
@@ -783,8 +792,10 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
 #endif
     // weight gradients of <= 32 output rows: the 32 x 128 tile (1 x 4 waves) of the LDS-DMA kernels
     const bool lay1 = A_KM && B_KM && (dma || gather) && vec && maxM <= 32 && maxN > 64;
-    if (lay1) wm = wn = 1;
-    const int TM = lay1 ? 32 : 64 * wm, TN = lay1 ? 128 : 64 * wn;
+    // forward problems of <= 32 output columns over many rows: the 128 x 32 tile (4 x 1 waves)
+    const bool lay2 = !A_KM && !B_KM && big && (dma || gather) && vec && maxN <= 32;
+    if (lay1 || lay2) wm = wn = 1;
+    const int TM = lay1 ? 32 : (lay2 ? 128 : 64 * wm), TN = lay1 ? 128 : (lay2 ? 32 : 64 * wn);
     int blocks = 0;
     for (int i = 0; i < g.n; ++i) {
         Gemm2Prob& p = g.p[i];
@@ -805,13 +816,13 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
             const bool kok = A_KM ? (q.kchunk % G2_TK == 0) : (q.K % G2_TK == 0 && q.kchunk % G2_TK == 0);
             if (!q.gidx || !q.gzero || !vec || !kok || q.gC % 4 != 0 || q.gJ < 1 || (long)q.gJ * q.gC != (A_KM ? q.N : q.K)) return PM_EINVAL;
         }
-        if constexpr (A_KM == B_KM) g2_launch_dma<A_KM, B_KM, true>(g, wm, wn, blocks, stream, lay1);
+        if constexpr (A_KM == B_KM) g2_launch_dma<A_KM, B_KM, true>(g, wm, wn, blocks, stream, lay1, lay2);
         else return PM_EUNSUPPORTED;
         PM_CHECK_LAUNCH();
         return PM_OK;
     }
     const dim3 grid(blocks), blk(256);
-    if (dma) g2_launch_dma<A_KM, B_KM, false>(g, wm, wn, blocks, stream, lay1);
+    if (dma) g2_launch_dma<A_KM, B_KM, false>(g, wm, wn, blocks, stream, lay1, lay2);
     else if (big && vec) hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 2, 2, true>), grid, blk, 0, pm_stream(stream), g);
     else if (big) hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 2, 2, false>), grid, blk, 0, pm_stream(stream), g);
     else if (vec) hipLaunchKernelGGL((gemm2_kernel<A_KM, B_KM, 1, 1, true>), grid, blk, 0, pm_stream(stream), g);

@@ -44,20 +44,37 @@ __global__ __launch_bounds__(256) void vx_grid0_kernel(const float* __restrict__
     }
 }
 
-// 27 neighbours of every row: nbr[r][o], o = (dx+1)*9 + (dy+1)*3 + (dz+1); offset 26 - o is the mirrored one
+// 27 neighbours of every row: nbr[r][o], o = (dx+1)*9 + (dy+1)*3 + (dz+1); offset 26 - o is the mirrored one.  ld >= 27 is the
+// table's row stride: columns 27 .. ld-1 are written as -1 ("absent" taps that pad the gathered operand of a layer whose
+// 27 * C_in is not a whole number of K-steps -- conv0: 27 x 4 = 108 -> 32 taps = 128 columns).
+// (Four elements per thread and trip, their loads issued back to back, measured 14 % SLOWER than this one-at-a-time loop.)
 __global__ __launch_bounds__(256) void vx_nbr27_kernel(const int32_t* __restrict__ coords, long rows, const int32_t* __restrict__ grid,
-                                                        int R, int32_t* __restrict__ nbr) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < rows * 27; e += (long)gridDim.x * 256) {
-        const long r = e / 27;
-        const int o = (int)(e - r * 27);
-        const int dx = o / 9 - 1, dy = (o / 3) % 3 - 1, dz = o % 3 - 1;
-        const int b = coords[r * 4], X = coords[r * 4 + 1] + dx, Y = coords[r * 4 + 2] + dy, Z = coords[r * 4 + 3] + dz;
+                                                        int R, int32_t* __restrict__ nbr, int ld) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < rows * ld; e += (long)gridDim.x * 256) {
+        const long r = e / ld;
+        const int o = (int)(e - r * ld);
         int v = -1;
-        if (X >= 0 && X < R && Y >= 0 && Y < R && Z >= 0 && Z < R) {
-            const int g = grid[(long)b * R * R * R + ((long)X * R + Y) * R + Z];
-            v = g == VX_EMPTY ? -1 : g;
+        if (o < 27) {
+            const int dx = o / 9 - 1, dy = (o / 3) % 3 - 1, dz = o % 3 - 1;
+            const int b = coords[r * 4], X = coords[r * 4 + 1] + dx, Y = coords[r * 4 + 2] + dy, Z = coords[r * 4 + 3] + dz;
+            if (X >= 0 && X < R && Y >= 0 && Y < R && Z >= 0 && Z < R) {
+                const int g = grid[(long)b * R * R * R + ((long)X * R + Y) * R + Z];
+                v = g == VX_EMPTY ? -1 : g;
+            }
         }
         nbr[e] = v;
+    }
+}
+// The table through which the DATA gradient of a 3^3 submanifold convolution gathers: row r reads s as neighbour o  <=>  s
+// reads r as neighbour 26 - o, so the rows whose output used r are nbr[r] reversed.  A row that is nobody's neighbour (a
+// duplicate coordinate: its own-cell entry points at the canonical row, not at itself) gets -1 everywhere.
+__global__ __launch_bounds__(256) void vx_mirror27_kernel(const int32_t* __restrict__ nbr, long rows, int32_t* __restrict__ out) {
+    const long total = rows * 27;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / 27;
+        const int o = (int)(e - r * 27);
+        const bool canon = nbr[r * 27 + 13] == (int)r;
+        out[e] = canon ? nbr[r * 27 + 26 - o] : -1;
     }
 }
 
@@ -149,6 +166,7 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const float* __restric
     }
 }
 // dsrc[r][c] (= or +=) (sum_j tidx[r][j] >= 0 ? dcols[tidx[r][j]][slot(r,j)*C + c] : 0) * (y ? 1 - y[r][c]^2 : 1)
+// accumulate: 0 = overwrite, 1 = add the product to what dsrc holds, 2 = add what dsrc holds to the SUM, then multiply
 // slot(r, j) = tslot ? tslot[r*J + j] : (mirror ? J - 1 - j ... see host) -- the host passes explicit conventions:
 //   mode 0: block = j (table already arranged per block), mode 1: block = tslot[r*J + j], mode 2: block = 0 (plain rows)
 __global__ __launch_bounds__(256) void rows_gather_bwd_kernel(const float* __restrict__ dcols, long ldc, const int32_t* __restrict__ tidx,
@@ -172,12 +190,16 @@ __global__ __launch_bounds__(256) void rows_gather_bwd_kernel(const float* __res
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
         }
+        float4* o = (float4*)(dsrc + r * lds + 4 * q);
+        if (accumulate == 2) {                             // dsrc holds a RAW contribution: (it + the gathered sum) * act'
+            const float4 p = *o;
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
         if (y) {
             const float4 h = *(const float4*)(y + r * ldy + 4 * q);
             s.x *= 1.0f - h.x * h.x; s.y *= 1.0f - h.y * h.y; s.z *= 1.0f - h.z * h.z; s.w *= 1.0f - h.w * h.w;
         }
-        float4* o = (float4*)(dsrc + r * lds + 4 * q);
-        if (accumulate) {
+        if (accumulate == 1) {                             // dsrc holds a finished (pre-activation) contribution
             const float4 p = *o;
             s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
         }
@@ -210,9 +232,16 @@ extern "C" int pm_voxel_grid0_f32(const float* x, long ldx, int B, int P, int C,
     return PM_OK;
 }
 
-extern "C" int pm_voxel_nbr27_i32(const int32_t* coords, long rows, const int32_t* grid, int R, int32_t* nbr, void* stream) {
-    PM_REQUIRE(coords && grid && nbr && rows > 0 && R > 0);
-    VX_LAUNCH(vx_nbr27_kernel, rows * 27, coords, rows, grid, R, nbr);
+extern "C" int pm_voxel_nbr27_i32(const int32_t* coords, long rows, const int32_t* grid, int R, int32_t* nbr, int ld, void* stream) {
+    PM_REQUIRE(coords && grid && nbr && rows > 0 && R > 0 && ld >= 27);
+    VX_LAUNCH(vx_nbr27_kernel, rows * ld, coords, rows, grid, R, nbr, ld);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_voxel_mirror27_i32(const int32_t* nbr, long rows, int32_t* out, void* stream) {
+    PM_REQUIRE(nbr && out && rows > 0 && nbr != out);
+    VX_LAUNCH(vx_mirror27_kernel, rows * 27, nbr, rows, out);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }

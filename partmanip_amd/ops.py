@@ -160,6 +160,7 @@ def linear_bwd_data(dy, w, h, dx, act):
     check(lib.pm_linear_bwd_data_f32(_ptr(dy), _rows(dy, "dy"), _ptr(w), _rows(w, "w"), _ptr(h),
                                      _rows(h, "h") if h is not None else 0, _ptr(dx), _rows(dx, "dx"), M, N, K, act,
                                      _stream()), "pm_linear_bwd_data_f32")
+    return dx
 
 
 def linear_bwd_weight(dy, x, dw, db, ws):
@@ -644,12 +645,22 @@ def voxel_grid0(x, P, C, R):
     return grid, coords, feat
 
 
-def voxel_nbr27(coords, grid, R):
+def voxel_nbr27(coords, grid, R, taps=27):
+    """(rows, 27) neighbour table; taps > 27: the rows are `taps` wide and the extra columns hold -1 (absent taps), returned
+    as the (rows, taps) table -- its [:, :27] view is the plain table."""
     _req(coords, grid)
     rows = coords.shape[0]
-    nbr = torch.empty(rows, 27, dtype=torch.int32, device=coords.device)
-    check(lib.pm_voxel_nbr27_i32(_ptr(coords), rows, _ptr(grid), R, _ptr(nbr), _stream()), "pm_voxel_nbr27_i32")
+    nbr = torch.empty(rows, taps, dtype=torch.int32, device=coords.device)
+    check(lib.pm_voxel_nbr27_i32(_ptr(coords), rows, _ptr(grid), R, _ptr(nbr), int(taps), _stream()), "pm_voxel_nbr27_i32")
     return nbr
+
+
+def voxel_mirror27(nbr):
+    """The mirrored 27-neighbour table of the data gradient (pm_voxel_mirror27_i32)."""
+    _req(nbr)
+    out = torch.empty_like(nbr)
+    check(lib.pm_voxel_mirror27_i32(_ptr(nbr), nbr.shape[0], _ptr(out), _stream()), "pm_voxel_mirror27_i32")
+    return out
 
 
 def voxel_down(coords_f, grid_f, Rf, B):

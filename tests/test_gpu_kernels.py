@@ -756,7 +756,9 @@ def test_maxpool_rows_value_and_lowest_arg(G, ns, C):
 
 
 @pytest.mark.parametrize("rows,J,C,N", [(1000, 27, 32, 32), (333, 8, 32, 64), (4097, 27, 64, 64), (700, 32, 4, 32), (129, 27, 32, 128),
-                                        (50001, 27, 64, 32), (3000, 32, 32, 16), (2049, 8, 64, 32)])
+                                        (50001, 27, 64, 32), (3000, 32, 32, 16), (2049, 8, 64, 32),
+                                        # >= 512 big tiles and <= 32 output columns: the forward's 128 x 32 tile (4 x 1 waves)
+                                        (70001, 32, 4, 32), (66000, 3, 32, 32), (65600, 27, 32, 32)])
 def test_sparse_conv_entry_points_against_torch(rows, J, C, N):
     """The three gathered-GEMM entry points (the (rows x J*C) operand exists only inside the LDS-DMA loader) against a plain
     torch fp32 gather + matmul of the same op: random neighbour tables with ~30 % absent neighbours (-1 -> zero rows),
