@@ -235,17 +235,22 @@ def run_dagger(args, device, rank, world):
         macs = {"conv0": R0 * 108 * c0, "down0": R1 * 8 * c0 * c1, "conv1": R1 * 27 * c1 * c1, "down1": R2 * 8 * c1 * c2,
                 "conv2": R2 * 27 * c2 * c2, "up1": R1 * (c2 + c1) * c1, "up0": R0 * (c1 + c0) * c0}
         ffl = 2.0 * sum(macs.values())
-        bfl = 2.0 * ffl - 2.0 * macs["conv0"]
+        # backward = weight gradients (the forward's MACs) + data gradients: the forward's MACs again, except conv0 (its input
+        # is data) and the up layers, whose un-pooled half runs on the COARSE rows (children summed first, linearity)
+        dgrad = dict(macs, conv0=0, up1=R1 * c1 * c1 + R2 * c1 * c2, up0=R0 * c0 * c0 + R1 * c0 * c1)
+        bfl = ffl + 2.0 * sum(dgrad.values())
         if t and b:
             tf = (ffl + bfl) / ((t[0] + b[0]) * 1e-3) / 1e12
             out["roofline"] = dict(bound="mfma", kernel="SparseUNet forward + backward (gemm2_dma_kernel with fused neighbour gathers)",
                                    achieved=tf, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS, traffic=None,
                                    launches=t[1], fwd_mean_ms=t[0], bwd_mean_ms=b[0], level_rows=[R0, R1, R2],
                                    flops_fwd=ffl, flops_bwd=bfl,
-                                   note="3^3 / strided convolutions gather their neighbour rows inside the GEMM's LDS-DMA loader "
-                                        "(forward, weight gradient and the 3^3 data gradient through the mirrored table): no column "
-                                        "matrix in HBM except conv0's 108-wide one and the strided layers' data gradients; "
-                                        "kernel = gemm2_dma_kernel<..., GATHER>, 128 x 64 tiles on the 64-channel levels")
+                                   note="3^3 / strided convolutions and the up layers' [unpool | skip] operands are gathered inside the "
+                                        "GEMM's LDS-DMA loader (forward, weight gradient, the 3^3 data gradient through the mirrored "
+                                        "table): no column / concatenated matrix in HBM except the strided layers' data gradients; "
+                                        "flops = MACs of the GEMMs as executed (the un-pooled half of an up layer's data gradient runs "
+                                        "on the coarse rows); kernel = gemm2_dma_kernel<..., GATHER>, 128 x 64 / 128 x 32 tiles on the "
+                                        "64- / 32-channel levels")
     else:
         t = ops.TIMER.mean_ms("pointnet_enc_fwd")
         if t:

@@ -493,32 +493,46 @@ __device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Pro
         // tile index clamped: the redundant reloads of the last tile keep the outstanding-load count uniform (they land in
         // buffers nobody reads any more)
         constexpr int NGI = GATHER ? (A_KM ? TN : TM) / 32 : 1;
-        int gi[NGI];                                                       // GATHER: this lane's neighbour indices of the next tile
-        auto issue = [&](int tile) __attribute__((always_inline)) {
+        // GATHER: the neighbour indices of a tile are ordinary loads and VMEM returns in order, so the set a tile's issue()
+        // consumes must be OLDER than the previous tile's DMAs -- otherwise waiting for it also waits for those DMAs and only
+        // one tile is ever in flight (the first version: indices one tile ahead; the big sparse convolutions ran at 0.58 of
+        // the MFMA peak where the plain kernel reaches 0.65).  Two register sets, each refilled TWO tiles ahead by the issue()
+        // that has just consumed it: set A serves the even tiles, set B the odd ones.
+        int gia[NGI], gib[NGI];
+        auto issue = [&](int tile, int (&gi)[NGI]) __attribute__((always_inline)) {
             const int tt = min(tile, nk - 1), buf = tile % NBUF;
-            const int kt = kbeg + tt * G2_TK, ktn = kbeg + min(tile + 1, nk - 1) * G2_TK;
+            const int kt = kbeg + tt * G2_TK, ktn = kbeg + min(tile + 2, nk - 1) * G2_TK;
             if constexpr (GATHER && !A_KM) g2_dma_tile_gather<false, TM>(g, g.A, g.lda, m0, g.M, kt, ktn, As + buf * ABUF, wave, lane, gi);
             else g2_dma_tile<A_KM, TM, AUXA>(g.A, g.lda, m0, A_KM ? g.Mld : g.M, kt, As + buf * ABUF, wave, lane, g.K - 1);
             if constexpr (GATHER && A_KM) g2_dma_tile_gather<true, TN>(g, g.B, g.ldb, n0, g.N, kt, ktn, Bs + buf * BBUF, wave, lane, gi);
             else g2_dma_tile<B_KM, TN>(g.B, g.ldb, n0, B_KM ? g.Nld : g.N, kt, Bs + buf * BBUF, wave, lane);
         };
         if constexpr (GATHER) {
-            if constexpr (A_KM) g2_gather_first<true, TN>(g, n0, g.N, kbeg, wave, lane, gi);
-            else g2_gather_first<false, TM>(g, m0, g.M, kbeg, wave, lane, gi);
+            const int k1 = kbeg + min(1, nk - 1) * G2_TK;
+            if constexpr (A_KM) {
+                g2_gather_first<true, TN>(g, n0, g.N, kbeg, wave, lane, gia);
+                g2_gather_first<true, TN>(g, n0, g.N, k1, wave, lane, gib);
+            } else {
+                g2_gather_first<false, TM>(g, m0, g.M, kbeg, wave, lane, gia);
+                g2_gather_first<false, TM>(g, m0, g.M, k1, wave, lane, gib);
+            }
         }
-        // GATHER: an issue() ends with NGI index loads for the following tile; VMEM returns in order, so (a) the counted
-        // waits allow for them and (b) the next issue() -- which consumes them -- implicitly waits for everything older too:
-        // one tile (not two) stays in flight across the consumers' K-step.
+        // the counted waits allow for the NGI index loads an issue() ends with
         constexpr int NW1 = IPT + (GATHER ? NGI : 0);
-        issue(0);
-        issue(1);
+        issue(0, gia);
+        issue(1, gib);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW1) : "memory");         // tile 0 has landed (this wave's pieces)
         __builtin_amdgcn_s_barrier();                                      // ... and every other loader's
 #pragma unroll 1
-        for (int k = 0; k < nk; ++k) {
-            issue(k + 2);                                                  // into the buffer whose readers passed the last barrier
+        for (int k = 0; k < nk; k += 2) {
+            issue(k + 2, gia);                                             // into the buffer whose readers passed the last barrier
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW1) : "memory");     // tile k+1 landed, tile k+2 stays in flight
             __builtin_amdgcn_s_barrier();
+            if (k + 1 < nk) {
+                issue(k + 3, gib);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW1) : "memory");
+                __builtin_amdgcn_s_barrier();
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the tail loads must not land in the epilogue's image
     } else {
