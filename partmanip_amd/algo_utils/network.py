@@ -682,7 +682,11 @@ class SparseUNet(_HipNet):
         cout, cin = lin.weight.shape[0], lin.weight.shape[1] // 27
         if self.fused_gather and (27 * cout) % 32 == 0:
             wt = lin.weight.data.view(cout, 27, cin).permute(2, 1, 0).reshape(cin, 27 * cout).contiguous()
-            return ops.sparse_conv_bwd_data(dz, self._mirror(nbr), wt, y_in, dx, self._act, self._zero(dz.device))
+            g = self._saved["g"]
+            key = "mirror_" + name                              # (kept with the geometry: cached tables are mirrored once)
+            if key not in g:
+                g[key] = self._mirror(nbr)
+            return ops.sparse_conv_bwd_data(dz, g[key], wt, y_in, dx, self._act, self._zero(dz.device))
         dcols = torch.empty(dz.shape[0], 27 * cin, device=dz.device)
         ops.linear_bwd_data(dz, lin.weight.data, None, dcols, ops.ACT_NONE)
         return ops.rows_gather_bwd(dcols, nbr, cin, dx, reverse=True, self_col=13, y_tanh=y_in)
@@ -760,11 +764,28 @@ class SparseUNet(_HipNet):
         p = parent.view(-1).to(torch.int32) * m
         return torch.stack([p + k for k in range(m)] + [r + m * rows_hi], dim=1).contiguous()
 
+    # ---- geometry once per rollout (ppo.update): the tables depend on the coordinates only, and a sequential mini-batch is the
+    # same slice of the rollout in every epoch and for both networks -- 10 forwards share one set of tables (and the two host
+    # reads that size the strided levels happen once per mini-batch instead of once per forward)
+    def precompute_geometry(self, obs):
+        return dict(cache={}, rows=obs.shape[0])
+
+    def use_geometry(self, geom, rows):
+        """Take the next forward's tables from `geom` (built on first use) when `rows` is a (lo, n) slice of the rollout."""
+        object.__setattr__(self, "_geom_next", (geom["cache"], rows) if isinstance(rows, tuple) else None)
+
     def _hip_forward(self, x, out=None):
         B, P = x.shape[0], self.point_num
         c0, c1, c2 = self.channels
         dev = x.device
-        g = self.geometry(x)
+        nxt = getattr(self, "_geom_next", None)
+        object.__setattr__(self, "_geom_next", None)
+        if nxt is not None and nxt[1][1] == B:
+            g = nxt[0].get(nxt[1])
+            if g is None:
+                g = nxt[0][nxt[1]] = self.geometry(x)
+        else:
+            g = self.geometry(x)
         R0, R1, R2 = g["rows"]
         e = lambda r, c: torch.empty(r, c, device=dev)
         vcat = self._vcat_ok()
@@ -790,8 +811,9 @@ class SparseUNet(_HipNet):
         cols2 = self._conv("conv2", D2, g["nbr2"], c2, H2)
         E0 = e(R0, c0)
         if vcat:
-            g["up1_idx"] = self._vcat_table(g["l2"]["parent"], m1, R2)
-            g["up0_idx"] = self._vcat_table(g["l1"]["parent"], m0, R1)
+            if "up1_idx" not in g:
+                g["up1_idx"] = self._vcat_table(g["l2"]["parent"], m1, R2)
+                g["up0_idx"] = self._vcat_table(g["l1"]["parent"], m0, R1)
             lin = self.up1
             ops.sparse_conv_fwd(comb1, g["up1_idx"], c1, lin.weight.data, lin.bias.data, E1, self._act, self._zero(dev))
             lin = self.up0

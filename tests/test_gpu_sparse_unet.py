@@ -354,3 +354,40 @@ def test_sparse_unet_student_mixed_offline_and_on_policy_ring_two_ranks(tmp_path
     np.testing.assert_allclose(run.log_dict["Train/dagger_loss"], ref["log"]["Train/dagger_loss"], rtol=1e-5)
     assert_update_matches(single, flat_state(stu), init, c["lr"], len(ref["loss_trace"]))
     assert_update_matches(r0, flat_state(stu), init, c["lr"], len(ref["loss_trace"]))
+
+
+def test_ppo_update_with_cached_geometry_equals_the_uncached_one():
+    """`ppo.update` builds the SparseUNet index tables once per (sequential) mini-batch and reuses them over the epochs and for
+    both networks (geometry() used to be rebuilt in every forward, with two host reads each); the result must not
+    change by a bit, and the tables must be built exactly once per mini-batch."""
+    from partmanip_amd.algorithms import ppo
+    from tests.test_gpu_fullsize import _cfg, _fill
+    from tests.golden.detgen import det_normal, det_uniform
+    N, T, A, P, Rg = 8, 4, 5, NET["point_num"], NET["grid"]
+    O = 4 * P
+    obs = t(np.stack([cases.sparse_clouds(N, P, Rg, 900 + k, n_distinct=80, pad_tail=3) for k in range(T)]))
+    g = torch.Generator().manual_seed(3)
+    st = dict(observations=obs, actions=torch.tanh(torch.randn(T, N, A, generator=g)) * 0.9, rewards=t(det_normal((T, N, 1), 1)),
+              dones=torch.from_numpy(det_uniform((T, N, 1), 2, 0.0, 1.0) < 0.1), values=t(det_normal((T, N, 1), 3)) * 0.1,
+              actions_log_prob=t(det_normal((T, N, 1), 4)) * 0.1 - 3.0, mu=t(det_normal((T, N, A), 5)) * 0.1,
+              sigma=torch.full((T, N, A), float(np.log(0.5))), last_values=t(det_normal((N, 1), 6)) * 0.1)
+    st["succs"] = st["dones"] & torch.from_numpy(det_uniform((T, N, 1), 7, 0.0, 1.0) < 0.5)
+    sd = cases.actor_critic_state(NET, O, A, 0.5, 61)
+    res = []
+    for cache in (True, False):
+        with tempfile.TemporaryDirectory() as d:
+            run = ppo(FakeEnv(N, {"normal_state": O}, A), dict(_cfg(NET, N, T, 2, 3, 1e-3, DEV), desired_kl=1e9), FakeLogger(d))
+        run.actor_critic.load_state_dict({k: t(v.copy()) for k, v in sd.items()})
+        run.cache_geometry = cache
+        calls = [0]
+        for net in (run.actor_critic.actor, run.actor_critic.critic):
+            orig = net.geometry
+            object.__setattr__(net, "geometry", (lambda o: (lambda x: (calls.__setitem__(0, calls[0] + 1), o(x))[1]))(orig))
+        _fill(run, st)
+        run.log_dict = {}
+        run.curr_iter = 1
+        run.learn(st["last_values"].to(DEV))
+        torch.cuda.synchronize()
+        res.append((flat_state(run.actor_critic.state_dict()), calls[0]))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert res[0][1] == 2 and res[1][1] == 2 * 3 * 2, (res[0][1], res[1][1])     # 2 mini-batches | x 3 epochs x 2 networks
