@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""profiles/hbm_traffic.json from the PMC summaries of a profile set (tools/profile_round.sh -> tools/pmc_run.sh ->
+tools/pmc_summary.py).  FETCH_SIZE / WRITE_SIZE are KB per launch; FETCH_SIZE is doubled (gfx950 tallies the 128-byte
+requests of wide coalesced reads at 64 B: MI355X_MICROARCH.md, HBM section).  GRBM_GUI_ACTIVE sums the 8 XCDs;
+SQ_VALU_MFMA_BUSY_CYCLES sums the issued MFMAs' pipe cycles over the 1024 SIMDs.
+
+    python tools/make_hbm_traffic.py <tag> <pmc_enc summary.json> [<pmc_lin summary.json> [<pmc_su summary.json>]]
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, enc = sys.argv[1], json.load(open(sys.argv[2]))
+lin = json.load(open(sys.argv[3])) if len(sys.argv) > 3 and os.path.exists(sys.argv[3]) else None
+su = json.load(open(sys.argv[4])) if len(sys.argv) > 4 and os.path.exists(sys.argv[4]) else None
+dst = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+out = json.load(open(dst)) if os.path.exists(dst) else {}
+
+
+def find(tab, prefix):
+    ks = [k for k in tab if k.split("<")[0].replace("void ", "") == prefix]
+    if not ks:
+        raise KeyError(prefix)
+    return tab[max(ks, key=lambda k: tab[k].get("GRBM_GUI_ACTIVE", {}).get("mean", 0.0))]
+
+
+def traffic(k):
+    return 2.0 * k["FETCH_SIZE"]["mean"] * 1024.0, k["WRITE_SIZE"]["mean"] * 1024.0
+
+
+def busy(k):
+    return k["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0 / (k["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
+
+
+out["source"] = (f"round 3: tools/profile_round.sh {tag} -> tools/pmc_run.sh gpurun_out/{tag}/pmc_enc python tools/time_enc.py (separate "
+                 f"rocprofv3 --pmc passes, counters only) -> profiles/round3_{tag[2:]}_pmc_encoder.json; tools/make_hbm_traffic.py")
+out["correction"] = "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 tallies 128-B requests at 64 B); counters are KB"
+for name in ("pn_fwd_kernel", "pn_bwd16_kernel", "pn_bwd_prep_kernel"):
+    k = find(enc, name)
+    f, w = traffic(k)
+    out[f"{name}_fetch_bytes_raw"] = f / 2.0
+    out[f"{name}_write_bytes"] = w
+    out[f"{name}_bytes_per_launch"] = f + w
+    if name != "pn_bwd_prep_kernel":
+        out[f"{name}_mfma_busy"] = busy(k)
+        out[f"{name}_cycles_per_launch"] = k["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+        out[f"{name}_lds_bank_conflict_fraction"] = k["SQ_LDS_BANK_CONFLICT"]["mean"] / max(k["SQ_LDS_IDX_ACTIVE"]["mean"], 1.0)
+side = sum(find(enc, n)["GRBM_GUI_ACTIVE"]["mean"] / 8.0 for n in ("pn_bwd_prep_kernel", "pn_dw3_gather_kernel", "pn_dw3_finish_kernel",
+                                                                     "pn_bwd_reduce1_kernel", "pn_bwd_reduce2_kernel"))
+k16 = find(enc, "pn_bwd16_kernel")
+out["pn_bwd16_kernel_mfma_busy_over_backward_call"] = (k16["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0) / (k16["GRBM_GUI_ACTIVE"]["mean"] / 8.0 + side)
+if lin is not None:
+    for key, kern in (("fwd", "gemm2_dma_kernel<false, false, 1, 1, false, 0>"), ("bwd_data", "gemm2_dma_kernel<false, true, 1, 1, false, 0>"),
+                      ("bwd_weight", "gemm2_dma_kernel<true, true, 1, 1, false, 0>")):
+        k = lin.get("void " + kern) or lin.get(kern)
+        if k is None:
+            continue
+        f, w = traffic(k)
+        out[f"linear_2048x512x512_{key}_bytes_per_launch"] = f + w
+        out[f"linear_2048x512x512_{key}_mfma_insts"] = k["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 64.0
+    out["linear_2048x512x512_algorithmic_bytes"] = (2 * 2048 * 512 + 512 * 512) * 4
+    out["linear_2048x512x512_note"] = (f"tools/pmc_run.sh gpurun_out/{tag}/pmc_lin python tools/time_gemm.py 2048x512x512 -> "
+                                       f"profiles/round3_{tag[2:]}_pmc_linear.json; FETCH doubled (gfx950 correction); each of the 8 XCDs fetches "
+                                       "the whole weight matrix into its own L2")
+if su is not None:
+    f = sum(2.0 * v["FETCH_SIZE"]["mean"] * v["FETCH_SIZE"]["launches"] for v in su.values() if "FETCH_SIZE" in v) * 1024.0
+    w = sum(v["WRITE_SIZE"]["mean"] * v["WRITE_SIZE"]["launches"] for v in su.values() if "WRITE_SIZE" in v) * 1024.0
+    out["sparse_unet_256_clouds_note"] = (f"tools/pmc_run.sh gpurun_out/{tag}/pmc_su python tools/time_sparse_unet.py 256 (5 forward + backward "
+                                          "passes, ALL kernels of the process): bytes below are per forward + backward pass")
+    out["sparse_unet_256_clouds_fetch_bytes_per_pass"] = f / 5.0
+    out["sparse_unet_256_clouds_write_bytes_per_pass"] = w / 5.0
+json.dump(out, open(dst, "w"), indent=1)
+print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in out.items() if not k.endswith("note") and k not in ("source", "correction")})

@@ -18,12 +18,15 @@ prof bench_state --workload state --steps 2 --warmup 1 --no-cpu-baseline
 prof bench_dagger_sparse_unet --workload dagger --student sparse_unet --steps 1 --warmup 1 --no-cpu-baseline
 prof bench_vision_pn2 --workload vision_pn2 --steps 1 --warmup 1 --no-cpu-baseline
 # un-profiled bench lines (the numbers to quote: a profiled run clocks lower)
-timeout 400 python bench.py > $out/line_default.json 2> $out/line_default.err < /dev/null
+timeout 900 python bench.py > $out/line_default.json 2> $out/line_default.err < /dev/null
 timeout 300 python bench.py --workload state > $out/line_state.json 2>> $out/line_default.err < /dev/null
 timeout 400 python bench.py --workload vision_pn2 > $out/line_vision_pn2.json 2>> $out/line_default.err < /dev/null
 timeout 400 python bench.py --workload dagger > $out/line_dagger_pointnet.json 2>> $out/line_default.err < /dev/null
+timeout 400 python bench.py --workload dagger --student sparse_unet > $out/line_dagger_sparse_unet.json 2>> $out/line_default.err < /dev/null
 timeout 300 python bench.py --workload dagger --student conv3d > $out/line_dagger_conv3d.json 2>> $out/line_default.err < /dev/null
 timeout 300 python bench.py --workload depth2pc > $out/line_depth2pc.json 2>> $out/line_default.err < /dev/null
-# PMC passes (separate runs, counters only) on the short encoder-only command
+# PMC passes (separate runs, counters only) on short single-purpose commands
 PMC_PASS_TIMEOUT=150 bash tools/pmc_run.sh $out/pmc_enc python tools/time_enc.py < /dev/null
+PMC_PASS_TIMEOUT=150 bash tools/pmc_run.sh $out/pmc_lin python tools/time_gemm.py 2048x512x512 < /dev/null
+PMC_PASS_TIMEOUT=200 bash tools/pmc_run.sh $out/pmc_su python tools/time_sparse_unet.py 256 < /dev/null
 ls $out
