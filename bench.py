@@ -674,7 +674,8 @@ def optional_paths(run, ac, w, step, fence):
 def _brief(line):
     """The part of a workload's line that the default line carries as a `secondary` entry."""
     r = line.get("roofline") or {}
-    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "fwd_mean_ms", "bwd_mean_ms", "level_rows", "flops_per_env_step")
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "fwd_mean_ms", "bwd_mean_ms", "level_rows", "flops_per_env_step",
+            "mean_launch_ms", "kernels")
     out = dict(metric=line["metric"], value=line["value"], unit=line["unit"], steps=line["steps"], warmup=line["warmup"],
                ms_per_step=line["ms_per_step"], dtype=line["dtype"], workload=line["config"]["workload"],
                roofline={k: r[k] for k in keep if k in r})
@@ -693,12 +694,14 @@ def _brief(line):
 
 def secondary_lines(args, device):
     """The other single-GPU BASELINE configs, timed by the SAME process right after the headline workload so that the driver's
-    clock witnesses them too: cfg 2 (state PPO) and cfg 5 as written (DAgger, SparseUNet student on 4096-voxel clouds).  Fixed
-    3 timed steps + 1 warm-up each (their own `steps` / `warmup` fields say so), each with its roofline and CPU baseline."""
+    clock witnesses them too: cfg 2 (state PPO), cfg 5 as written (DAgger, SparseUNet student on 4096-voxel clouds) and cfg 3's
+    rollouts through the PointNet++ plug-in backbone (HIP FPS + ball query + fused set-abstraction kernels).  Fixed 3 timed
+    steps + 1 warm-up each (their own `steps` / `warmup` fields say so), each with its roofline and CPU baseline."""
     import copy
     import gc
     res = {}
-    for key, kw in (("state", dict(workload="state")), ("dagger_sparse_unet", dict(workload="dagger", student="sparse_unet", points=4096))):
+    for key, kw in (("state", dict(workload="state")), ("dagger_sparse_unet", dict(workload="dagger", student="sparse_unet", points=4096)),
+                    ("vision_pn2", dict(workload="vision_pn2"))):
         a = copy.copy(args)
         a.steps, a.warmup, a.n_steps, a.precision = 3, 1, 0, "f32"
         for k, v in kw.items():
