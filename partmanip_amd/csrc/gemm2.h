@@ -29,6 +29,9 @@ struct Gemm2Prob {
     // at A (resp. B) with its leading dimension, or 0 where the index is negative (read from gzero, >= gC zeros).  The
     // (rows x gJ*gC) operand never exists in HBM.  LDS-DMA path only (gC % 4 == 0, K resp. N = gJ*gC).
     const int32_t* gidx; const float* gzero; int gJ, gC;
+    int gsh;                      // log2(gC) when gC is a power of two, else -1 (filled by the launcher): the loader splits a virtual
+                                  // column into (tap, channel) per 16-byte piece and K-step -- as a shift / mask instead of two integer
+                                  // divisions (~10 VALU instructions each, issued from the SIMDs the MFMA waves run on)
     // scattered result (the input gradient of a convolution whose patches do not overlap): element (row r, column q) goes to
     // row sidx[r*sJ + q/sC], column q%sC of the matrix at C (row stride sC), and is dropped where the index is negative; H
     // (G2_EPI_MUL_DACT) is read at the same place.  sC % 4 == 0.  Rows no element maps to keep their contents.

@@ -400,6 +400,10 @@ __device__ __forceinline__ void g2_dma_tile(const float* __restrict__ P, long ld
     }
 }
 
+// (forward orientation only: there the column moves with the K-step; in the weight-gradient orientation it is loop-invariant,
+// the compiler hoists the divisions, and the shift form measured 7 % SLOWER -- 5.60 -> 6.01 ms at 2.7 M rows x 1728 x 64)
+__device__ __forceinline__ int g2_tap(const Gemm2Prob& g, int q) { return g.gsh >= 0 ? q >> g.gsh : q / g.gC; }
+__device__ __forceinline__ int g2_chan(const Gemm2Prob& g, int q) { return g.gsh >= 0 ? q & (g.gC - 1) : q % g.gC; }
 // The same for a GATHERED operand (see Gemm2Prob::gidx).  The neighbour indices of a tile are ordinary loads; VMEM returns in
 // order, so waiting for them would also drain every LDS-DMA issued before -- they are therefore fetched one K-step ahead
 // (`gi`: this tile's indices, loaded while the previous tile was issued; refilled here for the next tile `k0n`).
@@ -422,9 +426,9 @@ __device__ __forceinline__ void g2_dma_tile_gather(const Gemm2Prob& g, const flo
             rr = min(r0 + row, nrows - 1);
             q = k0 + ((c ^ ((row >> 1) & 7)) << 2);
             qn = k0n + ((c ^ ((row >> 1) & 7)) << 2);
-            const float* src = gi[j] >= 0 ? P + (long)gi[j] * ld + (q % g.gC) : g.gzero + (q % g.gC);
+            const float* src = gi[j] >= 0 ? P + (long)gi[j] * ld + g2_chan(g, q) : g.gzero + g2_chan(g, q);
             __builtin_amdgcn_global_load_lds(src, (g2_lds_ptr)(S + piece * 256), 16, 0, 0);
-            gi[j] = g.gidx[(long)rr * g.gJ + qn / g.gC];
+            gi[j] = g.gidx[(long)rr * g.gJ + g2_tap(g, qn)];
         }
     }
 }
@@ -438,7 +442,7 @@ __device__ __forceinline__ void g2_gather_first(const Gemm2Prob& g, int r0, int 
             gi[j] = k0 + k < g.K ? g.gidx[(long)(k0 + k) * g.gJ + min(r0 + c * 4, nrows - 4) / g.gC] : -1;
         } else {
             const int row = piece * 8 + (lane >> 3), c = lane & 7;
-            gi[j] = g.gidx[(long)min(r0 + row, nrows - 1) * g.gJ + (k0 + ((c ^ ((row >> 1) & 7)) << 2)) / g.gC];
+            gi[j] = g.gidx[(long)min(r0 + row, nrows - 1) * g.gJ + g2_tap(g, k0 + ((c ^ ((row >> 1) & 7)) << 2))];
         }
     }
 }
@@ -827,7 +831,10 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
     }
     if (gather) {                                                          // virtual (gathered) operand: LDS-DMA kernels only
         for (int i = 0; i < g.n; ++i) {
-            const Gemm2Prob& q = g.p[i];
+            Gemm2Prob& q = g.p[i];
+            q.gsh = -1;
+            for (int sh = 0; sh < 31; ++sh)
+                if (q.gC == (1 << sh)) q.gsh = sh;
             const bool kok = A_KM ? (q.kchunk % G2_TK == 0) : (q.K % G2_TK == 0 && q.kchunk % G2_TK == 0);
             if (!q.gidx || !q.gzero || !vec || !kok || q.gC % 4 != 0 || q.gJ < 1 || (long)q.gJ * q.gC != (A_KM ? q.N : q.K)) return PM_EINVAL;
         }
