@@ -805,6 +805,12 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
         if (maxM <= 64) wm = 1;
         if (maxN <= 64) wn = 1;
     }
+    // A GATHERED forward operand (sparse convolutions): 64-row tiles.  Measured at cfg 5's shapes (tools/time_sparse_conv.py,
+    // PM_G2_TILE A/B): 2.7 M x 1728 x 64 -- 64 x 64: 5.76 ms, 128 x 64: 6.07; 0.62 M x 3456 x 128 -- 64 x 128: 4.98 ms, 128 x 128:
+    // 5.80, 64 x 64: 5.15, 128 x 64: 5.57.  The 128 x 128 tile's three LDS stages (98 KB) leave ONE work-group per CU -- one
+    // multiplying wave per SIMD, whose every stall idles the matrix pipe -- and a gathered row costs its loader more issue slots
+    // than a plain one; 64 x 128 (74 KB) keeps two work-groups resident.
+    if (big && gather && !A_KM) { wm = 1; wn = maxN > 64 ? 2 : 1; }
 #ifdef G2_TILE_ENV                                         // A/B builds only: PM_G2_TILE=21 / 12 / 22 forces the (wm, wn) of forward / data-gradient launches
     if (const char* e = getenv("PM_G2_TILE"); e && dma && !(A_KM && B_KM)) { wm = e[0] - '0'; wn = e[1] - '0'; }
     if (const char* e = getenv("PM_G2_WTILE"); e && dma && A_KM && B_KM) { wm = e[0] - '0'; wn = e[1] - '0'; }   // weight gradients
