@@ -813,7 +813,7 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
     if (big && gather && !A_KM) { wm = 1; wn = maxN > 64 ? 2 : 1; }
 #ifdef G2_TILE_ENV                                         // A/B builds only: PM_G2_TILE=21 / 12 / 22 forces the (wm, wn) of forward / data-gradient launches
     if (const char* e = getenv("PM_G2_TILE"); e && dma && !(A_KM && B_KM)) { wm = e[0] - '0'; wn = e[1] - '0'; }
-    if (const char* e = getenv("PM_G2_WTILE"); e && dma && A_KM && B_KM) { wm = e[0] - '0'; wn = e[1] - '0'; }   // weight gradients
+    if (const char* e = getenv("PM_G2_WTILE"); e && (dma || gather) && A_KM && B_KM) { wm = e[0] - '0'; wn = e[1] - '0'; }   // weight gradients
 #endif
     // weight gradients of <= 32 output rows: the 32 x 128 tile (1 x 4 waves) of the LDS-DMA kernels
     const bool lay1 = A_KM && B_KM && (dma || gather) && vec && maxM <= 32 && maxN > 64;
