@@ -221,13 +221,15 @@ def gaussian_logp_entropy(mu, log_std, x):
     return logp, ent.expand(mu.shape[0])
 
 
-def update_act_cri(p, model_cfg, obs, actions, proprio_shape=0):
-    """actor_critic.py:71-82 -> (log_prob (B,), entropy (B,), value (B,1), mu (B,A), log_std rows (B,A))."""
+def update_act_cri(p, model_cfg, obs, actions, proprio_shape=0, with_value=True):
+    """actor_critic.py:71-82 -> (log_prob (B,), entropy (B,), value (B,1), mu (B,A), log_std rows (B,A)).
+    with_value=False skips the critic forward the reference also runs (its result never enters the actor loss): only for the
+    tests' fp64 evaluation of the actor's trajectory, where it halves the cost."""
     net = model_cfg["network"]
     mu = net_forward(p, "actor", net, obs, proprio_shape)
     x = action_deactivation(actions, model_cfg["action_activate"], model_cfg["clipAction"])
     logp, ent = gaussian_logp_entropy(mu, p["log_std"], x)
-    value = net_forward(p, "critic", net, obs, proprio_shape)
+    value = net_forward(p, "critic", net, obs, proprio_shape) if with_value else None
     return logp, ent, value, mu, p["log_std"].repeat(mu.shape[0], 1)
 
 
@@ -338,7 +340,7 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic
         lists = seq_lists if seq_lists is not None else minibatch_index_lists(n, cfg["n_minibatches"], sampler)
         for idx in lists:
             logp, _, _, mu, ls = update_act_cri(p, model_cfg, flat["observations"][idx], flat["actions"][idx],
-                                                cfg.get("proprio_shape", 0))
+                                                cfg.get("proprio_shape", 0), with_value="critic" in loops)
             kl_mean, loss = actor_loss_terms(logp, mu, ls, flat["actions_log_prob"][idx], flat["advantages"][idx],
                                              flat["mu"][idx], flat["sigma"][idx], cfg["epsilon_clip"],
                                              tricks["mini_adv_norm"])
