@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void vx_grid0_kernel(const float* __restrict__
 // 27 neighbours of every row: nbr[r][o], o = (dx+1)*9 + (dy+1)*3 + (dz+1); offset 26 - o is the mirrored one.  ld >= 27 is the
 // table's row stride: columns 27 .. ld-1 are written as -1 ("absent" taps that pad the gathered operand of a layer whose
 // 27 * C_in is not a whole number of K-steps -- conv0: 27 x 4 = 108 -> 32 taps = 128 columns).
-// (Four elements per thread and trip, their loads issued back to back, measured 14 % SLOWER than this one-at-a-time loop.)
+// (Measured SLOWER than this one-entry-per-thread loop: four entries per thread and trip with their loads issued back to back
+// (-14 %); one thread per (row, dx, dy) covering the three dz neighbours -- a third of the index arithmetic, three consecutive
+// stores per thread -- cost the SparseUNet forward +0.5 ms: the coalesced 4-byte store stream is what this kernel lives on.)
 __global__ __launch_bounds__(256) void vx_nbr27_kernel(const int32_t* __restrict__ coords, long rows, const int32_t* __restrict__ grid,
                                                         int R, int32_t* __restrict__ nbr, int ld) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < rows * ld; e += (long)gridDim.x * 256) {
@@ -182,12 +184,27 @@ __global__ __launch_bounds__(256) void rows_gather_bwd_kernel(const float* __res
         // self_col >= 0: the row only has consumers if the table's own-cell entry points back at it (a duplicate coordinate
         // is never anybody's neighbour: its gradient is zero, not its canonical twin's)
         const bool live = self_col < 0 || tidx[r * J + self_col] == (int)r;
-        for (int j = 0; live && j < J; ++j) {
-            const int i = tidx[r * J + (reverse ? J - 1 - j : j)];
-            if (i >= 0) {
-                const int blk = mode == 0 ? j : (mode == 1 ? tslot[r * J + j] : 0);
-                const float4 v = *(const float4*)(dcols + (long)i * ldc + (long)blk * C + 4 * q);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        if (live && J <= 8 && mode != 1) {
+            // up to eight sources (the children of a coarse row): all indices first, then all rows -- eight independent loads in
+            // flight instead of a chain of index -> row -> index -> row; same summation order
+            int ix[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ix[j] = j < J ? tidx[r * J + (reverse ? J - 1 - j : j)] : -1;
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = ix[j] >= 0 ? *(const float4*)(dcols + (long)ix[j] * ldc + (long)(mode == 0 ? j : 0) * C + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (ix[j] >= 0) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+        } else {
+            for (int j = 0; live && j < J; ++j) {
+                const int i = tidx[r * J + (reverse ? J - 1 - j : j)];
+                if (i >= 0) {
+                    const int blk = mode == 0 ? j : (mode == 1 ? tslot[r * J + j] : 0);
+                    const float4 v = *(const float4*)(dcols + (long)i * ldc + (long)blk * C + 4 * q);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
             }
         }
         float4* o = (float4*)(dsrc + r * lds + 4 * q);
