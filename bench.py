@@ -701,7 +701,8 @@ def secondary_lines(args, device):
     import gc
     res = {}
     for key, kw in (("state", dict(workload="state")), ("dagger_sparse_unet", dict(workload="dagger", student="sparse_unet", points=4096)),
-                    ("vision_pn2", dict(workload="vision_pn2"))):
+                    # (its CPU baseline alone takes ~4 minutes of host time: `python bench.py --workload vision_pn2` reports it)
+                    ("vision_pn2", dict(workload="vision_pn2", no_cpu_baseline=True))):
         a = copy.copy(args)
         a.steps, a.warmup, a.n_steps, a.precision = 3, 1, 0, "f32"
         for k, v in kw.items():
