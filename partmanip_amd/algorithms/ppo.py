@@ -561,6 +561,12 @@ class ppo:
 
         self._geom = None
         acc = self._acc.tolist()                              # the only host sync of the update
+        from ..algo_utils import network as _net
+        if _net.CHAIN_LAUNCH:                                 # opt-in chained layers: a stripe hand-off that gave up must not pass silently
+            for net in (ac.actor, ac.critic):
+                ch = getattr(net, '_chain', None)
+                if ch is not None and ch._cws is not None and ops.chain_gave_up(ch._cws):
+                    raise RuntimeError("a chained-layer launch ran into its spin limit (PARTMANIP_CHAIN=1): its results are invalid")
         sum_surr, sum_kl, kl_max, count, sum_v, n_v = acc[:6]
         if not all(np.isfinite(acc[:6])):
             print("WARNING: non-finite training statistics (loss / KL sums: "
