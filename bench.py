@@ -340,15 +340,26 @@ def run_depth2pc(args, device):
                            sparse_voxel_ms=dv * 1e3, sparse_voxel_band_voxels=band,
                            baseline="'~0.5s' for the sampling alone, utils/depth2tsdf.py:158 (BASELINE.md); "
                                     "vs_baseline = sampling time / 0.5 s"))
-    # dominant kernel: streaming farthest-point sampling -- every one of the K rounds re-reads each surviving point
-    # (12 B) and its running min-distance (4 B) and writes the min-distance back (4 B)
-    pts = float(n0.float().sum().item())
-    nbytes = 1024.0 * pts * 20.0
+    # dominant kernel: farthest-point sampling on G = 256 / envs work-groups per cloud (csrc/pointops.hip: fps_multi_kernel): each keeps
+    # 16 384 points of its chunk in registers and 8 192 in LDS for all K rounds; only the remainder re-reads its points (12 B) and
+    # running min-distance (4 B + 4 B back) every round
+    nn = n0.to(torch.int64).cpu()
+    G = max(1, min(8, 256 // b))
+    chunk = (nn + G - 1) // G
+    big = nn > 8192
+    streamed = torch.where(big, (chunk - 16384 - 8192).clamp(min=0) * G, nn.clamp(min=0) * 0).sum().item() if G >= 2 else float(nn[big].sum())
+    pts = float(nn.sum().item())
+    nbytes = 1024.0 * streamed * 20.0 + pts * 12.0
     gbs = nbytes / dfps / 1e9
-    out["roofline"] = dict(bound="hbm", kernel="fps_varlen (streaming rounds)", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
-                           frac=gbs / PEAK_HBM_GBS, traffic=None, mean_launch_ms=dfps * 1e3, bytes_per_launch=nbytes,
-                           note="64 clouds x ~134 k surviving points: the 1024 rounds re-read a working set that sits in the 256 MB "
-                                "Infinity Cache, so `achieved` is cache + HBM bandwidth, not DRAM traffic")
+    out["roofline"] = dict(bound="hbm", kernel="fps_multi_kernel (on-chip chunks, streamed remainder)", achieved=gbs, peak=PEAK_HBM_GBS,
+                           unit="GB/s", frac=gbs / PEAK_HBM_GBS, traffic=None, mean_launch_ms=dfps * 1e3, bytes_per_launch=nbytes,
+                           us_per_round=dfps * 1e6 / 1024.0, points=pts, points_streamed_per_round=float(streamed),
+                           one_work_group_per_cloud_bytes=1024.0 * pts * 20.0,
+                           note="the kernel is bound by its K = 1024 DEPENDENT rounds (per round: ~33 distance updates per thread, a "
+                                "work-group arg-max, one hand-off between the cloud's work-groups) and by the remainder that does not fit "
+                                "on chip (256 CUs x 24 576 points = 6.3 M of this call's 8.6 M: `points_streamed_per_round`, served by "
+                                "L2 / Infinity Cache); `one_work_group_per_cloud_bytes` is what the round-2 streaming kernel moved per "
+                                "call (2.8 TB/s, 59 ms)")
     if not args.no_cpu_baseline:
         from oracle import ref_cpu as R
         ncpu = os.cpu_count() or 1

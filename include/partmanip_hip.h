@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 137 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 138 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -364,6 +364,8 @@ int pm_depth_backproject_f32(const float* depth, int B, int M, int H, int W, con
  * (no -1 padding: once every point is taken the lowest index repeats, as on the full cloud); workspace
  * B*ld floats when ld > 8192. */
 int pm_depth_compact_f32(const float* xyz, int B, int P, float* out, int32_t* lengths, void* stream);
+size_t pm_fps_varlen_workspace_bytes(int B, int ld); /* 0 when every cloud fits in registers (ld <= 8192); with it (8-byte aligned) camera-sized
+                                                      * xyz clouds run on several work-groups per cloud, each keeping its chunk on chip */
 int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths,
                       int pad /* 1: pytorch3d semantics, -1 once a cloud is exhausted; 0: keep sampling (see above) */,
                       int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "pm_depth_backproject_f32": (I, [P, I, I, I, I, P, F, F, F, F, P, P, P, P]),
     "pm_depth_compact_f32": (I, [P, I, I, P, P, P]),
     "pm_fps_varlen_f32": (I, [P, I, I, I, I, P, I, P, P, Z, P]),
+    "pm_fps_varlen_workspace_bytes": (Z, [I, I]),
     "pm_tsdf_select_f32": (I, [P, I, I, F, F, P, P, P]),
     "pm_gaussian_sample_f32": (I, [P, L, P, P, I, I, F, I, P, P, P, P]),
     "pm_rms_update_workspace_bytes": (Z, [I]),
@@ -144,7 +145,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 137                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 138                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

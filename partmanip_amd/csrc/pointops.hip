@@ -133,11 +133,12 @@ __global__ __launch_bounds__(FPS_NT) void fps_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(FPS_NT) void fps_varlen_kernel(const float* __restrict__ xyz, int ld, int D, int K,
                                                              const int32_t* __restrict__ lengths, int pad,
                                                              int32_t* __restrict__ idx_out,
-                                                             float* __restrict__ mind_ws) {
+                                                             float* __restrict__ mind_ws, int small_only) {
     __shared__ float sv[FPS_NT / 64];
     __shared__ int si[FPS_NT / 64];
     __shared__ float sel[FPS_MAXD];
     const int b = blockIdx.x, n = lengths[b];
+    if (small_only && n > FPS_NT * FPS_RPT) return;      // (fps_multi_kernel samples the big clouds of this batch)
     const float* pts = xyz + (long)b * ld * D;
     int32_t* idx_b = idx_out + (long)b * K;
     if (n <= 0) {                                        // empty cloud: pytorch3d yields -1 everywhere
@@ -506,12 +507,191 @@ extern "C" int pm_maxpool_rows_bwd_f32(const float* dout, long lddo, const int32
 
 extern "C" int pm_version(void) { return PM_ABI_VERSION; }
 
+// ---- camera-sized clouds on SEVERAL work-groups per cloud ----------------------------------------------------------------
+// The streaming rounds of fps_body re-read every surviving point (12 B) and its running min-distance (4 B + 4 B back) from
+// L2 / Infinity Cache in each of the K rounds -- 176 GB per depth2pc call at 64 envs x 134 k points, 2.8 TB/s from the 64
+// CUs that one work-group per env occupies.  Here G work-groups share a cloud (G * B <= the CU count, so that
+// all of them are resident) and each keeps ITS chunk of the cloud ON CHIP for all K rounds: FM_RPT points per thread in
+// registers (x, y, z, min-distance: 64 VGPRs), the next FM_LDS points in LDS (128 KB), only what is left streams (four
+// points per trip).  A round is then ~33 distance updates per thread, a work-group arg-max (as before) and ONE hand-off between the G work-groups of the
+// cloud: each publishes its (distance, index) candidate as two 8-byte {round, value} granules (agent-scope atomic stores:
+// write-through, the data IS the flag -- MI355X_MICROARCH.md form R2), one wave of every work-group sweeps the 2 G granules
+// of its cloud until all carry this round's tag, and every work-group takes the same lowest-index arg-max.  Same fp32
+// distance expression and tie-breaks as fps_body: bit-identical indices.
+#ifndef FM_RPT
+#define FM_RPT 16             // measured per depth2pc call (64 envs x ~134 k points, K = 1024): 8: 14.6 ms, 12: 11.3, 14: 10.0, 16: 8.9,
+#endif                        // 20: 12.1, 24: 15.1 -- beyond 16 the 4 x FM_RPT point registers spill (128-VGPR budget at 1024 threads)
+#define FM_LDS 8192
+#define FM_MAXG 8
+#define FM_SPIN_LIMIT (1u << 22)
+typedef unsigned long long fm_u64;
+template <bool PAD>
+__global__ __launch_bounds__(FPS_NT) void fps_multi_kernel(const float* __restrict__ xyz, int ld, int K,
+                                                            const int32_t* __restrict__ lengths, int32_t* __restrict__ idx_out,
+                                                            float* __restrict__ mind_ws, fm_u64* __restrict__ slots, int G) {
+    extern __shared__ __attribute__((aligned(16))) float fm_lds[];           // [FM_LDS][4]: x, y, z, min-distance
+    __shared__ float sv[FPS_NT / 64];
+    __shared__ int si[FPS_NT / 64];
+    __shared__ float sel[4];
+    __shared__ int s_cur;
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G, tid = threadIdx.x;
+    const int n = lengths[b];
+    const float* pts = xyz + (long)b * ld * 3;
+    int32_t* idx_b = idx_out + (long)b * K;
+    fm_u64* err = slots + (long)gridDim.x * 2;
+    if (n <= FPS_NT * FPS_RPT) return;                   // small / empty clouds: fps_varlen_kernel (launched beside this one) samples them
+    const int chunk = (n + G - 1) / G, lo = g * chunk, hi = min(n, lo + chunk), cnt = max(hi - lo, 0);
+    const int n_reg = min(cnt, FPS_NT * FM_RPT), n_lds = min(cnt - n_reg, FM_LDS), n_str = cnt - n_reg - n_lds;
+    float px[FM_RPT], py[FM_RPT], pz[FM_RPT], md[FM_RPT];
+#pragma unroll
+    for (int r = 0; r < FM_RPT; ++r) {
+        const int l = tid + r * FPS_NT;
+        const bool in = l < n_reg;
+        const float* q = pts + (long)(lo + (in ? l : 0)) * 3;
+        px[r] = in ? q[0] : 0.f; py[r] = in ? q[1] : 0.f; pz[r] = in ? q[2] : 0.f;
+        md[r] = INFINITY;
+    }
+    for (int l = tid; l < n_lds; l += FPS_NT) {
+        const float* q = pts + (long)(lo + n_reg + l) * 3;
+        *(float4*)(fm_lds + 4 * l) = make_float4(q[0], q[1], q[2], INFINITY);
+    }
+    float* mind_g = mind_ws + (long)b * ld + lo + n_reg + n_lds;             // streamed remainder
+    const float* pstr = pts + (long)(lo + n_reg + n_lds) * 3;
+    for (int l = tid; l < n_str; l += FPS_NT) mind_g[l] = INFINITY;
+    fm_u64* my = slots + (long)blockIdx.x * 2;
+    const fm_u64* cloud = slots + (long)b * G * 2;
+    int cur = 0;
+    for (int j = 0; j < K; ++j) {
+        if (PAD && j >= n) {
+            if (tid == 0 && g == 0) idx_b[j] = -1;
+            continue;
+        }
+        if (tid == 0 && g == 0) idx_b[j] = cur;
+        if (tid < 3) sel[tid] = pts[(long)cur * 3 + tid];
+        __syncthreads();
+        const float s[3] = {sel[0], sel[1], sel[2]};
+        float bv = -1.0f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < FM_RPT; ++r) {
+            const int l = tid + r * FPS_NT;
+            const float q[3] = {px[r], py[r], pz[r]};
+            const float m = fminf(md[r], dist2_rn(q, s, 3));
+            md[r] = m;
+            if (l < n_reg && m > bv) {                   // strict: the lowest index inside the thread
+                bv = m;
+                bi = lo + l;
+            }
+        }
+        for (int l = tid; l < n_lds; l += FPS_NT) {
+            float4 v = *(const float4*)(fm_lds + 4 * l);
+            const float q[3] = {v.x, v.y, v.z};
+            const float m = fminf(v.w, dist2_rn(q, s, 3));
+            fm_lds[4 * l + 3] = m;
+            if (m > bv) {
+                bv = m;
+                bi = lo + n_reg + l;
+            }
+        }
+        for (int l0 = tid; l0 < n_str; l0 += 4 * FPS_NT) {          // four points per trip, their loads issued back to back
+            float q[4][3], mo[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int l = l0 + u * FPS_NT, lc = l < n_str ? l : l0;
+                q[u][0] = pstr[(long)lc * 3]; q[u][1] = pstr[(long)lc * 3 + 1]; q[u][2] = pstr[(long)lc * 3 + 2];
+                mo[u] = mind_g[lc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int l = l0 + u * FPS_NT;
+                if (l < n_str) {
+                    const float m = fminf(mo[u], dist2_rn(q[u], s, 3));
+                    mind_g[l] = m;
+                    if (m > bv) {
+                        bv = m;
+                        bi = lo + n_reg + n_lds + l;
+                    }
+                }
+            }
+        }
+        const int wbi = block_argmax(bv, bi, sv, si);    // (sv[], si[] hold the per-wave candidates; every thread returns the winner's index)
+        // ---- hand-off between the G work-groups of this cloud (round tag j + 1: never 0, the slots are zeroed per call)
+        if (tid < 64) {
+            // this work-group's winning value: the wave candidate that carries the winning index
+            float wv = -1.0f;
+            for (int k = 0; k < FPS_NT / 64; ++k)
+                if (si[k] == wbi) wv = sv[k];
+            const fm_u64 tag = (fm_u64)(unsigned)(j + 1) << 32;
+            if (tid == 0) {
+                __hip_atomic_store(my, tag | (fm_u64)__float_as_uint(wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(my + 1, tag | (fm_u64)(unsigned)wbi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            fm_u64 x = 0;
+            unsigned spins = 0;
+            for (;;) {
+                x = tid < 2 * G ? __hip_atomic_load(cloud + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+                if (__all((x >> 32) == (tag >> 32))) break;
+                if (++spins > FM_SPIN_LIMIT) {           // a partner is not resident / has died: give up loudly, do not hang the GPU
+                    if (tid == 0) __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            // lanes 2k / 2k+1 hold work-group k's value / index: the same lowest-index arg-max on every work-group
+            float cv = __uint_as_float((unsigned)__shfl(x, 0, 64));
+            int ci = (int)(unsigned)__shfl(x, 1, 64);
+            for (int k = 1; k < G; ++k) {
+                const float ov = __uint_as_float((unsigned)__shfl(x, 2 * k, 64));
+                const int oi = (int)(unsigned)__shfl(x, 2 * k + 1, 64);
+                if (ov > cv || (ov == cv && oi < ci)) {
+                    cv = ov;
+                    ci = oi;
+                }
+            }
+            if (tid == 0) s_cur = ci;
+        }
+        __syncthreads();
+        cur = s_cur;
+    }
+}
+
+extern "C" size_t pm_fps_varlen_workspace_bytes(int B, int ld) {
+    // running min-distances of the streamed part (clouds beyond the register-resident size) + the hand-off granules of the
+    // several-work-groups-per-cloud kernel (2 per work-group, <= 256 work-groups, + the error word), 8-byte aligned behind them
+    const size_t mind = ld > FPS_NT * FPS_RPT ? (((size_t)B * ld * sizeof(float) + 7) & ~(size_t)7) : 0;
+    return mind + (mind ? (size_t)(2 * 256 + 1) * sizeof(fm_u64) : 0);
+}
+
 extern "C" int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths, int pad,
                                  int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream) {
     PM_REQUIRE(xyz && lengths && idx_out && B > 0 && ld > 0 && D >= 1 && D <= FPS_MAXD && K > 0);
     if (ld > FPS_NT * FPS_RPT && (!workspace || workspace_bytes < (size_t)B * ld * sizeof(float))) return PM_EWORKSPACE;
+    // several work-groups per cloud: xyz clouds, few enough clouds that G >= 2 work-groups each are all resident (one
+    // 1024-thread work-group of 128 VGPRs per CU), and the caller handed over the larger workspace
+    int ncu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu > 256) ncu = 256;
+    int G = ncu / B;
+    if (G > FM_MAXG) G = FM_MAXG;
+    if (D == 3 && ld > FPS_NT * FPS_RPT && G >= 2 && workspace_bytes >= pm_fps_varlen_workspace_bytes(B, ld) &&
+        ((uintptr_t)workspace & 7) == 0) {
+        const size_t mind = (((size_t)B * ld * sizeof(float) + 7) & ~(size_t)7);
+        fm_u64* slots = (fm_u64*)((char*)workspace + mind);
+        if (hipMemsetAsync(slots, 0, (size_t)(2 * B * G + 1) * sizeof(fm_u64), pm_stream(stream)) != hipSuccess) return PM_EINVAL;
+        const size_t lds = (size_t)FM_LDS * 4 * sizeof(float);
+        if (pad) hipLaunchKernelGGL((fps_multi_kernel<true>), dim3(B * G), dim3(FPS_NT), lds, pm_stream(stream), xyz, ld, K, lengths,
+                                    idx_out, (float*)workspace, slots, G);
+        else hipLaunchKernelGGL((fps_multi_kernel<false>), dim3(B * G), dim3(FPS_NT), lds, pm_stream(stream), xyz, ld, K, lengths,
+                                idx_out, (float*)workspace, slots, G);
+        // the clouds of the batch that fit one work-group's registers (decided per cloud on the device, no host sync on the lengths)
+        hipLaunchKernelGGL(fps_varlen_kernel, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, ld, D, K, lengths, pad,
+                           idx_out, (float*)workspace, 1);
+        PM_CHECK_LAUNCH();
+        return PM_OK;
+    }
     hipLaunchKernelGGL(fps_varlen_kernel, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, ld, D, K, lengths, pad,
-                       idx_out, (float*)workspace);
+                       idx_out, (float*)workspace, 0);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }

@@ -867,10 +867,14 @@ def fps_varlen(xyz, lengths, K, ws, pad=False):
     _f32c(xyz, "xyz")
     B, ld, Dd = xyz.shape
     idx = torch.empty(B, K, dtype=torch.int32, device=xyz.device)
-    nb = B * ld * 4 if ld > 8192 else 0
-    w = ws.get(nb) if nb else None
-    check(lib.pm_fps_varlen_f32(_ptr(xyz), B, ld, Dd, K, _ptr(lengths), int(pad), _ptr(idx), _ptr(w),
-                                w.numel() if w is not None else 0, _stream()), "pm_fps_varlen_f32")
+    nb = int(lib.pm_fps_varlen_workspace_bytes(B, ld))
+    w, base, al = None, 0, 0
+    if nb:
+        w = ws.get(nb + 8)
+        base = w.data_ptr()
+        al = (-base) % 8
+    check(lib.pm_fps_varlen_f32(_ptr(xyz), B, ld, Dd, K, _ptr(lengths), int(pad), _ptr(idx), (base + al) if w is not None else None,
+                                (w.numel() - al) if w is not None else 0, _stream()), "pm_fps_varlen_f32")
     return idx
 
 

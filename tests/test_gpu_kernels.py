@@ -508,6 +508,39 @@ def test_depth2pc_streaming_fps_on_a_camera_sized_cloud():
     assert np.array_equal(idx.cpu().numpy().astype(np.int64), idx_ref)
 
 
+@pytest.mark.parametrize("B,ld,K,pad", [(64, 140000, 40, False), (30, 100000, 33, True), (128, 70000, 24, False), (3, 260000, 20, True)])
+def test_varlen_fps_on_several_work_groups_per_cloud_is_bit_exact(B, ld, K, pad):
+    """Camera-sized variable-length clouds: G = 256 / B work-groups share a cloud, each keeps its chunk in registers / LDS (the
+    rest streams) and the G candidates of a round are handed over inside the launch (pm_fps_varlen_f32 with the
+    pm_fps_varlen_workspace_bytes workspace).  Indices bit-exact against the restatement for clouds of every kind in one batch:
+    empty, register-sized (one work-group), chunks that fill registers only / registers + LDS / all three regions; exact ties
+    (duplicated points, also ACROSS chunks: the lowest index must win on every work-group) and, with pad, K > length."""
+    o = ops()
+    g = np.random.default_rng(B + ld)
+    pts = (g.random((B, ld, 3), dtype=np.float32) * 2 - 1).astype(np.float32)
+    lengths = np.zeros(B, dtype=np.int32)
+    kinds = [0, 17, 5000, 8192, 8193, 30000, ld // 2, ld - 3, ld]
+    for b in range(B):
+        lengths[b] = kinds[b % len(kinds)] if b < 2 * len(kinds) else int(g.integers(9000, ld + 1))
+    for b in range(B):
+        n = int(lengths[b])
+        if n > 100:
+            src = g.integers(0, n, size=n // 50)                       # 2 % duplicates of random earlier / later points
+            dst = g.integers(0, n, size=n // 50)
+            pts[b, dst] = pts[b, src]
+            pts[b, n - 1] = pts[b, 1]                                   # a tie between the first and the last chunk
+    ref = R.fps(pts, K, lengths)
+    if not pad:                                                          # !pad keeps sampling (index 0 repeats) once a cloud is exhausted
+        for b in range(B):
+            n = int(lengths[b])
+            if 0 < n < K:
+                ref[b, n:] = 0
+    idx = o.fps_varlen(torch.from_numpy(pts).to(DEV), torch.from_numpy(lengths).to(DEV), K, o.Workspace(torch.device(DEV)), pad=pad)
+    got = idx.cpu().numpy().astype(np.int64)
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, (bad[:5], got[bad[0][0], :8], ref[bad[0][0], :8], lengths[bad[0][0]])
+
+
 def test_tsdf_integrate_matches_reference():
     """TSDFVolume.integrate (pm_tsdf_integrate_f32) against the REFERENCE's own volume (fixture), bit for bit."""
     from partmanip_amd.depth2tsdf import TSDFVolume
