@@ -538,7 +538,7 @@ __global__ __launch_bounds__(FPS_NT) void fps_multi_kernel(const float* __restri
     const int n = lengths[b];
     const float* pts = xyz + (long)b * ld * 3;
     int32_t* idx_b = idx_out + (long)b * K;
-    fm_u64* err = slots + (long)gridDim.x * 2;
+    fm_u64* err = slots + 4 * 256;                        // fixed place (the last word of the reservation): the host reads it
     if (n <= FPS_NT * FPS_RPT) return;                   // small / empty clouds: fps_varlen_kernel (launched beside this one) samples them
     const int chunk = (n + G - 1) / G, lo = g * chunk, hi = min(n, lo + chunk), cnt = max(hi - lo, 0);
     const int n_reg = min(cnt, FPS_NT * FM_RPT), n_lds = min(cnt - n_reg, FM_LDS), n_str = cnt - n_reg - n_lds;
@@ -558,8 +558,12 @@ __global__ __launch_bounds__(FPS_NT) void fps_multi_kernel(const float* __restri
     float* mind_g = mind_ws + (long)b * ld + lo + n_reg + n_lds;             // streamed remainder
     const float* pstr = pts + (long)(lo + n_reg + n_lds) * 3;
     for (int l = tid; l < n_str; l += FPS_NT) mind_g[l] = INFINITY;
-    fm_u64* my = slots + (long)blockIdx.x * 2;
-    const fm_u64* cloud = slots + (long)b * G * 2;
+    // TWO granule sets, used by alternate rounds: a work-group that has passed round j's sweep may publish round j + 1 while a
+    // slower partner is still sweeping round j -- into the other set, so the sweep always finds round j's tags (nobody can be
+    // two rounds ahead: round j + 1's sweep needs every partner's round-j + 1 candidate)
+    fm_u64* my0 = slots + (long)blockIdx.x * 2;
+    const fm_u64* cloud0 = slots + (long)b * G * 2;
+    const long set_stride = (long)gridDim.x * 2;
     int cur = 0;
     for (int j = 0; j < K; ++j) {
         if (PAD && j >= n) {
@@ -622,6 +626,8 @@ __global__ __launch_bounds__(FPS_NT) void fps_multi_kernel(const float* __restri
             for (int k = 0; k < FPS_NT / 64; ++k)
                 if (si[k] == wbi) wv = sv[k];
             const fm_u64 tag = (fm_u64)(unsigned)(j + 1) << 32;
+            fm_u64* my = my0 + (j & 1) * set_stride;
+            const fm_u64* cloud = cloud0 + (j & 1) * set_stride;
             if (tid == 0) {
                 __hip_atomic_store(my, tag | (fm_u64)__float_as_uint(wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(my + 1, tag | (fm_u64)(unsigned)wbi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -657,9 +663,9 @@ __global__ __launch_bounds__(FPS_NT) void fps_multi_kernel(const float* __restri
 
 extern "C" size_t pm_fps_varlen_workspace_bytes(int B, int ld) {
     // running min-distances of the streamed part (clouds beyond the register-resident size) + the hand-off granules of the
-    // several-work-groups-per-cloud kernel (2 per work-group, <= 256 work-groups, + the error word), 8-byte aligned behind them
+    // several-work-groups-per-cloud kernel (two sets of 2 per work-group, <= 256 work-groups, + the error word), 8-byte aligned behind them
     const size_t mind = ld > FPS_NT * FPS_RPT ? (((size_t)B * ld * sizeof(float) + 7) & ~(size_t)7) : 0;
-    return mind + (mind ? (size_t)(2 * 256 + 1) * sizeof(fm_u64) : 0);
+    return mind + (mind ? (size_t)(4 * 256 + 1) * sizeof(fm_u64) : 0);
 }
 
 extern "C" int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths, int pad,
@@ -674,11 +680,12 @@ extern "C" int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, 
     if (ncu > 256) ncu = 256;
     int G = ncu / B;
     if (G > FM_MAXG) G = FM_MAXG;
-    if (D == 3 && ld > FPS_NT * FPS_RPT && G >= 2 && workspace_bytes >= pm_fps_varlen_workspace_bytes(B, ld) &&
-        ((uintptr_t)workspace & 7) == 0) {
-        const size_t mind = (((size_t)B * ld * sizeof(float) + 7) & ~(size_t)7);
-        fm_u64* slots = (fm_u64*)((char*)workspace + mind);
-        if (hipMemsetAsync(slots, 0, (size_t)(2 * B * G + 1) * sizeof(fm_u64), pm_stream(stream)) != hipSuccess) return PM_EINVAL;
+    const bool full_ws = ld > FPS_NT * FPS_RPT && workspace_bytes >= pm_fps_varlen_workspace_bytes(B, ld) && ((uintptr_t)workspace & 7) == 0;
+    const size_t mind = (((size_t)B * ld * sizeof(float) + 7) & ~(size_t)7);
+    fm_u64* slots = (fm_u64*)((char*)workspace + mind);
+    // a caller that handed over the full reservation may read its last word (the give-up flag) after ANY call: clear it always
+    if (full_ws && hipMemsetAsync(slots, 0, (size_t)(4 * 256 + 1) * sizeof(fm_u64), pm_stream(stream)) != hipSuccess) return PM_EINVAL;
+    if (D == 3 && G >= 2 && full_ws) {
         const size_t lds = (size_t)FM_LDS * 4 * sizeof(float);
         if (pad) hipLaunchKernelGGL((fps_multi_kernel<true>), dim3(B * G), dim3(FPS_NT), lds, pm_stream(stream), xyz, ld, K, lengths,
                                     idx_out, (float*)workspace, slots, G);

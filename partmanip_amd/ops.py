@@ -875,6 +875,12 @@ def fps_varlen(xyz, lengths, K, ws, pad=False):
         al = (-base) % 8
     check(lib.pm_fps_varlen_f32(_ptr(xyz), B, ld, Dd, K, _ptr(lengths), int(pad), _ptr(idx), (base + al) if w is not None else None,
                                 (w.numel() - al) if w is not None else 0, _stream()), "pm_fps_varlen_f32")
+    if nb and not torch.cuda.is_current_stream_capturing():
+        # the several-work-groups-per-cloud kernel gives up (bounded spin) rather than hang when a partner work-group is not
+        # resident; its error word is the last 8 bytes of the reservation.  One host read per >= 8192-point batch of clouds.
+        if int(w[al + nb - 8: al + nb].view(torch.int64).item()) != 0:
+            raise RuntimeError("pm_fps_varlen_f32: a work-group of the multi-work-group FPS gave up waiting for its partners "
+                               "(not all work-groups resident?) -- the sampled indices are not valid")
     return idx
 
 

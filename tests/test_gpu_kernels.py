@@ -541,6 +541,31 @@ def test_varlen_fps_on_several_work_groups_per_cloud_is_bit_exact(B, ld, K, pad)
     assert bad.size == 0, (bad[:5], got[bad[0][0], :8], ref[bad[0][0], :8], lengths[bad[0][0]])
 
 
+def test_varlen_fps_hand_off_under_competing_load():
+    """The same launch while another stream keeps the CUs busy with GEMMs of uneven length (work-groups of a cloud then start and
+    finish their rounds at different times, some a round ahead of their partners -- the two alternating granule sets): the
+    indices stay bit-identical over repeated calls and equal the restatement; no work-group gives up."""
+    o = ops()
+    B, ld, K = 40, 90000, 48
+    g = np.random.default_rng(77)
+    pts = (g.random((B, ld, 3), dtype=np.float32) * 2 - 1).astype(np.float32)
+    lengths = g.integers(20000, ld + 1, size=B).astype(np.int32)
+    ref = R.fps(pts, K, lengths)
+    x, n = torch.from_numpy(pts).to(DEV), torch.from_numpy(lengths).to(DEV)
+    ws = o.Workspace(torch.device(DEV))
+    side = torch.cuda.Stream()
+    mats = [torch.randn(m, m, device=DEV) for m in (512, 1536, 3072, 640)]
+    torch.cuda.synchronize()
+    for it in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(12):
+                for a in mats:
+                    a @ a
+        idx = o.fps_varlen(x, n, K, ws, pad=False)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref), it
+    torch.cuda.synchronize()
+
+
 def test_tsdf_integrate_matches_reference():
     """TSDFVolume.integrate (pm_tsdf_integrate_f32) against the REFERENCE's own volume (fixture), bit for bit."""
     from partmanip_amd.depth2tsdf import TSDFVolume
