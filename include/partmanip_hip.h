@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 138 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 139 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -406,8 +406,9 @@ int pm_conv3d_c1_wgrad_f32(const float* dz, long lddz, const float* x, int B, in
 int pm_im2col3d_f32(const float* x, int B, int C, int D, int H, int W, int k, int stride, int pad, long sb, long sc,
                     long sd, long sh, long sw, float* cols, int ldc, void* stream);
 int pm_col2im3d_f32(const float* dcols, int B, int C, int D, int H, int W, int k, int stride, int pad, long sb,
-                    long sc, long sd, long sh, long sw, const float* y_tanh /* NULL, or x itself when it is a tanh
-                    output laid out like dx: dx *= 1 - x^2 */, float* dx, int ldc, void* stream);
+                    long sc, long sd, long sh, long sw, const float* y_tanh /* NULL, or x itself when it is an activation
+                    output laid out like dx: dx *= act'(x), 1 - x^2 for tanh */, int act /* PM_ACT_* of that layer */,
+                    float* dx, int ldc, void* stream);
 
 /* ------------------------------------------------------------------ TSDF integration (observation side)
  * utils/depth2tsdf.py:68-86 `TSDFVolume.integrate`: depth (B, M, H*W) -> out (B, V) truncated signed distances

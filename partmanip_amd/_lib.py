@@ -86,7 +86,7 @@ SIGNATURES = {
     "pm_conv3d_c1_wgrad_workspace_bytes": (Z, [I]),
     "pm_conv3d_c1_fwd_f32": (I, [P, I, I, I, I, I, I, I, L, L, L, L, P, P, I, I, P, L, P, P]),
     "pm_conv3d_c1_wgrad_f32": (I, [P, L, P, I, I, I, I, I, I, I, L, L, L, L, I, P, L, P, P, P, Z, P]),
-    "pm_col2im3d_f32": (I, [P, I, I, I, I, I, I, I, I, L, L, L, L, L, P, P, I, P]),
+    "pm_col2im3d_f32": (I, [P, I, I, I, I, I, I, I, I, L, L, L, L, L, P, I, P, I, P]),
     "pm_tsdf_integrate_f32": (I, [P, P, P, I, I, L, L, F, F, P, P]),
     "pm_voxel_grid0_f32": (I, [P, L, I, I, I, I, P, P, P, P]),
     "pm_voxel_nbr27_i32": (I, [P, L, P, I, P, I, P]),
@@ -145,7 +145,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 138                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 139                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -17,8 +17,9 @@ import torch.nn as nn
 from .. import ops
 
 # network.py:7-24: every activation the reference's `get_activation` knows, as epilogues of the Linear kernels and in the fused
-# PointNet encoder (tanh: the tuned kernels; the others: their generic instantiation).  The plug-in backbones that are absent
-# from the reference (PointNet2, SparseUNet) and the Conv3DNet stencil kernels are tanh kernels -- every shipped cfg's activation.
+# PointNet encoder (tanh: the tuned kernels; the others: their generic instantiation) and in Conv3DNet (whose input-layer
+# stencil is a tanh kernel: other activations run that layer as patch matrix + GEMM).  The plug-in backbones that are absent
+# from the reference (PointNet2, SparseUNet) are tanh kernels -- every shipped cfg's activation.
 _LINEAR_ACT = {"tanh": ops.ACT_TANH, "relu": ops.ACT_RELU, "crelu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "elu": ops.ACT_ELU,
                "selu": ops.ACT_SELU, "sigmoid": ops.ACT_SIGMOID}
 _SUPPORTED_ACT = {"tanh": ops.ACT_TANH}
@@ -916,7 +917,9 @@ class Conv3DNet(_HipNet):
         super().__init__()
         self.res = round(input_dim ** (1 / 3))
         act = net_cfg['activation']
-        code = _act_code(act)
+        # every activation of get_activation (network.py:7-24, :70): the layers are GEMMs with activation epilogues; the
+        # single-channel input layer's direct stencil kernels are tanh kernels, other activations take its patch-matrix form
+        code = _act_code(act, linear_only=True)
         self.encoder = _ConvEncoder(1, self.FILTERS, self.KERNELS, self.STRIDES)
         self.activation = get_activation(act)
         self.final_mlp = nn.Sequential(nn.Linear(32 * 27 + proprio_shape, 256), self.activation, nn.Linear(256, output_dim))
@@ -1087,7 +1090,7 @@ class Conv3DNet(_HipNet):
             dz = torch.empty_like(y_prev)
             e, c = ext[i], convs[i - 1].out_channels
             as5 = lambda t: t.view(B, e, e, e, c).permute(0, 4, 1, 2, 3)
-            ops.col2im3d(dcols, as5(dz), k, st, k // 2, as5(y_prev))
+            ops.col2im3d(dcols, as5(dz), k, st, k // 2, as5(y_prev), self._act)
 
 
 def _out_of_scope(name):

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__
 // dx[b,c,d,h,w] = sum over the (output position, tap) pairs that read it -- a gather per input element
 // (deterministic, no atomics): tap kd contributes iff (d + pad - kd) is a non-negative multiple of stride below Do.
 __global__ __launch_bounds__(256) void col2im3d_kernel(const float* __restrict__ dcols, Conv3dGeom g, long total,
-                                                        const float* __restrict__ y_tanh, float* __restrict__ dx) {
+                                                        const float* __restrict__ y_tanh, int act, float* __restrict__ dx) {
     const int k3 = g.k * g.k * g.k, kk = g.k * g.k;
 #pragma unroll 4                                   // four independent elements in flight per thread: the chain decode -> load ->
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {   // load -> store is latency-bound
@@ -84,9 +84,9 @@ __global__ __launch_bounds__(256) void col2im3d_kernel(const float* __restrict__
             }
         }
         const long at = b * g.sb + c * g.sc + d * g.sd + h * g.sh + w * g.sw;
-        if (y_tanh) {                                       // x is the previous layer's tanh output: fold its derivative in
+        if (y_tanh) {                                       // x is the previous layer's activation output: fold its derivative in
             const float y = y_tanh[at];
-            s *= (1.0f - y * y);
+            s *= (act == PM_ACT_TANH) ? (1.0f - y * y) : pm_dact(y, act);
         }
         dx[at] = s;
     }
@@ -119,16 +119,17 @@ extern "C" int pm_im2col3d_f32(const float* x, int B, int C, int D, int H, int W
 }
 
 extern "C" int pm_col2im3d_f32(const float* dcols, int B, int C, int D, int H, int W, int k, int stride, int pad,
-                               long sb, long sc, long sd, long sh, long sw, const float* y_tanh, float* dx, int ldc,
+                               long sb, long sc, long sd, long sh, long sw, const float* y_tanh, int act, float* dx, int ldc,
                                void* stream) {
     PM_REQUIRE(dcols && dx && B > 0);
+    PM_REQUIRE(!y_tanh || (act > PM_ACT_NONE && act <= PM_ACT_MAX));
     Conv3dGeom g;
     const int rc = conv3d_geom(g, C, D, H, W, k, stride, pad, sb, sc, sd, sh, sw, ldc);
     if (rc != PM_OK) return rc;
     const long total = (long)B * C * D * H * W;
     long nb = (total + 255) / 256;
     if (nb > 16384) nb = 16384;
-    hipLaunchKernelGGL(col2im3d_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), dcols, g, total, y_tanh, dx);
+    hipLaunchKernelGGL(col2im3d_kernel, dim3((unsigned)nb), dim3(256), 0, pm_stream(stream), dcols, g, total, y_tanh, act, dx);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }

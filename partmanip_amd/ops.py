@@ -825,14 +825,14 @@ def conv3d_c1_wgrad(dz, x5, k, stride, pad, dw, db, ws, rows=None):
               "pm_conv3d_c1_wgrad_f32")
 
 
-def col2im3d(dcols, dx5, k, stride, pad, y_tanh5=None):
+def col2im3d(dcols, dx5, k, stride, pad, y_tanh5=None, act=None):
     """dcols (B*Do*Ho*Wo, ldc) -> every element of the 5-D view dx5 (B, C, D, H, W); y_tanh5 = the layer input
-    (a tanh output, same shape AND strides as dx5): its derivative is folded in."""
+    (an activation output -- tanh unless `act` says otherwise -- of the same shape AND strides as dx5): its derivative is folded in."""
     _req(dcols, dx5, y_tanh5)
     B, Cc, D, H, W = dx5.shape
     if y_tanh5 is not None and (y_tanh5.shape != dx5.shape or y_tanh5.stride() != dx5.stride()):
         raise ValueError("col2im3d: y_tanh5 must be laid out like dx5")
-    check(lib.pm_col2im3d_f32(_ptr(dcols), B, Cc, D, H, W, k, stride, pad, *dx5.stride(), _ptr(y_tanh5), _ptr(dx5),
+    check(lib.pm_col2im3d_f32(_ptr(dcols), B, Cc, D, H, W, k, stride, pad, *dx5.stride(), _ptr(y_tanh5), ACT_TANH if act is None else int(act), _ptr(dx5),
                               _rows(dcols, "dcols"), _stream()), "pm_col2im3d_f32")
 
 

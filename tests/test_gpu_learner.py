@@ -505,6 +505,34 @@ def test_conv3dnet_forward_backward_matches_reference_module(name):
         assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-7, k
 
 
+@pytest.mark.parametrize("act", ["relu", "lrelu", "elu", "selu", "sigmoid", "crelu"])
+def test_conv3dnet_other_activations_match_the_oracle(act):
+    """network.py:70 builds Conv3DNet with any of get_activation's seven (network.py:7-24): the layers' GEMM epilogues, the
+    scatter data gradient and pm_col2im3d_f32 take the activation code (the input layer leaves its tanh stencil for the
+    patch-matrix form).  Outputs and every parameter gradient against the restatement's autograd."""
+    from partmanip_amd.algo_utils import ActorCritic
+    c = cases.CONV3D_CASES["conv3d_proprio"]
+    net = dict(name="Conv3DNet", activation=act)
+    O = c["res"] ** 3 + c["proprio"]
+    ac = ActorCritic(O, c["out"], dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net), c["proprio"]).to(DEV)
+    sd = cases.conv3d_state(c)
+    ac.actor.load_state_dict({k: t(v.copy()) for k, v in sd.items()})
+    f = ac.flat()
+    inp = cases.conv3d_inputs(c)
+    p = {"actor." + k: t(v.copy()).requires_grad_(True) for k, v in sd.items()}
+    ref = R.net_forward(p, "actor", net, t(inp["x"]), c["proprio"])
+    out = ac.actor.hip_forward(t(inp["x"]).to(DEV))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=3e-6)
+    names = list(p)
+    grads = torch.autograd.grad((ref * t(inp["dy"])).sum(), [p[k] for k in names])
+    ac.actor.hip_backward(t(inp["dy"]).to(DEV))
+    off = 0
+    for k, v in ac.actor.named_parameters():
+        got = f["grad_actor"][off:off + v.numel()].view(v.shape)
+        off += v.numel()
+        assert rel_err(got, grads[names.index("actor." + k)]) < 2e-4, (act, k)
+
+
 # ------------------------------------------------------------------------------- PointNet++ backbone
 PN2_UNFUSED = dict(npoints=[128, 32], radii=[0.25, 0.5], nsamples=[16, 16], mlps=[[32, 32, 64], [64, 64, 128], [128, 256]])
 # the shapes the fused SA kernels are instantiated for (pm_sa_fwd_f32 / pm_sa_bwd_f32); 130 / 33 centres make the
