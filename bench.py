@@ -650,6 +650,8 @@ def run_ppo(args, device, rank, world):
 
 def optional_paths(run, ac, w, step, fence):
     """The same workload on the opt-in paths (reported next to, not instead of, the exact-fp32 line)."""
+    from partmanip_amd import ops
+
     def timed(n=2):
         step()
         fence()
@@ -673,6 +675,31 @@ def optional_paths(run, ac, w, step, fence):
         note="pm_pointnet_enc_fwd_bf6: operands split into three bf16 planes, products a0b0+a0b1+a1b0+a0b2+a1b1+a2b0 "
              "on bf16 MFMAs with fp32 accumulate; error against fp64 no larger than the fp32 MFMA kernel's "
              "(tests/test_gpu_learner.py::test_pointnet_bf16x6_forward_has_fp32_class_error); backward stays fp32")
+    # both encoder directions on the three-plane split: forward as above + dW2 / dh1 of the backward
+    ac.actor.precision = ac.critic.precision = "bf16x6"
+    ac.actor.precision_bwd = ac.critic.precision_bwd = "bf16x6"
+    ops.TIMER.enable("pointnet_enc_fwd", "pointnet_enc_bwd")
+    dt66 = timed()
+    f66, b66 = ops.TIMER.mean_ms("pointnet_enc_fwd"), ops.TIMER.mean_ms("pointnet_enc_bwd")
+    ops.TIMER.disable()
+    ac.actor.precision = ac.critic.precision = "f32"
+    ac.actor.precision_bwd = ac.critic.precision_bwd = "f32"
+    peak6 = 2500.0 / 6.0                                          # dense bf16 MFMA peak / six products per fp32 product
+    fl66 = 2.0 * ENC_MAC_PER_POINT * 1024 * 2048
+    res["encoder_bf16x6_forward_and_backward"] = dict(
+        value=w["N"] * w["T"] / dt66, unit="env-steps/s", ms_per_step=dt66 * 1e3,
+        dtype="bf16 x 3 planes x 6 products, fp32 accumulate (fp32-class error); layer 1, tanh, pooling, dW3, optimiser: f32",
+        encoder_fwd_ms=f66[0] if f66 else None, encoder_bwd_ms=b66[0] if b66 else None,
+        roofline=dict(bound="mfma", unit="TFLOP/s", peak=peak6,
+                      peak_note="2.5 PFLOP/s dense bf16 / 6 MFMAs per fp32-equivalent product = 417 TFLOP/s of fp32-equivalent flops",
+                      achieved=(fl66 / (f66[0] * 1e-3) / 1e12) if f66 else None,
+                      frac=(fl66 / (f66[0] * 1e-3) / 1e12 / peak6) if f66 else None,
+                      kernel="pn_fwd_bf6_kernel (fp32-equivalent flops of a 2048-cloud launch; the rollout's 4096-cloud "
+                             "launches are in the mean)"),
+        note="pm_pointnet_enc_fwd_bf6 + pm_pointnet_enc_bwd_bf6 (csrc/pointnet_enc_bwd_bf6.h): every parameter gradient within "
+             "the fp32 MFMA kernel's error against fp64 (tests/test_gpu_learner.py::"
+             "test_pointnet_bf16x6_backward_has_fp32_class_error); golden vision-PPO cases at the fp32 tolerances; "
+             "NOT the headline: the default line stays exact fp32")
     run.overlap = True
     dto = timed()
     run.overlap = False

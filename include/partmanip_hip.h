@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 139 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 140 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -190,6 +190,18 @@ int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, int C, int s
                             float* db1, float* dW2, float* db2, float* dW3, float* db3,
                             const float* h2_saved /* NULL = recompute layer 2; else what the forward saved */,
                             int act /* as the forward's */, void* workspace, size_t workspace_bytes, void* stream);
+/* OPT-IN fp32-class split-bf16 form of the same call (csrc/pointnet_enc_bwd_bf6.h): the two dense GEMMs of the backward
+ * (dW2 = dz2^T h1, dh1 = dz2 W2) run on bf16 MFMAs with every operand split into three bf16 planes and six products summed in
+ * the fp32 accumulator -- the fp32 kernel's error level at 2.7x less matrix-pipe time; everything else is the fp32 code.  tanh
+ * encoders with the forward's saved layer 2 only (h2_saved != NULL).  packed_w2_bf6 = pm_pointnet_packed_bwd_bf6_bytes()
+ * bytes written by pm_pointnet_pack_weights_bwd_bf6 from the current W2 (16-byte aligned); same workspace as the fp32 call. */
+size_t pm_pointnet_packed_bwd_bf6_bytes(void);
+int pm_pointnet_pack_weights_bwd_bf6(const float* W2, void* packed, void* stream);
+int pm_pointnet_enc_bwd_bf6(const float* x, long ldx, int B, int P, int C, int sub_mean, const float* W1,
+                            const float* b1, const float* b2, const float* W3, const float* packed,
+                            const void* packed_w2_bf6, int max_mean, const float* dfeat, long ldf, const int32_t* argmax,
+                            float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3, const float* h2_saved,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ K8  PPO actor loss
  * actor_critic.py:74-78,93-100 + ppo.py:327-344 in one pass over a mini-batch of B rows:

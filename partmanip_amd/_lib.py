@@ -44,6 +44,9 @@ SIGNATURES = {
     "pm_pointnet_enc_fwd_bf6": (I, [P, L, I, I, I, I, P, P, P, P, P, I, P, L, P, P, P]),
     "pm_pointnet_enc_bwd_workspace_bytes": (Z, [I, I, I]),
     "pm_pointnet_enc_bwd_f32": (I, [P, L, I, I, I, I, P, P, P, P, P, I, P, L, P, P, P, P, P, P, P, P, I, P, Z, P]),
+    "pm_pointnet_packed_bwd_bf6_bytes": (Z, []),
+    "pm_pointnet_pack_weights_bwd_bf6": (I, [P, P, P]),
+    "pm_pointnet_enc_bwd_bf6": (I, [P, L, I, I, I, I, P, P, P, P, P, P, I, P, L, P, P, P, P, P, P, P, P, P, Z, P]),
     "pm_ppo_actor_loss_fwd_bwd_f32": (I, [P, L, P, P, L, P, P, P, L, P, L, I, I, F, I, F, F, P, D, P, P, L, P, P, Z, P]),
     "pm_ppo_actor_loss_workspace_bytes": (Z, [I]),
     "pm_ppo_actor_head_supported": (I, [P, L, P, L, I, I, P, L]),
@@ -145,7 +148,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 139                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 140                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -296,17 +296,26 @@ class PointNet(_HipNet):
         self.save_h2 = bool(net_cfg.get('save_h2', True))
         if self.precision not in ('f32', 'bf16x3', 'bf16x6'):
             raise ValueError(f"PointNet precision '{self.precision}'")
+        # 'precision_bwd': 'f32' (default) | 'bf16x6' -- the backward's two dense GEMMs on three-plane split-bf16 MFMAs
+        # (csrc/pointnet_enc_bwd_bf6.h: the fp32 kernel's error level); needs the saved layer 2 and tanh
+        self.precision_bwd = net_cfg.get('precision_bwd', 'f32')
+        if self.precision_bwd not in ('f32', 'bf16x6'):
+            raise ValueError(f"PointNet precision_bwd '{self.precision_bwd}'")
+        if self.precision_bwd != 'f32' and not self.save_h2:
+            raise ValueError("PointNet precision_bwd 'bf16x6' reads the forward's saved layer 2 (save_h2: True)")
         # every activation of get_activation (network.py:7-24): tanh runs the tuned packed-tanh encoder kernels, the others
         # their generic instantiation (pm_act / pm_dact); the split-bf16 forwards are tanh kernels
         code = _act_code(act, linear_only=True)
-        if self.precision != 'f32' and code != ops.ACT_TANH:
-            raise NotImplementedError(f"PointNet precision '{self.precision}' is a tanh kernel; activation '{act}' runs on 'f32'")
+        if (self.precision != 'f32' or self.precision_bwd != 'f32') and code != ops.ACT_TANH:
+            raise NotImplementedError(f"PointNet precision '{self.precision}' / precision_bwd '{self.precision_bwd}' is a tanh "
+                                      f"kernel; activation '{act}' runs on 'f32'")
         object.__setattr__(self, "_act", code)
         object.__setattr__(self, "_head", _LinearChain([self.final_mlp[0], self.final_mlp[2], self.final_mlp[4]], code))
         object.__setattr__(self, "_enc_grads", None)
         object.__setattr__(self, "_packed", None)
         object.__setattr__(self, "_packed3", None)
         object.__setattr__(self, "_packed6", None)
+        object.__setattr__(self, "_packed6b", None)
 
     def set_grad_views(self, views):
         self._head.grads = [(views[f"final_mlp.{i}.weight"], views[f"final_mlp.{i}.bias"]) for i in (0, 2, 4)]
@@ -372,6 +381,18 @@ class PointNet(_HipNet):
         dfeat = torch.empty_like(feat)
         self._head.backward(dy, ws, dx_out=dfeat)
         g = self._enc_grads
+        if self.precision_bwd == 'bf16x6':
+            if h2 is None:
+                raise RuntimeError("PointNet precision_bwd 'bf16x6': the forward did not save layer 2 (an inference forward?)")
+            if self._packed6b is None or self._packed6b.device != dy.device:
+                object.__setattr__(self, "_packed6b", torch.empty(int(ops.lib.pm_pointnet_packed_bwd_bf6_bytes()),
+                                                                  dtype=torch.uint8, device=dy.device))
+            ops.pointnet_pack_bwd_bf6(self.mlp[2].weight.data, self._packed6b)
+            ops.pointnet_enc_bwd_bf6(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
+                                     self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].weight.data, self._packed,
+                                     self._packed6b, self.max_mean_concat, dfeat, argmax, g[0], g[1], g[2], g[3], g[4], g[5],
+                                     ws, h2)
+            return
         ops.pointnet_enc_bwd(x, self.point_num, self.in_channels, self.substract_mean, self.mlp[0].weight.data,
                              self.mlp[0].bias.data, self.mlp[2].bias.data, self.mlp[4].weight.data, self._packed,
                              self.max_mean_concat, dfeat, argmax, g[0], g[1], g[2], g[3], g[4], g[5], ws, h2, self._act)

@@ -25,7 +25,7 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mfma_f32.h"), os.path.join(CSRC, "gemm2.h"), os.path.join(CSRC, "skinny.h"),
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mfma_f32.h"), os.path.join(CSRC, "gemm2.h"), os.path.join(CSRC, "skinny.h"), os.path.join(CSRC, "pointnet_enc_bwd_bf6.h"),
             os.path.join(HERE, "..", "include", "partmanip_hip.h")]
     objs, rebuilt = [], False
     procs = []

@@ -1247,6 +1247,8 @@ __global__ __launch_bounds__(256) void pn_dw3_finish_kernel(const float* __restr
     if (k == 0) db3[c] = s;
 }
 
+#include "pointnet_enc_bwd_bf6.h"
+
 static inline int pn_bwd_grid(int B) { return B < PN_BWD_MAXG ? B : PN_BWD_MAXG; }
 static int pn_cu_count() {
     static int n = 0;
@@ -1286,14 +1288,17 @@ extern "C" size_t pm_pointnet_enc_bwd_workspace_bytes(int B, int P, int C) {
     return B > 0 ? pn_bwd_layout(B).total : 0;
 }
 
-extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, int C, int sub_mean,
-                                       const float* W1, const float* b1, const float* b2, const float* W3,
-                                       const float* packed, int max_mean, const float* dfeat, long ldf,
-                                       const int32_t* argmax, float* dW1, float* db1, float* dW2, float* db2,
-                                       float* dW3, float* db3, const float* h2_saved, int act, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+static int pn_enc_bwd_impl(const float* x, long ldx, int B, int P, int C, int sub_mean,
+                           const float* W1, const float* b1, const float* b2, const float* W3,
+                           const float* packed, int max_mean, const float* dfeat, long ldf,
+                           const int32_t* argmax, float* dW1, float* db1, float* dW2, float* db2,
+                           float* dW3, float* db3, const float* h2_saved, int act, void* workspace,
+                           size_t workspace_bytes, void* stream, const unsigned short* packW2_bf6) {
     PM_REQUIRE(x && W1 && b1 && b2 && W3 && packed && dfeat && argmax && dW1 && db1 && dW2 && db2 && dW3 && db3);
     PM_REQUIRE(act > PM_ACT_NONE && act <= PM_ACT_MAX);
+    // the split-bf16 kernel is the saved-layer-2, tanh form only: anything else is refused, not silently run in fp32
+    PM_REQUIRE(!packW2_bf6 || (h2_saved && act == PM_ACT_TANH));
+    if (packW2_bf6 && ((uintptr_t)packW2_bf6 & 15) != 0) return PM_EALIGN;
     if (h2_saved && ((uintptr_t)h2_saved & 15) != 0) return PM_EALIGN;
     PM_REQUIRE(B > 0 && P > 0 && P % PN_TM == 0 && P <= 4096 && C >= 1 && C <= PN_MAXC && ldx >= (long)P * C);
     PM_REQUIRE(ldf >= PN_C3 * (max_mean ? 2 : 1));
@@ -1314,7 +1319,23 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
         if (rc != PM_OK) return rc;
     }
     int G = pn_bwd_grid(B);
-    if (PN_BWD16 && h2_saved) {                   // saved layer 2: one 16-wave work-group per CU
+    if (packW2_bf6) {                             // saved layer 2, both GEMMs on split-bf16 MFMAs: one 8-wave work-group per CU
+        const int ncu = pn_cu_count();
+        G = B < ncu ? B : ncu;
+        int32_t* keys_g = (int32_t*)(ws + w.off_keys);
+        unsigned short* offs_g = (unsigned short*)(ws + w.off_offs);
+        float* Sg = (float*)(ws + w.off_Sg);
+        hipLaunchKernelGGL(pn_bwd_prep_kernel, dim3(B), dim3(256), 0, pm_stream(stream), argmax, P, keys_g, offs_g, slotmap,
+                           dfeat, ldf, W3, Sg);
+#define PN_BF6_LAUNCH(CT)                                                                                               \
+    hipLaunchKernelGGL((pn_bwd_bf6_kernel<CT>), dim3(G), dim3(PB6_NT), 0, pm_stream(stream), x, ldx, B, P, C, sub_mean, W1, b1, \
+                       packW2_bf6, max_mean, U, H2sum, Hg, (const int32_t*)keys_g, (const unsigned short*)offs_g, parts,  \
+                       h2_saved, (const float*)Sg)
+        if (C == 3) PN_BF6_LAUNCH(3);
+        else if (C == 4) PN_BF6_LAUNCH(4);
+        else PN_BF6_LAUNCH(0);
+#undef PN_BF6_LAUNCH
+    } else if (PN_BWD16 && h2_saved) {            // saved layer 2: one 16-wave work-group per CU
         const int ncu = pn_cu_count();
         G = B < ncu ? B : ncu;
         int32_t* keys_g = (int32_t*)(ws + w.off_keys);
@@ -1374,4 +1395,27 @@ extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, i
                        dw3_tmp, dW3, db3);
     PM_CHECK_LAUNCH();
     return PM_OK;
+}
+
+extern "C" int pm_pointnet_enc_bwd_f32(const float* x, long ldx, int B, int P, int C, int sub_mean,
+                                       const float* W1, const float* b1, const float* b2, const float* W3,
+                                       const float* packed, int max_mean, const float* dfeat, long ldf,
+                                       const int32_t* argmax, float* dW1, float* db1, float* dW2, float* db2,
+                                       float* dW3, float* db3, const float* h2_saved, int act, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    return pn_enc_bwd_impl(x, ldx, B, P, C, sub_mean, W1, b1, b2, W3, packed, max_mean, dfeat, ldf, argmax, dW1, db1, dW2, db2,
+                           dW3, db3, h2_saved, act, workspace, workspace_bytes, stream, nullptr);
+}
+
+// the same call with dW2 / dh1 on split-bf16 MFMAs (three planes, six products: pointnet_enc_bwd_bf6.h); tanh, saved layer 2
+extern "C" int pm_pointnet_enc_bwd_bf6(const float* x, long ldx, int B, int P, int C, int sub_mean,
+                                       const float* W1, const float* b1, const float* b2, const float* W3,
+                                       const float* packed, const void* packed_w2_bf6, int max_mean, const float* dfeat,
+                                       long ldf, const int32_t* argmax, float* dW1, float* db1, float* dW2, float* db2,
+                                       float* dW3, float* db3, const float* h2_saved, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(packed_w2_bf6);
+    return pn_enc_bwd_impl(x, ldx, B, P, C, sub_mean, W1, b1, b2, W3, packed, max_mean, dfeat, ldf, argmax, dW1, db1, dW2, db2,
+                           dW3, db3, h2_saved, PM_ACT_TANH, workspace, workspace_bytes, stream,
+                           (const unsigned short*)packed_w2_bf6);
 }

@@ -375,6 +375,27 @@ def pointnet_enc_bwd(x, P, Cc, sub_mean, w1, b1, b2, w3, packed, max_mean, dfeat
               "pm_pointnet_enc_bwd_f32")
 
 
+def pointnet_pack_bwd_bf6(w2, packed):
+    _req(w2, packed)
+    check(lib.pm_pointnet_pack_weights_bwd_bf6(_ptr(w2), _ptr(packed), _stream()), "pm_pointnet_pack_weights_bwd_bf6")
+
+
+def pointnet_enc_bwd_bf6(x, P, Cc, sub_mean, w1, b1, b2, w3, packed, packed_w2, max_mean, dfeat, argmax, dw1, db1, dw2, db2, dw3,
+                         db3, ws, h2_saved):
+    """pointnet_enc_bwd with dW2 / dh1 on split-bf16 MFMAs (three planes, six products); tanh, saved layer 2."""
+    _req(x, w1, b1, b2, w3, packed, packed_w2, dfeat, argmax, dw1, db1, dw2, db2, dw3, db3, h2_saved)
+    B = x.shape[0]
+    w = ws.get(lib.pm_pointnet_enc_bwd_workspace_bytes(B, P, Cc) + 256)
+    base = w.data_ptr()
+    al = (-base) % 256
+    with TIMER.bracket("pointnet_enc_bwd"):
+        check(lib.pm_pointnet_enc_bwd_bf6(_ptr(x), _rows(x, "x"), B, P, Cc, int(sub_mean), _ptr(w1), _ptr(b1), _ptr(b2),
+                                          _ptr(w3), _ptr(packed), _ptr(packed_w2), int(max_mean), _ptr(dfeat),
+                                          _rows(dfeat, "dfeat"), _ptr(argmax), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
+                                          _ptr(dw3), _ptr(db3), _ptr(h2_saved), base + al, w.numel() - al, _stream()),
+              "pm_pointnet_enc_bwd_bf6")
+
+
 # ----------------------------------------------------------------------------- K8-K11
 def ppo_actor_loss(mu, log_std, actions, old_logp, adv, old_mu, old_sigma, max_action, act_tanh, eps_clip, desired_kl,
                    adv_moments, adv_count, scal, dmu, dlog_std, ws):

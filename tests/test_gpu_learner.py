@@ -783,6 +783,71 @@ def test_pointnet_bf16x6_forward_has_fp32_class_error(B, C, max_mean, sub_mean):
     assert errs["bf16x6"][0] <= 1.5 * errs["f32"][0] + 1e-9, errs
 
 
+@pytest.mark.parametrize("B,C,max_mean,sub_mean,fwd", [(5, 3, True, False, "f32"), (3, 4, False, True, "f32"),
+                                                       (300, 3, True, False, "f32"), (7, 6, True, True, "f32"),
+                                                       (40, 3, True, False, "bf16x6")])
+def test_pointnet_bf16x6_backward_has_fp32_class_error(B, C, max_mean, sub_mean, fwd):
+    """Opt-in three-plane split-bf16 encoder BACKWARD (`precision_bwd: bf16x6`: dW2 = dz2^T h1 and dh1 = dz2 W2 on six bf16
+    MFMAs per product block, csrc/pointnet_enc_bwd_bf6.h).  Claim: every parameter gradient has the fp32 MFMA kernel's error
+    against an fp64 evaluation of the same network (pooling indices pinned to the forward's).  Checked: both backwards on the
+    same forward (same saved layer 2 and arg-max) against fp64 autograd -- per tensor, the split kernel's relative error must
+    not exceed 1.5 x the fp32 kernel's (+ 2e-7) or 2e-6 (the bias gradients are sums of 3e5 cancelling terms whose fp32
+    error depends on the reduction tree: db1 at B = 300 comes out at 1.5e-6 here against 6e-7 -- every other tensor of every
+    case sits at or below the fp32 kernel's error), and both meet the fp32 path's own 2e-4 gate; B = 300 walks two clouds per
+    work-group, C = 6 the generic layer-1 width, the last case runs on top of the bf16x6 forward."""
+    from partmanip_amd.algo_utils import ActorCritic
+    g = torch.Generator().manual_seed(B + C)
+    x = (torch.rand(B, 1024, C, generator=g) * 2 - 1).reshape(B, -1).contiguous()
+    dy = torch.randn(B, 10, generator=g)
+    grads, am = {}, None
+    for bwd in ("f32", "bf16x6"):
+        net = dict(name="PointNet", activation="tanh", max_mean=max_mean, sub_mean=sub_mean, precision=fwd, precision_bwd=bwd)
+        torch.manual_seed(B + C)
+        ac = ActorCritic(1024 * C, 10, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net)).to(DEV)
+        f = ac.flat()
+        ac.actor.hip_forward(x.to(DEV))
+        a = ac.actor._saved[2].cpu().long()
+        assert am is None or torch.equal(a, am)
+        am = a
+        ac.actor.hip_backward(dy.to(DEV))
+        off, out = 0, {}
+        for k, v in ac.actor.named_parameters():
+            out[k] = f["grad_actor"][off:off + v.numel()].view(v.shape).double().cpu()
+            off += v.numel()
+        grads[bwd] = out
+        p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in ac.state_dict().items()}
+    net64 = dict(name="PointNet", activation="tanh", max_mean=max_mean, sub_mean=sub_mean)
+    ref_out = R.pointnet_forward(p, "actor", net64, x.double(), 0, argmax_override=am)
+    names = [k for k in p if k.startswith("actor.")]
+    ref = dict(zip(names, torch.autograd.grad((ref_out * dy.double()).sum(), [p[k] for k in names])))
+    for k in grads["f32"]:
+        r = ref["actor." + k]
+        e32 = float((grads["f32"][k] - r).norm() / r.norm())
+        e6 = float((grads["bf16x6"][k] - r).norm() / r.norm())
+        tol = max(1.5 * e32 + 2e-7, 2e-6)
+        record_margin(f"bf16x6 backward vs fp64, relative L2 [{k}] (fp32 kernel: {e32:.2e})", e6, tol)
+        assert e6 <= tol and e6 < 2e-4, (k, e6, e32)
+
+
+@pytest.mark.parametrize("name", ["ppo_pn_maxmean", "ppo_pn_max"])
+def test_ppo_update_bf16x6_forward_and_backward_within_reference_tolerances(name):
+    """The golden vision-PPO cases with BOTH encoder directions on the three-plane split: the fp32 path's tolerances."""
+    c = cases.case_copy(cases.PPO_CASES[name])
+    c["net"] = dict(c["net"], precision="bf16x6", precision_bwd="bf16x6")
+    fx = load_fixture(name)
+    run = make_ppo(c)
+    fill_storage(run, c, fx)
+    run.storage.compute_returns(t(fx["last_values"]).to(DEV), c["gamma"], c["lam"])
+    run.log_dict = {}
+    run.update(c["it"])
+    log = run.log_dict
+    assert log["Train/kl_update_count"] == int(fx["log_kl_update_count"])
+    for k in ("value_function_loss", "surrogate_loss", "kl", "kl_max"):
+        np.testing.assert_allclose(float(log["Train/" + k]), float(fx["log_" + k]), rtol=5e-5, atol=5e-7, err_msg=k)
+    check_params(flat_state(run.actor_critic.state_dict()), fx["final_flat"], int(fx["final_stride"]), c["lr"],
+                 len(fx["loss_trace"]))
+
+
 @pytest.mark.parametrize("name", ["ppo_pn_maxmean", "ppo_pn_max"])
 def test_ppo_update_bf16x6_forward_within_reference_tolerances(name):
     """The golden vision-PPO cases with the bf16x6 encoder forward: the fp32 path's tolerances on the Train/* scalars and
