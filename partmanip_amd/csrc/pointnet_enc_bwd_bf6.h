@@ -40,6 +40,59 @@
 // alone is 9 per value pair, 12 pairs) and the two barriers' skew 2-2.5 k.  What would move it: VALU / MFMA overlap, i.e. the
 // planes twice -- 75 KB per buffer if dW2's A operand came from Zc through ds_read_b64_tr_b16 instead of a second layout.
 
+typedef __bf16 pb6_bf16x8 __attribute__((ext_vector_type(8)));
+#define PB6_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define PB6_LDZ (PN_C2 + 8)                 // halfwords per Zc row
+#define PB6_W2 (4 * 16 * 64 * 8)            // halfwords per packed W2 plane: [n-block 4][k-step 16][lane 64][8]
+#define PB6_PACKED_HALFS (3 * PB6_W2 + 4096)
+#define PB6_NT 512
+
+typedef __bf16 pb6_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pb6_cvt_pk(float a, float b) {          // {bf16(a) | bf16(b) << 16}, RNE: v_cvt_pk_bf16_f32
+    const f32x2 v = {a, b};                                                  // (the builtin conversion, not inline asm: the
+    const pb6_bf16x2 h = __builtin_convertvector(v, pb6_bf16x2);             // scheduler may interleave the split chains)
+    return *(const unsigned*)&h;
+}
+// (x, y) -> three packed bf16 pairs q[0..2] with q0 + q1 + q2 == the value exactly in each half (every residual is exact in fp32)
+__device__ __forceinline__ void pb6_split_pair(float x, float y, unsigned (&q)[3]) {
+    q[0] = pb6_cvt_pk(x, y);
+    const float rx = x - __uint_as_float(q[0] << 16), ry = y - __uint_as_float(q[0] & 0xffff0000u);
+    q[1] = pb6_cvt_pk(rx, ry);
+    const float sx = rx - __uint_as_float(q[1] << 16), sy = ry - __uint_as_float(q[1] & 0xffff0000u);
+    q[2] = pb6_cvt_pk(sx, sy);
+}
+__device__ __forceinline__ pb6_bf16x8 pb6_as_bf(const uint4& v) { return *(const pb6_bf16x8*)&v; }
+
+extern "C" size_t pm_pointnet_packed_bwd_bf6_bytes(void) { return (size_t)PB6_PACKED_HALFS * 2; }
+
+// W2 (256 x 128, row-major [c2][c1]) as the B operand of dh1 = dz2 * W2: B[k = c2][n = c1]; lane (li = lane & 31, lq = lane >> 5)
+// of fragment (n-block nb, k-step s) holds W2[16 s + 8 lq + e][32 nb + li], e = 0..7 -- three planes, + a zeroed tail.
+__global__ __launch_bounds__(256) void pn_pack_bwd_bf6_kernel(const float* __restrict__ W2, unsigned short* __restrict__ packed) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= PB6_W2) {
+        if (i < PB6_W2 + 4096) packed[3 * PB6_W2 + (i - PB6_W2)] = 0;
+        return;
+    }
+    const int e = i & 7, lane = (i >> 3) & 63, li = lane & 31, lq = lane >> 5, s = (i >> 9) & 15, nb = i >> 13;
+    const float w = W2[(s * 16 + lq * 8 + e) * PN_C1 + nb * 32 + li];
+    unsigned q[3];
+    pb6_split_pair(w, 0.f, q);
+    packed[i] = (unsigned short)(q[0] & 0xffffu);
+    packed[PB6_W2 + i] = (unsigned short)(q[1] & 0xffffu);
+    packed[2 * PB6_W2 + i] = (unsigned short)(q[2] & 0xffffu);
+}
+
+extern "C" int pm_pointnet_pack_weights_bwd_bf6(const float* W2, void* packed, void* stream) {
+    PM_REQUIRE(W2 && packed);
+    const int n = PB6_W2 + 4096;
+    hipLaunchKernelGGL(pn_pack_bwd_bf6_kernel, dim3((n + 255) / 256), dim3(256), 0, pm_stream(stream), W2, (unsigned short*)packed);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// byte offset of logical 16-byte chunk q (8 points) of row r in a 64-byte-row plane (Zt / Ht)
+__device__ __forceinline__ int pb6_chunk(int r, int q) { return r * 64 + (((q + (r >> 2)) & 3) << 4); }
+
 template <int CT>
 __global__ __launch_bounds__(PB6_NT, 2) void pn_bwd_bf6_kernel(
     const float* __restrict__ x, long ldx, int B, int P, int C, int sub_mean, const float* __restrict__ W1,
