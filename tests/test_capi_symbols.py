@@ -55,6 +55,12 @@ def test_argument_validation_without_gpu():
     assert lib.pm_pointnet_enc_fwd_f32(None, 0, 1, 1000, 3, 0, None, None, None, None, None, 1, None, 0, None, None, 1, None) == -1
     assert lib.pm_pointnet_packed_elems() == 196608 + 32768 + 1024      # fwd W2|W3, bwd W2^T in two MFMA operand orders, pad
     assert lib.pm_moments_workspace_bytes(10) >= 16
+    # the split-bf16 backward: no packed planes / no saved layer 2 -> refused (never a silent fp32 run)
+    assert lib.pm_pointnet_enc_bwd_bf6(None, 0, 1, 1024, 3, 0, None, None, None, None, None, None, 1, None, 0, None, None, None,
+                                       None, None, None, None, None, None, 0, None) == -1
+    assert lib.pm_pointnet_packed_bwd_bf6_bytes() == (3 * 4 * 16 * 64 * 8 + 4096) * 2
+    assert lib.pm_fps_varlen_workspace_bytes(4, 8192) == 0
+    assert lib.pm_fps_varlen_workspace_bytes(4, 10000) == 160000 + (4 * 256 + 1) * 8
     assert lib.pm_fps_workspace_bytes(2, 1024) == 0 and lib.pm_fps_workspace_bytes(2, 20000) == 160000
 
 

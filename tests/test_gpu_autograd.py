@@ -201,3 +201,9 @@ def test_plug_in_encoders_reject_other_activations_loudly():
         with pytest.raises(NotImplementedError, match="tanh"):
             ActorCritic(O, 4, model(net))
     ActorCritic(3072, 4, model(dict(name="PointNet", activation="relu", max_mean=True, sub_mean=False)))      # fp32 kernels: fine
+    # the split-bf16 backward is a tanh kernel on the forward's saved layer 2: both conditions are checked at construction
+    with pytest.raises(NotImplementedError, match="tanh"):
+        ActorCritic(3072, 4, model(dict(name="PointNet", activation="elu", max_mean=True, sub_mean=False, precision_bwd="bf16x6")))
+    with pytest.raises(ValueError, match="save_h2"):
+        ActorCritic(3072, 4, model(dict(name="PointNet", activation="tanh", max_mean=True, sub_mean=False, precision_bwd="bf16x6",
+                                        save_h2=False)))
