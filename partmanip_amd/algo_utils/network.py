@@ -796,13 +796,24 @@ class SparseUNet(_HipNet):
         """Take the next forward's tables from `geom` (built on first use) when `rows` is a (lo, n) slice of the rollout."""
         object.__setattr__(self, "_geom_next", (geom["cache"], rows) if isinstance(rows, tuple) else None)
 
+    def take_geometry(self, g):
+        """The next forward's tables, built ahead by the caller from the SAME rows (dagger.update: geometry(x) of mini-batch
+        k + 1 on a side stream under the GEMMs of mini-batch k -- the tables are latency-bound hash lookups, the GEMMs MFMA-bound)."""
+        object.__setattr__(self, "_geom_ready", g)
+
     def _hip_forward(self, x, out=None):
         B, P = x.shape[0], self.point_num
         c0, c1, c2 = self.channels
         dev = x.device
         nxt = getattr(self, "_geom_next", None)
         object.__setattr__(self, "_geom_next", None)
-        if nxt is not None and nxt[1][1] == B:
+        ready = getattr(self, "_geom_ready", None)
+        object.__setattr__(self, "_geom_ready", None)
+        if ready is not None:
+            if ready["rows"][0] != B * P:
+                raise ValueError("take_geometry(): the tables were built for another batch size")
+            g = ready
+        elif nxt is not None and nxt[1][1] == B:
             g = nxt[0].get(nxt[1])
             if g is None:
                 g = nxt[0][nxt[1]] = self.geometry(x)

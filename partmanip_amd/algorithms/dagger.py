@@ -141,6 +141,43 @@ class dagger:
         ops.gather_rows(src, idx, buf)
         return buf
 
+    # ---- geometry of the NEXT mini-batch on a side stream (SparseUNet student), OPT-IN (PARTMANIP_GEOM_PREFETCH=1): the voxel
+    # tables depend on the rows' coordinates only and are 2.9 of a 51.7 ms step at cfg 5, so they can be built for mini-batch
+    # k + 1 while mini-batch k computes.  Bit-identical, and measured WITHOUT gain (round 3, tools/time_geometry_overlap.py:
+    # forward + backward 48.1 ms with the tables ready, 51.7 inline, 51.1 with them on a side stream; bench.py cfg 5: 1228 vs
+    # 1226 env-steps/s): the table kernels are not idle-latency work, their 8192 work-groups take CU slots and L2 bandwidth
+    # from the gathered GEMMs for as long as they run.  Two staging buffers alternate; the side stream waits for the step that
+    # last read the buffer it overwrites, the main stream for the tables; every table is handed to the main stream's
+    # allocator bookkeeping (record_stream) before use.
+    def _geom_prefetch(self, obs_all, indices, slot, after):
+        side = self._side_stream
+        main = torch.cuda.current_stream()
+        if after is not None:
+            side.wait_event(after)
+        with torch.cuda.stream(side):
+            idx = torch.tensor(indices, dtype=torch.int64).to(obs_all.device, non_blocking=True)
+            key = ('stu_pf', slot)
+            buf = self._stage.get(key)
+            if buf is None or buf.shape[0] != len(indices):
+                buf = self._stage[key] = torch.empty(len(indices), obs_all.shape[1], device=obs_all.device)
+            ops.gather_rows(obs_all, idx, buf)
+            g = self.student.actor.geometry(buf)
+            ev = torch.cuda.Event()
+            ev.record(side)
+
+        def hand_over(o):
+            if isinstance(o, torch.Tensor):
+                o.record_stream(main)
+            elif isinstance(o, dict):
+                for v in o.values():
+                    hand_over(v)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    hand_over(v)
+        hand_over(g)
+        idx.record_stream(side)
+        return buf, g, ev
+
     def update(self, it):
         if self.storage.cur_buf_size < 16:
             return
@@ -161,11 +198,26 @@ class dagger:
         count = 0
         obs_all = self.storage.observations.view(-1, self.storage.observations.size(-1))
         tea_all = self.storage.tea_obs.view(-1, self.storage.tea_obs.size(-1))
+        prefetch = (hasattr(stu.actor, 'take_geometry') and self.storage.sampler != "sequential" and obs_all.is_cuda
+                    and os.environ.get("PARTMANIP_GEOM_PREFETCH", "0") == "1")
+        if prefetch and getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream()
+        step_no, done_ev = 0, [None, None]                 # done_ev[slot]: the step that last read staging buffer `slot` has been enqueued
         for _ in range(self.n_updates):
             batch = self.storage.mini_batch_generator(self.num_mini_batches)   # fresh sampler per epoch (dagger.py:305)
-            for indices in batch:
+            it_b = iter(batch)
+            nxt = next(it_b, None)
+            pending = None
+            while nxt is not None:
+                indices, nxt = nxt, next(it_b, None)
                 in_place = getattr(stu.actor, 'supports_row_index', False) and self.storage.sampler != "sequential"
-                stu_obs = None if in_place else self._rows('stu', obs_all, indices)
+                if pending is not None:                    # rows and tables of this mini-batch were built under the previous one
+                    stu_obs, g_ready, ev = pending
+                    torch.cuda.current_stream().wait_event(ev)
+                    stu.actor.take_geometry(g_ready)
+                    pending = None
+                else:
+                    stu_obs = None if in_place else self._rows('stu', obs_all, indices)
                 tea_obs = self._rows('tea', tea_all, indices)
                 with torch.no_grad():
                     tea_mu = tea.actor.hip_forward(tea_obs)                  # teacher.act, squashing fused into K11
@@ -185,6 +237,13 @@ class dagger:
                 self._loss_sum += scal[0:1]
                 self.optimizer.step(n=n_a, n_clip=0, max_norm=0.0)           # no clipping (dagger.py:317-319)
                 count += 1
+                if prefetch:
+                    slot = step_no & 1
+                    done_ev[slot] = torch.cuda.Event()
+                    done_ev[slot].record()
+                    step_no += 1
+                    if nxt is not None:                    # (this step is enqueued: the host may now block in the tables' two size reads)
+                        pending = self._geom_prefetch(obs_all, nxt, step_no & 1, done_ev[step_no & 1])
         mean_loss = float(self._loss_sum.item()) / count
         print('update loss', mean_loss)
         if self.lr_schedule == 'linear_decay':

@@ -109,6 +109,50 @@ def test_dagger_update_with_sparse_unet_student_matches_the_restatement(tmp_path
     assert_update_matches(flat_state(run.student.state_dict()), flat_state(stu), init, lr, len(ref["loss_trace"]))
 
 
+def test_dagger_geometry_prefetch_on_a_side_stream_is_bit_identical(tmp_path, monkeypatch):
+    """dagger.update can build the voxel tables of mini-batch k + 1 on a side stream under the GEMMs of mini-batch k (opt-in
+    PARTMANIP_GEOM_PREFETCH=1; random sampler; two staging buffers, events both ways, record_stream hand-over).  Same seed, prefetch on / off: the student's
+    parameters after 3 epochs x 3 mini-batches are bit-identical and so is the logged loss."""
+    from partmanip_amd.algorithms import ppo, dagger
+    monkeypatch.chdir(tmp_path)
+    P, Rg, A, N, O_t = NET["point_num"], NET["grid"], 6, 6, 20
+    O_s = 4 * P
+    tnet = dict(name="MLP", hid_dim=[32, 32], activation="tanh")
+    tc = dict(net=tnet, N=N, T=1, n_updates=1, n_minibatches=1, tricks=dict(cases.TRICKS_DEFAULT), sampler="sequential",
+              succ_value=None, lr=1e-3, desired_kl=0.1, lr_schedule="fixed", gamma=0.99, lam=0.95, epsilon_clip=0.2, action_std=0.5,
+              max_iterations=10)
+    tea = ppo(FakeEnv(N, {"normal_state": O_t}, A), ppo_cfg(tc, device=DEV), FakeLogger(str(tmp_path)))
+    tsd = cases.actor_critic_state(tnet, O_t, A, 0.5, 52)
+    tea.actor_critic.load_state_dict({k: t(v.copy()) for k, v in tsd.items()})
+    tea.save(1)
+    n_fill = 6
+    cfg = dict(num_envs=N, obs_mode="depth_sparse", model=_model(NET, 0.1), max_iterations=100, n_steps=1, n_updates=3,
+               n_minibatches=3, device=DEV, buf_size=n_fill, reward_reset=False, add_proprio_obs=False, offline_data_pth=None,
+               eval_round=1, eval_frequence=10 ** 9, save_frequence=10 ** 9, test_only=False, save_pose=False, save_video=False,
+               lr_schedule="fixed", lr=1e-3, teacher=str(tmp_path / "model_1.pth"), resume=None, pretrain=None, sampler="random")
+    obs = [cases.sparse_clouds(N, P, Rg, 160 + k, n_distinct=80, pad_tail=3) for k in range(n_fill)]
+    tob = [np.random.default_rng(170 + k).standard_normal((N, O_t)).astype(np.float32) for k in range(n_fill)]
+    init = cases.actor_critic_state(NET, O_s, A, 0.1, 51)
+    out = {}
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("PARTMANIP_GEOM_PREFETCH", mode)
+        env = FakeEnv(N, {"depth_sparse": O_s, "normal_state": O_t, "proprio_state": 0}, A)
+        run = dagger(env, cfg, FakeLogger(str(tmp_path)))
+        run.student.load_state_dict({k: t(v.copy()) for k, v in init.items()})
+        for a, b in zip(obs, tob):
+            run.storage.add_transitions_dagger(t(a).to(DEV), t(b).to(DEV))
+        run.log_dict = {}
+        torch.manual_seed(5)
+        run.update(1)
+        res = (flat_state(run.student.state_dict()), run.log_dict["Train/dagger_loss"])
+        if mode in out:
+            assert np.array_equal(out[mode][0], res[0])                # run-to-run
+        out[mode] = res
+    assert out["1"][1] == out["0"][1]
+    assert np.array_equal(out["1"][0], out["0"][0])
+    assert not np.array_equal(out["1"][0], np.concatenate([np.asarray(v, dtype=np.float32).reshape(-1) for v in init.values()]))
+
+
 def test_fused_and_materialised_gathers_agree_bit_for_bit():
     """`fused_gather`: the neighbour rows are gathered by the GEMM's LDS-DMA loader instead of being written to HBM first; the
     MFMA k-order is the same, so outputs and gradients are identical."""
