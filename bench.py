@@ -352,7 +352,11 @@ def run_depth2pc(args, device):
     nbytes = 1024.0 * streamed * 20.0 + pts * 12.0
     gbs = nbytes / dfps / 1e9
     out["roofline"] = dict(bound="hbm", kernel="fps_multi_kernel (on-chip chunks, streamed remainder)", achieved=gbs, peak=PEAK_HBM_GBS,
-                           unit="GB/s", frac=gbs / PEAK_HBM_GBS, traffic=None, mean_launch_ms=dfps * 1e3, bytes_per_launch=nbytes,
+                           unit="GB/s", frac=gbs / PEAK_HBM_GBS, traffic=_hbm_traffic("fps_multi_kernel_bytes_per_launch")[0],
+                           traffic_note="HBM bytes of the launch from the committed PMC pass (profiles/hbm_traffic.json): the streamed "
+                                        "remainder is re-read every round out of L2 / Infinity Cache, so HBM sees far less than the "
+                                        "algorithmic bytes",
+                           mean_launch_ms=dfps * 1e3, bytes_per_launch=nbytes,
                            us_per_round=dfps * 1e6 / 1024.0, points=pts, points_streamed_per_round=float(streamed),
                            one_work_group_per_cloud_bytes=1024.0 * pts * 20.0,
                            note="the kernel is bound by its K = 1024 DEPENDENT rounds (per round: ~33 distance updates per thread, a "

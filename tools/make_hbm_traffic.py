@@ -4,7 +4,7 @@ tools/pmc_summary.py).  FETCH_SIZE / WRITE_SIZE are KB per launch; FETCH_SIZE is
 requests of wide coalesced reads at 64 B: MI355X_MICROARCH.md, HBM section).  GRBM_GUI_ACTIVE sums the 8 XCDs;
 SQ_VALU_MFMA_BUSY_CYCLES sums the issued MFMAs' pipe cycles over the 1024 SIMDs.
 
-    python tools/make_hbm_traffic.py <tag> <pmc_enc summary.json> [<pmc_lin summary.json> [<pmc_su summary.json>]]
+    python tools/make_hbm_traffic.py <tag> <pmc_enc summary.json> [<pmc_lin summary.json> [<pmc_su summary.json> [<pmc_fps summary.json>]]]
 """
 import json
 import os
@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, enc = sys.argv[1], json.load(open(sys.argv[2]))
 lin = json.load(open(sys.argv[3])) if len(sys.argv) > 3 and os.path.exists(sys.argv[3]) else None
 su = json.load(open(sys.argv[4])) if len(sys.argv) > 4 and os.path.exists(sys.argv[4]) else None
+fps = json.load(open(sys.argv[5])) if len(sys.argv) > 5 and os.path.exists(sys.argv[5]) else None
 dst = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 out = json.load(open(dst)) if os.path.exists(dst) else {}
 
@@ -70,5 +71,13 @@ if su is not None:
                                           "passes, ALL kernels of the process): bytes below are per forward + backward pass")
     out["sparse_unet_256_clouds_fetch_bytes_per_pass"] = f / 5.0
     out["sparse_unet_256_clouds_write_bytes_per_pass"] = w / 5.0
+if fps is not None:
+    k = find(fps, "fps_multi_kernel")
+    f, w = traffic(k)
+    out["fps_multi_kernel_bytes_per_launch"] = f + w
+    out["fps_multi_kernel_fetch_bytes_raw"] = f / 2.0
+    out["fps_multi_kernel_cycles_per_launch"] = k["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+    out["fps_multi_kernel_note"] = (f"tools/pmc_run.sh gpurun_out/{tag}/pmc_fps python bench.py --workload depth2pc --no-cpu-baseline: the "
+                                    "multi-work-group FPS launch of depth2pc (64 envs x 6 views x 180 x 320), FETCH doubled")
 json.dump(out, open(dst, "w"), indent=1)
 print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in out.items() if not k.endswith("note") and k not in ("source", "correction")})

@@ -17,6 +17,7 @@ prof bench_default --no-optional --no-secondary --steps 2 --warmup 1
 prof bench_state --workload state --steps 2 --warmup 1 --no-cpu-baseline
 prof bench_dagger_sparse_unet --workload dagger --student sparse_unet --steps 1 --warmup 1 --no-cpu-baseline
 prof bench_vision_pn2 --workload vision_pn2 --steps 1 --warmup 1 --no-cpu-baseline
+prof bench_depth2pc --workload depth2pc --no-cpu-baseline
 # un-profiled bench lines (the numbers to quote: a profiled run clocks lower)
 timeout 900 python bench.py > $out/line_default.json 2> $out/line_default.err < /dev/null
 timeout 300 python bench.py --workload state > $out/line_state.json 2>> $out/line_default.err < /dev/null
@@ -29,4 +30,5 @@ timeout 300 python bench.py --workload depth2pc > $out/line_depth2pc.json 2>> $o
 PMC_PASS_TIMEOUT=150 bash tools/pmc_run.sh $out/pmc_enc python tools/time_enc.py < /dev/null
 PMC_PASS_TIMEOUT=150 bash tools/pmc_run.sh $out/pmc_lin python tools/time_gemm.py 2048x512x512 < /dev/null
 PMC_PASS_TIMEOUT=200 bash tools/pmc_run.sh $out/pmc_su python tools/time_sparse_unet.py 256 < /dev/null
+PMC_PASS_TIMEOUT=150 bash tools/pmc_run.sh $out/pmc_fps python bench.py --workload depth2pc --no-cpu-baseline < /dev/null
 ls $out
