@@ -37,8 +37,10 @@
 // 2048 clouds): the call takes 2.10 ms against 2.63 for the fp32 kernel -- far from the 2.7 x of the matrix pipe: the in-kernel
 // timeline (-DPN_PROFILE, tools/pn_profile.py with PN_PRECISION_BWD=bf16x6) shows a 15-16 k-cycle tile of which the MFMA
 // stage is 7-8 k (6.1 k of MFMAs), the VALU stage 4-4.5 k (~550 VALU instructions per thread and tile: the three-plane split
-// alone is 9 per value pair, 12 pairs) and the two barriers' skew 2-2.5 k.  What would move it: VALU / MFMA overlap, i.e. the
-// planes twice -- 75 KB per buffer if dW2's A operand came from Zc through ds_read_b64_tr_b16 instead of a second layout.
+// alone is 9 per value pair, 12 pairs) and the two barriers' skew 2-2.5 k.  MFMA and VALU cycles are ADDITIVE on a SIMD for the
+// bf16 pipe as for the fp32 one (tools/ubench/mfma_bf16_valu_overlap.hip), so the floor of this kernel is 6.1 + 4.4 k cycles
+// per tile (1.35 ms); a variant that walks dh1 / dW2 and the two halves of the VALU stage as skewed chunks on the two waves of a
+// SIMD was built on the opposite hope, is bit-identical and measured 2.22 ms.
 
 typedef __bf16 pb6_bf16x8 __attribute__((ext_vector_type(8)));
 #define PB6_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
