@@ -379,7 +379,10 @@ int pm_depth_compact_f32(const float* xyz, int B, int P, float* out, int32_t* le
 size_t pm_fps_varlen_workspace_bytes(int B, int ld); /* 0 when every cloud fits in registers (ld <= 8192); with it (8-byte aligned) camera-sized
                                                       * xyz clouds run on several work-groups per cloud, each keeping its chunk on chip;
                                                       * its last 8 bytes are then cleared by every call and set non-zero when a work-group
-                                                      * gave up waiting for its partners (bounded spin): read them after the call */
+                                                      * gave up waiting for its partners (bounded spin): read them after the call.
+                                                      * The partners wait for each other INSIDE the launch: other kernels on the device only
+                                                      * delay it (their work-groups drain), but two such launches running concurrently on
+                                                      * two streams can hold each other's CUs -- issue them from one stream */
 int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths,
                       int pad /* 1: pytorch3d semantics, -1 once a cloud is exhausted; 0: keep sampling (see above) */,
                       int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream);
