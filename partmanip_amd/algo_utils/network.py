@@ -467,6 +467,9 @@ class PointNet2(_HipNet):
         object.__setattr__(self, "_sa_h2", [None] * len(self.npoints))
         object.__setattr__(self, "_save_h2_now", False)
         self.save_h2 = bool(net_cfg.get('save_h2', True))
+        # fused levels run over each group's DISTINCT rows (ball query pads short groups with copies of their first hit;
+        # a copy never wins the max-pool): same outputs and gradients as the dense kernels, `False` keeps the dense form (A/B)
+        self.unique_rows = bool(net_cfg.get('sa_unique_rows', True))
         object.__setattr__(self, "_sa_grads", None)
 
     def set_grad_views(self, views):
@@ -496,19 +499,29 @@ class PointNet2(_HipNet):
             if buf is None or buf.numel() < n or buf.device != xyz.device:
                 buf = self._sa_h2[l] = torch.empty(n, device=xyz.device)
             h2 = buf[:n]
-        arg = ops.sa_fwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
-                         packed, dims, pooled, h2)
-        return (idx_g, arg, "fused", xyz, feat, centers, Y, packed, dims, pooled, h2)
+        plan = None
+        if self.unique_rows:
+            plan = ops.sa_plan(idx_g, Pl, dims, self._workspace(xyz.device))
+            arg = ops.sa_fwd_packed(xyz, centers, plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
+                                    packed, dims, pooled, h2)
+        else:
+            arg = ops.sa_fwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
+                             packed, dims, pooled, h2)
+        return (idx_g, arg, "fused", xyz, feat, centers, Y, packed, dims, pooled, h2, plan)
 
     def _sa_backward_fused(self, l, rec, dpooled, ws, need_dfeat):
-        idx_g, arg, _, xyz, feat, centers, Y, packed, dims, pooled, h2 = rec
+        idx_g, arg, _, xyz, feat, centers, Y, packed, dims, pooled, h2, plan = rec
         B, Pl = xyz.shape[0], xyz.shape[1]
         lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
         (dW1, db1), (dW2, db2), (dW3, db3) = self._chains[l].grads
         cf = 0 if feat is None else feat.shape[2]
         dY = torch.zeros(B * Pl, dims[0], device=xyz.device) if cf > 0 else None
-        ops.sa_bwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data, packed,
-                   dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws, h2)
+        if plan is not None:
+            ops.sa_bwd_packed(xyz, centers, plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data,
+                              packed, dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws, h2)
+        else:
+            ops.sa_bwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data, packed,
+                       dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws, h2)
         if dW1.shape[1] > 3 + cf:
             dW1[:, 3 + cf:].zero_()                        # pad columns never receive data
         if cf == 0:

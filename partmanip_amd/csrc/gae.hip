@@ -1,5 +1,6 @@
 // K1 GAE return scan, K2 advantage normalisation, K3 row gather.  HBM / latency bound.
 #include "common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------- K1
 // storage.py:96-112.  The recurrence  adv_t = notdone_t * (delta_t + gamma*lam * adv_{t+1})  is the only serial part of
@@ -12,8 +13,8 @@
 // work-groups on 64 CUs): 40-55 us for 4096 x 128.  With 16 envs per work-group every CU takes part in the
 // element-wise phases.  All arithmetic is the reference's op-by-op sequence in explicit round-to-nearest ops (no FMA
 // contraction), evaluated per element exactly as before: the result stays bit-identical to the reference's tensors.
-#define GAE_E 16
 #define GAE_TC 128
+template <int GAE_E>
 __global__ __launch_bounds__(256) void gae_scan_kernel(const float* __restrict__ rewards,
                                                         const float* __restrict__ values,
                                                         const uint8_t* __restrict__ dones,
@@ -95,9 +96,21 @@ extern "C" int pm_gae_scan_f32(const float* rewards, const float* values, const 
     PM_REQUIRE(rewards && values && dones && last_values && returns && advantages);
     PM_REQUIRE(T > 0 && N > 0);
     PM_REQUIRE(!use_succ || succs);
-    hipLaunchKernelGGL(gae_scan_kernel, dim3((N + GAE_E - 1) / GAE_E), dim3(256), 0, pm_stream(stream), rewards, values,
-                       dones, succs, last_values, returns, advantages, T, N, gamma, gamma_lam, use_succ,
-                       succ_value);
+    // Envs per work-group: the widest row piece (64 envs = 256-byte segments of every time step) that still leaves one
+    // work-group per CU; 4096 envs -> 16 (256 work-groups, 64-byte pieces), >= 16384 envs -> 64.  PM_GAE_E overrides (A/B).
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("PM_GAE_E");
+        forced = e ? atoi(e) : 0;
+    }
+    int E = forced ? forced : (N >= 64 * 256 ? 64 : N >= 32 * 256 ? 32 : 16);
+#define GAE_LAUNCH(E_)                                                                                                     \
+    hipLaunchKernelGGL(gae_scan_kernel<E_>, dim3((N + (E_) - 1) / (E_)), dim3(256), 0, pm_stream(stream), rewards, values, \
+                       dones, succs, last_values, returns, advantages, T, N, gamma, gamma_lam, use_succ, succ_value)
+    if (E == 64) GAE_LAUNCH(64);
+    else if (E == 32) GAE_LAUNCH(32);
+    else GAE_LAUNCH(16);
+#undef GAE_LAUNCH
     PM_CHECK_LAUNCH();
     return PM_OK;
 }

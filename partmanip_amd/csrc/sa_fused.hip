@@ -672,3 +672,632 @@ extern "C" int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
+
+// ============================================================================================================
+// Duplicate-free ("packed") form of the same level.
+//
+// Ball query pads a group whose ball holds fewer than 32 points with copies of its FIRST hit (the canonical
+// PointNet++ rule; oracle/ref_cpu.py::ball_query).  A padded row is the same source point against the same
+// centre as row 0 of its group, so its three activations are bit-identical to row 0's; the max-pool takes the
+// LOWEST row attaining the maximum, so a padding row never wins, never receives a gradient, and the level's
+// outputs (pooled, arg) and every gradient are exactly those of the group's DISTINCT rows.  On the SURVEY's
+// synthetic clouds (1024 points uniform in a 2 m cube, radius 0.2 / 0.4) a group has 3.9 / 5.4 distinct rows of
+// 32: the dense kernels above spend 88 % / 83 % of their rows on copies.
+//
+// pm_sa_plan_i32 (once per neighbourhood table) lists the distinct rows back to back (rowmap: source point and
+// group per packed row; grow: first packed row of every group) and cuts them into tiles of whole groups
+// (<= tile_rows rows, <= tile_groups groups, never across clouds).  The kernels below run the SAME per-row
+// arithmetic as sa_fwd_kernel / sa_bwd_kernel on those tiles:
+//   forward   layers 1-3 as above on the tile's rows; the pre-activations of layer 3 go through LDS and one thread
+//             per (group, channel) takes the max over the group's rows (same strict `>` in row order => same arg).
+//   backward  dZ3 has one non-zero per (group, channel) at packed row grow[g] + arg: the MFMA A operand is built
+//             per row from ITS group's (val, arg) entries, so dH2 = dZ3 * W3 is ONE rows x C3 x C2 product per
+//             tile whatever the number of groups in it (the dense kernel runs it per group on 32 rows).
+// Results are bit-identical to the dense kernels wherever those are deterministic (pooled, arg, the saved layer 2);
+// the weight gradients differ by fp32 summation order only (fewer, exactly-zero terms dropped).
+// The kernels read the tile count from device memory (persistent work-groups): no host synchronisation anywhere.
+struct SaPk {
+    const int32_t* grow;     // (G + 1)   first packed row of each group
+    const int2* rowmap;      // (R)       {flat source point b*P + idx, group}
+    const int4* tiles;       // (T)       {first packed row, first group, groups, rows}
+    const int32_t* totals;   // [0] = R, [1] = T
+};
+
+extern "C" int pm_sa_packed_tile(int C1, int C2, int C3, int* tile_rows, int* tile_groups) {
+    PM_REQUIRE(tile_rows && tile_groups);
+    if (SA_CFG_A(C1, C2, C3)) { *tile_rows = 64; *tile_groups = 20; return PM_OK; }
+    if (SA_CFG_B(C1, C2, C3)) { *tile_rows = 128; *tile_groups = 28; return PM_OK; }
+    return PM_EUNSUPPORTED;
+}
+
+// ---- plan ---------------------------------------------------------------------------------------------------
+// one work-group per cloud: distinct rows per group (entries j >= 1 equal to entry 0 are padding: real hits are
+// ascending and distinct), their prefix inside the cloud, and the greedy cut into tiles of whole groups
+__global__ __launch_bounds__(256) void sa_plan_count_kernel(const int32_t* __restrict__ idx, int S, int ns, int tile_rows,
+                                                             int tile_groups, int32_t* __restrict__ lrow,
+                                                             int4* __restrict__ ltiles, int32_t* __restrict__ crows,
+                                                             int32_t* __restrict__ ctiles) {
+    __shared__ int cnt[1024];
+    const long b = blockIdx.x;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const int32_t* p = idx + (b * S + s) * ns;
+        const int first = p[0];
+        int c = 1;
+        for (int j = 1; j < ns; ++j) c += p[j] != first;
+        cnt[s] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int rows = 0, start = 0, prefix = 0, nt = 0, row0 = 0;
+        for (int s = 0; s < S; ++s) {
+            const int c = cnt[s];
+            if (s > start && (rows + c > tile_rows || s - start == tile_groups)) {
+                ltiles[b * S + nt++] = make_int4(row0, start, s - start, rows);
+                start = s;
+                row0 = prefix;
+                rows = 0;
+            }
+            lrow[b * S + s] = prefix;
+            prefix += c;
+            rows += c;
+        }
+        ltiles[b * S + nt++] = make_int4(row0, start, S - start, rows);
+        crows[b] = prefix;
+        ctiles[b] = nt;
+    }
+}
+
+// exclusive prefix over the clouds (one work-group)
+__global__ __launch_bounds__(1024) void sa_plan_scan_kernel(const int32_t* __restrict__ crows, const int32_t* __restrict__ ctiles,
+                                                             int B, int32_t* __restrict__ rbase, int32_t* __restrict__ tbase,
+                                                             int32_t* __restrict__ totals) {
+    __shared__ int sr[1024], st[1024];
+    __shared__ int carry[2];
+    if (threadIdx.x == 0) carry[0] = carry[1] = 0;
+    __syncthreads();
+    for (int lo = 0; lo < B; lo += 1024) {
+        const int i = lo + threadIdx.x;
+        const int r = i < B ? crows[i] : 0, t = i < B ? ctiles[i] : 0;
+        sr[threadIdx.x] = r;
+        st[threadIdx.x] = t;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int ar = threadIdx.x >= o ? sr[threadIdx.x - o] : 0, at = threadIdx.x >= o ? st[threadIdx.x - o] : 0;
+            __syncthreads();
+            sr[threadIdx.x] += ar;
+            st[threadIdx.x] += at;
+            __syncthreads();
+        }
+        if (i < B) {
+            rbase[i] = carry[0] + sr[threadIdx.x] - r;
+            tbase[i] = carry[1] + st[threadIdx.x] - t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+            carry[0] += sr[1023];
+            carry[1] += st[1023];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = carry[0];
+        totals[1] = carry[1];
+    }
+}
+
+__global__ __launch_bounds__(256) void sa_plan_fill_kernel(const int32_t* __restrict__ idx, int B, int P, int S, int ns,
+                                                            const int32_t* __restrict__ lrow, const int4* __restrict__ ltiles,
+                                                            const int32_t* __restrict__ ctiles, const int32_t* __restrict__ rbase,
+                                                            const int32_t* __restrict__ tbase, const int32_t* __restrict__ totals,
+                                                            int32_t* __restrict__ grow, int2* __restrict__ rowmap,
+                                                            int4* __restrict__ tiles) {
+    const long b = blockIdx.x;
+    const int rb = rbase[b], tb = tbase[b];
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const long g = b * S + s;
+        const int r0 = rb + lrow[g];
+        grow[g] = r0;
+        const int32_t* p = idx + g * ns;
+        const int first = p[0];
+        rowmap[r0] = make_int2((int)(b * P + first), (int)g);
+        int k = 1;
+        for (int j = 1; j < ns; ++j) {
+            const int v = p[j];
+            if (v != first) rowmap[r0 + k++] = make_int2((int)(b * P + v), (int)g);
+        }
+    }
+    const int nt = ctiles[b];
+    for (int t = threadIdx.x; t < nt; t += 256) {
+        const int4 lt = ltiles[b * S + t];
+        tiles[tb + t] = make_int4(rb + lt.x, (int)(b * S) + lt.y, lt.z, lt.w);
+    }
+    if (b == B - 1 && threadIdx.x == 0) grow[(long)B * S] = totals[0];
+}
+
+extern "C" size_t pm_sa_plan_workspace_bytes(int B, int S) {
+    return ((size_t)B * S * 5 + (size_t)B * 4) * sizeof(int32_t) + 64;
+}
+
+extern "C" int pm_sa_plan_i32(const int32_t* idx, int B, int P, int S, int nsample, int tile_rows, int tile_groups,
+                              int32_t* grow, int32_t* rowmap, int32_t* tiles, int32_t* totals, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(idx && grow && rowmap && tiles && totals && workspace);
+    PM_REQUIRE(B > 0 && P > 0 && S > 0 && S <= 1024 && nsample > 0 && nsample <= tile_rows && tile_groups > 0 && tile_groups <= 255);
+    PM_REQUIRE((long)B * P < (1L << 31) && (long)B * S * nsample < (1L << 31));
+    if (workspace_bytes < pm_sa_plan_workspace_bytes(B, S)) return PM_EWORKSPACE;
+    if ((((uintptr_t)workspace) & 15) || (((uintptr_t)tiles) & 15) || (((uintptr_t)rowmap) & 7)) return PM_EALIGN;
+    const size_t G = (size_t)B * S;
+    int4* ltiles = (int4*)workspace;
+    int32_t* lrow = (int32_t*)(ltiles + G);
+    int32_t* crows = lrow + G;
+    int32_t *ctiles = crows + B, *rbase = ctiles + B, *tbase = rbase + B;
+    hipStream_t st = pm_stream(stream);
+    hipLaunchKernelGGL(sa_plan_count_kernel, dim3(B), dim3(256), 0, st, idx, S, nsample, tile_rows, tile_groups, lrow, ltiles,
+                       crows, ctiles);
+    hipLaunchKernelGGL(sa_plan_scan_kernel, dim3(1), dim3(1024), 0, st, crows, ctiles, B, rbase, tbase, totals);
+    hipLaunchKernelGGL(sa_plan_fill_kernel, dim3(B), dim3(256), 0, st, idx, B, P, S, nsample, lrow, ltiles, ctiles, rbase,
+                       tbase, totals, grow, (int2*)rowmap, (int4*)tiles);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// ---- shared staging of a packed tile -------------------------------------------------------------------------
+// Xz / Src as sa_stage; Lgr[t] = local group << 8 | local row (rows past the tile's end: row 255, which no arg-max
+// equals); Ls[j] = first tile-local row of group j (j <= groups).  Rows past the end repeat the tile's first row
+// (finite activations that nothing reads back).
+template <int TM, int NT>
+__device__ __forceinline__ void sa_stage_pk(const SaArgs& a, const SaPk& k, const int4 td, int tid, float* __restrict__ Xz,
+                                            int* __restrict__ Src, int* __restrict__ Lgr, int* __restrict__ Ls) {
+    for (int t = tid; t < TM; t += NT) {
+        const bool live = t < td.w;
+        const int2 rm = k.rowmap[td.x + (live ? t : 0)];
+        const long sp = rm.x, g = rm.y;
+        float4 v;
+        v.x = sub_rn(a.xyz[sp * 3], a.centers[g * 3]);
+        v.y = sub_rn(a.xyz[sp * 3 + 1], a.centers[g * 3 + 1]);
+        v.z = sub_rn(a.xyz[sp * 3 + 2], a.centers[g * 3 + 2]);
+        v.w = 0.f;
+        *(float4*)(Xz + t * 4) = v;
+        Src[t] = rm.x;
+        if (Lgr) Lgr[t] = live ? (((rm.y - td.y) << 8) | (td.x + t - k.grow[rm.y])) : 255;
+    }
+    for (int j = tid; j <= td.z; j += NT) Ls[j] = k.grow[td.y + j] - td.x;
+}
+
+// ==================================================================================== packed forward
+// NBW3 waves side by side along the C3 axis (NW / NBW3 along the rows); a staging round holds NBW3*32 channels of Z3.
+template <int C1, int C2, int C3, int TM, int NW, int WPE, int NGMAX, int NBW3>
+__global__ __launch_bounds__(NW * 64, WPE) void sa_fwd_pk_kernel(SaArgs a, SaPk k) {
+    constexpr int NT = NW * 64, LD1 = C1 + 4, LD2 = C2 + 4, LDM = LD1 > LD2 ? LD1 : LD2;
+    constexpr int MW3 = NW / NBW3, MB3 = TM / 32 / MW3, NB3 = C3 / 32 / NBW3, W3S = NBW3 * 32, LDZ = W3S + 4;
+    static_assert(MW3 * NBW3 == NW && MB3 * MW3 * 32 == TM && NB3 * NBW3 * 32 == C3 && NT % W3S == 0, "layer-3 wave mapping");
+    constexpr int HSZ = TM * LDM, ZSZ = TM * LDZ, BUF = HSZ > ZSZ ? HSZ : ZSZ;
+    __shared__ __attribute__((aligned(16))) float smem[BUF + TM * 4 + TM + (NGMAX + 4)];
+    float* H1 = smem;
+    float* H2 = smem;
+    float* Zs = smem;                                    // layer-3 pre-activations of a staging round (after H2 is dead)
+    float* Xz = smem + BUF;
+    int* Src = (int*)(Xz + TM * 4);
+    int* Ls = Src + TM;
+    constexpr int NG3 = C2 / 8;
+
+    const int tid0 = threadIdx.x;
+    const float4* P2v = (const float4*)a.packed;
+    const float4* P3v = (const float4*)(a.packed + (size_t)C1 * C2);
+    const int ntiles = k.totals[1];
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));                    // see sa_fwd_kernel: recompute, don't hoist
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int li = lane & 31, lh = lane >> 5;
+        const int4 td = k.tiles[tile];
+        sa_stage_pk<TM, NT>(a, k, td, tid, Xz, Src, nullptr, Ls);
+        __syncthreads();
+        sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
+        __syncthreads();
+        sa_layer2<C1, C2, TM, NW, true>(H1, P2v, a.b2, wave, lane, H2);
+        __syncthreads();
+        // ---- layer 3 ---------------------------------------------------------------------------------
+        const int wn = wave % NBW3, wm = wave / NBW3;
+        f32x16 acc[MB3][NB3];
+        zero_acc<MB3, NB3>(acc);
+        mfma_stream<MB3, NB3, NG3>(H2 + (wm * MB3 * 32 + li) * LD2 + lh * (C2 / 2), LD2,
+                                   P3v + (size_t)(wn * NB3) * NG3 * 64 + lane, acc);
+        if (a.h2) {                                          // training forward: keep H2 (packed rows) for the backward
+#pragma unroll 2
+            for (int q = tid; q < TM * C2 / 4; q += NT) {
+                const int row = q / (C2 / 4), c4 = q % (C2 / 4);
+                if (row < td.w)
+                    *(float4*)(a.h2 + (long)(td.x + row) * C2 + 4 * c4) = *(const float4*)(H2 + row * LD2 + 4 * c4);
+            }
+        }
+        // ---- max over each group's rows: Z3 through LDS, one thread per (group, channel) ------------------
+#pragma unroll
+        for (int nb = 0; nb < NB3; ++nb) {
+            __syncthreads();                             // H2 (or the previous round of Zs) is no longer read
+#pragma unroll
+            for (int mb = 0; mb < MB3; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * MB3 + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    Zs[row * LDZ + wn * 32 + li] = acc[mb][nb][r];
+                }
+            __syncthreads();
+            const int s = tid % W3S, ch = ((s >> 5) * NB3 + nb) * 32 + (s & 31);
+            const float bv = a.b3[ch];
+            for (int j = tid / W3S; j < td.z; j += NT / W3S) {
+                const int r0 = Ls[j], r1 = Ls[j + 1];
+                float best = Zs[r0 * LDZ + s];
+                int bi = 0;
+                for (int r = r0 + 1; r < r1; ++r) {
+                    const float v = Zs[r * LDZ + s];
+                    if (v > best) {
+                        best = v;
+                        bi = r - r0;
+                    }
+                }
+                const long g = td.y + j;
+                a.pooled[g * a.ldp + ch] = pm_tanh(best + bv);
+                a.arg[g * C3 + ch] = bi;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static long sa_pk_grid(long G, int ncu, int wgcu, long cap) {
+    long grid = (long)ncu * wgcu;
+    if (cap > 0 && grid > cap) grid = cap;
+    if (grid > G) grid = G;                              // a tile holds at least one group
+    return grid;
+}
+
+extern "C" int pm_sa_fwd_packed_f32(const float* xyz, const float* centers, const float* Y, int B, int P, int S,
+                                    const int32_t* grow, const int32_t* rowmap, const int32_t* tiles, const int32_t* totals,
+                                    const float* W1, long ldw1, const float* b1, const float* b2, const float* b3,
+                                    const float* packed, int C1, int C2, int C3, float* pooled, long ldp, int32_t* arg,
+                                    float* h2_save, void* stream) {
+    PM_REQUIRE(xyz && centers && grow && rowmap && tiles && totals && W1 && b1 && b2 && b3 && packed && pooled && arg);
+    PM_REQUIRE(B > 0 && P > 0 && S > 0 && ldw1 >= 3 && ldp >= C3);
+    if (!pm_sa_supported(C1, C2, C3, SA_NS)) return PM_EUNSUPPORTED;
+    if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)tiles & 15) != 0) return PM_EALIGN;
+    SaArgs a = {};
+    a.xyz = xyz; a.centers = centers; a.Y = Y; a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.b2 = b2; a.b3 = b3;
+    a.packed = packed; a.pooled = pooled; a.ldp = ldp; a.arg = arg; a.G = (long)B * S; a.S = S; a.P = P;
+    a.h2 = h2_save;
+    SaPk k = {grow, (const int2*)rowmap, (const int4*)tiles, totals};
+    const int ncu = sa_cu_count();
+    if (SA_CFG_A(C1, C2, C3))
+        hipLaunchKernelGGL((sa_fwd_pk_kernel<64, 64, 128, 64, 4, 4, 20, 4>), dim3((unsigned)sa_pk_grid(a.G, ncu, 4, 0)),
+                           dim3(256), 0, pm_stream(stream), a, k);
+    else
+        hipLaunchKernelGGL((sa_fwd_pk_kernel<128, 128, 256, 128, 8, 2, 28, 4>), dim3((unsigned)sa_pk_grid(a.G, ncu, 2, 0)),
+                           dim3(512), 0, pm_stream(stream), a, k);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// =================================================================================== packed backward
+// as mfma_stream_fn, for a window of NGC k-groups out of a packed operand with NGS k-groups per N-block
+template <int MB, int NB, int NGS, int NGC, class AF>
+__device__ __forceinline__ void mfma_stream_fn_win(AF aload, const float4* __restrict__ Bp, f32x16 (&acc)[MB][NB]) {
+    OperandSet<MB, NB> ping, pong;
+#define PM_LOAD_FN(o, g_)                                                                   \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) o.b[nb] = Bp[(size_t)(nb * NGS + (g_)) * 64]; \
+    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) o.a[mb] = aload(mb, (g_));
+    PM_LOAD_FN(ping, 0)
+#pragma unroll 1
+    for (int g = 0; g < NGC; g += 2) {
+        PM_LOAD_FN(pong, g + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set<MB, NB>(ping, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        PM_LOAD_FN(ping, g + 2)                    // unconditional: one group past the window, discarded
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set<MB, NB>(pong, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef PM_LOAD_FN
+}
+
+template <int C1, int C2, int C3, int TM, int NW, int WPE, int NGMAX>
+__global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk k) {
+    constexpr int NT = NW * 64, LD1 = C1 + 4, LD2 = C2 + 4;
+    // channels are staged 128 at a time (slots 0-63: channels [64q, 64q+64), slots 64-127: C3/2 + the same -- the two
+    // k halves the MFMA lanes own); Val rows padded to 132 floats, Arg rows to 132 bytes (bank spread across groups)
+    constexpr int NCH = C3 / 128, LDV = 132, LDA = 33;
+    __shared__ __attribute__((aligned(16))) float smem[TM * (LD1 + LD2 + 4) + 2 * TM + (NGMAX + 4) + NGMAX * (LDV + LDA)];
+    float* H1 = smem;                        // H1, later dZ1 in place
+    float* H2 = H1 + TM * LD1;
+    float* D = H2;                           // dZ2 overwrites H2 in place
+    float* Xz = H2 + TM * LD2;
+    int* Src = (int*)(Xz + TM * 4);
+    int* Lgr = Src + TM;
+    int* Ls = Lgr + TM;
+    float* Val = (float*)(Ls + NGMAX + 4);
+    uint32_t* ArgW = (uint32_t*)(Val + NGMAX * LDV);
+    using P = SaPart<C1, C2, C3>;
+    using M2 = WaveMap<TM, C2, NW>;          // dH2 output mapping
+    using MH = WaveMap<TM, C1, NW>;          // dH1 output mapping
+    constexpr int NGT = C2 / 8;
+
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
+    const float4* P2v = (const float4*)a.packed;
+    const float4* P2Tv = (const float4*)(a.packed + (size_t)C1 * C2 + (size_t)C2 * C3);
+    const float4* P3Tv = (const float4*)(a.packed + (size_t)C1 * C2 * 2 + (size_t)C2 * C3);
+    const int ntiles = k.totals[1];
+
+    // persistent accumulators
+    constexpr int TPC = NT / 128, KS = C2 / TPC;            // dW3: thread (slot = tid % 128, ks = tid / 128) owns KS k's per chunk
+    static_assert(NT % 128 == 0 && C2 % TPC == 0 && KS % 4 == 0 && NCH * 128 == C3, "dW3 thread mapping");
+    float accW3[NCH][KS], accb3[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        accb3[q] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) accW3[q][j] = 0.f;
+    }
+    float accW1[4] = {0.f, 0.f, 0.f, 0.f};
+    float accb2[M2::NB];
+#pragma unroll
+    for (int nb = 0; nb < M2::NB; ++nb) accb2[nb] = 0.f;
+    constexpr int WBLK = (C2 / 32) * (C1 / 32), NBK = WBLK / NW;
+    static_assert(NBK * NW == WBLK && (C1 / 32) % NBK == 0, "dW2 wave mapping");
+    f32x16 accW2[NBK];
+#pragma unroll
+    for (int j = 0; j < NBK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW2[j][r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int li = lane & 31, lh = lane >> 5;
+        const int w2_m = wave % (C2 / 32), w2_n0 = (wave / (C2 / 32)) * NBK;
+        const int4 td = k.tiles[tile];
+        // ---- P0: gather ------------------------------------------------------------------
+        sa_stage_pk<TM, NT>(a, k, td, tid, Xz, Src, Lgr, Ls);
+        __syncthreads();
+        // ---- P1/P2: H1 recomputed, H2 loaded (or recomputed) -----------------------------------------
+        sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
+        __syncthreads();
+        if (a.h2) {
+#pragma unroll 2
+            for (int q = tid; q < TM * C2 / 4; q += NT) {
+                const int row = q / (C2 / 4), c4 = q % (C2 / 4);
+                float4 h = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past the end: zero (their dZ2 is 0 * (1 - 0))
+                if (row < td.w) h = *(const float4*)(a.h2 + (long)(td.x + row) * C2 + 4 * c4);
+                *(float4*)(H2 + row * LD2 + 4 * c4) = h;
+            }
+        } else {
+            sa_layer2<C1, C2, TM, NW, false>(H1, P2v, a.b2, wave, lane, H2);
+        }
+        // ---- P3: structured layer-3 backward, 128 channels at a time ---------------------------------------
+        const int wn2 = wave % M2::NBW, wm2 = wave / M2::NBW;
+        f32x16 acc[M2::MB][M2::NB];
+        zero_acc<M2::MB, M2::NB>(acc);
+        int lgv[M2::MB], lrv[M2::MB];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            __syncthreads();                 // H2 complete / the previous chunk's Val, Arg no longer read
+            if (q == 0) {
+#pragma unroll
+                for (int mb = 0; mb < M2::MB; ++mb) {
+                    const int lgr = Lgr[(wm2 * M2::MB + mb) * 32 + li];
+                    lgv[mb] = lgr >> 8;
+                    lrv[mb] = lgr & 255;
+                }
+            }
+            for (int i = tid; i < td.z * 128; i += NT) {
+                const int j = i >> 7, s = i & 127;
+                const int c = (s < 64 ? 64 * q + s : C3 / 2 + 64 * q + (s - 64));
+                const long g = td.y + j;
+                const float p = a.pooled[g * a.ldp + c];
+                Val[j * LDV + s] = a.dpooled[g * a.lddp + c] * (1.0f - p * p);
+                ((uint8_t*)ArgW)[j * (LDA * 4) + s] = (uint8_t)a.arg[g * C3 + c];
+            }
+            __syncthreads();
+            {   // dW3[c, :] += val * H2[row of the arg-max, :]   (VALU; the slice stays in registers for the whole kernel)
+                const int s = tid & 127, ks = tid >> 7;
+                for (int j = 0; j < td.z; ++j) {
+                    const float v = Val[j * LDV + s];
+                    const int row = Ls[j] + ((const uint8_t*)ArgW)[j * (LDA * 4) + s];
+                    const float* hrow = H2 + row * LD2 + ks * KS;
+#pragma unroll
+                    for (int k4 = 0; k4 < KS / 4; ++k4) {
+                        const float4 h = *(const float4*)(hrow + 4 * k4);
+                        accW3[q][4 * k4] = fmaf(v, h.x, accW3[q][4 * k4]);
+                        accW3[q][4 * k4 + 1] = fmaf(v, h.y, accW3[q][4 * k4 + 1]);
+                        accW3[q][4 * k4 + 2] = fmaf(v, h.z, accW3[q][4 * k4 + 2]);
+                        accW3[q][4 * k4 + 3] = fmaf(v, h.w, accW3[q][4 * k4 + 3]);
+                        if ((k4 & 3) == 3) {
+                            asm volatile("" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (ks == 0) accb3[q] += v;
+                }
+            }
+            __syncthreads();                 // a real barrier (register live ranges, see sa_bwd_kernel)
+            // dH2 += dZ3[:, chunk] * W3[chunk, :]: A built per ROW from its own group's entries
+            auto asel = [&](int mb, int g) -> float4 {
+                const int slot = lh * 64 + g * 4;
+                const float4 vv = *(const float4*)(Val + lgv[mb] * LDV + slot);
+                const uint32_t ab = ArgW[lgv[mb] * LDA + (slot >> 2)];
+                const int lr = lrv[mb];
+                float4 o;
+                o.x = (int)(ab & 255u) == lr ? vv.x : 0.f;
+                o.y = (int)((ab >> 8) & 255u) == lr ? vv.y : 0.f;
+                o.z = (int)((ab >> 16) & 255u) == lr ? vv.z : 0.f;
+                o.w = (int)(ab >> 24) == lr ? vv.w : 0.f;
+                return o;
+            };
+            mfma_stream_fn_win<M2::MB, M2::NB, C3 / 8, 16>(asel, P3Tv + ((size_t)(wn2 * M2::NB) * (C3 / 8) + 16 * q) * 64 + lane, acc);
+        }
+        __syncthreads();                     // every wave is done with its dW3 reads of H2 rows
+        // ---- P4: dZ2 = dH2 .* (1 - H2^2) -> D, db2 ---------------------------------------------------
+#pragma unroll
+        for (int nb = 0; nb < M2::NB; ++nb) {
+            const int col = (wn2 * M2::NB + nb) * 32 + li;
+#pragma unroll
+            for (int mb = 0; mb < M2::MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm2 * M2::MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float h = H2[row * LD2 + col];
+                    const float z = acc[mb][nb][r] * (1.0f - h * h);
+                    D[row * LD2 + col] = z;
+                    accb2[nb] += z;
+                }
+        }
+        __syncthreads();
+        // ---- P5: dW2 += dZ2^T * H1 ------------------------------------------------------------------
+        {
+            const float* Ap = D + (lh * (TM / 2)) * LD2 + w2_m * 32 + li;
+            const float* Bp = H1 + (lh * (TM / 2)) * LD1 + w2_n0 * 32 + li;
+            float ap, bp[NBK], aq, bq[NBK];
+#define SA_DW2_LOAD(a_, b_, s_)  \
+    a_ = Ap[(s_) * LD2];         \
+    _Pragma("unroll") for (int j = 0; j < NBK; ++j) b_[j] = Bp[(s_) * LD1 + j * 32];
+#define SA_DW2_MMA(a_, b_) _Pragma("unroll") for (int j = 0; j < NBK; ++j) accW2[j] = MFMA(a_, b_[j], accW2[j]);
+            SA_DW2_LOAD(ap, bp, 0)
+#pragma unroll 1
+            for (int s = 0; s < TM / 2; s += 2) {
+                SA_DW2_LOAD(aq, bq, s + 1)
+                SA_DW2_MMA(ap, bp)
+                SA_DW2_LOAD(ap, bp, s + 2)          // last trip reads one row past this half: discarded
+                SA_DW2_MMA(aq, bq)
+            }
+#undef SA_DW2_LOAD
+#undef SA_DW2_MMA
+        }
+        // ---- P6: dH1 = dZ2 * W2 -> dZ1 = dH1 .* (1 - H1^2), in place of H1 ----------------------------
+        {
+            const int wn = wave % MH::NBW, wm = wave / MH::NBW;
+            f32x16 accH[MH::MB][MH::NB];
+            zero_acc<MH::MB, MH::NB>(accH);
+            mfma_stream<MH::MB, MH::NB, NGT>(D + (wm * MH::MB * 32 + li) * LD2 + lh * (C2 / 2), LD2,
+                                             P2Tv + (size_t)(wn * MH::NB) * NGT * 64 + lane, accH);
+            __syncthreads();
+#pragma unroll
+            for (int nb = 0; nb < MH::NB; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < MH::MB; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (wm * MH::MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int col = (wn * MH::NB + nb) * 32 + li;
+                        const float h = H1[row * LD1 + col];
+                        H1[row * LD1 + col] = accH[mb][nb][r] * (1.0f - h * h);
+                    }
+        }
+        __syncthreads();
+        // ---- P7: dW1[:, :3], db1, scatter dZ1 to the source points (live rows only) ---------------------
+        {
+            constexpr int PARTS = NT / C1, RPT = TM / PARTS;
+            const int c = tid % C1, p0 = (tid / C1) * RPT;
+            const int p1 = p0 + RPT < td.w ? p0 + RPT : td.w;
+#pragma unroll 4
+            for (int p = p0; p < p1; ++p) {
+                const float z = H1[p * LD1 + c];
+                const float4 x = *(const float4*)(Xz + p * 4);
+                accW1[0] = fmaf(z, x.x, accW1[0]);
+                accW1[1] = fmaf(z, x.y, accW1[1]);
+                accW1[2] = fmaf(z, x.z, accW1[2]);
+                accW1[3] += z;
+                if (a.dY) unsafeAtomicAdd(a.dY + (long)Src[p] * C1 + c, z);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- write this work-group's partial sums (layout of SaPart, reduced by sa_bwd_reduce_kernel) ----------------
+    float* part = a.parts + (size_t)blockIdx.x * P::N;
+    const int tid = tid0, wave = wave0, lh0 = lane0 >> 5, li0 = lane0 & 31;
+    const int w2_m = wave % (C2 / 32), w2_n0 = (wave / (C2 / 32)) * NBK;
+#pragma unroll
+    for (int j = 0; j < NBK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c2 = w2_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh0;
+            part[P::O_DW2 + c2 * C1 + (w2_n0 + j) * 32 + li0] = accW2[j][r];
+        }
+    {
+        const int s = tid & 127, ks = tid >> 7;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int c = (s < 64 ? 64 * q + s : C3 / 2 + 64 * q + (s - 64));
+#pragma unroll
+            for (int j = 0; j < KS; ++j) part[P::O_DW3 + c * C2 + ks * KS + j] = accW3[q][j];
+            if (ks == 0) part[P::O_DB3 + c] = accb3[q];
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int PARTS1 = NT / C1;
+        float* s2 = H1;                              // [M2::MW][C2]
+        float* s1 = H2;                              // [PARTS1][C1][4]
+        static_assert(M2::MW * C2 <= TM * LD1 && PARTS1 * C1 * 4 <= TM * LD2, "reduction scratch");
+        const int wn = wave % M2::NBW, wm = wave / M2::NBW;
+#pragma unroll
+        for (int nb = 0; nb < M2::NB; ++nb) {
+            const float v = accb2[nb] + __shfl_xor(accb2[nb], 32, 64);
+            if (lh0 == 0) s2[wm * C2 + (wn * M2::NB + nb) * 32 + li0] = v;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) s1[tid * 4 + d] = accW1[d];
+        __syncthreads();
+        if (tid < C2) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < M2::MW; ++q) s += s2[q * C2 + tid];
+            part[P::O_DB2 + tid] = s;
+        }
+        if (tid < C1 * 4) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS1; ++q) s += s1[q * C1 * 4 + tid];
+            part[P::O_DW1 + tid] = s;
+        }
+    }
+}
+
+extern "C" int pm_sa_bwd_packed_f32(const float* xyz, const float* centers, const float* Y, int B, int P, int S,
+                                    const int32_t* grow, const int32_t* rowmap, const int32_t* tiles, const int32_t* totals,
+                                    const float* W1, long ldw1, const float* b1, const float* b2, const float* W3,
+                                    const float* packed, int C1, int C2, int C3, const float* pooled, long ldp,
+                                    const int32_t* arg, const float* dpooled, long lddp, float* dW1, long lddw1, float* db1,
+                                    float* dW2, float* db2, float* dW3, float* db3, float* dY, const float* h2_saved,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(xyz && centers && grow && rowmap && tiles && totals && W1 && b1 && b2 && W3 && packed && pooled && arg && dpooled);
+    PM_REQUIRE(dW1 && db1 && dW2 && db2 && dW3 && db3 && workspace);
+    PM_REQUIRE(B > 0 && P > 0 && S > 0 && ldw1 >= 3 && lddw1 >= 3 && ldp >= C3 && lddp >= C3);
+    if (!pm_sa_supported(C1, C2, C3, SA_NS)) return PM_EUNSUPPORTED;
+    if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)tiles & 15) != 0) return PM_EALIGN;
+    if (workspace_bytes < pm_sa_bwd_workspace_bytes(C1, C2, C3)) return PM_EWORKSPACE;
+    SaArgs a = {};
+    a.xyz = xyz; a.centers = centers; a.Y = Y; a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.b2 = b2;
+    a.packed = packed; a.pooled = const_cast<float*>(pooled); a.ldp = ldp; a.arg = const_cast<int32_t*>(arg);
+    a.G = (long)B * S; a.S = S; a.P = P; a.W3 = W3; a.dpooled = dpooled; a.lddp = lddp; a.dY = dY;
+    a.parts = (float*)workspace;
+    a.h2 = const_cast<float*>(h2_saved);
+    SaPk k = {grow, (const int2*)rowmap, (const int4*)tiles, totals};
+    const int ncu = sa_cu_count();
+    if (SA_CFG_A(C1, C2, C3)) {
+        const long grid = sa_pk_grid(a.G, ncu, 3, SA_BWD_MAXGRID);
+        hipLaunchKernelGGL((sa_bwd_pk_kernel<64, 64, 128, 64, 4, 3, 20>), dim3((unsigned)grid), dim3(256), 0, pm_stream(stream), a, k);
+        constexpr int n = SaPart<64, 64, 128>::N;
+        hipLaunchKernelGGL((sa_bwd_reduce_kernel<64, 64, 128>), dim3((n + 255) / 256), dim3(256), 0, pm_stream(stream), a.parts,
+                           (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3);
+    } else {
+        const long grid = sa_pk_grid(a.G, ncu, 1, SA_BWD_MAXGRID);
+        hipLaunchKernelGGL((sa_bwd_pk_kernel<128, 128, 256, 128, 16, 4, 28>), dim3((unsigned)grid), dim3(1024), 0, pm_stream(stream), a, k);
+        constexpr int n = SaPart<128, 128, 256>::N;
+        hipLaunchKernelGGL((sa_bwd_reduce_kernel<128, 128, 256>), dim3((n + 255) / 256), dim3(256), 0, pm_stream(stream), a.parts,
+                           (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3);
+    }
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}

@@ -3,6 +3,8 @@
 PyTorch is plumbing here: it owns device memory and the HIP stream; every op below passes
 raw device pointers to libpartmanip_hip.so.  Ops refuse CPU tensors -- there is no CPU path.
 """
+import ctypes as C
+
 import torch
 
 from ._lib import lib, check
@@ -651,6 +653,85 @@ def sa_bwd(xyz, centers, idx, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpoo
                                 _rows(pooled, "pooled"), _ptr(arg), _ptr(dpooled), _rows(dpooled, "dpooled"), _ptr(dw1),
                                 _rows(dw1, "dw1"), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(dw3), _ptr(db3), _ptr(dY),
                                 _ptr(h2_saved), _ptr(w), w.numel(), _stream()), "pm_sa_bwd_f32")
+
+
+# ---- duplicate-free ("packed") form: the level over each group's DISTINCT rows (ball query pads with copies of the first hit)
+class SaPlan:
+    """Packed-row tables of one neighbourhood table (pm_sa_plan_i32): nothing here is read by the host."""
+    __slots__ = ("grow", "rowmap", "tiles", "totals", "B", "P", "S", "ns", "dims")
+
+    def counts(self):
+        """(packed rows, tiles) -- a host read; diagnostics / buffer sizing only."""
+        t = self.totals.cpu()
+        return int(t[0]), int(t[1])
+
+
+def sa_packed_tile(dims):
+    r, g = C.c_int(0), C.c_int(0)
+    check(lib.pm_sa_packed_tile(dims[0], dims[1], dims[2], C.byref(r), C.byref(g)), "pm_sa_packed_tile")
+    return r.value, g.value
+
+
+def sa_plan(idx, P, dims, ws):
+    """idx (B, S, 32) int32 ball-query table -> SaPlan for the fused level of shape `dims`."""
+    _req(idx)
+    B, S, ns = idx.shape
+    if idx.dtype != torch.int32 or not idx.is_contiguous():
+        raise TypeError("sa_plan: idx must be a contiguous int32 tensor")
+    tr, tg = sa_packed_tile(dims)
+    G = B * S
+    pl = SaPlan()
+    pl.B, pl.P, pl.S, pl.ns, pl.dims = B, P, S, ns, tuple(dims)
+    dev = idx.device
+    pl.grow = torch.empty(G + 1, dtype=torch.int32, device=dev)
+    pl.rowmap = torch.empty(G * ns, 2, dtype=torch.int32, device=dev)
+    pl.tiles = torch.empty(G, 4, dtype=torch.int32, device=dev)
+    pl.totals = torch.zeros(4, dtype=torch.int32, device=dev)
+    nb = int(lib.pm_sa_plan_workspace_bytes(B, S))
+    w = ws.get(nb + 16)
+    base = w.data_ptr()
+    al = (-base) % 16
+    with TIMER.bracket("sa_plan"):
+        check(lib.pm_sa_plan_i32(_ptr(idx), B, P, S, ns, tr, tg, _ptr(pl.grow), _ptr(pl.rowmap), _ptr(pl.tiles), _ptr(pl.totals),
+                                 base + al, w.numel() - al, _stream()), "pm_sa_plan_i32")
+    return pl
+
+
+def sa_fwd_packed(xyz, centers, plan, Y, w1, b1, b2, b3, packed, dims, pooled, h2_save=None):
+    _req(xyz, centers, Y, w1, packed, pooled)
+    B, P, _ = xyz.shape
+    S = centers.shape[1]
+    C1, C2, C3 = dims
+    if (B, P, S) != (plan.B, plan.P, plan.S) or tuple(dims) != plan.dims:
+        raise ValueError("sa_fwd_packed: the plan was built for another batch / level shape")
+    _f32c(xyz, "xyz")
+    _f32c(centers, "centers")
+    arg = torch.empty(B * S, C3, dtype=torch.int32, device=xyz.device)
+    with TIMER.bracket(f"sa_fwd_{C1}x{C2}x{C3}"):
+        check(lib.pm_sa_fwd_packed_f32(_ptr(xyz), _ptr(centers), _ptr(Y), B, P, S, _ptr(plan.grow), _ptr(plan.rowmap),
+                                       _ptr(plan.tiles), _ptr(plan.totals), _ptr(w1), _rows(w1, "w1"), _ptr(b1), _ptr(b2),
+                                       _ptr(b3), _ptr(packed), C1, C2, C3, _ptr(pooled), _rows(pooled, "pooled"), _ptr(arg),
+                                       _ptr(h2_save), _stream()), "pm_sa_fwd_packed_f32")
+    return arg
+
+
+def sa_bwd_packed(xyz, centers, plan, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpooled, dw1, db1, dw2, db2, dw3, db3, dY,
+                  ws, h2_saved=None):
+    _req(xyz, centers, Y, w1, w3, packed, pooled, arg, dpooled, dw1, dw2, dw3, dY)
+    B, P, _ = xyz.shape
+    S = centers.shape[1]
+    C1, C2, C3 = dims
+    if (B, P, S) != (plan.B, plan.P, plan.S) or tuple(dims) != plan.dims:
+        raise ValueError("sa_bwd_packed: the plan was built for another batch / level shape")
+    _f32c(w3, "w3")
+    w = ws.get(lib.pm_sa_bwd_workspace_bytes(C1, C2, C3))
+    with TIMER.bracket(f"sa_bwd_{C1}x{C2}x{C3}"):
+        check(lib.pm_sa_bwd_packed_f32(_ptr(xyz), _ptr(centers), _ptr(Y), B, P, S, _ptr(plan.grow), _ptr(plan.rowmap),
+                                       _ptr(plan.tiles), _ptr(plan.totals), _ptr(w1), _rows(w1, "w1"), _ptr(b1), _ptr(b2),
+                                       _ptr(w3), _ptr(packed), C1, C2, C3, _ptr(pooled), _rows(pooled, "pooled"), _ptr(arg),
+                                       _ptr(dpooled), _rows(dpooled, "dpooled"), _ptr(dw1), _rows(dw1, "dw1"), _ptr(db1),
+                                       _ptr(dw2), _ptr(db2), _ptr(dw3), _ptr(db3), _ptr(dY), _ptr(h2_saved), _ptr(w),
+                                       w.numel(), _stream()), "pm_sa_bwd_packed_f32")
 
 
 # ----------------------------------------------------------------------------- sparse-voxel U-Net blocks

@@ -705,6 +705,86 @@ def test_sa_kernels_are_invariant_to_neighbour_order_at_bench_size(dims, P, S, c
         assert float((y0 - y2).abs().max()) < 1e-5 * float(y0.abs().max())      # global fp32 atomics: order varies
 
 
+@pytest.mark.parametrize("dims,P,S,cf,radius", [((64, 64, 128), 1024, 256, 0, 0.2), ((128, 128, 256), 256, 64, 128, 0.4),
+                                                 ((64, 64, 128), 300, 40, 0, 5.0), ((128, 128, 256), 200, 24, 128, 0.05)])
+def test_sa_packed_rows_equal_the_dense_level(dims, P, S, cf, radius):
+    """The duplicate-free form of the fused level (pm_sa_plan_i32 + pm_sa_*_packed_f32) against the dense kernels on the
+    same neighbourhood table: the plan's tables against a numpy restatement (distinct rows per group = entries that
+    differ from entry 0, whole groups per tile, tile limits respected), pooled / arg / the saved layer 2 BIT-identical,
+    every gradient equal to fp32 summation order.  Radii: the benchmark's (3.9 / 5.4 distinct rows of 32), 5.0 (every
+    ball full: 32 distinct rows, the packed form degenerates to the dense one) and 0.05 (most balls hold the centre only)."""
+    o = ops()
+    B, (C1, C2, C3) = 37, dims
+    g = torch.Generator().manual_seed(P + cf + int(radius * 100))
+    xyz = (torch.rand(B, P, 3, generator=g) * 2 - 1).to(DEV)
+    ws = o.Workspace(torch.device(DEV))
+    idx_c = o.fps(xyz, S, ws)
+    centers = o.group_points(xyz, idx_c.view(B, S, 1)).view(B, S, 3).contiguous()
+    if radius < 0.1:
+        centers[:, 0] += 10.0                                  # empty balls: the row is all zeros (point 0, once)
+    idx = o.ball_query(xyz, centers, radius, 32)
+    plan = o.sa_plan(idx, P, dims, ws)
+    R_, T_ = plan.counts()
+    # ---- the plan against numpy
+    ii = idx.cpu().numpy().reshape(B * S, 32)
+    cnt = 1 + (ii[:, 1:] != ii[:, :1]).sum(1)
+    grow = np.concatenate([[0], np.cumsum(cnt)])
+    assert R_ == grow[-1] and np.array_equal(plan.grow.cpu().numpy(), grow)
+    rm = plan.rowmap.cpu().numpy()[:R_]
+    want_g = np.repeat(np.arange(B * S), cnt)
+    assert np.array_equal(rm[:, 1], want_g)
+    want_sp = np.concatenate([np.concatenate([r[:1], r[1:][r[1:] != r[0]]]) for r in ii]) + (want_g // S) * P
+    assert np.array_equal(rm[:, 0], want_sp)
+    tr, tg = o.sa_packed_tile(dims)
+    tl = plan.tiles.cpu().numpy()[:T_]
+    assert tl[0, 0] == 0 and tl[0, 1] == 0 and np.array_equal(tl[1:, 0], tl[:-1, 0] + tl[:-1, 3])
+    assert np.array_equal(tl[1:, 1], tl[:-1, 1] + tl[:-1, 2]) and tl[-1, 1] + tl[-1, 2] == B * S and tl[-1, 0] + tl[-1, 3] == R_
+    assert tl[:, 3].max() <= tr and tl[:, 2].max() <= tg and tl[:, 2].min() >= 1
+    assert np.array_equal(tl[:, 3], grow[tl[:, 1] + tl[:, 2]] - grow[tl[:, 1]])          # whole groups
+    assert np.all(tl[:, 1] // S == (tl[:, 1] + tl[:, 2] - 1) // S)                         # never across clouds
+    # ---- kernels
+    ldw1 = (3 + cf + 3) // 4 * 4
+    W1 = (torch.randn(C1, ldw1, generator=g) * 0.3).to(DEV)
+    W2 = (torch.randn(C2, C1, generator=g) / C1 ** 0.5).to(DEV)
+    W3 = (torch.randn(C3, C2, generator=g) / C2 ** 0.5).to(DEV)
+    b1, b2, b3 = ((torch.randn(c, generator=g) * 0.1).to(DEV) for c in dims)
+    packed = torch.empty(int(o.lib.pm_sa_packed_elems(*dims)), device=DEV)
+    o.sa_pack(W2, W3, packed)
+    Y = None
+    if cf:
+        feat = (torch.randn(B * P, cf, generator=g) * 0.5).to(DEV)
+        Y = torch.empty(B * P, C1, device=DEV)
+        o.linear_fwd(feat, W1[:, 3:3 + cf], None, Y, o.ACT_NONE)
+    dpooled = torch.randn(B * S, C3, generator=g).to(DEV)
+    out = {}
+    for mode in ("dense", "packed", "packed_recompute"):
+        pooled = torch.full((B * S, C3), float("nan"), device=DEV)
+        h2 = torch.zeros(B * S * 32, C2, device=DEV) if mode != "packed_recompute" else None
+        grads = [torch.full_like(t_, float("nan")) for t_ in (W1, b1, W2, b2, W3, b3)]
+        dY = torch.zeros(B * P, C1, device=DEV) if cf else None
+        if mode == "dense":
+            arg = o.sa_fwd(xyz, centers, idx, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
+            o.sa_bwd(xyz, centers, idx, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *grads, dY, ws, h2)
+        else:
+            arg = o.sa_fwd_packed(xyz, centers, plan, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
+            o.sa_bwd_packed(xyz, centers, plan, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *grads, dY, ws, h2)
+        out[mode] = (pooled, arg, h2, grads, dY)
+    pd, ad, hd, gd, yd = out["dense"]
+    for mode in ("packed", "packed_recompute"):
+        pp, ap, hp, gp, yp = out[mode]
+        assert torch.equal(pd, pp) and torch.equal(ad, ap), mode
+        if hp is not None:                                     # packed row r of group g = dense row g*32 + (r - grow[g])
+            dense_rows = torch.from_numpy(want_g * 32 + (np.arange(R_) - grow[want_g])).to(DEV)
+            assert torch.equal(hd[dense_rows], hp[:R_])
+        for k_, (x0, x1) in enumerate(zip(gd, gp)):
+            a_ = x0[:, :3] if k_ == 0 else x0                  # dW1: only the xyz columns are written by the kernels
+            b_ = x1[:, :3] if k_ == 0 else x1
+            scale = float(a_.abs().max()) + 1e-12
+            assert bool(torch.isfinite(b_).all()) and float((a_ - b_).abs().max()) < 2e-5 * scale, (mode, k_)
+        if cf:
+            assert float((yd - yp).abs().max()) < 1e-5 * float(yd.abs().max())
+
+
 def test_grouped_linear_ops_equal_the_single_problem_ops():
     """pm_linear_*_group_f32: several problems per launch, each bit-identical to its own single-problem launch; the
     split-K slabs of the grouped weight gradient add up (in slab order) to the single call's result to fp32 round-off."""

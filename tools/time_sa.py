@@ -34,18 +34,32 @@ for name, P, S, radius, dims, cf in LEVELS:
     import os
     h2 = torch.empty(B * S * 32, C2, device=DEV) if os.environ.get("SA_SAVE_H2", "1") == "1" else None
 
+    PACKED = os.environ.get("SA_PACKED", "1") == "1"       # duplicate-free rows (default) or the dense 32-row groups
+    plan = ops.sa_plan(idx_g, P, dims, ws) if PACKED else None
+
     def run(n):
         for _ in range(n):
-            arg = ops.sa_fwd(xyz, centers, idx_g, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
-            ops.sa_bwd(xyz, centers, idx_g, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws, h2)
+            if PACKED:
+                pl = ops.sa_plan(idx_g, P, dims, ws)
+                arg = ops.sa_fwd_packed(xyz, centers, pl, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
+                ops.sa_bwd_packed(xyz, centers, pl, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws, h2)
+            else:
+                arg = ops.sa_fwd(xyz, centers, idx_g, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
+                ops.sa_bwd(xyz, centers, idx_g, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws, h2)
     run(2)
     nf, nb = f"sa_fwd_{C1}x{C2}x{C3}", f"sa_bwd_{C1}x{C2}x{C3}"
-    ops.TIMER.enable(nf, nb)
+    ops.TIMER.enable(nf, nb, "sa_plan")
     run(5)
     f = ops.TIMER.mean_ms(nf)[0]
     b = ops.TIMER.mean_ms(nb)[0]
+    pt = ops.TIMER.mean_ms("sa_plan")[0] if PACKED else 0.0
     ops.TIMER.disable()
     rows = B * S * 32
+    if PACKED:
+        R_, T_ = plan.counts()
+        print(f"level {name}: plan {pt:.3f} ms, {R_} distinct rows of {rows} ({R_ / (B * S):.2f} per group), {T_} tiles "
+              f"({R_ / T_:.1f} rows per tile)")
+        rows = R_
     ff = 2.0 * rows * (C1 * C2 + C2 * C3) / 1e9                 # MFMA flops fwd
     fb = 2.0 * rows * ((2 if h2 is not None else 3) * C1 * C2 + C2 * C3) / 1e9   # [L2 recompute +] dW2 + dH1 + dH2
     print(f"level {name}: fwd {f:.3f} ms ({ff / f:.1f} TF)  bwd {b:.3f} ms ({fb / b:.1f} TF executed)")
