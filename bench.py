@@ -78,7 +78,8 @@ def cpu_baseline_ppo(w, rollout_cpu, sd_cpu, cfg):
     from oracle import ref_cpu as R
     ncpu = os.cpu_count() or 1
     vision = w["net"]["name"] in ("PointNet", "PointNet2")
-    mb, n_mb = (512, 3) if vision else (2048, 128)
+    pn2 = w["net"]["name"] == "PointNet2"                # its restatement samples / groups in Python loops: a smaller bounded sample
+    mb, n_mb = (64, 3) if pn2 else (512, 3) if vision else (2048, 128)
     T, N = w["T"], w["N"]
     keys = ("observations", "actions", "values", "returns", "actions_log_prob", "advantages", "mu", "sigma")
 
@@ -93,7 +94,7 @@ def cpu_baseline_ppo(w, rollout_cpu, sd_cpu, cfg):
         R.ppo_update(p, sample(mb_, n_), c, 1)          # n_ actor steps + n_ critic steps
         return time.perf_counter() - t0
 
-    used, tried = _pick_threads(lambda: run(32 if vision else 2048, 1), ncpu)
+    used, tried = _pick_threads(lambda: run(8 if pn2 else 32 if vision else 2048, 1), ncpu if not pn2 else min(ncpu, 32))
     gae = lambda: R.gae_returns(rollout_cpu["rewards_full"], rollout_cpu["values_full"], rollout_cpu["dones_full"],
                                 rollout_cpu["succs_full"], rollout_cpu["last_values"], 0.99, 0.95, None, False)
     gae()
@@ -239,10 +240,20 @@ def run_dagger(args, device, rank, world):
         # is data) and the up layers, whose un-pooled half runs on the COARSE rows (children summed first, linearity)
         dgrad = dict(macs, conv0=0, up1=R1 * c1 * c1 + R2 * c1 * c2, up0=R0 * c0 * c0 + R1 * c0 * c1)
         bfl = ffl + 2.0 * sum(dgrad.values())
+        # algorithmic HBM bytes of one forward + backward (every operand once: a layer reads its input rows, its table and
+        # writes its output; its backward reads dY, its own output (tanh'), the input again (weight gradient) and writes dX)
+        lay = [(R0, 4, 32, R0, c0), (R0, c0, 8, R1, c1), (R1, c1, 27, R1, c1), (R1, c1, 8, R2, c2), (R2, c2, 27, R2, c2),
+               (R1, c1 + c2, 3, R1, c1), (R0, c0 + c1, 3, R0, c0)]            # rows_in, C_in, table entries per output row, rows_out, C_out
+        fwd_b = sum(ri * ci * 4.0 + ro * (tb * 4.0 + co * 4.0) for ri, ci, tb, ro, co in lay) + R0 * c0 * 4.0
+        bwd_b = sum(ro * (2 * co * 4.0 + tb * 4.0) + 2 * ri * ci * 4.0 for ri, ci, tb, ro, co in lay) - R0 * 4 * 4.0
+        tr = _hbm_traffic(f"sparse_unet_{mb}_clouds_bytes_per_pass")[0]
         if t and b:
             tf = (ffl + bfl) / ((t[0] + b[0]) * 1e-3) / 1e12
             out["roofline"] = dict(bound="mfma", kernel="SparseUNet forward + backward (gemm2_dma_kernel with fused neighbour gathers)",
-                                   achieved=tf, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS, traffic=None,
+                                   achieved=tf, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS, traffic=tr,
+                                   algorithmic_bytes=fwd_b + bwd_b,
+                                   traffic_note="HBM bytes of one forward + backward of a mini-batch, ALL its kernels (PMC over "
+                                                f"tools/time_sparse_unet.py {mb}, profiles/hbm_traffic.json)",
                                    launches=t[1], fwd_mean_ms=t[0], bwd_mean_ms=b[0], level_rows=[R0, R1, R2],
                                    flops_fwd=ffl, flops_bwd=bfl,
                                    note="3^3 / strided convolutions and the up layers' [unpool | skip] operands are gathered inside the "
@@ -349,21 +360,30 @@ def run_depth2pc(args, device):
     big = nn > 8192
     streamed = torch.where(big, (chunk - 16384 - 8192).clamp(min=0) * G, nn.clamp(min=0) * 0).sum().item() if G >= 2 else float(nn[big].sum())
     pts = float(nn.sum().item())
-    nbytes = 1024.0 * streamed * 20.0 + pts * 12.0
-    gbs = nbytes / dfps / 1e9
+    impl_bytes = 1024.0 * streamed * 20.0 + pts * 12.0          # what THIS implementation moves: the streamed remainder, every round
+    algo_bytes = pts * 12.0 + b * 1024 * 4.0                      # the operator's own traffic: every candidate point once in, K indices out
+    gbs = algo_bytes / dfps / 1e9
+    # FPS is K = 1024 DEPENDENT rounds: round j's arg-max is round j + 1's reference point.  A round cannot be shorter than one
+    # hand-off between the cloud's work-groups (drained write-through store + flag sweep: MI355X_MICROARCH.md price list,
+    # "handoff-flag", 1.3 us on an idle chip) plus the dependent chain inside a work-group (distance update -> 6-step wave
+    # butterfly -> LDS pass over 16 waves -> barrier, ~0.5 us): that latency floor, not the HBM roofline, bounds the launch.
+    floor_us = 1.8
     out["roofline"] = dict(bound="hbm", kernel="fps_multi_kernel (on-chip chunks, streamed remainder)", achieved=gbs, peak=PEAK_HBM_GBS,
                            unit="GB/s", frac=gbs / PEAK_HBM_GBS, traffic=_hbm_traffic("fps_multi_kernel_bytes_per_launch")[0],
-                           traffic_note="HBM bytes of the launch from the committed PMC pass (profiles/hbm_traffic.json): the streamed "
-                                        "remainder is re-read every round out of L2 / Infinity Cache, so HBM sees far less than the "
-                                        "algorithmic bytes",
-                           mean_launch_ms=dfps * 1e3, bytes_per_launch=nbytes,
-                           us_per_round=dfps * 1e6 / 1024.0, points=pts, points_streamed_per_round=float(streamed),
-                           one_work_group_per_cloud_bytes=1024.0 * pts * 20.0,
-                           note="the kernel is bound by its K = 1024 DEPENDENT rounds (per round: ~33 distance updates per thread, a "
-                                "work-group arg-max, one hand-off between the cloud's work-groups) and by the remainder that does not fit "
-                                "on chip (256 CUs x 24 576 points = 6.3 M of this call's 8.6 M: `points_streamed_per_round`, served by "
-                                "L2 / Infinity Cache); `one_work_group_per_cloud_bytes` is what the round-2 streaming kernel moved per "
-                                "call (2.8 TB/s, 59 ms)")
+                           algorithmic_bytes=algo_bytes, mean_launch_ms=dfps * 1e3,
+                           latency=dict(rounds=1024, us_per_round=dfps * 1e6 / 1024.0, floor_us_per_round=floor_us,
+                                        frac_of_floor=floor_us / (dfps * 1e6 / 1024.0),
+                                        note="K dependent rounds; floor = one cross-work-group hand-off (1.3 us, MI355X_MICROARCH.md "
+                                             "'handoff-flag') + the in-work-group arg-max chain (~0.5 us)"),
+                           implementation=dict(streamed_bytes_per_launch=impl_bytes, streamed_gbs=impl_bytes / dfps / 1e9,
+                                               points=pts, points_streamed_per_round=float(streamed),
+                                               one_work_group_per_cloud_bytes=1024.0 * pts * 20.0,
+                                               note="points that fit neither the registers (16 384 per work-group) nor LDS (8 192) are "
+                                                    "re-read every round (12 B + the running minimum 4 B in, 4 B out), mostly out of L2 / "
+                                                    "Infinity Cache: `traffic` (PMC, HBM side) is what reaches memory"),
+                           note="`achieved` = the operator's algorithmic bytes (each candidate point once, K indices out) over the launch "
+                                "time: a latency-bound sampler sits far below the HBM roofline by construction -- `latency` is the bound "
+                                "that applies; `traffic` / `algorithmic_bytes` shows the re-reads of the streamed remainder")
     if not args.no_cpu_baseline:
         from oracle import ref_cpu as R
         ncpu = os.cpu_count() or 1
@@ -429,6 +449,35 @@ def _max_over_ranks(dt, device, world):
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     return float(tmax.item())
+
+
+def _dp_report(syncs, flats, dt_local, steps, device, world):
+    """Data-parallel evidence for a multi-GPU line: every rank's own wall time per step, the time its all-reduces took
+    (HIP events around each call on the issuing stream: partmanip_amd/dist.py GradSync.time_collectives), and an all-rank
+    equality check of the parameters after the last step -- replicas that start equal and exchange every gradient must END
+    equal, bit for bit; a silent divergence (a rank that skipped a collective, a different KL branch) fails the run here."""
+    comm, calls = 0.0, 0
+    for s_ in syncs:
+        ms, n = s_.comm_ms()
+        comm += ms
+        calls += n
+    mine = torch.tensor([dt_local / steps * 1e3, comm / steps, float(calls) / steps], device=device, dtype=torch.float64)
+    cs = torch.stack([t.detach().double().sum() for t in flats] +
+                     [t.detach().view(torch.int32).to(torch.int64).sum().double() for t in flats])
+    if world > 1:
+        allm = [torch.empty_like(mine) for _ in range(world)]
+        allc = [torch.empty_like(cs) for _ in range(world)]
+        torch.distributed.all_gather(allm, mine)
+        torch.distributed.all_gather(allc, cs)
+    else:
+        allm, allc = [mine], [cs]
+    equal = all(bool(torch.equal(allc[0], c)) for c in allc)
+    rep = dict(per_rank_ms_per_step=[float(m[0]) for m in allm], comm_ms_per_step=max(float(m[1]) for m in allm),
+               per_rank_comm_ms_per_step=[float(m[1]) for m in allm], all_reduces_per_step=float(allm[0][2]),
+               param_checksum_equal=equal, param_checksum=[float(x) for x in allc[0]])
+    if not equal:
+        raise RuntimeError(f"data-parallel replicas diverged: parameter checksums differ across ranks: {[c.tolist() for c in allc]}")
+    return rep
 
 
 def _hbm_traffic(key):
@@ -517,6 +566,9 @@ def run_ppo(args, device, rank, world):
 
     for _ in range(args.warmup):
         step()
+    syncs = list({id(x): x for x in (run.sync, getattr(run, "sync_c", None)) if x is not None}.values())
+    for s_ in syncs:
+        s_.time_collectives(True)
     timers = ["gae_scan"]
     if args.workload == "vision":
         timers += ["pointnet_enc_fwd", "pointnet_enc_bwd"]
@@ -530,9 +582,15 @@ def run_ppo(args, device, rank, world):
     fence()
     dt = time.perf_counter() - t0
     ops.TIMER.disable()
+    dt_local = dt
     dt = _max_over_ranks(dt, device, world)
     ms_per_step = dt / args.steps * 1e3
     value = w["N"] * w["T"] * world / (dt / args.steps)
+    dp = None
+    if world > 1 or syncs:
+        fl = ac.flat()
+        dp = _dp_report(syncs, [fl["actor"], fl["critic"]], dt_local, args.steps, device, world)
+        dp["graph_mode"] = run.dp_graph_mode if run.use_graphs else "eager (no hipGraph replay for this backbone)"
 
     vision = args.workload.startswith("vision")
     metric = ("PPO env-steps/sec (whole node), 4096 envs x 1024-pt clouds" if vision
@@ -545,13 +603,16 @@ def run_ppo(args, device, rank, world):
                            minibatch=2048, n_updates=5, parallelism=f"dp{world}", world_size_observed=_world_observed(),
                            backend=(torch.distributed.get_backend() if world > 1 else None),
                            train_scalars={k: float(v) for k, v in run.log_dict.items() if k.startswith("Train/")}))
+    if dp is not None:
+        out["config"]["data_parallel"] = dp
+        out["comm_ms_per_step"] = dp["comm_ms_per_step"]
     gae = ops.TIMER.mean_ms("gae_scan")
     gae_blk = None
     if gae:
         nbytes = 18.0 * w["T"] * w["N"]                    # r, V 8 B + 2 mask B in; ret, adv 8 B out
         # the iteration launches the scan ONCE, between host work: events around that single ~10 us launch mostly time
         # its dispatch.  The kernel's own rate is taken from 32 launches replayed from one hipGraph on scratch outputs.
-        k_ms = _gae_kernel_ms(run.storage)
+        k_ms = _gae_kernel_ms(run.storage) if not args.lean else gae[0]
         gae_blk = dict(kernel="gae_scan_kernel", bound="hbm", mean_launch_ms=k_ms, launches=32, bytes_per_launch=nbytes,
                        achieved_gbs=nbytes / (k_ms * 1e-3) / 1e9, frac=nbytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                        in_iteration_event_ms=gae[0], in_iteration_launches=gae[1],
@@ -596,20 +657,46 @@ def run_ppo(args, device, rank, world):
                      "per channel, layer 3 linear), so a backward EXECUTES 0.4 F instead of 2 F.  `frac` here is executed flops "
                      "/ wall / peak; survey_30F_useful_tflops (> peak) is the same wall time priced the survey's way")
     if args.workload == "vision_pn2":
-        # the four fused set-abstraction kernels; `achieved` counts the MFMA flops each launch EXECUTES
-        # (fwd: layers 2-3; bwd: dW2 + dH1 [+ dH2 where it is dense] -- layer 2 is loaded from what the forward saved)
-        kern = {}
-        for k, (c1, c2, c3, S) in SA_LEVELS.items():
-            rows = 2048.0 * S * 32
+        # the four fused set-abstraction kernels.  They run over each group's DISTINCT rows (ball query pads a short group with
+        # copies of its first hit, and a copy never wins the max-pool: DESIGN.md 3.4), so `achieved` counts the MFMA flops of
+        # the distinct rows of one 2048-cloud mini-batch -- fwd: layers 2-3; bwd: dH2 + dW2 + dH1 (layer 2 is loaded from what
+        # the forward saved) -- and `dense_equivalent_tflops` what the padded 32-row groups would have needed in the same time
+        net = ac.actor
+        tabs = net.precompute_geometry(st.observations.view(-1, w["O"])[:2048])
+        wsb = ops.Workspace(torch.device(device))
+        kern, lv = {}, {}
+        for l, (k, (c1, c2, c3, S)) in enumerate(SA_LEVELS.items()):
+            P_l = net.point_num if l == 0 else net.npoints[l - 1]
+            if getattr(net, "unique_rows", False):
+                R_, T_ = ops.sa_plan(tabs[l][1].contiguous(), P_l, (c1, c2, c3), wsb).counts()
+            else:
+                R_, T_ = 2048 * S * 32, 2048 * S * 32 // 64
+            dense = 2048.0 * S * 32
+            G_ = 2048.0 * S
+            lv[k] = dict(distinct_rows=R_, padded_rows=int(dense), rows_per_group=R_ / G_, tiles=T_)
+            yb = R_ * c1 * 4.0 if l > 0 else 0.0               # level 2 gathers / scatters the per-source-point layer-1 rows
+            algo = dict(fwd=R_ * (c2 * 4.0 + 8 + 12) + yb + G_ * c3 * 8.0,                    # h2 out, rowmap, xyz, pooled + arg out
+                        bwd=R_ * (c2 * 4.0 + 8 + 12) + 3 * yb + G_ * c3 * 12.0)               # h2 in, Y in, dY read-modify-write, pooled / dpooled / arg in
             for d_, macs in (("fwd", c1 * c2 + c2 * c3), ("bwd", 2 * c1 * c2 + c2 * c3)):
                 t = ops.TIMER.mean_ms(f"sa_{d_}_{k}")
                 if t:
-                    kern[f"sa_{d_}_{k}"] = dict(mean_launch_ms=t[0], launches=t[1], tflops=2 * rows * macs / (t[0] * 1e-3) / 1e12)
+                    tf = 2 * R_ * macs / (t[0] * 1e-3) / 1e12
+                    traffic = _hbm_traffic(f"sa_{d_}_{k}_bytes_per_launch")[0]
+                    kern[f"sa_{d_}_{k}"] = dict(mean_launch_ms=t[0], launches=t[1], tflops=tf, frac=tf / PEAK_F32_MFMA_TFLOPS,
+                                                dense_equivalent_tflops=2 * dense * macs / (t[0] * 1e-3) / 1e12,
+                                                algorithmic_bytes=algo[d_], traffic=traffic)
         if kern:
             name = max(kern, key=lambda n: kern[n]["mean_launch_ms"] * kern[n]["launches"])
             out["roofline"] = dict(bound="mfma", kernel=name, achieved=kern[name]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
-                                   unit="TFLOP/s", frac=kern[name]["tflops"] / PEAK_F32_MFMA_TFLOPS, traffic=None,
-                                   launches=kern[name]["launches"], mean_launch_ms=kern[name]["mean_launch_ms"], kernels=kern)
+                                   unit="TFLOP/s", frac=kern[name]["tflops"] / PEAK_F32_MFMA_TFLOPS, traffic=kern[name]["traffic"],
+                                   algorithmic_bytes=kern[name]["algorithmic_bytes"],
+                                   launches=kern[name]["launches"], mean_launch_ms=kern[name]["mean_launch_ms"], kernels=kern,
+                                   levels=lv, sa_kernels_ms_per_network_step=sum(v["mean_launch_ms"] for v in kern.values()),
+                                   note="flops = MFMA flops of the DISTINCT rows (no copy of a group's first hit is computed); "
+                                        "`dense_equivalent_tflops` prices the same launch at the padded 32 rows per group the "
+                                        "round-1..3 kernels executed (it may exceed the peak: that work is not done any more); the "
+                                        "distinct-row count is data dependent (`levels`): clouds whose balls hold >= 32 points fall "
+                                        "back to the dense cost (tests/test_gpu_kernels.py::test_sa_packed_rows_equal_the_dense_level)")
     if args.workload == "state":
         # 33.3 MFLOP of useful work per env-step (n_updates x 3 x (F_actor + F_critic)); the step is
         # 2 x 1280 dependent mini-batch updates of 2048 samples
@@ -617,11 +704,23 @@ def run_ppo(args, device, rank, world):
         hid = w["net"]["hid_dim"]
         per_env_step = 5 * 3 * (F([w["O"]] + hid + [w["A"]]) + F([w["O"]] + hid + [1]))
         tf = per_env_step * w["N"] * w["T"] / (dt / args.steps) / 1e12
+        # algorithmic HBM bytes of one iteration: GAE 18 B per env-step + the update's rollout reads (actor 340 B +
+        # critic 220 B per env-step and epoch) + per optimiser step the fused clip + Adam pass over each network's parameters
+        # (p, g, m, v in; p, m, v out = 28 B per parameter; they stay L2-resident between the 2560 steps, so HBM sees far less)
+        n_par = sum(a * b + b for a, b in zip([w["O"]] + hid, hid + [w["A"]])) + sum(a * b + b for a, b in zip([w["O"]] + hid, hid + [1]))
+        steps_it = cfg["n_updates"] * (w["N"] * w["T"] // 2048)
+        algo_roll = (18.0 + cfg["n_updates"] * (340.0 + 220.0)) * w["N"] * w["T"]
+        algo_opt = 28.0 * n_par * steps_it
         out["roofline"] = dict(bound="mfma", kernel="whole learner iteration (2 x 1280 dependent MLP mini-batch updates)",
                                achieved=tf, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
-                               traffic=None, flops_per_env_step=per_env_step,
+                               traffic=_hbm_traffic("state_iteration_bytes")[0], algorithmic_bytes=algo_roll + algo_opt,
+                               algorithmic_bytes_rollout=algo_roll, algorithmic_bytes_optimiser_state=algo_opt,
+                               traffic_note="HBM bytes of ONE iteration, all kernels (PMC FETCH_SIZE x 2 + WRITE_SIZE summed over every "
+                                            "launch of `bench.py --workload state --lean`, profiles/hbm_traffic.json); the optimiser-state "
+                                            "term of algorithmic_bytes is what the 2560 steps touch, almost all of it out of L2",
+                               flops_per_env_step=per_env_step,
                                note="algorithmic flops of the iteration / its wall time: every launch gap is inside")
-        if rank == 0:
+        if rank == 0 and not args.lean:
             # the dominant kernel on its own: a hidden layer (mini-batch x 512 x 512) on gemm2_dma_kernel, 32 dependent launches
             # replayed from a graph on the otherwise idle chip (in the iteration two networks' chains share it)
             Bm, H = 2048, hid[0]
@@ -716,8 +815,8 @@ def optional_paths(run, ac, w, step, fence):
 def _brief(line):
     """The part of a workload's line that the default line carries as a `secondary` entry."""
     r = line.get("roofline") or {}
-    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "fwd_mean_ms", "bwd_mean_ms", "level_rows", "flops_per_env_step",
-            "mean_launch_ms", "kernels")
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "fwd_mean_ms", "bwd_mean_ms",
+            "level_rows", "flops_per_env_step", "mean_launch_ms", "kernels", "levels", "latency", "traffic_note")
     out = dict(metric=line["metric"], value=line["value"], unit=line["unit"], steps=line["steps"], warmup=line["warmup"],
                ms_per_step=line["ms_per_step"], dtype=line["dtype"], workload=line["config"]["workload"],
                roofline={k: r[k] for k in keep if k in r})
@@ -743,8 +842,7 @@ def secondary_lines(args, device):
     import gc
     res = {}
     for key, kw in (("state", dict(workload="state")), ("dagger_sparse_unet", dict(workload="dagger", student="sparse_unet", points=4096)),
-                    # (its CPU baseline alone takes ~4 minutes of host time: `python bench.py --workload vision_pn2` reports it)
-                    ("vision_pn2", dict(workload="vision_pn2", no_cpu_baseline=True))):
+                    ("vision_pn2", dict(workload="vision_pn2")), ("depth2pc", dict(workload="depth2pc"))):
         a = copy.copy(args)
         a.steps, a.warmup, a.n_steps, a.precision = 3, 1, 0, "f32"
         for k, v in kw.items():
@@ -753,7 +851,8 @@ def secondary_lines(args, device):
         torch.cuda.empty_cache()
         t0 = time.perf_counter()
         try:
-            line = run_dagger(a, device, 0, 1) if a.workload == "dagger" else run_ppo(a, device, 0, 1)
+            line = (run_dagger(a, device, 0, 1) if a.workload == "dagger" else run_depth2pc(a, device) if a.workload == "depth2pc"
+                    else run_ppo(a, device, 0, 1))
             res[key] = _brief(line)
             res[key]["wall_s_incl_setup_and_cpu_baseline"] = time.perf_counter() - t0
         except Exception as e:                             # the headline line must survive a secondary's failure -- and say so
@@ -793,6 +892,7 @@ def main():
     ap.add_argument("--workload", default="vision", choices=list(WORKLOADS) + ["dagger", "depth2pc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optional", action="store_true", help="vision workload: skip the opt-in paths (profiling runs)")
+    ap.add_argument("--lean", action="store_true", help="profiling runs: only the timed iterations (no side measurements of single kernels)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default (vision) line on one GPU: skip the cfg 2 / cfg 5 sub-lines that the same run otherwise times")
     ap.add_argument("--n-steps", type=int, default=0, help="override the rollout length T (e.g. 128 for the vision workload)")
@@ -813,6 +913,12 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
+    if world > 1:
+        be = torch.distributed.get_backend()
+        if torch.distributed.get_world_size() != args.gpus or (be != "nccl" and not os.environ.get("PARTMANIP_DIST_BACKEND")):
+            print(f"bench.py: process group reports world {torch.distributed.get_world_size()} / backend {be}; a --gpus {args.gpus} "
+                  "line needs that many ranks over RCCL (backend nccl)", file=sys.stderr)
+            sys.exit(2)
     with contextlib.redirect_stdout(sys.stderr):           # the runners print progress lines: keep stdout = ONE JSON line
         if args.workload == "depth2pc":
             out = run_depth2pc(args, device) if rank == 0 else None

@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 141 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 143 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -73,6 +73,10 @@ int pm_gae_scan_f32(const float* rewards, const float* values, const uint8_t* do
 size_t pm_moments_workspace_bytes(long n);
 int pm_moments_f64(const float* x, long n, double* moments, void* workspace, size_t workspace_bytes, void* stream);
 int pm_normalize_apply_f32(float* x, long n, const double* moments, double count, float eps, void* stream);
+/* The single-process form in ONE call (the name SURVEY.md 8b lists): x <- (x - mean) / (std_unbiased + eps) over x's n
+ * elements = pm_moments_f64 + pm_normalize_apply_f32 with count = n.  Workspace (8-byte aligned): pm_adv_normalize_workspace_bytes. */
+size_t pm_adv_normalize_workspace_bytes(long n);
+int pm_adv_normalize_f32(float* x, long n, float eps, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ K3  mini-batch gather
  * ppo.py:317-324,361-364 / dagger.py:307-308: dst[i,:] = src[idx[i],:] for `sampler: random`
@@ -97,6 +101,17 @@ size_t pm_linear_bwd_weight_workspace_bytes(int M, int N, int K);
 int pm_linear_bwd_weight_f32(const float* dY, long lddy, const float* X, long ldx, float* dW, long lddw,
                              float* db, int M, int N, int K, void* workspace, size_t workspace_bytes,
                              void* stream);
+
+/* Whole-MLP forms (the names SURVEY.md 8b lists; network.py:27-54 `MLP`: activation after every layer but the last).  dims[0..
+ * n_layers] = layer widths; W, b, H, dW, db = HOST arrays of n_layers DEVICE pointers; H[l] (M, dims[l+1]) = output of layer l.
+ * They issue the per-layer entry points above in order on `stream` (same kernels, same bits); pm_mlp_bwd_f32 returns dW[l],
+ * db[l] (db or db[l] may be NULL) and, when dX != NULL, the input gradient (M, dims[0]).  Workspace 16-byte aligned. */
+int pm_mlp_fwd_f32(const float* X, long ldx, int M, int n_layers, const int* dims, const float* const* W, const float* const* b,
+                   int act, float* const* H, void* stream);
+size_t pm_mlp_bwd_workspace_bytes(int M, int n_layers, const int* dims);
+int pm_mlp_bwd_f32(const float* X, long ldx, int M, int n_layers, const int* dims, const float* const* W, const float* const* H,
+                   int act, const float* dY, float* const* dW, float* const* db, float* dX, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* Grouped forms (new; the reference runs one ATen GEMM per layer per network): up to PM_LINEAR_GROUP_MAX independent
  * problems of the SAME kind in ONE launch.  The small-step regime (state PPO, ppo.py:315-384: 2560 dependent optimiser
@@ -376,13 +391,18 @@ int pm_depth_backproject_f32(const float* depth, int B, int M, int H, int W, con
  * (no -1 padding: once every point is taken the lowest index repeats, as on the full cloud); workspace
  * B*ld floats when ld > 8192. */
 int pm_depth_compact_f32(const float* xyz, int B, int P, float* out, int32_t* lengths, void* stream);
-size_t pm_fps_varlen_workspace_bytes(int B, int ld); /* 0 when every cloud fits in registers (ld <= 8192); with it (8-byte aligned) camera-sized
-                                                      * xyz clouds run on several work-groups per cloud, each keeping its chunk on chip;
-                                                      * its last 8 bytes are then cleared by every call and set non-zero when a work-group
-                                                      * gave up waiting for its partners (bounded spin): read them after the call.
-                                                      * The partners wait for each other INSIDE the launch: other kernels on the device only
-                                                      * delay it (their work-groups drain), but two such launches running concurrently on
-                                                      * two streams can hold each other's CUs -- issue them from one stream */
+/* Workspace: 0 when every cloud fits in registers (ld <= 8192).  With the full reservation (8-byte aligned) camera-sized xyz
+ * clouds run on pm_fps_varlen_groups(B, ld, D) >= 2 work-groups per cloud, each keeping its chunk on chip; the partners of a
+ * cloud wait for each other INSIDE the launch, with ONE bounded poll budget per work-group and launch (~1 s; PM_FPS_SPIN_LIMIT).
+ * A work-group that exhausts it gives up ONCE: it latches the flag, sets the reservation's last 8 bytes (which every other
+ * work-group of the launch watches and follows) and returns; the call then DEGRADES on the device: a launch queued behind it
+ * re-samples the batch's big clouds on one work-group each when -- and only when -- that word is set (no host round trip, the
+ * indices are valid either way; the word stays set for diagnostics until the next multi-work-group call clears it).  Other
+ * kernels on the device only delay the hand-offs (their work-groups drain); two such launches running concurrently on two
+ * streams can hold each other's CUs until the budget trips -- issue them from one stream, or cap the group count (PM_FPS_MAXG,
+ * 0 / 1 = one work-group per cloud) when CUs are masked or shared. */
+size_t pm_fps_varlen_workspace_bytes(int B, int ld);
+int pm_fps_varlen_groups(int B, int ld, int D);
 int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths,
                       int pad /* 1: pytorch3d semantics, -1 once a cloud is exhausted; 0: keep sampling (see above) */,
                       int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream);

@@ -402,6 +402,14 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+class _GeomTabs(list):
+    """Per-level (centres, neighbour index) tables of a rollout + the packed-row plans of the mini-batch slices taken from it."""
+
+    def __init__(self, it=()):
+        super().__init__(it)
+        self.plans = {}
+
+
 class PointNet2(_HipNet):
     """PointNet++ (single-scale grouping) encoder as a backbone plug-in (`network.name: PointNet2`).
 
@@ -477,7 +485,7 @@ class PointNet2(_HipNet):
             ch.grads = [(views[f"sa.{l}.{2 * i}.weight"], views[f"sa.{l}.{2 * i}.bias"]) for i in range(len(ch.linears))]
         self._head.grads = [(views[f"final_mlp.{i}.weight"], views[f"final_mlp.{i}.bias"]) for i in (0, 2, 4)]
 
-    def _sa_forward_fused(self, l, xyz, feat, centers, idx_g, pooled):
+    def _sa_forward_fused(self, l, xyz, feat, centers, idx_g, pooled, plan_slot=None):
         """One fused SA level.  Layer 1's feature part is applied per SOURCE point (Y) by the Linear kernel."""
         B, Pl = xyz.shape[0], xyz.shape[1]
         lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
@@ -501,7 +509,12 @@ class PointNet2(_HipNet):
             h2 = buf[:n]
         plan = None
         if self.unique_rows:
-            plan = ops.sa_plan(idx_g, Pl, dims, self._workspace(xyz.device))
+            cache, key = plan_slot if plan_slot is not None else (None, None)
+            plan = cache.get(key) if cache is not None else None
+            if plan is None:
+                plan = ops.sa_plan(idx_g, Pl, dims, self._workspace(xyz.device))
+                if cache is not None:                      # a sequential mini-batch of a cached rollout: both networks and
+                    cache[key] = plan.trim()               # every epoch reuse it (one host read of the row / tile counts)
             arg = ops.sa_fwd_packed(xyz, centers, plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
                                     packed, dims, pooled, h2)
         else:
@@ -543,9 +556,9 @@ class PointNet2(_HipNet):
         """obs (M, O) -> [(centres (M,S_l,3) f32, idx (M,S_l,ns_l) i32) per SA level] for use_geometry()."""
         M, P, C = obs.shape[0], self.point_num, self.in_channels
         ws = self._workspace(obs.device)
-        tabs = [(torch.empty(M, S, 3, device=obs.device),
-                 torch.empty(M, S, self.nsamples[l], dtype=torch.int32, device=obs.device))
-                for l, S in enumerate(self.npoints)]
+        tabs = _GeomTabs((torch.empty(M, S, 3, device=obs.device),
+                          torch.empty(M, S, self.nsamples[l], dtype=torch.int32, device=obs.device))
+                         for l, S in enumerate(self.npoints))
         for lo in range(0, M, chunk):
             x = obs[lo:lo + chunk]
             b = x.shape[0]
@@ -560,12 +573,13 @@ class PointNet2(_HipNet):
 
     def use_geometry(self, tabs, rows):
         """Take the next forward's neighbourhood tables from `tabs`: rows = (lo, n) slice or an index tensor."""
+        plans = getattr(tabs, "plans", None)
         if isinstance(rows, tuple):
             lo, n = rows
-            sel = [(c[lo:lo + n], i[lo:lo + n]) for c, i in tabs]
+            sel = [(c[lo:lo + n], i[lo:lo + n], None if plans is None else (plans, (l, lo, n))) for l, (c, i) in enumerate(tabs)]
         else:
             r = rows.to(tabs[0][0].device, non_blocking=True)
-            sel = [(c.index_select(0, r), i.index_select(0, r)) for c, i in tabs]
+            sel = [(c.index_select(0, r), i.index_select(0, r), None) for c, i in tabs]
         object.__setattr__(self, "_geom_next", sel)
 
     def forward(self, x):                 # rollout / eval inference: nothing is kept for a backward
@@ -585,15 +599,16 @@ class PointNet2(_HipNet):
             raise ValueError("use_geometry(): table rows do not match the batch")
         saved = []
         for l, S in enumerate(self.npoints):
+            plan_slot = None
             if geom is not None:
-                centers, idx_g = geom[l]
+                centers, idx_g, plan_slot = geom[l]
             else:
                 idx_c = ops.fps(xyz, S, ws)
                 centers = ops.group_points(xyz, idx_c.view(B, S, 1)).view(B, S, 3)
                 idx_g = ops.ball_query(xyz, centers, self.radii[l], self.nsamples[l])
             if self._fused[l]:
                 pooled = torch.empty(B * S, self.sa[l][4].out_features, device=x.device)
-                saved.append(self._sa_forward_fused(l, xyz, feat, centers, idx_g, pooled))
+                saved.append(self._sa_forward_fused(l, xyz, feat, centers, idx_g, pooled, plan_slot))
                 xyz, feat = centers, pooled.view(B, S, -1)
                 continue
             ldo = self.sa[l][0].in_features

@@ -15,6 +15,7 @@ Differences that are deliberate and semantics-preserving:
   * sequential mini-batches are zero-copy slices of the (T*N, D) views.
 """
 import os
+import sys
 import time
 from copy import deepcopy
 from os.path import join as pjoin
@@ -119,8 +120,11 @@ class ppo:
         if self.sync is not None:
             be = torch.distributed.get_backend()
             self.dp_graph_mode = os.environ.get("PARTMANIP_DP_GRAPHS") or ("capture" if be == "nccl" else "split")
-            if self.dp_graph_mode not in ("capture", "split") or self.tricks['mini_adv_norm'] or self.tricks['use_clipped_value_loss']:
+            if self.dp_graph_mode not in ("capture", "split") or self.tricks['mini_adv_norm'] or self.tricks['use_clipped_value_loss'] \
+                    or os.environ.get("PARTMANIP_SOLO_GROUP", "1") != "1":    # the pre / post split exists for the grouped step only
                 self.use_graphs, self.dp_graph_mode = False, None
+            if not self.use_graphs:
+                self.dp_graph_mode = None
             # actor and critic steps run on two streams: give the critic's all-reduces their own communicator, so that two
             # concurrently replayed graphs never interleave collectives of ONE communicator in rank-dependent order
             self.sync_c = pdist.GradSync(group=torch.distributed.new_group()) if self.overlap else self.sync
@@ -466,11 +470,26 @@ class ppo:
                 fn()
             else:
                 # capture needs a non-default stream; replay may use any stream (the actor's is the default one)
+                if graphs.get('broken'):                       # an earlier capture failed: the rest of the run is eager
+                    fn()
+                    return
                 cap = self._side if stream is not self._side else self._cap
                 cap.wait_stream(stream)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=graphs['pool'][k[0]], stream=cap):
+                try:
+                    with torch.cuda.graph(g, pool=graphs['pool'][k[0]], stream=cap):
+                        if os.environ.get("PARTMANIP_TEST_CAPTURE_FAIL") == "1":
+                            raise RuntimeError("PARTMANIP_TEST_CAPTURE_FAIL")
+                        fn()
+                except Exception as e:                         # e.g. a collective that cannot be captured on this stack
+                    # nothing of the step has executed (capture only records): run it eagerly and stop capturing.  Graphs
+                    # captured before stay valid.  Every rank takes this branch together (same software, same step).
+                    graphs['broken'] = True
+                    self.dp_graph_mode = f"eager ({self.dp_graph_mode or 'graphs'}: capture failed: {type(e).__name__}: {str(e)[:120]})"
+                    print(f"[ppo] hipGraph capture of step {k[:2]} failed, continuing eagerly: {e}", file=sys.stderr)
+                    stream.wait_stream(cap)
                     fn()
+                    return
                 stream.wait_stream(cap)
                 graphs[k] = g
                 g.replay()

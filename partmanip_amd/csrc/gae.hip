@@ -201,6 +201,21 @@ extern "C" int pm_normalize_apply_f32(float* x, long n, const double* moments, d
     return PM_OK;
 }
 
+// SURVEY.md 8(b) names this entry point: the single-process form of storage.py:114 / ppo.py:329 in one call --
+// x <- (x - mean(x)) / (std_unbiased(x) + eps) -- i.e. pm_moments_f64 + pm_normalize_apply_f32 with count = n (data-parallel
+// callers use the two halves and all-reduce the moments between them).  The two doubles live at the end of the workspace.
+extern "C" size_t pm_adv_normalize_workspace_bytes(long n) { return pm_moments_workspace_bytes(n) + 2 * sizeof(double); }
+
+extern "C" int pm_adv_normalize_f32(float* x, long n, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(x && n > 1);
+    if (!workspace || workspace_bytes < pm_adv_normalize_workspace_bytes(n)) return PM_EWORKSPACE;
+    if ((uintptr_t)workspace & 7) return PM_EALIGN;
+    double* mom = (double*)((char*)workspace + pm_moments_workspace_bytes(n));
+    const int rc = pm_moments_f64(x, n, mom, workspace, pm_moments_workspace_bytes(n), stream);
+    if (rc != PM_OK) return rc;
+    return pm_normalize_apply_f32(x, n, mom, (double)n, eps, stream);
+}
+
 // ---------------------------------------------------------------------------------- K3
 // dst[i,:] = src[idx[i],:].  One wave per row chunk; float4 when rows are 16 B aligned.
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src,

@@ -711,6 +711,10 @@ __global__ __launch_bounds__(512) void gemm2_chain_kernel(Gemm2Chain ch) {
         const g2_u64 per_launch = (g2_u64)ch.G * (g2_u64)(ch.n - 1);
         const g2_u64 v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_base = v - v % per_launch;
+        // a launch that was aborted half-way (device error, killed process sharing the workspace) leaves the counter off a
+        // launch boundary: what this work-group reads must be boundary + (< G arrivals of this launch's first barrier).  If not,
+        // say so in the error word (the host re-zeroes the counters when it sees it) instead of passing barriers early.
+        if (v % per_launch >= (g2_u64)ch.G) __hip_atomic_store(err, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const g2_u64 base = s_base;

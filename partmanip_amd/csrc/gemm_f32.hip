@@ -209,6 +209,77 @@ extern "C" int pm_linear_bwd_weight_f32(const float* dY, long lddy, const float*
 }
 
 // ---- grouped forms: several problems of one kind in ONE launch (include/partmanip_hip.h) -----------------------------
+// ---- whole-MLP forms (SURVEY.md 8(b) names pm_mlp_fwd_f32 / pm_mlp_bwd_f32) ------------------------------------------------
+// network.py:27-54 `MLP`: n_layers Linear layers, the activation after every layer but the last.  dims[0..n_layers] are the
+// layer widths (dims[0] = input features); W / b / H / dW / db are HOST arrays of n_layers DEVICE pointers; H[l] is the
+// (M, dims[l+1]) output of layer l (H[n_layers-1] = the network output).  These are the per-layer entry points above, issued
+// in order on one stream: same kernels, same bits -- the learner itself uses the grouped / fused-head forms.
+extern "C" int pm_mlp_fwd_f32(const float* X, long ldx, int M, int n_layers, const int* dims, const float* const* W,
+                              const float* const* b, int act, float* const* H, void* stream) {
+    PM_REQUIRE(X && dims && W && H && M > 0 && n_layers > 0 && n_layers <= 64);
+    const float* in = X;
+    long ldin = ldx;
+    for (int l = 0; l < n_layers; ++l) {
+        PM_REQUIRE(W[l] && H[l] && dims[l] > 0 && dims[l + 1] > 0);
+        const int rc = pm_linear_fwd_f32(in, ldin, W[l], dims[l], b ? b[l] : nullptr, H[l], dims[l + 1], M, dims[l + 1], dims[l],
+                                         l + 1 < n_layers ? act : PM_ACT_NONE, stream);
+        if (rc != PM_OK) return rc;
+        in = H[l];
+        ldin = dims[l + 1];
+    }
+    return PM_OK;
+}
+
+static size_t mlp_bwd_scratch_elems(int M, int n_layers, const int* dims) {
+    int mx = 0;
+    for (int l = 1; l < n_layers; ++l) mx = dims[l] > mx ? dims[l] : mx;      // hidden widths: dz ping-pong buffers
+    return ((size_t)M * mx + 3) / 4 * 4;
+}
+
+extern "C" size_t pm_mlp_bwd_workspace_bytes(int M, int n_layers, const int* dims) {
+    if (!dims || M <= 0 || n_layers <= 0) return 0;
+    size_t ww = 16;
+    for (int l = 0; l < n_layers; ++l) {
+        const size_t w = pm_linear_bwd_weight_workspace_bytes(M, dims[l + 1], dims[l]);
+        ww = w > ww ? w : ww;
+    }
+    return 2 * mlp_bwd_scratch_elems(M, n_layers, dims) * sizeof(float) + ((ww + 15) & ~(size_t)15);
+}
+
+// dY (M, dims[n_layers]) = d loss / d output -> dW[l] (dims[l+1], dims[l]), db[l] (may be NULL per layer or as a whole) and,
+// if dX != NULL, d loss / d input (M, dims[0]).  X / H as passed to (returned by) pm_mlp_fwd_f32.
+extern "C" int pm_mlp_bwd_f32(const float* X, long ldx, int M, int n_layers, const int* dims, const float* const* W,
+                              const float* const* H, int act, const float* dY, float* const* dW, float* const* db, float* dX,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(X && dims && W && H && dY && dW && M > 0 && n_layers > 0 && n_layers <= 64);
+    if (!workspace || workspace_bytes < pm_mlp_bwd_workspace_bytes(M, n_layers, dims)) return PM_EWORKSPACE;
+    if ((uintptr_t)workspace & 15) return PM_EALIGN;
+    const size_t se = mlp_bwd_scratch_elems(M, n_layers, dims);
+    float* dz[2] = {(float*)workspace, (float*)workspace + se};
+    void* wws = (float*)workspace + 2 * se;
+    const size_t wwb = workspace_bytes - 2 * se * sizeof(float);
+    const float* cur = dY;
+    for (int l = n_layers - 1; l >= 0; --l) {
+        const float* in = l ? H[l - 1] : X;
+        const long ldin = l ? dims[l] : ldx;
+        PM_REQUIRE(W[l] && dW[l]);
+        int rc = pm_linear_bwd_weight_f32(cur, dims[l + 1], in, ldin, dW[l], dims[l], db ? db[l] : nullptr, M, dims[l + 1], dims[l],
+                                          wws, wwb, stream);
+        if (rc != PM_OK) return rc;
+        if (l > 0) {                                       // through the layer and the activation that produced its input
+            float* nxt = dz[l & 1];
+            rc = pm_linear_bwd_data_f32(cur, dims[l + 1], W[l], dims[l], H[l - 1], dims[l], nxt, dims[l], M, dims[l + 1], dims[l], act,
+                                        stream);
+            if (rc != PM_OK) return rc;
+            cur = nxt;
+        } else if (dX) {
+            rc = pm_linear_bwd_data_f32(cur, dims[1], W[0], dims[0], nullptr, 0, dX, dims[0], M, dims[1], dims[0], PM_ACT_NONE, stream);
+            if (rc != PM_OK) return rc;
+        }
+    }
+    return PM_OK;
+}
+
 extern "C" int pm_linear_fwd_group_f32(int n, const pm_linear_fwd_desc* d, void* stream) {
     PM_REQUIRE(d && n >= 1 && n <= PM_LINEAR_GROUP_MAX);
     Gemm2Group gg{};

@@ -293,6 +293,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
                         vmax[nb] = v;
                         imax[nb] = p;
                     }
+                    if constexpr (!TANH) {               // unbounded activations: track a NaN explicitly (see the epilogue)
+                        if (v != v && vmax[nb] == vmax[nb]) {       // the FIRST NaN sticks: no later `>` is true against it
+                            vmax[nb] = v;
+                            imax[nb] = p;
+                        }
+                    }
                     vsum[nb] += v;
                 }
         // Training forward: the H2 tile (still intact in LDS) also goes to HBM, 1 KB rows, so that the backward
@@ -319,14 +325,22 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
         const float os = __shfl_xor(vsum[nb], 32, 64);
         float v = vmax[nb];
         int i = imax[nb];
-        if (ov > v || (ov == v && oi < i)) {
+        if (!TANH && (ov != ov || v != v)) {        // a NaN in either half: torch.max returns NaN and the index of the first one
+            if (ov != ov && (v == v || oi < i)) {
+                v = ov;
+                i = oi;
+            }
+        } else if (ov > v || (ov == v && oi < i)) {
             v = ov;
             i = oi;
         }
         if (lh == 0) {
             const int ch = (wave * NB3 + nb) * 32 + li;
             const float sm = vsum[nb] + os;
-            if (sm != sm) v = sm;                 // a NaN anywhere in the channel's column: torch.max returns NaN (the strict > above skips it)
+            // tanh: |h| <= 1, so the column sum is NaN exactly when the column holds a NaN (no overflow, no inf - inf) and the
+            // strict > above skipped it: torch.max returns NaN.  Other activations are unbounded (a column with +inf and -inf
+            // sums to NaN without holding one): they track the NaN itself, and its first index, above.
+            if (TANH && sm != sm) v = sm;
             feat[(long)b * ldf + ch] = v;
             if (max_mean) feat[(long)b * ldf + PN_C3 + ch] = sm / (float)P;
             argmax[(long)b * PN_C3 + ch] = i;

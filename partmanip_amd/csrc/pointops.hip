@@ -3,6 +3,7 @@
 // expression ((dx*dx)+dy*dy)+dz*dz with no FMA contraction, same tie-breaks).
 // The reference tree holds no implementation of these: parity unpinned.
 #include "common.h"
+#include <stdlib.h>
 
 #define FPS_NT 1024
 #define FPS_MAXD 4
@@ -133,12 +134,18 @@ __global__ __launch_bounds__(FPS_NT) void fps_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(FPS_NT) void fps_varlen_kernel(const float* __restrict__ xyz, int ld, int D, int K,
                                                              const int32_t* __restrict__ lengths, int pad,
                                                              int32_t* __restrict__ idx_out,
-                                                             float* __restrict__ mind_ws, int small_only) {
+                                                             float* __restrict__ mind_ws, int mode,
+                                                             const unsigned long long* __restrict__ gave_up) {
     __shared__ float sv[FPS_NT / 64];
     __shared__ int si[FPS_NT / 64];
     __shared__ float sel[FPS_MAXD];
     const int b = blockIdx.x, n = lengths[b];
-    if (small_only && n > FPS_NT * FPS_RPT) return;      // (fps_multi_kernel samples the big clouds of this batch)
+    // mode 0: every cloud.  mode 1: the clouds that fit one work-group's registers (fps_multi_kernel samples the big ones of
+    // this batch).  mode 2: the big clouds, and only if the multi-work-group launch in front of this one GAVE UP (its error
+    // word is set): the batch degrades to the one-work-group streaming sampler instead of returning invalid indices -- no host
+    // round trip; in the normal case this launch returns at once.
+    if (mode == 1 && n > FPS_NT * FPS_RPT) return;
+    if (mode == 2 && (n <= FPS_NT * FPS_RPT || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull)) return;
     const float* pts = xyz + (long)b * ld * D;
     int32_t* idx_b = idx_out + (long)b * K;
     if (n <= 0) {                                        // empty cloud: pytorch3d yields -1 everywhere
@@ -523,17 +530,21 @@ extern "C" int pm_version(void) { return PM_ABI_VERSION; }
 #endif                        // 20: 12.1, 24: 15.1 -- beyond 16 the 4 x FM_RPT point registers spill (128-VGPR budget at 1024 threads)
 #define FM_LDS 8192
 #define FM_MAXG 8
-#define FM_SPIN_LIMIT (1u << 22)
+#define FM_SPIN_LIMIT (1u << 20)   // polls a work-group may spend waiting for partners over the WHOLE launch (~1 s); normal: a few thousand
 typedef unsigned long long fm_u64;
 template <bool PAD>
 __global__ __launch_bounds__(FPS_NT) void fps_multi_kernel(const float* __restrict__ xyz, int ld, int K,
                                                             const int32_t* __restrict__ lengths, int32_t* __restrict__ idx_out,
-                                                            float* __restrict__ mind_ws, fm_u64* __restrict__ slots, int G) {
+                                                            float* __restrict__ mind_ws, fm_u64* __restrict__ slots, int G,
+                                                            unsigned spin_limit) {
     extern __shared__ __attribute__((aligned(16))) float fm_lds[];           // [FM_LDS][4]: x, y, z, min-distance
     __shared__ float sv[FPS_NT / 64];
     __shared__ int si[FPS_NT / 64];
     __shared__ float sel[4];
     __shared__ int s_cur;
+    __shared__ int s_dead;                               // latched give-up: the whole work-group leaves at the end of the round
+    if (threadIdx.x == 0) s_dead = 0;
+    unsigned spent = 0;                                  // polls spent waiting, CUMULATIVE over the launch (one budget, not one per round)
     const int b = blockIdx.x / G, g = blockIdx.x - b * G, tid = threadIdx.x;
     const int n = lengths[b];
     const float* pts = xyz + (long)b * ld * 3;
@@ -633,12 +644,19 @@ __global__ __launch_bounds__(FPS_NT) void fps_multi_kernel(const float* __restri
                 __hip_atomic_store(my + 1, tag | (fm_u64)(unsigned)wbi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             fm_u64 x = 0;
-            unsigned spins = 0;
             for (;;) {
                 x = tid < 2 * G ? __hip_atomic_load(cloud + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
                 if (__all((x >> 32) == (tag >> 32))) break;
-                if (++spins > FM_SPIN_LIMIT) {           // a partner is not resident / has died: give up loudly, do not hang the GPU
-                    if (tid == 0) __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // A partner is not resident / has given up: give up too, ONCE -- the flag is latched for the work-group and the
+                // error word tells every other work-group of the launch (they look at it every 64 polls) and the fallback launch
+                // behind this one (fps_varlen_kernel mode 2), which re-samples the batch's big clouds on one work-group each.
+                ++spent;
+                const bool told = (spent & 63u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+                if (spent > spin_limit || told) {
+                    if (tid == 0) {
+                        __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_dead = 1;
+                    }
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -657,6 +675,7 @@ __global__ __launch_bounds__(FPS_NT) void fps_multi_kernel(const float* __restri
             if (tid == 0) s_cur = ci;
         }
         __syncthreads();
+        if (s_dead) return;                              // gave up: no further sweeps, no further spinning (the fallback launch re-samples)
         cur = s_cur;
     }
 }
@@ -668,37 +687,62 @@ extern "C" size_t pm_fps_varlen_workspace_bytes(int B, int ld) {
     return mind + (mind ? (size_t)(4 * 256 + 1) * sizeof(fm_u64) : 0);
 }
 
+static int fps_cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+        if (n > 256) n = 256;
+    }
+    return n;
+}
+
+// Work-groups per cloud of the multi-work-group sampler for a (B, ld, D) batch; < 2: the one-work-group kernels run.
+// PM_FPS_MAXG caps it (0 / 1 switches the multi-work-group path off, e.g. when the caller masks CUs or shares the device
+// with another long-running launch: the partners of a cloud must all be resident).
+extern "C" int pm_fps_varlen_groups(int B, int ld, int D) {
+    if (B <= 0 || D != 3 || ld <= FPS_NT * FPS_RPT) return 1;
+    int G = fps_cu_count() / B;
+    if (G > FM_MAXG) G = FM_MAXG;
+    const char* e = getenv("PM_FPS_MAXG");
+    if (e && atoi(e) < G) G = atoi(e);
+    return G < 1 ? 1 : G;
+}
+
 extern "C" int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths, int pad,
                                  int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream) {
     PM_REQUIRE(xyz && lengths && idx_out && B > 0 && ld > 0 && D >= 1 && D <= FPS_MAXD && K > 0);
     if (ld > FPS_NT * FPS_RPT && (!workspace || workspace_bytes < (size_t)B * ld * sizeof(float))) return PM_EWORKSPACE;
     // several work-groups per cloud: xyz clouds, few enough clouds that G >= 2 work-groups each are all resident (one
     // 1024-thread work-group of 128 VGPRs per CU), and the caller handed over the larger workspace
-    int ncu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    if (ncu > 256) ncu = 256;
-    int G = ncu / B;
-    if (G > FM_MAXG) G = FM_MAXG;
+    const int G = pm_fps_varlen_groups(B, ld, D);
     const bool full_ws = ld > FPS_NT * FPS_RPT && workspace_bytes >= pm_fps_varlen_workspace_bytes(B, ld) && ((uintptr_t)workspace & 7) == 0;
-    const size_t mind = (((size_t)B * ld * sizeof(float) + 7) & ~(size_t)7);
-    fm_u64* slots = (fm_u64*)((char*)workspace + mind);
-    // a caller that handed over the full reservation may read its last word (the give-up flag) after ANY call: clear it always
-    if (full_ws && hipMemsetAsync(slots, 0, (size_t)(4 * 256 + 1) * sizeof(fm_u64), pm_stream(stream)) != hipSuccess) return PM_EINVAL;
-    if (D == 3 && G >= 2 && full_ws) {
+    if (G >= 2 && full_ws) {
+        const size_t mind = (((size_t)B * ld * sizeof(float) + 7) & ~(size_t)7);
+        fm_u64* slots = (fm_u64*)((char*)workspace + mind);
+        // round tags start at 1 and the give-up word is per call: the granules are cleared in front of every multi-work-group launch
+        if (hipMemsetAsync(slots, 0, (size_t)(4 * 256 + 1) * sizeof(fm_u64), pm_stream(stream)) != hipSuccess) return PM_EINVAL;
+        unsigned limit = FM_SPIN_LIMIT;
+        const char* e = getenv("PM_FPS_SPIN_LIMIT");     // tests force the give-up path with a tiny budget
+        if (e) limit = (unsigned)strtoul(e, nullptr, 10);
         const size_t lds = (size_t)FM_LDS * 4 * sizeof(float);
         if (pad) hipLaunchKernelGGL((fps_multi_kernel<true>), dim3(B * G), dim3(FPS_NT), lds, pm_stream(stream), xyz, ld, K, lengths,
-                                    idx_out, (float*)workspace, slots, G);
+                                    idx_out, (float*)workspace, slots, G, limit);
         else hipLaunchKernelGGL((fps_multi_kernel<false>), dim3(B * G), dim3(FPS_NT), lds, pm_stream(stream), xyz, ld, K, lengths,
-                                idx_out, (float*)workspace, slots, G);
+                                idx_out, (float*)workspace, slots, G, limit);
         // the clouds of the batch that fit one work-group's registers (decided per cloud on the device, no host sync on the lengths)
         hipLaunchKernelGGL(fps_varlen_kernel, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, ld, D, K, lengths, pad,
-                           idx_out, (float*)workspace, 1);
+                           idx_out, (float*)workspace, 1, (const unsigned long long*)nullptr);
+        // ... and, only if a work-group above gave up, the big clouds once more on one work-group each (returns at once otherwise)
+        hipLaunchKernelGGL(fps_varlen_kernel, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, ld, D, K, lengths, pad,
+                           idx_out, (float*)workspace, 2, (const unsigned long long*)(slots + 4 * 256));
         PM_CHECK_LAUNCH();
         return PM_OK;
     }
     hipLaunchKernelGGL(fps_varlen_kernel, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, ld, D, K, lengths, pad,
-                       idx_out, (float*)workspace, 0);
+                       idx_out, (float*)workspace, 0, (const unsigned long long*)nullptr);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }

@@ -677,7 +677,7 @@ extern "C" int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32
 // Duplicate-free ("packed") form of the same level.
 //
 // Ball query pads a group whose ball holds fewer than 32 points with copies of its FIRST hit (the canonical
-// PointNet++ rule; oracle/ref_cpu.py::ball_query).  A padded row is the same source point against the same
+// PointNet++ rule, pm_ball_query_f32).  A padded row is the same source point against the same
 // centre as row 0 of its group, so its three activations are bit-identical to row 0's; the max-pool takes the
 // LOWEST row attaining the maximum, so a padding row never wins, never receives a gradient, and the level's
 // outputs (pooled, arg) and every gradient are exactly those of the group's DISTINCT rows.  On the SURVEY's

@@ -53,15 +53,41 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.events = None                 # bench.py: HIP events around every all-reduce (time_collectives)
+        self.calls = 0
+
+    def time_collectives(self, on=True):
+        """Bracket every all-reduce with HIP events on the issuing stream (bench.py's comm_ms_per_step).  Off by default;
+        skipped while a stream is being captured into a hipGraph (events cannot be timed inside a graph)."""
+        self.events = [] if on else None
+        self.calls = 0
+
+    def comm_ms(self):
+        """(total ms, calls) of the bracketed all-reduces since time_collectives(); synchronises."""
+        if not self.events:
+            return 0.0, self.calls
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.events), self.calls
+
+    def _all_reduce(self, flat):
+        self.calls += 1
+        if self.events is None or not flat.is_cuda or torch.cuda.is_current_stream_capturing():
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        e1.record()
+        self.events.append((e0, e1))
 
     def mean_(self, flat):
         """In-place average of a flat tensor over ranks (sum + scale: gloo has no AVG op)."""
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        self._all_reduce(flat)
         flat.mul_(1.0 / self.world)
         return flat
 
     def sum_(self, flat):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        self._all_reduce(flat)
         return flat
 
     def moments_sync(self, mom2, count):

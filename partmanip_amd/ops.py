@@ -251,7 +251,10 @@ def linear_bwd_data_chain(items, ws):
 def chain_gave_up(ws):
     """True when a stripe barrier of the last chain launch on this workspace ran into its spin limit (host sync)."""
     tab = getattr(ws, "chain_ctr", None) or {}
-    return any(int(t[-1].item()) != 0 for t in tab.values())
+    bad = [t for t in tab.values() if int(t[-1].item()) != 0]
+    for t in bad:                # counters are monotonic across launches: after a failed launch they are off a launch boundary --
+        t.zero_()                # start over (error word included), so that the NEXT launch is valid again
+    return bool(bad)
 
 
 def padded_cols(rows, cols, device, zero=False):
@@ -608,6 +611,51 @@ def maxpool_rows_bwd(dout, arg, ns, y_tanh=None):
     return dx
 
 
+# ----------------------------------------------------------------------------- SURVEY 8(b) names: one-call forms
+def adv_normalize(x, ws, eps=1e-8):
+    """In place x <- (x - mean) / (std_unbiased + eps) over all elements (storage.py:114, single process): pm_adv_normalize_f32."""
+    _req(x)
+    _f32c(x, "x")
+    n = x.numel()
+    w = ws.get(int(lib.pm_adv_normalize_workspace_bytes(n)) + 8)
+    base = w.data_ptr()
+    al = (-base) % 8
+    check(lib.pm_adv_normalize_f32(_ptr(x), n, float(eps), base + al, w.numel() - al, _stream()), "pm_adv_normalize_f32")
+    return x
+
+
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[0 if t is None else t.data_ptr() for t in ts])
+
+
+def mlp_fwd(x, weights, biases, act):
+    """network.py:27-54 `MLP` forward through pm_mlp_fwd_f32 -> list of the layer outputs (the last one is the network output)."""
+    _req(x, *weights, *biases)
+    M = x.shape[0]
+    dims = [weights[0].shape[1]] + [w.shape[0] for w in weights]
+    hs = [torch.empty(M, d, dtype=torch.float32, device=x.device) for d in dims[1:]]
+    check(lib.pm_mlp_fwd_f32(_ptr(x), _rows(x, "x"), M, len(weights), (C.c_int * len(dims))(*dims), _ptr_array(weights),
+                             _ptr_array(biases), act, _ptr_array(hs), _stream()), "pm_mlp_fwd_f32")
+    return hs
+
+
+def mlp_bwd(x, weights, hs, act, dy, ws, need_dx=False):
+    """-> (dW list, db list, dX or None) through pm_mlp_bwd_f32."""
+    _req(x, dy, *weights, *hs)
+    M = x.shape[0]
+    dims = [weights[0].shape[1]] + [w.shape[0] for w in weights]
+    cd = (C.c_int * len(dims))(*dims)
+    dws = [torch.empty_like(w) for w in weights]
+    dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=x.device) for w in weights]
+    dx = torch.empty(M, dims[0], dtype=torch.float32, device=x.device) if need_dx else None
+    w = ws.get(int(lib.pm_mlp_bwd_workspace_bytes(M, len(weights), cd)) + 16)
+    base = w.data_ptr()
+    al = (-base) % 16
+    check(lib.pm_mlp_bwd_f32(_ptr(x), _rows(x, "x"), M, len(weights), cd, _ptr_array(weights), _ptr_array(hs), act, _ptr(dy),
+                             _ptr_array(dws), _ptr_array(dbs), _ptr(dx), base + al, w.numel() - al, _stream()), "pm_mlp_bwd_f32")
+    return dws, dbs, dx
+
+
 # ----------------------------------------------------------------------------- K15 fused SA level
 def sa_supported(C1, C2, C3, ns):
     return bool(lib.pm_sa_supported(C1, C2, C3, ns))
@@ -664,6 +712,13 @@ class SaPlan:
         """(packed rows, tiles) -- a host read; diagnostics / buffer sizing only."""
         t = self.totals.cpu()
         return int(t[0]), int(t[1])
+
+    def trim(self):
+        """Drop the worst-case capacity of the tables (one host read): for plans that are kept, e.g. per mini-batch slice."""
+        R, T = self.counts()
+        self.rowmap = self.rowmap[:max(R, 1)].clone()
+        self.tiles = self.tiles[:max(T, 1)].clone()
+        return self
 
 
 def sa_packed_tile(dims):
@@ -977,13 +1032,17 @@ def fps_varlen(xyz, lengths, K, ws, pad=False):
         al = (-base) % 8
     check(lib.pm_fps_varlen_f32(_ptr(xyz), B, ld, Dd, K, _ptr(lengths), int(pad), _ptr(idx), (base + al) if w is not None else None,
                                 (w.numel() - al) if w is not None else 0, _stream()), "pm_fps_varlen_f32")
-    if nb and not torch.cuda.is_current_stream_capturing():
-        # the several-work-groups-per-cloud kernel gives up (bounded spin) rather than hang when a partner work-group is not
-        # resident; its error word is the last 8 bytes of the reservation.  One host read per >= 8192-point batch of clouds.
-        if int(w[al + nb - 8: al + nb].view(torch.int64).item()) != 0:
-            raise RuntimeError("pm_fps_varlen_f32: a work-group of the multi-work-group FPS gave up waiting for its partners "
-                               "(not all work-groups resident?) -- the sampled indices are not valid")
+    # a multi-work-group launch that gives up degrades on the device (a launch queued behind it re-samples the big clouds when
+    # the reservation's last word is set): nothing to check here, no host sync.  fps_varlen_gave_up(ws) reads the word.
+    ws.fps_err = w[al + nb - 8: al + nb].view(torch.int64) if (nb and int(lib.pm_fps_varlen_groups(B, ld, Dd)) >= 2) else None
     return idx
+
+
+def fps_varlen_gave_up(ws):
+    """Diagnostics (a host read): did the last multi-work-group fps_varlen call on this workspace fall back to the
+    one-work-group sampler because a work-group's partners were not resident?"""
+    e = getattr(ws, "fps_err", None)
+    return bool(e is not None and int(e.item()) != 0)
 
 
 def tsdf_sparse_voxel(vol, K, lo, hi, ws):

@@ -20,7 +20,15 @@ def header_functions():
 
 def test_header_declares_the_survey_minimum_symbol_set():
     fns = header_functions()
-    for need in ("pm_gae_scan_f32", "pm_gather_rows_f32", "pm_linear_fwd_f32", "pm_linear_bwd_data_f32",
+    # SURVEY.md 8(b)'s list, name for name ...
+    for need in ("pm_gae_scan_f32", "pm_adv_normalize_f32", "pm_gather_rows_f32", "pm_mlp_fwd_f32", "pm_mlp_bwd_f32",
+                 "pm_pointnet_enc_fwd_f32", "pm_pointnet_enc_bwd_f32", "pm_ppo_actor_loss_fwd_bwd_f32", "pm_value_loss_fwd_bwd_f32",
+                 "pm_mse_tanh_loss_fwd_bwd_f32", "pm_clip_adam_step_f32", "pm_fps_f32", "pm_ball_query_f32", "pm_group_points_f32",
+                 "pm_group_points_bwd_f32", "pm_version"):
+        assert need in fns, need
+    # ... and the finer-grained forms the learner itself calls (INTEGRATION.md maps one to the other)
+    for need in ("pm_gae_scan_f32", "pm_gather_rows_f32", "pm_linear_fwd_f32", "pm_linear_bwd_data_f32", "pm_moments_f64",
+                 "pm_normalize_apply_f32",
                  "pm_linear_bwd_weight_f32", "pm_pointnet_enc_fwd_f32", "pm_pointnet_enc_bwd_f32",
                  "pm_ppo_actor_loss_fwd_bwd_f32", "pm_value_loss_fwd_bwd_f32", "pm_mse_tanh_loss_fwd_bwd_f32",
                  "pm_clip_adam_step_f32", "pm_fps_f32", "pm_ball_query_f32", "pm_group_points_f32",

@@ -344,3 +344,131 @@ def test_bench_self_launches_n_ranks(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["world_size_observed"] == 2 and rec["config"]["parallelism"] == "dp2"
     assert rec["value"] > 0
+    dp = rec["config"]["data_parallel"]                           # a multi-GPU line explains itself
+    assert dp["param_checksum_equal"] is True and len(dp["per_rank_ms_per_step"]) == 2 and dp["all_reduces_per_step"] > 0
+    assert rec["comm_ms_per_step"] == dp["comm_ms_per_step"] >= 0.0 and dp["graph_mode"] in ("split", "capture")
+    assert rec["config"]["backend"] == "gloo"
+
+
+# ----------------------------------------------------------------------------------------------- two REAL RCCL ranks (>= 2 GPUs)
+# A 1-GPU box skips these; on a multi-GPU node (the driver's SCALE run has one) they are the first place where RCCL carries the
+# learner's collectives between two devices: PPO-MLP with the hipGraph fast path (all-reduce captured inside the graphs),
+# PPO-PointNet and DAgger, each equal to the single-process run over the union of the env shards.
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="two RCCL ranks need two GPUs")
+
+
+def _rccl_env(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    os.environ.pop("PARTMANIP_DIST_BACKEND", None)
+    os.environ.pop("PARTMANIP_SHARE_GPU", None)
+    from partmanip_amd import dist as pdist
+    r, w, local = pdist.init_from_env("nccl")
+    assert torch.distributed.get_backend() == "nccl" and w == world and local == rank
+    torch.cuda.set_device(local)
+    return pdist
+
+
+def _rank_main_rccl(rank, world, port, name, out_dir):
+    global DEV
+    pdist = _rccl_env(rank, world, port)
+    DEV = f"cuda:{rank}"
+    c, fx = cases.PPO_CASES[name], load_fixture(name)
+    lo, hi = pdist.shard_envs(c["N"], rank, world)
+    run = _run_hip(c, fx, lo, hi, os.path.join(out_dir, f"r{rank}.npy"))
+    assert run.sync is not None and run.sync.world == world
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("name", ["ppo_mlp_allon", "ppo_pn_maxmean"])
+def test_two_rccl_ranks_match_single_process(name, tmp_path):
+    c, fx = cases.PPO_CASES[name], load_fixture(name)
+    mp.spawn(_rank_main_rccl, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
+    _run_hip(c, fx, 0, c["N"], str(tmp_path / "single.npy"))
+    r0, r1, single = (np.load(tmp_path / f) for f in ("r0.npy", "r1.npy", "single.npy"))
+    assert np.array_equal(r0, r1), "ranks diverged"
+    assert_flat_params_close("two RCCL ranks vs one process", r0, single, c["lr"], 16)
+
+
+def _rank_big_rccl2(rank, world, port, out_dir):
+    global DEV
+    pdist = _rccl_env(rank, world, port)
+    DEV = f"cuda:{rank}"
+    lo, hi = pdist.shard_envs(_BIG["N"], rank, world)
+    run, n_graphs = _run_big(lo, hi, os.path.join(out_dir, f"r{rank}.npy"), "capture")
+    assert run.sync.world == world and run.sync_c is not run.sync
+    assert n_graphs == 2 and run.dp_graph_mode == "capture", (n_graphs, run.dp_graph_mode)   # all-reduces INSIDE the two 4-step graphs
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@needs_two_gpus
+def test_two_rccl_ranks_keep_the_graph_fast_path(tmp_path):
+    """The default data-parallel mode of the small-step regime under RCCL -- gradient all-reduces captured INSIDE the multi-step
+    hipGraphs, the critic's collectives on their own communicator -- with a second rank on a second GPU."""
+    c = _BIG
+    mp.spawn(_rank_big_rccl2, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    _run_big(0, c["N"], str(tmp_path / "single.npy"), None)
+    r0, r1, single = (np.load(tmp_path / f) for f in ("r0.npy", "r1.npy", "single.npy"))
+    assert np.array_equal(r0, r1), "ranks diverged"
+    assert_flat_params_close("graph fast path: two RCCL ranks vs one process", r0, single, c["lr"], c["n_up"] * c["n_mb"])
+
+
+def _rank_dagger_rccl(rank, world, port, teacher, out_dir):
+    global DEV
+    pdist = _rccl_env(rank, world, port)
+    DEV = f"cuda:{rank}"
+    lo, hi = pdist.shard_envs(_DAG["N"], rank, world)
+    run = _run_dagger_hip(lo, hi, teacher, os.path.join(out_dir, f"r{rank}.npy"), out_dir)
+    assert run.sync is not None and run.sync.world == world
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@needs_two_gpus
+def test_two_rccl_rank_dagger_update_matches_single_process(tmp_path):
+    teacher = _write_teacher(str(tmp_path))
+    mp.spawn(_rank_dagger_rccl, args=(2, _free_port(), teacher, str(tmp_path)), nprocs=2, join=True)
+    _run_dagger_hip(0, _DAG["N"], teacher, str(tmp_path / "single.npy"), str(tmp_path))
+    r0, r1, single = (np.load(tmp_path / f) for f in ("r0.npy", "r1.npy", "single.npy"))
+    assert np.array_equal(r0, r1), "ranks diverged"
+    assert_flat_params_close("dagger: two RCCL ranks vs one process", r0, single, _DAG["lr"], 4)
+
+
+@needs_two_gpus
+def test_bench_two_rccl_ranks_report_the_data_parallel_block():
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PARTMANIP_SHARE_GPU", "PARTMANIP_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-optional"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    dp = rec["config"]["data_parallel"]
+    assert rec["n_gpus"] == 2 and rec["config"]["backend"] == "nccl" and dp["param_checksum_equal"] and dp["comm_ms_per_step"] > 0
+
+
+# ----------------------------------------------------------------------------------------------- capture failure -> eager
+def _rank_capture_fails(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", PARTMANIP_FORCE_SYNC="1",
+                      PARTMANIP_TEST_CAPTURE_FAIL="1")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    run, n_graphs = _run_big(0, _BIG["N"], os.path.join(out_dir, "fallback.npy"), "capture")
+    assert n_graphs == 0 and str(run.dp_graph_mode).startswith("eager ("), (n_graphs, run.dp_graph_mode)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_a_failing_graph_capture_falls_back_to_eager_steps(tmp_path):
+    """If capturing a step (with its RCCL all-reduce) into a hipGraph throws -- forced here -- the learner must neither die nor
+    skip the step: the step runs eagerly, capturing stops, `dp_graph_mode` says what happened (bench.py prints it in the
+    line's data_parallel block), and the update is the one the graphs would have produced."""
+    mp.spawn(_rank_capture_fails, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    _run_big(0, _BIG["N"], str(tmp_path / "single.npy"), None)
+    got, single = np.load(tmp_path / "fallback.npy"), np.load(tmp_path / "single.npy")
+    assert np.array_equal(got, single)

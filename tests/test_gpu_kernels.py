@@ -412,6 +412,53 @@ def test_clip_adam_steps(n, n_clip, max_norm):
     assert rel_err(m, adam.m[0]) < 1e-5 and rel_err(v, adam.v[0]) < 1e-5
 
 
+def test_one_call_forms_named_by_the_survey_boundary():
+    """SURVEY.md 8(b) lists pm_adv_normalize_f32 and pm_mlp_fwd_f32 / pm_mlp_bwd_f32; the learner calls finer-grained forms
+    (pm_moments_f64 + pm_normalize_apply_f32, pm_linear_*).  The listed names exist as entry points composed of those: the
+    normalisation equals the reference expression `(x - x.mean()) / (x.std() + 1e-8)` (storage.py:114) and the two-call form
+    bit for bit; the MLP forms equal the per-layer calls bit for bit and torch autograd (fp64) to fp32 round-off."""
+    o = ops()
+    g = torch.Generator().manual_seed(3)
+    ws = o.Workspace(torch.device(DEV))
+    x = (torch.randn(64 * 300, 1, generator=g) * 3 + 1).to(DEV)
+    a = x.clone()
+    o.adv_normalize(a, ws)
+    b = x.clone()
+    mom = torch.empty(2, dtype=torch.float64, device=DEV)
+    o.moments(b, mom, ws)
+    o.normalize_apply(b, mom, b.numel(), 1e-8)
+    assert torch.equal(a, b)
+    want = (x.cpu() - x.cpu().mean()) / (x.cpu().std() + 1e-8)
+    np.testing.assert_allclose(a.cpu().numpy(), want.numpy(), rtol=2e-6, atol=2e-6)
+    # the MLP of cfg 2's shape on a ragged batch
+    M, dims = 1000, [53, 512, 512, 512, 10]
+    xs = torch.randn(M, dims[0], generator=g).to(DEV)
+    W = [(torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5).to(DEV) for i in range(4)]
+    B_ = [(torch.randn(dims[i + 1], generator=g) * 0.1).to(DEV) for i in range(4)]
+    hs = o.mlp_fwd(xs, W, B_, o.ACT_TANH)
+    h, ref_h = xs, []
+    for i in range(4):
+        y = torch.empty(M, dims[i + 1], device=DEV)
+        o.linear_fwd(h, W[i], B_[i], y, o.ACT_TANH if i < 3 else o.ACT_NONE)
+        ref_h.append(y)
+        h = y
+    assert all(torch.equal(p, q) for p, q in zip(hs, ref_h))
+    dy = torch.randn(M, dims[-1], generator=g).to(DEV)
+    dws, dbs, dx = o.mlp_bwd(xs, W, hs, o.ACT_TANH, dy, ws, need_dx=True)
+    xd = xs.double().requires_grad_(True)
+    Wd = [w.double().requires_grad_(True) for w in W]
+    Bd = [b.double().requires_grad_(True) for b in B_]
+    hh = xd
+    for i in range(4):
+        hh = hh @ Wd[i].t() + Bd[i]
+        if i < 3:
+            hh = torch.tanh(hh)
+    np.testing.assert_allclose(hs[-1].cpu().numpy(), hh.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    (hh * dy.double()).sum().backward()
+    for got, want_ in list(zip(dws, [w.grad for w in Wd])) + list(zip(dbs, [b.grad for b in Bd])) + [(dx, xd.grad)]:
+        assert rel_err(got, want_) < 2e-5
+
+
 # ------------------------------------------------------------------------------- point-set ops
 # wave-per-cloud variant: P <= 2048 with D == 3 (every points-per-lane instantiation, B not a multiple of 4,
 # K > P); work-group variant: 2048 < P <= 8192 or D != 3; streaming variant beyond
@@ -563,7 +610,50 @@ def test_varlen_fps_hand_off_under_competing_load():
                     a @ a
         idx = o.fps_varlen(x, n, K, ws, pad=False)
         assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref), it
+        assert not o.fps_varlen_gave_up(ws), it              # delayed hand-offs, never an exhausted poll budget
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("pad", [False, True])
+def test_varlen_fps_degrades_when_a_work_group_gives_up(pad, monkeypatch):
+    """A multi-work-group launch whose partners cannot all be resident must DEGRADE, not fail (VERDICT r3 #8 / ADVICE): with the
+    poll budget forced to zero every work-group that has to wait at all gives up in its first round, latches the flag, tells the
+    others through the error word and returns; the launch queued behind re-samples the big clouds on one work-group each.  The
+    indices are bit-exact all the same (empty / register-sized clouds of the batch included), no host round trip is involved,
+    and the launch returns at once instead of spinning K times its budget."""
+    import time
+    o = ops()
+    B, ld, K = 24, 40000, 64
+    g = np.random.default_rng(5)
+    pts = (g.random((B, ld, 3), dtype=np.float32) * 2 - 1).astype(np.float32)
+    lengths = g.integers(9000, ld + 1, size=B).astype(np.int32)
+    lengths[:3] = (0, 100, 8192)
+    ref = R.fps(pts, K, lengths)
+    if not pad:
+        for b in range(B):
+            if 0 < lengths[b] < K:
+                ref[b, lengths[b]:] = 0
+    x, n = torch.from_numpy(pts).to(DEV), torch.from_numpy(lengths).to(DEV)
+    ws = o.Workspace(torch.device(DEV))
+    assert int(o.lib.pm_fps_varlen_groups(B, ld, 3)) >= 2
+    idx = o.fps_varlen(x, n, K, ws, pad=pad)                      # normal budget
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref) and not o.fps_varlen_gave_up(ws)
+    monkeypatch.setenv("PM_FPS_SPIN_LIMIT", "0")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    idx = o.fps_varlen(x, n, K, ws, pad=pad)
+    got = idx.cpu().numpy().astype(np.int64)
+    dt = time.perf_counter() - t0
+    assert o.fps_varlen_gave_up(ws), "the forced give-up did not happen"
+    assert np.array_equal(got, ref)
+    assert dt < 5.0, dt
+    monkeypatch.delenv("PM_FPS_SPIN_LIMIT")
+    idx = o.fps_varlen(x, n, K, ws, pad=pad)                      # the next call clears the word and runs on several work-groups again
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref) and not o.fps_varlen_gave_up(ws)
+    monkeypatch.setenv("PM_FPS_MAXG", "1")                        # the cap: one work-group per cloud, no hand-offs at all
+    assert int(o.lib.pm_fps_varlen_groups(B, ld, 3)) == 1
+    idx = o.fps_varlen(x, n, K, ws, pad=pad)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref)
 
 
 def test_tsdf_integrate_matches_reference():

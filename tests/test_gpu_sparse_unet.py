@@ -196,11 +196,13 @@ def _full_size_clouds(B, seed):
     return x.reshape(B, 4 * P).contiguous()
 
 
-def test_full_size_geometry_tables_equal_the_restatement():
-    """Whole-batch tables (256 clouds) against the numpy restatement on the first four and the last four clouds (rows are
-    numbered cloud by cloud, so the last clouds' tables are the restatement's plus the rows in front of them)."""
+@pytest.mark.parametrize("B", [256, 2048])
+def test_full_size_geometry_tables_equal_the_restatement(B):
+    """Whole-batch tables against the numpy restatement on the first, a middle and the last four clouds (rows are numbered
+    cloud by cloud, so later clouds' tables are the restatement's plus the rows in front of them).  B = 2048 is the bench's
+    mini-batch (8.4 M / 2.7 M / 0.6 M level rows: row * 27 and row * channels products beyond 2^31 bytes)."""
     from partmanip_amd.algo_utils import ActorCritic
-    B, P, Rg = 256, NET_FULL["point_num"], NET_FULL["grid"]
+    P, Rg = NET_FULL["point_num"], NET_FULL["grid"]
     x = _full_size_clouds(B, 770)
     ac = ActorCritic(4 * P, 10, _model(NET_FULL)).to(DEV)
     g = ac.actor.geometry(x)
@@ -208,7 +210,7 @@ def test_full_size_geometry_tables_equal_the_restatement():
     assert R0 == B * P and 0 < R2 < R1 < R0
     cl1, cl2 = g["l1"]["coords"][:, 0].cpu().numpy(), g["l2"]["coords"][:, 0].cpu().numpy()       # cloud of every coarse row
     assert np.all(np.diff(cl1) >= 0) and np.all(np.diff(cl2) >= 0)
-    for lo in (0, B - 4):
+    for lo in (0, B // 2 - 2, B - 4):
         ref = R.sparse_unet_geometry(x[lo:lo + 4].cpu().numpy(), P, 4, Rg)
         b0, b1, b2 = lo * P, int((cl1 < lo).sum()), int((cl2 < lo).sum())
         n0, n1, n2 = ref["rows"]
@@ -227,16 +229,18 @@ def test_full_size_geometry_tables_equal_the_restatement():
             np.testing.assert_array_equal(got["coords"][cb:cb + cn, 1:].cpu().numpy(), np.concatenate(want["coords"]))
 
 
-def test_full_size_forward_and_gradients_fused_vs_materialised_and_vs_restatement():
-    """256 clouds x 4096 voxels through the cfg 5 network: (a) gathers fused into the GEMM loaders vs materialised operands on the
+@pytest.mark.parametrize("B", [256, 2048])
+def test_full_size_forward_and_gradients_fused_vs_materialised_and_vs_restatement(B):
+    """B clouds x 4096 voxels through the cfg 5 network (B = 2048: the mini-batch `bench.py --workload dagger --student
+    sparse_unet` times, ~60 GB of materialised operands in the A/B leg): (a) gathers fused into the GEMM loaders vs materialised operands on the
     WHOLE batch -- outputs bit for bit, parameter gradients to 1e-6; (b) four clouds spread over the batch (first, two inner,
     last) against the restatement in fp64: outputs, and parameter gradients of a loss that weighs only those clouds (their rows
     sit at the start, inside and at the end of every level's row range); everything finite."""
     from partmanip_amd.algo_utils import ActorCritic
     from partmanip_amd.autograd import backbone_apply
     from tests.helpers import record_margin
-    B, P, A = 256, NET_FULL["point_num"], 10
-    pick = [0, 85, 170, B - 1]
+    P, A = NET_FULL["point_num"], 10
+    pick = [0, B // 3, 2 * B // 3, B - 1]
     sd = cases.actor_critic_state(NET_FULL, 4 * P, A, 0.5, 47)
     x = _full_size_clouds(B, 771)
     gen = torch.Generator(device=DEV).manual_seed(5)
@@ -251,6 +255,7 @@ def test_full_size_forward_and_gradients_fused_vs_materialised_and_vs_restatemen
         out = backbone_apply(ac.actor, x)
         (out * w_all).sum().backward()
         res[fused] = (out.detach().clone(), {n: p.grad.clone() for n, p in ac.actor.named_parameters()})
+        torch.cuda.synchronize()
         if fused:
             for p in ac.actor.parameters():
                 p.grad = None
@@ -258,7 +263,8 @@ def test_full_size_forward_and_gradients_fused_vs_materialised_and_vs_restatemen
             (out2 * w_pick).sum().backward()
             g_pick = {n: p.grad.clone() for n, p in ac.actor.named_parameters()}
             assert torch.equal(out2.detach(), out.detach())
-        del ac
+        del ac, out
+        torch.cuda.empty_cache()
     assert torch.isfinite(res[True][0]).all() and all(torch.isfinite(v).all() for v in res[True][1].values())
     assert torch.equal(res[True][0], res[False][0])
     worst = 0.0

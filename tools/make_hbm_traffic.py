@@ -5,12 +5,16 @@ requests of wide coalesced reads at 64 B: MI355X_MICROARCH.md, HBM section).  GR
 SQ_VALU_MFMA_BUSY_CYCLES sums the issued MFMAs' pipe cycles over the 1024 SIMDs.
 
     python tools/make_hbm_traffic.py <tag> <pmc_enc summary.json> [<pmc_lin summary.json> [<pmc_su summary.json> [<pmc_fps summary.json>]]]
+                                     [sa=<summary of tools/time_sa.py>] [su2048=<summary of tools/time_sparse_unet.py 2048>]
+                                     [state=<summary of bench.py --workload state --lean --steps 2 --warmup 0>]
 """
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+extra = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a and not a.startswith("-"))
+sys.argv = [a for a in sys.argv if "=" not in a]
 tag, enc = sys.argv[1], json.load(open(sys.argv[2]))
 lin = json.load(open(sys.argv[3])) if len(sys.argv) > 3 and os.path.exists(sys.argv[3]) else None
 su = json.load(open(sys.argv[4])) if len(sys.argv) > 4 and os.path.exists(sys.argv[4]) else None
@@ -34,8 +38,8 @@ def busy(k):
     return k["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0 / (k["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
 
 
-out["source"] = (f"round 3: tools/profile_round.sh {tag} -> tools/pmc_run.sh gpurun_out/{tag}/pmc_enc python tools/time_enc.py (separate "
-                 f"rocprofv3 --pmc passes, counters only) -> profiles/round3_{tag[2:]}_pmc_encoder.json; tools/make_hbm_traffic.py")
+out["source"] = (f"tools/profile_round.sh {tag} -> tools/pmc_run.sh gpurun_out/{tag}/pmc_enc python tools/time_enc.py (separate "
+                 f"rocprofv3 --pmc passes, counters only) -> profiles/round{tag[1]}_{tag[2:]}_pmc_encoder.json; tools/make_hbm_traffic.py")
 out["correction"] = "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 tallies 128-B requests at 64 B); counters are KB"
 for name in ("pn_fwd_kernel", "pn_bwd16_kernel", "pn_bwd_prep_kernel"):
     k = find(enc, name)
@@ -62,7 +66,7 @@ if lin is not None:
         out[f"linear_2048x512x512_{key}_mfma_insts"] = k["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 64.0
     out["linear_2048x512x512_algorithmic_bytes"] = (2 * 2048 * 512 + 512 * 512) * 4
     out["linear_2048x512x512_note"] = (f"tools/pmc_run.sh gpurun_out/{tag}/pmc_lin python tools/time_gemm.py 2048x512x512 -> "
-                                       f"profiles/round3_{tag[2:]}_pmc_linear.json; FETCH doubled (gfx950 correction); each of the 8 XCDs fetches "
+                                       f"profiles/round{tag[1]}_{tag[2:]}_pmc_linear.json; FETCH doubled (gfx950 correction); each of the 8 XCDs fetches "
                                        "the whole weight matrix into its own L2")
 if su is not None:
     f = sum(2.0 * v["FETCH_SIZE"]["mean"] * v["FETCH_SIZE"]["launches"] for v in su.values() if "FETCH_SIZE" in v) * 1024.0
@@ -79,5 +83,44 @@ if fps is not None:
     out["fps_multi_kernel_cycles_per_launch"] = k["GRBM_GUI_ACTIVE"]["mean"] / 8.0
     out["fps_multi_kernel_note"] = (f"tools/pmc_run.sh gpurun_out/{tag}/pmc_fps python bench.py --workload depth2pc --no-cpu-baseline: the "
                                     "multi-work-group FPS launch of depth2pc (64 envs x 6 views x 180 x 320), FETCH doubled")
+
+
+def total(tab, passes):
+    """HBM bytes of ALL kernels of a command / the number of passes it ran (FETCH doubled)."""
+    f = sum(2.0 * v["FETCH_SIZE"]["mean"] * v["FETCH_SIZE"]["launches"] for v in tab.values() if "FETCH_SIZE" in v) * 1024.0
+    w = sum(v["WRITE_SIZE"]["mean"] * v["WRITE_SIZE"]["launches"] for v in tab.values() if "WRITE_SIZE" in v) * 1024.0
+    return f / passes, w / passes
+
+
+if "sa" in extra and os.path.exists(extra["sa"]):
+    sa = json.load(open(extra["sa"]))
+    for kname, v in sa.items():
+        base = kname.replace("void ", "").split("<")[0]
+        if base not in ("sa_fwd_pk_kernel", "sa_bwd_pk_kernel", "sa_fwd_kernel", "sa_bwd_kernel") or "FETCH_SIZE" not in v:
+            continue
+        dims = [x.strip() for x in kname.split("<")[1].split(",")[:3]]
+        key = f"sa_{'fwd' if 'fwd' in base else 'bwd'}_{dims[0]}x{dims[1]}x{dims[2]}"
+        f, w = traffic(v)
+        out[f"{key}_bytes_per_launch"] = f + w
+        out[f"{key}_kernel"] = base
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+            out[f"{key}_mfma_busy"] = busy(v)
+    out["sa_note"] = (f"tools/pmc_run.sh gpurun_out/{tag}/pmc_sa python tools/time_sa.py (2048 clouds, the distinct-row kernels): HBM bytes "
+                      "per launch, FETCH doubled")
+if "su2048" in extra and os.path.exists(extra["su2048"]):
+    f, w = total(json.load(open(extra["su2048"])), 5.0)
+    out["sparse_unet_2048_clouds_fetch_bytes_per_pass"] = f
+    out["sparse_unet_2048_clouds_write_bytes_per_pass"] = w
+    out["sparse_unet_2048_clouds_bytes_per_pass"] = f + w
+    out["sparse_unet_2048_clouds_note"] = (f"tools/pmc_run.sh gpurun_out/{tag}/pmc_su2048 python tools/time_sparse_unet.py 2048 (5 forward + "
+                                           "backward passes of a 2048-cloud mini-batch, ALL kernels of the process incl. the voxel tables)")
+if "state" in extra and os.path.exists(extra["state"]):
+    f, w = total(json.load(open(extra["state"])), 2.0)
+    out["state_iteration_bytes"] = f + w
+    out["state_iteration_fetch_bytes"] = f
+    out["state_iteration_write_bytes"] = w
+    out["state_iteration_note"] = (f"tools/pmc_run.sh gpurun_out/{tag}/pmc_state env PARTMANIP_GRAPHS=0 python bench.py --workload state --lean "
+                                   "--no-cpu-baseline --steps 2 --warmup 0: ALL kernels of the process (two iterations + the rollout "
+                                   "forward), divided by 2")
 json.dump(out, open(dst, "w"), indent=1)
 print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in out.items() if not k.endswith("note") and k not in ("source", "correction")})

@@ -31,4 +31,10 @@ PMC_PASS_TIMEOUT=150 bash tools/pmc_run.sh $out/pmc_enc python tools/time_enc.py
 PMC_PASS_TIMEOUT=150 bash tools/pmc_run.sh $out/pmc_lin python tools/time_gemm.py 2048x512x512 < /dev/null
 PMC_PASS_TIMEOUT=200 bash tools/pmc_run.sh $out/pmc_su python tools/time_sparse_unet.py 256 < /dev/null
 PMC_PASS_TIMEOUT=150 bash tools/pmc_run.sh $out/pmc_fps python bench.py --workload depth2pc --no-cpu-baseline < /dev/null
+PMC_PASS_TIMEOUT=150 bash tools/pmc_run.sh $out/pmc_sa python tools/time_sa.py < /dev/null
+PMC_PASS_TIMEOUT=300 bash tools/pmc_run.sh $out/pmc_su2048 python tools/time_sparse_unet.py 2048 < /dev/null
+PMC_PASS_TIMEOUT=400 bash tools/pmc_run.sh $out/pmc_state env PARTMANIP_GRAPHS=0 python bench.py --workload state --lean --no-cpu-baseline --steps 2 --warmup 0 < /dev/null
+python tools/make_hbm_traffic.py $tag $out/pmc_enc/summary.json $out/pmc_lin/summary.json $out/pmc_su/summary.json $out/pmc_fps/summary.json \
+  sa=$out/pmc_sa/summary.json su2048=$out/pmc_su2048/summary.json state=$out/pmc_state/summary.json > $out/hbm_traffic.txt 2>&1
+cp profiles/hbm_traffic.json $out/hbm_traffic.json
 ls $out
