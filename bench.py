@@ -666,9 +666,11 @@ def run_ppo(args, device, rank, world):
         wsb = ops.Workspace(torch.device(device))
         kern, lv = {}, {}
         for l, (k, (c1, c2, c3, S)) in enumerate(SA_LEVELS.items()):
-            P_l = net.point_num if l == 0 else net.npoints[l - 1]
+            # level l samples its centres among level l - 1's centres (level 0: the cloud itself)
+            xyz_l = (st.observations.view(-1, w["O"])[:2048, :net.point_num * net.in_channels].reshape(2048, net.point_num, net.in_channels)[..., :3].contiguous()
+                     if l == 0 else tabs[l - 1][0].contiguous())
             if getattr(net, "unique_rows", False):
-                R_, T_ = ops.sa_plan(tabs[l][1].contiguous(), P_l, (c1, c2, c3), wsb).counts()
+                R_, T_ = ops.sa_plan(tabs[l][1].contiguous(), xyz_l, tabs[l][0].contiguous(), (c1, c2, c3), wsb).counts()
             else:
                 R_, T_ = 2048 * S * 32, 2048 * S * 32 // 64
             dense = 2048.0 * S * 32

@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 143 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 144 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -486,27 +486,31 @@ int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32_t* idx, co
  * of whole groups; pm_sa_fwd_packed_f32 / pm_sa_bwd_packed_f32 run the same per-row arithmetic as pm_sa_fwd_f32 /
  * pm_sa_bwd_f32 on the tiles.  pooled, arg and the saved layer 2 are bit-identical to the dense entry points' (arg is
  * the row inside the group in both); weight gradients agree to fp32 summation order.
- *   grow    (B*S + 1)        first packed row of each group, grow[B*S] = R
- *   rowmap  (2 * B*S*nsample) capacity: {flat source point b*P + idx, group} per packed row; R pairs are written
- *   tiles   (4 * B*S)        capacity: {first row, first group, groups, rows} per tile; T quadruples are written
- *   totals  (4)              [0] = R packed rows, [1] = T tiles -- read by the kernels on the device (persistent
- *                            work-groups), never by the host: nothing here synchronises
- *   h2_save / h2_saved       (R, C2) -- capacity (B*S*nsample, C2) when R is not read back
+ *   grow    (B*S + 1)         first packed row of each group, grow[B*S] = R
+ *   rowmap  (2 * B*S*nsample) capacity: {flat source point b*P + idx, (group - first group of its tile) << 8 | row inside the
+ *                             group} per packed row; R pairs are written
+ *   relxyz  (4 * B*S*nsample) capacity: xyz[source point] - centre[group] per packed row (x, y, z, 0): the staging of the level
+ *                             kernels is two coalesced loads per row (coordinates only: weights never enter the plan)
+ *   tiles   (4 * B*S)         capacity: {first row, first group, groups, rows} per tile; T quadruples are written
+ *   totals  (4)               [0] = R packed rows, [1] = T tiles -- read by the kernels on the device (persistent
+ *                             work-groups), never by the host: nothing here synchronises
+ *   h2_save / h2_saved        (R, C2) -- capacity (B*S*nsample, C2) when R is not read back
  * tile_rows / tile_groups come from pm_sa_packed_tile (they are the kernels' tile shapes for that level shape). */
 int pm_sa_packed_tile(int C1, int C2, int C3, int* tile_rows, int* tile_groups);
 size_t pm_sa_plan_workspace_bytes(int B, int S);
-int pm_sa_plan_i32(const int32_t* idx, int B, int P, int S, int nsample, int tile_rows, int tile_groups, int32_t* grow,
-                   int32_t* rowmap, int32_t* tiles, int32_t* totals, void* workspace, size_t workspace_bytes, void* stream);
-int pm_sa_fwd_packed_f32(const float* xyz, const float* centers, const float* Y, int B, int P, int S, const int32_t* grow,
-                         const int32_t* rowmap, const int32_t* tiles, const int32_t* totals, const float* W1, long ldw1,
-                         const float* b1, const float* b2, const float* b3, const float* packed, int C1, int C2, int C3,
-                         float* pooled, long ldp, int32_t* arg, float* h2_save, void* stream);
-int pm_sa_bwd_packed_f32(const float* xyz, const float* centers, const float* Y, int B, int P, int S, const int32_t* grow,
-                         const int32_t* rowmap, const int32_t* tiles, const int32_t* totals, const float* W1, long ldw1,
-                         const float* b1, const float* b2, const float* W3, const float* packed, int C1, int C2, int C3,
-                         const float* pooled, long ldp, const int32_t* arg, const float* dpooled, long lddp, float* dW1,
-                         long lddw1, float* db1, float* dW2, float* db2, float* dW3, float* db3, float* dY,
-                         const float* h2_saved, void* workspace, size_t workspace_bytes, void* stream);
+int pm_sa_plan_i32(const int32_t* idx, const float* xyz, const float* centers, int B, int P, int S, int nsample, int tile_rows,
+                   int tile_groups, int32_t* grow, int32_t* rowmap, float* relxyz, int32_t* tiles, int32_t* totals, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int pm_sa_fwd_packed_f32(const float* Y, int B, int P, int S, const int32_t* grow, const int32_t* rowmap, const float* relxyz,
+                         const int32_t* tiles, const int32_t* totals, const float* W1, long ldw1, const float* b1, const float* b2,
+                         const float* b3, const float* packed, int C1, int C2, int C3, float* pooled, long ldp, int32_t* arg,
+                         float* h2_save, void* stream);
+int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const int32_t* grow, const int32_t* rowmap, const float* relxyz,
+                         const int32_t* tiles, const int32_t* totals, const float* W1, long ldw1, const float* b1, const float* b2,
+                         const float* W3, const float* packed, int C1, int C2, int C3, const float* pooled, long ldp,
+                         const int32_t* arg, const float* dpooled, long lddp, float* dW1, long lddw1, float* db1, float* dW2,
+                         float* db2, float* dW3, float* db3, float* dY, const float* h2_saved, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* ---- rollout side ------------------------------------------------------------------------
  * algorithms/algo_utils/actor_critic.py:36-47 `random_act_cri` after the two network forwards: x = mu + sigma^2 * eps

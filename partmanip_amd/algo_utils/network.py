@@ -75,10 +75,17 @@ class _LinearChain:
         self.x, self.x_w = x, x_w
         self.h = []
         cur = x
+        # rows wider than the first layer's fan-in (the caller zero-filled the extra columns so that K is a multiple of the
+        # GEMM's 32-wide K-step: the LDS-DMA kernels instead of the register-staged one): a zero-padded copy of the weights
+        self.w0p = None
+        if x.shape[1] != self.linears[0].in_features:
+            w0 = self.linears[0].weight.data
+            self.w0p = torch.zeros(w0.shape[0], x.shape[1], device=x.device)
+            self.w0p[:, :w0.shape[1]].copy_(w0)
         for i, lin in enumerate(self.linears):
             last = i == n - 1
             y = out if (last and out is not None) else torch.empty(cur.shape[0], lin.out_features, device=cur.device)
-            ops.linear_fwd(cur, lin.weight.data, lin.bias.data, y,
+            ops.linear_fwd(cur, self.w0p if (i == 0 and self.w0p is not None) else lin.weight.data, lin.bias.data, y,
                            self.act if (not last or self.final_act) else ops.ACT_NONE)
             if not last:
                 self.h.append(y)
@@ -116,13 +123,19 @@ class _LinearChain:
             lin = self.linears[i]
             inp = self.h[i - 1] if i > 0 else self.x
             dW, db = self.grads[i]
-            ops.linear_bwd_weight(dy, inp, dW, db, ws)
+            w0p = getattr(self, "w0p", None) if i == 0 else None
+            if w0p is not None:                            # zero-padded K: the gradient of the real columns is the leading block
+                dWp = torch.empty_like(w0p)
+                ops.linear_bwd_weight(dy, inp, dWp, db, ws)
+                dW.copy_(dWp[:, :dW.shape[1]])
+            else:
+                ops.linear_bwd_weight(dy, inp, dW, db, ws)
             if i > 0:
                 dx = torch.empty_like(inp)
                 ops.linear_bwd_data(dy, lin.weight.data, inp, dx, self.act)
                 dy = dx
             elif dx_out is not None:
-                ops.linear_bwd_data(dy, lin.weight.data, inp if x_is_activation else None, dx_out,
+                ops.linear_bwd_data(dy, w0p if w0p is not None else lin.weight.data, inp if x_is_activation else None, dx_out,
                                     self.act if x_is_activation else ops.ACT_NONE)
         return dx_out
 
@@ -491,10 +504,12 @@ class PointNet2(_HipNet):
         lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
         dims = (lin1.out_features, lin2.out_features, lin3.out_features)
         cf = 0 if feat is None else feat.shape[2]
-        Y = None
+        Y, w1f = None, None
         if cf > 0:
+            # the feature columns of W1 start 12 bytes into a row: an aligned copy (64 KB) takes the 16-byte LDS-DMA loaders
+            w1f = lin1.weight.data[:, 3:3 + cf].contiguous()
             Y = torch.empty(B * Pl, dims[0], device=xyz.device)
-            ops.linear_fwd(feat.reshape(B * Pl, cf), lin1.weight.data[:, 3:3 + cf], None, Y, ops.ACT_NONE)
+            ops.linear_fwd(feat.reshape(B * Pl, cf), w1f, None, Y, ops.ACT_NONE)
         packed = self._sa_packed[l]
         if packed is None or packed.device != xyz.device:
             packed = torch.empty(int(ops.lib.pm_sa_packed_elems(*dims)), device=xyz.device)
@@ -512,25 +527,25 @@ class PointNet2(_HipNet):
             cache, key = plan_slot if plan_slot is not None else (None, None)
             plan = cache.get(key) if cache is not None else None
             if plan is None:
-                plan = ops.sa_plan(idx_g, Pl, dims, self._workspace(xyz.device))
+                plan = ops.sa_plan(idx_g, xyz, centers, dims, self._workspace(xyz.device))
                 if cache is not None:                      # a sequential mini-batch of a cached rollout: both networks and
                     cache[key] = plan.trim()               # every epoch reuse it (one host read of the row / tile counts)
-            arg = ops.sa_fwd_packed(xyz, centers, plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
+            arg = ops.sa_fwd_packed(plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
                                     packed, dims, pooled, h2)
         else:
             arg = ops.sa_fwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
                              packed, dims, pooled, h2)
-        return (idx_g, arg, "fused", xyz, feat, centers, Y, packed, dims, pooled, h2, plan)
+        return (idx_g, arg, "fused", xyz, feat, centers, Y, packed, dims, pooled, h2, plan, w1f)
 
     def _sa_backward_fused(self, l, rec, dpooled, ws, need_dfeat):
-        idx_g, arg, _, xyz, feat, centers, Y, packed, dims, pooled, h2, plan = rec
+        idx_g, arg, _, xyz, feat, centers, Y, packed, dims, pooled, h2, plan, w1f = rec
         B, Pl = xyz.shape[0], xyz.shape[1]
         lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
         (dW1, db1), (dW2, db2), (dW3, db3) = self._chains[l].grads
         cf = 0 if feat is None else feat.shape[2]
         dY = torch.zeros(B * Pl, dims[0], device=xyz.device) if cf > 0 else None
         if plan is not None:
-            ops.sa_bwd_packed(xyz, centers, plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data,
+            ops.sa_bwd_packed(plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data,
                               packed, dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws, h2)
         else:
             ops.sa_bwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data, packed,
@@ -540,11 +555,13 @@ class PointNet2(_HipNet):
         if cf == 0:
             return None
         feat2 = feat.reshape(B * Pl, cf)
-        ops.linear_bwd_weight(dY, feat2, dW1[:, 3:3 + cf], None, ws)
+        dW1f = torch.empty_like(w1f)
+        ops.linear_bwd_weight(dY, feat2, dW1f, None, ws)
+        dW1[:, 3:3 + cf].copy_(dW1f)
         if not need_dfeat:
             return None
         dfeat = torch.empty(B * Pl, cf, device=xyz.device)
-        ops.linear_bwd_data(dY, lin1.weight.data[:, 3:3 + cf], None, dfeat, ops.ACT_NONE)
+        ops.linear_bwd_data(dY, w1f, None, dfeat, ops.ACT_NONE)
         return dfeat
 
     # ---- neighbourhood tables ------------------------------------------------------------------------
@@ -621,7 +638,7 @@ class PointNet2(_HipNet):
         S = xyz.shape[1]                                   # group-all level: absolute coordinates
         idx_all = torch.arange(S, dtype=torch.int32, device=x.device).repeat(B, 1).view(B, 1, S)
         zeros = torch.zeros(B, 1, 3, device=x.device)
-        ldo = self.sa[-1][0].in_features
+        ldo = (self.sa[-1][0].in_features + 31) // 32 * 32     # zero columns up to the GEMM's K-step (the chain pads its weights alike)
         rows = ops.group_concat(xyz, feat, zeros, idx_all, ldo)
         h = self._chains[-1].forward(rows)
         fbuf = torch.empty(B, self.feat_dim + self.proprio_shape, device=x.device)

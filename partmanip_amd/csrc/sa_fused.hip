@@ -698,7 +698,8 @@ extern "C" int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32
 // The kernels read the tile count from device memory (persistent work-groups): no host synchronisation anywhere.
 struct SaPk {
     const int32_t* grow;     // (G + 1)   first packed row of each group
-    const int2* rowmap;      // (R)       {flat source point b*P + idx, group}
+    const int2* rowmap;      // (R)       {flat source point b*P + idx, local group << 8 | row inside the group}
+    const float4* relxyz;    // (R)       xyz[source point] - centre[group]
     const int4* tiles;       // (T)       {first packed row, first group, groups, rows}
     const int32_t* totals;   // [0] = R, [1] = T
 };
@@ -715,8 +716,8 @@ extern "C" int pm_sa_packed_tile(int C1, int C2, int C3, int* tile_rows, int* ti
 // ascending and distinct), their prefix inside the cloud, and the greedy cut into tiles of whole groups
 __global__ __launch_bounds__(256) void sa_plan_count_kernel(const int32_t* __restrict__ idx, int S, int ns, int tile_rows,
                                                              int tile_groups, int32_t* __restrict__ lrow,
-                                                             int4* __restrict__ ltiles, int32_t* __restrict__ crows,
-                                                             int32_t* __restrict__ ctiles) {
+                                                             int32_t* __restrict__ lstart, int4* __restrict__ ltiles,
+                                                             int32_t* __restrict__ crows, int32_t* __restrict__ ctiles) {
     __shared__ int cnt[1024];
     const long b = blockIdx.x;
     for (int s = threadIdx.x; s < S; s += 256) {
@@ -738,6 +739,7 @@ __global__ __launch_bounds__(256) void sa_plan_count_kernel(const int32_t* __res
                 rows = 0;
             }
             lrow[b * S + s] = prefix;
+            lstart[b * S + s] = start;                   // first group of the tile this group belongs to
             prefix += c;
             rows += c;
         }
@@ -785,25 +787,35 @@ __global__ __launch_bounds__(1024) void sa_plan_scan_kernel(const int32_t* __res
     }
 }
 
-__global__ __launch_bounds__(256) void sa_plan_fill_kernel(const int32_t* __restrict__ idx, int B, int P, int S, int ns,
-                                                            const int32_t* __restrict__ lrow, const int4* __restrict__ ltiles,
+// rowmap[r] = {flat source point, (group - its tile's first group) << 8 | row inside the group}; relxyz[r] = xyz[source] -
+// centre[group] (the sub_rn the dense kernels evaluate per row and tile): both depend on the coordinates only, so the level
+// kernels' staging is two coalesced loads per row instead of a chain row -> point -> coordinates.
+__global__ __launch_bounds__(256) void sa_plan_fill_kernel(const int32_t* __restrict__ idx, const float* __restrict__ xyz,
+                                                            const float* __restrict__ centers, int B, int P, int S, int ns,
+                                                            const int32_t* __restrict__ lrow, const int32_t* __restrict__ lstart,
+                                                            const int4* __restrict__ ltiles,
                                                             const int32_t* __restrict__ ctiles, const int32_t* __restrict__ rbase,
                                                             const int32_t* __restrict__ tbase, const int32_t* __restrict__ totals,
                                                             int32_t* __restrict__ grow, int2* __restrict__ rowmap,
-                                                            int4* __restrict__ tiles) {
+                                                            float4* __restrict__ relxyz, int4* __restrict__ tiles) {
     const long b = blockIdx.x;
     const int rb = rbase[b], tb = tbase[b];
     for (int s = threadIdx.x; s < S; s += 256) {
         const long g = b * S + s;
         const int r0 = rb + lrow[g];
         grow[g] = r0;
+        const int lg = (s - lstart[g]) << 8;
+        const float cx = centers[g * 3], cy = centers[g * 3 + 1], cz = centers[g * 3 + 2];
         const int32_t* p = idx + g * ns;
         const int first = p[0];
-        rowmap[r0] = make_int2((int)(b * P + first), (int)g);
-        int k = 1;
-        for (int j = 1; j < ns; ++j) {
+        int k = 0;
+        for (int j = 0; j < ns; ++j) {
             const int v = p[j];
-            if (v != first) rowmap[r0 + k++] = make_int2((int)(b * P + v), (int)g);
+            if (j > 0 && v == first) continue;
+            const long sp = b * P + v;
+            rowmap[r0 + k] = make_int2((int)sp, lg | k);
+            relxyz[r0 + k] = make_float4(sub_rn(xyz[sp * 3], cx), sub_rn(xyz[sp * 3 + 1], cy), sub_rn(xyz[sp * 3 + 2], cz), 0.f);
+            ++k;
         }
     }
     const int nt = ctiles[b];
@@ -815,51 +827,47 @@ __global__ __launch_bounds__(256) void sa_plan_fill_kernel(const int32_t* __rest
 }
 
 extern "C" size_t pm_sa_plan_workspace_bytes(int B, int S) {
-    return ((size_t)B * S * 5 + (size_t)B * 4) * sizeof(int32_t) + 64;
+    return ((size_t)B * S * 6 + (size_t)B * 4) * sizeof(int32_t) + 64;
 }
 
-extern "C" int pm_sa_plan_i32(const int32_t* idx, int B, int P, int S, int nsample, int tile_rows, int tile_groups,
-                              int32_t* grow, int32_t* rowmap, int32_t* tiles, int32_t* totals, void* workspace,
-                              size_t workspace_bytes, void* stream) {
-    PM_REQUIRE(idx && grow && rowmap && tiles && totals && workspace);
-    PM_REQUIRE(B > 0 && P > 0 && S > 0 && S <= 1024 && nsample > 0 && nsample <= tile_rows && tile_groups > 0 && tile_groups <= 255);
+extern "C" int pm_sa_plan_i32(const int32_t* idx, const float* xyz, const float* centers, int B, int P, int S, int nsample,
+                              int tile_rows, int tile_groups, int32_t* grow, int32_t* rowmap, float* relxyz, int32_t* tiles,
+                              int32_t* totals, void* workspace, size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(idx && xyz && centers && grow && rowmap && relxyz && tiles && totals && workspace);
+    PM_REQUIRE(B > 0 && P > 0 && S > 0 && S <= 1024 && nsample > 0 && nsample <= tile_rows && nsample <= 255 && tile_groups > 0);
     PM_REQUIRE((long)B * P < (1L << 31) && (long)B * S * nsample < (1L << 31));
     if (workspace_bytes < pm_sa_plan_workspace_bytes(B, S)) return PM_EWORKSPACE;
-    if ((((uintptr_t)workspace) & 15) || (((uintptr_t)tiles) & 15) || (((uintptr_t)rowmap) & 7)) return PM_EALIGN;
+    if ((((uintptr_t)workspace) & 15) || (((uintptr_t)tiles) & 15) || (((uintptr_t)rowmap) & 7) || (((uintptr_t)relxyz) & 15)) return PM_EALIGN;
     const size_t G = (size_t)B * S;
     int4* ltiles = (int4*)workspace;
     int32_t* lrow = (int32_t*)(ltiles + G);
-    int32_t* crows = lrow + G;
+    int32_t* lstart = lrow + G;
+    int32_t* crows = lstart + G;
     int32_t *ctiles = crows + B, *rbase = ctiles + B, *tbase = rbase + B;
     hipStream_t st = pm_stream(stream);
-    hipLaunchKernelGGL(sa_plan_count_kernel, dim3(B), dim3(256), 0, st, idx, S, nsample, tile_rows, tile_groups, lrow, ltiles,
+    hipLaunchKernelGGL(sa_plan_count_kernel, dim3(B), dim3(256), 0, st, idx, S, nsample, tile_rows, tile_groups, lrow, lstart, ltiles,
                        crows, ctiles);
     hipLaunchKernelGGL(sa_plan_scan_kernel, dim3(1), dim3(1024), 0, st, crows, ctiles, B, rbase, tbase, totals);
-    hipLaunchKernelGGL(sa_plan_fill_kernel, dim3(B), dim3(256), 0, st, idx, B, P, S, nsample, lrow, ltiles, ctiles, rbase,
-                       tbase, totals, grow, (int2*)rowmap, (int4*)tiles);
+    hipLaunchKernelGGL(sa_plan_fill_kernel, dim3(B), dim3(256), 0, st, idx, xyz, centers, B, P, S, nsample, lrow, lstart, ltiles, ctiles,
+                       rbase, tbase, totals, grow, (int2*)rowmap, (float4*)relxyz, (int4*)tiles);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
 
 // ---- shared staging of a packed tile -------------------------------------------------------------------------
-// Xz / Src as sa_stage; Lgr[t] = local group << 8 | local row (rows past the tile's end: row 255, which no arg-max
-// equals); Ls[j] = first tile-local row of group j (j <= groups).  Rows past the end repeat the tile's first row
-// (finite activations that nothing reads back).
+// Xz / Src as sa_stage, from the plan's per-row tables (two coalesced loads per row); Lgr[t] = local group << 8 | local row
+// (rows past the tile's end: row 255, which no arg-max equals); Ls[j] = first tile-local row of group j (j <= groups).  Rows
+// past the end repeat the tile's first row (finite activations that nothing reads back).
 template <int TM, int NT>
-__device__ __forceinline__ void sa_stage_pk(const SaArgs& a, const SaPk& k, const int4 td, int tid, float* __restrict__ Xz,
+__device__ __forceinline__ void sa_stage_pk(const SaPk& k, const int4 td, int tid, float* __restrict__ Xz,
                                             int* __restrict__ Src, int* __restrict__ Lgr, int* __restrict__ Ls) {
     for (int t = tid; t < TM; t += NT) {
         const bool live = t < td.w;
-        const int2 rm = k.rowmap[td.x + (live ? t : 0)];
-        const long sp = rm.x, g = rm.y;
-        float4 v;
-        v.x = sub_rn(a.xyz[sp * 3], a.centers[g * 3]);
-        v.y = sub_rn(a.xyz[sp * 3 + 1], a.centers[g * 3 + 1]);
-        v.z = sub_rn(a.xyz[sp * 3 + 2], a.centers[g * 3 + 2]);
-        v.w = 0.f;
-        *(float4*)(Xz + t * 4) = v;
+        const long r = td.x + (live ? t : 0);
+        const int2 rm = k.rowmap[r];
+        *(float4*)(Xz + t * 4) = k.relxyz[r];
         Src[t] = rm.x;
-        if (Lgr) Lgr[t] = live ? (((rm.y - td.y) << 8) | (td.x + t - k.grow[rm.y])) : 255;
+        if (Lgr) Lgr[t] = live ? rm.y : 255;
     }
     for (int j = tid; j <= td.z; j += NT) Ls[j] = k.grow[td.y + j] - td.x;
 }
@@ -886,13 +894,15 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_fwd_pk_kernel(SaArgs a, SaPk 
     const float4* P3v = (const float4*)(a.packed + (size_t)C1 * C2);
     const int ntiles = k.totals[1];
 
+    int4 td = k.tiles[(int)blockIdx.x < ntiles ? blockIdx.x : 0];
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));                    // see sa_fwd_kernel: recompute, don't hoist
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int li = lane & 31, lh = lane >> 5;
-        const int4 td = k.tiles[tile];
-        sa_stage_pk<TM, NT>(a, k, td, tid, Xz, Src, nullptr, Ls);
+        const int nxt = tile + (int)gridDim.x;
+        const int4 tdn = k.tiles[nxt < ntiles ? nxt : tile];       // the next tile's descriptor: one hop off the next staging
+        sa_stage_pk<TM, NT>(k, td, tid, Xz, Src, nullptr, Ls);
         __syncthreads();
         sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
         __syncthreads();
@@ -943,6 +953,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_fwd_pk_kernel(SaArgs a, SaPk 
             }
         }
         __syncthreads();
+        td = tdn;
     }
 }
 
@@ -953,20 +964,20 @@ static long sa_pk_grid(long G, int ncu, int wgcu, long cap) {
     return grid;
 }
 
-extern "C" int pm_sa_fwd_packed_f32(const float* xyz, const float* centers, const float* Y, int B, int P, int S,
-                                    const int32_t* grow, const int32_t* rowmap, const int32_t* tiles, const int32_t* totals,
+extern "C" int pm_sa_fwd_packed_f32(const float* Y, int B, int P, int S, const int32_t* grow, const int32_t* rowmap,
+                                    const float* relxyz, const int32_t* tiles, const int32_t* totals,
                                     const float* W1, long ldw1, const float* b1, const float* b2, const float* b3,
                                     const float* packed, int C1, int C2, int C3, float* pooled, long ldp, int32_t* arg,
                                     float* h2_save, void* stream) {
-    PM_REQUIRE(xyz && centers && grow && rowmap && tiles && totals && W1 && b1 && b2 && b3 && packed && pooled && arg);
+    PM_REQUIRE(grow && rowmap && relxyz && tiles && totals && W1 && b1 && b2 && b3 && packed && pooled && arg);
     PM_REQUIRE(B > 0 && P > 0 && S > 0 && ldw1 >= 3 && ldp >= C3);
     if (!pm_sa_supported(C1, C2, C3, SA_NS)) return PM_EUNSUPPORTED;
-    if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)tiles & 15) != 0) return PM_EALIGN;
+    if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)tiles & 15) != 0 || ((uintptr_t)relxyz & 15) != 0) return PM_EALIGN;
     SaArgs a = {};
-    a.xyz = xyz; a.centers = centers; a.Y = Y; a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.b2 = b2; a.b3 = b3;
+    a.Y = Y; a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.b2 = b2; a.b3 = b3;
     a.packed = packed; a.pooled = pooled; a.ldp = ldp; a.arg = arg; a.G = (long)B * S; a.S = S; a.P = P;
     a.h2 = h2_save;
-    SaPk k = {grow, (const int2*)rowmap, (const int4*)tiles, totals};
+    SaPk k = {grow, (const int2*)rowmap, (const float4*)relxyz, (const int4*)tiles, totals};
     const int ncu = sa_cu_count();
     if (SA_CFG_A(C1, C2, C3))
         hipLaunchKernelGGL((sa_fwd_pk_kernel<64, 64, 128, 64, 4, 4, 20, 4>), dim3((unsigned)sa_pk_grid(a.G, ncu, 4, 0)),
@@ -1050,28 +1061,66 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
 #pragma unroll
         for (int r = 0; r < 16; ++r) accW2[j][r] = 0.f;
 
+    constexpr int EPT = TM * C2 / 4 / NT, NV = (NGMAX * 128 + NT - 1) / NT;
+    static_assert(EPT * NT * 4 == TM * C2, "H2 tile pieces per thread");
+    int4 td = k.tiles[(int)blockIdx.x < ntiles ? blockIdx.x : 0];
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int li = lane & 31, lh = lane >> 5;
         const int w2_m = wave % (C2 / 32), w2_n0 = (wave / (C2 / 32)) * NBK;
-        const int4 td = k.tiles[tile];
-        // ---- P0: gather ------------------------------------------------------------------
-        sa_stage_pk<TM, NT>(a, k, td, tid, Xz, Src, Lgr, Ls);
-        __syncthreads();
-        // ---- P1/P2: H1 recomputed, H2 loaded (or recomputed) -----------------------------------------
-        sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
-        __syncthreads();
+        const int nxt = tile + (int)gridDim.x;
+        const int4 tdn = k.tiles[nxt < ntiles ? nxt : tile];
+        // ---- P0: gather; the tile's saved H2 rows and the first channel chunk's (pooled, dpooled, arg) entries are REQUESTED
+        // here and stored to LDS behind the layer-1 recompute, which needs none of them: their round trips run under it
+        sa_stage_pk<TM, NT>(k, td, tid, Xz, Src, Lgr, Ls);
+        float4 hq[EPT];
         if (a.h2) {
-#pragma unroll 2
-            for (int q = tid; q < TM * C2 / 4; q += NT) {
-                const int row = q / (C2 / 4), c4 = q % (C2 / 4);
-                float4 h = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past the end: zero (their dZ2 is 0 * (1 - 0))
-                if (row < td.w) h = *(const float4*)(a.h2 + (long)(td.x + row) * C2 + 4 * c4);
-                *(float4*)(H2 + row * LD2 + 4 * c4) = h;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int q = tid + i * NT, row = q / (C2 / 4), c4 = q % (C2 / 4);
+                hq[i] = make_float4(0.f, 0.f, 0.f, 0.f);             // rows past the end: zero (their dZ2 is 0 * (1 - 0))
+                if (row < td.w) hq[i] = *(const float4*)(a.h2 + (long)(td.x + row) * C2 + 4 * c4);
             }
-        } else {
+        }
+        float pv[NV], dv[NV];
+        int av[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i = tid + u * NT, j = i >> 7, sl = i & 127;
+            pv[u] = dv[u] = 0.f;
+            av[u] = 0;
+            if (j < td.z) {
+                const int c = (sl < 64 ? sl : C3 / 2 + (sl - 64));
+                const long g = td.y + j;
+                pv[u] = a.pooled[g * a.ldp + c];
+                dv[u] = a.dpooled[g * a.lddp + c];
+                av[u] = a.arg[g * C3 + c];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // ---- P1/P2: H1 recomputed, H2 stored (or recomputed) -----------------------------------------
+        sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (a.h2) {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int q = tid + i * NT, row = q / (C2 / 4), c4 = q % (C2 / 4);
+                *(float4*)(H2 + row * LD2 + 4 * c4) = hq[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i = tid + u * NT, j = i >> 7, sl = i & 127;
+            if (j < td.z) {
+                Val[j * LDV + sl] = dv[u] * (1.0f - pv[u] * pv[u]);
+                ((uint8_t*)ArgW)[j * (LDA * 4) + sl] = (uint8_t)av[u];
+            }
+        }
+        if (!a.h2) {
+            __syncthreads();
             sa_layer2<C1, C2, TM, NW, false>(H1, P2v, a.b2, wave, lane, H2);
         }
         // ---- P3: structured layer-3 backward, 128 channels at a time ---------------------------------------
@@ -1081,7 +1130,6 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
         int lgv[M2::MB], lrv[M2::MB];
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
-            __syncthreads();                 // H2 complete / the previous chunk's Val, Arg no longer read
             if (q == 0) {
 #pragma unroll
                 for (int mb = 0; mb < M2::MB; ++mb) {
@@ -1089,16 +1137,18 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                     lgv[mb] = lgr >> 8;
                     lrv[mb] = lgr & 255;
                 }
+            } else {
+                __syncthreads();             // the previous chunk's Val, Arg are no longer read
+                for (int i = tid; i < td.z * 128; i += NT) {
+                    const int j = i >> 7, s = i & 127;
+                    const int c = (s < 64 ? 64 * q + s : C3 / 2 + 64 * q + (s - 64));
+                    const long g = td.y + j;
+                    const float p = a.pooled[g * a.ldp + c];
+                    Val[j * LDV + s] = a.dpooled[g * a.lddp + c] * (1.0f - p * p);
+                    ((uint8_t*)ArgW)[j * (LDA * 4) + s] = (uint8_t)a.arg[g * C3 + c];
+                }
             }
-            for (int i = tid; i < td.z * 128; i += NT) {
-                const int j = i >> 7, s = i & 127;
-                const int c = (s < 64 ? 64 * q + s : C3 / 2 + 64 * q + (s - 64));
-                const long g = td.y + j;
-                const float p = a.pooled[g * a.ldp + c];
-                Val[j * LDV + s] = a.dpooled[g * a.lddp + c] * (1.0f - p * p);
-                ((uint8_t*)ArgW)[j * (LDA * 4) + s] = (uint8_t)a.arg[g * C3 + c];
-            }
-            __syncthreads();
+            __syncthreads();                 // H1, H2 and this chunk's Val, Arg complete
             {   // dW3[c, :] += val * H2[row of the arg-max, :]   (VALU; the slice stays in registers for the whole kernel)
                 const int s = tid & 127, ks = tid >> 7;
                 for (int j = 0; j < td.z; ++j) {
@@ -1211,6 +1261,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
             }
         }
         __syncthreads();
+        td = tdn;
     }
 
     // ---- write this work-group's partial sums (layout of SaPart, reduced by sa_bwd_reduce_kernel) ----------------
@@ -1264,26 +1315,26 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
     }
 }
 
-extern "C" int pm_sa_bwd_packed_f32(const float* xyz, const float* centers, const float* Y, int B, int P, int S,
-                                    const int32_t* grow, const int32_t* rowmap, const int32_t* tiles, const int32_t* totals,
+extern "C" int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const int32_t* grow, const int32_t* rowmap,
+                                    const float* relxyz, const int32_t* tiles, const int32_t* totals,
                                     const float* W1, long ldw1, const float* b1, const float* b2, const float* W3,
                                     const float* packed, int C1, int C2, int C3, const float* pooled, long ldp,
                                     const int32_t* arg, const float* dpooled, long lddp, float* dW1, long lddw1, float* db1,
                                     float* dW2, float* db2, float* dW3, float* db3, float* dY, const float* h2_saved,
                                     void* workspace, size_t workspace_bytes, void* stream) {
-    PM_REQUIRE(xyz && centers && grow && rowmap && tiles && totals && W1 && b1 && b2 && W3 && packed && pooled && arg && dpooled);
+    PM_REQUIRE(grow && rowmap && relxyz && tiles && totals && W1 && b1 && b2 && W3 && packed && pooled && arg && dpooled);
     PM_REQUIRE(dW1 && db1 && dW2 && db2 && dW3 && db3 && workspace);
     PM_REQUIRE(B > 0 && P > 0 && S > 0 && ldw1 >= 3 && lddw1 >= 3 && ldp >= C3 && lddp >= C3);
     if (!pm_sa_supported(C1, C2, C3, SA_NS)) return PM_EUNSUPPORTED;
-    if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)tiles & 15) != 0) return PM_EALIGN;
+    if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)tiles & 15) != 0 || ((uintptr_t)relxyz & 15) != 0) return PM_EALIGN;
     if (workspace_bytes < pm_sa_bwd_workspace_bytes(C1, C2, C3)) return PM_EWORKSPACE;
     SaArgs a = {};
-    a.xyz = xyz; a.centers = centers; a.Y = Y; a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.b2 = b2;
+    a.Y = Y; a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.b2 = b2;
     a.packed = packed; a.pooled = const_cast<float*>(pooled); a.ldp = ldp; a.arg = const_cast<int32_t*>(arg);
     a.G = (long)B * S; a.S = S; a.P = P; a.W3 = W3; a.dpooled = dpooled; a.lddp = lddp; a.dY = dY;
     a.parts = (float*)workspace;
     a.h2 = const_cast<float*>(h2_saved);
-    SaPk k = {grow, (const int2*)rowmap, (const int4*)tiles, totals};
+    SaPk k = {grow, (const int2*)rowmap, (const float4*)relxyz, (const int4*)tiles, totals};
     const int ncu = sa_cu_count();
     if (SA_CFG_A(C1, C2, C3)) {
         const long grid = sa_pk_grid(a.G, ncu, 3, SA_BWD_MAXGRID);

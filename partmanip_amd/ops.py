@@ -706,7 +706,7 @@ def sa_bwd(xyz, centers, idx, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpoo
 # ---- duplicate-free ("packed") form: the level over each group's DISTINCT rows (ball query pads with copies of the first hit)
 class SaPlan:
     """Packed-row tables of one neighbourhood table (pm_sa_plan_i32): nothing here is read by the host."""
-    __slots__ = ("grow", "rowmap", "tiles", "totals", "B", "P", "S", "ns", "dims")
+    __slots__ = ("grow", "rowmap", "relxyz", "tiles", "totals", "B", "P", "S", "ns", "dims")
 
     def counts(self):
         """(packed rows, tiles) -- a host read; diagnostics / buffer sizing only."""
@@ -717,6 +717,7 @@ class SaPlan:
         """Drop the worst-case capacity of the tables (one host read): for plans that are kept, e.g. per mini-batch slice."""
         R, T = self.counts()
         self.rowmap = self.rowmap[:max(R, 1)].clone()
+        self.relxyz = self.relxyz[:max(R, 1)].clone()
         self.tiles = self.tiles[:max(T, 1)].clone()
         return self
 
@@ -727,10 +728,13 @@ def sa_packed_tile(dims):
     return r.value, g.value
 
 
-def sa_plan(idx, P, dims, ws):
-    """idx (B, S, 32) int32 ball-query table -> SaPlan for the fused level of shape `dims`."""
-    _req(idx)
+def sa_plan(idx, xyz, centers, dims, ws):
+    """idx (B, S, 32) int32 ball-query table of centres (B, S, 3) over xyz (B, P, 3) -> SaPlan for the fused level `dims`."""
+    _req(idx, xyz, centers)
+    _f32c(xyz, "xyz")
+    _f32c(centers, "centers")
     B, S, ns = idx.shape
+    P = xyz.shape[1]
     if idx.dtype != torch.int32 or not idx.is_contiguous():
         raise TypeError("sa_plan: idx must be a contiguous int32 tensor")
     tr, tg = sa_packed_tile(dims)
@@ -740,6 +744,7 @@ def sa_plan(idx, P, dims, ws):
     dev = idx.device
     pl.grow = torch.empty(G + 1, dtype=torch.int32, device=dev)
     pl.rowmap = torch.empty(G * ns, 2, dtype=torch.int32, device=dev)
+    pl.relxyz = torch.empty(G * ns, 4, dtype=torch.float32, device=dev)
     pl.tiles = torch.empty(G, 4, dtype=torch.int32, device=dev)
     pl.totals = torch.zeros(4, dtype=torch.int32, device=dev)
     nb = int(lib.pm_sa_plan_workspace_bytes(B, S))
@@ -747,41 +752,36 @@ def sa_plan(idx, P, dims, ws):
     base = w.data_ptr()
     al = (-base) % 16
     with TIMER.bracket("sa_plan"):
-        check(lib.pm_sa_plan_i32(_ptr(idx), B, P, S, ns, tr, tg, _ptr(pl.grow), _ptr(pl.rowmap), _ptr(pl.tiles), _ptr(pl.totals),
-                                 base + al, w.numel() - al, _stream()), "pm_sa_plan_i32")
+        check(lib.pm_sa_plan_i32(_ptr(idx), _ptr(xyz), _ptr(centers), B, P, S, ns, tr, tg, _ptr(pl.grow), _ptr(pl.rowmap),
+                                 _ptr(pl.relxyz), _ptr(pl.tiles), _ptr(pl.totals), base + al, w.numel() - al, _stream()), "pm_sa_plan_i32")
     return pl
 
 
-def sa_fwd_packed(xyz, centers, plan, Y, w1, b1, b2, b3, packed, dims, pooled, h2_save=None):
-    _req(xyz, centers, Y, w1, packed, pooled)
-    B, P, _ = xyz.shape
-    S = centers.shape[1]
+def sa_fwd_packed(plan, Y, w1, b1, b2, b3, packed, dims, pooled, h2_save=None):
+    _req(Y, w1, packed, pooled)
+    B, P, S = plan.B, plan.P, plan.S
     C1, C2, C3 = dims
-    if (B, P, S) != (plan.B, plan.P, plan.S) or tuple(dims) != plan.dims:
+    if tuple(dims) != plan.dims or pooled.shape[0] != B * S or (Y is not None and Y.shape[0] != B * P):
         raise ValueError("sa_fwd_packed: the plan was built for another batch / level shape")
-    _f32c(xyz, "xyz")
-    _f32c(centers, "centers")
-    arg = torch.empty(B * S, C3, dtype=torch.int32, device=xyz.device)
+    arg = torch.empty(B * S, C3, dtype=torch.int32, device=pooled.device)
     with TIMER.bracket(f"sa_fwd_{C1}x{C2}x{C3}"):
-        check(lib.pm_sa_fwd_packed_f32(_ptr(xyz), _ptr(centers), _ptr(Y), B, P, S, _ptr(plan.grow), _ptr(plan.rowmap),
+        check(lib.pm_sa_fwd_packed_f32(_ptr(Y), B, P, S, _ptr(plan.grow), _ptr(plan.rowmap), _ptr(plan.relxyz),
                                        _ptr(plan.tiles), _ptr(plan.totals), _ptr(w1), _rows(w1, "w1"), _ptr(b1), _ptr(b2),
                                        _ptr(b3), _ptr(packed), C1, C2, C3, _ptr(pooled), _rows(pooled, "pooled"), _ptr(arg),
                                        _ptr(h2_save), _stream()), "pm_sa_fwd_packed_f32")
     return arg
 
 
-def sa_bwd_packed(xyz, centers, plan, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpooled, dw1, db1, dw2, db2, dw3, db3, dY,
-                  ws, h2_saved=None):
-    _req(xyz, centers, Y, w1, w3, packed, pooled, arg, dpooled, dw1, dw2, dw3, dY)
-    B, P, _ = xyz.shape
-    S = centers.shape[1]
+def sa_bwd_packed(plan, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpooled, dw1, db1, dw2, db2, dw3, db3, dY, ws, h2_saved=None):
+    _req(Y, w1, w3, packed, pooled, arg, dpooled, dw1, dw2, dw3, dY)
+    B, P, S = plan.B, plan.P, plan.S
     C1, C2, C3 = dims
-    if (B, P, S) != (plan.B, plan.P, plan.S) or tuple(dims) != plan.dims:
+    if tuple(dims) != plan.dims or pooled.shape[0] != B * S:
         raise ValueError("sa_bwd_packed: the plan was built for another batch / level shape")
     _f32c(w3, "w3")
     w = ws.get(lib.pm_sa_bwd_workspace_bytes(C1, C2, C3))
     with TIMER.bracket(f"sa_bwd_{C1}x{C2}x{C3}"):
-        check(lib.pm_sa_bwd_packed_f32(_ptr(xyz), _ptr(centers), _ptr(Y), B, P, S, _ptr(plan.grow), _ptr(plan.rowmap),
+        check(lib.pm_sa_bwd_packed_f32(_ptr(Y), B, P, S, _ptr(plan.grow), _ptr(plan.rowmap), _ptr(plan.relxyz),
                                        _ptr(plan.tiles), _ptr(plan.totals), _ptr(w1), _rows(w1, "w1"), _ptr(b1), _ptr(b2),
                                        _ptr(w3), _ptr(packed), C1, C2, C3, _ptr(pooled), _rows(pooled, "pooled"), _ptr(arg),
                                        _ptr(dpooled), _rows(dpooled, "dpooled"), _ptr(dw1), _rows(dw1, "dw1"), _ptr(db1),

@@ -277,7 +277,7 @@ def test_cfg2_first_graph_chunk_is_tight_against_the_oracle():
     got, log = passes[2]
     ref = out["log"]
     assert log["Train/kl_update_count"] == ref["Train/kl_update_count"] == 16
-    for k, rtol in (("Train/value_function_loss", 1e-6), ("Train/kl", 2e-4), ("Train/kl_max", 2e-4)):
+    for k, rtol in (("Train/value_function_loss", 1e-6), ("Train/kl", 2e-4), ("Train/kl_max", 2e-4)):      # observed 6e-9, 3.5e-5, 5.5e-5
         assert_close_rec("cfg 2 first chunk " + k, float(log[k]), float(ref[k]), rtol=rtol, atol=1e-12)
     assert_close_rec("cfg 2 first chunk Train/surrogate_loss", float(log["Train/surrogate_loss"]), float(ref["Train/surrogate_loss"]), rtol=0, atol=5e-6)
     err = per_tensor_update_error(got, flat_state(p), sd)
@@ -285,9 +285,10 @@ def test_cfg2_first_graph_chunk_is_tight_against_the_oracle():
     worst_c = max(v[0] for k, v in err.items() if k.startswith("critic."))
     # Adam's first steps move an element by ~lr * sign(g): where |g| is at round-off the sign -- hence a whole +-lr -- is not
     # determined by fp32 arithmetic, for the oracle no more than for the kernels; per TENSOR (L2) that stays small
-    record_margin("cfg 2 first 16 steps, actor: worst ||hip - oracle32|| / ||oracle32 - init|| per tensor", worst_a, 2e-3)
-    record_margin("cfg 2 first 16 steps, critic: worst ||hip - oracle32|| / ||oracle32 - init|| per tensor", worst_c, 1e-4)
-    assert worst_c < 1e-4 and worst_a < 2e-3, (worst_a, worst_c, {k: v[0] for k, v in err.items()})
+    # observed on the box: actor 2.7e-5, critic 3.4e-5 of the update per tensor (the 80-step cfg 1 update: 3.6e-5) -- bounds ~4x
+    record_margin("cfg 2 first 16 steps, actor: worst ||hip - oracle32|| / ||oracle32 - init|| per tensor", worst_a, 1.2e-4)
+    record_margin("cfg 2 first 16 steps, critic: worst ||hip - oracle32|| / ||oracle32 - init|| per tensor", worst_c, 1.2e-4)
+    assert worst_c < 1.2e-4 and worst_a < 1.2e-4, (worst_a, worst_c, {k: v[0] for k, v in err.items()})
 
 
 def test_cfg1_fused_policy_head_is_bit_identical(cfg1_problem):

@@ -456,7 +456,7 @@ def test_one_call_forms_named_by_the_survey_boundary():
     np.testing.assert_allclose(hs[-1].cpu().numpy(), hh.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
     (hh * dy.double()).sum().backward()
     for got, want_ in list(zip(dws, [w.grad for w in Wd])) + list(zip(dbs, [b.grad for b in Bd])) + [(dx, xd.grad)]:
-        assert rel_err(got, want_) < 2e-5
+        assert rel_err(got, want_.cpu()) < 2e-5
 
 
 # ------------------------------------------------------------------------------- point-set ops
@@ -813,7 +813,7 @@ def test_sa_packed_rows_equal_the_dense_level(dims, P, S, cf, radius):
     if radius < 0.1:
         centers[:, 0] += 10.0                                  # empty balls: the row is all zeros (point 0, once)
     idx = o.ball_query(xyz, centers, radius, 32)
-    plan = o.sa_plan(idx, P, dims, ws)
+    plan = o.sa_plan(idx, xyz, centers, dims, ws)
     R_, T_ = plan.counts()
     # ---- the plan against numpy
     ii = idx.cpu().numpy().reshape(B * S, 32)
@@ -822,11 +822,16 @@ def test_sa_packed_rows_equal_the_dense_level(dims, P, S, cf, radius):
     assert R_ == grow[-1] and np.array_equal(plan.grow.cpu().numpy(), grow)
     rm = plan.rowmap.cpu().numpy()[:R_]
     want_g = np.repeat(np.arange(B * S), cnt)
-    assert np.array_equal(rm[:, 1], want_g)
     want_sp = np.concatenate([np.concatenate([r[:1], r[1:][r[1:] != r[0]]]) for r in ii]) + (want_g // S) * P
     assert np.array_equal(rm[:, 0], want_sp)
     tr, tg = o.sa_packed_tile(dims)
     tl = plan.tiles.cpu().numpy()[:T_]
+    # rowmap.y = (group - first group of its tile) << 8 | row inside the group; relxyz = xyz[source] - centre[group] (fp32 sub)
+    tile_of_row = np.repeat(np.arange(T_), tl[:, 3])
+    assert np.array_equal(rm[:, 1] >> 8, want_g - tl[tile_of_row, 1]) and np.array_equal(rm[:, 1] & 255, np.arange(R_) - grow[want_g])
+    rel = plan.relxyz.cpu().numpy()[:R_]
+    want_rel = xyz.cpu().numpy().reshape(-1, 3)[want_sp] - centers.cpu().numpy().reshape(-1, 3)[want_g]
+    assert np.array_equal(rel[:, :3], want_rel) and not rel[:, 3].any()
     assert tl[0, 0] == 0 and tl[0, 1] == 0 and np.array_equal(tl[1:, 0], tl[:-1, 0] + tl[:-1, 3])
     assert np.array_equal(tl[1:, 1], tl[:-1, 1] + tl[:-1, 2]) and tl[-1, 1] + tl[-1, 2] == B * S and tl[-1, 0] + tl[-1, 3] == R_
     assert tl[:, 3].max() <= tr and tl[:, 2].max() <= tg and tl[:, 2].min() >= 1
@@ -856,8 +861,8 @@ def test_sa_packed_rows_equal_the_dense_level(dims, P, S, cf, radius):
             arg = o.sa_fwd(xyz, centers, idx, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
             o.sa_bwd(xyz, centers, idx, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *grads, dY, ws, h2)
         else:
-            arg = o.sa_fwd_packed(xyz, centers, plan, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
-            o.sa_bwd_packed(xyz, centers, plan, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *grads, dY, ws, h2)
+            arg = o.sa_fwd_packed(plan, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
+            o.sa_bwd_packed(plan, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *grads, dY, ws, h2)
         out[mode] = (pooled, arg, h2, grads, dY)
     pd, ad, hd, gd, yd = out["dense"]
     for mode in ("packed", "packed_recompute"):

@@ -14,3 +14,4 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BAN
   i=$((i+1))
 done
 python tools/pmc_summary.py "$out" "$out/summary.json" > "$out/summary.txt"
+rm -rf "$out"/pmc_[0-9]        # the raw per-dispatch CSVs are tens of MB per pass: gpurun merges at most 64 MiB back

@@ -35,14 +35,14 @@ for name, P, S, radius, dims, cf in LEVELS:
     h2 = torch.empty(B * S * 32, C2, device=DEV) if os.environ.get("SA_SAVE_H2", "1") == "1" else None
 
     PACKED = os.environ.get("SA_PACKED", "1") == "1"       # duplicate-free rows (default) or the dense 32-row groups
-    plan = ops.sa_plan(idx_g, P, dims, ws) if PACKED else None
+    plan = ops.sa_plan(idx_g, xyz, centers, dims, ws) if PACKED else None
 
     def run(n):
         for _ in range(n):
             if PACKED:
-                pl = ops.sa_plan(idx_g, P, dims, ws)
-                arg = ops.sa_fwd_packed(xyz, centers, pl, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
-                ops.sa_bwd_packed(xyz, centers, pl, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws, h2)
+                pl = ops.sa_plan(idx_g, xyz, centers, dims, ws) if os.environ.get('SA_PLAN_EACH', '0') == '1' else plan
+                arg = ops.sa_fwd_packed(pl, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
+                ops.sa_bwd_packed(pl, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws, h2)
             else:
                 arg = ops.sa_fwd(xyz, centers, idx_g, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
                 ops.sa_bwd(xyz, centers, idx_g, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws, h2)
@@ -52,7 +52,7 @@ for name, P, S, radius, dims, cf in LEVELS:
     run(5)
     f = ops.TIMER.mean_ms(nf)[0]
     b = ops.TIMER.mean_ms(nb)[0]
-    pt = ops.TIMER.mean_ms("sa_plan")[0] if PACKED else 0.0
+    pt = (ops.TIMER.mean_ms("sa_plan") or [0.0])[0] if PACKED else 0.0
     ops.TIMER.disable()
     rows = B * S * 32
     if PACKED:
