@@ -530,6 +530,10 @@ class PointNet2(_HipNet):
                 plan = ops.sa_plan(idx_g, xyz, centers, dims, self._workspace(xyz.device))
                 if cache is not None:                      # a sequential mini-batch of a cached rollout: both networks and
                     cache[key] = plan.trim()               # every epoch reuse it (one host read of the row / tile counts)
+                    plan.ready = torch.cuda.Event()
+                    plan.ready.record()
+            elif plan.ready is not None:                   # built on another stream (actor || critic): its tables must be complete
+                torch.cuda.current_stream().wait_event(plan.ready)
             arg = ops.sa_fwd_packed(plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
                                     packed, dims, pooled, h2)
         else:

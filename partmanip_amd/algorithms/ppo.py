@@ -105,7 +105,10 @@ class ppo:
         # default to the reference's serial order.  PARTMANIP_OVERLAP=0/1 overrides.
         ov = os.environ.get("PARTMANIP_OVERLAP")
         is_mlp = self.model_cfg['network']['name'] == 'MLP'
-        self.overlap = (ov == "1") if ov in ("0", "1") else is_mlp
+        # (round 4) PointNet++ too: since its set-abstraction levels run over the distinct rows only, a network step is ~25 launches
+        # of 0.1-1.6 ms whose persistent work-groups end ragged -- the other network's launches fill the tails: 27.1 k -> 29.6 k
+        # env-steps/s at cfg 3's shape (alternating A/B runs on one box)
+        self.overlap = (ov == "1") if ov in ("0", "1") else (is_mlp or self.model_cfg['network']['name'] == 'PointNet2')
         # hipGraph replay of the per-mini-batch launch chains: the MLP step is ~24 kernels of 5-15 us, i.e.
         # host-launch-bound (3.7 us per launch measured).  Needs constant kernel arguments per step: sequential
         # sampler (slices of persistent storage), a fixed learning rate, no collective inside the chain.

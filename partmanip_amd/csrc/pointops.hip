@@ -529,6 +529,9 @@ extern "C" int pm_version(void) { return PM_ABI_VERSION; }
 #define FM_RPT 16             // measured per depth2pc call (64 envs x ~134 k points, K = 1024): 8: 14.6 ms, 12: 11.3, 14: 10.0, 16: 8.9,
 #endif                        // 20: 12.1, 24: 15.1 -- beyond 16 the 4 x FM_RPT point registers spill (128-VGPR budget at 1024 threads)
 #define FM_LDS 8192
+#ifndef FM_STR_U
+#define FM_STR_U 4            // streamed points per thread and trip (A/B: 8 halves the dependent round trips of the streamed pass)
+#endif
 #define FM_MAXG 8
 #define FM_SPIN_LIMIT (1u << 20)   // polls a work-group may spend waiting for partners over the WHOLE launch (~1 s); normal: a few thousand
 typedef unsigned long long fm_u64;
@@ -608,16 +611,16 @@ __global__ __launch_bounds__(FPS_NT) void fps_multi_kernel(const float* __restri
                 bi = lo + n_reg + l;
             }
         }
-        for (int l0 = tid; l0 < n_str; l0 += 4 * FPS_NT) {          // four points per trip, their loads issued back to back
-            float q[4][3], mo[4];
+        for (int l0 = tid; l0 < n_str; l0 += FM_STR_U * FPS_NT) {   // FM_STR_U points per trip, their loads issued back to back
+            float q[FM_STR_U][3], mo[FM_STR_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < FM_STR_U; ++u) {
                 const int l = l0 + u * FPS_NT, lc = l < n_str ? l : l0;
                 q[u][0] = pstr[(long)lc * 3]; q[u][1] = pstr[(long)lc * 3 + 1]; q[u][2] = pstr[(long)lc * 3 + 2];
                 mo[u] = mind_g[lc];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < FM_STR_U; ++u) {
                 const int l = l0 + u * FPS_NT;
                 if (l < n_str) {
                     const float m = fminf(mo[u], dist2_rn(q[u], s, 3));

@@ -28,6 +28,12 @@ class KernelTimer:
         self.enabled = set(names)
         self.events = {n: [] for n in names}
 
+    def add(self, *names):
+        """Enable more names without dropping the events collected so far."""
+        self.enabled |= set(names)
+        for n in names:
+            self.events.setdefault(n, [])
+
     def disable(self):
         self.enabled = set()
 
@@ -706,7 +712,7 @@ def sa_bwd(xyz, centers, idx, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpoo
 # ---- duplicate-free ("packed") form: the level over each group's DISTINCT rows (ball query pads with copies of the first hit)
 class SaPlan:
     """Packed-row tables of one neighbourhood table (pm_sa_plan_i32): nothing here is read by the host."""
-    __slots__ = ("grow", "rowmap", "relxyz", "tiles", "totals", "B", "P", "S", "ns", "dims")
+    __slots__ = ("grow", "rowmap", "relxyz", "tiles", "totals", "B", "P", "S", "ns", "dims", "ready")
 
     def counts(self):
         """(packed rows, tiles) -- a host read; diagnostics / buffer sizing only."""
@@ -740,6 +746,7 @@ def sa_plan(idx, xyz, centers, dims, ws):
     tr, tg = sa_packed_tile(dims)
     G = B * S
     pl = SaPlan()
+    pl.ready = None                       # set by a caller that shares the plan between streams (an event recorded after the build)
     pl.B, pl.P, pl.S, pl.ns, pl.dims = B, P, S, ns, tuple(dims)
     dev = idx.device
     pl.grow = torch.empty(G + 1, dtype=torch.int32, device=dev)
