@@ -452,10 +452,13 @@ __device__ __forceinline__ void g2_gather_first(const Gemm2Prob& g, int r0, int 
 // tile half of every MFMA multiplies columns that do not exist); 1: 1 x 4 (tile 32 WM x 128 WN)
 // for problems with at most 32 rows (the weight gradient of a 32-channel convolution over millions of rows: on the 2 x 2 layout
 // half of every MFMA multiplies rows that do not exist -- 6.5 ms per launch at 142 TFLOP/s of ISSUED work, 71 of useful).
-template <int WM, int WN, int LAY>
+// NB: LDS stages of the operand ring.  3 keeps two tiles in flight; 2 (one in flight, requested a whole K-step = 4096 MFMA
+// cycles ahead) shrinks the 128 x 128 tile from 98 KB to its 68 KB epilogue image: TWO work-groups per CU, i.e. a second
+// multiplying wave per SIMD that runs while the first sits at a barrier or waits for a fragment.
+template <int WM, int WN, int LAY, int NB = 3>
 struct G2DmaShape {
     static constexpr int TM = LAY == 2 ? 128 * WM : (LAY ? 32 * WM : 64 * WM), TN = LAY == 2 ? 32 * WN : (LAY ? 128 * WN : 64 * WN);
-    static constexpr int NBUF = 3;
+    static constexpr int NBUF = NB;
     static constexpr int ABUF = TM * 32, BBUF = TN * 32;
     static constexpr int EPI = TM * (TN + 4);                              // the epilogue's staging image
     static constexpr int LDSF = NBUF * (ABUF + BBUF) > EPI ? NBUF * (ABUF + BBUF) : EPI;
@@ -463,13 +466,14 @@ struct G2DmaShape {
 
 // One work-group tile (tm, tn, slab z) of problem g: the whole K loop + epilogue.  AUXA: cache policy of the A-operand loads,
 // SC1C: write-through result stores (both for tiles that hand data to / take data from other work-groups of the same launch).
-template <bool A_KM, bool B_KM, int WM, int WN, bool GATHER, int LAY, int AUXA, bool SC1C>
+template <bool A_KM, bool B_KM, int WM, int WN, bool GATHER, int LAY, int AUXA, bool SC1C, int NB = 3>
 __device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Prob& g, int tm, int tn, int z, float* __restrict__ lds) {
     // 8 waves: waves 0-3 multiply (one per SIMD), waves 4-7 only feed the LDS ring.  Issuing one
     // 1 KiB LDS-DMA costs the issuing wave ~90 cycles (measured: 4 of them in front of a half-step's MFMAs stretched it from
     // 512 to 885 cycles) and an in-order wave cannot issue MFMAs meanwhile -- a second wave on the SIMD can.
-    using SH = G2DmaShape<WM, WN, LAY>;
+    using SH = G2DmaShape<WM, WN, LAY, NB>;
     constexpr int TM = SH::TM, TN = SH::TN, NBUF = SH::NBUF, ABUF = SH::ABUF, BBUF = SH::BBUF;
+    static_assert(NB == 3 || (NB == 2 && !GATHER), "the two-stage ring is built for plain operands");
     constexpr int IPT = (TM + TN) / 32;                                    // DMA instructions per tile per loader wave
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
     const bool loader = tid >= 256;
@@ -523,6 +527,19 @@ __device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Pro
         }
         // the counted waits allow for the NGI index loads an issue() ends with
         constexpr int NW1 = IPT + (GATHER ? NGI : 0);
+        if constexpr (NB == 2) {
+            // two stages: tile k + 1 is requested at the top of K-step k (its buffer's readers passed the last barrier) and must have
+            // landed at the step's end -- nothing else stays in flight
+            issue(0, gia);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+            for (int k = 0; k < nk; ++k) {
+                issue(k + 1, gia);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        } else {
         issue(0, gia);
         issue(1, gib);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW1) : "memory");         // tile 0 has landed (this wave's pieces)
@@ -539,6 +556,7 @@ __device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Pro
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the tail loads must not land in the epilogue's image
+        }
     } else {
         G2Frag<WM> xa, ya;
         G2Frag<WN> xb, yb;
@@ -596,9 +614,9 @@ __device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Pro
     G2_STAMP(3);
 }
 
-template <bool A_KM, bool B_KM, int WM, int WN, bool GATHER = false, int LAY = 0>
+template <bool A_KM, bool B_KM, int WM, int WN, bool GATHER = false, int LAY = 0, int NB = 3>
 __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
-    __shared__ __attribute__((aligned(1024))) float lds[G2DmaShape<WM, WN, LAY>::LDSF];
+    __shared__ __attribute__((aligned(1024))) float lds[G2DmaShape<WM, WN, LAY, NB>::LDSF];
 #ifdef G2_PROFILE
     if (gg.prof && threadIdx.x == 0) gg.prof[(size_t)blockIdx.x * 4] = __builtin_readcyclecounter();
 #endif
@@ -613,7 +631,7 @@ __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
     if ((nblk & 7) == 0) local = (local & 7) * (nblk >> 3) + (local >> 3);
     const int z = local / tiles, t = local - z * tiles;
     const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
-    g2_dma_body<A_KM, B_KM, WM, WN, GATHER, LAY, 0, false>(gg, g, tm, tn, z, lds);
+    g2_dma_body<A_KM, B_KM, WM, WN, GATHER, LAY, 0, false, NB>(gg, g, tm, tn, z, lds);
 }
 
 // =====================================================================================================================
@@ -771,6 +789,9 @@ int gemm2_chain_launch(Gemm2Chain& ch, bool b_kmajor, void* stream) {
 // (WM, WN) of a launch: 64 x 64 work-group tiles for small grids; for big ones 128 rows / columns only along a dimension some
 // problem actually extends past 64 -- a 128 x 128 tile on an N = 64 problem (the 64-channel sparse convolutions: 2.7 M rows,
 // K = 1728) spends half of its MFMAs on columns that do not exist.
+#ifndef G2_NBUF_DEFAULT
+#define G2_NBUF_DEFAULT 3
+#endif
 template <bool A_KM, bool B_KM, bool GATHER>
 static void g2_launch_dma(const Gemm2Group& g, int wm, int wn, int blocks, void* stream, bool lay1 = false, bool lay2 = false) {
     const dim3 grid(blocks), blk(512);
@@ -783,6 +804,17 @@ static void g2_launch_dma(const Gemm2Group& g, int wm, int wn, int blocks, void*
     if constexpr (!A_KM && !B_KM) {
         if (lay2) {
             hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 1, GATHER, 2>), grid, blk, 0, pm_stream(stream), g);
+            return;
+        }
+    }
+    if constexpr (!GATHER) {
+        static int nb2 = -1;                                               // PM_G2_NBUF=2: the two-stage ring for 128 x 128 tiles (A/B)
+        if (nb2 < 0) {
+            const char* e = getenv("PM_G2_NBUF");
+            nb2 = e ? atoi(e) : G2_NBUF_DEFAULT;
+        }
+        if (wm == 2 && wn == 2 && nb2 == 2) {
+            hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 2, false, 0, 2>), grid, blk, 0, pm_stream(stream), g);
             return;
         }
     }
