@@ -473,7 +473,7 @@ __device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Pro
     // 512 to 885 cycles) and an in-order wave cannot issue MFMAs meanwhile -- a second wave on the SIMD can.
     using SH = G2DmaShape<WM, WN, LAY, NB>;
     constexpr int TM = SH::TM, TN = SH::TN, NBUF = SH::NBUF, ABUF = SH::ABUF, BBUF = SH::BBUF;
-    static_assert(NB == 3 || (NB == 2 && !GATHER), "the two-stage ring is built for plain operands");
+    static_assert(NB == 3 || NB == 2, "two or three LDS stages");
     constexpr int IPT = (TM + TN) / 32;                                    // DMA instructions per tile per loader wave
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
     const bool loader = tid >= 256;
@@ -509,7 +509,7 @@ __device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Pro
         int gia[NGI], gib[NGI];
         auto issue = [&](int tile, int (&gi)[NGI]) __attribute__((always_inline)) {
             const int tt = min(tile, nk - 1), buf = tile % NBUF;
-            const int kt = kbeg + tt * G2_TK, ktn = kbeg + min(tile + 2, nk - 1) * G2_TK;
+            const int kt = kbeg + tt * G2_TK, ktn = kbeg + min(tile + (NB == 2 ? 1 : 2), nk - 1) * G2_TK;   // (two stages: ONE index set, refilled a tile ahead)
             if constexpr (GATHER && !A_KM) g2_dma_tile_gather<false, TM>(g, g.A, g.lda, m0, g.M, kt, ktn, As + buf * ABUF, wave, lane, gi);
             else g2_dma_tile<A_KM, TM, AUXA>(g.A, g.lda, m0, A_KM ? g.Mld : g.M, kt, As + buf * ABUF, wave, lane, g.K - 1);
             if constexpr (GATHER && A_KM) g2_dma_tile_gather<true, TN>(g, g.B, g.ldb, n0, g.N, kt, ktn, Bs + buf * BBUF, wave, lane, gi);
@@ -818,6 +818,15 @@ static void g2_launch_dma(const Gemm2Group& g, int wm, int wn, int blocks, void*
             return;
         }
     }
+#ifdef G2_TILE_ENV                                         // A/B builds only: PM_G2_NBUF=2 for every tile shape, gathered operands included
+    if (const char* e = getenv("PM_G2_NBUF"); e && atoi(e) == 2) {
+        if (wm == 2 && wn == 2) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 2, GATHER, 0, 2>), grid, blk, 0, pm_stream(stream), g);
+        else if (wm == 2) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 1, GATHER, 0, 2>), grid, blk, 0, pm_stream(stream), g);
+        else if (wn == 2) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 2, GATHER, 0, 2>), grid, blk, 0, pm_stream(stream), g);
+        else hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 1, GATHER, 0, 2>), grid, blk, 0, pm_stream(stream), g);
+        return;
+    }
+#endif
     if (wm == 2 && wn == 2) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 2, GATHER>), grid, blk, 0, pm_stream(stream), g);
     else if (wm == 2) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 1, GATHER>), grid, blk, 0, pm_stream(stream), g);
     else if (wn == 2) hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 1, 2, GATHER>), grid, blk, 0, pm_stream(stream), g);
