@@ -7,6 +7,12 @@ import raises, and every op refuses non-GPU tensors (see ops.py).  Build the lib
 import ctypes as C
 import os
 
+# torch FIRST: its wheel bundles its own HIP runtime (torch/lib/libamdhip64.so) while this library links /opt/rocm's.  Whichever is
+# loaded first serves both; loaded in the other order (this library before torch -- e.g. __graft_entry__.build() followed by
+# smoke() in one process) the process ends up with kernels registered in one runtime and torch's device context in the other, and
+# the first launch fails with hipErrorNoDevice (100).
+import torch  # noqa: F401,E402
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PARTMANIP_HIP_LIB") or os.path.join(HERE, "lib", "libpartmanip_hip.so")   # env: A/B kernel builds
 
