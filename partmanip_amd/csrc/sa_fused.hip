@@ -696,6 +696,9 @@ extern "C" int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32
 // Results are bit-identical to the dense kernels wherever those are deterministic (pooled, arg, the saved layer 2);
 // the weight gradients differ by fp32 summation order only (fewer, exactly-zero terms dropped).
 // The kernels read the tile count from device memory (persistent work-groups): no host synchronisation anywhere.
+#ifndef SA_PK_ABLATE
+#define SA_PK_ABLATE 0   // timing probes (wrong results): bwd 1 = no dW3, 2 = no dH2 MFMA, 4 = no layer-1 recompute, 8 = no P7, 16 = no dW2 / dH1 MFMA; fwd 32 = no pooling pass, 64 = no layer 2 / 3 MFMA
+#endif
 struct SaPk {
     const int32_t* grow;     // (G + 1)   first packed row of each group
     const int2* rowmap;      // (R)       {flat source point b*P + idx, local group << 8 | row inside the group}
@@ -912,8 +915,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_fwd_pk_kernel(SaArgs a, SaPk 
         const int wn = wave % NBW3, wm = wave / NBW3;
         f32x16 acc[MB3][NB3];
         zero_acc<MB3, NB3>(acc);
-        mfma_stream<MB3, NB3, NG3>(H2 + (wm * MB3 * 32 + li) * LD2 + lh * (C2 / 2), LD2,
-                                   P3v + (size_t)(wn * NB3) * NG3 * 64 + lane, acc);
+        if (!(SA_PK_ABLATE & 64))
+            mfma_stream<MB3, NB3, NG3>(H2 + (wm * MB3 * 32 + li) * LD2 + lh * (C2 / 2), LD2,
+                                       P3v + (size_t)(wn * NB3) * NG3 * 64 + lane, acc);
         if (a.h2) {                                          // training forward: keep H2 (packed rows) for the backward
 #pragma unroll 2
             for (int q = tid; q < TM * C2 / 4; q += NT) {
@@ -936,7 +940,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_fwd_pk_kernel(SaArgs a, SaPk 
             __syncthreads();
             const int s = tid % W3S, ch = ((s >> 5) * NB3 + nb) * 32 + (s & 31);
             const float bv = a.b3[ch];
-            for (int j = tid / W3S; j < td.z; j += NT / W3S) {
+            for (int j = tid / W3S; j < ((SA_PK_ABLATE & 32) ? 0 : td.z); j += NT / W3S) {
                 const int r0 = Ls[j], r1 = Ls[j + 1];
                 float best = Zs[r0 * LDZ + s];
                 int bi = 0;
@@ -1102,7 +1106,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         // ---- P1/P2: H1 recomputed, H2 stored (or recomputed) -----------------------------------------
-        sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
+        if (!(SA_PK_ABLATE & 4)) sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
         __builtin_amdgcn_sched_barrier(0);
         if (a.h2) {
 #pragma unroll
@@ -1151,7 +1155,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
             __syncthreads();                 // H1, H2 and this chunk's Val, Arg complete
             {   // dW3[c, :] += val * H2[row of the arg-max, :]   (VALU; the slice stays in registers for the whole kernel)
                 const int s = tid & 127, ks = tid >> 7;
-                for (int j = 0; j < td.z; ++j) {
+                for (int j = 0; j < ((SA_PK_ABLATE & 1) ? 0 : td.z); ++j) {
                     const float v = Val[j * LDV + s];
                     const int row = Ls[j] + ((const uint8_t*)ArgW)[j * (LDA * 4) + s];
                     const float* hrow = H2 + row * LD2 + ks * KS;
@@ -1184,7 +1188,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                 o.w = (int)(ab >> 24) == lr ? vv.w : 0.f;
                 return o;
             };
-            mfma_stream_fn_win<M2::MB, M2::NB, C3 / 8, 16>(asel, P3Tv + ((size_t)(wn2 * M2::NB) * (C3 / 8) + 16 * q) * 64 + lane, acc);
+            if (!(SA_PK_ABLATE & 2))
+                mfma_stream_fn_win<M2::MB, M2::NB, C3 / 8, 16>(asel, P3Tv + ((size_t)(wn2 * M2::NB) * (C3 / 8) + 16 * q) * 64 + lane, acc);
         }
         __syncthreads();                     // every wave is done with its dW3 reads of H2 rows
         // ---- P4: dZ2 = dH2 .* (1 - H2^2) -> D, db2 ---------------------------------------------------
@@ -1214,7 +1219,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
 #define SA_DW2_MMA(a_, b_) _Pragma("unroll") for (int j = 0; j < NBK; ++j) accW2[j] = MFMA(a_, b_[j], accW2[j]);
             SA_DW2_LOAD(ap, bp, 0)
 #pragma unroll 1
-            for (int s = 0; s < TM / 2; s += 2) {
+            for (int s = 0; s < ((SA_PK_ABLATE & 16) ? 0 : TM / 2); s += 2) {
                 SA_DW2_LOAD(aq, bq, s + 1)
                 SA_DW2_MMA(ap, bp)
                 SA_DW2_LOAD(ap, bp, s + 2)          // last trip reads one row past this half: discarded
@@ -1228,8 +1233,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
             const int wn = wave % MH::NBW, wm = wave / MH::NBW;
             f32x16 accH[MH::MB][MH::NB];
             zero_acc<MH::MB, MH::NB>(accH);
-            mfma_stream<MH::MB, MH::NB, NGT>(D + (wm * MH::MB * 32 + li) * LD2 + lh * (C2 / 2), LD2,
-                                             P2Tv + (size_t)(wn * MH::NB) * NGT * 64 + lane, accH);
+            if (!(SA_PK_ABLATE & 16))
+                mfma_stream<MH::MB, MH::NB, NGT>(D + (wm * MH::MB * 32 + li) * LD2 + lh * (C2 / 2), LD2,
+                                                 P2Tv + (size_t)(wn * MH::NB) * NGT * 64 + lane, accH);
             __syncthreads();
 #pragma unroll
             for (int nb = 0; nb < MH::NB; ++nb)
@@ -1248,7 +1254,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
         {
             constexpr int PARTS = NT / C1, RPT = TM / PARTS;
             const int c = tid % C1, p0 = (tid / C1) * RPT;
-            const int p1 = p0 + RPT < td.w ? p0 + RPT : td.w;
+            const int p1 = (SA_PK_ABLATE & 8) ? p0 : (p0 + RPT < td.w ? p0 + RPT : td.w);
 #pragma unroll 4
             for (int p = p0; p < p1; ++p) {
                 const float z = H1[p * LD1 + c];
