@@ -523,7 +523,7 @@ class PointNet2(_HipNet):
                 buf = self._sa_h2[l] = torch.empty(n, device=xyz.device)
             h2 = buf[:n]
         plan = None
-        if self.unique_rows:
+        if self.unique_rows and centers.shape[1] <= 1024:      # (the plan's per-cloud pass holds up to 1024 groups; more: the padded kernels)
             cache, key = plan_slot if plan_slot is not None else (None, None)
             plan = cache.get(key) if cache is not None else None
             if plan is None:
