@@ -352,38 +352,50 @@ def run_depth2pc(args, device):
                            baseline="'~0.5s' for the sampling alone, utils/depth2tsdf.py:158 (BASELINE.md); "
                                     "vs_baseline = sampling time / 0.5 s"))
     # dominant kernel: farthest-point sampling on G = 256 / envs work-groups per cloud (csrc/pointops.hip: fps_multi_kernel): each keeps
-    # 16 384 points of its chunk in registers and 8 192 in LDS for all K rounds; only the remainder re-reads its points (12 B) and
-    # running min-distance (4 B + 4 B back) every round
+    # 25 600 points of its chunk in registers (512 threads x 50) and 10 176 in LDS for all K rounds; only a remainder beyond those
+    # 35 776 re-reads its points (12 B) and running min-distance (4 B + 4 B back) every round
+    on_reg, on_lds = (512 * 50, 10176) if os.environ.get("PM_FM_CFG", "1") != "0" else (1024 * 16, 8192)
     nn = n0.to(torch.int64).cpu()
     G = max(1, min(8, 256 // b))
     chunk = (nn + G - 1) // G
     big = nn > 8192
-    streamed = torch.where(big, (chunk - 16384 - 8192).clamp(min=0) * G, nn.clamp(min=0) * 0).sum().item() if G >= 2 else float(nn[big].sum())
+    streamed = torch.where(big, (chunk - on_reg - on_lds).clamp(min=0) * G, nn.clamp(min=0) * 0).sum().item() if G >= 2 else float(nn[big].sum())
     pts = float(nn.sum().item())
     impl_bytes = 1024.0 * streamed * 20.0 + pts * 12.0          # what THIS implementation moves: the streamed remainder, every round
     algo_bytes = pts * 12.0 + b * 1024 * 4.0                      # the operator's own traffic: every candidate point once in, K indices out
     gbs = algo_bytes / dfps / 1e9
-    # FPS is K = 1024 DEPENDENT rounds: round j's arg-max is round j + 1's reference point.  A round cannot be shorter than one
-    # hand-off between the cloud's work-groups (drained write-through store + flag sweep: MI355X_MICROARCH.md price list,
-    # "handoff-flag", 1.3 us on an idle chip) plus the dependent chain inside a work-group (distance update -> 6-step wave
-    # butterfly -> LDS pass over 16 waves -> barrier, ~0.5 us): that latency floor, not the HBM roofline, bounds the launch.
-    floor_us = 1.8
+    # FPS is K = 1024 DEPENDENT rounds: round j's arg-max is round j + 1's reference point.  A round cannot be shorter than
+    #  (1) the distance update of the largest chunk on ONE CU (G x B = 256 work-groups: one CU each).  Exact fp32, op by op as the
+    #      reference rounds (3 sub, 3 mul, 2 add -- no FMA) = 8 packed-fp32 instructions per PAIR of points, + 2 min + 1 max3:
+    #      5.5 VALU issue slots per point at the packed-fp32 rate the 157 TF vector peak assumes.  (Measured here packed fp32 runs
+    #      at HALF that rate -- the scalar form of the same sweep takes the same time, profiles/round4_h_fps_multi_ab.txt -- i.e.
+    #      9.5 slots per point, 2.07 us: `distance_update_valu_as_measured`.)  4 cycles per slot per 64 points per SIMD, 4 SIMDs;
+    #  (2) one hand-off between the cloud's work-groups (drained write-through store + flag sweep: MI355X_MICROARCH.md price list,
+    #      "handoff-flag", 1.3 us on an idle chip);
+    #  (3) the dependent chain inside a work-group (wave maximum -> LDS -> barrier -> index recovery -> barrier, ~0.5 us).
+    # That latency floor, not the HBM roofline, bounds the launch.
+    sweep_us = float(chunk.max().item()) * 5.5 * 4.0 / 256.0 / 2400.0
+    floor_us = sweep_us + 1.3 + 0.5
     out["roofline"] = dict(bound="hbm", kernel="fps_multi_kernel (on-chip chunks, streamed remainder)", achieved=gbs, peak=PEAK_HBM_GBS,
                            unit="GB/s", frac=gbs / PEAK_HBM_GBS, traffic=_hbm_traffic("fps_multi_kernel_bytes_per_launch")[0],
                            algorithmic_bytes=algo_bytes, mean_launch_ms=dfps * 1e3,
                            latency=dict(rounds=1024, us_per_round=dfps * 1e6 / 1024.0, floor_us_per_round=floor_us,
                                         frac_of_floor=floor_us / (dfps * 1e6 / 1024.0),
-                                        note="K dependent rounds; floor = one cross-work-group hand-off (1.3 us, MI355X_MICROARCH.md "
+                                        floor_parts_us=dict(distance_update_valu=sweep_us, hand_off=1.3, work_group_arg_max=0.5,
+                                                            distance_update_valu_as_measured=sweep_us * 9.5 / 5.5),
+                                        note="K dependent rounds; floor = the exact-fp32 distance update of the largest chunk on one CU "
+                                             "(5.5 VALU slots per point at the nominal packed-fp32 rate) + one cross-work-group hand-off (1.3 us, MI355X_MICROARCH.md "
                                              "'handoff-flag') + the in-work-group arg-max chain (~0.5 us)"),
                            implementation=dict(streamed_bytes_per_launch=impl_bytes, streamed_gbs=impl_bytes / dfps / 1e9,
                                                points=pts, points_streamed_per_round=float(streamed),
+                                               points_on_chip_per_work_group=on_reg + on_lds,
                                                one_work_group_per_cloud_bytes=1024.0 * pts * 20.0,
-                                               note="points that fit neither the registers (16 384 per work-group) nor LDS (8 192) are "
+                                               note=f"points that fit neither the registers ({on_reg} per work-group) nor LDS ({on_lds}) are "
                                                     "re-read every round (12 B + the running minimum 4 B in, 4 B out), mostly out of L2 / "
                                                     "Infinity Cache: `traffic` (PMC, HBM side) is what reaches memory"),
                            note="`achieved` = the operator's algorithmic bytes (each candidate point once, K indices out) over the launch "
                                 "time: a latency-bound sampler sits far below the HBM roofline by construction -- `latency` is the bound "
-                                "that applies; `traffic` / `algorithmic_bytes` shows the re-reads of the streamed remainder")
+                                "that applies; `traffic` / `algorithmic_bytes` shows what reaches HBM beyond reading the cloud once")
     if not args.no_cpu_baseline:
         from oracle import ref_cpu as R
         ncpu = os.cpu_count() or 1

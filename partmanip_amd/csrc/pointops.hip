@@ -2,6 +2,7 @@
 // Integer-index outputs: bit-exact against the CPU restatement used by the tests (same fp32 distance
 // expression ((dx*dx)+dy*dy)+dz*dz with no FMA contraction, same tie-breaks).
 // The reference tree holds no implementation of these: parity unpinned.
+#include <type_traits>
 #include "common.h"
 #include <stdlib.h>
 
@@ -519,136 +520,258 @@ extern "C" int pm_version(void) { return PM_ABI_VERSION; }
 // L2 / Infinity Cache in each of the K rounds -- 176 GB per depth2pc call at 64 envs x 134 k points, 2.8 TB/s from the 64
 // CUs that one work-group per env occupies.  Here G work-groups share a cloud (G * B <= the CU count, so that
 // all of them are resident) and each keeps ITS chunk of the cloud ON CHIP for all K rounds: FM_RPT points per thread in
-// registers (x, y, z, min-distance: 64 VGPRs), the next FM_LDS points in LDS (128 KB), only what is left streams (four
-// points per trip).  A round is then ~33 distance updates per thread, a work-group arg-max (as before) and ONE hand-off between the G work-groups of the
-// cloud: each publishes its (distance, index) candidate as two 8-byte {round, value} granules (agent-scope atomic stores:
-// write-through, the data IS the flag -- MI355X_MICROARCH.md form R2), one wave of every work-group sweeps the 2 G granules
-// of its cloud until all carry this round's tag, and every work-group takes the same lowest-index arg-max.  Same fp32
-// distance expression and tie-breaks as fps_body: bit-identical indices.
-#ifndef FM_RPT
-#define FM_RPT 16             // measured per depth2pc call (64 envs x ~134 k points, K = 1024): 8: 14.6 ms, 12: 11.3, 14: 10.0, 16: 8.9,
-#endif                        // 20: 12.1, 24: 15.1 -- beyond 16 the 4 x FM_RPT point registers spill (128-VGPR budget at 1024 threads)
-#define FM_LDS 8192
+// registers (x, y, z, min-distance: 4 x FM_RPT VGPRs), the next FM_LDS points in LDS, only what is left streams (four
+// points per trip).  A round is the distance update of the chunk, a work-group arg-max and ONE hand-off between the G
+// work-groups of the cloud: each publishes its candidate -- value, index, coordinates -- as five 8-byte {round, word} granules
+// (agent-scope atomic stores: write-through, the data IS the flag -- MI355X_MICROARCH.md form R2), one wave of every work-group
+// sweeps the granules of its cloud until all carry this round's tag, and every work-group takes the same lowest-index arg-max.
+// Same fp32 distance expression and tie-breaks as fps_body: bit-identical indices.
+//
+// Shape (per depth2pc call, 64 envs x ~134 k points, K = 1024; profiles/round4_h_fps_multi_ab.txt):
+//   1024 threads x 16 points + 8 192 in LDS, (value, index) carried through the sweep      8.9 ms   (rounds 2-3)
+//   the same with packed-fp32 distances                                                    9.0      (v_pk_*_f32 is NOT double rate here)
+//   512 x 48 + 9 728: no streamed pass                                                     7.7
+//   + the winner's coordinates inside the hand-off (no load, one barrier less)             7.7      (no gain alone)
+//   + value-only sweep, index recovered afterwards (fm_min / fm_max3 below)                5.7
+//   512 x 50 + 10 176 (253 VGPRs, no spill; 35 776 points on chip)                         5.6
+#define FM_NT 512
+#define FM_RPT 50
+#define FM_LDS 10176
 #ifndef FM_STR_U
 #define FM_STR_U 4            // streamed points per thread and trip (A/B: 8 halves the dependent round trips of the streamed pass)
 #endif
 #define FM_MAXG 8
+#define FM_GRAN 8             // 64-bit words per work-group and set: value, index, x, y, z of its candidate (+3 pad: one 64-byte line)
+#define FM_SLOT_WORDS (2 * 256 * FM_GRAN)     // two sets x <= 256 work-groups; the error word sits right behind them
 #define FM_SPIN_LIMIT (1u << 20)   // polls a work-group may spend waiting for partners over the WHOLE launch (~1 s); normal: a few thousand
 typedef unsigned long long fm_u64;
-template <bool PAD>
-__global__ __launch_bounds__(FPS_NT) void fps_multi_kernel(const float* __restrict__ xyz, int ld, int K,
-                                                            const int32_t* __restrict__ lengths, int32_t* __restrict__ idx_out,
-                                                            float* __restrict__ mind_ws, fm_u64* __restrict__ slots, int G,
-                                                            unsigned spin_limit) {
-    extern __shared__ __attribute__((aligned(16))) float fm_lds[];           // [FM_LDS][4]: x, y, z, min-distance
-    __shared__ float sv[FPS_NT / 64];
-    __shared__ int si[FPS_NT / 64];
+// NT threads, RPT points per thread in registers, LP points in LDS (16 B each, structure of arrays).  (1024, 16, 8192): four waves
+// per SIMD, 24 576 points on chip; (512, 44 | 48, 9728): two waves per SIMD with 256 registers each, 32 256 | 34 304 points on chip
+// -- a quarter of a 134 k-point cloud then needs (almost) no streamed pass (`PM_FM_CFG`; bench.py --workload depth2pc).
+//
+// The sweep carries VALUES only.  Per pair of points: 8 packed-fp32 instructions for the two squared distances (v_pk_add / v_pk_mul:
+// IEEE per element, no contraction under -ffp-contract=off, so the sums keep the reference's op-by-op rounding), two v_min, one
+// v_max3 -- 5.5 instructions per point against 12 with an (value, index) pair carried through every point (compare, two selects,
+// a range predicate, the canonicalising v_max the compiler puts in front of fminf).  The index is recovered AFTERWARDS, by the few
+// threads whose own maximum equals the work-group's: their first point (ascending index) holding that value, an LDS atomic min
+// over those.  Lowest index among equal values, as fps_body: bit-identical indices.
+typedef float fm_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fm_f32x2 fm_dist2_pk(fm_f32x2 x, fm_f32x2 y, fm_f32x2 z, const float* s) {
+    const fm_f32x2 tx = x - (fm_f32x2){s[0], s[0]}, ty = y - (fm_f32x2){s[1], s[1]}, tz = z - (fm_f32x2){s[2], s[2]};
+    fm_f32x2 d = tx * tx;
+    d = d + ty * ty;
+    d = d + tz * tz;
+    return d;
+}
+// min / max of values that are never NaN on the right (a NaN distance leaves the running minimum alone, as fminf does)
+__device__ __forceinline__ float fm_min(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fm_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// maximum over the wave, in every lane: four DPP steps inside each row of 16 (quad swaps, half-row and row mirrors -- VALU
+// operand modifiers, no LDS round trip as in __shfl_xor), then the four row results through scalar registers
+__device__ __forceinline__ float fm_wave_max(float v) {
+#define FM_DPP_MAX(CTRL) v = fm_max3(v, v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)))
+    FM_DPP_MAX(0xB1);     // quad_perm [1, 0, 3, 2]
+    FM_DPP_MAX(0x4E);     // quad_perm [2, 3, 0, 1]
+    FM_DPP_MAX(0x141);    // row_half_mirror
+    FM_DPP_MAX(0x140);    // row_mirror
+#undef FM_DPP_MAX
+    const int vi = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+// loops over the register-resident points are unrolled by TEMPLATE (constant indices from the first optimisation pass on): with a
+// `#pragma unroll` loop the arrays are still memory when the branch tree of fm_pick is simplified, the tree's reads get folded into
+// one dynamically indexed read, and the arrays then stay in scratch for the sweep as well (24 scratch loads per round, measured)
+template <int I, int N, int STEP, class F>
+__device__ __forceinline__ void fm_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        fm_static_for<I + STEP, N, STEP>(f);
+    }
+}
+// px[r], py[r], pz[r] for a wave-uniform r: a binary search of scalar branches over statically indexed registers
+template <int LO, int HI, int RPT>
+__device__ __forceinline__ void fm_pick(const float (&px)[RPT], const float (&py)[RPT], const float (&pz)[RPT], int r, float& x, float& y, float& z) {
+    if constexpr (HI - LO == 1) {
+        x = px[LO]; y = py[LO]; z = pz[LO];
+        asm volatile("" : "+v"(x), "+v"(y), "+v"(z));    // keeps the leaves' reads apart: merged, they become ONE dynamically indexed read
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (r < MID) fm_pick<LO, MID, RPT>(px, py, pz, r, x, y, z);
+        else fm_pick<MID, HI, RPT>(px, py, pz, r, x, y, z);
+    }
+}
+template <bool PAD, int NT, int RPT, int LP>
+__global__ __launch_bounds__(NT) void fps_multi_kernel(const float* __restrict__ xyz, int ld, int K,
+                                                       const int32_t* __restrict__ lengths, int32_t* __restrict__ idx_out,
+                                                       float* __restrict__ mind_ws, fm_u64* __restrict__ slots, int G,
+                                                       unsigned spin_limit) {
+    extern __shared__ __attribute__((aligned(16))) float fm_lds[];           // x[LP], y[LP], z[LP], min-distance[LP]
+    static_assert(RPT % 2 == 0 && LP % 2 == 0, "points are paired for the packed distance");
+    float* const lx = fm_lds;
+    float* const ly = lx + LP;
+    float* const lz = ly + LP;
+    float* const lm = lz + LP;
+    __shared__ float sv[NT / 64];
     __shared__ float sel[4];
+    __shared__ int s_idx;                                // the work-group's winning index of the round (atomic min of the candidates)
     __shared__ int s_cur;
     __shared__ int s_dead;                               // latched give-up: the whole work-group leaves at the end of the round
-    if (threadIdx.x == 0) s_dead = 0;
+    if (threadIdx.x == 0) {
+        s_dead = 0;
+        s_idx = 0x7fffffff;
+    }
     unsigned spent = 0;                                  // polls spent waiting, CUMULATIVE over the launch (one budget, not one per round)
     const int b = blockIdx.x / G, g = blockIdx.x - b * G, tid = threadIdx.x;
     const int n = lengths[b];
     const float* pts = xyz + (long)b * ld * 3;
     int32_t* idx_b = idx_out + (long)b * K;
-    fm_u64* err = slots + 4 * 256;                        // fixed place (the last word of the reservation): the host reads it
+    fm_u64* err = slots + FM_SLOT_WORDS;                 // fixed place (the last word of the reservation): the host reads it
     if (n <= FPS_NT * FPS_RPT) return;                   // small / empty clouds: fps_varlen_kernel (launched beside this one) samples them
     const int chunk = (n + G - 1) / G, lo = g * chunk, hi = min(n, lo + chunk), cnt = max(hi - lo, 0);
-    const int n_reg = min(cnt, FPS_NT * FM_RPT), n_lds = min(cnt - n_reg, FM_LDS), n_str = cnt - n_reg - n_lds;
-    float px[FM_RPT], py[FM_RPT], pz[FM_RPT], md[FM_RPT];
-#pragma unroll
-    for (int r = 0; r < FM_RPT; ++r) {
-        const int l = tid + r * FPS_NT;
+    const int n_reg = min(cnt, NT * RPT), n_lds = min(cnt - n_reg, LP), n_str = cnt - n_reg - n_lds;
+    const int n_lds2 = (n_lds + 1) & ~1;                 // the LDS points are swept in pairs
+    // a slot beyond the chunk holds the running minimum -1: it stays -1 (every distance is >= 0) and never reaches a maximum
+    float px[RPT], py[RPT], pz[RPT], md[RPT];
+    fm_static_for<0, RPT, 1>([&](auto R) __attribute__((always_inline)) {
+        constexpr int r = decltype(R)::value;
+        const int l = tid + r * NT;
         const bool in = l < n_reg;
         const float* q = pts + (long)(lo + (in ? l : 0)) * 3;
         px[r] = in ? q[0] : 0.f; py[r] = in ? q[1] : 0.f; pz[r] = in ? q[2] : 0.f;
-        md[r] = INFINITY;
-    }
-    for (int l = tid; l < n_lds; l += FPS_NT) {
-        const float* q = pts + (long)(lo + n_reg + l) * 3;
-        *(float4*)(fm_lds + 4 * l) = make_float4(q[0], q[1], q[2], INFINITY);
+        md[r] = in ? INFINITY : -1.0f;
+    });
+    for (int l = tid; l < n_lds2; l += NT) {
+        const bool in = l < n_lds;
+        const float* q = pts + (long)(lo + n_reg + (in ? l : 0)) * 3;
+        lx[l] = in ? q[0] : 0.f; ly[l] = in ? q[1] : 0.f; lz[l] = in ? q[2] : 0.f;
+        lm[l] = in ? INFINITY : -1.0f;
     }
     float* mind_g = mind_ws + (long)b * ld + lo + n_reg + n_lds;             // streamed remainder
     const float* pstr = pts + (long)(lo + n_reg + n_lds) * 3;
-    for (int l = tid; l < n_str; l += FPS_NT) mind_g[l] = INFINITY;
+    for (int l = tid; l < n_str; l += NT) mind_g[l] = INFINITY;
     // TWO granule sets, used by alternate rounds: a work-group that has passed round j's sweep may publish round j + 1 while a
     // slower partner is still sweeping round j -- into the other set, so the sweep always finds round j's tags (nobody can be
-    // two rounds ahead: round j + 1's sweep needs every partner's round-j + 1 candidate)
-    fm_u64* my0 = slots + (long)blockIdx.x * 2;
-    const fm_u64* cloud0 = slots + (long)b * G * 2;
-    const long set_stride = (long)gridDim.x * 2;
+    // two rounds ahead: round j + 1's sweep needs every partner's round-j + 1 candidate).  A candidate is FIVE tagged words --
+    // value, index and the point's coordinates -- so the next round starts from the hand-off itself: no load of the winner's
+    // coordinates in the K-round dependent chain.
+    fm_u64* my0 = slots + (long)blockIdx.x * FM_GRAN;
+    const fm_u64* cloud0 = slots + (long)b * G * FM_GRAN;
+    const long set_stride = (long)gridDim.x * FM_GRAN;     // <= 256 work-groups (all resident): FM_SLOT_WORDS covers both sets
     int cur = 0;
+    if (tid < 3) sel[tid] = pts[tid];
+    __syncthreads();
     for (int j = 0; j < K; ++j) {
         if (PAD && j >= n) {
             if (tid == 0 && g == 0) idx_b[j] = -1;
             continue;
         }
         if (tid == 0 && g == 0) idx_b[j] = cur;
-        if (tid < 3) sel[tid] = pts[(long)cur * 3 + tid];
-        __syncthreads();
         const float s[3] = {sel[0], sel[1], sel[2]};
         float bv = -1.0f;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int r = 0; r < FM_RPT; ++r) {
-            const int l = tid + r * FPS_NT;
-            const float q[3] = {px[r], py[r], pz[r]};
-            const float m = fminf(md[r], dist2_rn(q, s, 3));
-            md[r] = m;
-            if (l < n_reg && m > bv) {                   // strict: the lowest index inside the thread
-                bv = m;
-                bi = lo + l;
-            }
+        fm_static_for<0, RPT, 2>([&](auto R) __attribute__((always_inline)) {
+            constexpr int r = decltype(R)::value;
+            const fm_f32x2 d = fm_dist2_pk((fm_f32x2){px[r], px[r + 1]}, (fm_f32x2){py[r], py[r + 1]}, (fm_f32x2){pz[r], pz[r + 1]}, s);
+            md[r] = fm_min(md[r], d.x);
+            md[r + 1] = fm_min(md[r + 1], d.y);
+            bv = fm_max3(bv, md[r], md[r + 1]);
+        });
+        for (int l = 2 * tid; l < n_lds2; l += 2 * NT) {
+            const fm_f32x2 d = fm_dist2_pk(*(const fm_f32x2*)(lx + l), *(const fm_f32x2*)(ly + l), *(const fm_f32x2*)(lz + l), s);
+            fm_f32x2 m = *(const fm_f32x2*)(lm + l);
+            m.x = fm_min(m.x, d.x);
+            m.y = fm_min(m.y, d.y);
+            *(fm_f32x2*)(lm + l) = m;
+            bv = fm_max3(bv, m.x, m.y);
         }
-        for (int l = tid; l < n_lds; l += FPS_NT) {
-            float4 v = *(const float4*)(fm_lds + 4 * l);
-            const float q[3] = {v.x, v.y, v.z};
-            const float m = fminf(v.w, dist2_rn(q, s, 3));
-            fm_lds[4 * l + 3] = m;
-            if (m > bv) {
-                bv = m;
-                bi = lo + n_reg + l;
-            }
-        }
-        for (int l0 = tid; l0 < n_str; l0 += FM_STR_U * FPS_NT) {   // FM_STR_U points per trip, their loads issued back to back
+        for (int l0 = tid; l0 < n_str; l0 += FM_STR_U * NT) {   // FM_STR_U points per trip, their loads issued back to back
             float q[FM_STR_U][3], mo[FM_STR_U];
 #pragma unroll
             for (int u = 0; u < FM_STR_U; ++u) {
-                const int l = l0 + u * FPS_NT, lc = l < n_str ? l : l0;
+                const int l = l0 + u * NT, lc = l < n_str ? l : l0;
                 q[u][0] = pstr[(long)lc * 3]; q[u][1] = pstr[(long)lc * 3 + 1]; q[u][2] = pstr[(long)lc * 3 + 2];
                 mo[u] = mind_g[lc];
             }
 #pragma unroll
             for (int u = 0; u < FM_STR_U; ++u) {
-                const int l = l0 + u * FPS_NT;
+                const int l = l0 + u * NT;
                 if (l < n_str) {
-                    const float m = fminf(mo[u], dist2_rn(q[u], s, 3));
+                    const float m = fm_min(mo[u], dist2_rn(q[u], s, 3));
                     mind_g[l] = m;
-                    if (m > bv) {
-                        bv = m;
-                        bi = lo + n_reg + n_lds + l;
-                    }
+                    bv = fmaxf(bv, m);
                 }
             }
         }
-        const int wbi = block_argmax(bv, bi, sv, si);    // (sv[], si[] hold the per-wave candidates; every thread returns the winner's index)
-        // ---- hand-off between the G work-groups of this cloud (round tag j + 1: never 0, the slots are zeroed per call)
-        if (tid < 64) {
-            // this work-group's winning value: the wave candidate that carries the winning index
-            float wv = -1.0f;
-            for (int k = 0; k < FPS_NT / 64; ++k)
-                if (si[k] == wbi) wv = sv[k];
-            const fm_u64 tag = (fm_u64)(unsigned)(j + 1) << 32;
-            fm_u64* my = my0 + (j & 1) * set_stride;
-            const fm_u64* cloud = cloud0 + (j & 1) * set_stride;
-            if (tid == 0) {
-                __hip_atomic_store(my, tag | (fm_u64)__float_as_uint(wv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(my + 1, tag | (fm_u64)(unsigned)wbi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- the work-group's maximum ...
+        const float wv = fm_wave_max(bv);
+        if ((tid & 63) == 0) sv[tid >> 6] = wv;
+        __syncthreads();
+        float wmax = sv[0];
+#pragma unroll
+        for (int k = 1; k < NT / 64; ++k) wmax = fmaxf(wmax, sv[k]);
+        // ... and the lowest index holding it: only threads whose own maximum IS the work-group's look (their points in ascending order)
+        int mine = 0x7fffffff, mr = 0;
+        if (bv == wmax && wmax >= 0.0f) {
+            int rr = -1;
+            fm_static_for<0, RPT, 1>([&](auto R) __attribute__((always_inline)) {
+                constexpr int r = RPT - 1 - decltype(R)::value;        // descending: the lowest matching r stays
+                if (md[r] == wmax) rr = r;
+            });
+            if (rr >= 0) {
+                mine = lo + tid + rr * NT;
+                mr = rr;
+            } else {
+                for (int l = 2 * tid; l < n_lds2 && mine == 0x7fffffff; l += 2 * NT) {
+                    if (lm[l] == wmax) mine = lo + n_reg + l;
+                    else if (lm[l + 1] == wmax) mine = lo + n_reg + l + 1;
+                }
+                for (int l = tid; l < n_str && mine == 0x7fffffff; l += NT)
+                    if (mind_g[l] == wmax) mine = lo + n_reg + n_lds + l;
             }
+            atomicMin(&s_idx, mine);
+        }
+        __syncthreads();
+        const int wbi = s_idx;
+        // ---- hand-off between the G work-groups of this cloud (round tag j + 1: never 0, the slots are zeroed per call)
+        const fm_u64 tag = (fm_u64)(unsigned)(j + 1) << 32;
+        fm_u64* my = my0 + (j & 1) * set_stride;
+        // the ONE thread that owns the winning point publishes it; a work-group without a candidate (empty chunk) publishes the
+        // losing value -1 from thread 0
+        if (mine == wbi && (wbi != 0x7fffffff || tid == 0)) {
+            float cx = 0.f, cy = 0.f, cz = 0.f;
+            if (wbi != 0x7fffffff) {
+                const int l = wbi - lo;
+                if (l < n_reg) {
+                    fm_pick<0, RPT, RPT>(px, py, pz, __builtin_amdgcn_readfirstlane(mr), cx, cy, cz);
+                } else if (l < n_reg + n_lds) {
+                    cx = lx[l - n_reg]; cy = ly[l - n_reg]; cz = lz[l - n_reg];
+                } else {
+                    const float* q = pstr + (long)(l - n_reg - n_lds) * 3;
+                    cx = q[0]; cy = q[1]; cz = q[2];
+                }
+            }
+            const float pv = wbi != 0x7fffffff ? wmax : -1.0f;
+            __hip_atomic_store(my, tag | (fm_u64)__float_as_uint(pv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(my + 1, tag | (fm_u64)(unsigned)wbi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(my + 2, tag | (fm_u64)__float_as_uint(cx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(my + 3, tag | (fm_u64)__float_as_uint(cy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(my + 4, tag | (fm_u64)__float_as_uint(cz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < 64) {
+            const fm_u64* cloud = cloud0 + (j & 1) * set_stride;
+            const bool word = tid < FM_GRAN * G && (tid & (FM_GRAN - 1)) < 5;
             fm_u64 x = 0;
             for (;;) {
-                x = tid < 2 * G ? __hip_atomic_load(cloud + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+                x = word ? __hip_atomic_load(cloud + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
                 if (__all((x >> 32) == (tag >> 32))) break;
                 // A partner is not resident / has given up: give up too, ONCE -- the flag is latched for the work-group and the
                 // error word tells every other work-group of the launch (they look at it every 64 polls) and the fallback launch
@@ -664,18 +787,26 @@ __global__ __launch_bounds__(FPS_NT) void fps_multi_kernel(const float* __restri
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            // lanes 2k / 2k+1 hold work-group k's value / index: the same lowest-index arg-max on every work-group
-            float cv = __uint_as_float((unsigned)__shfl(x, 0, 64));
-            int ci = (int)(unsigned)__shfl(x, 1, 64);
+            // lanes 8k .. 8k+4 hold work-group k's value / index / coordinates: the same lowest-index arg-max on every work-group
+            const int xl = (int)(unsigned)x;
+            int kw = 0;
+            float cv = __int_as_float(__builtin_amdgcn_readlane(xl, 0));
+            int ci = __builtin_amdgcn_readlane(xl, 1);
             for (int k = 1; k < G; ++k) {
-                const float ov = __uint_as_float((unsigned)__shfl(x, 2 * k, 64));
-                const int oi = (int)(unsigned)__shfl(x, 2 * k + 1, 64);
+                const float ov = __int_as_float(__builtin_amdgcn_readlane(xl, FM_GRAN * k));
+                const int oi = __builtin_amdgcn_readlane(xl, FM_GRAN * k + 1);
                 if (ov > cv || (ov == cv && oi < ci)) {
                     cv = ov;
                     ci = oi;
+                    kw = k;
                 }
             }
-            if (tid == 0) s_cur = ci;
+            const int wc = __shfl(xl, FM_GRAN * kw + (tid < 5 ? tid : 0), 64);     // lanes 2..4: the winner's x, y, z
+            if (tid >= 2 && tid < 5) sel[tid - 2] = __int_as_float(wc);
+            if (tid == 0) {
+                s_cur = ci;
+                s_idx = 0x7fffffff;                      // (every thread has read this round's; the candidates of the next come after its first barrier)
+            }
         }
         __syncthreads();
         if (s_dead) return;                              // gave up: no further sweeps, no further spinning (the fallback launch re-samples)
@@ -687,7 +818,7 @@ extern "C" size_t pm_fps_varlen_workspace_bytes(int B, int ld) {
     // running min-distances of the streamed part (clouds beyond the register-resident size) + the hand-off granules of the
     // several-work-groups-per-cloud kernel (two sets of 2 per work-group, <= 256 work-groups, + the error word), 8-byte aligned behind them
     const size_t mind = ld > FPS_NT * FPS_RPT ? (((size_t)B * ld * sizeof(float) + 7) & ~(size_t)7) : 0;
-    return mind + (mind ? (size_t)(4 * 256 + 1) * sizeof(fm_u64) : 0);
+    return mind + (mind ? (size_t)(FM_SLOT_WORDS + 1) * sizeof(fm_u64) : 0);
 }
 
 static int fps_cu_count() {
@@ -726,21 +857,27 @@ extern "C" int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, 
         const size_t mind = (((size_t)B * ld * sizeof(float) + 7) & ~(size_t)7);
         fm_u64* slots = (fm_u64*)((char*)workspace + mind);
         // round tags start at 1 and the give-up word is per call: the granules are cleared in front of every multi-work-group launch
-        if (hipMemsetAsync(slots, 0, (size_t)(4 * 256 + 1) * sizeof(fm_u64), pm_stream(stream)) != hipSuccess) return PM_EINVAL;
+        if (hipMemsetAsync(slots, 0, (size_t)(FM_SLOT_WORDS + 1) * sizeof(fm_u64), pm_stream(stream)) != hipSuccess) return PM_EINVAL;
         unsigned limit = FM_SPIN_LIMIT;
         const char* e = getenv("PM_FPS_SPIN_LIMIT");     // tests force the give-up path with a tiny budget
         if (e) limit = (unsigned)strtoul(e, nullptr, 10);
-        const size_t lds = (size_t)FM_LDS * 4 * sizeof(float);
-        if (pad) hipLaunchKernelGGL((fps_multi_kernel<true>), dim3(B * G), dim3(FPS_NT), lds, pm_stream(stream), xyz, ld, K, lengths,
-                                    idx_out, (float*)workspace, slots, G, limit);
-        else hipLaunchKernelGGL((fps_multi_kernel<false>), dim3(B * G), dim3(FPS_NT), lds, pm_stream(stream), xyz, ld, K, lengths,
-                                idx_out, (float*)workspace, slots, G, limit);
+        static int cfg = -1;                                 // PM_FM_CFG=0 (A/B): the 1024-thread x 16-point shape of rounds 2-3
+        if (cfg < 0) {
+            const char* c = getenv("PM_FM_CFG");
+            cfg = c ? atoi(c) : 1;
+        }
+#define FM_LAUNCH(PAD_, NT_, RPT_, LP_)                                                                                      \
+        hipLaunchKernelGGL((fps_multi_kernel<PAD_, NT_, RPT_, LP_>), dim3(B * G), dim3(NT_), (size_t)(LP_) * 16, pm_stream(stream), \
+                           xyz, ld, K, lengths, idx_out, (float*)workspace, slots, G, limit)
+        if (cfg == 0) { if (pad) FM_LAUNCH(true, 1024, 16, 8192); else FM_LAUNCH(false, 1024, 16, 8192); }
+        else { if (pad) FM_LAUNCH(true, FM_NT, FM_RPT, FM_LDS); else FM_LAUNCH(false, FM_NT, FM_RPT, FM_LDS); }
+#undef FM_LAUNCH
         // the clouds of the batch that fit one work-group's registers (decided per cloud on the device, no host sync on the lengths)
         hipLaunchKernelGGL(fps_varlen_kernel, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, ld, D, K, lengths, pad,
                            idx_out, (float*)workspace, 1, (const unsigned long long*)nullptr);
         // ... and, only if a work-group above gave up, the big clouds once more on one work-group each (returns at once otherwise)
         hipLaunchKernelGGL(fps_varlen_kernel, dim3(B), dim3(FPS_NT), 0, pm_stream(stream), xyz, ld, D, K, lengths, pad,
-                           idx_out, (float*)workspace, 2, (const unsigned long long*)(slots + 4 * 256));
+                           idx_out, (float*)workspace, 2, (const unsigned long long*)(slots + FM_SLOT_WORDS));
         PM_CHECK_LAUNCH();
         return PM_OK;
     }

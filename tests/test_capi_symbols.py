@@ -68,7 +68,7 @@ def test_argument_validation_without_gpu():
                                        None, None, None, None, None, None, 0, None) == -1
     assert lib.pm_pointnet_packed_bwd_bf6_bytes() == (3 * 4 * 16 * 64 * 8 + 4096) * 2
     assert lib.pm_fps_varlen_workspace_bytes(4, 8192) == 0
-    assert lib.pm_fps_varlen_workspace_bytes(4, 10000) == 160000 + (4 * 256 + 1) * 8
+    assert lib.pm_fps_varlen_workspace_bytes(4, 10000) == 160000 + (2 * 256 * 8 + 1) * 8    # two sets x 256 work-groups x 8 words + the error word
     assert lib.pm_fps_workspace_bytes(2, 1024) == 0 and lib.pm_fps_workspace_bytes(2, 20000) == 160000
 
 
