@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 144 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 145 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -511,6 +511,25 @@ int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const int32_t* gro
                          const int32_t* arg, const float* dpooled, long lddp, float* dW1, long lddw1, float* db1, float* dW2,
                          float* db2, float* dW3, float* db3, float* dY, const float* h2_saved, void* workspace,
                          size_t workspace_bytes, void* stream);
+
+/* ---- PointNet++ group-all level: its LAST layer fused with the max over the cloud (csrc/sa_groupall.hip) ----------------
+ * (BASELINE.json cfg 3's backbone; the reference ships no PointNet++ source -- `PointNet2` in algo_utils/network.py.)
+ *   feat[b][c] = max_r tanh(H[b*R + r][:] . W[c][:] + bias[c]),  argmax[b][c] = the lowest row r attaining it
+ * H: (B*R) x CK activations of the layer before (row-major, ld = CK), W: CO x CK.  Supported: CK = 256, CO = 512, R = 64
+ * (pm_sa_groupall_supported; callers fall back to pm_linear_fwd_f32 + pm_maxpool_rows_f32 otherwise).
+ * pack: W -> the MFMA operand order the forward streams (pm_sa_groupall_packed_elems floats); re-pack after every update.
+ * bwd: dz[b][c] = dfeat[b][c] * (1 - feat[b][c]^2);  dH[b*R + r][:] = (sum over c with argmax[b][c] == r of dz[b][c] * W[c][:]) * (1 - H^2)
+ * for EVERY row (rows without a winner: 0);  dW[c][:] = sum_b dz[b][c] * H[b*R + argmax[b][c]][:];  dbias[c] = sum_b dz[b][c].
+ * Fixed summation orders (run-to-run identical). */
+int pm_sa_groupall_supported(int CK, int CO, int R);
+size_t pm_sa_groupall_packed_elems(int CK, int CO);
+int pm_sa_groupall_pack_f32(const float* W, int CK, int CO, float* packed, void* stream);
+int pm_sa_groupall_fwd_f32(const float* H, int B, int R, int CK, int CO, const float* bias, const float* packed, float* feat, long ldf,
+                           int32_t* argmax, void* stream);
+size_t pm_sa_groupall_bwd_workspace_bytes(int B, int CK, int CO);
+int pm_sa_groupall_bwd_f32(const float* dfeat, long lddf, const float* feat, long ldf, const int32_t* argmax, const float* W,
+                           const float* H, int B, int R, int CK, int CO, float* dH, float* dW, float* dbias, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* ---- rollout side ------------------------------------------------------------------------
  * algorithms/algo_utils/actor_critic.py:36-47 `random_act_cri` after the two network forwards: x = mu + sigma^2 * eps

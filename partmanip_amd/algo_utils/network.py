@@ -484,6 +484,14 @@ class PointNet2(_HipNet):
         object.__setattr__(self, "_fused", [
             fused_ok and len(mlps[l]) == 3 and ops.sa_supported(*mlps[l], self.nsamples[l])
             for l in range(len(self.npoints))])
+        # group-all level: its last layer runs fused with the max over the cloud, the backward without the two dense GEMMs on
+        # the one-non-zero-per-(cloud, channel) gradient (csrc/sa_groupall.hip); `fused_groupall: False` keeps Linear + max-pool (A/B)
+        ga = mlps[-1]
+        object.__setattr__(self, "_ga_fused", bool(
+            fused_ok and net_cfg.get('fused_groupall', True) and len(ga) >= 2 and act == 'tanh'
+            and ops.sa_groupall_supported(ga[-2], ga[-1], self.npoints[-1])))
+        object.__setattr__(self, "_ga_chain", _LinearChain(chains[-1].linears[:-1], code, final_act=True) if self._ga_fused else None)
+        object.__setattr__(self, "_ga_packed", None)
         object.__setattr__(self, "_sa_packed", [None] * len(self.npoints))
         object.__setattr__(self, "_sa_h2", [None] * len(self.npoints))
         object.__setattr__(self, "_save_h2_now", False)
@@ -497,6 +505,8 @@ class PointNet2(_HipNet):
         for l, ch in enumerate(self._chains):
             ch.grads = [(views[f"sa.{l}.{2 * i}.weight"], views[f"sa.{l}.{2 * i}.bias"]) for i in range(len(ch.linears))]
         self._head.grads = [(views[f"final_mlp.{i}.weight"], views[f"final_mlp.{i}.bias"]) for i in (0, 2, 4)]
+        if self._ga_chain is not None:
+            self._ga_chain.grads = self._chains[-1].grads[:-1]
 
     def _sa_forward_fused(self, l, xyz, feat, centers, idx_g, pooled, plan_slot=None):
         """One fused SA level.  Layer 1's feature part is applied per SOURCE point (Y) by the Linear kernel."""
@@ -644,10 +654,21 @@ class PointNet2(_HipNet):
         zeros = torch.zeros(B, 1, 3, device=x.device)
         ldo = (self.sa[-1][0].in_features + 31) // 32 * 32     # zero columns up to the GEMM's K-step (the chain pads its weights alike)
         rows = ops.group_concat(xyz, feat, zeros, idx_all, ldo)
-        h = self._chains[-1].forward(rows)
         fbuf = torch.empty(B, self.feat_dim + self.proprio_shape, device=x.device)
-        arg = ops.maxpool_rows(h, B, S, fbuf[:, :self.feat_dim])
-        saved.append((idx_all, arg, h, S, feat.shape[2], ldo))
+        if self._ga_fused:
+            h = self._ga_chain.forward(rows)               # (B*S, CK): the layers before the last, tanh applied
+            lin = self._chains[-1].linears[-1]
+            packed = self._ga_packed
+            if packed is None or packed.device != x.device:
+                packed = torch.empty(int(ops.lib.pm_sa_groupall_packed_elems(lin.in_features, lin.out_features)), device=x.device)
+                object.__setattr__(self, "_ga_packed", packed)
+            ops.sa_groupall_pack(lin.weight.data, packed)
+            arg = ops.sa_groupall_fwd(h, B, S, lin.bias.data, packed, fbuf[:, :self.feat_dim])
+            saved.append((idx_all, arg, "groupall", S, feat.shape[2], ldo, h, fbuf))
+        else:
+            h = self._chains[-1].forward(rows)
+            arg = ops.maxpool_rows(h, B, S, fbuf[:, :self.feat_dim])
+            saved.append((idx_all, arg, h, S, feat.shape[2], ldo))
         if self.proprio_shape != 0:
             fbuf[:, self.feat_dim:].copy_(x[:, -self.proprio_shape:])
         object.__setattr__(self, "_saved", saved)
@@ -660,6 +681,17 @@ class PointNet2(_HipNet):
         self._head.backward(dy, ws, dx_out=dfbuf)
         dpooled = dfbuf[:, :self.feat_dim]                 # (G, C) view with row stride feat_dim + proprio
         for l in reversed(range(len(saved))):
+            if isinstance(saved[l][2], str) and saved[l][2] == "groupall":
+                idx_g, arg, _, P_l, cf, ldo, h, fbuf = saved[l]
+                lin = self._chains[-1].linears[-1]
+                dW, db = self._chains[-1].grads[-1]
+                dh = torch.empty_like(h)
+                ops.sa_groupall_bwd(dpooled, fbuf[:, :self.feat_dim], arg, lin.weight.data, h, B, P_l, dh, dW, db, ws)
+                drows = torch.empty(h.shape[0], ldo, device=dy.device) if l > 0 else None     # level-0 inputs are data
+                self._ga_chain.backward(dh, ws, dx_out=drows)
+                if l > 0:
+                    dpooled = ops.group_concat_bwd(drows, idx_g, B, P_l, cf, ldo).view(B * P_l, cf)
+                continue
             if isinstance(saved[l][2], str):                 # fused level record
                 # level-0 features are data: no gradient flows to them
                 dpooled = self._sa_backward_fused(l, saved[l], dpooled, ws, need_dfeat=l > 0)

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpartmanip_hip.so")
-SOURCES = ["gae.hip", "losses.hip", "adam.hip", "gemm_f32.hip", "gemm2_f32.hip", "pointnet_enc.hip", "pointnet_enc_bf3.hip", "pointnet_enc_bf6.hip", "pointops.hip", "sa_fused.hip", "conv3d.hip", "sparse_voxel.hip"]
+SOURCES = ["gae.hip", "losses.hip", "adam.hip", "gemm_f32.hip", "gemm2_f32.hip", "pointnet_enc.hip", "pointnet_enc_bf3.hip", "pointnet_enc_bf6.hip", "pointops.hip", "sa_fused.hip", "sa_groupall.hip", "conv3d.hip", "sparse_voxel.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"]
 

@@ -709,6 +709,46 @@ def sa_bwd(xyz, centers, idx, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpoo
                                 _ptr(h2_saved), _ptr(w), w.numel(), _stream()), "pm_sa_bwd_f32")
 
 
+# ---- group-all level: last layer + max over the cloud in one kernel, structured backward (csrc/sa_groupall.hip)
+def sa_groupall_supported(ck, co, rows):
+    return bool(lib.pm_sa_groupall_supported(int(ck), int(co), int(rows)))
+
+
+def sa_groupall_pack(w, packed):
+    _req(w, packed)
+    _f32c(w, "w")
+    check(lib.pm_sa_groupall_pack_f32(_ptr(w), w.shape[1], w.shape[0], _ptr(packed), _stream()), "pm_sa_groupall_pack_f32")
+
+
+def sa_groupall_fwd(h, B, R, bias, packed, feat):
+    """h (B*R, CK) -> feat (B, CO) view (any row stride) = max over the cloud's rows of tanh(h W^T + bias); arg (B, CO) int32."""
+    _req(h, bias, packed, feat)
+    _f32c(h, "h")
+    ck, co = h.shape[1], feat.shape[1]
+    arg = torch.empty(B, co, dtype=torch.int32, device=h.device)
+    with TIMER.bracket("sa_groupall_fwd"):
+        check(lib.pm_sa_groupall_fwd_f32(_ptr(h), B, R, ck, co, _ptr(bias), _ptr(packed), _ptr(feat), _rows(feat, "feat"), _ptr(arg),
+                                         _stream()), "pm_sa_groupall_fwd_f32")
+    return arg
+
+
+def sa_groupall_bwd(dfeat, feat, arg, w, h, B, R, dh, dw, db, ws):
+    """dh (B*R, CK) = d loss / d (pre-activation of h), every row written; dw (CO, CK), db (CO) overwritten."""
+    _req(dfeat, feat, arg, w, h, dh, dw, db)
+    _f32c(w, "w")
+    _f32c(h, "h")
+    _f32c(dh, "dh")
+    _f32c(dw, "dw")
+    co, ck = w.shape
+    wsb = ws.get(int(lib.pm_sa_groupall_bwd_workspace_bytes(B, ck, co)) + 16)
+    base = wsb.data_ptr()
+    al = (-base) % 16
+    with TIMER.bracket("sa_groupall_bwd"):
+        check(lib.pm_sa_groupall_bwd_f32(_ptr(dfeat), _rows(dfeat, "dfeat"), _ptr(feat), _rows(feat, "feat"), _ptr(arg), _ptr(w), _ptr(h),
+                                         B, R, ck, co, _ptr(dh), _ptr(dw), _ptr(db), base + al, wsb.numel() - al, _stream()),
+              "pm_sa_groupall_bwd_f32")
+
+
 # ---- duplicate-free ("packed") form: the level over each group's DISTINCT rows (ball query pads with copies of the first hit)
 class SaPlan:
     """Packed-row tables of one neighbourhood table (pm_sa_plan_i32): nothing here is read by the host."""

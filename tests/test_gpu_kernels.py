@@ -1051,3 +1051,82 @@ def test_sparse_conv_bwd_data_scatter_against_torch(rows, J, C, N):
     m = perm >= 0
     ref[perm[m].long()] = full[m] * (1 - h.double()[perm[m].long()] ** 2)
     np.testing.assert_allclose(dx.cpu().numpy(), ref.numpy(), rtol=5e-6, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------- PointNet++ group-all level, fused
+@pytest.mark.parametrize("B,proprio", [(1, 0), (37, 5), (300, 0)])
+def test_sa_groupall_fused_matches_fp64(B, proprio):
+    """csrc/sa_groupall.hip: last layer + max over the cloud in one kernel, and the structured backward (no dense GEMM on the
+    one-non-zero-per-(cloud, channel) gradient), against the same level written in fp64 torch.  Tolerances as the Linear kernels."""
+    o = ops()
+    R_, CK, CO = 64, 256, 512
+    assert o.sa_groupall_supported(CK, CO, R_) and not o.sa_groupall_supported(128, CO, R_) and not o.sa_groupall_supported(CK, CO, 48)
+    g = torch.Generator().manual_seed(100 + B)
+    h = torch.tanh(torch.randn(B * R_, CK, generator=g))
+    W = torch.randn(CO, CK, generator=g) / 16.0
+    bias = torch.randn(CO, generator=g) * 0.1
+    dfeat_full = torch.randn(B, CO + proprio, generator=g)
+    hd, Wd, bd = h.to(DEV), W.to(DEV), bias.to(DEV)
+    packed = torch.empty(int(o.lib.pm_sa_groupall_packed_elems(CK, CO)), device=DEV)
+    o.sa_groupall_pack(Wd, packed)
+    fbuf = torch.full((B, CO + proprio), 7.0, device=DEV)
+    arg = o.sa_groupall_fwd(hd, B, R_, bd, packed, fbuf[:, :CO])
+    z = torch.tanh(h.double() @ W.double().t() + bias.double()).view(B, R_, CO)
+    want, want_arg = z.max(dim=1)
+    assert float((fbuf[:, :CO].cpu().double() - want).abs().max()) < 2e-5
+    if proprio:
+        assert bool((fbuf[:, CO:] == 7.0).all())                       # the columns beside the feature block are the caller's
+    a = arg.cpu().long()
+    assert int(a.min()) >= 0 and int(a.max()) < R_
+    picked = torch.gather(z, 1, a.view(B, 1, CO)).view(B, CO)
+    assert float((picked - want).abs().max()) < 2e-6                     # the chosen row attains the maximum (fp32 ties may differ)
+    assert float((a == want_arg).float().mean()) > 0.999
+    # backward, routed through the rows the kernel chose
+    dfd = dfeat_full.to(DEV)
+    dh = torch.full((B * R_, CK), float("nan"), device=DEV)
+    dW = torch.full((CO, CK), float("nan"), device=DEV)
+    db = torch.full((CO,), float("nan"), device=DEV)
+    ws = o.Workspace(torch.device(DEV))
+    o.sa_groupall_bwd(dfd[:, :CO], fbuf[:, :CO], arg, Wd, hd, B, R_, dh, dW, db, ws)
+    y = fbuf[:, :CO].cpu().double()
+    dz = dfeat_full[:, :CO].double() * (1.0 - y * y)
+    D = torch.zeros(B, R_, CO, dtype=torch.float64)
+    D.scatter_(1, a.view(B, 1, CO), dz.view(B, 1, CO))
+    h3 = h.double().view(B, R_, CK)
+    dh_ref = (D @ W.double()) * (1.0 - h3 * h3)
+    dW_ref = torch.einsum("brc,brk->ck", D, h3)
+    assert rel_err(dh.view(B, R_, CK), dh_ref) < 1e-5
+    assert rel_err(dW, dW_ref) < 1e-5
+    assert rel_err(db, dz.sum(0)) < 1e-5
+    # run-to-run identical (fixed summation orders)
+    dh2, dW2, db2 = torch.empty_like(dh), torch.empty_like(dW), torch.empty_like(db)
+    o.sa_groupall_bwd(dfd[:, :CO], fbuf[:, :CO], arg, Wd, hd, B, R_, dh2, dW2, db2, ws)
+    assert torch.equal(dh, dh2) and torch.equal(dW, dW2) and torch.equal(db, db2)
+
+
+def test_pointnet2_fused_groupall_equals_the_unfused_level():
+    """The whole PointNet2 plug-in with and without the fused group-all level: same outputs and parameter gradients (the
+    two differ in summation order only)."""
+    from partmanip_amd.algo_utils import ActorCritic
+    B, P, C, A = 6, 1024, 3, 5
+    shape = dict(npoints=[128, 64], radii=[0.3, 0.6], nsamples=[32, 32], mlps=[[64, 64, 128], [128, 128, 256], [256, 512]])
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(B, P * C, generator=g) * 2 - 1).to(DEV)
+    dy = torch.randn(B, A, generator=g).to(DEV)
+    outs, grads = [], []
+    for fused in (True, False):
+        torch.manual_seed(11)
+        net = dict(name="PointNet2", activation="tanh", fused_groupall=fused, **shape)
+        ac = ActorCritic(P * C, A, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net), 0).to(DEV)
+        assert ac.actor._ga_fused == fused
+        f = ac.flat()
+        out = ac.actor.hip_forward(x)
+        ac.actor.hip_backward(dy)
+        outs.append(out.clone())
+        grads.append(f["grad_actor"].clone())
+    assert rel_err(outs[0], outs[1].cpu()) < 2e-5
+    off = 0
+    for k, v in ac.actor.named_parameters():
+        a_, b_ = grads[0][off:off + v.numel()], grads[1][off:off + v.numel()]
+        off += v.numel()
+        assert rel_err(a_, b_.cpu()) < 2e-4, k

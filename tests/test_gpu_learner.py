@@ -538,10 +538,12 @@ PN2_UNFUSED = dict(npoints=[128, 32], radii=[0.25, 0.5], nsamples=[16, 16], mlps
 # the shapes the fused SA kernels are instantiated for (pm_sa_fwd_f32 / pm_sa_bwd_f32); 130 / 33 centres make the
 # last tile of both levels ragged
 PN2_FUSED = dict(npoints=[130, 33], radii=[0.25, 0.5], nsamples=[32, 32], mlps=[[64, 64, 128], [128, 128, 256], [256, 512]])
+# 64 centres at the last level: the group-all level runs fused too (csrc/sa_groupall.hip) -- the bench's shape
+PN2_FUSED_GA = dict(npoints=[130, 64], radii=[0.25, 0.5], nsamples=[32, 32], mlps=[[64, 64, 128], [128, 128, 256], [256, 512]])
 
 
 @pytest.mark.parametrize("B,C,proprio,shape", [(3, 3, 0, PN2_UNFUSED), (2, 5, 6, PN2_UNFUSED), (3, 3, 0, PN2_FUSED),
-                                               (2, 5, 6, PN2_FUSED)])
+                                               (2, 5, 6, PN2_FUSED), (3, 3, 0, PN2_FUSED_GA), (2, 5, 6, PN2_FUSED_GA)])
 def test_pointnet2_forward_backward(B, C, proprio, shape):
     """PointNet2 plug-in (FPS + ball query + grouping + shared MLP + max-pool; absent from the reference,
     parity unpinned): HIP path vs this build's CPU restatement -- sampled / grouped indices bit-exact,
@@ -559,7 +561,7 @@ def test_pointnet2_forward_backward(B, C, proprio, shape):
     out_ref, aux, ref_args = R.pointnet2_forward(p, "actor", net, x.clone(), proprio, return_aux=True)
     out = ac.actor.hip_forward(x.to(DEV))
     saved = ac.actor._saved
-    assert ac.actor._fused == [shape is PN2_FUSED] * 2
+    assert ac.actor._fused == [shape is not PN2_UNFUSED] * 2 and ac.actor._ga_fused == (shape is PN2_FUSED_GA)
     for l, (idx_c, idx_g) in enumerate(aux):
         assert torch.equal(saved[l][0].cpu().long(), idx_g), f"ball-query indices differ at level {l}"
     assert rel_err(out, out_ref.detach()) < 3e-5

@@ -4,7 +4,7 @@ set -e
 name=$1; src=$2; shift 2
 mkdir -p gpurun_ab/obj_$name
 objs=""
-for f in gae losses adam gemm_f32 gemm2_f32 pointnet_enc pointnet_enc_bf3 pointnet_enc_bf6 pointops sa_fused conv3d sparse_voxel; do
+for f in gae losses adam gemm_f32 gemm2_f32 pointnet_enc pointnet_enc_bf3 pointnet_enc_bf6 pointops sa_fused sa_groupall conv3d sparse_voxel; do
   if [ "$f.hip" == "$src" ]; then
     /opt/rocm/bin/hipcc -x hip -c partmanip_amd/csrc/$f.hip -o gpurun_ab/obj_$name/$f.o -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off "$@"
     objs="$objs gpurun_ab/obj_$name/$f.o"
