@@ -64,6 +64,8 @@ class _LinearChain:
         self.x_w = None                    # the chain input again, in rows padded for 16-byte loads (ops.padded_cols): weight gradient only
         self.grads = None                  # list[(dW view, db view)] set by ActorCritic.flatten()
         self._cws = None                   # stripe counters of the chained launches (one set per network: they run on two streams)
+        self.col_blocks = None             # [(weight column start, end, input column start)]: the caller's rows hold the first layer's
+                                           # input columns in another order (PointNet2 group-all: [features | xyz | 0] instead of [xyz | features])
 
     def _chain_ws(self, device):
         if self._cws is None or self._cws.device != device:
@@ -78,10 +80,11 @@ class _LinearChain:
         # rows wider than the first layer's fan-in (the caller zero-filled the extra columns so that K is a multiple of the
         # GEMM's 32-wide K-step: the LDS-DMA kernels instead of the register-staged one): a zero-padded copy of the weights
         self.w0p = None
-        if x.shape[1] != self.linears[0].in_features:
+        if x.shape[1] != self.linears[0].in_features or self.col_blocks is not None:
             w0 = self.linears[0].weight.data
             self.w0p = torch.zeros(w0.shape[0], x.shape[1], device=x.device)
-            self.w0p[:, :w0.shape[1]].copy_(w0)
+            for s_, e_, d_ in (self.col_blocks or [(0, w0.shape[1], 0)]):
+                self.w0p[:, d_:d_ + e_ - s_].copy_(w0[:, s_:e_])
         for i, lin in enumerate(self.linears):
             last = i == n - 1
             y = out if (last and out is not None) else torch.empty(cur.shape[0], lin.out_features, device=cur.device)
@@ -127,7 +130,12 @@ class _LinearChain:
             if w0p is not None:                            # zero-padded K: the gradient of the real columns is the leading block
                 dWp = torch.empty_like(w0p)
                 ops.linear_bwd_weight(dy, inp, dWp, db, ws)
-                dW.copy_(dWp[:, :dW.shape[1]])
+                if self.col_blocks is None:
+                    dW.copy_(dWp[:, :dW.shape[1]])
+                else:
+                    dW.zero_()                             # (columns outside the blocks are padding: they never receive data)
+                    for s_, e_, d_ in self.col_blocks:
+                        dW[:, s_:e_].copy_(dWp[:, d_:d_ + e_ - s_])
             else:
                 ops.linear_bwd_weight(dy, inp, dW, db, ws)
             if i > 0:
@@ -492,6 +500,12 @@ class PointNet2(_HipNet):
             and ops.sa_groupall_supported(ga[-2], ga[-1], self.npoints[-1])))
         object.__setattr__(self, "_ga_chain", _LinearChain(chains[-1].linears[:-1], code, final_act=True) if self._ga_fused else None)
         object.__setattr__(self, "_ga_packed", None)
+        # ... and the last set-abstraction level then writes its pooled rows straight into the group-all input rows
+        # ([features | xyz | 0], the first layer's weight columns permuted alike): no gather copy forward, no scatter copy backward
+        object.__setattr__(self, "_ga_direct", bool(self._ga_fused and self.npoints and self._fused[-1]
+                                                    and net_cfg.get('groupall_direct_rows', True)))
+        if self._ga_direct:
+            self._ga_chain.col_blocks = [(3, 3 + mlps[-2][-1], 0), (0, 3, mlps[-2][-1])]
         object.__setattr__(self, "_sa_packed", [None] * len(self.npoints))
         object.__setattr__(self, "_sa_h2", [None] * len(self.npoints))
         object.__setattr__(self, "_save_h2_now", False)
@@ -628,7 +642,7 @@ class PointNet2(_HipNet):
         object.__setattr__(self, "_geom_next", None)
         if geom is not None and geom[0][0].shape[0] != B:
             raise ValueError("use_geometry(): table rows do not match the batch")
-        saved = []
+        saved, ga_rows = [], None
         for l, S in enumerate(self.npoints):
             plan_slot = None
             if geom is not None:
@@ -638,7 +652,12 @@ class PointNet2(_HipNet):
                 centers = ops.group_points(xyz, idx_c.view(B, S, 1)).view(B, S, 3)
                 idx_g = ops.ball_query(xyz, centers, self.radii[l], self.nsamples[l])
             if self._fused[l]:
-                pooled = torch.empty(B * S, self.sa[l][4].out_features, device=x.device)
+                c3 = self.sa[l][4].out_features
+                if self._ga_direct and l == len(self.npoints) - 1:
+                    ga_rows = torch.empty(B * S, (self.sa[-1][0].in_features + 31) // 32 * 32, device=x.device)
+                    pooled = ga_rows[:, :c3]
+                else:
+                    pooled = torch.empty(B * S, c3, device=x.device)
                 saved.append(self._sa_forward_fused(l, xyz, feat, centers, idx_g, pooled, plan_slot))
                 xyz, feat = centers, pooled.view(B, S, -1)
                 continue
@@ -650,10 +669,15 @@ class PointNet2(_HipNet):
             saved.append((idx_g, arg, h, xyz.shape[1], 0 if feat is None else feat.shape[2], ldo))
             xyz, feat = centers, pooled.view(B, S, -1)
         S = xyz.shape[1]                                   # group-all level: absolute coordinates
-        idx_all = torch.arange(S, dtype=torch.int32, device=x.device).repeat(B, 1).view(B, 1, S)
-        zeros = torch.zeros(B, 1, 3, device=x.device)
         ldo = (self.sa[-1][0].in_features + 31) // 32 * 32     # zero columns up to the GEMM's K-step (the chain pads its weights alike)
-        rows = ops.group_concat(xyz, feat, zeros, idx_all, ldo)
+        if ga_rows is not None:                            # the features are already in place: [features | xyz | 0]
+            idx_all, rows, cf_ = None, ga_rows, feat.shape[2]
+            rows[:, cf_:cf_ + 3].copy_(xyz.reshape(B * S, 3))
+            rows[:, cf_ + 3:].zero_()
+        else:
+            idx_all = torch.arange(S, dtype=torch.int32, device=x.device).repeat(B, 1).view(B, 1, S)
+            zeros = torch.zeros(B, 1, 3, device=x.device)
+            rows = ops.group_concat(xyz, feat, zeros, idx_all, ldo)
         fbuf = torch.empty(B, self.feat_dim + self.proprio_shape, device=x.device)
         if self._ga_fused:
             h = self._ga_chain.forward(rows)               # (B*S, CK): the layers before the last, tanh applied
@@ -690,7 +714,8 @@ class PointNet2(_HipNet):
                 drows = torch.empty(h.shape[0], ldo, device=dy.device) if l > 0 else None     # level-0 inputs are data
                 self._ga_chain.backward(dh, ws, dx_out=drows)
                 if l > 0:
-                    dpooled = ops.group_concat_bwd(drows, idx_g, B, P_l, cf, ldo).view(B * P_l, cf)
+                    dpooled = (drows[:, :cf] if idx_g is None else                      # (direct rows: the feature block, in place)
+                               ops.group_concat_bwd(drows, idx_g, B, P_l, cf, ldo).view(B * P_l, cf))
                 continue
             if isinstance(saved[l][2], str):                 # fused level record
                 # level-0 features are data: no gradient flows to them

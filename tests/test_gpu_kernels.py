@@ -1114,19 +1114,20 @@ def test_pointnet2_fused_groupall_equals_the_unfused_level():
     x = (torch.rand(B, P * C, generator=g) * 2 - 1).to(DEV)
     dy = torch.randn(B, A, generator=g).to(DEV)
     outs, grads = [], []
-    for fused in (True, False):
+    for fused, direct in ((True, True), (False, False), (True, False)):     # (direct: the last SA level writes into the group-all rows)
         torch.manual_seed(11)
-        net = dict(name="PointNet2", activation="tanh", fused_groupall=fused, **shape)
+        net = dict(name="PointNet2", activation="tanh", fused_groupall=fused, groupall_direct_rows=direct, **shape)
         ac = ActorCritic(P * C, A, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net), 0).to(DEV)
-        assert ac.actor._ga_fused == fused
+        assert ac.actor._ga_fused == fused and ac.actor._ga_direct == direct
         f = ac.flat()
         out = ac.actor.hip_forward(x)
         ac.actor.hip_backward(dy)
         outs.append(out.clone())
         grads.append(f["grad_actor"].clone())
-    assert rel_err(outs[0], outs[1].cpu()) < 2e-5
-    off = 0
-    for k, v in ac.actor.named_parameters():
-        a_, b_ = grads[0][off:off + v.numel()], grads[1][off:off + v.numel()]
-        off += v.numel()
-        assert rel_err(a_, b_.cpu()) < 2e-4, k
+    for i in (0, 2):
+        assert rel_err(outs[i], outs[1].cpu()) < 2e-5
+        off = 0
+        for k, v in ac.actor.named_parameters():
+            a_, b_ = grads[i][off:off + v.numel()], grads[1][off:off + v.numel()]
+            off += v.numel()
+            assert rel_err(a_, b_.cpu()) < 2e-4, (i, k)
