@@ -597,7 +597,7 @@ def run_ppo(args, device, rank, world):
         # they run on two and share the chip, which stretches every launch), outside the timed region
         ov = run.overlap
         run.overlap = False
-        ops.TIMER.add(*[f"sa_{d}_{k}" for d in ("fwd", "bwd") for k in SA_LEVELS])
+        ops.TIMER.add(*[f"sa_{d}_{k}" for d in ("fwd", "bwd") for k in SA_LEVELS], "sa_groupall_fwd", "sa_groupall_bwd")
         step()
         torch.cuda.synchronize()
         ops.TIMER.disable()
@@ -707,9 +707,24 @@ def run_ppo(args, device, rank, world):
                     kern[f"sa_{d_}_{k}"] = dict(mean_launch_ms=t[0], launches=t[1], tflops=tf, frac=tf / PEAK_F32_MFMA_TFLOPS,
                                                 dense_equivalent_tflops=2 * dense * macs / (t[0] * 1e-3) / 1e12,
                                                 algorithmic_bytes=algo[d_], traffic=traffic)
+        # group-all level: its last layer (256 -> 512 over 64 rows per cloud) fused with the max over the cloud; the backward call
+        # = dH (sorted winners, one running sum per column) + dW gather + finish: 3 x 2048 x 512 x 256 multiply-adds instead of
+        # the two dense GEMMs (2 x 34.4 GFLOP) on the one-non-zero-per-(cloud, channel) gradient (csrc/sa_groupall.hip)
+        ga = {}
+        if getattr(net, "_ga_fused", False):
+            gf, gb = ops.TIMER.mean_ms("sa_groupall_fwd"), ops.TIMER.mean_ms("sa_groupall_bwd")
+            rows_ga = 2048.0 * net.npoints[-1]
+            if gf:
+                tf = 2.0 * rows_ga * 256 * 512 / (gf[0] * 1e-3) / 1e12
+                ga["fwd"] = dict(mean_launch_ms=gf[0], launches=gf[1], tflops=tf, frac=tf / PEAK_F32_MFMA_TFLOPS,
+                                 algorithmic_bytes=rows_ga * 256 * 4.0 + 2048 * 512 * 8.0)
+            if gb:
+                by = rows_ga * 256 * 4.0 * 2 + 2048 * 512 * 16.0           # H in, dH out, pooled / gradient / arg-max in
+                ga["bwd"] = dict(mean_call_ms=gb[0], calls=gb[1], algorithmic_bytes=by, achieved_gbs=by / (gb[0] * 1e-3) / 1e9,
+                                 frac_of_hbm=by / (gb[0] * 1e-3) / 1e9 / PEAK_HBM_GBS, dense_gemm_flops_not_executed=2 * 2.0 * rows_ga * 256 * 512)
         if kern:
             name = max(kern, key=lambda n: kern[n]["mean_launch_ms"] * kern[n]["launches"])
-            out["roofline"] = dict(bound="mfma", kernel=name, achieved=kern[name]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
+            out["roofline"] = dict(group_all=ga, bound="mfma", kernel=name, achieved=kern[name]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
                                    unit="TFLOP/s", frac=kern[name]["tflops"] / PEAK_F32_MFMA_TFLOPS, traffic=kern[name]["traffic"],
                                    algorithmic_bytes=kern[name]["algorithmic_bytes"],
                                    launches=kern[name]["launches"], mean_launch_ms=kern[name]["mean_launch_ms"], kernels=kern,

@@ -118,9 +118,10 @@ class _LinearChain:
             cur = y
         return cur
 
-    def backward(self, dy, ws, dx_out=None, x_is_activation=False):
+    def backward(self, dy, ws, dx_out=None, x_is_activation=False, dx_cols=None):
         """dy: d loss / d output.  Fills self.grads; returns d loss / d input if dx_out is given
-        (x_is_activation: the chain input is itself a tanh output whose derivative must be applied)."""
+        (x_is_activation: the chain input is itself a tanh output whose derivative must be applied; dx_cols: only the
+        first dx_cols input columns are wanted -- dx_out is that narrow)."""
         n = len(self.linears)
         for i in reversed(range(n)):
             lin = self.linears[i]
@@ -143,7 +144,8 @@ class _LinearChain:
                 ops.linear_bwd_data(dy, lin.weight.data, inp, dx, self.act)
                 dy = dx
             elif dx_out is not None:
-                ops.linear_bwd_data(dy, w0p if w0p is not None else lin.weight.data, inp if x_is_activation else None, dx_out,
+                w_in = w0p if w0p is not None else lin.weight.data
+                ops.linear_bwd_data(dy, w_in if dx_cols is None else w_in[:, :dx_cols], inp if x_is_activation else None, dx_out,
                                     self.act if x_is_activation else ops.ACT_NONE)
         return dx_out
 
@@ -711,11 +713,11 @@ class PointNet2(_HipNet):
                 dW, db = self._chains[-1].grads[-1]
                 dh = torch.empty_like(h)
                 ops.sa_groupall_bwd(dpooled, fbuf[:, :self.feat_dim], arg, lin.weight.data, h, B, P_l, dh, dW, db, ws)
-                drows = torch.empty(h.shape[0], ldo, device=dy.device) if l > 0 else None     # level-0 inputs are data
-                self._ga_chain.backward(dh, ws, dx_out=drows)
+                direct = idx_g is None                     # the rows are [features | xyz | 0]: only the feature block's gradient is wanted
+                drows = torch.empty(h.shape[0], cf if direct else ldo, device=dy.device) if l > 0 else None     # level-0 inputs are data
+                self._ga_chain.backward(dh, ws, dx_out=drows, dx_cols=cf if (direct and l > 0) else None)
                 if l > 0:
-                    dpooled = (drows[:, :cf] if idx_g is None else                      # (direct rows: the feature block, in place)
-                               ops.group_concat_bwd(drows, idx_g, B, P_l, cf, ldo).view(B * P_l, cf))
+                    dpooled = drows if direct else ops.group_concat_bwd(drows, idx_g, B, P_l, cf, ldo).view(B * P_l, cf)
                 continue
             if isinstance(saved[l][2], str):                 # fused level record
                 # level-0 features are data: no gradient flows to them
