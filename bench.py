@@ -868,7 +868,7 @@ def _brief(line):
     out = dict(metric=line["metric"], value=line["value"], unit=line["unit"], steps=line["steps"], warmup=line["warmup"],
                ms_per_step=line["ms_per_step"], dtype=line["dtype"], workload=line["config"]["workload"],
                roofline={k: r[k] for k in keep if k in r})
-    for k in ("hidden_layer_gemm", "gae_scan"):
+    for k in ("hidden_layer_gemm", "gae_scan", "group_all"):
         if k in r:
             out["roofline"][k] = r[k]
     if "cpu_baseline" in line:
