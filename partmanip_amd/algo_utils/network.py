@@ -777,6 +777,7 @@ class SparseUNet(_HipNet):
         object.__setattr__(self, "_head", _LinearChain([self.final_mlp[0], self.final_mlp[2], self.final_mlp[4]], code))
         object.__setattr__(self, "_g", None)
         self.fused_gather = bool(net_cfg.get('fused_gather', True))          # False: materialise every gathered operand (A/B)
+        self.sparse_top = bool(net_cfg.get('sparse_top', True))               # False: conv2's weight gradient over all level-2 rows (A/B)
 
     _LAYERS = ("conv0", "down0", "conv1", "down1", "conv2", "up1", "up0")
 
@@ -1013,7 +1014,24 @@ class SparseUNet(_HipNet):
             dzH2 = ops.rows_gather_bwd(dcat1[:, :c2], g["l2"]["child"], c2, torch.empty_like(s["D2"]), mode=2)
             dzH1, dzH0 = dcat1[:, c2:], dcat0[:, c1:]
             acc_mode = True                                                                 # skip part already pre-activation
-        self._conv_wgrad("conv2", dzH2, s["D2"], g["nbr2"], c2, s["cols2"], ws)
+        if self.sparse_top and s["cols2"] is None:
+            # The cloud-wide max-pool leaves ONE non-zero per (cloud, channel) in the gradient of E0, and everything above the
+            # coarsest convolution is row-local (1 x 1 layers, un-pooling): the gradient that reaches conv2's output is non-zero
+            # on at most c0 rows per cloud -- the level-2 ancestors of the winning rows (32 of ~300).  Its weight gradient is
+            # the sum over THOSE rows: the same gathered GEMM on a compacted (gradient rows, neighbour rows) pair, B * c0 rows
+            # instead of the level's (a duplicate ancestor counts once: later copies become all-absent rows).
+            r0 = s["arg"].long() + (torch.arange(B, device=dy.device) * P).view(B, 1)
+            r2 = g["l2"]["parent"].view(-1)[g["l1"]["parent"].view(-1)[r0].long()].long()
+            r2, _ = torch.sort(r2, dim=1)
+            dup = torch.zeros_like(r2, dtype=torch.bool)
+            dup[:, 1:] = r2[:, 1:] == r2[:, :-1]
+            rows_c = r2.masked_fill(dup, 0).view(-1)
+            keep = (~dup).view(-1, 1)
+            dz_c = dzH2.index_select(0, rows_c) * keep
+            idx_c = g["nbr2"].index_select(0, rows_c).masked_fill(~keep, -1)
+            ops.sparse_conv_bwd_weight(dz_c, s["D2"], idx_c, c2, *self._g["conv2"], self._zero(dy.device), ws)
+        else:
+            self._conv_wgrad("conv2", dzH2, s["D2"], g["nbr2"], c2, s["cols2"], ws)
         dzD2 = self._conv_dgrad("conv2", dzH2, g["nbr2"], s["D2"], torch.empty_like(s["D2"]))
         self._conv_wgrad("down1", dzD2, H1, g["l2"]["child"], c1, s["colsd1"], ws)
         dcolsd1 = torch.empty(dzD2.shape[0], 8 * c1, device=dy.device)

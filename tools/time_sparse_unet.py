@@ -11,7 +11,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 P = 4096
 env = FeederEnv(B, {"depth_sparse": 4 * P, "proprio_state": 0}, 10, DEV, seed=7, point_num=P)
 x = env.reset()["depth_sparse"]
-net = dict(name="SparseUNet", activation="tanh", point_num=P, grid=50)
+import os
+net = dict(name="SparseUNet", activation="tanh", point_num=P, grid=50, sparse_top=os.environ.get("SPARSE_TOP", "1") == "1")
 torch.manual_seed(0)
 ac = ActorCritic(4 * P, 10, dict(action_std=0.1, action_activate="tanh", clipAction=1.0, network=net)).to(DEV)
 ac.flat()
