@@ -239,7 +239,16 @@ def run_dagger(args, device, rank, world):
         # backward = weight gradients (the forward's MACs) + data gradients: the forward's MACs again, except conv0 (its input
         # is data) and the up layers, whose un-pooled half runs on the COARSE rows (children summed first, linearity)
         dgrad = dict(macs, conv0=0, up1=R1 * c1 * c1 + R2 * c1 * c2, up0=R0 * c0 * c0 + R1 * c0 * c1)
-        bfl = ffl + 2.0 * sum(dgrad.values())
+        wgrad = dict(macs)
+        compact_rows = None
+        if getattr(run.student.actor, "sparse_top", False) and run.student.actor._saved.get("vcat") and run.student.actor._saved.get("cols2") is None:
+            # the cloud-wide max-pool leaves one non-zero per (cloud, channel): max-pool, up0, up1 and conv2's weight gradient run
+            # over the winners' rows and their ancestors -- mb * c0 rows per level instead of the level's (network.py::
+            # _decoder_backward_compact); conv2's data gradient and everything below it stay dense
+            compact_rows = Nc = mb * c0
+            wgrad.update(conv2=Nc * 27 * c2 * c2, up1=Nc * (c2 + c1) * c1, up0=Nc * (c1 + c0) * c0)
+            dgrad.update(up1=Nc * c1 * c1 + Nc * c1 * c2, up0=Nc * c0 * c0 + Nc * c0 * c1)
+        bfl = 2.0 * sum(wgrad.values()) + 2.0 * sum(dgrad.values())
         # algorithmic HBM bytes of one forward + backward (every operand once: a layer reads its input rows, its table and
         # writes its output; its backward reads dY, its own output (tanh'), the input again (weight gradient) and writes dX)
         lay = [(R0, 4, 32, R0, c0), (R0, c0, 8, R1, c1), (R1, c1, 27, R1, c1), (R1, c1, 8, R2, c2), (R2, c2, 27, R2, c2),
@@ -255,7 +264,9 @@ def run_dagger(args, device, rank, world):
                                    traffic_note="HBM bytes of one forward + backward of a mini-batch, ALL its kernels (PMC over "
                                                 f"tools/time_sparse_unet.py {mb}, profiles/hbm_traffic.json)",
                                    launches=t[1], fwd_mean_ms=t[0], bwd_mean_ms=b[0], level_rows=[R0, R1, R2],
-                                   flops_fwd=ffl, flops_bwd=bfl,
+                                   flops_fwd=ffl, flops_bwd=bfl, compact_decoder_backward_rows=compact_rows,
+                                   flops_bwd_dense_decoder=ffl + 2.0 * sum(dict(macs, conv0=0, up1=R1 * c1 * c1 + R2 * c1 * c2,
+                                                                                 up0=R0 * c0 * c0 + R1 * c0 * c1).values()),
                                    note="3^3 / strided convolutions and the up layers' [unpool | skip] operands are gathered inside the "
                                         "GEMM's LDS-DMA loader (forward, weight gradient, the 3^3 data gradient through the mirrored "
                                         "table): no column / concatenated matrix in HBM except the strided layers' data gradients; "

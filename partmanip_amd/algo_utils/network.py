@@ -974,6 +974,71 @@ class SparseUNet(_HipNet):
                                                 H0=H0, H1=H1, E1=E1, comb0=comb0 if vcat else None, comb1=comb1 if vcat else None))
         return self._head.forward(fbuf, out)
 
+    @staticmethod
+    def _uniq_rows(v, pad):
+        """v (B, S) row ids -> (u, rank): u (B, S) the cloud's distinct ids ascending, padded with `pad`; rank (B, S) the slot of
+        v[b, i] in u[b].  Sort + first differences + scatters of equal values: deterministic, no host read."""
+        srt, order = v.sort(dim=1)
+        new = torch.ones_like(srt, dtype=torch.bool)
+        new[:, 1:] = srt[:, 1:] != srt[:, :-1]
+        rs = new.cumsum(1) - 1
+        rank = torch.empty_like(rs).scatter_(1, order, rs)
+        u = torch.full_like(srt, pad).scatter_(1, rs, srt)
+        return u, rank
+
+    def _decoder_backward_compact(self, s, g, dfbuf, ws):
+        """Backward of max-pool, up0, up1 and conv2's weight gradient over the rows that carry gradient.
+
+        The cloud-wide max-pool leaves ONE non-zero per (cloud, channel) in the gradient of E0, and everything above the coarsest
+        convolution is row-local (1 x 1 layers on [un-pooled | skip] rows): the gradient is non-zero on at most c0 rows per cloud
+        at level 0 (the winners), on their parents at level 1 and on their grand-parents at level 2 -- 32 of 4096 / ~1300 / ~300.
+        Each level keeps the cloud's DISTINCT rows (c0 slots, padded with a dummy row behind the level) and a (slots x slots)
+        0/1 matrix that sums the children of a coarse row (a batched product: fixed order); the layers' GEMMs run on those
+        B * c0 rows -- the same kernels, compacted (gradient rows, table rows) pairs -- and the dense tensors the strided layers'
+        backward adds into (dzH0, dzH1: raw skip gradients; dzH2) are zero-filled and receive their rows by index (distinct
+        rows: no atomics).  Same sums as the dense form up to their order."""
+        c0, c1, c2 = self.channels
+        P, B = self.point_num, s["B"]
+        dev = dfbuf.device
+        R0, R1, R2 = g["rows"]
+        W = lambda n: getattr(self, n).weight.data
+        zero = self._zero(dev)
+        e = lambda r, c: torch.empty(r, c, device=dev)
+        if "p1x" not in g:                                   # parent tables with the dummy row mapped to the next level's dummy row
+            g["p1x"] = torch.cat([g["l1"]["parent"].view(-1).long(), torch.tensor([R1], device=dev)])
+            g["p2x"] = torch.cat([g["l2"]["parent"].view(-1).long(), torch.tensor([R2], device=dev)])
+        N = B * c0
+        v0 = s["arg"].long() + (torch.arange(B, device=dev) * P).view(B, 1)
+        u0, rank0 = self._uniq_rows(v0, R0)
+        u1, rank1 = self._uniq_rows(g["p1x"][u0], R1)
+        u2, rank2 = self._uniq_rows(g["p2x"][u1], R2)
+        r0, r1, r2 = u0.view(-1), u1.view(-1), u2.view(-1)
+        pad0, pad1, pad2 = (r0 == R0).view(N, 1), (r1 == R1).view(N, 1), (r2 == R2).view(N, 1)
+        r0c, r1c, r2c = r0.clamp(max=R0 - 1), r1.clamp(max=R1 - 1), r2.clamp(max=R2 - 1)
+        sel = lambda t, r: t.index_select(0, r)
+        tab = lambda t, r, pad: t.index_select(0, r).masked_fill(pad, -1)
+        ones = torch.ones(B, 1, c0, device=dev)
+        A1 = torch.zeros(B, c0, c0, device=dev).scatter_(1, rank1.view(B, 1, c0), ones)      # A1[b, slot of u0's parent, u0] = 1
+        A2 = torch.zeros(B, c0, c0, device=dev).scatter_(1, rank2.view(B, 1, c0), ones)
+        # level 0: pooled gradient -> the winners' rows (slot = rank of the channel's winner), times tanh'(E0)
+        dzE0 = ops.maxpool_rows_bwd(dfbuf[:, :c0], rank0.to(torch.int32).contiguous(), c0, y_tanh=sel(s["E0"], r0c))
+        ops.sparse_conv_bwd_weight(dzE0, s["comb0"], tab(g["up0_idx"], r0c, pad0), c0, *self._g["up0"], zero, ws)
+        dzH0 = torch.zeros(R0 + 1, c0, device=dev)
+        dzH0.index_copy_(0, r0, ops.linear_bwd_data(dzE0, W("up0")[:, c1:], None, e(N, c0), ops.ACT_NONE))      # skip half, raw
+        # level 1
+        sum0 = torch.bmm(A1, dzE0.view(B, c0, c0)).view(N, c0)
+        dzE1 = ops.linear_bwd_data(sum0, W("up0")[:, :c1], sel(s["E1"], r1c), e(N, c1), self._act)
+        ops.sparse_conv_bwd_weight(dzE1, s["comb1"], tab(g["up1_idx"], r1c, pad1), c1, *self._g["up1"], zero, ws)
+        dzH1 = torch.zeros(R1 + 1, c1, device=dev)
+        dzH1.index_copy_(0, r1, ops.linear_bwd_data(dzE1, W("up1")[:, c2:], None, e(N, c1), ops.ACT_NONE))
+        # level 2
+        sum1 = torch.bmm(A2, dzE1.view(B, c0, c1)).view(N, c1)
+        dzH2c = ops.linear_bwd_data(sum1, W("up1")[:, :c2], sel(s["H2"], r2c), e(N, c2), self._act)
+        ops.sparse_conv_bwd_weight(dzH2c, s["D2"], tab(g["nbr2"], r2c, pad2), c2, *self._g["conv2"], zero, ws)
+        dzH2 = torch.zeros(R2 + 1, c2, device=dev)
+        dzH2.index_copy_(0, r2, dzH2c)
+        return dzH0[:R0], dzH1[:R1], dzH2[:R2]
+
     def _hip_backward(self, dy):
         s, g = self._saved, self._saved["g"]
         c0, c1, c2 = self.channels
@@ -982,9 +1047,16 @@ class SparseUNet(_HipNet):
         W = lambda n: getattr(self, n).weight.data
         dfbuf = torch.empty(B, c0 + self.proprio_shape, device=dy.device)
         self._head.backward(dy, ws, dx_out=dfbuf)
-        dzE0 = ops.maxpool_rows_bwd(dfbuf[:, :c0], s["arg"], P, y_tanh=s["E0"])            # pre-activation gradient of up0
         H0, H1 = s["H0"], s["H1"]
-        if s["vcat"]:
+        compact = self.sparse_top and s["vcat"] and s["cols2"] is None
+        if compact:
+            dzH0, dzH1, dzH2 = self._decoder_backward_compact(s, g, dfbuf, ws)
+            acc_mode = 2
+        else:
+            dzE0 = ops.maxpool_rows_bwd(dfbuf[:, :c0], s["arg"], P, y_tanh=s["E0"])        # pre-activation gradient of up0
+        if compact:
+            pass
+        elif s["vcat"]:
             # the concatenated operands are virtual (see _vcat_ok): weight gradients gather them again; the data gradients are
             # taken RAW (no activation derivative: nothing to read back) -- tanh' of the un-pooled half is applied after the sum
             # over a coarse row's children, tanh' of the skip half after the strided layer's contribution has been added
@@ -1014,23 +1086,7 @@ class SparseUNet(_HipNet):
             dzH2 = ops.rows_gather_bwd(dcat1[:, :c2], g["l2"]["child"], c2, torch.empty_like(s["D2"]), mode=2)
             dzH1, dzH0 = dcat1[:, c2:], dcat0[:, c1:]
             acc_mode = True                                                                 # skip part already pre-activation
-        if self.sparse_top and s["cols2"] is None:
-            # The cloud-wide max-pool leaves ONE non-zero per (cloud, channel) in the gradient of E0, and everything above the
-            # coarsest convolution is row-local (1 x 1 layers, un-pooling): the gradient that reaches conv2's output is non-zero
-            # on at most c0 rows per cloud -- the level-2 ancestors of the winning rows (32 of ~300).  Its weight gradient is
-            # the sum over THOSE rows: the same gathered GEMM on a compacted (gradient rows, neighbour rows) pair, B * c0 rows
-            # instead of the level's (a duplicate ancestor counts once: later copies become all-absent rows).
-            r0 = s["arg"].long() + (torch.arange(B, device=dy.device) * P).view(B, 1)
-            r2 = g["l2"]["parent"].view(-1)[g["l1"]["parent"].view(-1)[r0].long()].long()
-            r2, _ = torch.sort(r2, dim=1)
-            dup = torch.zeros_like(r2, dtype=torch.bool)
-            dup[:, 1:] = r2[:, 1:] == r2[:, :-1]
-            rows_c = r2.masked_fill(dup, 0).view(-1)
-            keep = (~dup).view(-1, 1)
-            dz_c = dzH2.index_select(0, rows_c) * keep
-            idx_c = g["nbr2"].index_select(0, rows_c).masked_fill(~keep, -1)
-            ops.sparse_conv_bwd_weight(dz_c, s["D2"], idx_c, c2, *self._g["conv2"], self._zero(dy.device), ws)
-        else:
+        if not compact:
             self._conv_wgrad("conv2", dzH2, s["D2"], g["nbr2"], c2, s["cols2"], ws)
         dzD2 = self._conv_dgrad("conv2", dzH2, g["nbr2"], s["D2"], torch.empty_like(s["D2"]))
         self._conv_wgrad("down1", dzD2, H1, g["l2"]["child"], c1, s["colsd1"], ws)
