@@ -244,10 +244,11 @@ def run_dagger(args, device, rank, world):
         if getattr(run.student.actor, "sparse_top", False) and run.student.actor._saved.get("vcat") and run.student.actor._saved.get("cols2") is None:
             # the cloud-wide max-pool leaves one non-zero per (cloud, channel): max-pool, up0, up1 and conv2's weight gradient run
             # over the winners' rows and their ancestors -- mb * c0 rows per level instead of the level's (network.py::
-            # _decoder_backward_compact); conv2's data gradient and everything below it stay dense
+            # _decoder_backward_compact), conv2's data gradient as the column gradient of those rows + a row-mapped gather; everything
+            # below conv2 stays dense
             compact_rows = Nc = mb * c0
             wgrad.update(conv2=Nc * 27 * c2 * c2, up1=Nc * (c2 + c1) * c1, up0=Nc * (c1 + c0) * c0)
-            dgrad.update(up1=Nc * c1 * c1 + Nc * c1 * c2, up0=Nc * c0 * c0 + Nc * c0 * c1)
+            dgrad.update(up1=Nc * c1 * c1 + Nc * c1 * c2, up0=Nc * c0 * c0 + Nc * c0 * c1, conv2=Nc * 27 * c2 * c2)
         bfl = 2.0 * sum(wgrad.values()) + 2.0 * sum(dgrad.values())
         # algorithmic HBM bytes of one forward + backward (every operand once: a layer reads its input rows, its table and
         # writes its output; its backward reads dY, its own output (tanh'), the input again (weight gradient) and writes dX)

@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 145 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 146 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -614,6 +614,11 @@ int pm_sparse_conv_bwd_weight_f32(const float* dY, long lddy, const float* src, 
 int pm_rows_gather_bwd_f32(const float* dcols, long ldc, const int32_t* tidx, const int32_t* tslot, int mode, int reverse,
                            int self_col, long rows, int J, int C, const float* y_tanh, long ldy, int accumulate, float* dsrc,
                            long lds, void* stream);
+/* The same with a COMPACTED column gradient: the table holds rows of a level, dcols only a subset of them; rowmap[row] = that
+ * row's row in dcols, or -1 (its contribution is zero).  rowmap NULL: pm_rows_gather_bwd_f32. */
+int pm_rows_gather_bwd_mapped_f32(const float* dcols, long ldc, const int32_t* tidx, const int32_t* tslot, int mode, int reverse,
+                                  int self_col, long rows, int J, int C, const float* y_tanh, long ldy, int accumulate,
+                                  float* dsrc, long lds, const int32_t* rowmap, void* stream);
 
 #ifdef __cplusplus
 }

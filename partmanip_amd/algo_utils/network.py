@@ -1035,9 +1035,14 @@ class SparseUNet(_HipNet):
         sum1 = torch.bmm(A2, dzE1.view(B, c0, c1)).view(N, c1)
         dzH2c = ops.linear_bwd_data(sum1, W("up1")[:, :c2], sel(s["H2"], r2c), e(N, c2), self._act)
         ops.sparse_conv_bwd_weight(dzH2c, s["D2"], tab(g["nbr2"], r2c, pad2), c2, *self._g["conv2"], zero, ws)
-        dzH2 = torch.zeros(R2 + 1, c2, device=dev)
-        dzH2.index_copy_(0, r2, dzH2c)
-        return dzH0[:R0], dzH1[:R1], dzH2[:R2]
+        # conv2's data gradient: the column gradient of the B * c0 rows only ((rows x 27 c2) = dz W), then every level-2 row sums
+        # the blocks of its neighbours THAT ARE among them (row -> compact row map; most taps miss) -- B * c0 x 27 c2 x c2 MACs
+        # + a gather instead of the gathered GEMM over all of the level's rows
+        slot = torch.full((R2 + 1,), -1, dtype=torch.int32, device=dev)
+        slot.index_copy_(0, r2, torch.arange(N, dtype=torch.int32, device=dev))
+        dcols = ops.linear_bwd_data(dzH2c, W("conv2"), None, e(N, 27 * c2), ops.ACT_NONE)
+        dzD2 = ops.rows_gather_bwd(dcols, g["nbr2"], c2, torch.empty_like(s["D2"]), reverse=True, self_col=13, y_tanh=s["D2"], rowmap=slot)
+        return dzH0[:R0], dzH1[:R1], dzD2
 
     def _hip_backward(self, dy):
         s, g = self._saved, self._saved["g"]
@@ -1050,7 +1055,7 @@ class SparseUNet(_HipNet):
         H0, H1 = s["H0"], s["H1"]
         compact = self.sparse_top and s["vcat"] and s["cols2"] is None
         if compact:
-            dzH0, dzH1, dzH2 = self._decoder_backward_compact(s, g, dfbuf, ws)
+            dzH0, dzH1, dzD2 = self._decoder_backward_compact(s, g, dfbuf, ws)
             acc_mode = 2
         else:
             dzE0 = ops.maxpool_rows_bwd(dfbuf[:, :c0], s["arg"], P, y_tanh=s["E0"])        # pre-activation gradient of up0
@@ -1088,7 +1093,7 @@ class SparseUNet(_HipNet):
             acc_mode = True                                                                 # skip part already pre-activation
         if not compact:
             self._conv_wgrad("conv2", dzH2, s["D2"], g["nbr2"], c2, s["cols2"], ws)
-        dzD2 = self._conv_dgrad("conv2", dzH2, g["nbr2"], s["D2"], torch.empty_like(s["D2"]))
+            dzD2 = self._conv_dgrad("conv2", dzH2, g["nbr2"], s["D2"], torch.empty_like(s["D2"]))
         self._conv_wgrad("down1", dzD2, H1, g["l2"]["child"], c1, s["colsd1"], ws)
         dcolsd1 = torch.empty(dzD2.shape[0], 8 * c1, device=dy.device)
         ops.linear_bwd_data(dzD2, W("down1"), None, dcolsd1, ops.ACT_NONE)

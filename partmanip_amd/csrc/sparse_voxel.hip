@@ -174,7 +174,10 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const float* __restric
 __global__ __launch_bounds__(256) void rows_gather_bwd_kernel(const float* __restrict__ dcols, long ldc, const int32_t* __restrict__ tidx,
                                                                const int32_t* __restrict__ tslot, int mode, int reverse, int self_col,
                                                                long rows, int J, int C, const float* __restrict__ y, long ldy,
-                                                               int accumulate, float* __restrict__ dsrc, long lds) {
+                                                               int accumulate, float* __restrict__ dsrc, long lds,
+                                                               const int32_t* __restrict__ rowmap) {
+    // rowmap (nullable): the table holds rows of a level, dcols only a SUBSET of them -- rowmap[row] = its row in dcols, or -1
+    // (a compacted column gradient: network.py::_decoder_backward_compact)
     const int c4 = C >> 2;
     const long total = rows * c4;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -190,6 +193,10 @@ __global__ __launch_bounds__(256) void rows_gather_bwd_kernel(const float* __res
             int ix[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) ix[j] = j < J ? tidx[r * J + (reverse ? J - 1 - j : j)] : -1;
+            if (rowmap) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ix[j] = ix[j] >= 0 ? rowmap[ix[j]] : -1;
+            }
             float4 v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -199,7 +206,8 @@ __global__ __launch_bounds__(256) void rows_gather_bwd_kernel(const float* __res
                 if (ix[j] >= 0) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
         } else {
             for (int j = 0; live && j < J; ++j) {
-                const int i = tidx[r * J + (reverse ? J - 1 - j : j)];
+                int i = tidx[r * J + (reverse ? J - 1 - j : j)];
+                if (i >= 0 && rowmap) i = rowmap[i];
                 if (i >= 0) {
                     const int blk = mode == 0 ? j : (mode == 1 ? tslot[r * J + j] : 0);
                     const float4 v = *(const float4*)(dcols + (long)i * ldc + (long)blk * C + 4 * q);
@@ -296,15 +304,21 @@ extern "C" int pm_rows_gather_f32(const float* src, long lds, const int32_t* idx
     return PM_OK;
 }
 
-extern "C" int pm_rows_gather_bwd_f32(const float* dcols, long ldc, const int32_t* tidx, const int32_t* tslot, int mode, int reverse,
-                                      int self_col, long rows, int J, int C, const float* y_tanh, long ldy, int accumulate,
-                                      float* dsrc, long lds, void* stream) {
+extern "C" int pm_rows_gather_bwd_mapped_f32(const float* dcols, long ldc, const int32_t* tidx, const int32_t* tslot, int mode,
+                                             int reverse, int self_col, long rows, int J, int C, const float* y_tanh, long ldy,
+                                             int accumulate, float* dsrc, long lds, const int32_t* rowmap, void* stream) {
     PM_REQUIRE(dcols && tidx && dsrc && rows > 0 && J > 0 && C > 0 && C % 4 == 0 && mode >= 0 && mode <= 2 && (mode != 1 || tslot) &&
                self_col < J);
     if ((((uintptr_t)dcols | (uintptr_t)dsrc | (uintptr_t)y_tanh) & 15) != 0 || ldc % 4 != 0 || lds % 4 != 0 || (y_tanh && ldy % 4 != 0))
         return PM_EALIGN;
     VX_LAUNCH(rows_gather_bwd_kernel, rows * (C / 4), dcols, ldc, tidx, tslot, mode, reverse, self_col, rows, J, C, y_tanh, ldy,
-              accumulate, dsrc, lds);
+              accumulate, dsrc, lds, rowmap);
     PM_CHECK_LAUNCH();
     return PM_OK;
+}
+extern "C" int pm_rows_gather_bwd_f32(const float* dcols, long ldc, const int32_t* tidx, const int32_t* tslot, int mode, int reverse,
+                                      int self_col, long rows, int J, int C, const float* y_tanh, long ldy, int accumulate,
+                                      float* dsrc, long lds, void* stream) {
+    return pm_rows_gather_bwd_mapped_f32(dcols, ldc, tidx, tslot, mode, reverse, self_col, rows, J, C, y_tanh, ldy, accumulate, dsrc, lds,
+                                         nullptr, stream);
 }

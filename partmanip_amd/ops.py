@@ -947,13 +947,15 @@ def sparse_conv_bwd_weight(dy, src, idx, C, dw, db, zero, ws):
           "pm_sparse_conv_bwd_weight_f32")
 
 
-def rows_gather_bwd(dcols, tidx, C, dsrc, tslot=None, mode=0, reverse=False, self_col=-1, y_tanh=None, accumulate=False):
-    _req(dcols, tidx, dsrc, tslot, y_tanh)
+def rows_gather_bwd(dcols, tidx, C, dsrc, tslot=None, mode=0, reverse=False, self_col=-1, y_tanh=None, accumulate=False, rowmap=None):
+    """rowmap (int32, one entry per row the table can name): dcols holds a subset of those rows -- rowmap[row] = its row in dcols or -1."""
+    _req(dcols, tidx, dsrc, tslot, y_tanh, rowmap)
     rows = tidx.shape[0]
     J = tidx.shape[1] if tidx.dim() == 2 else 1
-    check(lib.pm_rows_gather_bwd_f32(_ptr(dcols), _rows(dcols, "dcols"), _ptr(tidx), _ptr(tslot), int(mode), int(reverse),
-                                     int(self_col), rows, J, C, _ptr(y_tanh), _rows(y_tanh, "y") if y_tanh is not None else 0,
-                                     int(accumulate), _ptr(dsrc), _rows(dsrc, "dsrc"), _stream()), "pm_rows_gather_bwd_f32")
+    check(lib.pm_rows_gather_bwd_mapped_f32(_ptr(dcols), _rows(dcols, "dcols"), _ptr(tidx), _ptr(tslot), int(mode), int(reverse),
+                                            int(self_col), rows, J, C, _ptr(y_tanh), _rows(y_tanh, "y") if y_tanh is not None else 0,
+                                            int(accumulate), _ptr(dsrc), _rows(dsrc, "dsrc"), _ptr(rowmap), _stream()),
+          "pm_rows_gather_bwd_mapped_f32")
     return dsrc
 
 
