@@ -14,7 +14,7 @@
 //                      column k and walks the sorted list with one running sum
 //   ga_dw_gather_kernel / ga_dw_finish_kernel   dW[c, :] = sum_b dz[b, c] * H[b, arg[b, c], :], db[c] = sum_b dz[b, c]
 //                      (the layout of pn_dw3_gather_kernel: cloud ranges x channel blocks, fixed-order partial sums)
-// dz[b, c] = dfeat[b, c] * (1 - feat[b, c]^2).  Ties: the lowest row wins, as maxpool_rows_kernel.
+// dz[b, c] = dfeat[b, c] * (1 - feat[b, c]^2).  Ties: the lowest row wins, as maxpool_rows_kernel; a NaN wins (the first one), as torch.max.
 #include "mfma_f32.h"
 
 #define GA_TM 64                 // rows per tile
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(GA_NW * 64, GA_NW / 2) void ga_fwd_kernel(const flo
                         for (int j = 0; j < 2; ++j) {
                             const float v = j ? v2.y : v2.x;
                             const int p = t * GA_TM + mb * 32 + ((r + j) & 3) + 8 * ((r + j) >> 2) + 4 * lh;
-                            if (v > vmax[nb]) {
+                            if (v > vmax[nb] || (v != v && vmax[nb] == vmax[nb])) {   // (the FIRST NaN sticks, as torch.max: no later > is true against it)
                                 vmax[nb] = v;
                                 imax[nb] = p;
                             }
@@ -110,7 +110,12 @@ __global__ __launch_bounds__(GA_NW * 64, GA_NW / 2) void ga_fwd_kernel(const flo
             const int oi = __shfl_xor(imax[nb], 32, 64);
             float v = vmax[nb];
             int i = imax[nb];
-            if (ov > v || (ov == v && oi < i)) {
+            if (ov != ov || v != v) {                  // a NaN in either half: NaN, and the row of the first one
+                if (ov != ov && (v == v || oi < i)) {
+                    v = ov;
+                    i = oi;
+                }
+            } else if (ov > v || (ov == v && oi < i)) {
                 v = ov;
                 i = oi;
             }

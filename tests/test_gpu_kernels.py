@@ -1081,6 +1081,14 @@ def test_sa_groupall_fused_matches_fp64(B, proprio):
     picked = torch.gather(z, 1, a.view(B, 1, CO)).view(B, CO)
     assert float((picked - want).abs().max()) < 2e-6                     # the chosen row attains the maximum (fp32 ties may differ)
     assert float((a == want_arg).float().mean()) > 0.999
+    if B > 1:                                                            # a NaN row: torch.max semantics (NaN, the first NaN's row)
+        hn = hd.clone()
+        hn[R_ * 1 + 5] = float("nan")
+        hn[R_ * 1 + 9, 3] = float("nan")
+        fb2 = torch.empty(B, CO, device=DEV)
+        arg2 = o.sa_groupall_fwd(hn, B, R_, bd, packed, fb2)
+        assert bool(torch.isnan(fb2[1]).all()) and bool((arg2[1] == 5).all())
+        assert torch.equal(fb2[0], fbuf[0, :CO]) and torch.equal(fb2[2:], fbuf[2:, :CO]) and torch.equal(arg2[0], arg[0])
     # backward, routed through the rows the kernel chose
     dfd = dfeat_full.to(DEV)
     dh = torch.full((B * R_, CK), float("nan"), device=DEV)
