@@ -601,7 +601,7 @@ def test_pointnet2_ppo_iteration_runs():
     assert run.curr_iter == 2 and np.isfinite(float(run.log_dict["Train/surrogate_loss"]))
 
 
-@pytest.mark.parametrize("shape", [PN2_UNFUSED, PN2_FUSED])
+@pytest.mark.parametrize("shape", [PN2_UNFUSED, PN2_FUSED, PN2_FUSED_GA])
 def test_pointnet2_neighbourhood_tables_reproduce_the_recomputed_forward(shape):
     """precompute_geometry() + use_geometry() (what ppo.update does once per rollout) must give the bit-identical
     forward as running FPS + ball query inside every forward, for slice and for index-tensor row selections."""
@@ -621,21 +621,21 @@ def test_pointnet2_neighbourhood_tables_reproduce_the_recomputed_forward(shape):
     assert torch.equal(ac.actor.hip_forward(obs), ref)                       # tables are consumed by ONE forward
 
 
-@pytest.mark.parametrize("sampler", ["sequential", "random"])
-def test_ppo_update_pointnet2_follows_the_cpu_restatement(sampler):
+@pytest.mark.parametrize("sampler,shape", [("sequential", PN2_FUSED), ("random", PN2_FUSED), ("sequential", PN2_FUSED_GA)])
+def test_ppo_update_pointnet2_follows_the_cpu_restatement(sampler, shape):
     """Whole `ppo.update` through the PointNet2 backbone (fused SA kernels + neighbourhood tables built once per
     rollout) against oracle/ref_cpu.py's ppo_update on the same rollout.  Parity unpinned (no PointNet2 in the
     reference): this checks the HIP path against this build's own restatement, same tolerances as the golden cases."""
     from partmanip_amd.algorithms import ppo
     c = cases.case_copy(cases.PPO_CASES["ppo_pn_maxmean"])
     fx = load_fixture("ppo_pn_maxmean")
-    c["net"] = dict(name="PointNet2", activation="tanh", **PN2_FUSED)
+    c["net"] = dict(name="PointNet2", activation="tanh", **shape)
     c["desired_kl"] = 10.0                 # the fixture's old policy is a PointNet: keep the KL early-stop out of the way
     c["sampler"] = sampler
     with tempfile.TemporaryDirectory() as d:
         torch.manual_seed(3)
         run = ppo(FakeEnv(c["N"], {"normal_state": c["O"]}, c["A"]), ppo_cfg(c, device=DEV), FakeLogger(d))
-    assert run.actor_critic.actor._fused == [True, True]
+    assert run.actor_critic.actor._fused == [True, True] and run.actor_critic.actor._ga_direct == (shape is PN2_FUSED_GA)
     p = {k: v.detach().cpu().clone() for k, v in run.actor_critic.state_dict().items()}
     fill_storage(run, c, fx)
     run.storage.compute_returns(t(fx["last_values"]).to(DEV), c["gamma"], c["lam"])
