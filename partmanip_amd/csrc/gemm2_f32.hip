@@ -856,6 +856,11 @@ static int g2_launch_o(Gemm2Group& g, bool big, void* stream) {
     // multiplying wave per SIMD, whose every stall idles the matrix pipe -- and a gathered row costs its loader more issue slots
     // than a plain one; 64 x 128 (74 KB) keeps two work-groups resident.
     if (big && gather && !A_KM) { wm = 1; wn = maxN > 64 ? 2 : 1; }
+    // PLAIN forward / data-gradient operands: 128 x 64, for the same reason (74 KB: two work-groups per CU).  tools/time_gemm.py under
+    // PM_G2_TILE (profiles/round4_m_gemm_tiles.txt), 128 x 128 -> 128 x 64: 524 288 x 128 x 128 forward 253 -> 232 us, data gradient
+    // 290 -> 227; 131 072 x 288 x 256: 207 -> 189 / 307 -> 209; 131 072 x 256 x 512: 377 -> 343 / 338 -> 309 (64 x 128 the same
+    // forward, slower data gradients; two stages instead of three: slower on every shape but the first).
+    if (big && dma && !gather && !(A_KM && B_KM) && wm == 2 && wn == 2) wn = 1;
 #ifdef G2_TILE_ENV                                         // A/B builds only: PM_G2_TILE=21 / 12 / 22 forces the (wm, wn) of forward / data-gradient launches
     if (const char* e = getenv("PM_G2_TILE"); e && dma && !(A_KM && B_KM)) { wm = e[0] - '0'; wn = e[1] - '0'; }
     if (const char* e = getenv("PM_G2_WTILE"); e && (dma || gather) && A_KM && B_KM) { wm = e[0] - '0'; wn = e[1] - '0'; }   // weight gradients
