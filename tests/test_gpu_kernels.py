@@ -555,7 +555,10 @@ def test_depth2pc_streaming_fps_on_a_camera_sized_cloud():
     assert np.array_equal(idx.cpu().numpy().astype(np.int64), idx_ref)
 
 
-@pytest.mark.parametrize("B,ld,K,pad", [(64, 140000, 40, False), (30, 100000, 33, True), (128, 70000, 24, False), (3, 260000, 20, True)])
+# (100, 120 000): two work-groups per cloud, chunks of up to 60 000 points -- beyond the 25 600 register + 10 176 LDS points of a
+# work-group, i.e. the streamed region as well (the other shapes stay on chip since round 4)
+@pytest.mark.parametrize("B,ld,K,pad", [(64, 140000, 40, False), (30, 100000, 33, True), (128, 70000, 24, False), (3, 260000, 20, True),
+                                        (100, 120000, 16, False)])
 def test_varlen_fps_on_several_work_groups_per_cloud_is_bit_exact(B, ld, K, pad):
     """Camera-sized variable-length clouds: G = 256 / B work-groups share a cloud, each keeps its chunk in registers / LDS (the
     rest streams) and the G candidates of a round are handed over inside the launch (pm_fps_varlen_f32 with the
@@ -1139,3 +1142,34 @@ def test_pointnet2_fused_groupall_equals_the_unfused_level():
             a_, b_ = grads[i][off:off + v.numel()], grads[1][off:off + v.numel()]
             off += v.numel()
             assert rel_err(a_, b_.cpu()) < 2e-4, (i, k)
+
+
+def test_sa_groupall_at_the_bench_size_equals_linear_plus_max_pool():
+    """2048 clouds x 64 rows, 256 -> 512 (the shape `bench.py --workload vision_pn2` runs): the fused level against the launches it
+    replaces -- Linear + max-pool forward; pooled-gradient scatter + the two dense GEMMs backward -- on the same device tensors."""
+    o = ops()
+    B, R_, CK, CO = 2048, 64, 256, 512
+    g = torch.Generator(device=DEV).manual_seed(9)
+    h = torch.tanh(torch.randn(B * R_, CK, device=DEV, generator=g))
+    W = torch.randn(CO, CK, device=DEV, generator=g) / 16.0
+    bias = torch.randn(CO, device=DEV, generator=g) * 0.1
+    dfeat = torch.randn(B, CO, device=DEV, generator=g)
+    ws = o.Workspace(torch.device(DEV))
+    packed = torch.empty(int(o.lib.pm_sa_groupall_packed_elems(CK, CO)), device=DEV)
+    o.sa_groupall_pack(W, packed)
+    feat = torch.empty(B, CO, device=DEV)
+    arg = o.sa_groupall_fwd(h, B, R_, bias, packed, feat)
+    y = torch.empty(B * R_, CO, device=DEV)
+    o.linear_fwd(h, W, bias, y, o.ACT_TANH)
+    feat2 = torch.empty(B, CO, device=DEV)
+    arg2 = o.maxpool_rows(y, B, R_, feat2)
+    assert float((feat - feat2).abs().max()) < 2e-5
+    assert float((arg != arg2).float().mean()) < 2e-3                    # near-ties only (two summation orders)
+    dh, dW, db = torch.empty_like(h), torch.empty_like(W), torch.empty_like(bias)
+    o.sa_groupall_bwd(dfeat, feat, arg, W, h, B, R_, dh, dW, db, ws)
+    dy = o.maxpool_rows_bwd(dfeat, arg, R_, y_tanh=y)                   # routed through the fused kernel's rows
+    dW2, db2, dh2 = torch.empty_like(W), torch.empty_like(bias), torch.empty_like(h)
+    o.linear_bwd_weight(dy, h, dW2, db2, ws)
+    o.linear_bwd_data(dy, W, h, dh2, o.ACT_TANH)
+    assert rel_err(dh, dh2.cpu()) < 2e-5 and rel_err(dW, dW2.cpu()) < 2e-5 and rel_err(db, db2.cpu()) < 2e-5
+    assert bool(torch.isfinite(dh).all())
