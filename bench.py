@@ -729,10 +729,13 @@ def run_ppo(args, device, rank, world):
             if gf:
                 tf = 2.0 * rows_ga * 256 * 512 / (gf[0] * 1e-3) / 1e12
                 ga["fwd"] = dict(mean_launch_ms=gf[0], launches=gf[1], tflops=tf, frac=tf / PEAK_F32_MFMA_TFLOPS,
-                                 algorithmic_bytes=rows_ga * 256 * 4.0 + 2048 * 512 * 8.0)
+                                 algorithmic_bytes=rows_ga * 256 * 4.0 + 2048 * 512 * 8.0,
+                                 traffic=_hbm_traffic("ga_fwd_kernel_bytes_per_launch")[0])
             if gb:
                 by = rows_ga * 256 * 4.0 * 2 + 2048 * 512 * 16.0           # H in, dH out, pooled / gradient / arg-max in
+                tb = [_hbm_traffic(f"{k}_bytes_per_launch")[0] for k in ("ga_bwd_dh_kernel", "ga_dw_gather_kernel", "ga_dw_finish_kernel")]
                 ga["bwd"] = dict(mean_call_ms=gb[0], calls=gb[1], algorithmic_bytes=by, achieved_gbs=by / (gb[0] * 1e-3) / 1e9,
+                                 traffic=sum(tb) if all(t is not None for t in tb) else None,
                                  frac_of_hbm=by / (gb[0] * 1e-3) / 1e9 / PEAK_HBM_GBS, dense_gemm_flops_not_executed=2 * 2.0 * rows_ga * 256 * 512)
         if kern:
             name = max(kern, key=lambda n: kern[n]["mean_launch_ms"] * kern[n]["launches"])

@@ -113,6 +113,17 @@ if "sa" in extra and os.path.exists(extra["sa"]):
             out[f"{key}_mfma_busy"] = busy(v)
     out["sa_note"] = (f"tools/pmc_run.sh gpurun_out/{tag}/pmc_sa python tools/time_sa.py (2048 clouds, the distinct-row kernels): HBM bytes "
                       "per launch, FETCH doubled")
+if "ga" in extra and os.path.exists(extra["ga"]):
+    ga = json.load(open(extra["ga"]))
+    for kname, v in ga.items():
+        base = kname.replace("void ", "").split("<")[0].split("(")[0]
+        if base in ("ga_fwd_kernel", "ga_bwd_dh_kernel", "ga_dw_gather_kernel", "ga_dw_finish_kernel") and "FETCH_SIZE" in v:
+            f, w = traffic(v)
+            out[f"{base}_bytes_per_launch"] = f + w
+            if base == "ga_fwd_kernel" and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+                out["ga_fwd_kernel_mfma_busy"] = busy(v)
+    out["ga_note"] = (f"tools/pmc_run.sh gpurun_out/{tag}/pmc_ga python tools/time_groupall.py (2048 clouds x 64 rows, 256 -> 512): HBM bytes per "
+                      "launch, FETCH doubled")
 if "su2048" in extra and os.path.exists(extra["su2048"]):
     f, w = total(json.load(open(extra["su2048"])), 5.0)
     out["sparse_unet_2048_clouds_fetch_bytes_per_pass"] = f
