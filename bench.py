@@ -636,7 +636,7 @@ def run_ppo(args, device, rank, world):
                            backend=(torch.distributed.get_backend() if world > 1 else None),
                            train_scalars={k: float(v) for k, v in run.log_dict.items() if k.startswith("Train/")}))
     if args.workload == "vision":
-        out["config"]["backbone"] = ("PointNet -- the backbone the reference ships for this task (algo_utils/network.py:141-198); BASELINE.json "
+        out["config"]["workload_note"] = ("PointNet -- the backbone the reference ships for this task (algo_utils/network.py:141-198); BASELINE.json "
                                      "configs[2] words it as PointNet2, which the snapshot does not contain: the same 4096 env x 8 step x 1024-pt "
                                      "rollouts through the PointNet2 plug-in (HIP FPS + ball query + fused set-abstraction kernels) are "
                                      "`secondary.vision_pn2` of this line (--workload vision_pn2), with their own roofline, traffic and CPU baseline")
