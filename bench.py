@@ -622,7 +622,7 @@ def run_ppo(args, device, rank, world):
     if world > 1 or syncs:
         fl = ac.flat()
         dp = _dp_report(syncs, [fl["actor"], fl["critic"]], dt_local, args.steps, device, world)
-        dp["graph_mode"] = run.dp_graph_mode if run.use_graphs else "eager (no hipGraph replay for this backbone)"
+        dp["graph_mode"] = (run.graph_status or run.dp_graph_mode) if run.use_graphs else "eager (no hipGraph replay for this backbone)"
 
     vision = args.workload.startswith("vision")
     metric = ("PPO env-steps/sec (whole node), 4096 envs x 1024-pt clouds" if vision

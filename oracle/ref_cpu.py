@@ -176,14 +176,15 @@ def conv3dnet_forward(p, prefix, net_cfg, x, proprio_shape=0):
     return _lin(p, f"{prefix}.final_mlp.2", h)
 
 
-def net_forward(p, prefix, net_cfg, x, proprio_shape=0):
-    """actor_critic.py:16,19: backbone chosen by `net_cfg['name']`."""
+def net_forward(p, prefix, net_cfg, x, proprio_shape=0, geom=None):
+    """actor_critic.py:16,19: backbone chosen by `net_cfg['name']`.  geom: PointNet2's neighbourhood tables of these rows
+    when the caller built them ahead (`pointnet2_geometry`)."""
     if net_cfg["name"] == "MLP":
         return mlp_forward(p, prefix, net_cfg, x)
     if net_cfg["name"] == "PointNet":
         return pointnet_forward(p, prefix, net_cfg, x, proprio_shape, point_num=int(net_cfg.get("point_num", 1024)))
     if net_cfg["name"] == "PointNet2":
-        return pointnet2_forward(p, prefix, net_cfg, x, proprio_shape)
+        return pointnet2_forward(p, prefix, net_cfg, x, proprio_shape, geom=geom)
     if net_cfg["name"] == "Conv3DNet":
         return conv3dnet_forward(p, prefix, net_cfg, x, proprio_shape)
     if net_cfg["name"] == "SparseUNet":
@@ -221,15 +222,15 @@ def gaussian_logp_entropy(mu, log_std, x):
     return logp, ent.expand(mu.shape[0])
 
 
-def update_act_cri(p, model_cfg, obs, actions, proprio_shape=0, with_value=True):
+def update_act_cri(p, model_cfg, obs, actions, proprio_shape=0, with_value=True, geom=None):
     """actor_critic.py:71-82 -> (log_prob (B,), entropy (B,), value (B,1), mu (B,A), log_std rows (B,A)).
     with_value=False skips the critic forward the reference also runs (its result never enters the actor loss): only for the
     tests' fp64 evaluation of the actor's trajectory, where it halves the cost."""
     net = model_cfg["network"]
-    mu = net_forward(p, "actor", net, obs, proprio_shape)
+    mu = net_forward(p, "actor", net, obs, proprio_shape, geom)
     x = action_deactivation(actions, model_cfg["action_activate"], model_cfg["clipAction"])
     logp, ent = gaussian_logp_entropy(mu, p["log_std"], x)
-    value = net_forward(p, "critic", net, obs, proprio_shape) if with_value else None
+    value = net_forward(p, "critic", net, obs, proprio_shape, geom) if with_value else None
     return logp, ent, value, mu, p["log_std"].repeat(mu.shape[0], 1)
 
 
@@ -309,7 +310,7 @@ def split_params(p):
     return actor, critic
 
 
-def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic")):
+def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic"), geom=None):
     """ppo.py:307-411 on explicit tensors.
 
     p   : dict name -> leaf tensor (ActorCritic.state_dict() layout), updated in place.
@@ -321,6 +322,8 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic
     grad_sync : optional callable(list_of_grads, list_of_scalars)->None used by the
           multi-process parity tests to average grads/scalars across ranks.
     loops : which of the two loops to run (tests that need an fp64 evaluation of the actor's trajectory alone).
+    geom : optional PointNet2 tables of ALL rollout rows (`pointnet2_geometry` of the flat observations): every mini-batch
+          takes its rows of them instead of sampling / querying again (they depend on the coordinates only).
     Returns dict(log=..., loss_trace=[...], opt=(adam_actor, adam_critic)).
     """
     tricks, model_cfg = cfg["tricks"], cfg["model"]
@@ -336,11 +339,17 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic
     seq_lists = minibatch_index_lists(n, cfg["n_minibatches"], "sequential") if sampler == "sequential" else None
     trace, sum_surr, sum_kl, kl_max, count, sum_v, n_v = [], 0.0, 0.0, 0.0, 0, 0.0, 0
 
+    def rows_geom(idx):
+        if geom is None:
+            return None
+        r = torch.as_tensor(idx, device=geom[0][0].device)
+        return [(c[r], g[r]) for c, g in geom]
+
     for _ in range(cfg["n_updates"] if "actor" in loops else 0):
         lists = seq_lists if seq_lists is not None else minibatch_index_lists(n, cfg["n_minibatches"], sampler)
         for idx in lists:
             logp, _, _, mu, ls = update_act_cri(p, model_cfg, flat["observations"][idx], flat["actions"][idx],
-                                                cfg.get("proprio_shape", 0), with_value="critic" in loops)
+                                                cfg.get("proprio_shape", 0), with_value="critic" in loops, geom=rows_geom(idx))
             kl_mean, loss = actor_loss_terms(logp, mu, ls, flat["actions_log_prob"][idx], flat["advantages"][idx],
                                              flat["mu"][idx], flat["sigma"][idx], cfg["epsilon_clip"],
                                              tricks["mini_adv_norm"])
@@ -368,7 +377,7 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic
         for idx in lists:
             # ppo.py:366: the critic loop also calls update_act_cri, i.e. runs BOTH networks forward
             _, _, value, _, _ = update_act_cri(p, model_cfg, flat["observations"][idx], flat["actions"][idx],
-                                               cfg.get("proprio_shape", 0))
+                                               cfg.get("proprio_shape", 0), geom=rows_geom(idx))
             loss = value_loss_fn(value, flat["returns"][idx], flat["values"][idx], cfg["epsilon_clip"],
                                  tricks["use_clipped_value_loss"])
             grads = list(torch.autograd.grad(loss, [p[k] for k in ck]))
@@ -676,17 +685,83 @@ def group_points(feat, idx):
     return np.stack([feat[b][idx[b]] for b in range(B)], axis=0)
 
 
+def fps_torch(points, K):
+    """`fps` above for equal-length clouds as batched torch ops on whatever device `points` lives on (the whole-update
+    parity tests evaluate the restatement on the GPU through ATen).  Same arithmetic, element for element: fp32
+    differences, squares and the left-to-right sum as SEPARATE tensor ops (no fused multiply-add can form across them),
+    running minimum, lowest-index arg-max.  tests/test_oracle_pointnet2_rows.py pins it to the loop form."""
+    pts = torch.as_tensor(points, dtype=torch.float32)
+    B, P, D = pts.shape
+    out = torch.full((B, K), -1, dtype=torch.int64, device=pts.device)
+    mind = torch.full((B, P), float("inf"), dtype=torch.float32, device=pts.device)
+    sel = torch.zeros(B, dtype=torch.int64, device=pts.device)
+    ar, lane = torch.arange(B, device=pts.device), torch.arange(P, device=pts.device)
+    for j in range(min(K, P)):
+        out[:, j] = sel
+        d = pts - pts[ar, sel].unsqueeze(1)
+        sq = d * d
+        d2 = sq[..., 0]
+        for c in range(1, D):
+            d2 = d2 + sq[..., c]
+        mind = torch.minimum(mind, d2)
+        top = mind.max(dim=1, keepdim=True)[0]
+        sel = torch.where(mind == top, lane, P).min(dim=1)[0]        # lowest index among the maxima
+    return out
+
+
+def ball_query_torch(xyz, centers, radius, nsample, chunk=128):
+    """`ball_query` above as batched torch ops on xyz's device: (B,P,3), (B,S,3) -> (B,S,nsample) int32."""
+    xyz = torch.as_tensor(xyz, dtype=torch.float32)
+    ctr = torch.as_tensor(centers, dtype=torch.float32, device=xyz.device)
+    B, P, _ = xyz.shape
+    S = ctr.shape[1]
+    r2 = float(np.float32(radius) * np.float32(radius))
+    lane = torch.arange(P, device=xyz.device)
+    out = torch.zeros(B, S, nsample, dtype=torch.int32, device=xyz.device)
+    for lo in range(0, B, chunk):
+        d = xyz[lo:lo + chunk, None, :, :] - ctr[lo:lo + chunk, :, None, :]
+        sq = d * d
+        d2 = sq[..., 0] + sq[..., 1]
+        d2 = d2 + sq[..., 2]
+        key = torch.where(d2 < r2, lane, P)                          # hits keep their index, misses sort behind them
+        first = torch.sort(key, dim=-1)[0][..., :nsample]
+        if first.shape[-1] < nsample:
+            first = F.pad(first, (0, nsample - first.shape[-1]), value=P)
+        head = first[..., :1]
+        row = torch.where(first < P, first, head)                    # short groups repeat their first hit
+        out[lo:lo + chunk] = torch.where(head < P, row, torch.zeros_like(row)).to(torch.int32)      # no hit at all: zeros
+    return out
+
+
+def pointnet2_geometry(x, net_cfg):
+    """Centre / neighbour tables of every set-abstraction level for the clouds in x (B, >= P*C): [(idx_c (B,S) int64,
+    idx_g (B,S,ns) int64)] -- what `pointnet2_forward` computes inline, as batched torch ops on x's device so that a whole
+    rollout's tables are built once (they depend on the coordinates only) and handed to every forward (`geom=`)."""
+    P = int(net_cfg.get("point_num", 1024))
+    B = x.shape[0]
+    C = x.shape[1] // P
+    xyz = x[:, :P * C].reshape(B, P, C)[..., :3].to(torch.float32)
+    out = []
+    for S, r, ns in zip(net_cfg.get("npoints", [256, 64]), net_cfg.get("radii", [0.2, 0.4]), net_cfg.get("nsamples", [32, 32])):
+        idx_c = fps_torch(xyz, S)
+        centers = torch.gather(xyz, 1, idx_c.unsqueeze(-1).expand(B, S, 3))
+        out.append((idx_c, ball_query_torch(xyz, centers, r, ns).long()))
+        xyz = centers
+    return out
+
+
 def _pad4(n):
     return (n + 3) // 4 * 4
 
 
-def pointnet2_forward(p, prefix, net_cfg, x, proprio_shape=0, pool_args=None, return_aux=False):
+def pointnet2_forward(p, prefix, net_cfg, x, proprio_shape=0, pool_args=None, return_aux=False, geom=None):
     """PointNet++ single-scale-grouping encoder -- PARITY UNPINNED (absent from the reference; this
     restates the published structure the way partmanip_amd.algo_utils.network.PointNet2 documents it:
     per level FPS -> ball query -> rows [xyz-centre | feat | 0-pad to a multiple of 4] -> shared MLP with
     the activation after every layer -> max over the group; a final group-all level on absolute
     coordinates; the PointNet head).  `pool_args`: optional list of (G, C) index tensors pinning each
-    max-pool's arg-max (test hook, see pointnet_forward)."""
+    max-pool's arg-max (test hook, see pointnet_forward).  `geom`: the levels' (idx_c, idx_g) tables built ahead by
+    `pointnet2_geometry` from the same rows (they depend on the coordinates only); None: sampled / queried here."""
     P = int(net_cfg.get("point_num", 1024))
     B = x.shape[0]
     C = x.shape[1] // P
@@ -718,9 +793,15 @@ def pointnet2_forward(p, prefix, net_cfg, x, proprio_shape=0, pool_args=None, re
 
     for l in range(n_levels - 1):
         S, ns = npoints[l], nsamples[l]
-        idx_c = torch.from_numpy(fps(xyz.detach().numpy(), S))                       # (B,S)
-        centers = torch.gather(xyz, 1, idx_c.unsqueeze(-1).expand(B, S, 3))
-        idx_g = torch.from_numpy(ball_query(xyz.detach().numpy(), centers.detach().numpy(), radii[l], ns)).long()
+        if geom is not None:
+            idx_c, idx_g = geom[l]
+            centers = torch.gather(xyz, 1, idx_c.unsqueeze(-1).expand(B, S, 3))
+        else:
+            on_host = x.device.type == "cpu"                                         # (elsewhere: the batched torch forms)
+            idx_c = torch.from_numpy(fps(xyz.detach().numpy(), S)) if on_host else fps_torch(xyz.detach(), S)      # (B,S)
+            centers = torch.gather(xyz, 1, idx_c.unsqueeze(-1).expand(B, S, 3))
+            idx_g = torch.from_numpy(ball_query(xyz.detach().numpy(), centers.detach().numpy(), radii[l], ns)).long() if on_host \
+                else ball_query_torch(xyz.detach(), centers.detach(), radii[l], ns).long()
         flat = idx_g.reshape(B, S * ns)
         g_xyz = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(B, S * ns, 3)).reshape(B, S, ns, 3) - centers.unsqueeze(2)
         cols = [g_xyz]
@@ -730,7 +811,7 @@ def pointnet2_forward(p, prefix, net_cfg, x, proprio_shape=0, pool_args=None, re
             cols.append(torch.gather(feat, 1, flat.unsqueeze(-1).expand(B, S * ns, cf)).reshape(B, S, ns, cf))
         pad = _pad4(3 + cf) - (3 + cf)
         if pad:
-            cols.append(torch.zeros(B, S, ns, pad))
+            cols.append(torch.zeros(B, S, ns, pad, dtype=x.dtype, device=x.device))
         rows = torch.cat(cols, dim=-1).reshape(B * S * ns, -1)
         pooled = pool(shared_mlp(l, rows), B * S, ns, l)
         aux.append((idx_c, idx_g))
@@ -739,7 +820,7 @@ def pointnet2_forward(p, prefix, net_cfg, x, proprio_shape=0, pool_args=None, re
     cols = [xyz, feat]
     pad = _pad4(3 + cf) - (3 + cf)
     if pad:
-        cols.append(torch.zeros(B, S, pad))
+        cols.append(torch.zeros(B, S, pad, dtype=x.dtype, device=x.device))
     rows = torch.cat(cols, dim=-1).reshape(B * S, -1)
     f = pool(shared_mlp(n_levels - 1, rows), B, S, n_levels - 1)
     if proprio_shape != 0:
@@ -813,9 +894,62 @@ def sparse_unet_geometry(x, P, C, R):
     return dict(feat0=feat0, nbr0=nbr0, nbr1=nbr1, nbr2=nbr2, l1=l1, l2=l2, rows=(B * P, l1["rows"], l2["rows"]))
 
 
+def sparse_unet_geometry_torch(x, P, C, R):
+    """`sparse_unet_geometry` above as batched torch ops on x's device (dense per-cloud index grids instead of dicts): the same
+    tables as int64 tensors, level coordinates as one (rows, 3) tensor + the rows' cloud ids instead of per-cloud lists.
+    tests/test_oracle_sparse_unet.py pins it to the dict form."""
+    dev = x.device
+    B = x.shape[0]
+    pts = x[:, :P * C].reshape(B, P, C).to(torch.float32)
+    co = torch.floor(pts[..., :3]).long().clamp(0, R - 1)
+    f = pts[..., 3] if C > 3 else torch.ones(B, P, device=dev)
+    feat0 = torch.cat([f.unsqueeze(-1), co.to(torch.float32) / torch.full((), R, dtype=torch.float32, device=dev)], dim=-1).reshape(B * P, 4)
+    offs = torch.tensor([(dx, dy, dz) for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)], device=dev)
+    BIG = torch.iinfo(torch.int64).max
+
+    def canon_grid(coords, cloud, Rl):
+        """flat (B * Rl^3) grid: lowest row with that coordinate, -1 where the cell is empty"""
+        key = cloud * Rl ** 3 + (coords[:, 0] * Rl + coords[:, 1]) * Rl + coords[:, 2]
+        grid = torch.full((B * Rl ** 3,), BIG, dtype=torch.int64, device=dev)
+        grid.scatter_reduce_(0, key, torch.arange(coords.shape[0], device=dev), reduce="amin")
+        return torch.where(grid == BIG, torch.full_like(grid, -1), grid), key
+
+    def lookup(grid, q, cloud, Rl):
+        ok = ((q >= 0) & (q < Rl)).all(dim=-1)
+        qc = q.clamp(0, Rl - 1)
+        key = cloud * Rl ** 3 + (qc[..., 0] * Rl + qc[..., 1]) * Rl + qc[..., 2]
+        return torch.where(ok, grid[key], torch.full_like(key, -1))
+
+    def down(coords, cloud, grid, key, Rf):
+        Rc = (Rf + 1) // 2
+        cell = coords >> 1
+        ck = cloud * Rc ** 3 + (cell[:, 0] * Rc + cell[:, 1]) * Rc + cell[:, 2]
+        uniq, parent = torch.unique(ck, sorted=True, return_inverse=True)         # coarse rows: cloud by cloud, cell order
+        ccloud, rem = uniq // Rc ** 3, uniq % Rc ** 3
+        cc = torch.stack([rem // (Rc * Rc), (rem // Rc) % Rc, rem % Rc], dim=1)
+        bits = torch.tensor([(s >> 2, (s >> 1) & 1, s & 1) for s in range(8)], device=dev)
+        child = lookup(grid, 2 * cc[:, None, :] + bits[None], ccloud[:, None], Rf)
+        is_canon = grid[key] == torch.arange(coords.shape[0], device=dev)
+        slot = (coords[:, 0] & 1) * 4 + (coords[:, 1] & 1) * 2 + (coords[:, 2] & 1)
+        return dict(R=Rc, coords=cc, cloud=ccloud, rows=int(uniq.numel()), child=child, parent=parent,
+                    parent_canon=torch.where(is_canon, parent, torch.full_like(parent, -1)), slot=slot)
+
+    c0 = co.reshape(B * P, 3)
+    b0 = torch.arange(B, device=dev).repeat_interleave(P)
+    g0, k0 = canon_grid(c0, b0, R)
+    nbr0 = lookup(g0, c0[:, None, :] + offs[None], b0[:, None], R)
+    l1 = down(c0, b0, g0, k0, R)
+    g1, k1 = canon_grid(l1["coords"], l1["cloud"], l1["R"])
+    nbr1 = lookup(g1, l1["coords"][:, None, :] + offs[None], l1["cloud"][:, None], l1["R"])
+    l2 = down(l1["coords"], l1["cloud"], g1, k1, l1["R"])
+    g2, _ = canon_grid(l2["coords"], l2["cloud"], l2["R"])
+    nbr2 = lookup(g2, l2["coords"][:, None, :] + offs[None], l2["cloud"][:, None], l2["R"])
+    return dict(feat0=feat0, nbr0=nbr0, nbr1=nbr1, nbr2=nbr2, l1=l1, l2=l2, rows=(B * P, l1["rows"], l2["rows"]))
+
+
 def _rows_gather(src, idx):
     """(rows, J) index table -> (rows, J*C): neighbour rows side by side, zeros where idx < 0."""
-    idx = torch.as_tensor(idx)
+    idx = torch.as_tensor(idx, device=src.device)
     if idx.dim() == 1:
         idx = idx.view(-1, 1)
     g = src[idx.clamp(min=0)] * (idx >= 0).unsqueeze(-1).to(src.dtype)
@@ -829,9 +963,10 @@ def sparse_unet_forward(p, prefix, net_cfg, x, proprio_shape=0, return_aux=False
     B = x.shape[0]
     C = x.shape[1] // P
     act = net_cfg["activation"]
-    g = sparse_unet_geometry(x.detach().numpy(), P, C, R)
+    # (a tensor that lives on a device: the batched torch form of the same tables -- the dict form is host Python)
+    g = sparse_unet_geometry(x.detach().numpy(), P, C, R) if x.device.type == "cpu" else sparse_unet_geometry_torch(x.detach(), P, C, R)
     lin = lambda n, v: _act(act, _lin(p, f"{prefix}.{n}", v))
-    F0 = torch.from_numpy(g["feat0"]).to(x.dtype)
+    F0 = torch.as_tensor(g["feat0"]).to(x.dtype)
     H0 = lin("conv0", _rows_gather(F0, g["nbr0"]))
     D1 = lin("down0", _rows_gather(H0, g["l1"]["child"]))
     H1 = lin("conv1", _rows_gather(D1, g["nbr1"]))

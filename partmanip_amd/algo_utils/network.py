@@ -499,7 +499,7 @@ class PointNet2(_HipNet):
         ga = mlps[-1]
         object.__setattr__(self, "_ga_fused", bool(
             fused_ok and net_cfg.get('fused_groupall', True) and len(ga) >= 2 and act == 'tanh'
-            and ops.sa_groupall_supported(ga[-2], ga[-1], self.npoints[-1])))
+            and bool(self.npoints) and ops.sa_groupall_supported(ga[-2], ga[-1], self.npoints[-1])))
         object.__setattr__(self, "_ga_chain", _LinearChain(chains[-1].linears[:-1], code, final_act=True) if self._ga_fused else None)
         object.__setattr__(self, "_ga_packed", None)
         # ... and the last set-abstraction level then writes its pooled rows straight into the group-all input rows
@@ -551,6 +551,8 @@ class PointNet2(_HipNet):
         plan = None
         if self.unique_rows and centers.shape[1] <= 1024:      # (the plan's per-cloud pass holds up to 1024 groups; more: the padded kernels)
             cache, key = plan_slot if plan_slot is not None else (None, None)
+            if key is not None:
+                key = key + (dims,)                        # tile sizes follow the level's widths: actor and critic share a plan only when theirs agree
             plan = cache.get(key) if cache is not None else None
             if plan is None:
                 plan = ops.sa_plan(idx_g, xyz, centers, dims, self._workspace(xyz.device))
@@ -617,6 +619,36 @@ class PointNet2(_HipNet):
                 tabs[l][1][lo:lo + b] = ops.ball_query(xyz, centers, self.radii[l], self.nsamples[l])
                 xyz = centers
         return tabs
+
+    def precompute_plans(self, tabs, obs, slices):
+        """Packed-row plans (pm_sa_plan_i32) of every fused level for the (lo, n) row slices of `obs` a sequential pass will visit,
+        built back to back and trimmed to their real sizes after ONE host read of all the row / tile counts (`_sa_forward_fused`
+        builds a missing plan on first use with a read of its own).  Plans already in `tabs.plans` -- the other network's, same
+        widths -- are kept."""
+        P, C = self.point_num, self.in_channels
+        ws = self._workspace(obs.device)
+        built = []
+        for lo, n in slices:
+            xyz = None
+            for l, S in enumerate(self.npoints):
+                centers, idx_g = tabs[l][0][lo:lo + n], tabs[l][1][lo:lo + n]
+                if self._fused[l] and self.unique_rows and S <= 1024:
+                    lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
+                    dims = (lin1.out_features, lin2.out_features, lin3.out_features)
+                    key = (l, lo, n, dims)
+                    if key not in tabs.plans and key not in {k for k, _ in built}:
+                        if xyz is None:
+                            xyz = obs[lo:lo + n, :P * C].reshape(n, P, C)[..., :3].contiguous() if l == 0 else tabs[l - 1][0][lo:lo + n]
+                        built.append((key, ops.sa_plan(idx_g, xyz, centers, dims, ws)))
+                xyz = centers
+        if not built:
+            return
+        totals = torch.stack([pl.totals for _, pl in built]).cpu()
+        ready = torch.cuda.Event()
+        for (key, pl), t in zip(built, totals):
+            tabs.plans[key] = pl.trim((int(t[0]), int(t[1])))
+            pl.ready = ready
+        ready.record()
 
     def use_geometry(self, tabs, rows):
         """Take the next forward's neighbourhood tables from `tabs`: rows = (lo, n) slice or an index tensor."""

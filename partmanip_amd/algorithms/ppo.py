@@ -132,6 +132,7 @@ class ppo:
             # concurrently replayed graphs never interleave collectives of ONE communicator in rank-dependent order
             self.sync_c = pdist.GradSync(group=torch.distributed.new_group()) if self.overlap else self.sync
         self._graphs = {}
+        self.graph_status = None           # set once a hipGraph capture has failed and the run continued eagerly (text for the logs)
         self._obs_pad = None
         self.fused_head = os.environ.get("PARTMANIP_FUSED_HEAD", "1") == "1"
         # mini-batch steps per graph: 16 consecutive steps of a network replay as one graph (cfg 2: 1 -> 1.88 M env-steps/s,
@@ -479,21 +480,38 @@ class ppo:
                 cap = self._side if stream is not self._side else self._cap
                 cap.wait_stream(stream)
                 g = torch.cuda.CUDAGraph()
+                err = None
                 try:
                     with torch.cuda.graph(g, pool=graphs['pool'][k[0]], stream=cap):
-                        if os.environ.get("PARTMANIP_TEST_CAPTURE_FAIL") == "1":
+                        fail = os.environ.get("PARTMANIP_TEST_CAPTURE_FAIL")
+                        if fail == "1" or (fail is not None and fail.startswith("rank") and self.sync is not None
+                                           and int(fail[4:]) == self.sync.rank):
                             raise RuntimeError("PARTMANIP_TEST_CAPTURE_FAIL")
                         fn()
                 except Exception as e:                         # e.g. a collective that cannot be captured on this stack
-                    # nothing of the step has executed (capture only records): run it eagerly and stop capturing.  Graphs
-                    # captured before stay valid.  Every rank takes this branch together (same software, same step).
+                    err = e
+                stream.wait_stream(cap)
+                # Nothing of the step has executed yet (capture only records).  Under data parallelism the ranks must take the
+                # SAME path -- a rank replaying a graph with the all-reduce inside while another issues it eagerly would order
+                # the collectives of one communicator differently and hang -- so they agree on the outcome first (a capture can
+                # fail on one rank alone: memory).  One tiny all-reduce per captured graph, on this network's communicator.
+                sy = getattr(self, 'sync_c', self.sync) if k[0] == 'c' else self.sync
+                failed_here = err is not None
+                if sy is not None and sy.world > 1:
+                    failed = sy.any_(failed_here, views_device=self.device)
+                else:
+                    failed = failed_here
+                if failed:
+                    # run it eagerly and stop capturing; graphs captured before stay valid.  `dp_graph_mode` keeps naming the
+                    # launch structure of the data-parallel step (the '== "split"' checks depend on it); what happened is
+                    # said in `graph_status` (bench.py prints it).
                     graphs['broken'] = True
-                    self.dp_graph_mode = f"eager ({self.dp_graph_mode or 'graphs'}: capture failed: {type(e).__name__}: {str(e)[:120]})"
-                    print(f"[ppo] hipGraph capture of step {k[:2]} failed, continuing eagerly: {e}", file=sys.stderr)
-                    stream.wait_stream(cap)
+                    why = f"{type(err).__name__}: {str(err)[:120]}" if failed_here else "capture failed on another rank"
+                    self.graph_status = f"eager ({self.dp_graph_mode or 'graphs'}: capture failed: {why})"
+                    print(f"[ppo] hipGraph capture of step {k[:2]} failed, continuing eagerly: {why}", file=sys.stderr)
+                    del g
                     fn()
                     return
-                stream.wait_stream(cap)
                 graphs[k] = g
                 g.replay()
 
@@ -527,6 +545,13 @@ class ppo:
         batch = self.storage.mini_batch_generator(self.num_mini_batches)
         lists_a = [self._epoch_plan(batch) for _ in range(self.n_updates)]          # ppo.py:315-316
         lists_c = [self._epoch_plan(batch) for _ in range(self.n_updates)]          # ppo.py:359-360
+        if self._geom is not None and hasattr(ac.actor, 'precompute_plans'):
+            # sequential mini-batches are the same slices in every epoch and for both networks: their packed-row plans are built
+            # here, back to back, and sized by ONE host read -- not one read per (level, slice) in the middle of the first epoch,
+            # where it would stall the two streams of actor || critic
+            slices = sorted({i for ep in lists_a + lists_c for i in ep if isinstance(i, tuple)})
+            for net in (ac.actor, ac.critic):
+                net.precompute_plans(self._geom, views['obs'], slices)
         main = torch.cuda.current_stream()
         if self.overlap:
             if self._side is None:

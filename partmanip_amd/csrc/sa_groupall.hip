@@ -292,6 +292,8 @@ extern "C" int pm_sa_groupall_bwd_f32(const float* dfeat, long lddf, const float
     PM_REQUIRE(dfeat && feat && argmax && W && H && dH && dW && dbias && B > 0 && lddf >= CO && ldf >= CO && R == 64 &&
                pm_sa_groupall_supported(CK, CO, R));
     if (!workspace || workspace_bytes < pm_sa_groupall_bwd_workspace_bytes(B, CK, CO)) return PM_EWORKSPACE;
+    // dz / tmp are read and written in 16-byte pieces, H / W / dH rows likewise
+    if (((uintptr_t)workspace & 15) != 0 || ((uintptr_t)H & 15) != 0 || ((uintptr_t)W & 15) != 0 || ((uintptr_t)dH & 15) != 0) return PM_EALIGN;
     float* dz = (float*)workspace;
     float* tmp = dz + (size_t)B * CO;
     hipLaunchKernelGGL((ga_bwd_dh_kernel<256, 512, 64>), dim3(B < 2048 ? B : 2048), dim3(256), 0, pm_stream(stream), dfeat, lddf, feat, ldf,

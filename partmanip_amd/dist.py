@@ -95,6 +95,14 @@ class GradSync:
         self.sum_(mom2)
         return count * self.world
 
+    def any_(self, flag, views_device=None):
+        """True on every rank if `flag` is true on ANY rank (MAX all-reduce of one int; a host read -- control flow that all
+        ranks must take together, e.g. whether a hipGraph capture succeeded everywhere)."""
+        dev = views_device if (views_device is not None and dist.get_backend(self.group) == "nccl") else "cpu"
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.item()))
+
     def broadcast_(self, t, src=0):
         """Rank `src`'s tensor to every rank (initial parameters / optimiser state: one model, W replicas)."""
         dist.broadcast(t, src=src, group=self.group)

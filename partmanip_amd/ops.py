@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the HIP stream; every op bel
 raw device pointers to libpartmanip_hip.so.  Ops refuse CPU tensors -- there is no CPU path.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -759,9 +760,10 @@ class SaPlan:
         t = self.totals.cpu()
         return int(t[0]), int(t[1])
 
-    def trim(self):
-        """Drop the worst-case capacity of the tables (one host read): for plans that are kept, e.g. per mini-batch slice."""
-        R, T = self.counts()
+    def trim(self, counts=None):
+        """Drop the worst-case capacity of the tables: for plans that are kept, e.g. per mini-batch slice.  counts: the (packed rows,
+        tiles) a caller has already read (several plans, one host read); None: read here."""
+        R, T = counts if counts is not None else self.counts()
         self.rowmap = self.rowmap[:max(R, 1)].clone()
         self.relxyz = self.relxyz[:max(R, 1)].clone()
         self.tiles = self.tiles[:max(T, 1)].clone()
@@ -1079,12 +1081,41 @@ def fps_varlen(xyz, lengths, K, ws, pad=False):
         w = ws.get(nb + 8)
         base = w.data_ptr()
         al = (-base) % 8
+    _fps_watch_poll(ws)
     check(lib.pm_fps_varlen_f32(_ptr(xyz), B, ld, Dd, K, _ptr(lengths), int(pad), _ptr(idx), (base + al) if w is not None else None,
                                 (w.numel() - al) if w is not None else 0, _stream()), "pm_fps_varlen_f32")
     # a multi-work-group launch that gives up degrades on the device (a launch queued behind it re-samples the big clouds when
-    # the reservation's last word is set): nothing to check here, no host sync.  fps_varlen_gave_up(ws) reads the word.
+    # the reservation's last word is set): nothing to check here, no host sync.  fps_varlen_gave_up(ws) reads the word; the
+    # watch below copies it to pinned host memory behind the launch and the NEXT call looks at it (no sync either).
     ws.fps_err = w[al + nb - 8: al + nb].view(torch.int64) if (nb and int(lib.pm_fps_varlen_groups(B, ld, Dd)) >= 2) else None
+    if ws.fps_err is not None and getattr(ws, "_fps_watch", None) is None:
+        host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        host.copy_(ws.fps_err, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ws._fps_watch = (host, ev)
     return idx
+
+
+_FPS_GIVE_UPS = [0]
+
+
+def _fps_watch_poll(ws):
+    """A multi-work-group FPS launch that gave up costs its whole spin budget (~1 s) before the one-work-group sampler redoes the
+    clouds -- correct, but silent.  The give-up word of an earlier call on this workspace, copied to the host behind that call:
+    once it has arrived and is set, say so and switch the multi-work-group path off for the rest of the process (PM_FPS_MAXG=1;
+    not when a test is forcing give-ups through PM_FPS_SPIN_LIMIT)."""
+    watch = getattr(ws, "_fps_watch", None)
+    if watch is None or not watch[1].query():
+        return
+    ws._fps_watch = None
+    if int(watch[0][0]) != 0:
+        _FPS_GIVE_UPS[0] += 1
+        if os.environ.get("PM_FPS_SPIN_LIMIT") is None and os.environ.get("PM_FPS_MAXG") != "1":
+            import warnings
+            warnings.warn("pm_fps_varlen_f32: a multi-work-group sampling launch gave up waiting for its partner work-groups (the "
+                          "device is shared or CU-masked?) and fell back to one work-group per cloud; PM_FPS_MAXG=1 from now on")
+            os.environ["PM_FPS_MAXG"] = "1"
 
 
 def fps_varlen_gave_up(ws):

@@ -98,3 +98,32 @@ def test_distinct_rows_of_a_group_carry_the_whole_level():
     g_dis = torch.autograd.grad((out_dis * w).sum(), [p[k] for k in names])
     for k, a, b in zip(names, g_dis, g_pad):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=0, atol=1e-11 * max(1.0, float(b.abs().max())), err_msg=k)
+
+
+def test_batched_torch_fps_and_ball_query_equal_the_loop_forms():
+    """`fps_torch` / `ball_query_torch` (what the whole-update parity tests run on the GPU through ATen, tests/test_gpu_wholeupdate.py)
+    are the loop restatements element for element: float clouds, exact ties (duplicated points, integer voxel coordinates), short and
+    empty groups, K == P."""
+    rng = np.random.default_rng(0)
+    for B, P, S in ((3, 200, 50), (2, 64, 64), (2, 1024, 256)):
+        pts = rng.uniform(-1, 1, (B, P, 3)).astype(np.float32)
+        pts[0, 5] = pts[0, 3]
+        a = R.fps(pts, S)
+        assert np.array_equal(a, R.fps_torch(torch.from_numpy(pts), S).numpy())
+        ctr = np.take_along_axis(pts, a[..., None].repeat(3, -1), 1)
+        for r, ns in ((0.2, 32), (0.05, 8), (2.5, 16)):
+            want = R.ball_query(pts, ctr, r, ns)
+            assert np.array_equal(want, R.ball_query_torch(torch.from_numpy(pts), torch.from_numpy(ctr), r, ns, chunk=2).numpy()), (r, ns)
+    ip = rng.integers(0, 6, (3, 100, 3)).astype(np.float32)
+    assert np.array_equal(R.fps(ip, 40), R.fps_torch(torch.from_numpy(ip), 40).numpy())
+    far = np.full((1, 4, 3), 9.0, np.float32)                        # no point within the radius: all-zero rows
+    assert not R.ball_query_torch(torch.from_numpy(ip[:1]), torch.from_numpy(far), 0.5, 8).any()
+
+
+def test_forward_with_prebuilt_geometry_equals_the_inline_form():
+    x = torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, (3, NET["point_num"] * 3))).double()
+    p = _params(NET, 3, 5, 1)
+    geom = R.pointnet2_geometry(x, NET)
+    a = R.pointnet2_forward(p, "actor", NET, x)
+    b = R.pointnet2_forward(p, "actor", NET, x, geom=geom)
+    assert torch.equal(a, b)

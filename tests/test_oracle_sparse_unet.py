@@ -4,6 +4,7 @@ a submanifold 3^3 convolution is torch's conv3d with padding 1, the strided leve
 nearest-neighbour upsampling -- so the whole network must equal the dense U-Net written with torch.nn.functional.  Plus the
 set properties a voxel network has to have: invariance to the order of the rows and to duplicated / padding rows."""
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -99,3 +100,20 @@ def test_geometry_tables_are_consistent():
         for o in range(27):
             if nb[r, o] >= 0:
                 assert nb[nb[r, o], 26 - o] == r
+
+
+@pytest.mark.parametrize("dups", [False, True])
+def test_batched_torch_geometry_equals_the_dict_form(dups):
+    """`sparse_unet_geometry_torch` (dense index grids, batched: what the whole-update parity tests run on the GPU through ATen) builds
+    the tables of the per-cloud dict form entry for entry -- canonical rows of duplicated coordinates, out-of-grid taps, odd grid sizes."""
+    P, Rg = 96, 13
+    x = cases.sparse_clouds(5, P, Rg, 11, n_distinct=60 if dups else None, pad_tail=7 if dups else 0)
+    a, b = R.sparse_unet_geometry(x, P, 4, Rg), R.sparse_unet_geometry_torch(torch.from_numpy(x), P, 4, Rg)
+    assert a["rows"] == b["rows"]
+    assert np.array_equal(a["feat0"], b["feat0"].numpy())
+    for k in ("nbr0", "nbr1", "nbr2"):
+        assert np.array_equal(a[k], b[k].numpy()), k
+    for lv in ("l1", "l2"):
+        for k in ("child", "parent", "parent_canon", "slot"):
+            assert np.array_equal(a[lv][k], b[lv][k].numpy().reshape(a[lv][k].shape)), (lv, k)
+        assert np.array_equal(np.concatenate(a[lv]["coords"]), b[lv]["coords"].numpy())
