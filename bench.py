@@ -952,6 +952,40 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def _rank_table(rank, world, local):
+    """Multi-rank runs: which process drives which device over which collective library -- gathered to rank 0, printed to stderr
+    before the first step (a hang in the first all-reduce is then a hang with the topology on the screen) and kept in the line
+    (`config.ranks`)."""
+    if world <= 1:
+        return None
+    be = torch.distributed.get_backend()
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                                  # a build without the binding: say so, do not fail the run
+        ver = f"unavailable ({type(e).__name__})"
+    pr = torch.cuda.get_device_properties(local)
+    mine = dict(rank=rank, local_rank=local, pid=os.getpid(), device=f"cuda:{local}", name=pr.name,
+                pci=f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}",
+                hbm_gib=round(pr.total_memory / 2 ** 30, 1), cus=pr.multi_processor_count)
+    table = [None] * world
+    torch.distributed.all_gather_object(table, mine)
+    info = dict(backend=be, rccl_version=ver if be == "nccl" else None, world=world, ranks=table,
+                visible_devices=torch.cuda.device_count(),
+                env={k: os.environ.get(k) for k in ("NCCL_DEBUG", "HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES",
+                                                    "PARTMANIP_SHARE_GPU", "PARTMANIP_DIST_BACKEND", "PARTMANIP_DP_GRAPHS")})
+    if rank == 0:
+        print(f"[bench] {world} ranks over {be}" + (f" (RCCL {ver})" if be == "nccl" else "") + f"; {info['visible_devices']} device(s) visible",
+              file=sys.stderr)
+        for r in table:
+            print(f"[bench]   rank {r['rank']}: pid {r['pid']} -> {r['device']} {r['name']} pci {r['pci']} {r['hbm_gib']} GiB {r['cus']} CUs", file=sys.stderr)
+        if len({r["pci"] for r in table}) < world and os.environ.get("PARTMANIP_SHARE_GPU") != "1":
+            print("[bench] WARNING: several ranks drive the same device", file=sys.stderr)
+        if not os.environ.get("NCCL_DEBUG"):
+            print("[bench] a hang or an RCCL error in the first collective: rerun with NCCL_DEBUG=INFO (NCCL_DEBUG_SUBSYS=INIT,COLL) and "
+                  "check HSA_ENABLE_IPC_MODE_LEGACY=0", file=sys.stderr)
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -987,6 +1021,7 @@ def main():
             print(f"bench.py: process group reports world {torch.distributed.get_world_size()} / backend {be}; a --gpus {args.gpus} "
                   "line needs that many ranks over RCCL (backend nccl)", file=sys.stderr)
             sys.exit(2)
+    topo = _rank_table(rank, world, local)
     with contextlib.redirect_stdout(sys.stderr):           # the runners print progress lines: keep stdout = ONE JSON line
         if args.workload == "depth2pc":
             out = run_depth2pc(args, device) if rank == 0 else None
@@ -997,6 +1032,8 @@ def main():
             if args.workload == "vision" and world == 1 and args.precision == "f32" and not args.n_steps and not args.no_secondary:
                 out["secondary"] = secondary_lines(args, device)
     if rank == 0:
+        if topo is not None and isinstance(out.get("config"), dict):
+            out["config"]["ranks"] = topo
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

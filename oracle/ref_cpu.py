@@ -310,7 +310,11 @@ def split_params(p):
     return actor, critic
 
 
-def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic"), geom=None):
+def _chunks(n, chunk):
+    return [(lo, min(lo + chunk, n)) for lo in range(0, n, chunk)]
+
+
+def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic"), geom=None, grad_chunk=None):
     """ppo.py:307-411 on explicit tensors.
 
     p   : dict name -> leaf tensor (ActorCritic.state_dict() layout), updated in place.
@@ -322,6 +326,10 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic
     grad_sync : optional callable(list_of_grads, list_of_scalars)->None used by the
           multi-process parity tests to average grads/scalars across ranks.
     loops : which of the two loops to run (tests that need an fp64 evaluation of the actor's trajectory alone).
+    grad_chunk : evaluate every mini-batch in row chunks of this size -- the mini-batch's mean loss (and KL) is the size-weighted
+          sum of the chunk means and its gradient the same sum of chunk gradients; batch statistics (mini_adv_norm, the clipped
+          value loss's width) are taken over the whole mini-batch first.  Same mathematics as one shot (None); for evaluation
+          where a whole 2048-cloud mini-batch's intermediates exceed what the tensor library handles (the whole-update GPU tests).
     geom : optional PointNet2 tables of ALL rollout rows (`pointnet2_geometry` of the flat observations): every mini-batch
           takes its rows of them instead of sampling / querying again (they depend on the coordinates only).
     Returns dict(log=..., loss_trace=[...], opt=(adam_actor, adam_critic)).
@@ -348,11 +356,28 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic
     for _ in range(cfg["n_updates"] if "actor" in loops else 0):
         lists = seq_lists if seq_lists is not None else minibatch_index_lists(n, cfg["n_minibatches"], sampler)
         for idx in lists:
-            logp, _, _, mu, ls = update_act_cri(p, model_cfg, flat["observations"][idx], flat["actions"][idx],
-                                                cfg.get("proprio_shape", 0), with_value="critic" in loops, geom=rows_geom(idx))
-            kl_mean, loss = actor_loss_terms(logp, mu, ls, flat["actions_log_prob"][idx], flat["advantages"][idx],
-                                             flat["mu"][idx], flat["sigma"][idx], cfg["epsilon_clip"],
-                                             tricks["mini_adv_norm"])
+            gp = [p[k] for k in ak] + [p["log_std"]]
+            if grad_chunk is None:
+                logp, _, _, mu, ls = update_act_cri(p, model_cfg, flat["observations"][idx], flat["actions"][idx],
+                                                    cfg.get("proprio_shape", 0), with_value="critic" in loops, geom=rows_geom(idx))
+                kl_mean, loss = actor_loss_terms(logp, mu, ls, flat["actions_log_prob"][idx], flat["advantages"][idx],
+                                                 flat["mu"][idx], flat["sigma"][idx], cfg["epsilon_clip"],
+                                                 tricks["mini_adv_norm"])
+                grads = None
+            else:
+                adv = flat["advantages"][idx]
+                if tricks["mini_adv_norm"]:
+                    adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+                kl_mean, loss, grads = 0.0, 0.0, None
+                for lo, hi in _chunks(len(idx), grad_chunk):
+                    ci, w = idx[lo:hi], (hi - lo) / len(idx)
+                    logp, _, _, mu, ls = update_act_cri(p, model_cfg, flat["observations"][ci], flat["actions"][ci],
+                                                        cfg.get("proprio_shape", 0), with_value=False, geom=rows_geom(ci))
+                    kl_c, loss_c = actor_loss_terms(logp, mu, ls, flat["actions_log_prob"][ci], adv[lo:hi], flat["mu"][ci],
+                                                    flat["sigma"][ci], cfg["epsilon_clip"], False)
+                    g_c = torch.autograd.grad(loss_c * w, gp)
+                    grads = [g.clone() for g in g_c] if grads is None else [a + g for a, g in zip(grads, g_c)]
+                    kl_mean, loss = kl_mean + kl_c.detach() * w, loss + loss_c.detach() * w
             kl_mean = kl_mean.detach()
             if grad_sync is not None:
                 kl_mean = grad_sync.mean_scalar(kl_mean)
@@ -360,8 +385,8 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic
                 kl_max = float(kl_mean)
             if float(kl_mean) > cfg["desired_kl"]:
                 continue
-            gp = [p[k] for k in ak] + [p["log_std"]]
-            grads = list(torch.autograd.grad(loss, gp))
+            if grads is None:
+                grads = list(torch.autograd.grad(loss, gp))
             if grad_sync is not None:
                 grad_sync.mean_grads(grads)
             if tricks["use_grad_clip"]:
@@ -376,11 +401,25 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic
         lists = seq_lists if seq_lists is not None else minibatch_index_lists(n, cfg["n_minibatches"], sampler)
         for idx in lists:
             # ppo.py:366: the critic loop also calls update_act_cri, i.e. runs BOTH networks forward
-            _, _, value, _, _ = update_act_cri(p, model_cfg, flat["observations"][idx], flat["actions"][idx],
-                                               cfg.get("proprio_shape", 0), geom=rows_geom(idx))
-            loss = value_loss_fn(value, flat["returns"][idx], flat["values"][idx], cfg["epsilon_clip"],
-                                 tricks["use_clipped_value_loss"])
-            grads = list(torch.autograd.grad(loss, [p[k] for k in ck]))
+            if grad_chunk is None:
+                _, _, value, _, _ = update_act_cri(p, model_cfg, flat["observations"][idx], flat["actions"][idx],
+                                                   cfg.get("proprio_shape", 0), geom=rows_geom(idx))
+                loss = value_loss_fn(value, flat["returns"][idx], flat["values"][idx], cfg["epsilon_clip"],
+                                     tricks["use_clipped_value_loss"])
+                grads = list(torch.autograd.grad(loss, [p[k] for k in ck]))
+            else:
+                ret, old_v = flat["returns"][idx], flat["values"][idx]
+                if tricks["use_clipped_value_loss"]:                 # the clip width is a mean over the WHOLE mini-batch (ppo.py:370)
+                    d = (cfg["epsilon_clip"] * old_v).abs().mean()
+                    ret = old_v + (ret - old_v).clamp(-d, d)
+                loss, grads = 0.0, None
+                for lo, hi in _chunks(len(idx), grad_chunk):
+                    ci, w = idx[lo:hi], (hi - lo) / len(idx)
+                    value = net_forward(p, "critic", model_cfg["network"], flat["observations"][ci], cfg.get("proprio_shape", 0), rows_geom(ci))
+                    loss_c = (ret[lo:hi] - value).pow(2).mean()
+                    g_c = torch.autograd.grad(loss_c * w, [p[k] for k in ck])
+                    grads = [g.clone() for g in g_c] if grads is None else [a + g for a, g in zip(grads, g_c)]
+                    loss = loss + loss_c.detach() * w
             if grad_sync is not None:
                 grad_sync.mean_grads(grads)
             if tricks["use_grad_clip"]:
@@ -414,10 +453,11 @@ def ppo_update(p, st, cfg, it, opt=None, grad_sync=None, loops=("actor", "critic
 # =============================================================================
 # dagger.py
 # =============================================================================
-def dagger_update(stu, tea, ring_obs, ring_tea, cur_buf_size, cfg, it, opt=None, grad_sync=None):
+def dagger_update(stu, tea, ring_obs, ring_tea, cur_buf_size, cfg, it, opt=None, grad_sync=None, grad_chunk=None):
     """dagger.py:299-337.  `stu`/`tea`: state dicts; cfg has model (student), tea_model,
     n_updates, n_minibatches, sampler, lr, lr_schedule, max_iterations, proprio_shape.
-    grad_sync: as in ppo_update (multi-process parity tests average the gradients across ranks)."""
+    grad_sync: as in ppo_update (multi-process parity tests average the gradients across ranks); grad_chunk: as in ppo_update
+    (the mini-batch's mean loss and its gradient as size-weighted sums over row chunks)."""
     if cur_buf_size < 16:
         return None
     for k in stu:
@@ -431,10 +471,21 @@ def dagger_update(stu, tea, ring_obs, ring_tea, cur_buf_size, cfg, it, opt=None,
         for idx in minibatch_index_lists(cur_buf_size, cfg["n_minibatches"], cfg["sampler"]):
             with torch.no_grad():
                 tea_act = act(tea, cfg["tea_model"], ring_tea[idx])
-            mu = net_forward(stu, "actor", cfg["model"]["network"], ring_obs[idx], cfg.get("proprio_shape", 0))
-            stu_act = action_activation(mu, cfg["model"]["action_activate"], cfg["model"]["clipAction"])
-            loss = (tea_act - stu_act).pow(2).mean()
-            grads = list(torch.autograd.grad(loss, [stu[k] for k in names], allow_unused=True))
+            if grad_chunk is None:
+                mu = net_forward(stu, "actor", cfg["model"]["network"], ring_obs[idx], cfg.get("proprio_shape", 0))
+                stu_act = action_activation(mu, cfg["model"]["action_activate"], cfg["model"]["clipAction"])
+                loss = (tea_act - stu_act).pow(2).mean()
+                grads = list(torch.autograd.grad(loss, [stu[k] for k in names], allow_unused=True))
+            else:
+                loss, grads = 0.0, None
+                for lo, hi in _chunks(len(idx), grad_chunk):
+                    w = (hi - lo) / len(idx)
+                    mu = net_forward(stu, "actor", cfg["model"]["network"], ring_obs[idx[lo:hi]], cfg.get("proprio_shape", 0))
+                    stu_act = action_activation(mu, cfg["model"]["action_activate"], cfg["model"]["clipAction"])
+                    loss_c = (tea_act[lo:hi] - stu_act).pow(2).mean()
+                    g_c = torch.autograd.grad(loss_c * w, [stu[k] for k in names], allow_unused=True)
+                    grads = list(g_c) if grads is None else [a if g is None else a + g for a, g in zip(grads, g_c)]
+                    loss = loss + loss_c.detach() * w
             if grad_sync is not None:
                 live = [g for g in grads if g is not None]
                 grad_sync.mean_grads(live)
@@ -952,7 +1003,8 @@ def _rows_gather(src, idx):
     idx = torch.as_tensor(idx, device=src.device)
     if idx.dim() == 1:
         idx = idx.view(-1, 1)
-    g = src[idx.clamp(min=0)] * (idx >= 0).unsqueeze(-1).to(src.dtype)
+    # (index_select: the same rows as src[idx]; its backward is an index_add instead of a sort over every index)
+    g = src.index_select(0, idx.clamp(min=0).reshape(-1)).view(idx.shape[0], idx.shape[1], -1) * (idx >= 0).unsqueeze(-1).to(src.dtype)
     return g.reshape(idx.shape[0], -1)
 
 

@@ -1093,7 +1093,7 @@ def fps_varlen(xyz, lengths, K, ws, pad=False):
         host.copy_(ws.fps_err, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        ws._fps_watch = (host, ev)
+        ws._fps_watch = (host, ev, os.environ.get("PM_FPS_SPIN_LIMIT") is not None)      # (forced by a test: report, do not act)
     return idx
 
 
@@ -1104,14 +1104,14 @@ def _fps_watch_poll(ws):
     """A multi-work-group FPS launch that gave up costs its whole spin budget (~1 s) before the one-work-group sampler redoes the
     clouds -- correct, but silent.  The give-up word of an earlier call on this workspace, copied to the host behind that call:
     once it has arrived and is set, say so and switch the multi-work-group path off for the rest of the process (PM_FPS_MAXG=1;
-    not when a test is forcing give-ups through PM_FPS_SPIN_LIMIT)."""
+    not when that call ran with a forced spin budget, PM_FPS_SPIN_LIMIT: the tests' way to provoke give-ups)."""
     watch = getattr(ws, "_fps_watch", None)
     if watch is None or not watch[1].query():
         return
     ws._fps_watch = None
     if int(watch[0][0]) != 0:
         _FPS_GIVE_UPS[0] += 1
-        if os.environ.get("PM_FPS_SPIN_LIMIT") is None and os.environ.get("PM_FPS_MAXG") != "1":
+        if not watch[2] and os.environ.get("PM_FPS_MAXG") != "1":
             import warnings
             warnings.warn("pm_fps_varlen_f32: a multi-work-group sampling launch gave up waiting for its partner work-groups (the "
                           "device is shared or CU-masked?) and fell back to one work-group per cloud; PM_FPS_MAXG=1 from now on")

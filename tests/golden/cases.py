@@ -107,6 +107,18 @@ def net_param_shapes(net, in_dim, out_dim, proprio=0):
         return [("conv0", (c0, 27 * 4)), ("down0", (c1, 8 * c0)), ("conv1", (c1, 27 * c1)), ("down1", (c2, 8 * c1)),
                 ("conv2", (c2, 27 * c2)), ("up1", (c1, c2 + c1)), ("up0", (c0, c1 + c0)),
                 ("final_mlp.0", (128, c0 + proprio)), ("final_mlp.2", (32, 128)), ("final_mlp.4", (out_dim, 32))]
+    if net["name"] == "PointNet2":
+        # partmanip_amd.algo_utils.network.PointNet2: per level Linear(pad4(3 + C_prev), d0)-act-Linear-act-...; the PointNet head
+        P = int(net.get("point_num", 1024))
+        cf = (in_dim - proprio) // P - 3
+        out = []
+        for l, dims in enumerate(net.get("mlps", [[64, 64, 128], [128, 128, 256], [256, 512]])):
+            cin = (3 + cf + 3) // 4 * 4
+            for i, d in enumerate(dims):
+                out.append((f"sa.{l}.{2 * i}", (d, cin)))
+                cin = d
+            cf = dims[-1]
+        return out + [("final_mlp.0", (128, cf + proprio)), ("final_mlp.2", (32, 128)), ("final_mlp.4", (out_dim, 32))]
     raise KeyError(net["name"])
 
 

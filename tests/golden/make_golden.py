@@ -256,6 +256,80 @@ def gen_dagger(ref_algos, cases):
         print("wrote", name, "losses", out["loss_trace"])
 
 
+def gen_dagger_ckpt(ref_algos, cases):
+    """A student checkpoint written by the REFERENCE's own `dagger.save` (dagger.py:81-95) after one update, then -- by the
+    reference again -- `dagger(..., resume=ckpt)` (dagger.py:107-120) continuing with a second update on the same ring, and
+    `load_pretrain(ckpt)` (dagger.py:98-105) into a differently initialised student.  Data only: tensors + plain dicts."""
+    import shutil
+    from algorithms import ppo, dagger
+    c = cases.DAGGER_CASES["dagger_mlp"]
+    N, A = c["N"], c["A"]
+    raw = cases.dagger_raw_inputs(c)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        cwd = os.getcwd()
+        os.chdir(d)
+        try:
+            np.save("teacher_reward.npy", np.linspace(0, 1, 200).astype(np.float32))
+            tc = dict(net=c["tea_net"], T=1, n_updates=1, n_minibatches=1, tricks=dict(cases.TRICKS_DEFAULT),
+                      sampler="sequential", succ_value=None, lr=1e-3, desired_kl=0.1, lr_schedule="fixed",
+                      gamma=0.99, lam=0.95, epsilon_clip=0.2, action_std=0.5, max_iterations=10)
+            tea_run = ppo(FakeEnv(N, {"normal_state": c["O_t"]}, A), ppo_cfg(tc, N), FakeLogger(d))
+            load_sd(tea_run.actor_critic, cases.actor_critic_state(c["tea_net"], c["O_t"], A, 0.5, c["seed"] + 1))
+            tea_run.save(1)
+            env = FakeEnv(N, {"stu_mode": c["O_s"], "normal_state": c["O_t"], "proprio_state": c["proprio"]}, A)
+
+            def make(resume=None, pretrain=None):
+                cfg = dict(num_envs=N, obs_mode="stu_mode",
+                           model=dict(action_std=c["action_std"], action_activate="tanh", clipAction=1.0, network=dict(c["stu_net"])),
+                           max_iterations=c["max_iterations"], n_steps=1, n_updates=c["n_updates"], n_minibatches=c["n_minibatches"],
+                           device="cpu", buf_size=c["buf_size"], reward_reset=True, add_proprio_obs=False, offline_data_pth=None,
+                           eval_round=1, eval_frequence=10 ** 9, save_frequence=10 ** 9, test_only=False, save_pose=False,
+                           save_video=False, lr_schedule=c["lr_schedule"], lr=c["lr"], teacher=os.path.join(d, "model_1.pth"),
+                           resume=resume, pretrain=pretrain, sampler=c["sampler"])
+                run = dagger(env, cfg, FakeLogger(d))
+                for k in range(c["n_fill"]):
+                    run.storage.add_transitions_dagger(torch.from_numpy(raw["stu"][k]), torch.from_numpy(raw["tea"][k]))
+                run.log_dict = {}
+                return run
+
+            run = make()
+            load_sd(run.student, cases.actor_critic_state(c["stu_net"], c["O_s"], A, c["action_std"], c["seed"], c["proprio"]))
+            torch.manual_seed(c["torch_seed"])
+            run.update(c["it"])
+            run.total_envsteps = 4321
+            os.makedirs("stu", exist_ok=True)
+            run.save_ckpt_dir = os.path.join(d, "stu")
+            run.save(c["it"])
+            ck = os.path.join(d, "stu", f"model_{c['it']}.pth")
+            shutil.copy(ck, os.path.join(HERE, "ref_ckpt_dagger_mlp.pth"))
+            out["saved_flat"] = flat_params(run.student.state_dict())
+            # ---- resume, by the reference
+            run2 = make(resume=ck)
+            assert run2.curr_iter == c["it"] and run2.total_envsteps == 4321
+            assert np.array_equal(flat_params(run2.student.state_dict()), out["saved_flat"])
+            torch.manual_seed(c["torch_seed"] + 1)
+            with Trace(lambda: list(run2.student.parameters())) as tr:
+                run2.update(c["it"] + 1)
+            out["resume_loss_trace"] = np.array(tr.losses, dtype=np.float64)
+            out["resume_log_dagger_loss"] = np.float64(float(run2.log_dict["Train/dagger_loss"]))
+            out["resume_log_learning_rate"] = np.float64(float(run2.log_dict["Train/learning_rate"]))
+            out["resume_final_flat"] = flat_params(run2.student.state_dict())
+            st = run2.optimizer.state_dict()["state"]
+            out["resume_adam_steps"] = np.array([float(st[k]["step"]) for k in sorted(st)], dtype=np.float64)
+            # ---- load_pretrain, by the reference: every tensor but log_std comes from the checkpoint
+            run3 = make()
+            other = cases.actor_critic_state(c["stu_net"], c["O_s"], A, 0.3, c["seed"] + 50, c["proprio"])
+            load_sd(run3.student, other)
+            run3.load_pretrain(ck)
+            out["pretrain_flat"] = flat_params(run3.student.state_dict())
+            out["pretrain_log_std"] = run3.student.log_std.detach().numpy().copy()
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, "dagger_mlp_ckpt.npz"), **out)
+    print("wrote dagger_mlp_ckpt + ref_ckpt_dagger_mlp.pth; resume losses", out["resume_loss_trace"], "adam steps", out["resume_adam_steps"][:3])
+
+
 def gen_dagger_offline(ref_algos, cases):
     """Mixed BC + on-policy DAgger by the reference's own code: `RolloutStorage.add_transitions_offline`
     (storage.py:58-82, the call `dagger.run` makes first, dagger.py:186-187) on shards written to disk, then
@@ -439,7 +513,7 @@ def main():
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
     from tests.golden import cases
-    which = sys.argv[1:] or ["gae", "ppo", "dagger", "dagger_offline", "depth2pc", "bc", "conv3d", "rollout"]
+    which = sys.argv[1:] or ["gae", "ppo", "dagger", "dagger_ckpt", "dagger_offline", "depth2pc", "bc", "conv3d", "rollout"]
     if "depth2pc" in which:
         gen_depth2pc(cases)
         which = [w for w in which if w != "depth2pc"]
@@ -452,6 +526,8 @@ def main():
         gen_ppo(ref, cases)
     if "dagger" in which:
         gen_dagger(ref, cases)
+    if "dagger_ckpt" in which:
+        gen_dagger_ckpt(ref, cases)
     if "dagger_offline" in which:
         gen_dagger_offline(ref, cases)
     if "bc" in which:

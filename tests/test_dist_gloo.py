@@ -66,6 +66,7 @@ def _rank_main(rank, world, port, name, out_dir):
     np.save(os.path.join(out_dir, f"r{rank}.npy"), flat_state(p))
     np.save(os.path.join(out_dir, f"m{rank}.npy"), np.array([float(mom[0]), float(mom[1]), count]))
     np.save(os.path.join(out_dir, f"c{rank}.npy"), np.array([out["log"]["Train/kl_update_count"]]))
+    np.save(os.path.join(out_dir, f"a{rank}.npy"), np.array([float(sync.any_(rank == 3 % world)), float(sync.any_(False))]))
     sync.barrier()
     torch.distributed.destroy_process_group()
 
@@ -92,11 +93,40 @@ def test_two_rank_dp_equals_single_process(name, tmp_path):
     assert m0[2] == adv.numel()
 
 
+def test_eight_rank_dp_equals_single_process(tmp_path):
+    """The world size the driver's scaling run ends at: eight gloo ranks, one env each (N = 8), every mini-batch the union of
+    the eight ranks' rows -- identical parameters on all ranks, equal to the one-process update; the KL predicate, the moments
+    reduction and `GradSync.any_` (the cross-rank agreement used around hipGraph captures) on an 8-rank group."""
+    from oracle import ref_cpu as R
+    name, world = "ppo_mlp_klskip", 8
+    mp.spawn(_rank_main, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    c, fx = cases.PPO_CASES[name], load_fixture(name)
+    assert c["N"] == world
+    st = ppo_rollout(c, fx)
+    st["returns"], st["advantages"] = t(fx["returns"]), t(fx["advantages"])
+    keys = ("observations", "actions", "values", "returns", "actions_log_prob", "advantages", "mu", "sigma")
+    p = state_dict_t(cases.actor_critic_state(c["net"], c["O"], c["A"], c["action_std"], c["seed"]))
+    ref = R.ppo_update(p, {k: st[k] for k in keys}, ppo_cfg(c), c["it"])
+    ranks = [np.load(tmp_path / f"r{r}.npy") for r in range(world)]
+    assert all(np.array_equal(ranks[0], x) for x in ranks[1:]), "ranks diverged"
+    assert_params_close(ranks[0], flat_state(p), c["lr"], len(ref["loss_trace"]))
+    assert all(int(np.load(tmp_path / f"c{r}.npy")[0]) == ref["log"]["Train/kl_update_count"] for r in range(world))
+    adv = st["advantages"].double().reshape(-1)
+    for r in (0, world - 1):
+        m = np.load(tmp_path / f"m{r}.npy")
+        np.testing.assert_allclose(m[:2], [float(adv.sum()), float((adv * adv).sum())], rtol=1e-12)
+        assert m[2] == adv.numel()
+        assert list(np.load(tmp_path / f"a{r}.npy")) == [1.0, 0.0]          # any_(rank == 3) is true everywhere, any_(False) nowhere
+
+
 def test_shard_envs_and_env_parsing(monkeypatch):
     from partmanip_amd import dist as pdist
     assert [pdist.shard_envs(32768, r, 8) for r in (0, 7)] == [(0, 4096), (28672, 32768)]
     with pytest.raises(ValueError):
         pdist.shard_envs(10, 0, 4)
+    with pytest.raises(ValueError):
+        pdist.shard_envs(4100, 0, 8)                           # 4096-env shards only from a multiple of the world size
+    assert [pdist.shard_envs(4096, r, 8) for r in range(8)] == [(512 * r, 512 * (r + 1)) for r in range(8)]
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     assert pdist.init_from_env("gloo") == (0, 1, 0)            # single process: no group is created

@@ -350,6 +350,36 @@ def test_bench_self_launches_n_ranks(tmp_path):
     assert rec["config"]["backend"] == "gloo"
 
 
+def test_bench_eight_ranks_on_the_headline_workload(tmp_path):
+    """The driver's scaling run ends at `bench.py --gpus 8` on the headline (vision) workload, and nothing had ever started eight
+    ranks of it.  Here all eight share the box's one GPU over gloo (T = 1 so that it takes a minute): eight processes rendezvous,
+    shard nothing (weak scaling: 4096 envs each), exchange one all-reduce per optimiser step on two communicators, end with equal
+    parameters, and rank 0 prints ONE line that names every rank's device."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PARTMANIP_SHARE_GPU="1", PARTMANIP_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--workload", "vision",
+           "--n-steps", "1", "--no-cpu-baseline", "--no-optional", "--lean"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 8 and cfg["world_size_observed"] == 8 and cfg["parallelism"] == "dp8" and cfg["backend"] == "gloo"
+    assert rec["scaling"] == "weak" and rec["value"] > 0
+    dp = cfg["data_parallel"]
+    assert dp["param_checksum_equal"] is True and len(dp["per_rank_ms_per_step"]) == 8
+    # T = 1: 4096 rows per rank, n_minibatches 8 -> 512-row mini-batches: 8 per epoch x 5 epochs x {actor, critic}
+    assert dp["all_reduces_per_step"] == 80, dp["all_reduces_per_step"]
+    ranks = cfg["ranks"]
+    assert ranks["world"] == 8 and [r["rank"] for r in ranks["ranks"]] == list(range(8)) and len({r["pid"] for r in ranks["ranks"]}) == 8
+    assert "[bench] 8 ranks over gloo" in out.stderr and "rank 7: pid" in out.stderr
+
+
 # ----------------------------------------------------------------------------------------------- two REAL RCCL ranks (>= 2 GPUs)
 # A 1-GPU box skips these; on a multi-GPU node (the driver's SCALE run has one) they are the first place where RCCL carries the
 # learner's collectives between two devices: PPO-MLP with the hipGraph fast path (all-reduce captured inside the graphs),

@@ -386,6 +386,67 @@ def test_dagger_update_matches_reference(name, tmp_path, monkeypatch):
     assert set(ck) >= {"iteration", "model_state_dict", "optimizer_state_dict", "total_steps", "obs_mode", "teacher"}
 
 
+def test_dagger_resume_and_load_pretrain_from_a_reference_checkpoint(tmp_path, monkeypatch):
+    """A14 (dagger.py:98-120): `dagger(..., resume=<student checkpoint written by the REFERENCE's dagger.save>)` restores the student
+    and the single Adam's state on the GPU; one more HIP update from there lands where the reference itself landed when IT resumed
+    from that checkpoint (tests/golden/dagger_mlp_ckpt.npz); `load_pretrain` takes every tensor but log_std from the checkpoint."""
+    import os
+    from partmanip_amd.algorithms import ppo, dagger
+    from tests.helpers import GOLDEN
+    c, fx = cases.DAGGER_CASES["dagger_mlp"], load_fixture("dagger_mlp_ckpt")
+    N, A = c["N"], c["A"]
+    ckpt = os.path.join(GOLDEN, "ref_ckpt_dagger_mlp.pth")
+    monkeypatch.chdir(tmp_path)
+    np.save("teacher_reward.npy", np.linspace(0, 1, 200).astype(np.float32))
+    tc = dict(net=c["tea_net"], N=N, T=1, n_updates=1, n_minibatches=1, tricks=dict(cases.TRICKS_DEFAULT), sampler="sequential",
+              succ_value=None, lr=1e-3, desired_kl=0.1, lr_schedule="fixed", gamma=0.99, lam=0.95, epsilon_clip=0.2, action_std=0.5,
+              max_iterations=10)
+    tea_run = ppo(FakeEnv(N, {"normal_state": c["O_t"]}, A), ppo_cfg(tc, device=DEV), FakeLogger(str(tmp_path)))
+    tea_run.actor_critic.load_state_dict({k: t(v.copy()) for k, v in cases.actor_critic_state(c["tea_net"], c["O_t"], A, 0.5, c["seed"] + 1).items()})
+    tea_run.save(1)
+    env = FakeEnv(N, {"stu_mode": c["O_s"], "normal_state": c["O_t"], "proprio_state": c["proprio"]}, A)
+
+    def make(resume=None, pretrain=None):
+        cfg = dict(num_envs=N, obs_mode="stu_mode",
+                   model=dict(action_std=c["action_std"], action_activate="tanh", clipAction=1.0, network=dict(c["stu_net"])),
+                   max_iterations=c["max_iterations"], n_steps=1, n_updates=c["n_updates"], n_minibatches=c["n_minibatches"], device=DEV,
+                   buf_size=c["buf_size"], reward_reset=True, add_proprio_obs=False, offline_data_pth=None, eval_round=1,
+                   eval_frequence=10 ** 9, save_frequence=10 ** 9, test_only=False, save_pose=False, save_video=False,
+                   lr_schedule=c["lr_schedule"], lr=c["lr"], teacher=str(tmp_path / "model_1.pth"), resume=resume, pretrain=pretrain,
+                   sampler=c["sampler"])
+        return dagger(env, cfg, FakeLogger(str(tmp_path)))
+
+    run = make(resume=ckpt)
+    assert run.curr_iter == c["it"] and run.total_envsteps == 4321
+    np.testing.assert_array_equal(flat_state(run.student.state_dict()), fx["saved_flat"])
+    raw = cases.dagger_raw_inputs(c)
+    for k in range(c["n_fill"]):
+        run.storage.add_transitions_dagger(t(raw["stu"][k]).to(DEV), t(raw["tea"][k]).to(DEV))
+    torch.manual_seed(c["torch_seed"] + 1)
+    run.log_dict = {}
+    run.update(c["it"] + 1)
+    np.testing.assert_allclose(run.log_dict["Train/dagger_loss"], float(fx["resume_log_dagger_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(run.log_dict["Train/learning_rate"], float(fx["resume_log_learning_rate"]), rtol=1e-12)
+    ck = torch.load(ckpt, map_location="cpu", weights_only=False)
+    check_params(flat_state(run.student.state_dict()), fx["resume_final_flat"], 1, c["lr"], len(fx["resume_loss_trace"]),
+                 init={k: v.numpy() for k, v in ck["model_state_dict"].items()})
+    # what we write back has the reference's layout: state for the actor's tensors only, the step counts the reference reached
+    run.save(c["it"] + 1)
+    ours = torch.load(str(tmp_path / f"model_{c['it'] + 1}.pth"), map_location="cpu", weights_only=False)
+    assert sorted(ours["optimizer_state_dict"]["state"].keys()) == sorted(ck["optimizer_state_dict"]["state"].keys())
+    assert [float(ours["optimizer_state_dict"]["state"][k]["step"]) for k in sorted(ours["optimizer_state_dict"]["state"])] == list(fx["resume_adam_steps"])
+    # ---- load_pretrain (called by the constructor, dagger.py:78-79; and explicitly on a differently initialised student)
+    run3 = make(pretrain=ckpt)
+    got = flat_state(run3.student.state_dict())
+    n_ls = run3.student.log_std.numel()
+    np.testing.assert_array_equal(got[n_ls:], fx["saved_flat"][n_ls:])
+    other = cases.actor_critic_state(c["stu_net"], c["O_s"], A, 0.3, c["seed"] + 50, c["proprio"])
+    run3.student.load_state_dict({k: t(v.copy()) for k, v in other.items()})
+    run3.load_pretrain(ckpt)
+    np.testing.assert_array_equal(flat_state(run3.student.state_dict()), fx["pretrain_flat"])
+    np.testing.assert_array_equal(run3.student.log_std.detach().cpu().numpy(), fx["pretrain_log_std"])
+
+
 def test_bc_run_matches_reference(tmp_path):
     """`bc(...).run()` (dataset resident in HBM, HIP step) against the reference's own bc.run() on the same shards:
     same shuffled batches (same RNG consumption), per-iteration losses, lr schedule, final student."""

@@ -129,7 +129,7 @@ def _bracket(tag, got, o32, f64, sd, lr):
     return max(v[0] for v in e_h32.values() if v[1] > 0)
 
 
-def _ppo_whole_update(net, seed, tag, geom_check=None):
+def _ppo_whole_update(net, seed, tag, geom_check=None, grad_chunk=512):
     from partmanip_amd.algorithms import ppo
     _exact_fp32()
     N, T, O, A, lr = 4096, 8, 3072, 10, 5e-5
@@ -161,11 +161,14 @@ def _ppo_whole_update(net, seed, tag, geom_check=None):
     # ---- the oracle on the same tensors: fp32, then fp64
     roll = {k: st[k] for k in ("observations", "actions", "values", "actions_log_prob", "mu", "sigma")}
     roll["returns"], roll["advantages"] = ret, adv
-    o = R.ppo_update(p32, roll, cfg, 1, geom=geom)
+    # (grad_chunk: the restatement evaluates a 2048-cloud mini-batch in pieces -- the same update, tests/test_oracle_golden.py::
+    # test_ppo_update_in_row_chunks_equals_one_shot -- because ATen's one-shot fp32 intermediates at this size go wrong on this stack:
+    # SparseUNet's gradients came back NaN / off by 2x, while <= 256-cloud pieces agree with fp64 to 1e-6, profiles/HISTORY.md)
+    o = R.ppo_update(p32, roll, cfg, 1, geom=geom, grad_chunk=grad_chunk)
     assert len(o["loss_trace"]) == 160 and R.minibatch_size(N * T, 8) == 2048
     _free()
     p64 = {k: t(v.copy()).to(DEV).double() for k, v in sd.items()}
-    o64 = R.ppo_update(p64, {k: v.double() for k, v in roll.items()}, cfg, 1, geom=geom)
+    o64 = R.ppo_update(p64, {k: v.double() for k, v in roll.items()}, cfg, 1, geom=geom, grad_chunk=grad_chunk)
     _free()
     ref, l64 = o["log"], o64["log"]
     assert log["Train/kl_update_count"] == ref["Train/kl_update_count"] == l64["Train/kl_update_count"] == 80
@@ -196,7 +199,7 @@ def test_vision_pn2_whole_iteration_matches_oracle_fp32_and_fp64():
             assert torch.equal(idx.long(), idx_g), f"level {l}: ball-query tables differ from the restatement"
             xyz = want
         record_margin("vision_pn2: FPS centres + ball-query tables of 32768 clouds vs restatement (mismatches)", 0, 0)
-    _ppo_whole_update(net, 842, "vision_pn2 whole iteration", geom_check=tables_equal)
+    _ppo_whole_update(net, 842, "vision_pn2 whole iteration", geom_check=tables_equal, grad_chunk=256)
 
 
 def test_dagger_sparse_unet_update_at_2048_clouds_matches_oracle_fp32_and_fp64(tmp_path, monkeypatch):
@@ -243,12 +246,12 @@ def test_dagger_sparse_unet_update_at_2048_clouds_matches_oracle_fp32_and_fp64(t
     tea32 = {k: t(v.copy()).to(DEV) for k, v in tsd.items()}
     stu32 = {k: t(v.copy()).to(DEV) for k, v in init.items()}
     torch.manual_seed(8530)
-    o = R.dagger_update(stu32, tea32, ring_obs, ring_tea, N * buf, ocfg, 1)
+    o = R.dagger_update(stu32, tea32, ring_obs, ring_tea, N * buf, ocfg, 1, grad_chunk=256)
     assert len(o["loss_trace"]) == 4 and R.minibatch_size(N * buf, 2) == 2048
     _free()
     stu64 = {k: t(v.copy()).to(DEV).double() for k, v in init.items()}
     torch.manual_seed(8530)
-    o64 = R.dagger_update(stu64, {k: v.double() for k, v in tea32.items()}, ring_obs.double(), ring_tea.double(), N * buf, ocfg, 1)
+    o64 = R.dagger_update(stu64, {k: v.double() for k, v in tea32.items()}, ring_obs.double(), ring_tea.double(), N * buf, ocfg, 1, grad_chunk=256)
     _free()
     assert_close_rec("dagger SparseUNet 2048 clouds: Train/dagger_loss vs oracle32", loss, o["log"]["Train/dagger_loss"], rtol=2e-5)
     record_margin("dagger SparseUNet 2048 clouds: |loss - fp64| hip / oracle32", abs(loss - o64["log"]["Train/dagger_loss"]) /

@@ -128,6 +128,96 @@ def test_dagger(name):
     assert_params_close(fin[::s], fx["final_flat"], c["lr"], len(fx["loss_trace"]))
 
 
+def test_dagger_resume_and_load_pretrain_match_reference():
+    """dagger.py:98-120 by the reference itself (tests/golden/make_golden.py::gen_dagger_ckpt): a student checkpoint the reference
+    wrote after one update (ref_ckpt_dagger_mlp.pth), the reference resuming from it and taking a second update, and
+    `load_pretrain` into another student.  The restatement continues from the same checkpoint and must land where the reference
+    did; the checkpoint's layout is the one A14 describes (one Adam over all student parameters, state only where a gradient
+    arrived: the actor's tensors)."""
+    import os
+    from tests.helpers import GOLDEN
+    c, fx = cases.DAGGER_CASES["dagger_mlp"], load_fixture("dagger_mlp_ckpt")
+    ck = torch.load(os.path.join(GOLDEN, "ref_ckpt_dagger_mlp.pth"), map_location="cpu", weights_only=False)
+    assert set(ck) == {"iteration", "model_state_dict", "optimizer_state_dict", "total_steps", "obs_mode", "teacher"}
+    assert ck["iteration"] == c["it"] and ck["total_steps"] == 4321 and ck["obs_mode"] == "stu_mode"
+    names = list(ck["model_state_dict"].keys())
+    assert names[0] == "log_std" and np.array_equal(flat_state(ck["model_state_dict"]), fx["saved_flat"])
+    n_actor = sum(1 for k in names if k.startswith("actor."))
+    osd = ck["optimizer_state_dict"]
+    assert sorted(osd["state"].keys()) == list(range(1, 1 + n_actor)) and len(osd["param_groups"]) == 1
+    stu = {k: v.clone() for k, v in ck["model_state_dict"].items()}
+    tea = state_dict_t(cases.actor_critic_state(c["tea_net"], c["O_t"], c["A"], 0.5, c["seed"] + 1))
+    opt = R.Adam([stu[k] for k in names], osd["param_groups"][0]["lr"])
+    for i, st_ in osd["state"].items():
+        opt.m[i], opt.v[i], opt.t[i] = st_["exp_avg"].clone(), st_["exp_avg_sq"].clone(), int(st_["step"])
+    raw = cases.dagger_raw_inputs(c)
+    cap = c["buf_size"] * c["N"]
+    ring_obs, ring_tea = torch.zeros(cap, c["O_s"]), torch.zeros(cap, c["O_t"])
+    ind, size = 0, 0
+    for k in range(c["n_fill"]):
+        ind, size = R.dagger_ring_insert(ring_obs, ring_tea, ind, size, t(raw["stu"][k]), t(raw["tea"][k]))
+    model = lambda net, std: dict(action_std=std, action_activate="tanh", clipAction=1.0, network=dict(net))
+    cfg = dict(model=model(c["stu_net"], c["action_std"]), tea_model=model(c["tea_net"], 0.5), n_updates=c["n_updates"],
+               n_minibatches=c["n_minibatches"], sampler=c["sampler"], lr=c["lr"], lr_schedule=c["lr_schedule"],
+               max_iterations=c["max_iterations"], proprio_shape=c["proprio"])
+    torch.manual_seed(c["torch_seed"] + 1)
+    out = R.dagger_update(stu, tea, ring_obs, ring_tea, size, cfg, c["it"] + 1, opt=opt)
+    np.testing.assert_allclose(out["loss_trace"], fx["resume_loss_trace"], rtol=2e-4, atol=1e-8)
+    np.testing.assert_allclose(out["log"]["Train/learning_rate"], float(fx["resume_log_learning_rate"]), rtol=1e-12)
+    assert_params_close(flat_state(stu), fx["resume_final_flat"], c["lr"], len(fx["resume_loss_trace"]))
+    assert [opt.t[i] for i in range(1, 1 + n_actor)] == [int(x) for x in fx["resume_adam_steps"]]
+    # load_pretrain: everything but log_std comes from the checkpoint (dagger.py:102-103)
+    other = cases.actor_critic_state(c["stu_net"], c["O_s"], c["A"], 0.3, c["seed"] + 50, c["proprio"])
+    want = np.concatenate([np.asarray(other["log_std"], np.float32).reshape(-1), fx["saved_flat"][other["log_std"].size:]])
+    assert np.array_equal(fx["pretrain_flat"], want) and np.array_equal(fx["pretrain_log_std"], other["log_std"])
+
+
+@pytest.mark.parametrize("name", ["ppo_mlp_allon", "ppo_mlp_klskip", "ppo_mlp_random"])
+def test_ppo_update_in_row_chunks_equals_one_shot(name):
+    """`grad_chunk` (what the whole-update GPU tests evaluate the restatement with: a 2048-cloud mini-batch in pieces) is the same
+    update: in fp64 the chunked and the one-shot evaluation agree to round-off -- with mini-batch advantage normalisation and the
+    clipped value loss on (batch statistics over the WHOLE mini-batch), with KL skips, with the random sampler."""
+    c, fx = cases.PPO_CASES[name], load_fixture(name)
+    st = ppo_rollout(c, fx)
+    st["returns"], st["advantages"] = t(fx["returns"]), t(fx["advantages"])
+    keys = ("observations", "actions", "values", "returns", "actions_log_prob", "advantages", "mu", "sigma")
+    res = []
+    for chunk in (None, 5):
+        p = {k: v.double() for k, v in state_dict_t(cases.actor_critic_state(c["net"], c["O"], c["A"], c["action_std"], c["seed"])).items()}
+        torch.manual_seed(c["seed"])
+        out = R.ppo_update(p, {k: st[k].double() for k in keys}, ppo_cfg(c), c["it"], grad_chunk=chunk)
+        res.append((np.concatenate([v.numpy().reshape(-1) for v in p.values()]), out))
+    (pa, oa), (pb, ob) = res
+    np.testing.assert_allclose(pb, pa, rtol=0, atol=1e-9)
+    assert oa["log"]["Train/kl_update_count"] == ob["log"]["Train/kl_update_count"]
+    np.testing.assert_allclose(ob["loss_trace"], oa["loss_trace"], rtol=1e-10, atol=1e-14)
+    for k in ("Train/surrogate_loss", "Train/kl", "Train/kl_max", "Train/value_function_loss"):
+        np.testing.assert_allclose(ob["log"][k], oa["log"][k], rtol=1e-10, atol=1e-14, err_msg=k)
+
+
+def test_dagger_update_in_row_chunks_equals_one_shot():
+    c = cases.DAGGER_CASES["dagger_mlp"]
+    tea = {k: v.double() for k, v in state_dict_t(cases.actor_critic_state(c["tea_net"], c["O_t"], c["A"], 0.5, c["seed"] + 1)).items()}
+    raw = cases.dagger_raw_inputs(c)
+    cap = c["buf_size"] * c["N"]
+    ring_obs, ring_tea = torch.zeros(cap, c["O_s"]), torch.zeros(cap, c["O_t"])
+    ind, size = 0, 0
+    for k in range(c["n_fill"]):
+        ind, size = R.dagger_ring_insert(ring_obs, ring_tea, ind, size, t(raw["stu"][k]), t(raw["tea"][k]))
+    model = lambda net, std: dict(action_std=std, action_activate="tanh", clipAction=1.0, network=dict(net))
+    cfg = dict(model=model(c["stu_net"], c["action_std"]), tea_model=model(c["tea_net"], 0.5), n_updates=c["n_updates"],
+               n_minibatches=c["n_minibatches"], sampler=c["sampler"], lr=c["lr"], lr_schedule=c["lr_schedule"],
+               max_iterations=c["max_iterations"], proprio_shape=c["proprio"])
+    res = []
+    for chunk in (None, 7):
+        stu = {k: v.double() for k, v in state_dict_t(cases.actor_critic_state(c["stu_net"], c["O_s"], c["A"], c["action_std"], c["seed"])).items()}
+        torch.manual_seed(c["torch_seed"])
+        out = R.dagger_update(stu, tea, ring_obs.double(), ring_tea.double(), size, cfg, c["it"], grad_chunk=chunk)
+        res.append((np.concatenate([v.numpy().reshape(-1) for v in stu.values()]), out["loss_trace"]))
+    np.testing.assert_allclose(res[1][1], res[0][1], rtol=1e-10)
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=0, atol=1e-9)
+
+
 def test_dagger_small_buffer_returns_early():
     assert R.dagger_update({}, {}, None, None, 15, {}, 1) is None
 
