@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 146 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 147 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -619,6 +619,32 @@ int pm_rows_gather_bwd_f32(const float* dcols, long ldc, const int32_t* tidx, co
 int pm_rows_gather_bwd_mapped_f32(const float* dcols, long ldc, const int32_t* tidx, const int32_t* tslot, int mode, int reverse,
                                   int self_col, long rows, int J, int C, const float* y_tanh, long ldy, int accumulate,
                                   float* dsrc, long lds, const int32_t* rowmap, void* stream);
+/* ... and with a SPARSE raw skip contribution added before the activation derivative (accumulate == 2 without the dense
+ * zero-filled tensor): row r additionally receives skip[skipmap[r]][:] when skipmap[r] >= 0; dsrc is overwritten. */
+int pm_rows_gather_bwd_skip_f32(const float* dcols, long ldc, const int32_t* tidx, const int32_t* tslot, int mode, int reverse,
+                                int self_col, long rows, int J, int C, const float* y_tanh, long ldy, float* dsrc, long lds,
+                                const float* skip, long ldskip, const int32_t* skipmap, void* stream);
+
+/* ------------------------------------------------------------------ row bookkeeping of the compact decoder backward
+ * (partmanip_amd/algo_utils/network.py::SparseUNet._decoder_backward_compact: after the cloud-wide max-pool only the winners'
+ * rows and their ancestors carry a gradient through the decoder -- at most S = c0 rows per cloud and level).  Integer work, fixed
+ * order, no sort library.  A Level-2 binder reproduces the SparseUNet backward from these + the entry points above.
+ *   pm_rows_uniq_i32: per cloud b the ids v[i] = map ? (src[b][i] == pad_in ? pad_out : map[src[b][i]]) : src[b][i] + b*row_base,
+ *     i < S <= 64 -> u (B, S) = the cloud's DISTINCT ids ascending, padded with pad_out (a dummy row id >= every real id);
+ *     um = u with -1 in the padding slots; rank (B, S) = slot of id i in u[b].
+ *   pm_child_sum_f32: y[b*S + j][:] = sum_{i ascending, rank[b][i] == j} x[b*S + i][:]  (children summed into their parent's slot).
+ *   pm_rowmap_scatter_i32: map[0..n) = -1; map[ids[k]] = k for ids[k] != pad  (row -> compact slot).
+ *   pm_table_rows_i32: out[k][0..J) = sel[k] >= 0 ? table[sel[k]][0..J) : -1  (rows of an index table; -1 rows = absent taps).
+ *   pm_voxel_vcat_table_i32: out[r] = {parent[r]*m .. parent[r]*m + m-1, r + m*rows_hi}: the (m + 1)-tap gather table of a
+ *     virtual [unpool(coarse) | skip] operand whose halves share one buffer of skip-width rows.
+ *   pm_exclusive_scan_i32: base[i] = counts[0] + .. + counts[i-1], total[0] = sum (pm_voxel_down_*'s `base`). */
+int pm_rows_uniq_i32(const int32_t* src, long lds, int B, int S, long row_base, const int32_t* map, int pad_in, int pad_out,
+                     int32_t* u, int32_t* um, int32_t* rank, void* stream);
+int pm_child_sum_f32(const float* x, long ldx, const int32_t* rank, int B, int S, int C, float* y, long ldy, void* stream);
+int pm_rowmap_scatter_i32(int32_t* map, long n, const int32_t* ids, long N, int pad, void* stream);
+int pm_table_rows_i32(const int32_t* table, long ldt, int J, const int32_t* sel, long N, int32_t* out, void* stream);
+int pm_voxel_vcat_table_i32(const int32_t* parent, long rows, int m, long rows_hi, int32_t* out, void* stream);
+int pm_exclusive_scan_i32(const int32_t* counts, int n, int32_t* base, int32_t* total, void* stream);
 
 #ifdef __cplusplus
 }

@@ -110,6 +110,13 @@ SIGNATURES = {
     "pm_sparse_conv_bwd_weight_f32": (I, [P, L, P, L, P, L, I, I, P, L, P, I, P, P, Z, P]),
     "pm_rows_gather_bwd_f32": (I, [P, L, P, P, I, I, I, L, I, I, P, L, I, P, L, P]),
     "pm_rows_gather_bwd_mapped_f32": (I, [P, L, P, P, I, I, I, L, I, I, P, L, I, P, L, P, P]),
+    "pm_rows_gather_bwd_skip_f32": (I, [P, L, P, P, I, I, I, L, I, I, P, L, P, L, P, L, P, P]),
+    "pm_rows_uniq_i32": (I, [P, L, I, I, L, P, I, I, P, P, P, P]),
+    "pm_child_sum_f32": (I, [P, L, P, I, I, I, P, L, P]),
+    "pm_rowmap_scatter_i32": (I, [P, L, P, L, I, P]),
+    "pm_table_rows_i32": (I, [P, L, I, P, L, P, P]),
+    "pm_voxel_vcat_table_i32": (I, [P, L, I, L, P, P]),
+    "pm_exclusive_scan_i32": (I, [P, I, P, P, P]),
     "pm_sa_supported": (I, [I, I, I, I]),
     "pm_sa_packed_elems": (Z, [I, I, I]),
     "pm_sa_pack_weights_f32": (I, [P, P, I, I, I, P, P]),
@@ -173,7 +180,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 146                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 147                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -923,9 +923,7 @@ class SparseUNet(_HipNet):
     @staticmethod
     def _vcat_table(parent, m, rows_hi):
         """(rows, m + 1) gather table of a virtual [unpool | skip] operand: m chunks of the parent's row, then the row's own."""
-        r = torch.arange(parent.shape[0], device=parent.device, dtype=torch.int32)
-        p = parent.view(-1).to(torch.int32) * m
-        return torch.stack([p + k for k in range(m)] + [r + m * rows_hi], dim=1).contiguous()
+        return ops.voxel_vcat_table(parent.view(-1), m, rows_hi)
 
     # ---- geometry once per rollout (ppo.update): the tables depend on the coordinates only, and a sequential mini-batch is the
     # same slice of the rollout in every epoch and for both networks -- 10 forwards share one set of tables (and the two host
@@ -1006,29 +1004,24 @@ class SparseUNet(_HipNet):
                                                 H0=H0, H1=H1, E1=E1, comb0=comb0 if vcat else None, comb1=comb1 if vcat else None))
         return self._head.forward(fbuf, out)
 
-    @staticmethod
-    def _uniq_rows(v, pad):
-        """v (B, S) row ids -> (u, rank): u (B, S) the cloud's distinct ids ascending, padded with `pad`; rank (B, S) the slot of
-        v[b, i] in u[b].  Sort + first differences + scatters of equal values: deterministic, no host read."""
-        srt, order = v.sort(dim=1)
-        new = torch.ones_like(srt, dtype=torch.bool)
-        new[:, 1:] = srt[:, 1:] != srt[:, :-1]
-        rs = new.cumsum(1) - 1
-        rank = torch.empty_like(rs).scatter_(1, order, rs)
-        u = torch.full_like(srt, pad).scatter_(1, rs, srt)
-        return u, rank
-
     def _decoder_backward_compact(self, s, g, dfbuf, ws):
         """Backward of max-pool, up0, up1 and conv2's weight gradient over the rows that carry gradient.
 
         The cloud-wide max-pool leaves ONE non-zero per (cloud, channel) in the gradient of E0, and everything above the coarsest
         convolution is row-local (1 x 1 layers on [un-pooled | skip] rows): the gradient is non-zero on at most c0 rows per cloud
         at level 0 (the winners), on their parents at level 1 and on their grand-parents at level 2 -- 32 of 4096 / ~1300 / ~300.
-        Each level keeps the cloud's DISTINCT rows (c0 slots, padded with a dummy row behind the level) and a (slots x slots)
-        0/1 matrix that sums the children of a coarse row (a batched product: fixed order); the layers' GEMMs run on those
-        B * c0 rows -- the same kernels, compacted (gradient rows, table rows) pairs -- and the dense tensors the strided layers'
-        backward adds into (dzH0, dzH1: raw skip gradients; dzH2) are zero-filled and receive their rows by index (distinct
-        rows: no atomics).  Same sums as the dense form up to their order."""
+        Each level keeps the cloud's DISTINCT rows (c0 slots, ascending, padded: pm_rows_uniq_i32) and every row's slot; a coarse
+        slot sums its children's gradient rows in slot order (pm_child_sum_f32: fixed order); the layers' GEMMs run on those
+        B * c0 rows -- the same kernels, on compacted (gradient rows, table rows) pairs (pm_table_rows_i32: the padding slots
+        read absent taps).  The skip halves' raw gradients stay COMPACT: the strided layers' backward picks them up through a
+        row -> slot map (pm_rowmap_scatter_i32, pm_rows_gather_bwd_skip_f32) instead of a dense zero-filled tensor per level
+        (1 GB + 0.7 GB of fills per backward at 2048 clouds).  Same sums as the dense form up to their order.  Every step is an
+        entry point of include/partmanip_hip.h: nothing of this backward runs in the tensor library.
+
+        (The dense form sums a coarse row's children through the `child` tables -- canonical rows only -- this one through
+        `parent`, which every row has.  They agree because a duplicate-coordinate row can never be a max-pool winner: its table
+        entries are its canonical twin's (its own centre tap points at the twin), so its E0 row EQUALS the twin's bit for bit,
+        and the max-pool takes the lowest row among equals -- the twin, which by construction has the lower row index.)"""
         c0, c1, c2 = self.channels
         P, B = self.point_num, s["B"]
         dev = dfbuf.device
@@ -1036,45 +1029,31 @@ class SparseUNet(_HipNet):
         W = lambda n: getattr(self, n).weight.data
         zero = self._zero(dev)
         e = lambda r, c: torch.empty(r, c, device=dev)
-        if "p1x" not in g:                                   # parent tables with the dummy row mapped to the next level's dummy row
-            g["p1x"] = torch.cat([g["l1"]["parent"].view(-1).long(), torch.tensor([R1], device=dev)])
-            g["p2x"] = torch.cat([g["l2"]["parent"].view(-1).long(), torch.tensor([R2], device=dev)])
         N = B * c0
-        v0 = s["arg"].long() + (torch.arange(B, device=dev) * P).view(B, 1)
-        u0, rank0 = self._uniq_rows(v0, R0)
-        u1, rank1 = self._uniq_rows(g["p1x"][u0], R1)
-        u2, rank2 = self._uniq_rows(g["p2x"][u1], R2)
-        r0, r1, r2 = u0.view(-1), u1.view(-1), u2.view(-1)
-        pad0, pad1, pad2 = (r0 == R0).view(N, 1), (r1 == R1).view(N, 1), (r2 == R2).view(N, 1)
-        r0c, r1c, r2c = r0.clamp(max=R0 - 1), r1.clamp(max=R1 - 1), r2.clamp(max=R2 - 1)
-        sel = lambda t, r: t.index_select(0, r)
-        tab = lambda t, r, pad: t.index_select(0, r).masked_fill(pad, -1)
-        ones = torch.ones(B, 1, c0, device=dev)
-        A1 = torch.zeros(B, c0, c0, device=dev).scatter_(1, rank1.view(B, 1, c0), ones)      # A1[b, slot of u0's parent, u0] = 1
-        A2 = torch.zeros(B, c0, c0, device=dev).scatter_(1, rank2.view(B, 1, c0), ones)
+        u0, um0, rank0 = ops.rows_uniq(s["arg"], c0, R0, row_base=P)
+        u1, um1, rank1 = ops.rows_uniq(u0, c0, R1, table=g["l1"]["parent"].view(-1), pad_in=R0)
+        u2, um2, rank2 = ops.rows_uniq(u1, c0, R2, table=g["l2"]["parent"].view(-1), pad_in=R1)
+        sel = lambda t, um: ops.rows_gather(t, um.view(N, 1), t.shape[1], e(N, t.shape[1]))      # padding slots: zero rows
         # level 0: pooled gradient -> the winners' rows (slot = rank of the channel's winner), times tanh'(E0)
-        dzE0 = ops.maxpool_rows_bwd(dfbuf[:, :c0], rank0.to(torch.int32).contiguous(), c0, y_tanh=sel(s["E0"], r0c))
-        ops.sparse_conv_bwd_weight(dzE0, s["comb0"], tab(g["up0_idx"], r0c, pad0), c0, *self._g["up0"], zero, ws)
-        dzH0 = torch.zeros(R0 + 1, c0, device=dev)
-        dzH0.index_copy_(0, r0, ops.linear_bwd_data(dzE0, W("up0")[:, c1:], None, e(N, c0), ops.ACT_NONE))      # skip half, raw
+        dzE0 = ops.maxpool_rows_bwd(dfbuf[:, :c0], rank0, c0, y_tanh=sel(s["E0"], um0))
+        ops.sparse_conv_bwd_weight(dzE0, s["comb0"], ops.table_rows(g["up0_idx"], um0.view(-1)), c0, *self._g["up0"], zero, ws)
+        skip0 = ops.linear_bwd_data(dzE0, W("up0")[:, c1:], None, e(N, c0), ops.ACT_NONE)              # skip half, raw, compact
         # level 1
-        sum0 = torch.bmm(A1, dzE0.view(B, c0, c0)).view(N, c0)
-        dzE1 = ops.linear_bwd_data(sum0, W("up0")[:, :c1], sel(s["E1"], r1c), e(N, c1), self._act)
-        ops.sparse_conv_bwd_weight(dzE1, s["comb1"], tab(g["up1_idx"], r1c, pad1), c1, *self._g["up1"], zero, ws)
-        dzH1 = torch.zeros(R1 + 1, c1, device=dev)
-        dzH1.index_copy_(0, r1, ops.linear_bwd_data(dzE1, W("up1")[:, c2:], None, e(N, c1), ops.ACT_NONE))
+        sum0 = ops.child_sum(dzE0, rank1, e(N, c0))
+        dzE1 = ops.linear_bwd_data(sum0, W("up0")[:, :c1], sel(s["E1"], um1), e(N, c1), self._act)
+        ops.sparse_conv_bwd_weight(dzE1, s["comb1"], ops.table_rows(g["up1_idx"], um1.view(-1)), c1, *self._g["up1"], zero, ws)
+        skip1 = ops.linear_bwd_data(dzE1, W("up1")[:, c2:], None, e(N, c1), ops.ACT_NONE)
         # level 2
-        sum1 = torch.bmm(A2, dzE1.view(B, c0, c1)).view(N, c1)
-        dzH2c = ops.linear_bwd_data(sum1, W("up1")[:, :c2], sel(s["H2"], r2c), e(N, c2), self._act)
-        ops.sparse_conv_bwd_weight(dzH2c, s["D2"], tab(g["nbr2"], r2c, pad2), c2, *self._g["conv2"], zero, ws)
+        sum1 = ops.child_sum(dzE1, rank2, e(N, c1))
+        dzH2c = ops.linear_bwd_data(sum1, W("up1")[:, :c2], sel(s["H2"], um2), e(N, c2), self._act)
+        ops.sparse_conv_bwd_weight(dzH2c, s["D2"], ops.table_rows(g["nbr2"], um2.view(-1)), c2, *self._g["conv2"], zero, ws)
         # conv2's data gradient: the column gradient of the B * c0 rows only ((rows x 27 c2) = dz W), then every level-2 row sums
         # the blocks of its neighbours THAT ARE among them (row -> compact row map; most taps miss) -- B * c0 x 27 c2 x c2 MACs
         # + a gather instead of the gathered GEMM over all of the level's rows
-        slot = torch.full((R2 + 1,), -1, dtype=torch.int32, device=dev)
-        slot.index_copy_(0, r2, torch.arange(N, dtype=torch.int32, device=dev))
         dcols = ops.linear_bwd_data(dzH2c, W("conv2"), None, e(N, 27 * c2), ops.ACT_NONE)
-        dzD2 = ops.rows_gather_bwd(dcols, g["nbr2"], c2, torch.empty_like(s["D2"]), reverse=True, self_col=13, y_tanh=s["D2"], rowmap=slot)
-        return dzH0[:R0], dzH1[:R1], dzD2
+        dzD2 = ops.rows_gather_bwd(dcols, g["nbr2"], c2, torch.empty_like(s["D2"]), reverse=True, self_col=13, y_tanh=s["D2"],
+                                   rowmap=ops.rowmap_scatter(R2, u2.view(-1), R2))
+        return (skip0, ops.rowmap_scatter(R0, u0.view(-1), R0)), (skip1, ops.rowmap_scatter(R1, u1.view(-1), R1)), dzD2
 
     def _hip_backward(self, dy):
         s, g = self._saved, self._saved["g"]
@@ -1085,10 +1064,12 @@ class SparseUNet(_HipNet):
         dfbuf = torch.empty(B, c0 + self.proprio_shape, device=dy.device)
         self._head.backward(dy, ws, dx_out=dfbuf)
         H0, H1 = s["H0"], s["H1"]
-        compact = self.sparse_top and s["vcat"] and s["cols2"] is None
+        compact = self.sparse_top and s["vcat"] and s["cols2"] is None and c0 <= 64
+        skip0 = skip1 = None
         if compact:
-            dzH0, dzH1, dzD2 = self._decoder_backward_compact(s, g, dfbuf, ws)
-            acc_mode = 2
+            skip0, skip1, dzD2 = self._decoder_backward_compact(s, g, dfbuf, ws)
+            dzH0, dzH1 = torch.empty(g["rows"][0], c0, device=dy.device), torch.empty(g["rows"][1], c1, device=dy.device)
+            acc_mode = False
         else:
             dzE0 = ops.maxpool_rows_bwd(dfbuf[:, :c0], s["arg"], P, y_tanh=s["E0"])        # pre-activation gradient of up0
         if compact:
@@ -1130,14 +1111,14 @@ class SparseUNet(_HipNet):
         dcolsd1 = torch.empty(dzD2.shape[0], 8 * c1, device=dy.device)
         ops.linear_bwd_data(dzD2, W("down1"), None, dcolsd1, ops.ACT_NONE)
         ops.rows_gather_bwd(dcolsd1, g["l2"]["parent_canon"].view(-1, 1), c1, dzH1, tslot=g["l2"]["slot"].view(-1, 1), mode=1,
-                            y_tanh=H1, accumulate=acc_mode)
+                            y_tanh=H1, accumulate=acc_mode, skip=skip1)
         self._conv_wgrad("conv1", dzH1, s["D1"], g["nbr1"], c1, s["cols1"], ws)
         dzD1 = self._conv_dgrad("conv1", dzH1, g["nbr1"], s["D1"], torch.empty_like(s["D1"]))
         self._conv_wgrad("down0", dzD1, H0, g["l1"]["child"], c0, s["colsd0"], ws)
         dcolsd0 = torch.empty(dzD1.shape[0], 8 * c0, device=dy.device)
         ops.linear_bwd_data(dzD1, W("down0"), None, dcolsd0, ops.ACT_NONE)
         ops.rows_gather_bwd(dcolsd0, g["l1"]["parent_canon"].view(-1, 1), c0, dzH0, tslot=g["l1"]["slot"].view(-1, 1), mode=1,
-                            y_tanh=H0, accumulate=acc_mode)
+                            y_tanh=H0, accumulate=acc_mode, skip=skip0)
         self._conv_wgrad("conv0", dzH0, g["feat0"], g["nbr0"], 4, s["cols0"], ws)           # the input features are data
 
 

@@ -175,7 +175,11 @@ __global__ __launch_bounds__(256) void rows_gather_bwd_kernel(const float* __res
                                                                const int32_t* __restrict__ tslot, int mode, int reverse, int self_col,
                                                                long rows, int J, int C, const float* __restrict__ y, long ldy,
                                                                int accumulate, float* __restrict__ dsrc, long lds,
-                                                               const int32_t* __restrict__ rowmap) {
+                                                               const int32_t* __restrict__ rowmap, const float* __restrict__ skip,
+                                                               long ldskip, const int32_t* __restrict__ skipmap) {
+    // skip / skipmap (nullable): a SPARSE raw contribution to add before the activation derivative -- row r receives
+    // skip[skipmap[r]] when skipmap[r] >= 0 (the compact decoder backward: only the max-pool winners' ancestors carry a skip
+    // gradient; the dense zero-filled tensor that accumulate == 2 reads back is never built)
     // rowmap (nullable): the table holds rows of a level, dcols only a SUBSET of them -- rowmap[row] = its row in dcols, or -1
     // (a compacted column gradient: network.py::_decoder_backward_compact)
     const int c4 = C >> 2;
@@ -219,6 +223,13 @@ __global__ __launch_bounds__(256) void rows_gather_bwd_kernel(const float* __res
         if (accumulate == 2) {                             // dsrc holds a RAW contribution: (it + the gathered sum) * act'
             const float4 p = *o;
             s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        if (skipmap) {
+            const int k = skipmap[r];
+            if (k >= 0) {
+                const float4 p = *(const float4*)(skip + (long)k * ldskip + 4 * q);
+                s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+            }
         }
         if (y) {
             const float4 h = *(const float4*)(y + r * ldy + 4 * q);
@@ -312,7 +323,21 @@ extern "C" int pm_rows_gather_bwd_mapped_f32(const float* dcols, long ldc, const
     if ((((uintptr_t)dcols | (uintptr_t)dsrc | (uintptr_t)y_tanh) & 15) != 0 || ldc % 4 != 0 || lds % 4 != 0 || (y_tanh && ldy % 4 != 0))
         return PM_EALIGN;
     VX_LAUNCH(rows_gather_bwd_kernel, rows * (C / 4), dcols, ldc, tidx, tslot, mode, reverse, self_col, rows, J, C, y_tanh, ldy,
-              accumulate, dsrc, lds, rowmap);
+              accumulate, dsrc, lds, rowmap, (const float*)nullptr, 0L, (const int32_t*)nullptr);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+extern "C" int pm_rows_gather_bwd_skip_f32(const float* dcols, long ldc, const int32_t* tidx, const int32_t* tslot, int mode,
+                                           int reverse, int self_col, long rows, int J, int C, const float* y_tanh, long ldy,
+                                           float* dsrc, long lds, const float* skip, long ldskip, const int32_t* skipmap,
+                                           void* stream) {
+    PM_REQUIRE(dcols && tidx && dsrc && skip && skipmap && rows > 0 && J > 0 && C > 0 && C % 4 == 0 && mode >= 0 && mode <= 2 &&
+               (mode != 1 || tslot) && self_col < J && ldskip >= C);
+    if ((((uintptr_t)dcols | (uintptr_t)dsrc | (uintptr_t)y_tanh | (uintptr_t)skip) & 15) != 0 || ldc % 4 != 0 || lds % 4 != 0 ||
+        ldskip % 4 != 0 || (y_tanh && ldy % 4 != 0))
+        return PM_EALIGN;
+    VX_LAUNCH(rows_gather_bwd_kernel, rows * (C / 4), dcols, ldc, tidx, tslot, mode, reverse, self_col, rows, J, C, y_tanh, ldy, 0,
+              dsrc, lds, (const int32_t*)nullptr, skip, ldskip, skipmap);
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
@@ -321,4 +346,174 @@ extern "C" int pm_rows_gather_bwd_f32(const float* dcols, long ldc, const int32_
                                       float* dsrc, long lds, void* stream) {
     return pm_rows_gather_bwd_mapped_f32(dcols, ldc, tidx, tslot, mode, reverse, self_col, rows, J, C, y_tanh, ldy, accumulate, dsrc, lds,
                                          nullptr, stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row bookkeeping of the compact decoder backward (network.py::SparseUNet._decoder_backward_compact) -- the cloud-wide max-pool
+// leaves at most S = c0 rows per cloud with a gradient; these kernels name those rows and their ancestors per level, sum the
+// children of a coarse row and build row -> compact-slot maps, all in fixed order (no sort library, no atomics on data).
+
+// One wave per cloud, S <= 64 ids: v[i] = src[b][i] (+ b * row_base), through `map` (v == pad_in -> pad_out); u[b] = the
+// cloud's DISTINCT mapped ids ascending, padded with pad_out; um = the same with -1 in the padding slots; rank[b][i] = the slot
+// of id i in u[b].  All-pairs through the wave (S shuffles): rank = number of distinct smaller ids.
+__global__ __launch_bounds__(64) void rows_uniq_kernel(const int32_t* __restrict__ src, long lds, int B, int S, long row_base,
+                                                        const int32_t* __restrict__ map, int pad_in, int pad_out,
+                                                        int32_t* __restrict__ u, int32_t* __restrict__ um,
+                                                        int32_t* __restrict__ rank) {
+    const int b = blockIdx.x, i = threadIdx.x;
+    int v = 0x7fffffff;
+    if (i < S) {
+        const int raw = src[(long)b * lds + i];
+        if (map) v = raw == pad_in ? pad_out : map[raw];
+        else v = (int)(raw + (long)b * row_base);
+    }
+    // first occurrence of its value? (lanes >= S hold INT_MAX and are ignored)
+    bool first = i < S;
+    for (int j = 0; j < S; ++j) {
+        const int vj = __shfl(v, j, 64);
+        if (j < i && vj == v) first = false;
+    }
+    int less = 0;
+    for (int j = 0; j < S; ++j) {
+        const int vj = __shfl(v, j, 64);
+        const bool fj = __shfl((int)first, j, 64) != 0;
+        if (fj && vj < v) ++less;
+    }
+    const unsigned long long firsts = __ballot(first && v != pad_out);
+    const int ndist = __popcll(firsts);                      // distinct live ids (the pad id sorts last: pad_out >= every row id)
+    if (i < S) {
+        rank[(long)b * S + i] = less;
+        if (first && v != pad_out) {
+            u[(long)b * S + less] = v;
+            um[(long)b * S + less] = v;
+        }
+        if (i >= ndist) {
+            u[(long)b * S + i] = pad_out;
+            um[(long)b * S + i] = -1;
+        }
+    }
+}
+
+extern "C" int pm_rows_uniq_i32(const int32_t* src, long lds, int B, int S, long row_base, const int32_t* map, int pad_in,
+                                int pad_out, int32_t* u, int32_t* um, int32_t* rank, void* stream) {
+    PM_REQUIRE(src && u && um && rank && B > 0 && S > 0 && S <= 64 && lds >= S && pad_out >= 0);
+    hipLaunchKernelGGL(rows_uniq_kernel, dim3(B), dim3(64), 0, pm_stream(stream), src, lds, B, S, row_base, map, pad_in, pad_out, u, um,
+                       rank);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// y[b*S + j][:] = sum over i (ascending) with rank[b][i] == j of x[b*S + i][:]   -- the children of compact coarse row j
+__global__ __launch_bounds__(256) void child_sum_kernel(const float* __restrict__ x, long ldx, const int32_t* __restrict__ rank,
+                                                         int S, int C, float* __restrict__ y, long ldy) {
+    __shared__ int rk[64];
+    const long b = blockIdx.x;
+    if (threadIdx.x < S) rk[threadIdx.x] = rank[b * S + threadIdx.x];
+    __syncthreads();
+    const int c4n = C >> 2;
+    for (int e = threadIdx.x; e < S * c4n; e += 256) {
+        const int j = e / c4n, q = e - j * c4n;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < S; ++i)
+            if (rk[i] == j) {
+                const float4 v = *(const float4*)(x + (b * S + i) * ldx + 4 * q);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        *(float4*)(y + (b * S + j) * ldy + 4 * q) = s;
+    }
+}
+
+extern "C" int pm_child_sum_f32(const float* x, long ldx, const int32_t* rank, int B, int S, int C, float* y, long ldy, void* stream) {
+    PM_REQUIRE(x && rank && y && B > 0 && S > 0 && S <= 64 && C > 0 && C % 4 == 0 && ldx >= C && ldy >= C);
+    if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0 || ldx % 4 != 0 || ldy % 4 != 0) return PM_EALIGN;
+    hipLaunchKernelGGL(child_sum_kernel, dim3(B), dim3(256), 0, pm_stream(stream), x, ldx, rank, S, C, y, ldy);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// map[0 .. n) = -1, then map[ids[k]] = k for the ids that are not `pad` (ids distinct apart from the padding)
+__global__ __launch_bounds__(256) void rowmap_scatter_kernel(int32_t* __restrict__ map, long n, const int32_t* __restrict__ ids, long N,
+                                                              int pad) {
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < N; k += (long)gridDim.x * 256) {
+        const int r = ids[k];
+        if (r != pad && r >= 0 && r < n) map[r] = (int)k;
+    }
+}
+
+extern "C" int pm_rowmap_scatter_i32(int32_t* map, long n, const int32_t* ids, long N, int pad, void* stream) {
+    PM_REQUIRE(map && ids && n > 0 && N > 0);
+    if (hipMemsetAsync(map, 0xFF, (size_t)n * sizeof(int32_t), pm_stream(stream)) != hipSuccess) return PM_EINVAL;
+    VX_LAUNCH(rowmap_scatter_kernel, N, map, n, ids, N, pad);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// out[k][:] = sel[k] >= 0 ? table[sel[k]][:] : -1      (rows of an index table picked by row id; -1 rows for the padding)
+__global__ __launch_bounds__(256) void table_rows_kernel(const int32_t* __restrict__ table, long ldt, int J, const int32_t* __restrict__ sel,
+                                                          long N, int32_t* __restrict__ out) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < N * J; e += (long)gridDim.x * 256) {
+        const long k = e / J;
+        const int j = (int)(e - k * J);
+        const int r = sel[k];
+        out[e] = r >= 0 ? table[(long)r * ldt + j] : -1;
+    }
+}
+
+extern "C" int pm_table_rows_i32(const int32_t* table, long ldt, int J, const int32_t* sel, long N, int32_t* out, void* stream) {
+    PM_REQUIRE(table && sel && out && J > 0 && ldt >= J && N > 0);
+    VX_LAUNCH(table_rows_kernel, N * J, table, ldt, J, sel, N, out);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// (rows, m + 1) gather table of a virtual [unpool | skip] operand: m chunks of the parent's row, then the row's own behind them
+__global__ __launch_bounds__(256) void vcat_table_kernel(const int32_t* __restrict__ parent, long rows, int m, long rows_hi,
+                                                          int32_t* __restrict__ out) {
+    const int J = m + 1;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < rows * J; e += (long)gridDim.x * 256) {
+        const long r = e / J;
+        const int j = (int)(e - r * J);
+        out[e] = j < m ? parent[r] * m + j : (int)(r + (long)m * rows_hi);
+    }
+}
+
+extern "C" int pm_voxel_vcat_table_i32(const int32_t* parent, long rows, int m, long rows_hi, int32_t* out, void* stream) {
+    PM_REQUIRE(parent && out && rows > 0 && m > 0 && rows_hi > 0 && rows + (long)m * rows_hi < (1L << 31));
+    VX_LAUNCH(vcat_table_kernel, rows * (m + 1), parent, rows, m, rows_hi, out);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// base[i] = counts[0] + ... + counts[i-1], total[0] = the sum (one work-group; n clouds)
+__global__ __launch_bounds__(1024) void exscan_kernel(const int32_t* __restrict__ counts, int n, int32_t* __restrict__ base,
+                                                       int32_t* __restrict__ total) {
+    __shared__ int sr[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int lo = 0; lo < n; lo += 1024) {
+        const int i = lo + threadIdx.x;
+        const int c = i < n ? counts[i] : 0;
+        sr[threadIdx.x] = c;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int a = threadIdx.x >= o ? sr[threadIdx.x - o] : 0;
+            __syncthreads();
+            sr[threadIdx.x] += a;
+            __syncthreads();
+        }
+        if (i < n) base[i] = carry + sr[threadIdx.x] - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sr[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry;
+}
+
+extern "C" int pm_exclusive_scan_i32(const int32_t* counts, int n, int32_t* base, int32_t* total, void* stream) {
+    PM_REQUIRE(counts && base && total && n > 0);
+    hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, pm_stream(stream), counts, n, base, total);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
 }

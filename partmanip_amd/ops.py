@@ -880,9 +880,9 @@ def voxel_down(coords_f, grid_f, Rf, B):
     counts = torch.empty(B, dtype=torch.int32, device=dev)
     check(lib.pm_voxel_down_count_i32(_ptr(coords_f), rows_f, B, Rc, _ptr(grid_c), _ptr(counts), _stream()),
           "pm_voxel_down_count_i32")
-    ends = torch.cumsum(counts, 0, dtype=torch.int32)                   # index bookkeeping (B integers)
-    base = (ends - counts).contiguous()
-    rows_c = int(ends[-1].item())
+    base = torch.empty(B + 1, dtype=torch.int32, device=dev)            # base[B] = the level's row count
+    check(lib.pm_exclusive_scan_i32(_ptr(counts), B, _ptr(base), base.data_ptr() + 4 * B, _stream()), "pm_exclusive_scan_i32")
+    rows_c = int(base[B].item())
     coords_c = torch.empty(rows_c, 4, dtype=torch.int32, device=dev)
     child = torch.empty(rows_c, 8, dtype=torch.int32, device=dev)
     parent = torch.empty(rows_f, dtype=torch.int32, device=dev)
@@ -949,16 +949,91 @@ def sparse_conv_bwd_weight(dy, src, idx, C, dw, db, zero, ws):
           "pm_sparse_conv_bwd_weight_f32")
 
 
-def rows_gather_bwd(dcols, tidx, C, dsrc, tslot=None, mode=0, reverse=False, self_col=-1, y_tanh=None, accumulate=False, rowmap=None):
-    """rowmap (int32, one entry per row the table can name): dcols holds a subset of those rows -- rowmap[row] = its row in dcols or -1."""
+def rows_gather_bwd(dcols, tidx, C, dsrc, tslot=None, mode=0, reverse=False, self_col=-1, y_tanh=None, accumulate=False, rowmap=None,
+                    skip=None):
+    """rowmap (int32, one entry per row the table can name): dcols holds a subset of those rows -- rowmap[row] = its row in dcols or -1.
+    skip = (values (N, C), skipmap (rows) int32): a sparse raw contribution added before the activation derivative (dsrc is overwritten)."""
     _req(dcols, tidx, dsrc, tslot, y_tanh, rowmap)
     rows = tidx.shape[0]
     J = tidx.shape[1] if tidx.dim() == 2 else 1
+    if skip is not None:
+        sv, sm = skip
+        _req(sv, sm)
+        if rowmap is not None or accumulate:
+            raise ValueError("rows_gather_bwd: skip= takes neither rowmap nor accumulate")
+        if sm.dtype != torch.int32 or sm.numel() < rows:
+            raise TypeError("rows_gather_bwd: skipmap must be int32 with one entry per row")
+        check(lib.pm_rows_gather_bwd_skip_f32(_ptr(dcols), _rows(dcols, "dcols"), _ptr(tidx), _ptr(tslot), int(mode), int(reverse),
+                                              int(self_col), rows, J, C, _ptr(y_tanh), _rows(y_tanh, "y") if y_tanh is not None else 0,
+                                              _ptr(dsrc), _rows(dsrc, "dsrc"), _ptr(sv), _rows(sv, "skip"), _ptr(sm), _stream()),
+              "pm_rows_gather_bwd_skip_f32")
+        return dsrc
     check(lib.pm_rows_gather_bwd_mapped_f32(_ptr(dcols), _rows(dcols, "dcols"), _ptr(tidx), _ptr(tslot), int(mode), int(reverse),
                                             int(self_col), rows, J, C, _ptr(y_tanh), _rows(y_tanh, "y") if y_tanh is not None else 0,
                                             int(accumulate), _ptr(dsrc), _rows(dsrc, "dsrc"), _ptr(rowmap), _stream()),
           "pm_rows_gather_bwd_mapped_f32")
     return dsrc
+
+
+def _i32c(t, name):
+    if t.dtype != torch.int32 or not t.is_contiguous():
+        raise TypeError(f"{name} must be a contiguous int32 tensor")
+
+
+def rows_uniq(src, S, pad_out, row_base=0, table=None, pad_in=-1):
+    """src (B, >= S) int32 ids per cloud -> (u, um, rank), each (B, S) int32: the cloud's distinct ids ascending (through `table` if
+    given; src == pad_in -> pad_out), padded with pad_out / -1, and every id's slot (pm_rows_uniq_i32; S <= 64)."""
+    _req(src, table)
+    if src.dtype != torch.int32 or src.stride(-1) != 1 or src.dim() != 2:
+        raise TypeError("rows_uniq: src must be a 2-D int32 tensor with unit inner stride")
+    if table is not None:
+        _i32c(table, "table")
+    B = src.shape[0]
+    u, um, rank = (torch.empty(B, S, dtype=torch.int32, device=src.device) for _ in range(3))
+    check(lib.pm_rows_uniq_i32(_ptr(src), src.stride(0), B, S, int(row_base), _ptr(table), int(pad_in), int(pad_out), _ptr(u), _ptr(um),
+                               _ptr(rank), _stream()), "pm_rows_uniq_i32")
+    return u, um, rank
+
+
+def child_sum(x, rank, out):
+    """out[b*S + j] = sum over i (ascending) with rank[b, i] == j of x[b*S + i]   (pm_child_sum_f32)."""
+    _req(x, rank, out)
+    _i32c(rank, "rank")
+    B, S = rank.shape
+    check(lib.pm_child_sum_f32(_ptr(x), _rows(x, "x"), _ptr(rank), B, S, x.shape[1], _ptr(out), _rows(out, "out"), _stream()),
+          "pm_child_sum_f32")
+    return out
+
+
+def rowmap_scatter(n, ids, pad):
+    """(n,) int32 map: -1 everywhere, map[ids[k]] = k for ids[k] != pad   (pm_rowmap_scatter_i32)."""
+    _req(ids)
+    _i32c(ids, "ids")
+    m = torch.empty(n, dtype=torch.int32, device=ids.device)
+    check(lib.pm_rowmap_scatter_i32(_ptr(m), n, _ptr(ids), ids.numel(), int(pad), _stream()), "pm_rowmap_scatter_i32")
+    return m
+
+
+def table_rows(table, sel):
+    """Rows sel (N,) of an int32 index table (rows, J) (unit inner stride; -1 in sel -> a row of -1)   (pm_table_rows_i32)."""
+    _req(table, sel)
+    _i32c(sel, "sel")
+    if table.dtype != torch.int32 or table.stride(1) != 1:
+        raise TypeError("table_rows: table must be int32 with unit inner stride")
+    out = torch.empty(sel.numel(), table.shape[1], dtype=torch.int32, device=table.device)
+    check(lib.pm_table_rows_i32(_ptr(table), table.stride(0), table.shape[1], _ptr(sel), sel.numel(), _ptr(out), _stream()),
+          "pm_table_rows_i32")
+    return out
+
+
+def voxel_vcat_table(parent, m, rows_hi):
+    """(rows, m + 1) int32 gather table of a virtual [unpool | skip] operand   (pm_voxel_vcat_table_i32)."""
+    _req(parent)
+    _i32c(parent, "parent")
+    rows = parent.numel()
+    out = torch.empty(rows, m + 1, dtype=torch.int32, device=parent.device)
+    check(lib.pm_voxel_vcat_table_i32(_ptr(parent), rows, int(m), int(rows_hi), _ptr(out), _stream()), "pm_voxel_vcat_table_i32")
+    return out
 
 
 # ----------------------------------------------------------------------------- depth -> cloud

@@ -69,6 +69,16 @@ def test_forward_and_parameter_gradients_match_the_restatement(proprio, dups, NE
         assert err < 2e-4, (name, err)
     # inference forward = training forward
     assert torch.equal(ac.actor(xd), out.detach())
+    # a duplicate-coordinate row computes its canonical twin's E0 row bit for bit and has the higher row index: the max-pool never
+    # picks it (which is why the compact decoder backward may sum children through `parent` where the dense one uses `child`)
+    sv = ac.actor._saved
+    win = sv["arg"].long() + (torch.arange(B, device=DEV) * P).view(B, 1)
+    assert bool((sv["g"]["l1"]["parent_canon"].view(-1)[win.view(-1)] >= 0).all()), "a duplicate row won the max-pool"
+    if dups:
+        dup_rows = (sv["g"]["l1"]["parent_canon"].view(-1) < 0).nonzero().view(-1)
+        assert dup_rows.numel() > 0
+        twin = sv["g"]["nbr0"][dup_rows, 13].long()
+        assert bool((twin < dup_rows).all()) and torch.equal(sv["E0"][dup_rows], sv["E0"][twin])
 
 
 def test_dagger_update_with_sparse_unet_student_matches_the_restatement(tmp_path, monkeypatch):
