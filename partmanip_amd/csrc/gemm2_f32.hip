@@ -418,9 +418,15 @@ __device__ __forceinline__ void g2_dma_tile_gather(const Gemm2Prob& g, const flo
             const int k = piece * (256 / T) + lane / (T / 4), c = lane % (T / 4);
             q = qn = min(r0 + c * 4, nrows - 4);
             rr = k0 + k;
-            const float* src = gi[j] >= 0 ? P + (long)gi[j] * ld + (q % g.gC) : g.gzero + (q % g.gC);
+            // rows behind the reduction's end read zeros -- decided HERE, from the row number, not by skipping the index load:
+            // a conditional load is compiled as a branch around it, and a wave whose pieces all lie behind the end then has
+            // FEWER VMEM operations in flight than the counted `s_waitcnt vmcnt(IPT + NGI)` of the ring assumes -- the wait
+            // let the last DMAs of the tile before pass unfinished, and the multiplying waves read a stale buffer (round 4's
+            // "down1 weight gradient once 5.5e-5 off": profiles/round5_sparse_unet_race.md).  Every issue() now performs
+            // exactly IPT + NGI operations, whatever the tile.
+            const float* src = (gi[j] >= 0 && rr < g.K) ? P + (long)gi[j] * ld + (q % g.gC) : g.gzero + (q % g.gC);
             __builtin_amdgcn_global_load_lds(src, (g2_lds_ptr)(S + piece * 256), 16, 0, 0);
-            gi[j] = k0n + k < g.K ? g.gidx[(long)(k0n + k) * g.gJ + qn / g.gC] : -1;     // rows behind the reduction's end: zeros
+            gi[j] = g.gidx[(long)min(k0n + k, g.K - 1) * g.gJ + qn / g.gC];
         } else {                                                           // A of a forward: rows = output rows
             const int row = piece * 8 + (lane >> 3), c = lane & 7;
             rr = min(r0 + row, nrows - 1);
@@ -439,7 +445,7 @@ __device__ __forceinline__ void g2_gather_first(const Gemm2Prob& g, int r0, int 
         const int piece = j * 4 + wave;
         if (KM) {
             const int k = piece * (256 / T) + lane / (T / 4), c = lane % (T / 4);
-            gi[j] = k0 + k < g.K ? g.gidx[(long)(k0 + k) * g.gJ + min(r0 + c * 4, nrows - 4) / g.gC] : -1;
+            gi[j] = g.gidx[(long)min(k0 + k, g.K - 1) * g.gJ + min(r0 + c * 4, nrows - 4) / g.gC];      // (unconditional: see g2_dma_tile_gather)
         } else {
             const int row = piece * 8 + (lane >> 3), c = lane & 7;
             gi[j] = g.gidx[(long)min(r0 + row, nrows - 1) * g.gJ + g2_tap(g, k0 + ((c ^ ((row >> 1) & 7)) << 2))];

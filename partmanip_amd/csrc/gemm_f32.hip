@@ -151,22 +151,34 @@ extern "C" size_t pm_linear_bwd_weight_workspace_bytes(int M, int N, int K) {
     return s > 1 ? (size_t)s * ((size_t)N * K + N) * sizeof(float) : 16;     // dW slabs + db slabs
 }
 
-// dW = sum_z slab_z (fixed order); the trailing N "elements" reduce the bias-gradient slabs.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int S, long slab,
-                                                           float* __restrict__ dW, long lddw, int N, int K,
-                                                           const float* __restrict__ bslabs, float* __restrict__ db) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+// dW = sum_z slab_z; the trailing N "elements" reduce the bias-gradient slabs.  A work-group owns 64 consecutive elements; its
+// SR_G waves take the slabs z = w, w + SR_G, ... (chains of S / SR_G loads instead of S: 256 slabs of a 128 x 128 gradient took
+// 75 us on 64 single-chain work-groups -- 3.6 % of a PointNet++ step), the partial sums are added in wave order through LDS:
+// a fixed order, whatever the launch.
+#define SR_G 8
+__global__ __launch_bounds__(64 * SR_G) void slab_reduce_kernel(const float* __restrict__ slabs, int S, long slab,
+                                                                float* __restrict__ dW, long lddw, int N, int K,
+                                                                const float* __restrict__ bslabs, float* __restrict__ db) {
+    __shared__ float part[SR_G][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + lane;
     const long nk = (long)N * K;
+    float s = 0.f;
     if (e < nk) {
-        float s = 0.f;
 #pragma unroll 4
-        for (int z = 0; z < S; ++z) s += slabs[z * slab + e];
-        dW[(e / K) * lddw + (e % K)] = s;
+        for (int z = w; z < S; z += SR_G) s += slabs[z * slab + e];
     } else if (db && e < nk + N) {
         const int n = (int)(e - nk);
-        float s = 0.f;
-        for (int z = 0; z < S; ++z) s += bslabs[(long)z * N + n];
-        db[n] = s;
+        for (int z = w; z < S; z += SR_G) s += bslabs[(long)z * N + n];
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0) {
+        float t = part[0][lane];
+#pragma unroll
+        for (int q = 1; q < SR_G; ++q) t += part[q][lane];
+        if (e < nk) dW[(e / K) * lddw + (e % K)] = t;
+        else if (db && e < nk + N) db[e - nk] = t;
     }
 }
 
@@ -201,7 +213,7 @@ extern "C" int pm_linear_bwd_weight_f32(const float* dY, long lddy, const float*
     }
     if (S > 1) {
         const long ne = (long)N * K + (db ? N : 0);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, pm_stream(stream),
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(64 * SR_G), 0, pm_stream(stream),
                            (const float*)workspace, S, (long)N * K, dW, lddw, N, K, (const float*)bslabs, db);
     }
     PM_CHECK_LAUNCH();
@@ -492,7 +504,7 @@ extern "C" int pm_sparse_conv_bwd_weight_f32(const float* dY, long lddy, const f
     if (rc != PM_OK) return rc;
     if (S > 1) {
         const long ne = (long)N * K + (db ? N : 0);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, pm_stream(stream),
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(64 * SR_G), 0, pm_stream(stream),
                            (const float*)workspace, S, (long)N * K, dW, lddw, N, K, (const float*)bslabs, db);
         PM_CHECK_LAUNCH();
     }

@@ -135,21 +135,31 @@ __device__ __forceinline__ void sa_layer1(const SaArgs& a, int tid, const float*
     const float w0 = a.W1[c * a.ldw1], w1 = a.W1[c * a.ldw1 + 1], w2 = a.W1[c * a.ldw1 + 2], bb = a.b1[c];
     if (a.Y) {
         static_assert(RPT % 2 == 0, "layer 1 pairs rows for the packed tanh");
-#pragma unroll 4
-        for (int p = p0; p < p0 + RPT; p += 2) {
-            float z[2];
+        // The Y rows of a tile are a gather (one 4*C1-byte row per source point, wherever it lies): ALL of a batch's loads are
+        // issued before the first is used -- with the loads inside the row loop (four in flight per thread) this phase was a chain
+        // of HBM / L2 round trips: 0.28 ms of the 1.67 ms SA2 backward (profiles/round4_f_sa_packed_phase_ablation.txt).
+        constexpr int CH = RPT < 16 ? RPT : 16;
+        static_assert(RPT % CH == 0 && CH % 2 == 0, "layer-1 load batches");
+#pragma unroll 1
+        for (int p = p0; p < p0 + RPT; p += CH) {
+            float y[CH];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float y = a.Y[(long)Src[p + j] * C1 + c];
-                const float4 x = *(const float4*)(Xz + (p + j) * 4);
-                float s = fmaf(w0, x.x, bb);
-                s = fmaf(w1, x.y, s);
-                s = fmaf(w2, x.z, s);
-                z[j] = s + y;
+            for (int j = 0; j < CH; ++j) y[j] = a.Y[(long)Src[p + j] * C1 + c];
+#pragma unroll
+            for (int j = 0; j < CH; j += 2) {
+                float z[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float4 x = *(const float4*)(Xz + (p + j + i) * 4);
+                    float s = fmaf(w0, x.x, bb);
+                    s = fmaf(w1, x.y, s);
+                    s = fmaf(w2, x.z, s);
+                    z[i] = s + y[j + i];
+                }
+                const f32x2 t = pm_tanh2(z[0], z[1]);
+                H1[(p + j) * LD1 + c] = t.x;
+                H1[(p + j + 1) * LD1 + c] = t.y;
             }
-            const f32x2 t = pm_tanh2(z[0], z[1]);
-            H1[p * LD1 + c] = t.x;
-            H1[(p + 1) * LD1 + c] = t.y;
         }
     } else {
 #pragma unroll 4
@@ -607,18 +617,30 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_kernel(SaArgs a) {
     }
 }
 
+// (a work-group owns 64 outputs; its 8 waves take the partial sums w, w + 8, ... and add up in wave order through LDS: with one
+// thread per output walking all <= 1024 partials the SA1 reduction took 220 us on 50 work-groups -- 2 % of a PointNet++ step)
+#define SA_RED_G 8
 template <int C1, int C2, int C3>
-__global__ __launch_bounds__(256) void sa_bwd_reduce_kernel(const float* __restrict__ parts, int nparts,
-                                                             float* __restrict__ dW1, long lddw1,
-                                                             float* __restrict__ db1, float* __restrict__ dW2,
-                                                             float* __restrict__ db2, float* __restrict__ dW3,
-                                                             float* __restrict__ db3) {
+__global__ __launch_bounds__(64 * SA_RED_G) void sa_bwd_reduce_kernel(const float* __restrict__ parts, int nparts,
+                                                                      float* __restrict__ dW1, long lddw1,
+                                                                      float* __restrict__ db1, float* __restrict__ dW2,
+                                                                      float* __restrict__ db2, float* __restrict__ dW3,
+                                                                      float* __restrict__ db3) {
     using P = SaPart<C1, C2, C3>;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P::N) return;
+    __shared__ float red[SA_RED_G][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     float s = 0.f;
-#pragma unroll 8
-    for (int w = 0; w < nparts; ++w) s += parts[(size_t)w * P::N + i];
+    if (i < P::N) {
+#pragma unroll 4
+        for (int w = wv; w < nparts; w += SA_RED_G) s += parts[(size_t)w * P::N + i];
+    }
+    red[wv][lane] = s;
+    __syncthreads();
+    if (wv != 0 || i >= P::N) return;
+    s = red[0][lane];
+#pragma unroll
+    for (int q = 1; q < SA_RED_G; ++q) s += red[q][lane];
     if (i < P::O_DB2) dW2[i] = s;
     else if (i < P::O_DW3) db2[i - P::O_DB2] = s;
     else if (i < P::O_DB3) dW3[i - P::O_DW3] = s;
@@ -663,7 +685,7 @@ extern "C" int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32
         hipLaunchKernelGGL((sa_bwd_kernel<C1_, C2_, C3_, TM_, NW_, WPE_>), dim3((unsigned)grid), dim3((NW_) * 64), \
                            0, pm_stream(stream), a);                                                               \
         constexpr int n = SaPart<C1_, C2_, C3_>::N;                                                                \
-        hipLaunchKernelGGL((sa_bwd_reduce_kernel<C1_, C2_, C3_>), dim3((n + 255) / 256), dim3(256), 0,             \
+        hipLaunchKernelGGL((sa_bwd_reduce_kernel<C1_, C2_, C3_>), dim3((n + 63) / 64), dim3(64 * SA_RED_G), 0,             \
                            pm_stream(stream), a.parts, (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3);            \
     }
     if (SA_CFG_A(C1, C2, C3)) SA_BWD_LAUNCH(64, 64, 128, 64, 4, SA_A_BWD_WPE, SA_A_BWD_WPE)
@@ -698,6 +720,12 @@ extern "C" int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32
 // The kernels read the tile count from device memory (persistent work-groups): no host synchronisation anywhere.
 #ifndef SA_PK_ABLATE
 #define SA_PK_ABLATE 0   // timing probes (wrong results): bwd 1 = no dW3, 2 = no dH2 MFMA, 4 = no layer-1 recompute, 8 = no P7, 16 = no dW2 / dH1 MFMA; fwd 32 = no pooling pass, 64 = no layer 2 / 3 MFMA
+#endif
+#ifndef SA_PK_DZ3_LDS
+#define SA_PK_DZ3_LDS 1   // 1: the layer-3 gradient rows of a channel window are BUILT ONCE PER TILE in LDS (zero-fill + one store per
+                          // (group, channel)) and the dH2 product streams its A operand from there; 0: every lane builds its operand
+                          // in registers from (val, arg) per k-group (round 4: ~14 VALU per 4 MFMAs, 0.53 ms of the 1.67 ms SA2 backward
+                          // against an MFMA floor of 0.30)
 #endif
 struct SaPk {
     const int32_t* grow;     // (G + 1)   first packed row of each group
@@ -1106,7 +1134,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         // ---- P1/P2: H1 recomputed, H2 stored (or recomputed) -----------------------------------------
-        if (!(SA_PK_ABLATE & 4)) sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
+        // (SA_PK_DZ3_LDS: H1's buffer holds the layer-3 gradient rows during P3; H1 itself is recomputed behind P4 -- with the
+        // saved layer 2 nothing needs it before the dW2 product.  Without the saved layer 2 it is computed here too, for layer 2.)
+        if (!(SA_PK_ABLATE & 4) && (!SA_PK_DZ3_LDS || !a.h2)) sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
         __builtin_amdgcn_sched_barrier(0);
         if (a.h2) {
 #pragma unroll
@@ -1131,16 +1161,25 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
         const int wn2 = wave % M2::NBW, wm2 = wave / M2::NBW;
         f32x16 acc[M2::MB][M2::NB];
         zero_acc<M2::MB, M2::NB>(acc);
+#if SA_PK_DZ3_LDS
+        // Z = the tile's dZ3 rows for a window of ZW channels (ZW / 2 from each k half), in H1's buffer (same row stride)
+        constexpr int ZW = C1, LDZ = LD1, NSUB = 128 / ZW, NGW = ZW / 8;
+        static_assert(NSUB * ZW == 128 && NGW % 2 == 0, "layer-3 gradient window");
+        float* Z = H1;
+#else
         int lgv[M2::MB], lrv[M2::MB];
+#endif
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             if (q == 0) {
+#if !SA_PK_DZ3_LDS
 #pragma unroll
                 for (int mb = 0; mb < M2::MB; ++mb) {
                     const int lgr = Lgr[(wm2 * M2::MB + mb) * 32 + li];
                     lgv[mb] = lgr >> 8;
                     lrv[mb] = lgr & 255;
                 }
+#endif
             } else {
                 __syncthreads();             // the previous chunk's Val, Arg are no longer read
                 for (int i = tid; i < td.z * 128; i += NT) {
@@ -1152,7 +1191,21 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                     ((uint8_t*)ArgW)[j * (LDA * 4) + s] = (uint8_t)a.arg[g * C3 + c];
                 }
             }
-            __syncthreads();                 // H1, H2 and this chunk's Val, Arg complete
+            __syncthreads();                 // H1, H2 and this chunk's Val, Arg complete (and nobody reads Z any more)
+#if SA_PK_DZ3_LDS
+            auto z_build = [&](int h) {      // window h of this chunk: zero, then ONE store per (group, channel)
+                for (int q4 = tid; q4 < TM * ZW / 4; q4 += NT)
+                    *(float4*)(Z + (q4 / (ZW / 4)) * LDZ + 4 * (q4 % (ZW / 4))) = make_float4(0.f, 0.f, 0.f, 0.f);
+                __syncthreads();
+                for (int i = tid; i < td.z * ZW; i += NT) {
+                    const int j = i / ZW, sl = i % ZW;
+                    const int s128 = sl < ZW / 2 ? (ZW / 2) * h + sl : 64 + (ZW / 2) * h + (sl - ZW / 2);
+                    const int row = Ls[j] + ((const uint8_t*)ArgW)[j * (LDA * 4) + s128];
+                    Z[row * LDZ + sl] = Val[j * LDV + s128];
+                }
+            };
+            if (!(SA_PK_ABLATE & 2)) z_build(0);
+#endif
             {   // dW3[c, :] += val * H2[row of the arg-max, :]   (VALU; the slice stays in registers for the whole kernel)
                 const int s = tid & 127, ks = tid >> 7;
                 for (int j = 0; j < ((SA_PK_ABLATE & 1) ? 0 : td.z); ++j) {
@@ -1174,7 +1227,24 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                     if (ks == 0) accb3[q] += v;
                 }
             }
-            __syncthreads();                 // a real barrier (register live ranges, see sa_bwd_kernel)
+            __syncthreads();                 // a real barrier (register live ranges, see sa_bwd_kernel); Z complete
+#if SA_PK_DZ3_LDS
+            // dH2 += dZ3[:, window] * W3[window, :]: the A operand streams from Z like any LDS tile
+#pragma unroll
+            for (int h = 0; h < NSUB; ++h) {
+                if (h > 0) {
+                    __syncthreads();         // the previous window's operand reads are done
+                    if (!(SA_PK_ABLATE & 2)) z_build(h);
+                    __syncthreads();
+                }
+                auto zload = [&](int mb, int g) -> float4 {
+                    return *(const float4*)(Z + ((wm2 * M2::MB + mb) * 32 + li) * LDZ + lh * (ZW / 2) + g * 4);
+                };
+                if (!(SA_PK_ABLATE & 2))
+                    mfma_stream_fn_win<M2::MB, M2::NB, C3 / 8, NGW>(
+                        zload, P3Tv + ((size_t)(wn2 * M2::NB) * (C3 / 8) + 16 * q + NGW * h) * 64 + lane, acc);
+            }
+#else
             // dH2 += dZ3[:, chunk] * W3[chunk, :]: A built per ROW from its own group's entries
             auto asel = [&](int mb, int g) -> float4 {
                 const int slot = lh * 64 + g * 4;
@@ -1190,8 +1260,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
             };
             if (!(SA_PK_ABLATE & 2))
                 mfma_stream_fn_win<M2::MB, M2::NB, C3 / 8, 16>(asel, P3Tv + ((size_t)(wn2 * M2::NB) * (C3 / 8) + 16 * q) * 64 + lane, acc);
+#endif
         }
-        __syncthreads();                     // every wave is done with its dW3 reads of H2 rows
+        __syncthreads();                     // every wave is done with its dW3 reads of H2 rows (and with Z)
         // ---- P4: dZ2 = dH2 .* (1 - H2^2) -> D, db2 ---------------------------------------------------
 #pragma unroll
         for (int nb = 0; nb < M2::NB; ++nb) {
@@ -1207,6 +1278,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                     accb2[nb] += z;
                 }
         }
+#if SA_PK_DZ3_LDS
+        if (!(SA_PK_ABLATE & 4)) sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);     // Z is dead: H1 for the dW2 / dH1 phases
+#endif
         __syncthreads();
         // ---- P5: dW2 += dZ2^T * H1 ------------------------------------------------------------------
         {
@@ -1346,13 +1420,13 @@ extern "C" int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const i
         const long grid = sa_pk_grid(a.G, ncu, 3, SA_BWD_MAXGRID);
         hipLaunchKernelGGL((sa_bwd_pk_kernel<64, 64, 128, 64, 4, 3, 20>), dim3((unsigned)grid), dim3(256), 0, pm_stream(stream), a, k);
         constexpr int n = SaPart<64, 64, 128>::N;
-        hipLaunchKernelGGL((sa_bwd_reduce_kernel<64, 64, 128>), dim3((n + 255) / 256), dim3(256), 0, pm_stream(stream), a.parts,
+        hipLaunchKernelGGL((sa_bwd_reduce_kernel<64, 64, 128>), dim3((n + 63) / 64), dim3(64 * SA_RED_G), 0, pm_stream(stream), a.parts,
                            (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3);
     } else {
         const long grid = sa_pk_grid(a.G, ncu, 1, SA_BWD_MAXGRID);
         hipLaunchKernelGGL((sa_bwd_pk_kernel<128, 128, 256, 128, 16, 4, 28>), dim3((unsigned)grid), dim3(1024), 0, pm_stream(stream), a, k);
         constexpr int n = SaPart<128, 128, 256>::N;
-        hipLaunchKernelGGL((sa_bwd_reduce_kernel<128, 128, 256>), dim3((n + 255) / 256), dim3(256), 0, pm_stream(stream), a.parts,
+        hipLaunchKernelGGL((sa_bwd_reduce_kernel<128, 128, 256>), dim3((n + 63) / 64), dim3(64 * SA_RED_G), 0, pm_stream(stream), a.parts,
                            (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3);
     }
     PM_CHECK_LAUNCH();
