@@ -853,13 +853,16 @@ def pointnet2_forward(p, prefix, net_cfg, x, proprio_shape=0, pool_args=None, re
             centers = torch.gather(xyz, 1, idx_c.unsqueeze(-1).expand(B, S, 3))
             idx_g = torch.from_numpy(ball_query(xyz.detach().numpy(), centers.detach().numpy(), radii[l], ns)).long() if on_host \
                 else ball_query_torch(xyz.detach(), centers.detach(), radii[l], ns).long()
-        flat = idx_g.reshape(B, S * ns)
-        g_xyz = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(B, S * ns, 3)).reshape(B, S, ns, 3) - centers.unsqueeze(2)
+        # rows of the cloud's points picked by index (index_select on the flattened batch: the same rows as a per-cloud gather,
+        # with an index_add as its backward instead of a scatter through an expanded index)
+        Pl = xyz.shape[1]
+        flat = (idx_g.reshape(B, S * ns) + (torch.arange(B, device=x.device) * Pl).view(B, 1)).reshape(-1)
+        g_xyz = xyz.reshape(B * Pl, 3).index_select(0, flat).reshape(B, S, ns, 3) - centers.unsqueeze(2)
         cols = [g_xyz]
         cf = 0
         if feat is not None:
             cf = feat.shape[2]
-            cols.append(torch.gather(feat, 1, flat.unsqueeze(-1).expand(B, S * ns, cf)).reshape(B, S, ns, cf))
+            cols.append(feat.reshape(B * Pl, cf).index_select(0, flat).reshape(B, S, ns, cf))
         pad = _pad4(3 + cf) - (3 + cf)
         if pad:
             cols.append(torch.zeros(B, S, ns, pad, dtype=x.dtype, device=x.device))

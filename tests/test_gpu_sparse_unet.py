@@ -317,8 +317,10 @@ def test_full_size_forward_and_gradients_fused_vs_materialised_and_vs_restatemen
         a, b = res[True][1][n], res[False][1][n]
         e = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
         worst = max(worst, e)
-        assert e <= 1e-6, (n, e)
-    record_margin("full size: fused vs materialised parameter gradients (max abs / max(1, max|ref|))", worst, 1e-6)
+        assert e <= 2e-6, (n, e)
+    # two summation orders of the same sums; observed 1.7e-7 (256 clouds) / 6.9e-7 (2048), bit-reproducible run to run since the
+    # gathered weight gradient's loader race is fixed (profiles/round5_sparse_unet_race.md: it used to show up here as a rare 5.5e-5)
+    record_margin("full size: fused vs materialised parameter gradients (max abs / max(1, max|ref|))", worst, 2e-6)
     # ---- the four picked clouds on the restatement (fp64)
     xs = x[pick].cpu()
     p = {k: torch.from_numpy(v.copy()).double().requires_grad_(True) for k, v in sd.items()}
