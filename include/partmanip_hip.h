@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 147 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 148 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -369,6 +369,12 @@ int pm_group_points_bwd_f32(const float* dout, const int32_t* idx, int B, int P,
  * (G, nsample, C) with the lowest arg-max index; its backward writes every element of dx. */
 int pm_group_concat_f32(const float* xyz, const float* feat, const float* centers, const int32_t* idx, int B, int P,
                         int Cf, int S, int nsample, int ldo, float* out, void* stream);
+/* Column-block copy: dst[r][d_b .. d_b + e_b - s_b) = src[r][s_b .. e_b) for two blocks b (an empty block: s == e); the other
+ * columns of dst in [col0, dst_cols) are zeroed when zero_other != 0; columns below col0 are left alone.  The PointNet++ plug-in's
+ * glue around its GEMMs in one launch each (weights in operand column order padded to the K-step, gradients back, [xyz | 0] behind the
+ * group-all rows' features). */
+int pm_col_blocks_f32(float* dst, long ldd, const float* src, long lds, long rows, int dst_cols, int col0, int s0, int e0, int d0,
+                      int s1, int e1, int d1, int zero_other, void* stream);
 int pm_group_concat_bwd_f32(const float* dout, const int32_t* idx, int B, int P, int Cf, int S, int nsample, int ldo,
                             float* dfeat, void* stream);
 int pm_maxpool_rows_f32(const float* x, long G, int nsample, int C, float* out, long ldo, int32_t* arg, void* stream);

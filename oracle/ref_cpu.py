@@ -112,8 +112,35 @@ def _act(name, x):
     raise ValueError(name)
 
 
+class _LinearSlabs(torch.autograd.Function):
+    """`F.linear` whose WEIGHT GRADIENT is evaluated in slabs of the row reduction -- dW = sum_s dY_s^T X_s as one batched product
+    -- the same sums in another association.  Used only for >= 2^16 rows on a device (`_lin`): the vendor library runs the
+    (64 x 2 M) x (2 M x 64) fp64 product of a PointNet++ level's weight gradient on ONE work-group (105 ms per call, 98 % of the
+    restatement's time on the MI355X: tests/test_gpu_wholeupdate.py).  tests/test_oracle_golden.py pins it to autograd's F.linear."""
+    SLABS = 256
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        R, S = x2.shape[0], _LinearSlabs.SLABS
+        n = R // S * S
+        dw = torch.bmm(dy2[:n].reshape(S, n // S, -1).transpose(1, 2), x2[:n].reshape(S, n // S, -1)).sum(0)
+        if n < R:
+            dw = dw + dy2[n:].t() @ x2[n:]
+        return (dy2 @ w).reshape(x.shape), dw, dy2.sum(0)
+
+
 def _lin(p, prefix, x):
-    return torch.nn.functional.linear(x, p[prefix + ".weight"], p[prefix + ".bias"])
+    w, b = p[prefix + ".weight"], p[prefix + ".bias"]
+    if x.device.type != "cpu" and x.numel() // x.shape[-1] >= 65536:
+        return _LinearSlabs.apply(x, w, b)
+    return torch.nn.functional.linear(x, w, b)
 
 
 def mlp_forward(p, prefix, net_cfg, x):

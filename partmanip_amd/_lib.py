@@ -111,6 +111,7 @@ SIGNATURES = {
     "pm_rows_gather_bwd_f32": (I, [P, L, P, P, I, I, I, L, I, I, P, L, I, P, L, P]),
     "pm_rows_gather_bwd_mapped_f32": (I, [P, L, P, P, I, I, I, L, I, I, P, L, I, P, L, P, P]),
     "pm_rows_gather_bwd_skip_f32": (I, [P, L, P, P, I, I, I, L, I, I, P, L, P, L, P, L, P, P]),
+    "pm_col_blocks_f32": (I, [P, L, P, L, L, I, I, I, I, I, I, I, I, I, P]),
     "pm_rows_uniq_i32": (I, [P, L, I, I, L, P, I, I, P, P, P, P]),
     "pm_child_sum_f32": (I, [P, L, P, I, I, I, P, L, P]),
     "pm_rowmap_scatter_i32": (I, [P, L, P, L, I, P]),
@@ -180,7 +181,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 147                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 148                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

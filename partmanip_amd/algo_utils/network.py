@@ -82,9 +82,8 @@ class _LinearChain:
         self.w0p = None
         if x.shape[1] != self.linears[0].in_features or self.col_blocks is not None:
             w0 = self.linears[0].weight.data
-            self.w0p = torch.zeros(w0.shape[0], x.shape[1], device=x.device)
-            for s_, e_, d_ in (self.col_blocks or [(0, w0.shape[1], 0)]):
-                self.w0p[:, d_:d_ + e_ - s_].copy_(w0[:, s_:e_])
+            self.w0p = torch.empty(w0.shape[0], x.shape[1], device=x.device)
+            ops.col_blocks(self.w0p, w0, self.col_blocks or [(0, w0.shape[1], 0)])        # one launch: permuted blocks + zero padding
         for i, lin in enumerate(self.linears):
             last = i == n - 1
             y = out if (last and out is not None) else torch.empty(cur.shape[0], lin.out_features, device=cur.device)
@@ -131,12 +130,8 @@ class _LinearChain:
             if w0p is not None:                            # zero-padded K: the gradient of the real columns is the leading block
                 dWp = torch.empty_like(w0p)
                 ops.linear_bwd_weight(dy, inp, dWp, db, ws)
-                if self.col_blocks is None:
-                    dW.copy_(dWp[:, :dW.shape[1]])
-                else:
-                    dW.zero_()                             # (columns outside the blocks are padding: they never receive data)
-                    for s_, e_, d_ in self.col_blocks:
-                        dW[:, s_:e_].copy_(dWp[:, d_:d_ + e_ - s_])
+                # back in the parameter's column order, one launch (columns outside the blocks are padding: zero gradient)
+                ops.col_blocks(dW, dWp, [(d_, d_ + e_ - s_, s_) for s_, e_, d_ in (self.col_blocks or [(0, dW.shape[1], 0)])])
             else:
                 ops.linear_bwd_weight(dy, inp, dW, db, ws)
             if i > 0:
@@ -533,7 +528,7 @@ class PointNet2(_HipNet):
         Y, w1f = None, None
         if cf > 0:
             # the feature columns of W1 start 12 bytes into a row: an aligned copy (64 KB) takes the 16-byte LDS-DMA loaders
-            w1f = lin1.weight.data[:, 3:3 + cf].contiguous()
+            w1f = ops.col_blocks(torch.empty(dims[0], cf, device=xyz.device), lin1.weight.data, [(3, 3 + cf, 0)], zero_other=False)
             Y = torch.empty(B * Pl, dims[0], device=xyz.device)
             ops.linear_fwd(feat.reshape(B * Pl, cf), w1f, None, Y, ops.ACT_NONE)
         packed = self._sa_packed[l]
@@ -582,14 +577,14 @@ class PointNet2(_HipNet):
         else:
             ops.sa_bwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data, packed,
                        dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws, h2)
-        if dW1.shape[1] > 3 + cf:
-            dW1[:, 3 + cf:].zero_()                        # pad columns never receive data
         if cf == 0:
+            if dW1.shape[1] > 3:
+                ops.col_blocks(dW1, dW1, [], col0=3)       # pad columns never receive data
             return None
         feat2 = feat.reshape(B * Pl, cf)
         dW1f = torch.empty_like(w1f)
         ops.linear_bwd_weight(dY, feat2, dW1f, None, ws)
-        dW1[:, 3:3 + cf].copy_(dW1f)
+        ops.col_blocks(dW1, dW1f, [(0, cf, 3)], col0=3)    # the feature columns' gradient in place, zeros in the pad columns
         if not need_dfeat:
             return None
         dfeat = torch.empty(B * Pl, cf, device=xyz.device)
@@ -706,8 +701,7 @@ class PointNet2(_HipNet):
         ldo = (self.sa[-1][0].in_features + 31) // 32 * 32     # zero columns up to the GEMM's K-step (the chain pads its weights alike)
         if ga_rows is not None:                            # the features are already in place: [features | xyz | 0]
             idx_all, rows, cf_ = None, ga_rows, feat.shape[2]
-            rows[:, cf_:cf_ + 3].copy_(xyz.reshape(B * S, 3))
-            rows[:, cf_ + 3:].zero_()
+            ops.col_blocks(rows, xyz.reshape(B * S, 3), [(0, 3, cf_)], col0=cf_)          # [features | xyz | 0]: the tail in one launch
         else:
             idx_all = torch.arange(S, dtype=torch.int32, device=x.device).repeat(B, 1).view(B, 1, S)
             zeros = torch.zeros(B, 1, 3, device=x.device)

@@ -513,6 +513,39 @@ extern "C" int pm_maxpool_rows_bwd_f32(const float* dout, long lddo, const int32
     return PM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- column-block copies
+// dst[r][d_b .. d_b + (e_b - s_b)) = src[r][s_b .. e_b) for up to two blocks b; every other column of dst below `dst_cols` is
+// written as zero when zero_other is set.  ONE launch for the glue the PointNet++ plug-in needs around the GEMMs -- a layer's
+// weight with its columns in the operand's order and padded to the K-step, its gradient back in the parameter's order, the
+// aligned copy of W1's feature columns, [xyz | 0] behind the pooled features of the group-all rows -- each of which was two to
+// four strided copy_ / zero_ launches of the tensor library (round 4: 6 % of the PointNet++ step's kernel time).
+__global__ __launch_bounds__(256) void col_blocks_kernel(float* __restrict__ dst, long ldd, const float* __restrict__ src, long lds,
+                                                          long rows, int dst_cols, int col0, int s0, int e0, int d0, int s1, int e1,
+                                                          int d1, int zero_other) {
+    const int w = dst_cols - col0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < rows * w; e += (long)gridDim.x * 256) {
+        const long r = e / w;
+        const int c = col0 + (int)(e - r * w);
+        if (c >= d0 && c < d0 + (e0 - s0)) dst[r * ldd + c] = src[r * lds + s0 + (c - d0)];
+        else if (c >= d1 && c < d1 + (e1 - s1)) dst[r * ldd + c] = src[r * lds + s1 + (c - d1)];
+        else if (zero_other) dst[r * ldd + c] = 0.f;
+    }
+}
+
+extern "C" int pm_col_blocks_f32(float* dst, long ldd, const float* src, long lds, long rows, int dst_cols, int col0, int s0, int e0,
+                                 int d0, int s1, int e1, int d1, int zero_other, void* stream) {
+    PM_REQUIRE(dst && src && rows > 0 && dst_cols > 0 && col0 >= 0 && col0 < dst_cols && ldd >= dst_cols);
+    PM_REQUIRE(s0 >= 0 && e0 >= s0 && d0 >= 0 && d0 + (e0 - s0) <= dst_cols && e0 <= lds);
+    PM_REQUIRE(s1 >= 0 && e1 >= s1 && d1 >= 0 && d1 + (e1 - s1) <= dst_cols && e1 <= lds);
+    const long n = rows * (dst_cols - col0);
+    long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(col_blocks_kernel, dim3((unsigned)blocks), dim3(256), 0, pm_stream(stream), dst, ldd, src, lds, rows, dst_cols, col0,
+                       s0, e0, d0, s1, e1, d1, zero_other);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
 extern "C" int pm_version(void) { return PM_ABI_VERSION; }
 
 // ---- camera-sized clouds on SEVERAL work-groups per cloud ----------------------------------------------------------------

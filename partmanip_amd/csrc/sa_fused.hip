@@ -1050,6 +1050,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
     // channels are staged 128 at a time (slots 0-63: channels [64q, 64q+64), slots 64-127: C3/2 + the same -- the two
     // k halves the MFMA lanes own); Val rows padded to 132 floats, Arg rows to 132 bytes (bank spread across groups)
     constexpr int NCH = C3 / 128, LDV = 132, LDA = 33;
+    // the LDS-built layer-3 gradient operand needs a 128-channel window to fit H1's buffer in ONE piece (C1 = 128: the SA2 shape);
+    // at C1 = 64 it takes two windows with their own zero / scatter / barrier rounds and measured SLOWER than the register build
+    // (SA1 backward 1.09 -> 1.17 ms per 2048 clouds, round 5 call B), so that shape keeps the per-lane build
+    constexpr bool ZL = SA_PK_DZ3_LDS && C1 == 128;
     __shared__ __attribute__((aligned(16))) float smem[TM * (LD1 + LD2 + 4) + 2 * TM + (NGMAX + 4) + NGMAX * (LDV + LDA)];
     float* H1 = smem;                        // H1, later dZ1 in place
     float* H2 = H1 + TM * LD1;
@@ -1136,7 +1140,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
         // ---- P1/P2: H1 recomputed, H2 stored (or recomputed) -----------------------------------------
         // (SA_PK_DZ3_LDS: H1's buffer holds the layer-3 gradient rows during P3; H1 itself is recomputed behind P4 -- with the
         // saved layer 2 nothing needs it before the dW2 product.  Without the saved layer 2 it is computed here too, for layer 2.)
-        if (!(SA_PK_ABLATE & 4) && (!SA_PK_DZ3_LDS || !a.h2)) sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
+        if (!(SA_PK_ABLATE & 4) && (!ZL || !a.h2)) sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
         __builtin_amdgcn_sched_barrier(0);
         if (a.h2) {
 #pragma unroll
@@ -1161,25 +1165,22 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
         const int wn2 = wave % M2::NBW, wm2 = wave / M2::NBW;
         f32x16 acc[M2::MB][M2::NB];
         zero_acc<M2::MB, M2::NB>(acc);
-#if SA_PK_DZ3_LDS
         // Z = the tile's dZ3 rows for a window of ZW channels (ZW / 2 from each k half), in H1's buffer (same row stride)
         constexpr int ZW = C1, LDZ = LD1, NSUB = 128 / ZW, NGW = ZW / 8;
         static_assert(NSUB * ZW == 128 && NGW % 2 == 0, "layer-3 gradient window");
         float* Z = H1;
-#else
         int lgv[M2::MB], lrv[M2::MB];
-#endif
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             if (q == 0) {
-#if !SA_PK_DZ3_LDS
+                if constexpr (!ZL) {
 #pragma unroll
-                for (int mb = 0; mb < M2::MB; ++mb) {
-                    const int lgr = Lgr[(wm2 * M2::MB + mb) * 32 + li];
-                    lgv[mb] = lgr >> 8;
-                    lrv[mb] = lgr & 255;
+                    for (int mb = 0; mb < M2::MB; ++mb) {
+                        const int lgr = Lgr[(wm2 * M2::MB + mb) * 32 + li];
+                        lgv[mb] = lgr >> 8;
+                        lrv[mb] = lgr & 255;
+                    }
                 }
-#endif
             } else {
                 __syncthreads();             // the previous chunk's Val, Arg are no longer read
                 for (int i = tid; i < td.z * 128; i += NT) {
@@ -1192,7 +1193,6 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                 }
             }
             __syncthreads();                 // H1, H2 and this chunk's Val, Arg complete (and nobody reads Z any more)
-#if SA_PK_DZ3_LDS
             auto z_build = [&](int h) {      // window h of this chunk: zero, then ONE store per (group, channel)
                 for (int q4 = tid; q4 < TM * ZW / 4; q4 += NT)
                     *(float4*)(Z + (q4 / (ZW / 4)) * LDZ + 4 * (q4 % (ZW / 4))) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1204,8 +1204,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                     Z[row * LDZ + sl] = Val[j * LDV + s128];
                 }
             };
-            if (!(SA_PK_ABLATE & 2)) z_build(0);
-#endif
+            if constexpr (ZL) {
+                if (!(SA_PK_ABLATE & 2)) z_build(0);
+            }
             {   // dW3[c, :] += val * H2[row of the arg-max, :]   (VALU; the slice stays in registers for the whole kernel)
                 const int s = tid & 127, ks = tid >> 7;
                 for (int j = 0; j < ((SA_PK_ABLATE & 1) ? 0 : td.z); ++j) {
@@ -1228,7 +1229,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                 }
             }
             __syncthreads();                 // a real barrier (register live ranges, see sa_bwd_kernel); Z complete
-#if SA_PK_DZ3_LDS
+            if constexpr (ZL) {
             // dH2 += dZ3[:, window] * W3[window, :]: the A operand streams from Z like any LDS tile
 #pragma unroll
             for (int h = 0; h < NSUB; ++h) {
@@ -1244,7 +1245,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                     mfma_stream_fn_win<M2::MB, M2::NB, C3 / 8, NGW>(
                         zload, P3Tv + ((size_t)(wn2 * M2::NB) * (C3 / 8) + 16 * q + NGW * h) * 64 + lane, acc);
             }
-#else
+            } else {
             // dH2 += dZ3[:, chunk] * W3[chunk, :]: A built per ROW from its own group's entries
             auto asel = [&](int mb, int g) -> float4 {
                 const int slot = lh * 64 + g * 4;
@@ -1260,7 +1261,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
             };
             if (!(SA_PK_ABLATE & 2))
                 mfma_stream_fn_win<M2::MB, M2::NB, C3 / 8, 16>(asel, P3Tv + ((size_t)(wn2 * M2::NB) * (C3 / 8) + 16 * q) * 64 + lane, acc);
-#endif
+            }
         }
         __syncthreads();                     // every wave is done with its dW3 reads of H2 rows (and with Z)
         // ---- P4: dZ2 = dH2 .* (1 - H2^2) -> D, db2 ---------------------------------------------------
@@ -1278,9 +1279,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                     accb2[nb] += z;
                 }
         }
-#if SA_PK_DZ3_LDS
-        if (!(SA_PK_ABLATE & 4)) sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);     // Z is dead: H1 for the dW2 / dH1 phases
-#endif
+        if constexpr (ZL) {
+            if (!(SA_PK_ABLATE & 4)) sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1); // Z is dead: H1 for the dW2 / dH1 phases
+        }
         __syncthreads();
         // ---- P5: dW2 += dZ2^T * H1 ------------------------------------------------------------------
         {

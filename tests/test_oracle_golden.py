@@ -218,6 +218,24 @@ def test_dagger_update_in_row_chunks_equals_one_shot():
     np.testing.assert_allclose(res[1][0], res[0][0], rtol=0, atol=1e-9)
 
 
+def test_slab_evaluated_linear_equals_autograd_linear():
+    """`_LinearSlabs` (the restatement's Linear for >= 2^16 rows on a device: weight gradient as a batched product over slabs of the
+    rows) against autograd's F.linear in fp64: output identical, gradients to round-off -- 2-D and 3-D inputs, a ragged row count."""
+    g = torch.Generator().manual_seed(0)
+    for shape in ((1000, 12), (7, 300, 5)):
+        x = torch.randn(*shape, generator=g, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(9, shape[-1], generator=g, dtype=torch.float64, requires_grad=True)
+        b = torch.randn(9, generator=g, dtype=torch.float64, requires_grad=True)
+        u = torch.randn(*shape[:-1], 9, generator=g, dtype=torch.float64)
+        ya = torch.nn.functional.linear(x, w, b)
+        ga = torch.autograd.grad((ya * u).sum(), (x, w, b))
+        yb = R._LinearSlabs.apply(x, w, b)
+        gb = torch.autograd.grad((yb * u).sum(), (x, w, b))
+        assert torch.equal(ya, yb)
+        for a, c in zip(ga, gb):
+            np.testing.assert_allclose(c.numpy(), a.numpy(), rtol=1e-12, atol=1e-12)
+
+
 def test_dagger_small_buffer_returns_early():
     assert R.dagger_update({}, {}, None, None, 15, {}, 1) is None
 
