@@ -172,7 +172,10 @@ def _ppo_whole_update(net, seed, tag, geom_check=None, grad_chunk=512):
     _free()
     ref, l64 = o["log"], o64["log"]
     assert log["Train/kl_update_count"] == ref["Train/kl_update_count"] == l64["Train/kl_update_count"] == 80
-    for k, rtol, atol in (("Train/value_function_loss", 2e-5, 0.0), ("Train/kl", 2e-3, 1e-9), ("Train/kl_max", 2e-3, 1e-9),
+    # KL is a mean of ~1e-3 quantities along a trajectory that two correct fp32 evaluations do not share bit for bit: the fp32 oracle
+    # itself moved from 7.8024e-4 to 7.82e-4 (fp64: 7.789e-4) when its mini-batches went from one shot to 512-cloud pieces (cfg 3,
+    # round 5); the HIP path sat at 7.80e-4 both times.  Observed |hip - oracle32| / oracle32: 3.2e-3 (cfg 3), 4.6e-5 (PointNet++).
+    for k, rtol, atol in (("Train/value_function_loss", 2e-5, 0.0), ("Train/kl", 1e-2, 1e-9), ("Train/kl_max", 1e-2, 1e-9),
                           ("Train/surrogate_loss", 0.0, 2e-5)):
         assert_close_rec(f"{tag} {k} vs oracle32", float(log[k]), float(ref[k]), rtol=rtol, atol=atol)
         record_margin(f"{tag} {k}: |hip - fp64| / |oracle32 - fp64|", abs(float(log[k]) - l64[k]) / max(abs(float(ref[k]) - l64[k]), 1e-300), 4.0,
