@@ -778,6 +778,41 @@ def run_ppo(args, device, rank, world):
                                             "term of algorithmic_bytes is what the 2560 steps touch, almost all of it out of L2",
                                flops_per_env_step=per_env_step,
                                note="algorithmic flops of the iteration / its wall time: every launch gap is inside")
+        if rank == 0 and world == 1 and not args.lean and run.use_graphs and run.graph_steps > 1:
+            # What bounds the iteration with TODAY's kernels ("a stated ceiling rather than an open question").  Each
+            # network's epoch is a list of 16-step hipGraphs; replayed ALONE on the idle chip they give that network's dependent-launch
+            # chain time -- kernel durations + in-graph launch boundaries, no host, no contention.  The iteration cannot beat
+            # n_updates x max(actor chain, critic chain) however well the two streams overlap, and needs no more than their sum.
+            g = run._graphs
+            floor = {}
+            for tag, stream in (("a", torch.cuda.current_stream()), ("c", run._side)):
+                keys = [k for k in g if isinstance(k, tuple) and k[0] == tag and k[-1] not in ("pre", "post")]
+                if not keys:
+                    continue
+                with torch.cuda.stream(stream):
+                    for k in keys:
+                        g[k].replay()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for k in keys:
+                        g[k].replay()
+                    torch.cuda.synchronize()
+                    floor[tag] = (time.perf_counter() - t0, sum(len(k) - 1 for k in keys))
+            if "a" in floor and "c" in floor:
+                (ta, na), (tc, nc) = floor["a"], floor["c"]
+                mf = lambda dims: 3 * 2048 * F(dims) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+                per_it = lambda t_epoch: w["N"] * w["T"] / (cfg["n_updates"] * t_epoch)
+                out["roofline"]["floor_us_per_step"] = dict(
+                    actor_chain_alone=ta / na * 1e6, critic_chain_alone=tc / nc * 1e6, steps_per_epoch=na,
+                    mfma_at_peak_actor=mf([w["O"]] + hid + [w["A"]]) * 1e6, mfma_at_peak_critic=mf([w["O"]] + hid + [1]) * 1e6,
+                    measured_pair=dt / args.steps / (cfg["n_updates"] * na) * 1e6,
+                    ceiling_env_steps_per_s_perfect_overlap=per_it(max(ta, tc)), env_steps_per_s_no_overlap=per_it(ta + tc),
+                    overlap_efficiency=(ta + tc - dt / args.steps / cfg["n_updates"]) / min(ta, tc),
+                    note="chains = one epoch of a network's 16-step hipGraphs replayed alone on the idle chip (sum of its ~24 kernels per "
+                         "step + in-graph launch boundaries); measured_pair = wall time of the iteration per (actor step, critic step) "
+                         "pair with both chains sharing the chip; overlap_efficiency = the fraction of the shorter chain hidden under "
+                         "the longer one.  Beating ceiling_env_steps_per_s_perfect_overlap needs faster kernels or fewer launch "
+                         "boundaries per step, not better scheduling")
         if rank == 0 and not args.lean:
             # the dominant kernel on its own: a hidden layer (mini-batch x 512 x 512) on gemm2_dma_kernel, 32 dependent launches
             # replayed from a graph on the otherwise idle chip (in the iteration two networks' chains share it)
