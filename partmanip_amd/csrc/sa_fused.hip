@@ -1111,6 +1111,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
         // ---- P0: gather; the tile's saved H2 rows and the first channel chunk's (pooled, dpooled, arg) entries are REQUESTED
         // here and stored to LDS behind the layer-1 recompute, which needs none of them: their round trips run under it
         sa_stage_pk<TM, NT>(k, td, tid, Xz, Src, Lgr, Ls);
+        // (ZL with the saved layer 2: nothing runs between these requests and their LDS stores any more -- layer 1 moved behind
+        // P4 -- so both go straight through: held across the barrier the sixteen H2 registers were SPILLED at this register budget,
+        // 0.8 GB of scratch traffic per launch, profiles/hbm_traffic.json round 5: 2.50 -> 2.81 GB)
+        const bool direct = ZL && a.h2 != nullptr;
         float4 hq[EPT];
         if (a.h2) {
 #pragma unroll
@@ -1118,6 +1122,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                 const int q = tid + i * NT, row = q / (C2 / 4), c4 = q % (C2 / 4);
                 hq[i] = make_float4(0.f, 0.f, 0.f, 0.f);             // rows past the end: zero (their dZ2 is 0 * (1 - 0))
                 if (row < td.w) hq[i] = *(const float4*)(a.h2 + (long)(td.x + row) * C2 + 4 * c4);
+            }
+            if (direct) {
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int q = tid + i * NT, row = q / (C2 / 4), c4 = q % (C2 / 4);
+                    *(float4*)(H2 + row * LD2 + 4 * c4) = hq[i];
+                }
             }
         }
         float pv[NV], dv[NV];
@@ -1135,6 +1146,16 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                 av[u] = a.arg[g * C3 + c];
             }
         }
+        if (direct) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int i = tid + u * NT, j = i >> 7, sl = i & 127;
+                if (j < td.z) {
+                    Val[j * LDV + sl] = dv[u] * (1.0f - pv[u] * pv[u]);
+                    ((uint8_t*)ArgW)[j * (LDA * 4) + sl] = (uint8_t)av[u];
+                }
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         // ---- P1/P2: H1 recomputed, H2 stored (or recomputed) -----------------------------------------
@@ -1142,19 +1163,21 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
         // saved layer 2 nothing needs it before the dW2 product.  Without the saved layer 2 it is computed here too, for layer 2.)
         if (!(SA_PK_ABLATE & 4) && (!ZL || !a.h2)) sa_layer1<C1, TM, NT>(a, tid, Xz, Src, H1);
         __builtin_amdgcn_sched_barrier(0);
-        if (a.h2) {
+        if (a.h2 && !direct) {
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
                 const int q = tid + i * NT, row = q / (C2 / 4), c4 = q % (C2 / 4);
                 *(float4*)(H2 + row * LD2 + 4 * c4) = hq[i];
             }
         }
+        if (!direct) {
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int i = tid + u * NT, j = i >> 7, sl = i & 127;
-            if (j < td.z) {
-                Val[j * LDV + sl] = dv[u] * (1.0f - pv[u] * pv[u]);
-                ((uint8_t*)ArgW)[j * (LDA * 4) + sl] = (uint8_t)av[u];
+            for (int u = 0; u < NV; ++u) {
+                const int i = tid + u * NT, j = i >> 7, sl = i & 127;
+                if (j < td.z) {
+                    Val[j * LDV + sl] = dv[u] * (1.0f - pv[u] * pv[u]);
+                    ((uint8_t*)ArgW)[j * (LDA * 4) + sl] = (uint8_t)av[u];
+                }
             }
         }
         if (!a.h2) {
