@@ -923,7 +923,7 @@ def _brief(line):
     out = dict(metric=line["metric"], value=line["value"], unit=line["unit"], steps=line["steps"], warmup=line["warmup"],
                ms_per_step=line["ms_per_step"], dtype=line["dtype"], workload=line["config"]["workload"],
                roofline={k: r[k] for k in keep if k in r})
-    for k in ("hidden_layer_gemm", "gae_scan", "group_all"):
+    for k in ("hidden_layer_gemm", "gae_scan", "group_all", "floor_us_per_step"):
         if k in r:
             out["roofline"][k] = r[k]
     if "cpu_baseline" in line:
