@@ -22,6 +22,15 @@ this file is "parity unpinned": it restates the published algorithms
 
 Each function cites the reference lines it follows (paths relative to
 /root/reference).
+
+The restatement is plain torch and device-agnostic: the whole-update parity tests
+(tests/test_gpu_wholeupdate.py) evaluate it on the MI355X through ATen in fp32 and fp64,
+where the host cores would take hours.  Three evaluation aids exist for that and change no
+mathematics: `grad_chunk` (a mini-batch's mean loss and gradient as size-weighted sums over
+row chunks), `_LinearSlabs` (a Linear whose weight gradient is summed over row slabs) and the
+batched index builders (`fps_torch`, `ball_query_torch`, `sparse_unet_geometry_torch`); each
+is pinned to its plain form on CPU (tests/test_oracle_golden.py, test_oracle_pointnet2_rows.py,
+test_oracle_sparse_unet.py).
 """
 import math
 
