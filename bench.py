@@ -1042,6 +1042,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))                  # re-exec as N ranks under torch.distributed.run
+    # stdout is ONE JSON line.  Libraries print there too (gloo's "[Gloo] Rank ... is connected", RCCL's version banner): from here
+    # to the final print the process's file descriptor 1 IS stderr, so whatever anything writes -- Python or C -- lands there.
+    sys.stdout.flush()
+    fd_out = os.dup(1)
+    os.dup2(2, 1)
     from partmanip_amd import dist as pdist
     rank, world, local = pdist.init_from_env("nccl")
     if world != args.gpus:
@@ -1066,13 +1071,16 @@ def main():
             out = run_ppo(args, device, rank, world)
             if args.workload == "vision" and world == 1 and args.precision == "f32" and not args.n_steps and not args.no_secondary:
                 out["secondary"] = secondary_lines(args, device)
-    if rank == 0:
-        if topo is not None and isinstance(out.get("config"), dict):
-            out["config"]["ranks"] = topo
-        print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(fd_out, 1)
+    os.close(fd_out)
+    if rank == 0:
+        if topo is not None and isinstance(out.get("config"), dict):
+            out["config"]["ranks"] = topo
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
