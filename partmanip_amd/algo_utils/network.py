@@ -452,6 +452,9 @@ class PointNet2(_HipNet):
         self.nsamples = list(net_cfg.get('nsamples', [32, 32]))
         mlps = [list(m) for m in net_cfg.get('mlps', [[64, 64, 128], [128, 128, 256], [256, 512]])]
         assert len(mlps) == len(self.npoints) + 1 == len(self.radii) + 1 == len(self.nsamples) + 1
+        if not self.npoints:
+            raise ValueError("PointNet2 needs at least one set-abstraction level (npoints / radii / nsamples / mlps[:-1]); a network "
+                             "with only the group-all level is `PointNet`")
         counts = [self.point_num] + self.npoints
         if any(b > a or b < 1 for a, b in zip(counts, counts[1:])):
             raise ValueError(f"PointNet2: npoints {self.npoints} must be non-increasing and <= point_num {self.point_num} "

@@ -27,6 +27,12 @@ def test_rows_uniq_names_the_distinct_rows_of_every_cloud(B, S):
         assert np.array_equal(u[b, :len(d)], d) and np.all(u[b, len(d):] == R0)
         assert np.array_equal(um[b, :len(d)], d) and np.all(um[b, len(d):] == -1)
         assert np.array_equal(u[b][rank[b]], v)
+    if S <= P:                                               # all ids distinct: no padding slot at all, rank = the sorted position
+        perm = np.stack([g.permutation(P)[:S] for _ in range(B)]).astype(np.int32)
+        ud, umd, rd = (t.cpu().numpy() for t in o.rows_uniq(torch.from_numpy(perm).to(DEV), S, R0, row_base=P))
+        for b in range(B):
+            assert np.array_equal(ud[b], np.sort(perm[b]) + b * P) and np.array_equal(umd[b], ud[b])
+            assert np.array_equal(ud[b][rd[b]], perm[b] + b * P)
     # second level: through a parent table, the padding id maps to the next level's padding id
     R1 = 37
     parent = g.integers(0, R1, size=R0).astype(np.int32)

@@ -225,3 +225,11 @@ def test_padded_cols_and_slab_count_host_side():
             chunk = (-(-B // S) + 31) // 32 * 32
             assert 1 <= S <= slabs and (S == 1 or (S - 1) * chunk < B) and (B >= 1024 or S == 1)
     assert ppo._slabs(SimpleNamespace(actor_critic=SimpleNamespace(GRAD_SLABS=3)), 2048) == 3
+
+
+def test_pointnet2_without_a_set_abstraction_level_is_refused_at_construction():
+    """`npoints: []` used to die with an IndexError inside the constructor; it is a configuration error and says so."""
+    import pytest
+    from partmanip_amd.algo_utils.network import PointNet2
+    with pytest.raises(ValueError, match="at least one set-abstraction level"):
+        PointNet2(3072, 10, dict(activation="tanh", npoints=[], radii=[], nsamples=[], mlps=[[64, 128]]), 0)
