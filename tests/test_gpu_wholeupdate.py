@@ -29,7 +29,11 @@ from tests.helpers import t, flat_state, FakeEnv, FakeLogger, per_tensor_update_
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-BRACKET = 2.0
+# observed over five full runs (three boxes): the worst tensor of the PointNet++ iteration at 1.16 .. 1.68 x the fp32 oracle's own
+# (or its network-median) distance to fp64 -- the oracle's ATen index_add / the level-1 dY atomics make both sides run-dependent in
+# their last bits, and 80 Adam steps amplify that -- cfg 3 and SparseUNet at <= 1.35 x.  3 x keeps a real regression (a wrong
+# gradient scores 10 x and more) apart from that noise.
+BRACKET = 3.0
 
 TRICKS = dict(mini_adv_norm=False, whole_adv_norm=False, use_state_norm=False, use_clipped_value_loss=False,
               use_grad_clip=True, max_grad_norm=0.5)
@@ -178,8 +182,8 @@ def _ppo_whole_update(net, seed, tag, geom_check=None, grad_chunk=512):
     for k, rtol, atol in (("Train/value_function_loss", 2e-5, 0.0), ("Train/kl", 1e-2, 1e-9), ("Train/kl_max", 1e-2, 1e-9),
                           ("Train/surrogate_loss", 0.0, 2e-5)):
         assert_close_rec(f"{tag} {k} vs oracle32", float(log[k]), float(ref[k]), rtol=rtol, atol=atol)
-        record_margin(f"{tag} {k}: |hip - fp64| / |oracle32 - fp64|", abs(float(log[k]) - l64[k]) / max(abs(float(ref[k]) - l64[k]), 1e-300), 4.0,
-                      hip=float(log[k]), oracle32=float(ref[k]), fp64=float(l64[k]))
+        # (the same bound against the fp64 evaluation; a RATIO of the two distances is not recorded: either can be ~0 by chance)
+        assert_close_rec(f"{tag} {k} vs fp64", float(log[k]), float(l64[k]), rtol=rtol, atol=atol)
     worst = _bracket(tag, got, flat_state(p32), {k: v.cpu().numpy() for k, v in p64.items()}, sd, lr)
     print(f"{tag}: worst per-tensor ||hip - oracle32|| / ||oracle32 - init|| = {worst:.2e}")
 
@@ -257,8 +261,7 @@ def test_dagger_sparse_unet_update_at_2048_clouds_matches_oracle_fp32_and_fp64(t
     o64 = R.dagger_update(stu64, {k: v.double() for k, v in tea32.items()}, ring_obs.double(), ring_tea.double(), N * buf, ocfg, 1, grad_chunk=256)
     _free()
     assert_close_rec("dagger SparseUNet 2048 clouds: Train/dagger_loss vs oracle32", loss, o["log"]["Train/dagger_loss"], rtol=2e-5)
-    record_margin("dagger SparseUNet 2048 clouds: |loss - fp64| hip / oracle32", abs(loss - o64["log"]["Train/dagger_loss"]) /
-                  max(abs(o["log"]["Train/dagger_loss"] - o64["log"]["Train/dagger_loss"]), 1e-300), 4.0)
+    assert_close_rec("dagger SparseUNet 2048 clouds: Train/dagger_loss vs fp64", loss, o64["log"]["Train/dagger_loss"], rtol=2e-5)
     # dagger.py:56: one Adam over every student parameter; only the actor receives gradients -- the critic and log_std must not move
     moved = {k: v for k, v in init.items() if k.startswith("actor.")}
     names = list(init.keys())
