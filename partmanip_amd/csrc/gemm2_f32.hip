@@ -407,6 +407,16 @@ __device__ __forceinline__ int g2_chan(const Gemm2Prob& g, int q) { return g.gsh
 // The same for a GATHERED operand (see Gemm2Prob::gidx).  The neighbour indices of a tile are ordinary loads; VMEM returns in
 // order, so waiting for them would also drain every LDS-DMA issued before -- they are therefore fetched one K-step ahead
 // (`gi`: this tile's indices, loaded while the previous tile was issued; refilled here for the next tile `k0n`).
+// A neighbour index fetched by an ordinary load the COMPILER DOES NOT SEE (inline asm): hipcc cannot count a loop-carried VMEM
+// result and guarded the index registers with `s_waitcnt vmcnt(0)` at the top of the loader loop -- the ring drained to one tile
+// there.  The hardware still counts the load (in order with the DMAs), so the ring's counted waits cover it: an index requested by
+// issue(t) has landed once issue(t + 1)'s hand-over wait has passed, and issue(t + 2) is its first reader.  The ISA must not copy
+// the register between the load and that wait (checked: tools/isa_stats.py / the loader loop of gemm2_dma_kernel<.., GATHER>).
+__device__ __forceinline__ int g2_idx_load(const int32_t* p) {
+    int v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 template <bool KM, int T>
 __device__ __forceinline__ void g2_dma_tile_gather(const Gemm2Prob& g, const float* __restrict__ P, long ld, int r0, int nrows, int k0,
                                                    int k0n, float* __restrict__ S, int wave, int lane, int (&gi)[T / 32]) {
@@ -426,7 +436,7 @@ __device__ __forceinline__ void g2_dma_tile_gather(const Gemm2Prob& g, const flo
             // exactly IPT + NGI operations, whatever the tile.
             const float* src = (gi[j] >= 0 && rr < g.K) ? P + (long)gi[j] * ld + (q % g.gC) : g.gzero + (q % g.gC);
             __builtin_amdgcn_global_load_lds(src, (g2_lds_ptr)(S + piece * 256), 16, 0, 0);
-            gi[j] = g.gidx[(long)min(k0n + k, g.K - 1) * g.gJ + qn / g.gC];
+            gi[j] = g2_idx_load(g.gidx + (long)min(k0n + k, g.K - 1) * g.gJ + qn / g.gC);
         } else {                                                           // A of a forward: rows = output rows
             const int row = piece * 8 + (lane >> 3), c = lane & 7;
             rr = min(r0 + row, nrows - 1);
@@ -434,7 +444,7 @@ __device__ __forceinline__ void g2_dma_tile_gather(const Gemm2Prob& g, const flo
             qn = k0n + ((c ^ ((row >> 1) & 7)) << 2);
             const float* src = gi[j] >= 0 ? P + (long)gi[j] * ld + g2_chan(g, q) : g.gzero + g2_chan(g, q);
             __builtin_amdgcn_global_load_lds(src, (g2_lds_ptr)(S + piece * 256), 16, 0, 0);
-            gi[j] = g.gidx[(long)rr * g.gJ + g2_tap(g, qn)];
+            gi[j] = g2_idx_load(g.gidx + (long)rr * g.gJ + g2_tap(g, qn));
         }
     }
 }
@@ -445,10 +455,10 @@ __device__ __forceinline__ void g2_gather_first(const Gemm2Prob& g, int r0, int 
         const int piece = j * 4 + wave;
         if (KM) {
             const int k = piece * (256 / T) + lane / (T / 4), c = lane % (T / 4);
-            gi[j] = g.gidx[(long)min(k0 + k, g.K - 1) * g.gJ + min(r0 + c * 4, nrows - 4) / g.gC];      // (unconditional: see g2_dma_tile_gather)
+            gi[j] = g2_idx_load(g.gidx + (long)min(k0 + k, g.K - 1) * g.gJ + min(r0 + c * 4, nrows - 4) / g.gC);      // (unconditional: see g2_dma_tile_gather)
         } else {
             const int row = piece * 8 + (lane >> 3), c = lane & 7;
-            gi[j] = g.gidx[(long)min(r0 + row, nrows - 1) * g.gJ + g2_tap(g, k0 + ((c ^ ((row >> 1) & 7)) << 2))];
+            gi[j] = g2_idx_load(g.gidx + (long)min(r0 + row, nrows - 1) * g.gJ + g2_tap(g, k0 + ((c ^ ((row >> 1) & 7)) << 2)));
         }
     }
 }
@@ -530,6 +540,7 @@ __device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Pro
                 g2_gather_first<false, TM>(g, m0, g.M, kbeg, wave, lane, gia);
                 g2_gather_first<false, TM>(g, m0, g.M, k1, wave, lane, gib);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the compiler does not know these loads: the first two tiles' indices are in
         }
         // the counted waits allow for the NGI index loads an issue() ends with
         constexpr int NW1 = IPT + (GATHER ? NGI : 0);
