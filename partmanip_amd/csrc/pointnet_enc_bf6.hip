@@ -19,7 +19,9 @@
 // prefetching A as well, change nothing): with 64-row tiles every 1 KB weight fragment feeds two 32-cycle MFMAs per
 // product class = 16 B/clk per wave, 64 B/clk per CU at full matrix rate -- the L1 fill rate.  More rows per fragment
 // need more than the 160 KB of LDS for three activation planes (128 rows: 203 KB); a 96-row tile (147 KB) is the next
-// thing to try.  A 16-wave work-group (four waves per SIMD) measured 4.3 ms.
+// thing to try -- measured first (round 5): a timing-only build with four row blocks per weight fragment (half the weight bytes
+// per MFMA, rows aliased) takes 3.70 ms against 3.97: larger tiles are a 7 % lever, not built.  A 16-wave work-group (four
+// waves per SIMD) measured 4.3 ms.  The packed planes are step-major (B6_STEP_MAJOR): -2 %.
 #include "common.h"
 
 
@@ -37,7 +39,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define B6_P3 (16 * 16 * 64 * 8)        // [nb 16][step 16][lane 64][8]
 #define B6_OFF_P2(p) ((p) * B6_P2)
 #define B6_OFF_P3(p) (3 * B6_P2 + (p) * B6_P3)
-#define B6_PACKED_HALFS (3 * B6_P2 + 3 * B6_P3 + 4096)
+#ifndef B6_STEP_MAJOR
+#define B6_STEP_MAJOR 1      // packed order [step][plane][nb][lane][8]: what the 8 waves of every CU request at one k-step is one contiguous 48 KB
+#endif
+#define B6_PAD (B6_STEP_MAJOR ? 32768 : 4096)    // the last k-step's prefetch over-reads one step (step-major: 3 planes x 16 N-blocks = 24 576 halfwords)
+#define B6_PACKED_HALFS (3 * B6_P2 + 3 * B6_P3 + B6_PAD)
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {        // {bf16(a) | bf16(b) << 16}, RNE
     unsigned r;
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void pn_pack_bf6_kernel(const float* __restric
                                                            unsigned short* __restrict__ packed) {
     const int i = blockIdx.x * 256 + threadIdx.x;                       // one (nb, step, lane, e) slot of P2 or P3
     if (i >= B6_P2 + B6_P3) {
-        if (i < B6_P2 + B6_P3 + 4096) packed[3 * B6_P2 + 3 * B6_P3 + (i - B6_P2 - B6_P3)] = 0;
+        if (i < B6_P2 + B6_P3 + B6_PAD) packed[3 * B6_P2 + 3 * B6_P3 + (i - B6_P2 - B6_P3)] = 0;
         return;
     }
     const int e = i & 7, lane = (i >> 3) & 63, li = lane & 31, lq = lane >> 5;
@@ -71,13 +77,13 @@ __global__ __launch_bounds__(256) void pn_pack_bf6_kernel(const float* __restric
     if (i < B6_P2) {
         const int step = (i >> 9) & 7, nb = i >> 12;
         w = W2[(nb * 32 + li) * 128 + step * 16 + lq * 8 + e];
-        o0 = B6_OFF_P2(0) + i;
-        stride = B6_P2;
+        o0 = B6_STEP_MAJOR ? B6_OFF_P2(0) + ((step * 3 * 8 + nb) * 64 + lane) * 8 + e : B6_OFF_P2(0) + i;
+        stride = B6_STEP_MAJOR ? 8 * 64 * 8 : B6_P2;
     } else {
         const int j = i - B6_P2, step = (j >> 9) & 15, nb = j >> 13;
         w = W3[(nb * 32 + li) * 256 + step * 16 + lq * 8 + e];
-        o0 = B6_OFF_P3(0) + j;
-        stride = B6_P3;
+        o0 = B6_STEP_MAJOR ? B6_OFF_P3(0) + ((step * 3 * 16 + nb) * 64 + lane) * 8 + e : B6_OFF_P3(0) + j;
+        stride = B6_STEP_MAJOR ? 16 * 64 * 8 : B6_P3;
     }
     unsigned short p0, p1, p2;
     split3_bf16(w, p0, p1, p2);
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256) void pn_pack_bf6_kernel(const float* __restric
 
 extern "C" int pm_pointnet_pack_weights_bf6(const float* W2, const float* W3, void* packed, void* stream) {
     PM_REQUIRE(W2 && W3 && packed);
-    const int n = B6_P2 + B6_P3 + 4096;
+    const int n = B6_P2 + B6_P3 + B6_PAD;
     hipLaunchKernelGGL(pn_pack_bf6_kernel, dim3((n + 255) / 256), dim3(256), 0, pm_stream(stream), W2, W3,
                        (unsigned short*)packed);
     PM_CHECK_LAUNCH();
@@ -105,14 +111,18 @@ __device__ __forceinline__ bf16x8 as_bf(const uint4& v) { return *(const bf16x8*
 // MFMAs (named ping/pong sets pinned with sched_barrier, as in pointnet_enc.hip); A comes from LDS at the top of the
 // step.  Term order: the smallest products first, each product class over all (mb, nb) accumulators before the next
 // (consecutive MFMAs never depend on each other).
-template <int MB, int NB, int NS>
+template <int MB, int NB, int NS, int NBT>
 __device__ __forceinline__ void bf6_stream(const unsigned short* __restrict__ A, int aps, int lda,
-                                           const uint4* __restrict__ B, size_t bps, f32x16 (&acc)[MB][NB]) {
+                                           const uint4* __restrict__ B, f32x16 (&acc)[MB][NB]) {
+    // strides of the packed planes in uint4s (NBT = N-blocks of the whole layer): plane, N-block, k-step
+    constexpr size_t bps = B6_STEP_MAJOR ? (size_t)NBT * 64 : (size_t)NBT * NS * 64;
+    constexpr size_t bnb = B6_STEP_MAJOR ? 64 : (size_t)NS * 64;
+    constexpr size_t bst = B6_STEP_MAJOR ? (size_t)3 * NBT * 64 : 64;
     uint4 b0[3][NB], b1[3][NB];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b0[pl][nb] = B[pl * bps + (size_t)(nb * NS) * 64];
+        for (int nb = 0; nb < NB; ++nb) b0[pl][nb] = B[pl * bps + nb * bnb];
 #define B6_TERM(pa, pb, BC)                                                                    \
     _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                          \
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                      \
@@ -125,7 +135,7 @@ __device__ __forceinline__ void bf6_stream(const unsigned short* __restrict__ A,
                 a[pl][mb] = *(const uint4*)(A + pl * aps + mb * 32 * lda + (S_) * 16);         \
         _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                       \
             _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)  /* next step (over-reads one step at the end: padded) */ \
-                BN[pl][nb] = B[pl * bps + (size_t)(nb * NS + (S_) + 1) * 64];                  \
+                BN[pl][nb] = B[pl * bps + nb * bnb + (size_t)((S_) + 1) * bst];                \
         __builtin_amdgcn_sched_barrier(0);                                                     \
         B6_TERM(2, 0, BC) B6_TERM(1, 1, BC) B6_TERM(0, 2, BC)                                  \
         B6_TERM(1, 0, BC) B6_TERM(0, 1, BC) B6_TERM(0, 0, BC)                                  \
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(B6_NT, 2) void pn_fwd_bf6_kernel(const float* __res
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[mb][0][r] = 0.f;
-            bf6_stream<2, 1, 8>(Hs + li * B6_LD1 + lq * 8, PL1, B6_LD1, P2 + (size_t)(wave * 8) * 64 + lane, B6_P2 / 8, acc2);
+            bf6_stream<2, 1, 8, 8>(Hs + li * B6_LD1 + lq * 8, PL1, B6_LD1, P2 + (size_t)wave * (B6_STEP_MAJOR ? 64 : 8 * 64) + lane, acc2);
             __syncthreads();                               // every wave has finished reading H1
             const float b2c = b2[wave * 32 + li];
 #pragma unroll
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(B6_NT, 2) void pn_fwd_bf6_kernel(const float* __res
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][nb][r] = b3c;
         }
-        bf6_stream<2, 2, 16>(Hs + li * B6_LD2 + lq * 8, PL2, B6_LD2, P3 + (size_t)(wave * 2 * 16) * 64 + lane, B6_P3 / 8, acc);
+        bf6_stream<2, 2, 16, 16>(Hs + li * B6_LD2 + lq * 8, PL2, B6_LD2, P3 + (size_t)(wave * 2) * (B6_STEP_MAJOR ? 64 : 16 * 64) + lane, acc);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
