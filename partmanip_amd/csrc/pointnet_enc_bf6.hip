@@ -62,6 +62,22 @@ __device__ __forceinline__ void split3_bf16(float x, unsigned short& p0, unsigne
     p2 = (unsigned short)c;
 }
 
+// (x, y) -> three packed bf16 pairs {plane(x) | plane(y) << 16}: one v_cvt_pk_bf16_f32 per plane for both values (the builtin
+// conversion, so the scheduler may interleave the chains); the same roundings as split3_bf16
+typedef __bf16 b6_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned b6_cvt_pk(float a, float b) {
+    const f32x2 v = {a, b};
+    const b6_bf16x2 h = __builtin_convertvector(v, b6_bf16x2);
+    return *(const unsigned*)&h;
+}
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned (&q)[3]) {
+    q[0] = b6_cvt_pk(x, y);
+    const float rx = x - __uint_as_float(q[0] << 16), ry = y - __uint_as_float(q[0] & 0xffff0000u);
+    q[1] = b6_cvt_pk(rx, ry);
+    const float sx = rx - __uint_as_float(q[1] << 16), sy = ry - __uint_as_float(q[1] & 0xffff0000u);
+    q[2] = b6_cvt_pk(sx, sy);
+}
+
 extern "C" size_t pm_pointnet_packed_bf6_bytes(void) { return (size_t)B6_PACKED_HALFS * 2; }
 
 __global__ __launch_bounds__(256) void pn_pack_bf6_kernel(const float* __restrict__ W2, const float* __restrict__ W3,
@@ -235,13 +251,12 @@ __global__ __launch_bounds__(B6_NT, 2) void pn_fwd_bf6_kernel(const float* __res
                     z[j] = s;
                 }
                 const f32x2 t = pm_tanh2(z[0], z[1]);
+                unsigned q[3];
+                split3_pair(t.x, t.y, q);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    unsigned short q0, q1, q2;
-                    split3_bf16(j ? t.y : t.x, q0, q1, q2);
-                    Hs[(p + j) * B6_LD1 + c] = q0;
-                    Hs[PL1 + (p + j) * B6_LD1 + c] = q1;
-                    Hs[2 * PL1 + (p + j) * B6_LD1 + c] = q2;
+                for (int pl = 0; pl < 3; ++pl) {
+                    Hs[pl * PL1 + p * B6_LD1 + c] = (unsigned short)q[pl];
+                    Hs[pl * PL1 + (p + 1) * B6_LD1 + c] = (unsigned short)(q[pl] >> 16);
                 }
             }
         }
@@ -260,17 +275,16 @@ __global__ __launch_bounds__(B6_NT, 2) void pn_fwd_bf6_kernel(const float* __res
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const f32x2 t = pm_tanh2(acc2[mb][0][r] + b2c, acc2[mb][0][r + 1] + b2c);
+                    unsigned q[3];
+                    split3_pair(t.x, t.y, q);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int row = mb * 32 + ((r + j) & 3) + 8 * ((r + j) >> 2) + 4 * lq;
-                        const float v = j ? t.y : t.x;
-                        unsigned short q0, q1, q2;
-                        split3_bf16(v, q0, q1, q2);
-                        Hs[row * B6_LD2 + wave * 32 + li] = q0;
-                        Hs[PL2 + row * B6_LD2 + wave * 32 + li] = q1;
-                        Hs[2 * PL2 + row * B6_LD2 + wave * 32 + li] = q2;
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            Hs[pl * PL2 + row * B6_LD2 + wave * 32 + li] = (unsigned short)(j ? q[pl] >> 16 : q[pl]);
                         // training forward: the fp32 activation also goes to HBM for the (fp32) backward, see pn_fwd_kernel
-                        if (h2_save) h2_save[((long)b * P + (long)tile * B6_TM + row) * 256 + wave * 32 + li] = v;
+                        if (h2_save) h2_save[((long)b * P + (long)tile * B6_TM + row) * 256 + wave * 32 + li] = j ? t.y : t.x;
                     }
                 }
         }
