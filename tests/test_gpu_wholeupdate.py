@@ -181,7 +181,10 @@ def _ppo_whole_update(net, seed, tag, geom_check=None, grad_chunk=512):
     # round 5); the HIP path sat at 7.80e-4 both times.  Observed |hip - oracle32| / oracle32: 3.2e-3 (cfg 3), 4.6e-5 (PointNet++).
     for k, rtol, atol in (("Train/value_function_loss", 2e-5, 0.0), ("Train/kl", 1e-2, 1e-9), ("Train/kl_max", 1e-2, 1e-9),
                           ("Train/surrogate_loss", 0.0, 2e-5)):
-        assert_close_rec(f"{tag} {k} vs oracle32", float(log[k]), float(ref[k]), rtol=rtol, atol=atol)
+        # against the fp32 oracle the bound is at least BRACKET x the oracle's own distance from fp64 (cfg 3, surrogate loss: the
+        # oracle sits 1.3e-5 from fp64, the HIP path 1.9e-6 -- the 2e-5 above would be a test of the ORACLE's rounding there)
+        assert_close_rec(f"{tag} {k} vs oracle32", float(log[k]), float(ref[k]), rtol=rtol,
+                         atol=max(atol, BRACKET * abs(float(ref[k]) - float(l64[k]))))
         # (the same bound against the fp64 evaluation; a RATIO of the two distances is not recorded: either can be ~0 by chance)
         assert_close_rec(f"{tag} {k} vs fp64", float(log[k]), float(l64[k]), rtol=rtol, atol=atol)
     worst = _bracket(tag, got, flat_state(p32), {k: v.cpu().numpy() for k, v in p64.items()}, sd, lr)
