@@ -159,3 +159,11 @@ __device__ __forceinline__ float pm_dact(float h, int act) {
         default: return 1.0f;
     }
 }
+
+// Work-groups b = x (mod 8) of a launch land on XCD x when the dispatcher round-robins (MI355X_MICROARCH.md, work-group dispatch):
+// this maps block b of n to a position such that every XCD owns a CONTIGUOUS range of positions (a bijection for any n), so that
+// neighbouring tiles / rows meet in one XCD's L2 instead of being fetched by all eight.  Speed and traffic only.
+__device__ __forceinline__ int pm_xcd_contiguous(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return x * q + min(x, r) + (b >> 3);
+}

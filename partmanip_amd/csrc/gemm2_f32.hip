@@ -221,6 +221,11 @@ __device__ __forceinline__ void g2_epilogue(const Gemm2Prob& g, f32x16 (&acc)[WM
     }
 }
 
+// T1 (pm_xcd_contiguous, common.h): an XCD owns a contiguous range of a problem's tiles -- for ANY tile count (round 5: with the
+// n % 8 == 0 condition this had, a 756-block weight gradient ran un-swizzled and the seven M-tiles of a split-K slab fetched their
+// dY slab, index rows and source rows on seven XCDs: 4.9 -> 2.0 GB per launch); a problem's block0 is a multiple of 8
+__device__ __forceinline__ int g2_xcd_local(int local, int n) { return pm_xcd_contiguous(local, n); }
+
 template <bool A_KM, bool B_KM, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void gemm2_kernel(Gemm2Group gg) {
     constexpr int TM = 64 * WM, TN = 64 * WN;
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(Gemm2Group gg) {
     const int tiles = g.tiles_m * g.tiles_n, nblk = tiles * g.splits;
     int local = (int)blockIdx.x - g.block0;
     if (local >= nblk) return;                                              // padding block behind a problem (launcher)
-    if ((nblk & 7) == 0) local = (local & 7) * (nblk >> 3) + (local >> 3);   // T1: an XCD (blocks = x mod 8) owns contiguous tiles
+    local = g2_xcd_local(local, nblk);                                      // T1: an XCD (blocks = x mod 8) owns contiguous tiles
     const int z = local / tiles, t = local - z * tiles;
     const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
     const int m0 = tm * TM, n0 = tn * TN;
@@ -645,7 +650,7 @@ __global__ __launch_bounds__(512) void gemm2_dma_kernel(Gemm2Group gg) {
     const int tiles = g.tiles_m * g.tiles_n, nblk = tiles * g.splits;
     int local = (int)blockIdx.x - g.block0;
     if (local >= nblk) return;
-    if ((nblk & 7) == 0) local = (local & 7) * (nblk >> 3) + (local >> 3);
+    local = g2_xcd_local(local, nblk);
     const int z = local / tiles, t = local - z * tiles;
     const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
     g2_dma_body<A_KM, B_KM, WM, WN, GATHER, LAY, 0, false, NB>(gg, g, tm, tn, z, lds);
@@ -732,7 +737,7 @@ __global__ __launch_bounds__(512) void gemm2_chain_kernel(Gemm2Chain ch) {
     // work-groups are consecutive WITHIN an XCD's block list (their tiles then meet in that XCD's L2 -- speed only)
     const int total = ch.stripes * ch.G;
     int local = (int)blockIdx.x;
-    if ((total & 7) == 0) local = (local & 7) * (total >> 3) + (local >> 3);
+    local = g2_xcd_local(local, total);
     const int stripe = local / ch.G, tn = local - stripe * ch.G;
     g2_u64* ctr = ch.bar + stripe;
     g2_u64* err = ch.bar + ch.stripes;
