@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 148 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 149 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -515,8 +515,17 @@ int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const int32_t* gro
                          const int32_t* tiles, const int32_t* totals, const float* W1, long ldw1, const float* b1, const float* b2,
                          const float* W3, const float* packed, int C1, int C2, int C3, const float* pooled, long ldp,
                          const int32_t* arg, const float* dpooled, long lddp, float* dW1, long lddw1, float* db1, float* dW2,
-                         float* db2, float* dW3, float* db3, float* dY, const float* h2_saved, void* workspace,
-                         size_t workspace_bytes, void* stream);
+                         float* db2, float* dW3, float* db3, float* dY /* fp32 atomics: A/B only */,
+                         float* dz1_rows /* (R, C1): the layer-1 gradient per packed row, plain stores (deterministic path) */,
+                         const float* h2_saved, void* workspace, size_t workspace_bytes, void* stream);
+/* The gradient of a level's per-source-point layer-1 rows (Y) WITHOUT floating-point atomics: a source point sits in several
+ * groups, so dY[point] = sum of dz1 over its packed rows.  pm_sa_plan_inverse_i32 (coordinates only, once per plan) lists every
+ * point's packed rows in ASCENDING order (CSR: inv_start (B*P + 1), inv_rows (R; capacity B*S*nsample)); pm_sa_dy_segsum_f32 adds
+ * them in that order -- bit-reproducible run to run, no zero-fill of dY (points in no group get zeros).  P <= 7000. */
+int pm_sa_plan_inverse_i32(const int32_t* rowmap, const int32_t* grow, int B, int P, int S, int32_t* inv_start, int32_t* inv_rows,
+                           void* stream);
+int pm_sa_dy_segsum_f32(const float* dz1, const int32_t* inv_start, const int32_t* inv_rows, long npoints, int C1, float* dY, long lddy,
+                        void* stream);
 
 /* ---- PointNet++ group-all level: its LAST layer fused with the max over the cloud (csrc/sa_groupall.hip) ----------------
  * (BASELINE.json cfg 3's backbone; the reference ships no PointNet++ source -- `PointNet2` in algo_utils/network.py.)

@@ -513,6 +513,10 @@ class PointNet2(_HipNet):
         # fused levels run over each group's DISTINCT rows (ball query pads short groups with copies of their first hit;
         # a copy never wins the max-pool): same outputs and gradients as the dense kernels, `False` keeps the dense form (A/B)
         self.unique_rows = bool(net_cfg.get('sa_unique_rows', True))
+        # the gradient of a level's per-source-point layer-1 rows summed in a FIXED order over the plan's inverse table (no fp32
+        # atomics: every bit of a backward is reproducible run to run); `False` keeps the atomic scatter (A/B)
+        self.sa_deterministic = bool(net_cfg.get('sa_deterministic', True))
+        object.__setattr__(self, "_sa_dz1", [None] * len(self.npoints))
         object.__setattr__(self, "_sa_grads", None)
 
     def set_grad_views(self, views):
@@ -553,7 +557,7 @@ class PointNet2(_HipNet):
                 key = key + (dims,)                        # tile sizes follow the level's widths: actor and critic share a plan only when theirs agree
             plan = cache.get(key) if cache is not None else None
             if plan is None:
-                plan = ops.sa_plan(idx_g, xyz, centers, dims, self._workspace(xyz.device))
+                plan = ops.sa_plan(idx_g, xyz, centers, dims, self._workspace(xyz.device), inverse=self._plan_inverse(l))
                 if cache is not None:                      # a sequential mini-batch of a cached rollout: both networks and
                     cache[key] = plan.trim()               # every epoch reuse it (one host read of the row / tile counts)
                     plan.ready = torch.cuda.Event()
@@ -567,14 +571,28 @@ class PointNet2(_HipNet):
                              packed, dims, pooled, h2)
         return (idx_g, arg, "fused", xyz, feat, centers, Y, packed, dims, pooled, h2, plan, w1f)
 
+    def _plan_inverse(self, l):
+        """Does level l's plan carry the source point -> packed rows table (its layer-1 rows have a gradient to sum)?"""
+        return bool(self.sa_deterministic and self.in_feats[l] > 0)
+
     def _sa_backward_fused(self, l, rec, dpooled, ws, need_dfeat):
         idx_g, arg, _, xyz, feat, centers, Y, packed, dims, pooled, h2, plan, w1f = rec
         B, Pl = xyz.shape[0], xyz.shape[1]
         lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
         (dW1, db1), (dW2, db2), (dW3, db3) = self._chains[l].grads
         cf = 0 if feat is None else feat.shape[2]
-        dY = torch.zeros(B * Pl, dims[0], device=xyz.device) if cf > 0 else None
-        if plan is not None:
+        det = cf > 0 and plan is not None and plan.inv_start is not None
+        dY = None if cf == 0 else torch.empty(B * Pl, dims[0], device=xyz.device) if det else torch.zeros(B * Pl, dims[0], device=xyz.device)
+        if det:
+            n = plan.rowmap.shape[0] * dims[0]             # (R, C1) once the plan is trimmed, its capacity before
+            buf = self._sa_dz1[l]
+            if buf is None or buf.numel() < n or buf.device != xyz.device:
+                buf = self._sa_dz1[l] = torch.empty(n, device=xyz.device)
+            dz1 = buf[:n].view(-1, dims[0])
+            ops.sa_bwd_packed(plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data,
+                              packed, dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, None, ws, h2, dz1=dz1)
+            ops.sa_dy_segsum(plan, dz1, dY)
+        elif plan is not None:
             ops.sa_bwd_packed(plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data,
                               packed, dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws, h2)
         else:
@@ -637,7 +655,7 @@ class PointNet2(_HipNet):
                     if key not in tabs.plans and key not in {k for k, _ in built}:
                         if xyz is None:
                             xyz = obs[lo:lo + n, :P * C].reshape(n, P, C)[..., :3].contiguous() if l == 0 else tabs[l - 1][0][lo:lo + n]
-                        built.append((key, ops.sa_plan(idx_g, xyz, centers, dims, ws)))
+                        built.append((key, ops.sa_plan(idx_g, xyz, centers, dims, ws, inverse=self._plan_inverse(l))))
                 xyz = centers
         if not built:
             return

@@ -47,7 +47,9 @@ struct SaArgs {
     const float* W3;         // (C3, C2) plain
     const float* dpooled;    // (G, lddp)
     long lddp;
-    float* dY;               // (B*P, C1) zero-filled by the caller, or null
+    float* dY;               // (B*P, C1) zero-filled by the caller, or null (fp32 atomics: run-dependent last bits; A/B only)
+    float* dz1;              // packed kernels: (R, C1) layer-1 pre-activation gradient PER PACKED ROW, plain stores -- summed per source
+                             // point in a fixed order by pm_sa_dy_segsum_f32 / pm_sa_dy_consume_f32 (the deterministic path)
     float* parts;            // per-work-group partial sums
     // layer-2 activations (G*32, C2): written by the training forward, read back by the backward instead of a
     // recompute (C2*4 B per row against 2*C1*C2 FLOP: 32-64 FLOP/B, machine balance ~20); null = recompute
@@ -885,6 +887,112 @@ extern "C" int pm_sa_plan_i32(const int32_t* idx, const float* xyz, const float*
     return PM_OK;
 }
 
+// ---- inverse of the plan: source point -> its packed rows (CSR, ascending) --------------------------------------
+// The layer-1 gradient of a level with input features leaves the backward PER PACKED ROW (dz1, plain stores); a source point
+// sits in several groups, so dY[point] = sum of its rows.  With the rows of every point listed in ascending order the sum has
+// ONE order whatever the launch does: no floating-point atomics anywhere (they were the build's only run-dependent bits).
+// One work-group per cloud (its rows are contiguous: [grow[b*S], grow[(b+1)*S])): integer counts by LDS atomics (order-free),
+// prefix, fill through per-point cursors (slot order run-dependent), then every point's short list is sorted.
+__global__ __launch_bounds__(256) void sa_plan_inverse_kernel(const int2* __restrict__ rowmap, const int32_t* __restrict__ grow, int B,
+                                                               int P, int S, int32_t* __restrict__ inv_start,
+                                                               int32_t* __restrict__ inv_rows) {
+    extern __shared__ int sh[];                          // cnt[P + 1] | cur[P] | part[256]
+    int* cnt = sh;
+    int* cur = sh + P + 1;
+    int* part = cur + P;
+    const long b = blockIdx.x;
+    const int rb = grow[b * S], re = grow[(b + 1) * S];
+    const int base = (int)(b * P);
+    for (int p = threadIdx.x; p <= P; p += 256) cnt[p] = 0;
+    __syncthreads();
+    for (int r = rb + threadIdx.x; r < re; r += 256) atomicAdd(&cnt[rowmap[r].x - base], 1);
+    __syncthreads();
+    // exclusive prefix over the P counts: a contiguous chunk per thread, then the 256 chunk sums
+    const int per = (P + 255) / 256, lo = threadIdx.x * per, hi = lo + per < P ? lo + per : P;
+    int sum = 0;
+    for (int p = lo; p < hi; ++p) sum += cnt[p];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int p = lo; p < hi; ++p) {
+        const int c = cnt[p];
+        cur[p] = run;
+        inv_start[base + p] = rb + run;
+        run += c;
+    }
+    if (b == B - 1 && threadIdx.x == 0) inv_start[(long)B * P] = re;
+    __syncthreads();
+    for (int r = rb + threadIdx.x; r < re; r += 256) {
+        const int p = rowmap[r].x - base;
+        inv_rows[rb + atomicAdd(&cur[p], 1)] = r;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += 256) {          // cur[p] is now the END of p's list
+        const int e = rb + cur[p], s = e - cnt[p];
+        for (int i = s + 1; i < e; ++i) {
+            const int v = inv_rows[i];
+            int j = i - 1;
+            while (j >= s && inv_rows[j] > v) {
+                inv_rows[j + 1] = inv_rows[j];
+                --j;
+            }
+            inv_rows[j + 1] = v;
+        }
+    }
+}
+
+extern "C" int pm_sa_plan_inverse_i32(const int32_t* rowmap, const int32_t* grow, int B, int P, int S, int32_t* inv_start,
+                                      int32_t* inv_rows, void* stream) {
+    PM_REQUIRE(rowmap && grow && inv_start && inv_rows && B > 0 && P > 0 && S > 0);
+    PM_REQUIRE(P <= 7000);                               // cnt + cur + part in 64 KB of LDS
+    PM_REQUIRE((long)B * P < (1L << 31));
+    if (((uintptr_t)rowmap) & 7) return PM_EALIGN;
+    const size_t lds = ((size_t)2 * P + 1 + 256) * sizeof(int);
+    hipLaunchKernelGGL(sa_plan_inverse_kernel, dim3(B), dim3(256), lds, pm_stream(stream), (const int2*)rowmap, grow, B, P, S, inv_start,
+                       inv_rows);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+// dY[point, :] = sum over the point's packed rows (ascending) of dz1[row, :]; points in no group get zeros (no zero-fill pass).
+// One thread per (point, 16-byte piece): the C1/4 threads of a point read whole 4*C1-byte rows.
+__global__ __launch_bounds__(256) void sa_dy_segsum_kernel(const float4* __restrict__ dz1, const int32_t* __restrict__ inv_start,
+                                                            const int32_t* __restrict__ inv_rows, long npoints, int c4n,
+                                                            float* __restrict__ dY, long lddy) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long p = i / c4n;
+    const int c4 = (int)(i % c4n);
+    if (p >= npoints) return;
+    const int s = inv_start[p], e = inv_start[p + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = s; j < e; ++j) {
+        const float4 v = dz1[(long)inv_rows[j] * c4n + c4];
+        acc.x += v.x;
+        acc.y += v.y;
+        acc.z += v.z;
+        acc.w += v.w;
+    }
+    *(float4*)(dY + p * lddy + 4 * c4) = acc;
+}
+
+extern "C" int pm_sa_dy_segsum_f32(const float* dz1, const int32_t* inv_start, const int32_t* inv_rows, long npoints, int C1, float* dY,
+                                   long lddy, void* stream) {
+    PM_REQUIRE(dz1 && inv_start && inv_rows && dY && npoints > 0 && C1 > 0 && C1 % 4 == 0 && lddy >= C1 && lddy % 4 == 0);
+    if ((((uintptr_t)dz1) & 15) || (((uintptr_t)dY) & 15)) return PM_EALIGN;
+    const long n = npoints * (C1 / 4);
+    hipLaunchKernelGGL(sa_dy_segsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pm_stream(stream), (const float4*)dz1, inv_start,
+                       inv_rows, npoints, C1 / 4, dY, lddy);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
 // ---- shared staging of a packed tile -------------------------------------------------------------------------
 // Xz / Src as sa_stage, from the plan's per-row tables (two coalesced loads per row); Lgr[t] = local group << 8 | local row
 // (rows past the tile's end: row 255, which no arg-max equals); Ls[j] = first tile-local row of group j (j <= groups).  Rows
@@ -1361,7 +1469,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_bwd_pk_kernel(SaArgs a, SaPk 
                 accW1[1] = fmaf(z, x.y, accW1[1]);
                 accW1[2] = fmaf(z, x.z, accW1[2]);
                 accW1[3] += z;
-                if (a.dY) unsafeAtomicAdd(a.dY + (long)Src[p] * C1 + c, z);
+                if (a.dz1) a.dz1[(long)(td.x + p) * C1 + c] = z;
+                else if (a.dY) unsafeAtomicAdd(a.dY + (long)Src[p] * C1 + c, z);
             }
         }
         __syncthreads();
@@ -1424,8 +1533,8 @@ extern "C" int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const i
                                     const float* W1, long ldw1, const float* b1, const float* b2, const float* W3,
                                     const float* packed, int C1, int C2, int C3, const float* pooled, long ldp,
                                     const int32_t* arg, const float* dpooled, long lddp, float* dW1, long lddw1, float* db1,
-                                    float* dW2, float* db2, float* dW3, float* db3, float* dY, const float* h2_saved,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
+                                    float* dW2, float* db2, float* dW3, float* db3, float* dY, float* dz1_rows,
+                                    const float* h2_saved, void* workspace, size_t workspace_bytes, void* stream) {
     PM_REQUIRE(grow && rowmap && relxyz && tiles && totals && W1 && b1 && b2 && W3 && packed && pooled && arg && dpooled);
     PM_REQUIRE(dW1 && db1 && dW2 && db2 && dW3 && db3 && workspace);
     PM_REQUIRE(B > 0 && P > 0 && S > 0 && ldw1 >= 3 && lddw1 >= 3 && ldp >= C3 && lddp >= C3);
@@ -1435,7 +1544,7 @@ extern "C" int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const i
     SaArgs a = {};
     a.Y = Y; a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.b2 = b2;
     a.packed = packed; a.pooled = const_cast<float*>(pooled); a.ldp = ldp; a.arg = const_cast<int32_t*>(arg);
-    a.G = (long)B * S; a.S = S; a.P = P; a.W3 = W3; a.dpooled = dpooled; a.lddp = lddp; a.dY = dY;
+    a.G = (long)B * S; a.S = S; a.P = P; a.W3 = W3; a.dpooled = dpooled; a.lddp = lddp; a.dY = dY; a.dz1 = dz1_rows;
     a.parts = (float*)workspace;
     a.h2 = const_cast<float*>(h2_saved);
     SaPk k = {grow, (const int2*)rowmap, (const float4*)relxyz, (const int4*)tiles, totals};

@@ -753,7 +753,7 @@ def sa_groupall_bwd(dfeat, feat, arg, w, h, B, R, dh, dw, db, ws):
 # ---- duplicate-free ("packed") form: the level over each group's DISTINCT rows (ball query pads with copies of the first hit)
 class SaPlan:
     """Packed-row tables of one neighbourhood table (pm_sa_plan_i32): nothing here is read by the host."""
-    __slots__ = ("grow", "rowmap", "relxyz", "tiles", "totals", "B", "P", "S", "ns", "dims", "ready")
+    __slots__ = ("grow", "rowmap", "relxyz", "tiles", "totals", "B", "P", "S", "ns", "dims", "ready", "inv_start", "inv_rows")
 
     def counts(self):
         """(packed rows, tiles) -- a host read; diagnostics / buffer sizing only."""
@@ -767,6 +767,8 @@ class SaPlan:
         self.rowmap = self.rowmap[:max(R, 1)].clone()
         self.relxyz = self.relxyz[:max(R, 1)].clone()
         self.tiles = self.tiles[:max(T, 1)].clone()
+        if self.inv_rows is not None:
+            self.inv_rows = self.inv_rows[:max(R, 1)].clone()
         return self
 
 
@@ -776,8 +778,10 @@ def sa_packed_tile(dims):
     return r.value, g.value
 
 
-def sa_plan(idx, xyz, centers, dims, ws):
-    """idx (B, S, 32) int32 ball-query table of centres (B, S, 3) over xyz (B, P, 3) -> SaPlan for the fused level `dims`."""
+def sa_plan(idx, xyz, centers, dims, ws, inverse=False):
+    """idx (B, S, 32) int32 ball-query table of centres (B, S, 3) over xyz (B, P, 3) -> SaPlan for the fused level `dims`.
+    inverse: also list every source point's packed rows in ascending order (pm_sa_plan_inverse_i32) -- what the deterministic
+    gradient of a level with input features sums over (sa_dy_segsum)."""
     _req(idx, xyz, centers)
     _f32c(xyz, "xyz")
     _f32c(centers, "centers")
@@ -803,7 +807,27 @@ def sa_plan(idx, xyz, centers, dims, ws):
     with TIMER.bracket("sa_plan"):
         check(lib.pm_sa_plan_i32(_ptr(idx), _ptr(xyz), _ptr(centers), B, P, S, ns, tr, tg, _ptr(pl.grow), _ptr(pl.rowmap),
                                  _ptr(pl.relxyz), _ptr(pl.tiles), _ptr(pl.totals), base + al, w.numel() - al, _stream()), "pm_sa_plan_i32")
+        pl.inv_start = pl.inv_rows = None
+        if inverse:
+            pl.inv_start = torch.empty(B * P + 1, dtype=torch.int32, device=dev)
+            pl.inv_rows = torch.empty(G * ns, dtype=torch.int32, device=dev)
+            check(lib.pm_sa_plan_inverse_i32(_ptr(pl.rowmap), _ptr(pl.grow), B, P, S, _ptr(pl.inv_start), _ptr(pl.inv_rows), _stream()),
+                  "pm_sa_plan_inverse_i32")
     return pl
+
+
+def sa_dy_segsum(plan, dz1, dY):
+    """dY (B*P, C1) = per source point the sum of its packed rows of dz1 (R, C1) in ascending row order (no atomics, no zero-fill)."""
+    _req(dz1, dY)
+    _f32c(dz1, "dz1")
+    if plan.inv_start is None:
+        raise ValueError("sa_dy_segsum: the plan was built without its inverse (sa_plan(..., inverse=True))")
+    if dY.shape[0] != plan.B * plan.P or dz1.shape[1] != dY.shape[1]:
+        raise ValueError("sa_dy_segsum: shapes do not match the plan")
+    with TIMER.bracket("sa_dy_segsum"):
+        check(lib.pm_sa_dy_segsum_f32(_ptr(dz1), _ptr(plan.inv_start), _ptr(plan.inv_rows), plan.B * plan.P, dz1.shape[1], _ptr(dY),
+                                      _rows(dY, "dY"), _stream()), "pm_sa_dy_segsum_f32")
+    return dY
 
 
 def sa_fwd_packed(plan, Y, w1, b1, b2, b3, packed, dims, pooled, h2_save=None):
@@ -821,8 +845,15 @@ def sa_fwd_packed(plan, Y, w1, b1, b2, b3, packed, dims, pooled, h2_save=None):
     return arg
 
 
-def sa_bwd_packed(plan, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpooled, dw1, db1, dw2, db2, dw3, db3, dY, ws, h2_saved=None):
-    _req(Y, w1, w3, packed, pooled, arg, dpooled, dw1, dw2, dw3, dY)
+def sa_bwd_packed(plan, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpooled, dw1, db1, dw2, db2, dw3, db3, dY, ws, h2_saved=None,
+                  dz1=None):
+    """dz1 (R, C1): the layer-1 gradient per packed row (plain stores; sum it per source point with sa_dy_segsum) -- the
+    deterministic path; dY (B*P, C1) zero-filled: the same sums by fp32 atomics (run-dependent last bits; kept for A/B)."""
+    _req(Y, w1, w3, packed, pooled, arg, dpooled, dw1, dw2, dw3, dY, dz1)
+    if dz1 is not None:
+        _f32c(dz1, "dz1")
+        if dz1.shape[1] != dims[0]:
+            raise ValueError("sa_bwd_packed: dz1 must be (R, C1)")
     B, P, S = plan.B, plan.P, plan.S
     C1, C2, C3 = dims
     if tuple(dims) != plan.dims or pooled.shape[0] != B * S:
@@ -834,7 +865,7 @@ def sa_bwd_packed(plan, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpooled, d
                                        _ptr(plan.tiles), _ptr(plan.totals), _ptr(w1), _rows(w1, "w1"), _ptr(b1), _ptr(b2),
                                        _ptr(w3), _ptr(packed), C1, C2, C3, _ptr(pooled), _rows(pooled, "pooled"), _ptr(arg),
                                        _ptr(dpooled), _rows(dpooled, "dpooled"), _ptr(dw1), _rows(dw1, "dw1"), _ptr(db1),
-                                       _ptr(dw2), _ptr(db2), _ptr(dw3), _ptr(db3), _ptr(dY), _ptr(h2_saved), _ptr(w),
+                                       _ptr(dw2), _ptr(db2), _ptr(dw3), _ptr(db3), _ptr(dY), _ptr(dz1), _ptr(h2_saved), _ptr(w),
                                        w.numel(), _stream()), "pm_sa_bwd_packed_f32")
 
 

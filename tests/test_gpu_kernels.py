@@ -881,6 +881,37 @@ def test_sa_packed_rows_equal_the_dense_level(dims, P, S, cf, radius):
             assert bool(torch.isfinite(b_).all()) and float((a_ - b_).abs().max()) < 2e-5 * scale, (mode, k_)
         if cf:
             assert float((yd - yp).abs().max()) < 1e-5 * float(yd.abs().max())
+    if not cf:
+        return
+    # ---- the deterministic gradient of the per-source-point layer-1 rows: no fp32 atomics (pm_sa_plan_inverse_i32 + dz1 rows +
+    # pm_sa_dy_segsum_f32).  The inverse table against numpy (every point's packed rows, ascending), the sums against a float64
+    # scatter-add of the same dz1 rows, and five repetitions of the whole backward bit-identical.
+    plan_i = o.sa_plan(idx, xyz, centers, dims, ws, inverse=True)
+    start, rows = plan_i.inv_start.cpu().numpy(), plan_i.inv_rows.cpu().numpy()[:R_]
+    order = np.argsort(want_sp, kind="stable")                 # stable: ascending packed row inside a point
+    assert np.array_equal(start, np.concatenate([[0], np.cumsum(np.bincount(want_sp, minlength=B * P))]))
+    assert np.array_equal(rows, order)
+    runs = []
+    for rep in range(5):
+        pooled = torch.empty(B * S, C3, device=DEV)
+        h2 = torch.empty(B * S * 32, C2, device=DEV)
+        grads = [torch.full_like(t_, float("nan")) for t_ in (W1, b1, W2, b2, W3, b3)]
+        dz1 = torch.full((R_ + 3, C1), float("nan"), device=DEV)[:R_]
+        dYd = torch.full((B * P, C1), float("nan"), device=DEV)
+        arg = o.sa_fwd_packed(plan_i, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
+        o.sa_bwd_packed(plan_i, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *grads, None, ws, h2, dz1=dz1)
+        o.sa_dy_segsum(plan_i, dz1, dYd)
+        runs.append((dYd, dz1, grads))
+    dYd, dz1, grads = runs[0]
+    assert bool(torch.isfinite(dYd).all()) and bool(torch.isfinite(dz1).all())
+    want = torch.zeros(B * P, C1, dtype=torch.float64, device=DEV).index_add_(0, torch.from_numpy(want_sp).to(DEV), dz1.double())
+    assert float((dYd.double() - want).abs().max()) < 1e-6 * float(want.abs().max())
+    assert float((dYd - out["packed"][4]).abs().max()) < 1e-5 * float(dYd.abs().max())          # the atomic path's sums
+    for k_, (x0, x1) in enumerate(zip(out["packed"][3], grads)):                                   # the other gradients: untouched
+        assert torch.equal(x0[:, :3] if k_ == 0 else x0, x1[:, :3] if k_ == 0 else x1), k_
+    for dYr, dzr, gr in runs[1:]:
+        assert torch.equal(dYr, dYd) and torch.equal(dzr, dz1) and all(
+            torch.equal(a_[:, :3] if k_ == 0 else a_, b_[:, :3] if k_ == 0 else b_) for k_, (a_, b_) in enumerate(zip(gr, grads)))
 
 
 def test_grouped_linear_ops_equal_the_single_problem_ops():

@@ -35,20 +35,28 @@ for name, P, S, radius, dims, cf in LEVELS:
     h2 = torch.empty(B * S * 32, C2, device=DEV) if os.environ.get("SA_SAVE_H2", "1") == "1" else None
 
     PACKED = os.environ.get("SA_PACKED", "1") == "1"       # duplicate-free rows (default) or the dense 32-row groups
-    plan = ops.sa_plan(idx_g, xyz, centers, dims, ws) if PACKED else None
+    DET = os.environ.get("SA_DET", "1") == "1" and cf > 0     # dz1 rows + fixed-order sums (default) or fp32 atomics into dY
+    plan = ops.sa_plan(idx_g, xyz, centers, dims, ws, inverse=DET) if PACKED else None
+    dz1 = torch.empty(plan.counts()[0], C1, device=DEV) if (PACKED and DET) else None
 
     def run(n):
         for _ in range(n):
             if PACKED:
                 pl = ops.sa_plan(idx_g, xyz, centers, dims, ws) if os.environ.get('SA_PLAN_EACH', '0') == '1' else plan
                 arg = ops.sa_fwd_packed(pl, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
-                ops.sa_bwd_packed(pl, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws, h2)
+                if DET:
+                    ops.sa_bwd_packed(pl, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, None, ws, h2, dz1=dz1)
+                    ops.sa_dy_segsum(pl, dz1, dY)
+                else:
+                    if dY is not None:
+                        ops.fill_zero(dY) if hasattr(ops, "fill_zero") else dY.zero_()
+                    ops.sa_bwd_packed(pl, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws, h2)
             else:
                 arg = ops.sa_fwd(xyz, centers, idx_g, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
                 ops.sa_bwd(xyz, centers, idx_g, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws, h2)
     run(2)
     nf, nb = f"sa_fwd_{C1}x{C2}x{C3}", f"sa_bwd_{C1}x{C2}x{C3}"
-    ops.TIMER.enable(nf, nb, "sa_plan")
+    ops.TIMER.enable(nf, nb, "sa_plan", "sa_dy_segsum")
     run(5)
     f = ops.TIMER.mean_ms(nf)[0]
     b = ops.TIMER.mean_ms(nb)[0]
@@ -62,5 +70,7 @@ for name, P, S, radius, dims, cf in LEVELS:
         rows = R_
     ff = 2.0 * rows * (C1 * C2 + C2 * C3) / 1e9                 # MFMA flops fwd
     fb = 2.0 * rows * ((2 if h2 is not None else 3) * C1 * C2 + C2 * C3) / 1e9   # [L2 recompute +] dW2 + dH1 + dH2
-    print(f"level {name}: fwd {f:.3f} ms ({ff / f:.1f} TF)  bwd {b:.3f} ms ({fb / b:.1f} TF executed)")
+    sg = ops.TIMER.mean_ms("sa_dy_segsum") if (PACKED and DET) else None
+    print(f"level {name}: fwd {f:.3f} ms ({ff / f:.1f} TF)  bwd {b:.3f} ms ({fb / b:.1f} TF executed)"
+          + (f"  dY segsum {sg[0]:.3f} ms" if sg else ""))
     xyz = centers.contiguous()
