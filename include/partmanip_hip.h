@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 149 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 150 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -526,6 +526,18 @@ int pm_sa_plan_inverse_i32(const int32_t* rowmap, const int32_t* grow, int B, in
                            void* stream);
 int pm_sa_dy_segsum_f32(const float* dz1, const int32_t* inv_start, const int32_t* inv_rows, long npoints, int C1, float* dY, long lddy,
                         void* stream);
+/* The same sums CONSUMED in place (C1 = CF = 128): dY never reaches HBM.  Per tile of 64 source points the rows are summed into LDS
+ * (same order, bit-identical to pm_sa_dy_segsum_f32), then  dfeat = dY * W1f  (the gradient the level below receives) and
+ * dW1[:, 3 : 3 + CF] = dY^T * feat  run on fp32 MFMA; columns [3 + CF, dw1_cols) of dW1 are zeroed (pad columns never receive
+ * data).  packedW = W1[:, 3 : 3 + CF] in operand order (pm_sa_dy_consume_pack_f32, after every update).  dfeat / dY may be NULL
+ * (dY: an optional copy of the sums).  Replaces zero-fill + scatter + two Linear launches + slab reduction + column copy. */
+int pm_sa_dy_consume_supported(int C1, int CF);
+size_t pm_sa_dy_consume_packed_elems(int C1, int CF);
+size_t pm_sa_dy_consume_workspace_bytes(int C1, int CF);
+int pm_sa_dy_consume_pack_f32(const float* W1, long ldw1, int C1, int CF, float* packed, void* stream);
+int pm_sa_dy_consume_f32(const float* dz1, const int32_t* inv_start, const int32_t* inv_rows, long npoints, int C1, int CF,
+                         const float* feat, long ldf, const float* packedW, float* dfeat, long lddf, float* dW1, long lddw1,
+                         int dw1_cols, float* dY, long lddy, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- PointNet++ group-all level: its LAST layer fused with the max over the cloud (csrc/sa_groupall.hip) ----------------
  * (BASELINE.json cfg 3's backbone; the reference ships no PointNet++ source -- `PointNet2` in algo_utils/network.py.)

@@ -139,6 +139,11 @@ SIGNATURES = {
                                  P, P, P, P, P, P, Z, P]),
     "pm_sa_plan_inverse_i32": (I, [P, P, I, I, I, P, P, P]),
     "pm_sa_dy_segsum_f32": (I, [P, P, P, L, I, P, L, P]),
+    "pm_sa_dy_consume_supported": (I, [I, I]),
+    "pm_sa_dy_consume_packed_elems": (Z, [I, I]),
+    "pm_sa_dy_consume_workspace_bytes": (Z, [I, I]),
+    "pm_sa_dy_consume_pack_f32": (I, [P, L, I, I, P, P]),
+    "pm_sa_dy_consume_f32": (I, [P, P, P, L, I, I, P, L, P, P, L, P, L, I, P, L, P, Z, P]),
     "pm_sa_groupall_supported": (I, [I, I, I]),
     "pm_sa_groupall_packed_elems": (Z, [I, I]),
     "pm_sa_groupall_pack_f32": (I, [P, I, I, P, P]),
@@ -183,7 +188,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 149                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 150                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -517,6 +517,8 @@ class PointNet2(_HipNet):
         # atomics: every bit of a backward is reproducible run to run); `False` keeps the atomic scatter (A/B)
         self.sa_deterministic = bool(net_cfg.get('sa_deterministic', True))
         object.__setattr__(self, "_sa_dz1", [None] * len(self.npoints))
+        self.sa_fused_dy = bool(net_cfg.get('sa_fused_dy', True))             # False: segmented-sum pass + the two Linear launches (A/B)
+        object.__setattr__(self, "_sa_packed_w1f", [None] * len(self.npoints))
         object.__setattr__(self, "_sa_grads", None)
 
     def set_grad_views(self, views):
@@ -582,7 +584,8 @@ class PointNet2(_HipNet):
         (dW1, db1), (dW2, db2), (dW3, db3) = self._chains[l].grads
         cf = 0 if feat is None else feat.shape[2]
         det = cf > 0 and plan is not None and plan.inv_start is not None
-        dY = None if cf == 0 else torch.empty(B * Pl, dims[0], device=xyz.device) if det else torch.zeros(B * Pl, dims[0], device=xyz.device)
+        fused_dy = det and self.sa_fused_dy and ops.sa_dy_consume_supported(dims[0], cf)
+        dY = None if (cf == 0 or fused_dy) else torch.empty(B * Pl, dims[0], device=xyz.device) if det else torch.zeros(B * Pl, dims[0], device=xyz.device)
         if det:
             n = plan.rowmap.shape[0] * dims[0]             # (R, C1) once the plan is trimmed, its capacity before
             buf = self._sa_dz1[l]
@@ -591,6 +594,14 @@ class PointNet2(_HipNet):
             dz1 = buf[:n].view(-1, dims[0])
             ops.sa_bwd_packed(plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data,
                               packed, dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, None, ws, h2, dz1=dz1)
+            if fused_dy:
+                # the sums are consumed where they are formed: dfeat = dY W1f and dW1[:, 3:3+cf] = dY^T feat in ONE launch, dY in LDS only
+                pw = self._sa_packed_w1f[l]
+                if pw is None or pw.device != xyz.device:
+                    pw = self._sa_packed_w1f[l] = torch.empty(int(ops.lib.pm_sa_dy_consume_packed_elems(dims[0], cf)), device=xyz.device)
+                ops.sa_dy_consume_pack(lin1.weight.data, cf, pw)
+                dfeat = torch.empty(B * Pl, cf, device=xyz.device) if need_dfeat else None
+                return ops.sa_dy_consume(plan, dz1, feat.reshape(B * Pl, cf), pw, dfeat, dW1, ws)
             ops.sa_dy_segsum(plan, dz1, dY)
         elif plan is not None:
             ops.sa_bwd_packed(plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data,

@@ -1565,3 +1565,257 @@ extern "C" int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const i
     PM_CHECK_LAUNCH();
     return PM_OK;
 }
+
+// ============================================================================================================
+// The consumer of a level's layer-1 gradient rows (levels with input features: Y = feat * W1f^T per SOURCE point).
+//
+//   dY[p, :]   = sum over p's packed rows (ascending: the plan's inverse table) of dz1[row, :]      -- never written to HBM
+//   dfeat[p,:] = dY[p, :] * W1f                  (the gradient the level below receives as its dpooled)
+//   dW1f      += dY^T * feat                     (W1f = columns 3 .. 3+CF of the level's first weight)
+//
+// ONE kernel instead of zero-fill + atomics (or the segmented-sum pass) + two Linear launches + a slab reduction + a column copy:
+// a work-group owns tiles of TM source points; every wave sums the rows of its TM/NW points into an LDS tile in the fixed order
+// (bit-identical to pm_sa_dy_segsum_f32: a sequential chain starting from the first row), the feature tile lands beside it, the
+// two products run on fp32 MFMA (dfeat: A from LDS, B = W1f streamed from its operand-order copy in L2; dW1f: both operands from
+// LDS, accumulators persistent in registers).  Two work-groups per CU: one's loads run under the other's MFMAs.
+// HBM per point: 1.35 rows of 4*C1 B in + 4*CF B in + 4*CF B out (SA2 of the bench: 0.9 GB per launch for 34.4 GFLOP).
+#define SA_DYC_MAXGRID 1024
+#ifndef SA_DYC_TM
+#define SA_DYC_TM 64          // source points per tile
+#endif
+#ifndef SA_DYC_NW
+#define SA_DYC_NW 8           // waves per work-group
+#endif
+#ifndef SA_DYC_WPC
+#define SA_DYC_WPC 2          // work-groups per CU (persistent grid = CUs x this)
+#endif
+#ifndef SA_DYC_BATCH
+#define SA_DYC_BATCH 4        // dz1 rows a wave has in flight
+#endif
+#ifndef SA_DYC_ABLATE
+#define SA_DYC_ABLATE 0       // timing probes (wrong results): 1 no row loads, 2 no dfeat MFMA, 4 no dW1f MFMA, 8 no dfeat stores, 16 no feature tile
+#endif
+template <int C1, int CF, int TM, int NW>
+__global__ __launch_bounds__(NW * 64, SA_DYC_WPC) void sa_dyc_kernel(const float* __restrict__ dz1, const int32_t* __restrict__ inv_start,
+                                                             const int32_t* __restrict__ inv_rows, long npoints,
+                                                             const float* __restrict__ feat, long ldf, const float* __restrict__ packedW,
+                                                             float* __restrict__ dfeat, long lddf, float* __restrict__ dY, long lddy,
+                                                             float* __restrict__ parts) {
+    constexpr int NT = NW * 64, LDA = C1 + 4, LDF = CF + 4, PPW = TM / NW, VPL = C1 / 64;
+    static_assert(C1 % 64 == 0 && CF % 32 == 0 && TM % NW == 0 && PPW < 63 && (TM * CF / 4) % NT == 0, "consumer tile mapping");
+    __shared__ __attribute__((aligned(16))) float smem[TM * (LDA + LDF)];
+    float* A = smem;                         // dY tile [TM][C1]
+    float* F = smem + TM * LDA;              // feature tile [TM][CF]
+    using MD = WaveMap<TM, CF, NW>;          // dfeat output mapping
+    constexpr int NG = C1 / 8;
+    constexpr int WBLK = (C1 / 32) * (CF / 32), NBK = WBLK / NW;       // dW1f blocks per wave: same c1 block, NBK feature blocks
+    static_assert(NBK * NW == WBLK && (CF / 32) % NBK == 0, "dW1f wave mapping");
+    constexpr int FPT = TM * CF / 4 / NT;
+    f32x16 accW[NBK];
+#pragma unroll
+    for (int j = 0; j < NBK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[j][r] = 0.f;
+    const int tid0 = threadIdx.x;
+    const long ntiles = (npoints + TM - 1) / TM;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));                    // see sa_fwd_kernel: recompute, don't hoist
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int li = lane & 31, lh = lane >> 5;
+        const long p0 = tile * TM;
+        // ---- feature tile: requested first, stored behind the row sums (their index chain needs none of it) ----
+        float4 fq[FPT];
+#pragma unroll
+        for (int i = 0; i < FPT; ++i) {
+            const int q = tid + i * NT, row = q / (CF / 4), c4 = q % (CF / 4);
+            long p = p0 + row;
+            if (p >= npoints) p = npoints - 1;           // ragged last tile: its dY rows are zero, whatever is multiplied
+            fq[i] = (SA_DYC_ABLATE & 16) ? make_float4(1.f, 1.f, 1.f, 1.f) : *(const float4*)(feat + p * ldf + 4 * c4);
+        }
+        // ---- dY tile: this wave's PPW points, rows in ascending order -----------------------------------
+        {
+            long ps = p0 + (long)wave * PPW + (lane <= PPW ? lane : PPW);
+            if (ps > npoints) ps = npoints;
+            const int st = inv_start[ps];
+            const int s0 = __builtin_amdgcn_readlane(st, 0), e1 = __builtin_amdgcn_readlane(st, PPW);
+            int pt = 0, bound = __builtin_amdgcn_readlane(st, 1);
+            float acc[VPL];
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) acc[v] = 0.f;
+            float* Arow = A + (wave * PPW) * LDA + lane * VPL;
+            for (int j0 = s0; j0 < ((SA_DYC_ABLATE & 1) ? s0 : e1); j0 += 64) {
+                const int nrow = e1 - j0 < 64 ? e1 - j0 : 64;
+                const int myrow = inv_rows[j0 + (lane < nrow ? lane : 0)];
+                for (int j = 0; j < nrow; j += SA_DYC_BATCH) {
+                    float v4[SA_DYC_BATCH][VPL];
+#pragma unroll
+                    for (int k = 0; k < SA_DYC_BATCH; ++k) {
+                        const int jj = j + k < nrow ? j + k : nrow - 1;
+                        const int r = __builtin_amdgcn_readlane(myrow, jj);
+                        const float* src = dz1 + (long)r * C1 + lane * VPL;
+#pragma unroll
+                        for (int v = 0; v < VPL; ++v) v4[k][v] = src[v];
+                    }
+#pragma unroll
+                    for (int k = 0; k < SA_DYC_BATCH; ++k) {
+                        if (j + k < nrow) {
+                            while (j0 + j + k >= bound) {            // (uniform) the previous point is complete
+#pragma unroll
+                                for (int v = 0; v < VPL; ++v) {
+                                    Arow[pt * LDA + v] = acc[v];
+                                    acc[v] = 0.f;
+                                }
+                                ++pt;
+                                bound = __builtin_amdgcn_readlane(st, pt + 1);
+                            }
+#pragma unroll
+                            for (int v = 0; v < VPL; ++v) acc[v] += v4[k][v];
+                        }
+                    }
+                }
+            }
+            for (; pt < PPW; ++pt) {                                 // the last point with rows, then the points without any
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                    Arow[pt * LDA + v] = acc[v];
+                    acc[v] = 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FPT; ++i) {
+            const int q = tid + i * NT, row = q / (CF / 4), c4 = q % (CF / 4);
+            *(float4*)(F + row * LDF + 4 * c4) = fq[i];
+        }
+        __syncthreads();
+        if (dY) {                                                    // optional copy of the sums (tests, A/B)
+            for (int q = tid; q < TM * C1 / 4; q += NT) {
+                const int row = q / (C1 / 4), c4 = q % (C1 / 4);
+                if (p0 + row < npoints) *(float4*)(dY + (p0 + row) * lddy + 4 * c4) = *(const float4*)(A + row * LDA + 4 * c4);
+            }
+        }
+        // ---- dfeat = dY * W1f --------------------------------------------------------------------------
+        if (dfeat) {
+            const int wn = wave % MD::NBW, wm = wave / MD::NBW;
+            f32x16 acc[MD::MB][MD::NB];
+            zero_acc<MD::MB, MD::NB>(acc);
+            if (!(SA_DYC_ABLATE & 2))
+                mfma_stream<MD::MB, MD::NB, NG>(A + (wm * MD::MB * 32 + li) * LDA + lh * (C1 / 2), LDA,
+                                                (const float4*)packedW + (size_t)(wn * MD::NB) * NG * 64 + lane, acc);
+#pragma unroll
+            for (int nb = 0; nb < MD::NB; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < MD::MB; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (wm * MD::MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int col = (wn * MD::NB + nb) * 32 + li;
+                        if (p0 + row < ((SA_DYC_ABLATE & 8) ? 0 : npoints)) dfeat[(p0 + row) * lddf + col] = acc[mb][nb][r];
+                    }
+        }
+        // ---- dW1f += dY^T * feat  (K = the tile's TM points; lanes < 32: points [0, TM/2), lanes >= 32: the rest) ----
+        {
+            const int w_m = wave % (C1 / 32), w_n0 = (wave / (C1 / 32)) * NBK;
+            const float* Ap = A + (lh * (TM / 2)) * LDA + w_m * 32 + li;          // A[m = c1][k = point]
+            const float* Bp = F + (lh * (TM / 2)) * LDF + w_n0 * 32 + li;         // B[k = point][n = feature]
+            float ap, bp[NBK], aq, bq[NBK];
+#define SA_DYC_LOAD(a_, b_, s_)  \
+    a_ = Ap[(s_) * LDA];         \
+    _Pragma("unroll") for (int j = 0; j < NBK; ++j) b_[j] = Bp[(s_) * LDF + j * 32];
+#define SA_DYC_MMA(a_, b_) _Pragma("unroll") for (int j = 0; j < NBK; ++j) accW[j] = MFMA(a_, b_[j], accW[j]);
+            SA_DYC_LOAD(ap, bp, 0)
+#pragma unroll 1
+            for (int s = 0; s < ((SA_DYC_ABLATE & 4) ? 0 : TM / 2); s += 2) {
+                SA_DYC_LOAD(aq, bq, s + 1)
+                SA_DYC_MMA(ap, bp)
+                SA_DYC_LOAD(ap, bp, (s + 2 < TM / 2 ? s + 2 : 0))        // last trip: a valid row, discarded
+                SA_DYC_MMA(aq, bq)
+            }
+#undef SA_DYC_LOAD
+#undef SA_DYC_MMA
+        }
+        __syncthreads();                                             // A, F are free for the next tile
+    }
+    // ---- this work-group's partial dW1f ------------------------------------------------------------------
+    float* part = parts + (size_t)blockIdx.x * (C1 * CF);
+    const int lane0 = tid0 & 63, wave0 = tid0 >> 6, lh0 = lane0 >> 5, li0 = lane0 & 31;
+    const int w_m = wave0 % (C1 / 32), w_n0 = (wave0 / (C1 / 32)) * NBK;
+#pragma unroll
+    for (int j = 0; j < NBK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c1 = w_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh0;
+            part[c1 * CF + (w_n0 + j) * 32 + li0] = accW[j][r];
+        }
+}
+
+// dW1[c1][3 + cf] = sum of the partials in work-group order (8 waves per 64 outputs, as sa_bwd_reduce_kernel); the pad columns
+// [3 + CF, lddw1) of every row are zeroed (they never receive data)
+__global__ __launch_bounds__(64 * SA_RED_G) void sa_dyc_reduce_kernel(const float* __restrict__ parts, int nparts, int C1, int CF,
+                                                                      float* __restrict__ dW1, long lddw1, int pad_end) {
+    __shared__ float red[SA_RED_G][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane, n = C1 * CF;
+    float s = 0.f;
+    if (i < n) {
+#pragma unroll 4
+        for (int w = wv; w < nparts; w += SA_RED_G) s += parts[(size_t)w * n + i];
+    }
+    red[wv][lane] = s;
+    __syncthreads();
+    if (wv != 0 || i >= n) return;
+    s = red[0][lane];
+#pragma unroll
+    for (int q = 1; q < SA_RED_G; ++q) s += red[q][lane];
+    const int c1 = i / CF, cf = i % CF;
+    dW1[c1 * lddw1 + 3 + cf] = s;
+    if (cf == 0)
+        for (int c = 3 + CF; c < pad_end; ++c) dW1[c1 * lddw1 + c] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void sa_dyc_pack_kernel(const float* __restrict__ W1, long ldw1, int C1, int CF, float* __restrict__ packed) {
+    const long n = (long)C1 * CF, total = n + 1024;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    if (i >= n) {
+        packed[i] = 0.f;
+        return;
+    }
+    const int e = i & 3, lane = (i >> 2) & 63, li = lane & 31, lh = lane >> 5;
+    const int ng = C1 / 8, g = (int)((i >> 8) % ng), nb = (int)((i >> 8) / ng);      // B[k = c1][n = feature] = W1[c1][3 + feature]
+    packed[i] = W1[(long)(lh * (C1 / 2) + g * 4 + e) * ldw1 + 3 + nb * 32 + li];
+}
+
+extern "C" int pm_sa_dy_consume_supported(int C1, int CF) { return C1 == 128 && CF == 128; }
+extern "C" size_t pm_sa_dy_consume_packed_elems(int C1, int CF) { return (size_t)C1 * CF + 1024; }
+extern "C" size_t pm_sa_dy_consume_workspace_bytes(int C1, int CF) { return (size_t)C1 * CF * SA_DYC_MAXGRID * sizeof(float); }
+
+extern "C" int pm_sa_dy_consume_pack_f32(const float* W1, long ldw1, int C1, int CF, float* packed, void* stream) {
+    PM_REQUIRE(W1 && packed && C1 > 0 && CF > 0 && C1 % 32 == 0 && CF % 32 == 0 && ldw1 >= 3 + CF);
+    const long total = (long)pm_sa_dy_consume_packed_elems(C1, CF);
+    hipLaunchKernelGGL(sa_dyc_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, pm_stream(stream), W1, ldw1, C1, CF, packed);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
+extern "C" int pm_sa_dy_consume_f32(const float* dz1, const int32_t* inv_start, const int32_t* inv_rows, long npoints, int C1, int CF,
+                                    const float* feat, long ldf, const float* packedW, float* dfeat, long lddf, float* dW1, long lddw1,
+                                    int dw1_cols, float* dY, long lddy, void* workspace, size_t workspace_bytes, void* stream) {
+    PM_REQUIRE(dz1 && inv_start && inv_rows && feat && packedW && dW1 && workspace && npoints > 0);
+    PM_REQUIRE(ldf >= CF && ldf % 4 == 0 && dw1_cols >= 3 + CF && lddw1 >= dw1_cols && (!dfeat || lddf >= CF) &&
+               (!dY || (lddy >= C1 && lddy % 4 == 0)));
+    if (!pm_sa_dy_consume_supported(C1, CF)) return PM_EUNSUPPORTED;
+    if ((((uintptr_t)dz1) & 15) || (((uintptr_t)feat) & 15) || (((uintptr_t)packedW) & 15) || (((uintptr_t)dY) & 15)) return PM_EALIGN;
+    if (workspace_bytes < pm_sa_dy_consume_workspace_bytes(C1, CF)) return PM_EWORKSPACE;
+    const long ntiles = (npoints + SA_DYC_TM - 1) / SA_DYC_TM;
+    long grid = (long)sa_cu_count() * SA_DYC_WPC;
+    if (grid > SA_DYC_MAXGRID) grid = SA_DYC_MAXGRID;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL((sa_dyc_kernel<128, 128, SA_DYC_TM, SA_DYC_NW>), dim3((unsigned)grid), dim3(SA_DYC_NW * 64), 0, pm_stream(stream), dz1, inv_start, inv_rows,
+                       npoints, feat, ldf, packedW, dfeat, lddf, dY, lddy, (float*)workspace);
+    hipLaunchKernelGGL(sa_dyc_reduce_kernel, dim3((unsigned)((C1 * CF + 63) / 64)), dim3(64 * SA_RED_G), 0, pm_stream(stream),
+                       (const float*)workspace, (int)grid, C1, CF, dW1, lddw1, dw1_cols);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}

@@ -845,6 +845,35 @@ def sa_fwd_packed(plan, Y, w1, b1, b2, b3, packed, dims, pooled, h2_save=None):
     return arg
 
 
+def sa_dy_consume_supported(C1, cf):
+    return bool(lib.pm_sa_dy_consume_supported(int(C1), int(cf)))
+
+
+def sa_dy_consume_pack(w1, cf, packed):
+    """w1 (C1, >= 3 + cf): its feature columns in MFMA operand order (after every update)."""
+    _req(w1, packed)
+    check(lib.pm_sa_dy_consume_pack_f32(_ptr(w1), _rows(w1, "w1"), w1.shape[0], cf, _ptr(packed), _stream()), "pm_sa_dy_consume_pack_f32")
+    return packed
+
+
+def sa_dy_consume(plan, dz1, feat, packed_w1f, dfeat, dw1, ws, dY=None):
+    """dz1 (R, C1) per packed row -> dfeat (B*P, cf) = dY W1f, dw1[:, 3:3+cf] = dY^T feat (pad columns zeroed), with dY = the fixed-order
+    per-source-point sums of dz1 formed in LDS (never written, unless the optional dY copy is asked for)."""
+    _req(dz1, feat, packed_w1f, dfeat, dw1, dY)
+    _f32c(dz1, "dz1")
+    C1, cf = dz1.shape[1], feat.shape[1]
+    npts = plan.B * plan.P
+    if plan.inv_start is None or feat.shape[0] != npts or (dfeat is not None and tuple(dfeat.shape) != (npts, cf)) or dw1.shape[0] != C1:
+        raise ValueError("sa_dy_consume: shapes do not match the plan (built with inverse=True?)")
+    w = ws.get(lib.pm_sa_dy_consume_workspace_bytes(C1, cf))
+    with TIMER.bracket("sa_dy_consume"):
+        check(lib.pm_sa_dy_consume_f32(_ptr(dz1), _ptr(plan.inv_start), _ptr(plan.inv_rows), npts, C1, cf, _ptr(feat), _rows(feat, "feat"),
+                                       _ptr(packed_w1f), _ptr(dfeat), _rows(dfeat, "dfeat") if dfeat is not None else 0, _ptr(dw1),
+                                       _rows(dw1, "dw1"), dw1.shape[1], _ptr(dY), _rows(dY, "dY") if dY is not None else 0, _ptr(w),
+                                       w.numel(), _stream()), "pm_sa_dy_consume_f32")
+    return dfeat
+
+
 def sa_bwd_packed(plan, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpooled, dw1, db1, dw2, db2, dw3, db3, dY, ws, h2_saved=None,
                   dz1=None):
     """dz1 (R, C1): the layer-1 gradient per packed row (plain stores; sum it per source point with sa_dy_segsum) -- the

@@ -912,6 +912,30 @@ def test_sa_packed_rows_equal_the_dense_level(dims, P, S, cf, radius):
     for dYr, dzr, gr in runs[1:]:
         assert torch.equal(dYr, dYd) and torch.equal(dzr, dz1) and all(
             torch.equal(a_[:, :3] if k_ == 0 else a_, b_[:, :3] if k_ == 0 else b_) for k_, (a_, b_) in enumerate(zip(gr, grads)))
+    # ---- the sums consumed where they are formed (pm_sa_dy_consume_f32): its optional dY copy BIT-identical to the segmented-sum pass,
+    # dfeat = dY W1f and dW1[:, 3:3+cf] = dY^T feat against float64 products of that dY, pad columns zeroed, xyz columns untouched,
+    # three repetitions bit-identical (npoints = 37 x 200 is not a multiple of the 64-point tile: the ragged last tile)
+    assert o.sa_dy_consume_supported(C1, cf)
+    pw = torch.empty(int(o.lib.pm_sa_dy_consume_packed_elems(C1, cf)), device=DEV)
+    o.sa_dy_consume_pack(W1, cf, pw)
+    cons = []
+    for rep in range(3):
+        dfeat = torch.full((B * P, cf), float("nan"), device=DEV)
+        dW1c = torch.full_like(W1, float("nan"))
+        dW1c[:, :3] = 7.0
+        dYc = torch.full((B * P, C1), float("nan"), device=DEV)
+        o.sa_dy_consume(plan_i, dz1, feat, pw, dfeat, dW1c, ws, dY=dYc if rep == 0 else None)
+        cons.append((dfeat, dW1c))
+        if rep == 0:
+            assert torch.equal(dYc, dYd)
+    dfeat, dW1c = cons[0]
+    want_df = dYd.double() @ W1[:, 3:3 + cf].double()
+    want_dw = dYd.double().t() @ feat.double()
+    assert float((dfeat.double() - want_df).abs().max()) < 2e-6 * float(want_df.abs().max())
+    assert float((dW1c[:, 3:3 + cf].double() - want_dw).abs().max()) < 5e-6 * float(want_dw.abs().max())
+    assert bool((dW1c[:, :3] == 7.0).all()) and not bool(dW1c[:, 3 + cf:].any())
+    for dfr, dwr in cons[1:]:
+        assert torch.equal(dfr, dfeat) and torch.equal(dwr, dW1c)
 
 
 def test_grouped_linear_ops_equal_the_single_problem_ops():

@@ -29,11 +29,12 @@ from tests.helpers import t, flat_state, FakeEnv, FakeLogger, per_tensor_update_
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-# observed over five full runs (three boxes): the worst tensor of the PointNet++ iteration at 1.16 .. 1.68 x the fp32 oracle's own
-# (or its network-median) distance to fp64 -- the oracle's ATen index_add / the level-1 dY atomics make both sides run-dependent in
-# their last bits, and 80 Adam steps amplify that -- cfg 3 and SparseUNet at <= 1.35 x.  3 x keeps a real regression (a wrong
-# gradient scores 10 x and more) apart from that noise.
-BRACKET = 3.0
+# Round 6: the HIP side has no floating-point atomics any more (the level-1 dY sums run in a fixed order over the plan's inverse
+# table, csrc/sa_fused.hip), so its trajectory is bit-reproducible; what still varies run to run is the ORACLE's ATen index_add.
+# Observed over five runs at 2 x (gpurun_out/r6c -> profiles/round6_pn2_bracket2_runs.txt): the worst tensor of the PointNet++
+# iteration at 0.61 .. 0.81 of the bound (1.2 .. 1.6 x the fp32 oracle's own distance to fp64); cfg 3 and SparseUNet <= 1.35 x.
+# A wrong gradient scores 10 x and more.
+BRACKET = 2.0
 
 TRICKS = dict(mini_adv_norm=False, whole_adv_norm=False, use_state_norm=False, use_clipped_value_loss=False,
               use_grad_clip=True, max_grad_norm=0.5)

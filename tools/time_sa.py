@@ -38,6 +38,11 @@ for name, P, S, radius, dims, cf in LEVELS:
     DET = os.environ.get("SA_DET", "1") == "1" and cf > 0     # dz1 rows + fixed-order sums (default) or fp32 atomics into dY
     plan = ops.sa_plan(idx_g, xyz, centers, dims, ws, inverse=DET) if PACKED else None
     dz1 = torch.empty(plan.counts()[0], C1, device=DEV) if (PACKED and DET) else None
+    if PACKED and DET:
+        pw = torch.empty(int(ops.lib.pm_sa_dy_consume_packed_elems(C1, cf)), device=DEV)
+        ops.sa_dy_consume_pack(W1, cf, pw)
+        dfeat, dW1c, dW1f = torch.empty(B * P, cf, device=DEV), torch.empty_like(W1), torch.empty(C1, cf, device=DEV)
+        w1f = W1[:, 3:3 + cf].contiguous()
 
     def run(n):
         for _ in range(n):
@@ -46,7 +51,13 @@ for name, P, S, radius, dims, cf in LEVELS:
                 arg = ops.sa_fwd_packed(pl, Y, W1, b1, b2, b3, packed, dims, pooled, h2)
                 if DET:
                     ops.sa_bwd_packed(pl, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, None, ws, h2, dz1=dz1)
-                    ops.sa_dy_segsum(pl, dz1, dY)
+                    if os.environ.get("SA_FUSED_DY", "1") == "1":
+                        ops.sa_dy_consume(pl, dz1, feat, pw, dfeat, dW1c, ws)
+                    else:
+                        ops.sa_dy_segsum(pl, dz1, dY)
+                        with ops.TIMER.bracket("dy_gemms"):
+                            ops.linear_bwd_weight(dY, feat, dW1f, None, ws)
+                            ops.linear_bwd_data(dY, w1f, None, dfeat, ops.ACT_NONE)
                 else:
                     if dY is not None:
                         ops.fill_zero(dY) if hasattr(ops, "fill_zero") else dY.zero_()
@@ -56,7 +67,7 @@ for name, P, S, radius, dims, cf in LEVELS:
                 ops.sa_bwd(xyz, centers, idx_g, Y, W1, b1, b2, W3, packed, dims, pooled, arg, dpooled, *g, dY, ws, h2)
     run(2)
     nf, nb = f"sa_fwd_{C1}x{C2}x{C3}", f"sa_bwd_{C1}x{C2}x{C3}"
-    ops.TIMER.enable(nf, nb, "sa_plan", "sa_dy_segsum")
+    ops.TIMER.enable(nf, nb, "sa_plan", "sa_dy_segsum", "sa_dy_consume", "dy_gemms")
     run(5)
     f = ops.TIMER.mean_ms(nf)[0]
     b = ops.TIMER.mean_ms(nb)[0]
@@ -72,5 +83,6 @@ for name, P, S, radius, dims, cf in LEVELS:
     fb = 2.0 * rows * ((2 if h2 is not None else 3) * C1 * C2 + C2 * C3) / 1e9   # [L2 recompute +] dW2 + dH1 + dH2
     sg = ops.TIMER.mean_ms("sa_dy_segsum") if (PACKED and DET) else None
     print(f"level {name}: fwd {f:.3f} ms ({ff / f:.1f} TF)  bwd {b:.3f} ms ({fb / b:.1f} TF executed)"
-          + (f"  dY segsum {sg[0]:.3f} ms" if sg else ""))
+          + (f"  dY segsum {sg[0]:.3f} ms" if sg else "")
+          + "".join(f"  {n_} {ops.TIMER.mean_ms(n_)[0]:.3f} ms" for n_ in ("sa_dy_consume", "dy_gemms") if ops.TIMER.mean_ms(n_)))
     xyz = centers.contiguous()
