@@ -366,7 +366,7 @@ def run_depth2pc(args, device):
     # dominant kernel: farthest-point sampling on G = 256 / envs work-groups per cloud (csrc/pointops.hip: fps_multi_kernel): each keeps
     # 25 600 points of its chunk in registers (512 threads x 50) and 10 176 in LDS for all K rounds; only a remainder beyond those
     # 35 776 re-reads its points (12 B) and running min-distance (4 B + 4 B back) every round
-    on_reg, on_lds = (512 * 50, 10176) if os.environ.get("PM_FM_CFG", "1") != "0" else (1024 * 16, 8192)
+    on_reg, on_lds = (512 * 50, 10176) if not ops.FPS_POLICY.legacy_shape else (1024 * 16, 8192)
     nn = n0.to(torch.int64).cpu()
     G = max(1, min(8, 256 // b))
     chunk = (nn + G - 1) // G

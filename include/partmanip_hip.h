@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 150 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 151 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -399,16 +399,31 @@ int pm_depth_backproject_f32(const float* depth, int B, int M, int H, int W, con
 int pm_depth_compact_f32(const float* xyz, int B, int P, float* out, int32_t* lengths, void* stream);
 /* Workspace: 0 when every cloud fits in registers (ld <= 8192).  With the full reservation (8-byte aligned) camera-sized xyz
  * clouds run on pm_fps_varlen_groups(B, ld, D) >= 2 work-groups per cloud, each keeping its chunk on chip; the partners of a
- * cloud wait for each other INSIDE the launch, with ONE bounded poll budget per work-group and launch (~1 s; PM_FPS_SPIN_LIMIT).
+ * cloud wait for each other INSIDE the launch, with ONE bounded poll budget per work-group and launch (~1 s; pm_fps_config.spin_limit).
  * A work-group that exhausts it gives up ONCE: it latches the flag, sets the reservation's last 8 bytes (which every other
  * work-group of the launch watches and follows) and returns; the call then DEGRADES on the device: a launch queued behind it
  * re-samples the batch's big clouds on one work-group each when -- and only when -- that word is set (no host round trip, the
  * indices are valid either way; the word stays set for diagnostics until the next multi-work-group call clears it).  Other
  * kernels on the device only delay the hand-offs (their work-groups drain); two such launches running concurrently on two
- * streams can hold each other's CUs until the budget trips -- issue them from one stream, or cap the group count (PM_FPS_MAXG,
+ * streams can hold each other's CUs until the budget trips -- issue them from one stream, or cap the group count (pm_fps_config.max_groups,
  * 0 / 1 = one work-group per cloud) when CUs are masked or shared. */
+/* Launch policy of the multi-work-group sampler, PASSED by the caller (the library reads no environment variable and keeps no
+ * state between calls); NULL = the defaults.  max_groups: cap on the work-groups per cloud (< 0: none; 0 / 1: one work-group per
+ * cloud -- when CUs are masked or shared); resident_cus: the CUs the caller knows the launch can occupy (0: all the device
+ * reports -- wrong under a CU mask or beside a long-running kernel, which is why it is the caller's to say); spin_limit (when
+ * spin_limit_set): the poll budget of a hand-off; legacy_shape: the 1024-thread x 16-point launch shape (A/B). */
+typedef struct pm_fps_config {
+    int max_groups;
+    int resident_cus;
+    unsigned spin_limit;
+    int spin_limit_set;
+    int legacy_shape;
+} pm_fps_config;
 size_t pm_fps_varlen_workspace_bytes(int B, int ld);
-int pm_fps_varlen_groups(int B, int ld, int D);
+int pm_fps_varlen_groups(int B, int ld, int D);                                  /* = _cfg(..., NULL) */
+int pm_fps_varlen_groups_cfg(int B, int ld, int D, const pm_fps_config* cfg);
+int pm_fps_varlen_cfg_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths, int pad, int32_t* idx_out,
+                          const pm_fps_config* cfg, void* workspace, size_t workspace_bytes, void* stream);
 int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths,
                       int pad /* 1: pytorch3d semantics, -1 once a cloud is exhausted; 0: keep sampling (see above) */,
                       int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream);

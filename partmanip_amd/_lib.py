@@ -126,6 +126,8 @@ SIGNATURES = {
     "pm_sa_bwd_f32": (I, [P, P, P, P, I, I, I, I, P, L, P, P, P, P, I, I, I, P, L, P, P, L, P, L, P, P, P, P, P, P,
                           P, P, Z, P]),
     "pm_fps_varlen_groups": (I, [I, I, I]),
+    "pm_fps_varlen_groups_cfg": (I, [I, I, I, P]),
+    "pm_fps_varlen_cfg_f32": (I, [P, I, I, I, I, P, I, P, P, P, Z, P]),
     "pm_adv_normalize_workspace_bytes": (Z, [L]),
     "pm_adv_normalize_f32": (I, [P, L, F, P, Z, P]),
     "pm_mlp_fwd_f32": (I, [P, L, I, I, P, P, P, I, P, P]),
@@ -188,7 +190,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 150                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 151                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -22,6 +22,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline hipStream_t pm_stream(void* s) { return (hipStream_t)s; }
 
+// Compute units of the current device, asked of the runtime on every call (an attribute lookup, no synchronisation): the
+// library keeps NO state between calls -- no function-static caches, no environment reads (include/partmanip_hip.h preamble).
+static inline int pm_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        n = 256;
+    return n;
+}
+
 // ---- wave / block reductions (64-lane waves) -------------------------------------------
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

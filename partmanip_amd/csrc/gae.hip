@@ -99,13 +99,12 @@ extern "C" int pm_gae_scan_f32(const float* rewards, const float* values, const 
     // Envs per work-group (measured, tools/time_gae.py, 128 steps): 4096 envs -- 16 / 32 / 64 all 9.8-11 us (launch-bound: 256 /
     // 128 / 64 work-groups); 32768 envs -- 16: 26.1 us (2.9 TB/s), 32: 18.5 us (4.1 TB/s of the 18 algorithmic B per env-step),
     // 64: 29.7 us (one 98 KB work-group per CU: nothing hides the serial phase).  32 envs = 128-byte row pieces of every time
-    // step once that still leaves a work-group per CU; PM_GAE_E overrides (A/B).
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("PM_GAE_E");
-        forced = e ? atoi(e) : 0;
-    }
-    int E = forced ? forced : (N >= 32 * 256 ? 32 : 16);
+    // step once that still leaves a work-group per CU; -DPM_GAE_E overrides (A/B builds).
+#ifdef PM_GAE_E                                            // A/B builds only (tools/build_ab.py ... -DPM_GAE_E=64)
+    const int E = PM_GAE_E;
+#else
+    const int E = N >= 32 * 256 ? 32 : 16;
+#endif
 #define GAE_LAUNCH(E_)                                                                                                     \
     hipLaunchKernelGGL(gae_scan_kernel<E_>, dim3((N + (E_) - 1) / (E_)), dim3(256), 0, pm_stream(stream), rewards, values, \
                        dones, succs, last_values, returns, advantages, T, N, gamma, gamma_lam, use_succ, succ_value)

@@ -416,11 +416,21 @@ __device__ __forceinline__ int g2_chan(const Gemm2Prob& g, int q) { return g.gsh
 // result and guarded the index registers with `s_waitcnt vmcnt(0)` at the top of the loader loop -- the ring drained to one tile
 // there.  The hardware still counts the load (in order with the DMAs), so the ring's counted waits cover it: an index requested by
 // issue(t) has landed once issue(t + 1)'s hand-over wait has passed, and issue(t + 2) is its first reader.  The ISA must not copy
-// the register between the load and that wait (checked: tools/isa_stats.py / the loader loop of gemm2_dma_kernel<.., GATHER>).
+// the register between the load and that wait: the wait itself carries the registers as in/out operands (g2_wait_idx below).
 __device__ __forceinline__ int g2_idx_load(const int32_t* p) {
     int v;
     asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
     return v;
+}
+// The counted wait that covers an index set also DEFINES its registers ("+v"): every later use of gi[] depends on this
+// statement's output, so hipcc cannot hoist the address arithmetic of the next issue() -- or a copy / spill of the register --
+// above the wait and read an index that is still in flight (before this the only safeguard was an ISA inspection).
+template <int CNT, int N>
+__device__ __forceinline__ void g2_wait_idx(int (&gi)[N]) {
+    static_assert(N == 1 || N == 2 || N == 4, "index registers per loader wave");
+    if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gi[0]) : "n"(CNT) : "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(gi[0]), "+v"(gi[1]) : "n"(CNT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gi[0]), "+v"(gi[1]), "+v"(gi[2]), "+v"(gi[3]) : "n"(CNT) : "memory");
 }
 template <bool KM, int T>
 __device__ __forceinline__ void g2_dma_tile_gather(const Gemm2Prob& g, const float* __restrict__ P, long ld, int r0, int nrows, int k0,
@@ -545,7 +555,8 @@ __device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Pro
                 g2_gather_first<false, TM>(g, m0, g.M, kbeg, wave, lane, gia);
                 g2_gather_first<false, TM>(g, m0, g.M, k1, wave, lane, gib);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the compiler does not know these loads: the first two tiles' indices are in
+            g2_wait_idx<0>(gia);                                           // the compiler does not know these loads: the first two tiles' indices are in
+            g2_wait_idx<0>(gib);
         }
         // the counted waits allow for the NGI index loads an issue() ends with
         constexpr int NW1 = IPT + (GATHER ? NGI : 0);
@@ -553,27 +564,34 @@ __device__ __forceinline__ void g2_dma_body(const Gemm2Group& gg, const Gemm2Pro
             // two stages: tile k + 1 is requested at the top of K-step k (its buffer's readers passed the last barrier) and must have
             // landed at the step's end -- nothing else stays in flight
             issue(0, gia);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (GATHER) g2_wait_idx<0>(gia);
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
 #pragma unroll 1
             for (int k = 0; k < nk; ++k) {
                 issue(k + 1, gia);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (GATHER) g2_wait_idx<0>(gia);
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
         } else {
+        // (GATHER: a wait that leaves only the LAST issue()'s operations in flight has seen the index loads of the issue() before
+        // it land -- that set is what the wait defines: gia after issue(.., gib) and the other way round)
         issue(0, gia);
         issue(1, gib);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW1) : "memory");         // tile 0 has landed (this wave's pieces)
+        if constexpr (GATHER) g2_wait_idx<NW1>(gia);                       // tile 0 has landed (this wave's pieces), and issue(0)'s indices
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW1) : "memory");
         __builtin_amdgcn_s_barrier();                                      // ... and every other loader's
 #pragma unroll 1
         for (int k = 0; k < nk; k += 2) {
             issue(k + 2, gia);                                             // into the buffer whose readers passed the last barrier
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW1) : "memory");     // tile k+1 landed, tile k+2 stays in flight
+            if constexpr (GATHER) g2_wait_idx<NW1>(gib);                   // tile k+1 landed (with the indices its issue() requested), tile k+2 stays in flight
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW1) : "memory");
             __builtin_amdgcn_s_barrier();
             if (k + 1 < nk) {
                 issue(k + 3, gib);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW1) : "memory");
+                if constexpr (GATHER) g2_wait_idx<NW1>(gia);
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW1) : "memory");
                 __builtin_amdgcn_s_barrier();
             }
         }
@@ -830,11 +848,7 @@ static void g2_launch_dma(const Gemm2Group& g, int wm, int wn, int blocks, void*
         }
     }
     if constexpr (!GATHER) {
-        static int nb2 = -1;                                               // PM_G2_NBUF=2: the two-stage ring for 128 x 128 tiles (A/B)
-        if (nb2 < 0) {
-            const char* e = getenv("PM_G2_NBUF");
-            nb2 = e ? atoi(e) : G2_NBUF_DEFAULT;
-        }
+        constexpr int nb2 = G2_NBUF_DEFAULT;                                // -DG2_NBUF_DEFAULT=2: the two-stage ring for 128 x 128 tiles (A/B builds)
         if (wm == 2 && wn == 2 && nb2 == 2) {
             hipLaunchKernelGGL((gemm2_dma_kernel<A_KM, B_KM, 2, 2, false, 0, 2>), grid, blk, 0, pm_stream(stream), g);
             return;

@@ -1264,17 +1264,7 @@ __global__ __launch_bounds__(256) void pn_dw3_finish_kernel(const float* __restr
 #include "pointnet_enc_bwd_bf6.h"
 
 static inline int pn_bwd_grid(int B) { return B < PN_BWD_MAXG ? B : PN_BWD_MAXG; }
-static int pn_cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        n = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n > PN_BWD_MAXG) n = PN_BWD_MAXG;
-    }
-    return n;
-}
+static int pn_cu_count() { const int n = pm_cu_count(); return n > PN_BWD_MAXG ? PN_BWD_MAXG : n; }
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct PnBwdWs {

@@ -854,51 +854,45 @@ extern "C" size_t pm_fps_varlen_workspace_bytes(int B, int ld) {
     return mind + (mind ? (size_t)(FM_SLOT_WORDS + 1) * sizeof(fm_u64) : 0);
 }
 
-static int fps_cu_count() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
-        if (n > 256) n = 256;
-    }
-    return n;
-}
-
 // Work-groups per cloud of the multi-work-group sampler for a (B, ld, D) batch; < 2: the one-work-group kernels run.
-// PM_FPS_MAXG caps it (0 / 1 switches the multi-work-group path off, e.g. when the caller masks CUs or shares the device
-// with another long-running launch: the partners of a cloud must all be resident).
-extern "C" int pm_fps_varlen_groups(int B, int ld, int D) {
+// Everything that used to come from the environment is the CALLER's to pass (pm_fps_config; NULL = defaults): the group cap
+// (0 / 1 switches the multi-work-group path off, e.g. when the caller masks CUs or shares the device with another long-running
+// launch: the partners of a cloud must all be resident), the CUs the caller knows to be available to the launch (0 = all the
+// device reports), the poll budget, and the launch shape.
+static int fps_groups_cfg(int B, int ld, int D, const pm_fps_config* cfg) {
     if (B <= 0 || D != 3 || ld <= FPS_NT * FPS_RPT) return 1;
-    int G = fps_cu_count() / B;
+    int ncu = cfg && cfg->resident_cus > 0 ? cfg->resident_cus : pm_cu_count();
+    if (ncu > 256) ncu = 256;
+    int G = ncu / B;
     if (G > FM_MAXG) G = FM_MAXG;
-    const char* e = getenv("PM_FPS_MAXG");
-    if (e && atoi(e) < G) G = atoi(e);
+    if (cfg && cfg->max_groups >= 0 && cfg->max_groups < G) G = cfg->max_groups;
     return G < 1 ? 1 : G;
 }
+extern "C" int pm_fps_varlen_groups(int B, int ld, int D) { return fps_groups_cfg(B, ld, D, nullptr); }
+extern "C" int pm_fps_varlen_groups_cfg(int B, int ld, int D, const pm_fps_config* cfg) { return fps_groups_cfg(B, ld, D, cfg); }
 
+extern "C" int pm_fps_varlen_cfg_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths, int pad, int32_t* idx_out,
+                                     const pm_fps_config* cfg, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int pm_fps_varlen_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths, int pad,
                                  int32_t* idx_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return pm_fps_varlen_cfg_f32(xyz, B, ld, D, K, lengths, pad, idx_out, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pm_fps_varlen_cfg_f32(const float* xyz, int B, int ld, int D, int K, const int32_t* lengths, int pad, int32_t* idx_out,
+                                     const pm_fps_config* cfg_in, void* workspace, size_t workspace_bytes, void* stream) {
     PM_REQUIRE(xyz && lengths && idx_out && B > 0 && ld > 0 && D >= 1 && D <= FPS_MAXD && K > 0);
     if (ld > FPS_NT * FPS_RPT && (!workspace || workspace_bytes < (size_t)B * ld * sizeof(float))) return PM_EWORKSPACE;
     // several work-groups per cloud: xyz clouds, few enough clouds that G >= 2 work-groups each are all resident (one
     // 1024-thread work-group of 128 VGPRs per CU), and the caller handed over the larger workspace
-    const int G = pm_fps_varlen_groups(B, ld, D);
+    const int G = fps_groups_cfg(B, ld, D, cfg_in);
     const bool full_ws = ld > FPS_NT * FPS_RPT && workspace_bytes >= pm_fps_varlen_workspace_bytes(B, ld) && ((uintptr_t)workspace & 7) == 0;
     if (G >= 2 && full_ws) {
         const size_t mind = (((size_t)B * ld * sizeof(float) + 7) & ~(size_t)7);
         fm_u64* slots = (fm_u64*)((char*)workspace + mind);
         // round tags start at 1 and the give-up word is per call: the granules are cleared in front of every multi-work-group launch
         if (hipMemsetAsync(slots, 0, (size_t)(FM_SLOT_WORDS + 1) * sizeof(fm_u64), pm_stream(stream)) != hipSuccess) return PM_EINVAL;
-        unsigned limit = FM_SPIN_LIMIT;
-        const char* e = getenv("PM_FPS_SPIN_LIMIT");     // tests force the give-up path with a tiny budget
-        if (e) limit = (unsigned)strtoul(e, nullptr, 10);
-        static int cfg = -1;                                 // PM_FM_CFG=0 (A/B): the 1024-thread x 16-point shape of rounds 2-3
-        if (cfg < 0) {
-            const char* c = getenv("PM_FM_CFG");
-            cfg = c ? atoi(c) : 1;
-        }
+        const unsigned limit = cfg_in && cfg_in->spin_limit_set ? cfg_in->spin_limit : FM_SPIN_LIMIT;    // (tests force the give-up path with 0)
+        const int cfg = cfg_in && cfg_in->legacy_shape ? 0 : 1;     // legacy_shape (A/B): the 1024-thread x 16-point shape of rounds 2-3
 #define FM_LAUNCH(PAD_, NT_, RPT_, LP_)                                                                                      \
         hipLaunchKernelGGL((fps_multi_kernel<PAD_, NT_, RPT_, LP_>), dim3(B * G), dim3(NT_), (size_t)(LP_) * 16, pm_stream(stream), \
                            xyz, ld, K, lengths, idx_out, (float*)workspace, slots, G, limit)

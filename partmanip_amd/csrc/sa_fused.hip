@@ -300,16 +300,7 @@ extern "C" int pm_sa_supported(int C1, int C2, int C3, int nsample) {
     return nsample == SA_NS && (SA_CFG_A(C1, C2, C3) || SA_CFG_B(C1, C2, C3));
 }
 
-static int sa_cu_count() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+static int sa_cu_count() { return pm_cu_count(); }
 
 extern "C" int pm_sa_fwd_f32(const float* xyz, const float* centers, const int32_t* idx, const float* Y, int B, int P,
                              int S, int nsample, const float* W1, long ldw1, const float* b1, const float* b2,

@@ -1216,9 +1216,42 @@ def depth_compact(world):
     return out, lengths
 
 
-def fps_varlen(xyz, lengths, K, ws, pad=False):
+class FpsConfig(C.Structure):
+    """pm_fps_config (include/partmanip_hip.h): the launch policy of the multi-work-group sampler, passed with every call."""
+    _fields_ = [("max_groups", C.c_int), ("resident_cus", C.c_int), ("spin_limit", C.c_uint), ("spin_limit_set", C.c_int),
+                ("legacy_shape", C.c_int)]
+
+
+class _FpsPolicy:
+    """Process-local policy behind fps_varlen's default (the LIBRARY has no state: this object is turned into a pm_fps_config
+    for every call).  max_groups: cap on the work-groups per cloud (None: the library's own; 1: one work-group per cloud);
+    resident_cus: the CUs a launch may occupy when the caller masks / shares the device (None: all); spin_limit: the hand-off
+    poll budget (None: ~1 s; tests force give-ups with 0); legacy_shape: the round-2 launch shape (A/B).  The PM_FPS_MAXG /
+    PM_FPS_SPIN_LIMIT / PM_FM_CFG environment variables of earlier rounds are read ONCE here, at import."""
+
+    def __init__(self):
+        e = os.environ
+        self.max_groups = int(e["PM_FPS_MAXG"]) if "PM_FPS_MAXG" in e else None
+        self.spin_limit = int(e["PM_FPS_SPIN_LIMIT"]) if "PM_FPS_SPIN_LIMIT" in e else None
+        self.legacy_shape = e.get("PM_FM_CFG", "1") == "0"
+        self.resident_cus = None
+        self.gave_up_cap = False                              # set by the watch below: a give-up capped the group count
+
+    def struct(self, max_groups=None, spin_limit=None, resident_cus=None):
+        mg = self.max_groups if max_groups is None else max_groups
+        sl = self.spin_limit if spin_limit is None else spin_limit
+        rc = self.resident_cus if resident_cus is None else resident_cus
+        return FpsConfig(-1 if mg is None else int(mg), 0 if rc is None else int(rc), 0 if sl is None else int(sl),
+                         0 if sl is None else 1, int(self.legacy_shape))
+
+
+FPS_POLICY = _FpsPolicy()
+
+
+def fps_varlen(xyz, lengths, K, ws, pad=False, max_groups=None, spin_limit=None, resident_cus=None):
     """FPS over the first lengths[b] rows of each cloud of xyz (B, ld, D) -> idx (B, K) int32; pad=True: pytorch3d's
-    -1 once a cloud is exhausted, pad=False: keep sampling (index 0 repeats), as the full depth cloud would."""
+    -1 once a cloud is exhausted, pad=False: keep sampling (index 0 repeats), as the full depth cloud would.
+    max_groups / spin_limit / resident_cus override FPS_POLICY for this call (see _FpsPolicy)."""
     _req(xyz, lengths)
     _f32c(xyz, "xyz")
     B, ld, Dd = xyz.shape
@@ -1230,18 +1263,23 @@ def fps_varlen(xyz, lengths, K, ws, pad=False):
         base = w.data_ptr()
         al = (-base) % 8
     _fps_watch_poll(ws)
-    check(lib.pm_fps_varlen_f32(_ptr(xyz), B, ld, Dd, K, _ptr(lengths), int(pad), _ptr(idx), (base + al) if w is not None else None,
-                                (w.numel() - al) if w is not None else 0, _stream()), "pm_fps_varlen_f32")
+    cfg = FPS_POLICY.struct(max_groups, spin_limit, resident_cus)
+    check(lib.pm_fps_varlen_cfg_f32(_ptr(xyz), B, ld, Dd, K, _ptr(lengths), int(pad), _ptr(idx), C.byref(cfg),
+                                    (base + al) if w is not None else None, (w.numel() - al) if w is not None else 0, _stream()),
+          "pm_fps_varlen_cfg_f32")
     # a multi-work-group launch that gives up degrades on the device (a launch queued behind it re-samples the big clouds when
     # the reservation's last word is set): nothing to check here, no host sync.  fps_varlen_gave_up(ws) reads the word; the
-    # watch below copies it to pinned host memory behind the launch and the NEXT call looks at it (no sync either).
-    ws.fps_err = w[al + nb - 8: al + nb].view(torch.int64) if (nb and int(lib.pm_fps_varlen_groups(B, ld, Dd)) >= 2) else None
-    if ws.fps_err is not None and getattr(ws, "_fps_watch", None) is None:
+    # watch below copies it to pinned host memory behind the launch and the NEXT call looks at it (no sync either).  Only a call
+    # that finds no earlier watch pending arms one (give-ups of the calls in between are seen by fps_varlen_gave_up only), and
+    # none is armed inside a stream capture (the pinned copy and the event are not capturable work).
+    multi = nb and int(lib.pm_fps_varlen_groups_cfg(B, ld, Dd, C.byref(cfg))) >= 2
+    ws.fps_err = w[al + nb - 8: al + nb].view(torch.int64) if multi else None
+    if ws.fps_err is not None and getattr(ws, "_fps_watch", None) is None and not torch.cuda.is_current_stream_capturing():
         host = torch.empty(1, dtype=torch.int64, pin_memory=True)
         host.copy_(ws.fps_err, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        ws._fps_watch = (host, ev, os.environ.get("PM_FPS_SPIN_LIMIT") is not None)      # (forced by a test: report, do not act)
+        ws._fps_watch = (host, ev, cfg.spin_limit_set != 0)                        # (a forced budget -- a test: report, do not act)
     return idx
 
 
@@ -1251,19 +1289,22 @@ _FPS_GIVE_UPS = [0]
 def _fps_watch_poll(ws):
     """A multi-work-group FPS launch that gave up costs its whole spin budget (~1 s) before the one-work-group sampler redoes the
     clouds -- correct, but silent.  The give-up word of an earlier call on this workspace, copied to the host behind that call:
-    once it has arrived and is set, say so and switch the multi-work-group path off for the rest of the process (PM_FPS_MAXG=1;
-    not when that call ran with a forced spin budget, PM_FPS_SPIN_LIMIT: the tests' way to provoke give-ups)."""
+    once it has arrived and is set, say so and cap FPS_POLICY.max_groups at 1 for the rest of the process (a module-level flag
+    that every later call PASSES to the library -- nothing in the environment or the library changes; not when that call ran
+    with a forced spin budget: the tests' way to provoke give-ups)."""
     watch = getattr(ws, "_fps_watch", None)
     if watch is None or not watch[1].query():
         return
     ws._fps_watch = None
     if int(watch[0][0]) != 0:
         _FPS_GIVE_UPS[0] += 1
-        if not watch[2] and os.environ.get("PM_FPS_MAXG") != "1":
+        if not watch[2] and FPS_POLICY.max_groups != 1:
             import warnings
-            warnings.warn("pm_fps_varlen_f32: a multi-work-group sampling launch gave up waiting for its partner work-groups (the "
-                          "device is shared or CU-masked?) and fell back to one work-group per cloud; PM_FPS_MAXG=1 from now on")
-            os.environ["PM_FPS_MAXG"] = "1"
+            warnings.warn("pm_fps_varlen_cfg_f32: a multi-work-group sampling launch gave up waiting for its partner work-groups (the "
+                          "device is shared or CU-masked?) and fell back to one work-group per cloud; ops.FPS_POLICY.max_groups = 1 "
+                          "from now on (pass resident_cus to keep the multi-work-group path on a masked device)")
+            FPS_POLICY.max_groups = 1
+            FPS_POLICY.gave_up_cap = True
 
 
 def fps_varlen_gave_up(ws):

@@ -641,22 +641,28 @@ def test_varlen_fps_degrades_when_a_work_group_gives_up(pad, monkeypatch):
     assert int(o.lib.pm_fps_varlen_groups(B, ld, 3)) >= 2
     idx = o.fps_varlen(x, n, K, ws, pad=pad)                      # normal budget
     assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref) and not o.fps_varlen_gave_up(ws)
-    monkeypatch.setenv("PM_FPS_SPIN_LIMIT", "0")
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()                                      # (the poll budget is an ARGUMENT, pm_fps_config.spin_limit: no environment)
     t0 = time.perf_counter()
-    idx = o.fps_varlen(x, n, K, ws, pad=pad)
+    idx = o.fps_varlen(x, n, K, ws, pad=pad, spin_limit=0)
     got = idx.cpu().numpy().astype(np.int64)
     dt = time.perf_counter() - t0
     assert o.fps_varlen_gave_up(ws), "the forced give-up did not happen"
     assert np.array_equal(got, ref)
     assert dt < 5.0, dt
-    monkeypatch.delenv("PM_FPS_SPIN_LIMIT")
     idx = o.fps_varlen(x, n, K, ws, pad=pad)                      # the next call clears the word and runs on several work-groups again
     assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref) and not o.fps_varlen_gave_up(ws)
-    monkeypatch.setenv("PM_FPS_MAXG", "1")                        # the cap: one work-group per cloud, no hand-offs at all
-    assert int(o.lib.pm_fps_varlen_groups(B, ld, 3)) == 1
-    idx = o.fps_varlen(x, n, K, ws, pad=pad)
-    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref)
+    import ctypes
+    cap = o.FPS_POLICY.struct(max_groups=1)                       # the cap: one work-group per cloud, no hand-offs at all
+    assert int(o.lib.pm_fps_varlen_groups_cfg(B, ld, 3, ctypes.byref(cap))) == 1
+    idx = o.fps_varlen(x, n, K, ws, pad=pad, max_groups=1)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref) and ws.fps_err is None
+    # the caller says how many CUs a launch may occupy (a CU mask, a co-resident kernel): half of them -> half the work-groups per cloud
+    full = int(o.lib.pm_fps_varlen_groups(B, ld, 3))
+    half = o.FPS_POLICY.struct(resident_cus=128)
+    assert int(o.lib.pm_fps_varlen_groups_cfg(B, ld, 3, ctypes.byref(half))) == max(1, min(full, 128 // B))
+    idx = o.fps_varlen(x, n, K, ws, pad=pad, resident_cus=128)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref) and not o.fps_varlen_gave_up(ws)
+    assert not o.FPS_POLICY.gave_up_cap                           # the forced give-up above reported, it did not cap the process
 
 
 def test_tsdf_integrate_matches_reference():

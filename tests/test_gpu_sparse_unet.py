@@ -2,6 +2,7 @@
 oracle/ref_cpu.py::sparse_unet_forward (PARITY UNPINNED: the backbone is named by README.md:30 but absent from the reference
 snapshot, README.md:23; the restatement itself is pinned to torch's dense conv3d U-Net on fully occupied grids,
 tests/test_oracle_sparse_unet.py).  Integer tables bit-exact; features / gradients fp32 round-off."""
+import os
 import tempfile
 
 import numpy as np
@@ -317,10 +318,10 @@ def test_full_size_forward_and_gradients_fused_vs_materialised_and_vs_restatemen
         a, b = res[True][1][n], res[False][1][n]
         e = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
         worst = max(worst, e)
-        assert e <= 2e-6, (n, e)
+        assert e <= 1e-6, (n, e)
     # two summation orders of the same sums; observed 1.7e-7 (256 clouds) / 6.9e-7 (2048), bit-reproducible run to run since the
     # gathered weight gradient's loader race is fixed (profiles/round5_sparse_unet_race.md: it used to show up here as a rare 5.5e-5)
-    record_margin("full size: fused vs materialised parameter gradients (max abs / max(1, max|ref|))", worst, 2e-6)
+    record_margin("full size: fused vs materialised parameter gradients (max abs / max(1, max|ref|))", worst, 1e-6)
     # ---- the four picked clouds on the restatement (fp64)
     xs = x[pick].cpu()
     p = {k: torch.from_numpy(v.copy()).double().requires_grad_(True) for k, v in sd.items()}
@@ -488,3 +489,16 @@ def test_ppo_update_with_cached_geometry_equals_the_uncached_one():
         res.append((flat_state(run.actor_critic.state_dict()), calls[0]))
     assert np.array_equal(res[0][0], res[1][0])
     assert res[0][1] == 2 and res[1][1] == 2 * 3 * 2, (res[0][1], res[1][1])     # 2 mini-batches | x 3 epochs x 2 networks
+
+
+def test_sparse_unet_backbone_is_bit_reproducible_under_a_noise_stream():
+    """ADVICE r5 (the gathered loader's index loads are invisible to hipcc: only the counted waits order them): a short run of the
+    race hunt that found the round-4 weight-gradient race -- the same forward + backward repeated with a second stream keeping
+    the chip busy, every launch's results hashed and compared with repetition 0 -- inside the suite (tools/stress_sparse_unet.py;
+    the long form is `--reps 1000 --B 256 --mode both --noise`)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "tools/stress_sparse_unet.py", "--reps", "40", "--B", "96", "--mode", "fused", "--noise"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "repetitions that differed: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
