@@ -250,6 +250,14 @@ def run_dagger(args, device, rank, world):
             wgrad.update(conv2=Nc * 27 * c2 * c2, up1=Nc * (c2 + c1) * c1, up0=Nc * (c1 + c0) * c0)
             dgrad.update(up1=Nc * c1 * c1 + Nc * c1 * c2, up0=Nc * c0 * c0 + Nc * c0 * c1, conv2=Nc * 27 * c2 * c2)
         bfl = 2.0 * sum(wgrad.values()) + 2.0 * sum(dgrad.values())
+        # USEFUL flops: a row of a 3^3 convolution multiplies all 27 taps and a strided level all 8 children,
+        # whether present or not (absent ones read a zero row) -- `frac` prices what the GEMMs execute, `useful_frac` only the
+        # products with a present tap / child.  Fractions of present entries from the tables of the timed mini-batch.
+        pres = lambda tbl, J: float((tbl[:, :J] >= 0).float().mean().item())
+        occ = dict(conv0=pres(g["nbr0"], 27) * 27 / 27, conv1=pres(g["nbr1"], 27), conv2=pres(g["nbr2"], 27),
+                   down0=pres(g["l1"]["child"], 8), down1=pres(g["l2"]["child"], 8), up1=1.0, up0=1.0)
+        useful = lambda d_: 2.0 * sum(v * occ[k_] for k_, v in d_.items())
+        ufl = useful(macs) + useful(wgrad) + useful(dgrad)
         # algorithmic HBM bytes of one forward + backward (every operand once: a layer reads its input rows, its table and
         # writes its output; its backward reads dY, its own output (tanh'), the input again (weight gradient) and writes dX)
         lay = [(R0, 4, 32, R0, c0), (R0, c0, 8, R1, c1), (R1, c1, 27, R1, c1), (R1, c1, 8, R2, c2), (R2, c2, 27, R2, c2),
@@ -266,6 +274,14 @@ def run_dagger(args, device, rank, world):
                                                 f"tools/time_sparse_unet.py {mb}, profiles/hbm_traffic.json)",
                                    launches=t[1], fwd_mean_ms=t[0], bwd_mean_ms=b[0], level_rows=[R0, R1, R2],
                                    flops_fwd=ffl, flops_bwd=bfl, compact_decoder_backward_rows=compact_rows,
+                                   useful_flops=ufl, useful_tflops=ufl / ((t[0] + b[0]) * 1e-3) / 1e12,
+                                   useful_frac=ufl / ((t[0] + b[0]) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                   present_tap_fraction={k_: round(v, 4) for k_, v in occ.items()},
+                                   useful_note="`frac` = flops the gathered GEMMs EXECUTE (every row multiplies all 27 taps / 8 children; absent "
+                                               "ones read a zero row); `useful_frac` = only the products with a present tap / child "
+                                               "(present_tap_fraction per layer, from the timed mini-batch's tables).  Skipping absent taps "
+                                               "needs rows grouped by presence pattern: in cell order no (64-row tile, tap) pair is empty "
+                                               "(profiles/HISTORY.md, round 4 (d))",
                                    flops_bwd_dense_decoder=ffl + 2.0 * sum(dict(macs, conv0=0, up1=R1 * c1 * c1 + R2 * c1 * c2,
                                                                                  up0=R0 * c0 * c0 + R1 * c0 * c1).values()),
                                    note="3^3 / strided convolutions and the up layers' [unpool | skip] operands are gathered inside the "
@@ -623,6 +639,11 @@ def run_ppo(args, device, rank, world):
         fl = ac.flat()
         dp = _dp_report(syncs, [fl["actor"], fl["critic"]], dt_local, args.steps, device, world)
         dp["graph_mode"] = (run.graph_status or run.dp_graph_mode) if run.use_graphs else "eager (no hipGraph replay for this backbone)"
+        # None, or what the learner fell back to when the first all-reduce of its second communicator failed on some rank
+        # (partmanip_amd/dist.py GradSync.probe: time-boxed, agreed over the rendezvous store, diagnosis on stderr)
+        dp["degraded"] = getattr(run, "dp_degraded", None)
+        if dp["degraded"]:
+            dp["graph_mode"] = "eager (degraded: see `degraded`)"
 
     vision = args.workload.startswith("vision")
     metric = ("PPO env-steps/sec (whole node), 4096 envs x 1024-pt clouds" if vision
@@ -987,6 +1008,23 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+@contextlib.contextmanager
+def _collective_diagnosis(rank, world, local):
+    """A collective that fails past the start-up probes (partmanip_amd/dist.py) must not end the run as a bare stack trace on one
+    of N interleaved stderr streams: say which rank / device it was and what to try, then exit non-zero (no JSON line: a line
+    without the collective would be a different measurement)."""
+    try:
+        yield
+    except Exception as e:                                      # noqa: BLE001
+        from partmanip_amd import dist as pdist
+        if world > 1 and (isinstance(e, pdist.CollectiveError) or "NCCL" in str(e) or "RCCL" in str(e) or "ProcessGroup" in str(e)):
+            print(f"[bench] rank {rank}/{world} (cuda:{local}) stopped on a collective: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            print("[bench] the start-up probes passed, so the communicators were built: look at the launch structure named above "
+                  "(PARTMANIP_DP_GRAPHS=split / PARTMANIP_GRAPHS=0 / PARTMANIP_OVERLAP=0 remove the capture, the graphs, the second "
+                  "communicator in turn) and at NCCL_DEBUG=INFO", file=sys.stderr, flush=True)
+        raise
+
+
 def _rank_table(rank, world, local):
     """Multi-rank runs: which process drives which device over which collective library -- gathered to rank 0, printed to stderr
     before the first step (a hang in the first all-reduce is then a hang with the topology on the screen) and kept in the line
@@ -1062,7 +1100,7 @@ def main():
                   "line needs that many ranks over RCCL (backend nccl)", file=sys.stderr)
             sys.exit(2)
     topo = _rank_table(rank, world, local)
-    with contextlib.redirect_stdout(sys.stderr):           # the runners print progress lines: keep stdout = ONE JSON line
+    with contextlib.redirect_stdout(sys.stderr), _collective_diagnosis(rank, world, local):   # the runners print progress lines: keep stdout = ONE JSON line
         if args.workload == "depth2pc":
             out = run_depth2pc(args, device) if rank == 0 else None
         elif args.workload == "dagger":

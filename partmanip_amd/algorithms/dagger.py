@@ -87,7 +87,12 @@ class dagger:
         self.storage = RolloutStorage(self.num_envs, self.buf_size, self.stu_num_obs, self.num_actions, self.device,
                                       sampler=cfg['sampler'], tea_obs_shape=self.tea_num_obs,
                                       max_length=self.max_episode_length)
-        self.sync = pdist.maybe_sync()
+        self.sync = pdist.maybe_sync(name="student")
+        if self.sync is not None and self.sync.world > 1:       # the first collective, time-boxed and agreed over the store (dist.py)
+            self.sync.mode = "eager"
+            bad = self.sync.probe(f['actor'].device)
+            if bad is not None:
+                raise pdist.CollectiveError("data-parallel DAgger cannot start: " + bad)
         self._stage = {}
         self._loss_sum = torch.zeros(1, device=f['actor'].device)
         if self.sync is not None:                        # one student: rank 0's parameters / Adam state on every replica

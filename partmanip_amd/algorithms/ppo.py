@@ -120,6 +120,7 @@ class ppo:
         # two graphs with the collective issued between them (any backend -- gloo on the 1-GPU test box).  Steps that need a
         # further collective BEFORE their loss (mini_adv_norm moments, the clipped value loss's batch-mean width) run eagerly.
         self.dp_graph_mode = None
+        self.dp_degraded = None
         if self.sync is not None:
             be = torch.distributed.get_backend()
             self.dp_graph_mode = os.environ.get("PARTMANIP_DP_GRAPHS") or ("capture" if be == "nccl" else "split")
@@ -130,7 +131,28 @@ class ppo:
                 self.dp_graph_mode = None
             # actor and critic steps run on two streams: give the critic's all-reduces their own communicator, so that two
             # concurrently replayed graphs never interleave collectives of ONE communicator in rank-dependent order
-            self.sync_c = pdist.GradSync(group=torch.distributed.new_group()) if self.overlap else self.sync
+            self.sync_c = pdist.GradSync(group=torch.distributed.new_group(), name="critic") if self.overlap else self.sync
+            # The first collective of every communicator is time-boxed and its outcome agreed between the ranks over the
+            # rendezvous store (dist.GradSync.probe): a communicator that cannot be built says so -- rank, device, communicator,
+            # launch structure, what to set -- instead of hanging the first optimiser step.  The default communicator failing
+            # leaves nothing to fall back to; the second one failing degrades ALL ranks to the conservative structure: one
+            # communicator, actor and critic steps on one stream, eager launches (no collective inside a hipGraph).
+            self.sync.mode = self.sync_c.mode = self.dp_graph_mode or "eager"
+            if self.sync.world > 1:
+                bad = self.sync.probe(dev)
+                if bad is not None:
+                    raise pdist.CollectiveError("data-parallel PPO cannot start: " + bad)
+                bad = self.sync_c.probe(dev) if self.sync_c is not self.sync else None
+                if bad is not None:
+                    print(f"[ppo] {bad}\n[ppo] DEGRADED: retrying with ONE communicator, actor and critic steps on one stream, eager "
+                          "launches", file=sys.stderr)
+                    self.dp_degraded = dict(reason=bad, mode="one communicator ('actor'), actor and critic steps on one stream, eager launches "
+                                                            "(no collective inside a hipGraph)")
+                    self.sync_c, self.overlap, self.use_graphs, self.dp_graph_mode = self.sync, False, False, None
+                    self.sync.mode = "eager (degraded)"
+                    bad = self.sync.probe(dev)                     # the retry: the remaining communicator must still work everywhere
+                    if bad is not None:
+                        raise pdist.CollectiveError("data-parallel PPO cannot continue after degrading: " + bad)
         self._graphs = {}
         self.graph_status = None           # set once a hipGraph capture has failed and the run continued eagerly (text for the logs)
         self._obs_pad = None

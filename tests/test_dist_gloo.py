@@ -208,3 +208,50 @@ def test_rank0_seed_and_parameters_reach_every_rank(tmp_path):
     mp.spawn(_seed_rank, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     s0, s1 = np.load(tmp_path / "s0.npy"), np.load(tmp_path / "s1.npy")
     assert list(s0) == list(s1) == [1000.0, 1.0]
+
+
+def _probe_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), PARTMANIP_PROBE_TIMEOUT="4")
+    from partmanip_amd import dist as pdist
+    pdist.init_from_env("gloo")
+    a = pdist.maybe_sync(name="actor")
+    c = pdist.GradSync(group=torch.distributed.new_group(), name="critic")
+    c2 = pdist.GradSync(group=torch.distributed.new_group(), name="spare")
+    a.mode = c.mode = c2.mode = "split"
+    res = [a.probe("cpu")]                                         # healthy: None everywhere
+    os.environ["PARTMANIP_TEST_COLLECTIVE_FAIL"] = "rank1:critic"
+    res.append(c.probe("cpu"))                                     # rank 1 alone sees an error: EVERY rank must learn it
+    os.environ["PARTMANIP_TEST_COLLECTIVE_FAIL"] = "rank1:spare:absent"
+    res.append(c2.probe("cpu"))                                    # rank 1 never joins: rank 0 runs into the time box
+    os.environ.pop("PARTMANIP_TEST_COLLECTIVE_FAIL")
+    res.append(a.probe("cpu"))                                     # the first communicator still works (fresh store keys)
+    x = torch.full((3,), float(rank + 1))
+    a.sum_(x)
+    # an all-reduce that fails past the probes names itself (here: a dtype no backend reduces)
+    try:
+        a._all_reduce(torch.zeros(2, dtype=torch.float8_e4m3fn))
+        res.append("no error")
+    except pdist.CollectiveError as e:
+        res.append(str(e))
+    except Exception as e:                                         # noqa: BLE001
+        res.append("other: " + type(e).__name__)
+    with open(os.path.join(out_dir, f"p{rank}.txt"), "w") as f:
+        f.write(repr((res, x.tolist())))
+    os._exit(0)                                                    # (rank 0's abandoned all-reduce of 'spare' never completes: no clean teardown)
+
+
+def test_first_collective_of_every_communicator_is_probed_and_the_outcome_agreed(tmp_path):
+    """dist.GradSync.probe: a failing first all-reduce on ONE rank is reported identically on EVERY rank
+    (agreement runs over the rendezvous store, not over the communicator under test) with rank / communicator / launch structure /
+    hint in the text; a rank that never joins shows up as a time-out on the others; a healthy communicator probes to None; a later
+    failing all-reduce raises CollectiveError naming the call."""
+    mp.spawn(_probe_rank, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (eval(open(tmp_path / f"p{r}.txt").read()) for r in (0, 1))
+    for (res, x), me in ((r0, 0), (r1, 1)):
+        assert res[0] is None and res[3] is None and x == [3.0, 3.0, 3.0]
+        assert "communicator 'critic' failed on 1 of 2 ranks" in res[1] and "rank 1: RuntimeError: PARTMANIP_TEST_COLLECTIVE_FAIL" in res[1]
+        assert f"seen from rank {me} of 2" in res[1] and "launch structure split" in res[1] and "every rank reached the same collective" in res[1]
+        assert "communicator 'spare' failed on 2 of 2 ranks" in res[2] and "rank 0: TimeoutError: no completion within 4 s" in res[2]
+        assert res[4].startswith("all-reduce #") and "communicator 'actor'" in res[4] and f"rank {me} of 2" in res[4], res[4]
+    assert r0[0][1].split(" -- seen from")[0] == r1[0][1].split(" -- seen from")[0]

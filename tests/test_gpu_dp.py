@@ -350,6 +350,38 @@ def test_bench_self_launches_n_ranks(tmp_path):
     assert rec["config"]["backend"] == "gloo"
 
 
+def test_bench_degrades_when_a_communicator_fails_on_one_rank(tmp_path):
+    """the first multi-device run must be diagnosable.  The first all-reduce of every communicator is
+    time-boxed and its outcome agreed over the rendezvous store (dist.GradSync.probe); here rank 1's probe of the SECOND
+    communicator ('critic') is made to fail: both ranks must print the diagnosis (rank, device, communicator, launch structure,
+    the NCCL_DEBUG / env hints), fall back TOGETHER to one communicator + one stream + eager launches, finish with equal
+    parameters, and the line must say so in config.data_parallel.degraded.  A failure of the DEFAULT communicator has nothing to
+    fall back to: the run stops with the diagnosis and prints no line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PARTMANIP_SHARE_GPU="1", PARTMANIP_DIST_BACKEND="gloo", PARTMANIP_TEST_COLLECTIVE_FAIL="rank1:critic", PARTMANIP_PROBE_TIMEOUT="20")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "state",
+           "--n-steps", "16", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    dp = json.loads(lines[0])["config"]["data_parallel"]
+    assert dp["degraded"] and "communicator 'critic'" in dp["degraded"]["reason"] and "rank 1: RuntimeError" in dp["degraded"]["reason"]
+    assert "one communicator" in dp["degraded"]["mode"] and dp["graph_mode"].startswith("eager (degraded")
+    assert dp["param_checksum_equal"] is True and dp["all_reduces_per_step"] > 0
+    assert out.stderr.count("DEGRADED: retrying with ONE communicator") == 2          # every rank said so
+    assert "NCCL_DEBUG" in out.stderr or "every rank reached the same collective" in out.stderr
+    # the default communicator: nothing to degrade to
+    env["PARTMANIP_TEST_COLLECTIVE_FAIL"] = "rank1:actor"
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "data-parallel PPO cannot start" in out.stderr and "communicator 'actor'" in out.stderr and "rank 1: RuntimeError" in out.stderr
+
+
 def test_bench_eight_ranks_on_the_headline_workload(tmp_path):
     """The driver's scaling run ends at `bench.py --gpus 8` on the headline (vision) workload, and nothing had ever started eight
     ranks of it.  Here all eight share the box's one GPU over gloo (T = 1 so that it takes a minute): eight processes rendezvous,
