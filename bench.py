@@ -823,13 +823,32 @@ def run_ppo(args, device, rank, world):
                 (ta, na), (tc, nc) = floor["a"], floor["c"]
                 mf = lambda dims: 3 * 2048 * F(dims) / (PEAK_F32_MFMA_TFLOPS * 1e12)
                 per_it = lambda t_epoch: w["N"] * w["T"] / (cfg["n_updates"] * t_epoch)
-                out["roofline"]["floor_us_per_step"] = dict(
+                # the PHYSICAL floor: a network step is ~9.1 dependent launches (profiles/round5_d_bench_state_kernel_stats.csv:
+                # 79 302 launches of the step's eight kernels over 8 704 network steps) at the guide's dependent-boundary cost inside a
+                # GEMM chain (MI355X_MICROARCH.md `boundary` row: 1.1-1.4 us; 1.2 taken) + its MFMA work at the fp32 peak; the two
+                # networks' chains share one chip, so a PAIR of steps cannot beat the sum of their MFMA work nor the longer chain
+                LPS, BOUNDARY_US = 9.1, 1.2
+                mfa, mfc = mf([w["O"]] + hid + [w["A"]]) * 1e6, mf([w["O"]] + hid + [1]) * 1e6
+                phys_pair = max(mfa + mfc, max(mfa, mfc) + LPS * BOUNDARY_US)
+                out["roofline"]["physical_floor_us_per_step"] = dict(
+                    launches_per_network_step=LPS, boundary_us=BOUNDARY_US, mfma_at_peak_actor=mfa, mfma_at_peak_critic=mfc,
+                    chain_floor_actor=mfa + LPS * BOUNDARY_US, chain_floor_critic=mfc + LPS * BOUNDARY_US, pair_floor=phys_pair,
+                    ceiling_env_steps_per_s=per_it(phys_pair * 1e-6 * na),
+                    measured_over_floor=(dt / args.steps / (cfg["n_updates"] * na) * 1e6) / phys_pair,
+                    note="what no schedule of THIS algorithm on this chip can beat: per network step 9.1 dependent launch boundaries at 1.2 us "
+                         "+ the step's MFMA work at 157.3 TFLOP/s; per (actor, critic) pair the larger of the two networks' summed MFMA "
+                         "work and the longer chain.  The measured chains (next block) are 2.5 x their chain floor: a 2048 x 512 x 512 "
+                         "layer takes 14.8 us where its MFMAs need 6.8 -- depth of the K loop at 128 tiles per launch, every XCD "
+                         "re-fetching W; round 6 A/B: each network on its own half of every XCD's CUs (CU-masked streams; a mask "
+                         "cannot select XCDs) measured 2.04 M against 2.29 M env-steps/s, profiles/round6_cfg2_cu_split_ab.txt")
+                out["roofline"]["chains_measured_us_per_step"] = dict(
                     actor_chain_alone=ta / na * 1e6, critic_chain_alone=tc / nc * 1e6, steps_per_epoch=na,
                     mfma_at_peak_actor=mf([w["O"]] + hid + [w["A"]]) * 1e6, mfma_at_peak_critic=mf([w["O"]] + hid + [1]) * 1e6,
                     measured_pair=dt / args.steps / (cfg["n_updates"] * na) * 1e6,
                     ceiling_env_steps_per_s_perfect_overlap=per_it(max(ta, tc)), env_steps_per_s_no_overlap=per_it(ta + tc),
                     overlap_efficiency=(ta + tc - dt / args.steps / cfg["n_updates"]) / min(ta, tc),
-                    note="chains = one epoch of a network's 16-step hipGraphs replayed alone on the idle chip (sum of its ~24 kernels per "
+                    note="a MEASUREMENT of today's kernels, not a floor (it was reported as `floor_us_per_step` in round 5): "
+                         "chains = one epoch of a network's 16-step hipGraphs replayed alone on the idle chip (sum of its ~9 kernels per "
                          "step + in-graph launch boundaries); measured_pair = wall time of the iteration per (actor step, critic step) "
                          "pair with both chains sharing the chip; overlap_efficiency = the fraction of the shorter chain hidden under "
                          "the longer one.  Beating ceiling_env_steps_per_s_perfect_overlap needs faster kernels or fewer launch "
@@ -944,7 +963,8 @@ def _brief(line):
     out = dict(metric=line["metric"], value=line["value"], unit=line["unit"], steps=line["steps"], warmup=line["warmup"],
                ms_per_step=line["ms_per_step"], dtype=line["dtype"], workload=line["config"]["workload"],
                roofline={k: r[k] for k in keep if k in r})
-    for k in ("hidden_layer_gemm", "gae_scan", "group_all", "floor_us_per_step"):
+    for k in ("hidden_layer_gemm", "gae_scan", "group_all", "physical_floor_us_per_step", "chains_measured_us_per_step", "useful_frac",
+              "useful_tflops", "present_tap_fraction", "useful_note", "floor_ms"):
         if k in r:
             out["roofline"][k] = r[k]
     if "cpu_baseline" in line:

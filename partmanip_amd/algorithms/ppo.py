@@ -153,6 +153,7 @@ class ppo:
                     bad = self.sync.probe(dev)                     # the retry: the remaining communicator must still work everywhere
                     if bad is not None:
                         raise pdist.CollectiveError("data-parallel PPO cannot continue after degrading: " + bad)
+        self.cu_split = os.environ.get("PARTMANIP_CU_SPLIT", "0") == "1" and self.overlap and self.sync is None
         self._graphs = {}
         self.graph_status = None           # set once a hipGraph capture has failed and the run continued eagerly (text for the logs)
         self._obs_pad = None
@@ -574,12 +575,21 @@ class ppo:
             slices = sorted({i for ep in lists_a + lists_c for i in ep if isinstance(i, tuple)})
             for net in (ac.actor, ac.critic):
                 net.precompute_plans(self._geom, views['obs'], slices)
-        main = torch.cuda.current_stream()
+        main = outer = torch.cuda.current_stream()
         if self.overlap:
             if self._side is None:
-                self._side, self._cap = torch.cuda.Stream(), torch.cuda.Stream()
+                if self.cu_split:
+                    # A/B: each network on its own HALF of every XCD's CUs (a CU mask cannot select XCDs:
+                    # ops.cu_masked_stream), so neither chain's work-groups queue behind the other's
+                    self._main_masked, self._side = ops.cu_masked_stream(0, 128), ops.cu_masked_stream(128, 128)
+                    self._cap = torch.cuda.Stream()
+                else:
+                    self._side, self._cap = torch.cuda.Stream(), torch.cuda.Stream()
+            if self.cu_split:
+                main = self._main_masked
+                main.wait_stream(outer)
             side = self._side
-            side.wait_stream(main)                                       # returns / advantages are ready
+            side.wait_stream(outer)                                      # returns / advantages are ready
         graphs = self._graph_table(views) if self.use_graphs else None
         chunk_a, chunk_c = [], []
         for ep, (la, lc) in enumerate(zip(lists_a, lists_c)):
@@ -614,7 +624,8 @@ class ppo:
                     self._replay(graphs, ('a', ia), lambda: self._actor_step(f, views, ia, self._stage), main)
                     self._replay(graphs, ('c', ic), lambda: self._critic_step(f, views, ic, self._stage_c), side)
                     continue
-                self._actor_step(f, views, ia, self._stage)
+                with torch.cuda.stream(main):
+                    self._actor_step(f, views, ia, self._stage)
                 if self.overlap:
                     with torch.cuda.stream(side):
                         self._critic_step(f, views, ic, self._stage_c)
@@ -622,7 +633,9 @@ class ppo:
                     self._pending_critic.append(ic)
             assert not chunk_a and not chunk_c, "a mini-batch chunk was left unissued at the end of the epoch"
         if self.overlap:
-            main.wait_stream(side)
+            outer.wait_stream(side)
+            if main is not outer:
+                outer.wait_stream(main)
         else:                                                            # reference order: critic loop afterwards
             for ic in self._pending_critic:
                 self._critic_step(f, views, ic, self._stage_c)

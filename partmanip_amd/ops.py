@@ -1216,6 +1216,29 @@ def depth_compact(world):
     return out, lengths
 
 
+_HIP_RT = [None]
+
+
+def cu_masked_stream(first, count, total=256):
+    """A HIP stream whose kernels may only occupy CU-mask bits [first, first + count) (hipExtStreamCreateWithCUMask), as a
+    torch.cuda.ExternalStream.  On the MI355X mask bit i is CU i // 8 of XCD i % 8 -- work-groups are still dealt round-robin over
+    ALL eight XCDs, and a mask that leaves an XCD without a CU is ignored (tools/ubench/cu_mask_probe.hip,
+    profiles/round6_cu_mask_probe.txt): a mask can split every XCD's CUs between two streams, it cannot give a stream its own
+    XCDs / L2s.  hipGraphs replayed into the stream keep the mask.  Never destroyed (process lifetime)."""
+    if _HIP_RT[0] is None:
+        _HIP_RT[0] = C.CDLL("libamdhip64.so")
+        _HIP_RT[0].hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+        _HIP_RT[0].hipExtStreamCreateWithCUMask.restype = C.c_int
+    words = (C.c_uint32 * ((total + 31) // 32))()
+    for i in range(first, first + count):
+        words[i // 32] |= 1 << (i % 32)
+    h = C.c_void_p()
+    rc = _HIP_RT[0].hipExtStreamCreateWithCUMask(C.byref(h), len(words), words)
+    if rc != 0 or not h.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(h.value)
+
+
 class FpsConfig(C.Structure):
     """pm_fps_config (include/partmanip_hip.h): the launch policy of the multi-work-group sampler, passed with every call."""
     _fields_ = [("max_groups", C.c_int), ("resident_cus", C.c_int), ("spin_limit", C.c_uint), ("spin_limit_set", C.c_int),
