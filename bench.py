@@ -690,6 +690,21 @@ def run_ppo(args, device, rank, world):
                                             "forward's algorithmic bytes (2.19 GB) but ~60x the op's own 38.5 MB (points in, "
                                             "features out); at < 0.5 TB/s (6 % of the HBM peak) the kernel stays MFMA-bound "
                                             "(DESIGN.md 3.2: backward -0.69 ms, forward +0.25 ms)")
+        # What the dominant kernel's time is made of: measured on ablation builds of pn_fwd_kernel in round 6
+        # (profiles/round6_pn_fwd_ablation.txt: -DPN_ABLATE builds, tools/time_enc.py, 2048 clouds).  The parts ADD UP to the launch:
+        # on gfx950 a SIMD's MFMA, VALU and VMEM issue slots are one port (profiles/HISTORY.md 3.2 micro-benchmarks).
+        out["roofline"]["floor_ms"] = dict(
+            mfma_at_2p4ghz=2.0 * ENC_MAC_PER_POINT * 1024 * 2048 / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e3,
+            mfma_and_barriers_measured=4.58, operand_issue=0.28, valu_stages=0.57,
+            valu_stage_parts=dict(layer1=0.095, layer2_tanh=0.087, saved_h2_copy=0.17, pooling=0.0, only_removable_together=0.22),
+            sum_of_parts=4.58 + 0.28 + 0.57, measured_same_run=5.43, this_run=mean_ms,
+            note="MFMAs + the five barriers per tile alone: 4.58 ms (= the 4.37 ms of 5120 MFMAs per 64-point tile at 2.4 GHz, at the "
+                 "~2.29 GHz the chip sustains under this load, barriers included); streaming the operands (ds_read_b128 + "
+                 "global_load_dwordx4 per 16 MFMAs) +0.28; layer 1, the two tanh epilogues and the saved-layer-2 copy +0.57 "
+                 "(pooling is free: it waits for the MFMA results anyway).  4.58 + 0.28 + 0.57 = 5.43 = the measured launch: "
+                 "0.80 of the 2.4 GHz peak (0.84 of the sustained-clock peak) is this structure's SUM, not a scheduling loss; "
+                 "0.86 needs 0.35 ms of VALU / VMEM work removed (the saved-h2 copy buys the backward 0.69 ms; halving the operand "
+                 "issue needs 128-point tiles = one work-group per CU)")
         bwd = ops.TIMER.mean_ms("pointnet_enc_bwd")
         if bwd:
             out["roofline"]["enc_bwd_mean_ms"] = bwd[0]

@@ -29,7 +29,8 @@
 #define PN_LD2 (PN_C2 + 4)
 #define PN_MAXC 8
 #ifndef PN_ABLATE
-#define PN_ABLATE 0          // profiling only: bit0 = skip layer-3 MFMAs, bit1 = skip layer-2 MFMAs (wrong results)
+#define PN_ABLATE 0          // profiling only (wrong results): forward 1 = no layer-3 MFMAs, 2 = no layer-2 MFMAs, 256 = no layer 1 (VALU), 512 = no tanh in the layer-2
+                             // epilogue, 1024 = no pooling, 2048 = no saved-h2 copy, 4096 = no point staging; 4 = no operand traffic in the MFMA loops; 8 .. 128: backward
 #endif
 #ifndef PN_FWD_NW
 #define PN_FWD_NW 8          // waves per forward work-group (4 or 8)
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
         asm volatile("" : "+v"(lane));
         const int li = lane & 31, lh = lane >> 5;
         __syncthreads();                          // Xs staged; previous tile's layer-3 reads of H are done
-        layer1_tile<CT, PN_TM, NT, TANH>(Xs, W1, b1, C, H, act);
+        if (!(PN_ABLATE & 256)) layer1_tile<CT, PN_TM, NT, TANH>(Xs, W1, b1, C, H, act);
         __syncthreads();
         {
             f32x16 acc2[2][NB2];
@@ -264,8 +265,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
             layer2_mfma<2, NB2>(H, P2v, wave, lane, acc2);
 #endif
             __syncthreads();                      // every wave has finished reading H1 (and Xs)
-            layer2_store<2, NB2, TANH>(acc2, b2, wave, lane, H, nullptr, act);
-            if (tile + 1 < ntiles) stage_points<PN_TM, NT>(xb, tile + 1, C, sub_mean, cen, Xs);
+            layer2_store<2, NB2, (PN_ABLATE & 512) ? false : TANH>(acc2, b2, wave, lane, H, nullptr, (PN_ABLATE & 512) ? PM_ACT_NONE : act);
+            if (!(PN_ABLATE & 4096) && tile + 1 < ntiles) stage_points<PN_TM, NT>(xb, tile + 1, C, sub_mean, cen, Xs);
         }
         __syncthreads();
 
@@ -281,8 +282,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
         mfma_stream<2, NB3, 32>(H + li * PN_LD2 + lh * 128, PN_LD2, P3v + (size_t)(wave * NB3) * 32 * 64 + lane, acc);
 #endif
         // ---- pooling over this tile's 64 points (rows), in increasing point order ------------
+#if (PN_ABLATE & 1024) && defined(__HIP_DEVICE_COMPILE__)   // timing probe: the layer-3 results stay live without the pooling arithmetic
 #pragma unroll
         for (int nb = 0; nb < NB3; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) asm volatile("" ::"v"(acc[mb][nb]));
+#endif
+#pragma unroll
+        for (int nb = 0; nb < ((PN_ABLATE & 1024) ? 0 : NB3); ++nb)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void pn_fwd_kernel(const float* __
         // (64 FLOP/B where the machine balance is ~20).  Costs the forward +0.25 ms per 2048 clouds (instruction
         // issue: 16 LDS/VMEM ops per thread and tile; plain, nt and sc1 stores, or storing from the layer-2
         // epilogue registers, all measure the same) and saves the backward 0.69 ms.
-        if (h2_save) {
+        if (h2_save && !(PN_ABLATE & 2048)) {
             float* dst = h2_save + ((long)b * P + (long)tile * PN_TM) * PN_C2;
 #pragma unroll 2
             for (int i = 0; i < PN_TM * PN_C2 / 4 / NT; ++i) {
