@@ -1568,7 +1568,10 @@ extern "C" int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const i
 // a work-group owns tiles of TM source points; every wave sums the rows of its TM/NW points into an LDS tile in the fixed order
 // (bit-identical to pm_sa_dy_segsum_f32: a sequential chain starting from the first row), the feature tile lands beside it, the
 // two products run on fp32 MFMA (dfeat: A from LDS, B = W1f streamed from its operand-order copy in L2; dW1f: both operands from
-// LDS, accumulators persistent in registers).  Two work-groups per CU: one's loads run under the other's MFMAs.
+// LDS, accumulators persistent in registers).  Two work-groups per CU.  Measured (round 6, tools/time_sa.py, -DSA_DYC_ABLATE builds):
+// 0.42 ms per launch = 0.30 ms with every load / store removed (MFMA floor 0.22) + 0.18 ms with the MFMAs removed, minus 0.05 of
+// overlap: VMEM issue slots and MFMAs share a SIMD's issue port, so they add up; 32-point tiles x 4 waves x 4 work-groups per CU,
+// 8 rows in flight per wave and half of the work-groups started half a tile late all measure the same (0.415-0.434).
 // HBM per point: 1.35 rows of 4*C1 B in + 4*CF B in + 4*CF B out (SA2 of the bench: 0.9 GB per launch for 34.4 GFLOP).
 #define SA_DYC_MAXGRID 1024
 #ifndef SA_DYC_TM
