@@ -370,7 +370,9 @@ int pm_group_points_bwd_f32(const float* dout, const int32_t* idx, int B, int P,
 int pm_group_concat_f32(const float* xyz, const float* feat, const float* centers, const int32_t* idx, int B, int P,
                         int Cf, int S, int nsample, int ldo, float* out, void* stream);
 /* Column-block copy: dst[r][d_b .. d_b + e_b - s_b) = src[r][s_b .. e_b) for two blocks b (an empty block: s == e); the other
- * columns of dst in [col0, dst_cols) are zeroed when zero_other != 0; columns below col0 are left alone.  The PointNet++ plug-in's
+ * columns of dst in [col0, dst_cols) are zeroed when zero_other != 0; columns below col0 are left alone.  A non-empty block must land
+ * inside [col0, dst_cols), the two blocks must not overlap, src may be NULL when both blocks are empty (zero-only), and dst == src is
+ * allowed only with blocks that read below col0 (PM_EINVAL otherwise -- never a silently skipped block).  The PointNet++ plug-in's
  * glue around its GEMMs in one launch each (weights in operand column order padded to the K-step, gradients back, [xyz | 0] behind the
  * group-all rows' features). */
 int pm_col_blocks_f32(float* dst, long ldd, const float* src, long lds, long rows, int dst_cols, int col0, int s0, int e0, int d0,

@@ -553,7 +553,7 @@ class PointNet2(_HipNet):
                 buf = self._sa_h2[l] = torch.empty(n, device=xyz.device)
             h2 = buf[:n]
         plan = None
-        if self.unique_rows and centers.shape[1] <= 1024:      # (the plan's per-cloud pass holds up to 1024 groups; more: the padded kernels)
+        if self._uses_plan(l, centers.shape[1]):               # (more than 1024 groups per cloud: the padded kernels)
             cache, key = plan_slot if plan_slot is not None else (None, None)
             if key is not None:
                 key = key + (dims,)                        # tile sizes follow the level's widths: actor and critic share a plan only when theirs agree
@@ -572,6 +572,12 @@ class PointNet2(_HipNet):
             arg = ops.sa_fwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
                              packed, dims, pooled, h2)
         return (idx_g, arg, "fused", xyz, feat, centers, Y, packed, dims, pooled, h2, plan, w1f)
+
+    PLAN_BATCH = 4                        # mini-batch slices whose plans are built before one host read trims them
+
+    def _uses_plan(self, l, S):
+        """Does level l run over packed rows (pm_sa_plan_i32)?  (The plan's per-cloud pass holds up to 1024 groups.)"""
+        return bool(self._fused[l] and self.unique_rows and S <= 1024)
 
     def _plan_inverse(self, l):
         """Does level l's plan carry the source point -> packed rows table (its layer-1 rows have a gradient to sum)?"""
@@ -611,7 +617,7 @@ class PointNet2(_HipNet):
                        dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws, h2)
         if cf == 0:
             if dW1.shape[1] > 3:
-                ops.col_blocks(dW1, dW1, [], col0=3)       # pad columns never receive data
+                ops.col_blocks(dW1, None, [], col0=3)      # pad columns never receive data (zero-only form)
             return None
         feat2 = feat.reshape(B * Pl, cf)
         dW1f = torch.empty_like(w1f)
@@ -655,11 +661,25 @@ class PointNet2(_HipNet):
         P, C = self.point_num, self.in_channels
         ws = self._workspace(obs.device)
         built = []
-        for lo, n in slices:
+
+        def flush():
+            # plans are built at their worst-case capacity (24 B per padded row + the inverse table): trimming in bounded batches --
+            # one host read per PLAN_BATCH slices -- keeps the transient at a few GB instead of all slices' capacities at once
+            if not built:
+                return
+            totals = torch.stack([pl.totals for _, pl in built]).cpu()
+            ready = torch.cuda.Event()
+            for (key, pl), t in zip(built, totals):
+                tabs.plans[key] = pl.trim((int(t[0]), int(t[1])))
+                pl.ready = ready
+            ready.record()
+            built.clear()
+
+        for k_, (lo, n) in enumerate(slices):
             xyz = None
             for l, S in enumerate(self.npoints):
                 centers, idx_g = tabs[l][0][lo:lo + n], tabs[l][1][lo:lo + n]
-                if self._fused[l] and self.unique_rows and S <= 1024:
+                if self._uses_plan(l, S):
                     lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
                     dims = (lin1.out_features, lin2.out_features, lin3.out_features)
                     key = (l, lo, n, dims)
@@ -668,14 +688,9 @@ class PointNet2(_HipNet):
                             xyz = obs[lo:lo + n, :P * C].reshape(n, P, C)[..., :3].contiguous() if l == 0 else tabs[l - 1][0][lo:lo + n]
                         built.append((key, ops.sa_plan(idx_g, xyz, centers, dims, ws, inverse=self._plan_inverse(l))))
                 xyz = centers
-        if not built:
-            return
-        totals = torch.stack([pl.totals for _, pl in built]).cpu()
-        ready = torch.cuda.Event()
-        for (key, pl), t in zip(built, totals):
-            tabs.plans[key] = pl.trim((int(t[0]), int(t[1])))
-            pl.ready = ready
-        ready.record()
+            if (k_ + 1) % self.PLAN_BATCH == 0:
+                flush()
+        flush()
 
     def use_geometry(self, tabs, rows):
         """Take the next forward's neighbourhood tables from `tabs`: rows = (lo, n) slice or an index tensor."""

@@ -519,7 +519,8 @@ extern "C" int pm_maxpool_rows_bwd_f32(const float* dout, long lddo, const int32
 // weight with its columns in the operand's order and padded to the K-step, its gradient back in the parameter's order, the
 // aligned copy of W1's feature columns, [xyz | 0] behind the pooled features of the group-all rows -- each of which was two to
 // four strided copy_ / zero_ launches of the tensor library (round 4: 6 % of the PointNet++ step's kernel time).
-__global__ __launch_bounds__(256) void col_blocks_kernel(float* __restrict__ dst, long ldd, const float* __restrict__ src, long lds,
+// (dst / src carry no __restrict__: the zero-only form -- no block, src == NULL -- and disjoint column ranges of ONE buffer are legal)
+__global__ __launch_bounds__(256) void col_blocks_kernel(float* dst, long ldd, const float* src, long lds,
                                                           long rows, int dst_cols, int col0, int s0, int e0, int d0, int s1, int e1,
                                                           int d1, int zero_other) {
     const int w = dst_cols - col0;
@@ -534,9 +535,21 @@ __global__ __launch_bounds__(256) void col_blocks_kernel(float* __restrict__ dst
 
 extern "C" int pm_col_blocks_f32(float* dst, long ldd, const float* src, long lds, long rows, int dst_cols, int col0, int s0, int e0,
                                  int d0, int s1, int e1, int d1, int zero_other, void* stream) {
-    PM_REQUIRE(dst && src && rows > 0 && dst_cols > 0 && col0 >= 0 && col0 < dst_cols && ldd >= dst_cols);
-    PM_REQUIRE(s0 >= 0 && e0 >= s0 && d0 >= 0 && d0 + (e0 - s0) <= dst_cols && e0 <= lds);
-    PM_REQUIRE(s1 >= 0 && e1 >= s1 && d1 >= 0 && d1 + (e1 - s1) <= dst_cols && e1 <= lds);
+    const int n0 = e0 - s0, n1 = e1 - s1;
+    PM_REQUIRE(dst && rows > 0 && dst_cols > 0 && col0 >= 0 && col0 < dst_cols && ldd >= dst_cols);
+    PM_REQUIRE(s0 >= 0 && n0 >= 0 && s1 >= 0 && n1 >= 0);
+    PM_REQUIRE(src || (n0 == 0 && n1 == 0));                   // src == NULL: zero-only (no block to copy)
+    // a block must land inside the written range [col0, dst_cols) -- one that starts below col0 would silently not be copied --
+    // read inside a source row, and the two blocks must not overlap (the first would win)
+    PM_REQUIRE(n0 == 0 || (d0 >= col0 && d0 + n0 <= dst_cols && e0 <= lds));
+    PM_REQUIRE(n1 == 0 || (d1 >= col0 && d1 + n1 <= dst_cols && e1 <= lds));
+    PM_REQUIRE(n0 == 0 || n1 == 0 || d0 + n0 <= d1 || d1 + n1 <= d0);
+    // the same buffer as source and destination: only with column ranges that do not touch what is written
+    if (src && (const float*)dst == src && (n0 || n1)) {
+        PM_REQUIRE(lds == ldd);
+        PM_REQUIRE(n0 == 0 || e0 <= col0);
+        PM_REQUIRE(n1 == 0 || e1 <= col0);
+    }
     const long n = rows * (dst_cols - col0);
     long blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;

@@ -1037,13 +1037,17 @@ def rows_gather_bwd(dcols, tidx, C, dsrc, tslot=None, mode=0, reverse=False, sel
 
 def col_blocks(dst, src, blocks, zero_other=True, col0=0, dst_cols=None):
     """dst[:, d : d + e - s] = src[:, s:e] for the (s, e, d) in `blocks` (at most two); the other columns of dst in [col0, dst_cols)
-    are zeroed if zero_other (pm_col_blocks_f32).  dst / src: 2-D float32 views with unit inner stride."""
+    are zeroed if zero_other (pm_col_blocks_f32).  dst / src: 2-D float32 views with unit inner stride; src=None with no block: zero-only.
+    Blocks must land inside [col0, dst_cols) and must not overlap (the library refuses otherwise)."""
     _req(dst, src)
-    if dst.dim() != 2 or src.dim() != 2 or dst.stride(1) != 1 or src.stride(1) != 1 or dst.shape[0] != src.shape[0]:
+    if dst.dim() != 2 or dst.stride(1) != 1 or (src is not None and (src.dim() != 2 or src.stride(1) != 1 or dst.shape[0] != src.shape[0])):
         raise ValueError("col_blocks: 2-D views with unit inner stride and equal row counts")
+    if src is None and blocks:
+        raise ValueError("col_blocks: blocks need a source")
     b = list(blocks) + [(0, 0, 0)] * (2 - len(blocks))
     (s0, e0, d0), (s1, e1, d1) = b
-    check(lib.pm_col_blocks_f32(_ptr(dst), dst.stride(0), _ptr(src), src.stride(0), dst.shape[0], dst.shape[1] if dst_cols is None else dst_cols,
+    check(lib.pm_col_blocks_f32(_ptr(dst), dst.stride(0), _ptr(src), src.stride(0) if src is not None else 0, dst.shape[0],
+                                dst.shape[1] if dst_cols is None else dst_cols,
                                 int(col0), s0, e0, d0, s1, e1, d1, int(zero_other), _stream()), "pm_col_blocks_f32")
     return dst
 

@@ -124,3 +124,20 @@ def test_col_blocks_copies_permuted_blocks_and_zero_fills():
     o.col_blocks(view, torch.from_numpy(src[:10, :8].copy()).to(DEV), [], col0=30)
     w[:, 4 + 30:36] = 0.0
     assert np.array_equal(big.cpu().numpy(), w)
+    # the zero-only form needs no source; a block that would land below col0 (silently not copied before), overlapping
+    # destination blocks, a block past the destination's columns and an in-place call touching what it writes are REFUSED
+    o.col_blocks(view, None, [], col0=28)
+    w[:, 4 + 28:36] = 0.0
+    assert np.array_equal(big.cpu().numpy(), w)
+    s8 = torch.from_numpy(src[:10, :8].copy()).to(DEV)
+    for bad in (dict(blocks=[(0, 8, 10)], col0=16),                    # destination starts below col0
+                dict(blocks=[(0, 8, 20), (0, 4, 24)], col0=16),        # the two blocks overlap in the destination
+                dict(blocks=[(0, 8, 28)], col0=16)):                   # runs past the last column
+        with pytest.raises(RuntimeError):
+            o.col_blocks(view, s8, **bad)
+    with pytest.raises(RuntimeError):
+        o.col_blocks(view, view, [(16, 24, 20)], col0=16)              # in place, reading what it writes
+    before = big.clone()
+    o.col_blocks(view, view, [(0, 8, 20)], zero_other=False, col0=16)  # in place, reading below col0: legal
+    before[:, 4 + 20:4 + 28] = before[:, 4:12]
+    assert torch.equal(big, before)
