@@ -625,7 +625,7 @@ def run_ppo(args, device, rank, world):
         # they run on two and share the chip, which stretches every launch), outside the timed region
         ov = run.overlap
         run.overlap = False
-        ops.TIMER.add(*[f"sa_{d}_{k}" for d in ("fwd", "bwd") for k in SA_LEVELS], "sa_groupall_fwd", "sa_groupall_bwd")
+        ops.TIMER.add(*[f"sa_{d}_{k}" for d in ("fwd", "bwd") for k in SA_LEVELS], "sa_groupall_fwd", "sa_groupall_bwd", "sa_dy_consume")
         step()
         torch.cuda.synchronize()
         ops.TIMER.disable()
@@ -751,7 +751,7 @@ def run_ppo(args, device, rank, world):
             lv[k] = dict(distinct_rows=R_, padded_rows=int(dense), rows_per_group=R_ / G_, tiles=T_)
             yb = R_ * c1 * 4.0 if l > 0 else 0.0               # level 2 gathers / scatters the per-source-point layer-1 rows
             algo = dict(fwd=R_ * (c2 * 4.0 + 8 + 12) + yb + G_ * c3 * 8.0,                    # h2 out, rowmap, xyz, pooled + arg out
-                        bwd=R_ * (c2 * 4.0 + 8 + 12) + 3 * yb + G_ * c3 * 12.0)               # h2 in, Y in, dY read-modify-write, pooled / dpooled / arg in
+                        bwd=R_ * (c2 * 4.0 + 8 + 12) + 2 * yb + G_ * c3 * 12.0)               # h2 in, Y in, dz1 rows out (round 6: no dY read-modify-write), pooled / dpooled / arg in
             for d_, macs in (("fwd", c1 * c2 + c2 * c3), ("bwd", 2 * c1 * c2 + c2 * c3)):
                 t = ops.TIMER.mean_ms(f"sa_{d_}_{k}")
                 if t:
@@ -760,6 +760,18 @@ def run_ppo(args, device, rank, world):
                     kern[f"sa_{d_}_{k}"] = dict(mean_launch_ms=t[0], launches=t[1], tflops=tf, frac=tf / PEAK_F32_MFMA_TFLOPS,
                                                 dense_equivalent_tflops=2 * dense * macs / (t[0] * 1e-3) / 1e12,
                                                 algorithmic_bytes=algo[d_], traffic=traffic)
+        # the consumer of level 2's layer-1 gradient rows (round 6): fixed-order per-source-point sums in LDS + dfeat = dY W1f +
+        # dW1f = dY^T feat on MFMA, one launch (was: zero-fill + fp32 atomics + two Linear launches + slab reduction + column copy)
+        tcons = ops.TIMER.mean_ms("sa_dy_consume")
+        if tcons and "128x128x256" in lv:
+            npts, c1_, cf_ = 2048.0 * net.npoints[0], 128, 128
+            fl = 2.0 * 2.0 * npts * c1_ * cf_
+            tf = fl / (tcons[0] * 1e-3) / 1e12
+            kern["sa_dy_consume_128x128"] = dict(mean_launch_ms=tcons[0], launches=tcons[1], tflops=tf, frac=tf / PEAK_F32_MFMA_TFLOPS,
+                                                 algorithmic_bytes=lv["128x128x256"]["distinct_rows"] * c1_ * 4.0 + 2 * npts * cf_ * 4.0, traffic=None,
+                                                 deterministic=True,
+                                                 note="dY = per-source-point sums of the packed rows' gradient in ascending row order (the plan's "
+                                                      "inverse table): no floating-point atomics, dY never written to HBM")
         # group-all level: its last layer (256 -> 512 over 64 rows per cloud) fused with the max over the cloud; the backward call
         # = dH (sorted winners, one running sum per column) + dW gather + finish: 3 x 2048 x 512 x 256 multiply-adds instead of
         # the two dense GEMMs (2 x 34.4 GFLOP) on the one-non-zero-per-(cloud, channel) gradient (csrc/sa_groupall.hip)
