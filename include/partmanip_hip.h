@@ -51,7 +51,7 @@ extern "C" {
 #define PM_ACT_MAX 6
 
 /* ABI version: major*10000 + minor*100 + patch */
-#define PM_ABI_VERSION 151 /* bumped whenever an entry point is added or a signature changes */
+#define PM_ABI_VERSION 152 /* bumped whenever an entry point is added or a signature changes */
 int pm_version(void);      /* returns PM_ABI_VERSION of the built library: loaders compare it with their header */
 
 /* ------------------------------------------------------------------ K1  GAE return scan
@@ -377,6 +377,11 @@ int pm_group_concat_f32(const float* xyz, const float* feat, const float* center
  * group-all rows' features). */
 int pm_col_blocks_f32(float* dst, long ldd, const float* src, long lds, long rows, int dst_cols, int col0, int s0, int e0, int d0,
                       int s1, int e1, int d1, int zero_other, void* stream);
+/* dst[q] = table[q] >= 0 ? src[table[q]] : 0 for q < n.  Every weight-derived operand copy of a network (the pack entry points'
+ * outputs, aligned / padded column blocks) is such a gather of the flat parameter buffer with a table fixed by the layouts: the host
+ * records the table once (by running the pack entry points on index-valued weights) and refreshes all copies with this ONE launch per
+ * forward instead of one tiny launch per copy. */
+int pm_gather_copy_f32(float* dst, const float* src, const int32_t* table, long n, void* stream);
 int pm_group_concat_bwd_f32(const float* dout, const int32_t* idx, int B, int P, int Cf, int S, int nsample, int ldo,
                             float* dfeat, void* stream);
 int pm_maxpool_rows_f32(const float* x, long G, int nsample, int C, float* out, long ldo, int32_t* arg, void* stream);
@@ -527,13 +532,17 @@ int pm_sa_plan_i32(const int32_t* idx, const float* xyz, const float* centers, i
 int pm_sa_fwd_packed_f32(const float* Y, int B, int P, int S, const int32_t* grow, const int32_t* rowmap, const float* relxyz,
                          const int32_t* tiles, const int32_t* totals, const float* W1, long ldw1, const float* b1, const float* b2,
                          const float* b3, const float* packed, int C1, int C2, int C3, float* pooled, long ldp, int32_t* arg,
-                         float* h2_save, void* stream);
+                         float* h2_save,
+                         const float* tail_xyz /* (B*S, 3) or NULL: columns [C3, C3 + tail_cols) of every pooled row = (x, y, z, 0 ...) -- the
+                                                  rows then ARE a group-all level's input rows [features | xyz | 0], no tail copy */,
+                         int tail_cols, void* stream);
 int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const int32_t* grow, const int32_t* rowmap, const float* relxyz,
                          const int32_t* tiles, const int32_t* totals, const float* W1, long ldw1, const float* b1, const float* b2,
                          const float* W3, const float* packed, int C1, int C2, int C3, const float* pooled, long ldp,
                          const int32_t* arg, const float* dpooled, long lddp, float* dW1, long lddw1, float* db1, float* dW2,
                          float* db2, float* dW3, float* db3, float* dY /* fp32 atomics: A/B only */,
                          float* dz1_rows /* (R, C1): the layer-1 gradient per packed row, plain stores (deterministic path) */,
+                         int dw1_zero_end /* columns [3, dw1_zero_end) of dW1 are zeroed (a level without input features: padding) */,
                          const float* h2_saved, void* workspace, size_t workspace_bytes, void* stream);
 /* The gradient of a level's per-source-point layer-1 rows (Y) WITHOUT floating-point atomics: a source point sits in several
  * groups, so dY[point] = sum of dz1 over its packed rows.  pm_sa_plan_inverse_i32 (coordinates only, once per plan) lists every

@@ -136,9 +136,10 @@ SIGNATURES = {
     "pm_sa_packed_tile": (I, [I, I, I, P, P]),
     "pm_sa_plan_workspace_bytes": (Z, [I, I]),
     "pm_sa_plan_i32": (I, [P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, Z, P]),
-    "pm_sa_fwd_packed_f32": (I, [P, I, I, I, P, P, P, P, P, P, L, P, P, P, P, I, I, I, P, L, P, P, P]),
+    "pm_sa_fwd_packed_f32": (I, [P, I, I, I, P, P, P, P, P, P, L, P, P, P, P, I, I, I, P, L, P, P, P, I, P]),
+    "pm_gather_copy_f32": (I, [P, P, P, L, P]),
     "pm_sa_bwd_packed_f32": (I, [P, I, I, I, P, P, P, P, P, P, L, P, P, P, P, I, I, I, P, L, P, P, L, P, L, P, P, P,
-                                 P, P, P, P, P, P, Z, P]),
+                                 P, P, P, P, I, P, P, Z, P]),
     "pm_sa_plan_inverse_i32": (I, [P, P, I, I, I, P, P, P]),
     "pm_sa_dy_segsum_f32": (I, [P, P, P, L, I, P, L, P]),
     "pm_sa_dy_consume_supported": (I, [I, I]),
@@ -190,7 +191,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 151                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
+ABI_VERSION = 152                      # == PM_ABI_VERSION in include/partmanip_hip.h (checked by tests/test_capi_symbols.py)
 if lib.pm_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} is stale: it reports ABI {lib.pm_version()}, this package needs {ABI_VERSION}. "
                       "Rebuild it with `python -m partmanip_amd.build`.")

@@ -80,6 +80,9 @@ class ActorCritic(nn.Module):
         vc, _ = rehome(c_params, flat_c, grad_c)
         self.actor.set_grad_views(va)
         self.critic.set_grad_views(vc)
+        # each network's slice of the flat parameter buffer (parameters() order): the source of its operand-copy gather
+        object.__setattr__(self.actor, "_param_flat", flat_a[:n_a])
+        object.__setattr__(self.critic, "_param_flat", flat_c[:n_c])
         object.__setattr__(self.actor, "_grad_list", [va[n] for n, _ in a_params])     # parameter order (autograd bridge)
         object.__setattr__(self.critic, "_grad_list", [vc[n] for n, _ in c_params])
         self._flat = dict(actor=flat_a, critic=flat_c, grad_actor=grad_a, grad_critic=grad_c, n_actor=n_a,

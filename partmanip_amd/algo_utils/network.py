@@ -82,8 +82,12 @@ class _LinearChain:
         self.w0p = None
         if x.shape[1] != self.linears[0].in_features or self.col_blocks is not None:
             w0 = self.linears[0].weight.data
-            self.w0p = torch.empty(w0.shape[0], x.shape[1], device=x.device)
-            ops.col_blocks(self.w0p, w0, self.col_blocks or [(0, w0.shape[1], 0)])        # one launch: permuted blocks + zero padding
+            ext = getattr(self, "w0p_ext", None)           # kept current by the owner's operand-copy gather (PointNet2._arena_refresh)
+            if ext is not None and ext.shape == (w0.shape[0], x.shape[1]) and ext.device == x.device:
+                self.w0p = ext
+            else:
+                self.w0p = torch.empty(w0.shape[0], x.shape[1], device=x.device)
+                ops.col_blocks(self.w0p, w0, self.col_blocks or [(0, w0.shape[1], 0)])    # one launch: permuted blocks + zero padding
         for i, lin in enumerate(self.linears):
             last = i == n - 1
             y = out if (last and out is not None) else torch.empty(cur.shape[0], lin.out_features, device=cur.device)
@@ -518,6 +522,9 @@ class PointNet2(_HipNet):
         self.sa_deterministic = bool(net_cfg.get('sa_deterministic', True))
         object.__setattr__(self, "_sa_dz1", [None] * len(self.npoints))
         self.sa_fused_dy = bool(net_cfg.get('sa_fused_dy', True))             # False: segmented-sum pass + the two Linear launches (A/B)
+        self.weight_arena = bool(net_cfg.get('weight_arena', True))           # False: one pack / copy launch per operand copy (A/B)
+        object.__setattr__(self, "_arena", None)
+        object.__setattr__(self, "_arena_views", None)
         object.__setattr__(self, "_sa_packed_w1f", [None] * len(self.npoints))
         object.__setattr__(self, "_sa_grads", None)
 
@@ -528,23 +535,104 @@ class PointNet2(_HipNet):
         if self._ga_chain is not None:
             self._ga_chain.grads = self._chains[-1].grads[:-1]
 
-    def _sa_forward_fused(self, l, xyz, feat, centers, idx_g, pooled, plan_slot=None):
+    # ---- operand copies of the weights: ONE gather per forward ------------------------------------------------------
+    # Before round 6 every forward re-packed its weights with one tiny launch per copy (two pm_sa_pack_weights_f32, the group-all
+    # pack, the aligned W1 feature block, the K-step-padded first group-all layer, the consumer's operand copy): six launches that
+    # each queue behind the other network's persistent kernels (6 % of the step's kernel time in rocprofv3).  All of them are
+    # gathers of the flat parameter buffer with a layout-fixed table: the table is recorded once by running those same entry
+    # points on index-valued weights, and a forward refreshes the whole arena with pm_gather_copy_f32.
+    def _arena_segments(self):
+        """[(key, numel)] of the weight-derived copies this configuration uses (16-byte aligned segments of one buffer)."""
+        segs = []
+        for l in range(len(self.npoints)):
+            if not self._fused[l]:
+                continue
+            lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
+            dims = (lin1.out_features, lin2.out_features, lin3.out_features)
+            segs.append((("sa_packed", l), int(ops.lib.pm_sa_packed_elems(*dims))))
+            cf = self.in_feats[l]
+            if cf > 0:
+                segs.append((("w1f", l), dims[0] * cf))
+                if ops.sa_dy_consume_supported(dims[0], cf):
+                    segs.append((("dyc", l), int(ops.lib.pm_sa_dy_consume_packed_elems(dims[0], cf))))
+        if self._ga_fused:
+            lin = self._chains[-1].linears[-1]
+            segs.append((("ga_packed",), int(ops.lib.pm_sa_groupall_packed_elems(lin.in_features, lin.out_features))))
+            w0 = self._ga_chain.linears[0].weight
+            ldo = (self.sa[-1][0].in_features + 31) // 32 * 32
+            if ldo != w0.shape[1] or self._ga_chain.col_blocks is not None:
+                segs.append((("ga_w0p",), w0.shape[0] * ldo))
+        return segs
+
+    def _arena_fill_by_entry_points(self, views):
+        """Every copy through its own entry point (the pre-round-6 path; also what records the gather table)."""
+        for key, v in views.items():
+            if key[0] == "sa_packed":
+                ops.sa_pack(self.sa[key[1]][2].weight.data, self.sa[key[1]][4].weight.data, v)
+            elif key[0] == "w1f":
+                cf = self.in_feats[key[1]]
+                ops.col_blocks(v.view(-1, cf), self.sa[key[1]][0].weight.data, [(3, 3 + cf, 0)], zero_other=False)
+            elif key[0] == "dyc":
+                ops.sa_dy_consume_pack(self.sa[key[1]][0].weight.data, self.in_feats[key[1]], v)
+            elif key[0] == "ga_packed":
+                ops.sa_groupall_pack(self._chains[-1].linears[-1].weight.data, v)
+            elif key[0] == "ga_w0p":
+                w0 = self._ga_chain.linears[0].weight.data
+                ops.col_blocks(v.view(w0.shape[0], -1), w0, self._ga_chain.col_blocks or [(0, w0.shape[1], 0)])
+
+    def _arena_refresh(self, device):
+        """Bring the operand copies up to date with the parameters; returns the views dict, or None when the parameters do not live
+        in one flat buffer (a network used outside ActorCritic.flat()): the callers then pack per copy as before."""
+        pf = getattr(self, "_param_flat", None)
+        first = next(self.parameters())
+        if not self.weight_arena or pf is None or pf.device != device or first.data_ptr() != pf.data_ptr() or pf.numel() >= (1 << 24):
+            return None
+        ar = getattr(self, "_arena", None)
+        if ar is None or ar["src_ptr"] != pf.data_ptr() or ar["buf"].device != device:
+            segs, off, views = self._arena_segments(), 0, {}
+            if not segs:
+                return None
+            offs = []
+            for key, n in segs:
+                offs.append((key, off, n))
+                off += (n + 63) // 64 * 64
+            buf = torch.zeros(off, device=device)
+            views = {key: buf[o:o + n] for key, o, n in offs}
+            # record the table: parameters := their flat index + 1 (exact in fp32 below 2^24), run the entry points, read the indices back
+            saved = pf.clone()
+            pf.copy_(torch.arange(1, pf.numel() + 1, device=device, dtype=torch.float32))
+            self._arena_fill_by_entry_points(views)
+            table = buf.round().to(torch.int32) - 1                      # untouched / padding slots hold 0 -> -1 -> written as 0
+            pf.copy_(saved)
+            ar = dict(buf=buf, table=table.contiguous(), views=views, src_ptr=pf.data_ptr())
+            object.__setattr__(self, "_arena", ar)
+        ops.gather_copy(ar["buf"], pf, ar["table"])
+        return ar["views"]
+
+    def _sa_forward_fused(self, l, xyz, feat, centers, idx_g, pooled, plan_slot=None, tail_xyz=None):
         """One fused SA level.  Layer 1's feature part is applied per SOURCE point (Y) by the Linear kernel."""
         B, Pl = xyz.shape[0], xyz.shape[1]
         lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
         dims = (lin1.out_features, lin2.out_features, lin3.out_features)
         cf = 0 if feat is None else feat.shape[2]
         Y, w1f = None, None
+        av = self._arena_views                              # operand copies refreshed by ONE gather at the top of hip_forward (or None)
         if cf > 0:
             # the feature columns of W1 start 12 bytes into a row: an aligned copy (64 KB) takes the 16-byte LDS-DMA loaders
-            w1f = ops.col_blocks(torch.empty(dims[0], cf, device=xyz.device), lin1.weight.data, [(3, 3 + cf, 0)], zero_other=False)
+            if av is not None:
+                w1f = av[("w1f", l)].view(dims[0], cf)
+            else:
+                w1f = ops.col_blocks(torch.empty(dims[0], cf, device=xyz.device), lin1.weight.data, [(3, 3 + cf, 0)], zero_other=False)
             Y = torch.empty(B * Pl, dims[0], device=xyz.device)
             ops.linear_fwd(feat.reshape(B * Pl, cf), w1f, None, Y, ops.ACT_NONE)
-        packed = self._sa_packed[l]
-        if packed is None or packed.device != xyz.device:
-            packed = torch.empty(int(ops.lib.pm_sa_packed_elems(*dims)), device=xyz.device)
-            self._sa_packed[l] = packed
-        ops.sa_pack(lin2.weight.data, lin3.weight.data, packed)
+        if av is not None:
+            packed = av[("sa_packed", l)]
+        else:
+            packed = self._sa_packed[l]
+            if packed is None or packed.device != xyz.device:
+                packed = torch.empty(int(ops.lib.pm_sa_packed_elems(*dims)), device=xyz.device)
+                self._sa_packed[l] = packed
+            ops.sa_pack(lin2.weight.data, lin3.weight.data, packed)
         h2 = None
         if self._save_h2_now:                              # training forward: keep layer 2 for the backward (reused buffer)
             n = idx_g.numel() * dims[1]
@@ -567,11 +655,11 @@ class PointNet2(_HipNet):
             elif plan.ready is not None:                   # built on another stream (actor || critic): its tables must be complete
                 torch.cuda.current_stream().wait_event(plan.ready)
             arg = ops.sa_fwd_packed(plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
-                                    packed, dims, pooled, h2)
+                                    packed, dims, pooled, h2, tail_xyz=tail_xyz)
         else:
             arg = ops.sa_fwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.bias.data,
                              packed, dims, pooled, h2)
-        return (idx_g, arg, "fused", xyz, feat, centers, Y, packed, dims, pooled, h2, plan, w1f)
+        return (idx_g, arg, "fused", xyz, feat, centers, Y, packed, dims, pooled, h2, plan, w1f, plan is not None and tail_xyz is not None)
 
     PLAN_BATCH = 4                        # mini-batch slices whose plans are built before one host read trims them
 
@@ -584,7 +672,7 @@ class PointNet2(_HipNet):
         return bool(self.sa_deterministic and self.in_feats[l] > 0)
 
     def _sa_backward_fused(self, l, rec, dpooled, ws, need_dfeat):
-        idx_g, arg, _, xyz, feat, centers, Y, packed, dims, pooled, h2, plan, w1f = rec
+        idx_g, arg, _, xyz, feat, centers, Y, packed, dims, pooled, h2, plan, w1f = rec[:13]
         B, Pl = xyz.shape[0], xyz.shape[1]
         lin1, lin2, lin3 = self.sa[l][0], self.sa[l][2], self.sa[l][4]
         (dW1, db1), (dW2, db2), (dW3, db3) = self._chains[l].grads
@@ -602,21 +690,25 @@ class PointNet2(_HipNet):
                               packed, dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, None, ws, h2, dz1=dz1)
             if fused_dy:
                 # the sums are consumed where they are formed: dfeat = dY W1f and dW1[:, 3:3+cf] = dY^T feat in ONE launch, dY in LDS only
-                pw = self._sa_packed_w1f[l]
-                if pw is None or pw.device != xyz.device:
-                    pw = self._sa_packed_w1f[l] = torch.empty(int(ops.lib.pm_sa_dy_consume_packed_elems(dims[0], cf)), device=xyz.device)
-                ops.sa_dy_consume_pack(lin1.weight.data, cf, pw)
+                av = self._arena_views
+                if av is not None:
+                    pw = av[("dyc", l)]
+                else:
+                    pw = self._sa_packed_w1f[l]
+                    if pw is None or pw.device != xyz.device:
+                        pw = self._sa_packed_w1f[l] = torch.empty(int(ops.lib.pm_sa_dy_consume_packed_elems(dims[0], cf)), device=xyz.device)
+                    ops.sa_dy_consume_pack(lin1.weight.data, cf, pw)
                 dfeat = torch.empty(B * Pl, cf, device=xyz.device) if need_dfeat else None
                 return ops.sa_dy_consume(plan, dz1, feat.reshape(B * Pl, cf), pw, dfeat, dW1, ws)
             ops.sa_dy_segsum(plan, dz1, dY)
         elif plan is not None:
             ops.sa_bwd_packed(plan, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data,
-                              packed, dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws, h2)
+                              packed, dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws, h2, zero_pad_cols=cf == 0)
         else:
             ops.sa_bwd(xyz, centers, idx_g, Y, lin1.weight.data, lin1.bias.data, lin2.bias.data, lin3.weight.data, packed,
                        dims, pooled, arg, dpooled, dW1, db1, dW2, db2, dW3, db3, dY, ws, h2)
         if cf == 0:
-            if dW1.shape[1] > 3:
+            if dW1.shape[1] > 3 and plan is None:          # (packed levels: the reduction launch zeroes them)
                 ops.col_blocks(dW1, None, [], col0=3)      # pad columns never receive data (zero-only form)
             return None
         feat2 = feat.reshape(B * Pl, cf)
@@ -719,6 +811,13 @@ class PointNet2(_HipNet):
         if geom is not None and geom[0][0].shape[0] != B:
             raise ValueError("use_geometry(): table rows do not match the batch")
         saved, ga_rows = [], None
+        object.__setattr__(self, "_arena_views", self._arena_refresh(x.device))
+        if self._arena_views is not None and ("ga_w0p",) in self._arena_views:
+            w0 = self._ga_chain.linears[0].weight
+            self._ga_chain.w0p_ext = self._arena_views[("ga_w0p",)].view(w0.shape[0], -1)
+        elif self._ga_chain is not None:
+            self._ga_chain.w0p_ext = None
+        tail_done = False
         for l, S in enumerate(self.npoints):
             plan_slot = None
             if geom is not None:
@@ -734,7 +833,10 @@ class PointNet2(_HipNet):
                     pooled = ga_rows[:, :c3]
                 else:
                     pooled = torch.empty(B * S, c3, device=x.device)
-                saved.append(self._sa_forward_fused(l, xyz, feat, centers, idx_g, pooled, plan_slot))
+                direct_rows = self._ga_direct and l == len(self.npoints) - 1
+                saved.append(self._sa_forward_fused(l, xyz, feat, centers, idx_g, pooled, plan_slot,
+                                                    tail_xyz=centers.reshape(B * S, 3) if direct_rows else None))
+                tail_done = tail_done or (direct_rows and saved[-1][13])
                 xyz, feat = centers, pooled.view(B, S, -1)
                 continue
             ldo = self.sa[l][0].in_features
@@ -748,7 +850,8 @@ class PointNet2(_HipNet):
         ldo = (self.sa[-1][0].in_features + 31) // 32 * 32     # zero columns up to the GEMM's K-step (the chain pads its weights alike)
         if ga_rows is not None:                            # the features are already in place: [features | xyz | 0]
             idx_all, rows, cf_ = None, ga_rows, feat.shape[2]
-            ops.col_blocks(rows, xyz.reshape(B * S, 3), [(0, 3, cf_)], col0=cf_)          # [features | xyz | 0]: the tail in one launch
+            if not tail_done:                              # (the packed level kernel writes [xyz | 0] behind its features itself)
+                ops.col_blocks(rows, xyz.reshape(B * S, 3), [(0, 3, cf_)], col0=cf_)      # [features | xyz | 0]: the tail in one launch
         else:
             idx_all = torch.arange(S, dtype=torch.int32, device=x.device).repeat(B, 1).view(B, 1, S)
             zeros = torch.zeros(B, 1, 3, device=x.device)
@@ -757,11 +860,14 @@ class PointNet2(_HipNet):
         if self._ga_fused:
             h = self._ga_chain.forward(rows)               # (B*S, CK): the layers before the last, tanh applied
             lin = self._chains[-1].linears[-1]
-            packed = self._ga_packed
-            if packed is None or packed.device != x.device:
-                packed = torch.empty(int(ops.lib.pm_sa_groupall_packed_elems(lin.in_features, lin.out_features)), device=x.device)
-                object.__setattr__(self, "_ga_packed", packed)
-            ops.sa_groupall_pack(lin.weight.data, packed)
+            if self._arena_views is not None:
+                packed = self._arena_views[("ga_packed",)]
+            else:
+                packed = self._ga_packed
+                if packed is None or packed.device != x.device:
+                    packed = torch.empty(int(ops.lib.pm_sa_groupall_packed_elems(lin.in_features, lin.out_features)), device=x.device)
+                    object.__setattr__(self, "_ga_packed", packed)
+                ops.sa_groupall_pack(lin.weight.data, packed)
             arg = ops.sa_groupall_fwd(h, B, S, lin.bias.data, packed, fbuf[:, :self.feat_dim])
             saved.append((idx_all, arg, "groupall", S, feat.shape[2], ldo, h, fbuf))
         else:

@@ -559,6 +559,29 @@ extern "C" int pm_col_blocks_f32(float* dst, long ldd, const float* src, long ld
     return PM_OK;
 }
 
+// ---- every weight-derived operand copy of a network in ONE launch ---------------------------------------------------------
+// The MFMA kernels stream their weights from operand-order copies (pm_sa_pack_weights_f32, pm_sa_groupall_pack_f32,
+// pm_sa_dy_consume_pack_f32), the Linear kernels want 16-byte-aligned / K-step-padded copies of misaligned column blocks
+// (pm_col_blocks_f32): six tiny launches per PointNet++ forward + backward, each of which queues behind the other network's
+// persistent kernels.  All of them are "dst[q] = parameter[t(q)] or 0" with t fixed by the layouts, so the host records t ONCE
+// (it runs the pack entry points on index-valued weights) and every later refresh is this one gather.
+__global__ __launch_bounds__(256) void gather_copy_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                           const int32_t* __restrict__ table, long n) {
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n; q += (long)gridDim.x * 256) {
+        const int t = table[q];
+        dst[q] = t >= 0 ? src[t] : 0.f;
+    }
+}
+
+extern "C" int pm_gather_copy_f32(float* dst, const float* src, const int32_t* table, long n, void* stream) {
+    PM_REQUIRE(dst && src && table && n > 0 && dst != src);
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gather_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, pm_stream(stream), dst, src, table, n);
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+}
+
 extern "C" int pm_version(void) { return PM_ABI_VERSION; }
 
 // ---- camera-sized clouds on SEVERAL work-groups per cloud ----------------------------------------------------------------

@@ -54,6 +54,7 @@ struct SaArgs {
     // layer-2 activations (G*32, C2): written by the training forward, read back by the backward instead of a
     // recompute (C2*4 B per row against 2*C1*C2 FLOP: 32-64 FLOP/B, machine balance ~20); null = recompute
     float* h2;
+    int tail_cols;           // packed forward with `centers`: columns [C3, C3 + tail_cols) of a pooled row = (centre x, y, z, 0 ...)
 };
 
 extern "C" size_t pm_sa_packed_elems(int C1, int C2, int C3) {
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(64 * SA_RED_G) void sa_bwd_reduce_kernel(const floa
                                                                       float* __restrict__ dW1, long lddw1,
                                                                       float* __restrict__ db1, float* __restrict__ dW2,
                                                                       float* __restrict__ db2, float* __restrict__ dW3,
-                                                                      float* __restrict__ db3) {
+                                                                      float* __restrict__ db3, int dw1_zero_end) {
     using P = SaPart<C1, C2, C3>;
     __shared__ float red[SA_RED_G][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -641,7 +642,11 @@ __global__ __launch_bounds__(64 * SA_RED_G) void sa_bwd_reduce_kernel(const floa
     else {
         const int j = i - P::O_DW1, c = j >> 2, d = j & 3;
         if (d < 3) dW1[c * lddw1 + d] = s;
-        else db1[c] = s;
+        else {
+            db1[c] = s;
+            // a level without input features: columns [3, dw1_zero_end) of its first weight are padding and never receive data
+            for (int z = 3; z < dw1_zero_end; ++z) dW1[c * lddw1 + z] = 0.f;
+        }
     }
 }
 
@@ -679,7 +684,7 @@ extern "C" int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32
                            0, pm_stream(stream), a);                                                               \
         constexpr int n = SaPart<C1_, C2_, C3_>::N;                                                                \
         hipLaunchKernelGGL((sa_bwd_reduce_kernel<C1_, C2_, C3_>), dim3((n + 63) / 64), dim3(64 * SA_RED_G), 0,             \
-                           pm_stream(stream), a.parts, (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3);            \
+                           pm_stream(stream), a.parts, (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3, 0);         \
     }
     if (SA_CFG_A(C1, C2, C3)) SA_BWD_LAUNCH(64, 64, 128, 64, 4, SA_A_BWD_WPE, SA_A_BWD_WPE)
     else SA_BWD_LAUNCH(128, 128, 256, SA_B_BWD_TM, SA_B_BWD_NW, (SA_B_BWD_NW / 4), 1)
@@ -1081,6 +1086,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void sa_fwd_pk_kernel(SaArgs a, SaPk 
                 const long g = td.y + j;
                 a.pooled[g * a.ldp + ch] = pm_tanh(best + bv);
                 a.arg[g * C3 + ch] = bi;
+                // the rows feed a group-all level directly ([features | xyz | 0], network.py): their tail in the same pass
+                if (a.centers && nb == 0 && s < a.tail_cols) a.pooled[g * a.ldp + C3 + s] = s < 3 ? a.centers[g * 3 + s] : 0.f;
             }
         }
         __syncthreads();
@@ -1099,15 +1106,18 @@ extern "C" int pm_sa_fwd_packed_f32(const float* Y, int B, int P, int S, const i
                                     const float* relxyz, const int32_t* tiles, const int32_t* totals,
                                     const float* W1, long ldw1, const float* b1, const float* b2, const float* b3,
                                     const float* packed, int C1, int C2, int C3, float* pooled, long ldp, int32_t* arg,
-                                    float* h2_save, void* stream) {
+                                    float* h2_save, const float* tail_xyz, int tail_cols, void* stream) {
     PM_REQUIRE(grow && rowmap && relxyz && tiles && totals && W1 && b1 && b2 && b3 && packed && pooled && arg);
     PM_REQUIRE(B > 0 && P > 0 && S > 0 && ldw1 >= 3 && ldp >= C3);
+    PM_REQUIRE(!tail_xyz || (tail_cols >= 3 && tail_cols <= 128 && C3 + tail_cols <= ldp));
     if (!pm_sa_supported(C1, C2, C3, SA_NS)) return PM_EUNSUPPORTED;
     if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)tiles & 15) != 0 || ((uintptr_t)relxyz & 15) != 0) return PM_EALIGN;
     SaArgs a = {};
     a.Y = Y; a.W1 = W1; a.ldw1 = ldw1; a.b1 = b1; a.b2 = b2; a.b3 = b3;
     a.packed = packed; a.pooled = pooled; a.ldp = ldp; a.arg = arg; a.G = (long)B * S; a.S = S; a.P = P;
     a.h2 = h2_save;
+    a.centers = tail_xyz;
+    a.tail_cols = tail_xyz ? tail_cols : 0;
     SaPk k = {grow, (const int2*)rowmap, (const float4*)relxyz, (const int4*)tiles, totals};
     const int ncu = sa_cu_count();
     if (SA_CFG_A(C1, C2, C3))
@@ -1525,10 +1535,10 @@ extern "C" int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const i
                                     const float* packed, int C1, int C2, int C3, const float* pooled, long ldp,
                                     const int32_t* arg, const float* dpooled, long lddp, float* dW1, long lddw1, float* db1,
                                     float* dW2, float* db2, float* dW3, float* db3, float* dY, float* dz1_rows,
-                                    const float* h2_saved, void* workspace, size_t workspace_bytes, void* stream) {
+                                    int dw1_zero_end, const float* h2_saved, void* workspace, size_t workspace_bytes, void* stream) {
     PM_REQUIRE(grow && rowmap && relxyz && tiles && totals && W1 && b1 && b2 && W3 && packed && pooled && arg && dpooled);
     PM_REQUIRE(dW1 && db1 && dW2 && db2 && dW3 && db3 && workspace);
-    PM_REQUIRE(B > 0 && P > 0 && S > 0 && ldw1 >= 3 && lddw1 >= 3 && ldp >= C3 && lddp >= C3);
+    PM_REQUIRE(B > 0 && P > 0 && S > 0 && ldw1 >= 3 && lddw1 >= 3 && ldp >= C3 && lddp >= C3 && dw1_zero_end <= lddw1);
     if (!pm_sa_supported(C1, C2, C3, SA_NS)) return PM_EUNSUPPORTED;
     if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)tiles & 15) != 0 || ((uintptr_t)relxyz & 15) != 0) return PM_EALIGN;
     if (workspace_bytes < pm_sa_bwd_workspace_bytes(C1, C2, C3)) return PM_EWORKSPACE;
@@ -1545,13 +1555,13 @@ extern "C" int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const i
         hipLaunchKernelGGL((sa_bwd_pk_kernel<64, 64, 128, 64, 4, 3, 20>), dim3((unsigned)grid), dim3(256), 0, pm_stream(stream), a, k);
         constexpr int n = SaPart<64, 64, 128>::N;
         hipLaunchKernelGGL((sa_bwd_reduce_kernel<64, 64, 128>), dim3((n + 63) / 64), dim3(64 * SA_RED_G), 0, pm_stream(stream), a.parts,
-                           (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3);
+                           (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3, dw1_zero_end);
     } else {
         const long grid = sa_pk_grid(a.G, ncu, 1, SA_BWD_MAXGRID);
         hipLaunchKernelGGL((sa_bwd_pk_kernel<128, 128, 256, 128, 16, 4, 28>), dim3((unsigned)grid), dim3(1024), 0, pm_stream(stream), a, k);
         constexpr int n = SaPart<128, 128, 256>::N;
         hipLaunchKernelGGL((sa_bwd_reduce_kernel<128, 128, 256>), dim3((n + 63) / 64), dim3(64 * SA_RED_G), 0, pm_stream(stream), a.parts,
-                           (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3);
+                           (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3, dw1_zero_end);
     }
     PM_CHECK_LAUNCH();
     return PM_OK;

@@ -830,8 +830,26 @@ def sa_dy_segsum(plan, dz1, dY):
     return dY
 
 
-def sa_fwd_packed(plan, Y, w1, b1, b2, b3, packed, dims, pooled, h2_save=None):
-    _req(Y, w1, packed, pooled)
+def gather_copy(dst, src, table):
+    """dst[q] = src[table[q]] (0 where table[q] < 0): all weight-derived operand copies of a network in one launch."""
+    _req(dst, src, table)
+    _f32c(dst, "dst")
+    _f32c(src, "src")
+    _i32c(table, "table")
+    if table.numel() != dst.numel():
+        raise ValueError("gather_copy: one table entry per destination element")
+    check(lib.pm_gather_copy_f32(_ptr(dst), _ptr(src), _ptr(table), dst.numel(), _stream()), "pm_gather_copy_f32")
+    return dst
+
+
+def sa_fwd_packed(plan, Y, w1, b1, b2, b3, packed, dims, pooled, h2_save=None, tail_xyz=None):
+    """tail_xyz (B*S, 3): the columns of `pooled`'s rows behind the C3 features become (x, y, z, 0 ...) -- pooled is then a view of
+    a group-all level's input rows and needs no tail copy."""
+    _req(Y, w1, packed, pooled, tail_xyz)
+    if tail_xyz is not None:
+        _f32c(tail_xyz, "tail_xyz")
+        if tuple(tail_xyz.shape) != (plan.B * plan.S, 3):
+            raise ValueError("sa_fwd_packed: tail_xyz must be (B*S, 3)")
     B, P, S = plan.B, plan.P, plan.S
     C1, C2, C3 = dims
     if tuple(dims) != plan.dims or pooled.shape[0] != B * S or (Y is not None and Y.shape[0] != B * P):
@@ -841,7 +859,8 @@ def sa_fwd_packed(plan, Y, w1, b1, b2, b3, packed, dims, pooled, h2_save=None):
         check(lib.pm_sa_fwd_packed_f32(_ptr(Y), B, P, S, _ptr(plan.grow), _ptr(plan.rowmap), _ptr(plan.relxyz),
                                        _ptr(plan.tiles), _ptr(plan.totals), _ptr(w1), _rows(w1, "w1"), _ptr(b1), _ptr(b2),
                                        _ptr(b3), _ptr(packed), C1, C2, C3, _ptr(pooled), _rows(pooled, "pooled"), _ptr(arg),
-                                       _ptr(h2_save), _stream()), "pm_sa_fwd_packed_f32")
+                                       _ptr(h2_save), _ptr(tail_xyz), (_rows(pooled, "pooled") - C3) if tail_xyz is not None else 0,
+                                       _stream()), "pm_sa_fwd_packed_f32")
     return arg
 
 
@@ -875,9 +894,10 @@ def sa_dy_consume(plan, dz1, feat, packed_w1f, dfeat, dw1, ws, dY=None):
 
 
 def sa_bwd_packed(plan, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpooled, dw1, db1, dw2, db2, dw3, db3, dY, ws, h2_saved=None,
-                  dz1=None):
+                  dz1=None, zero_pad_cols=False):
     """dz1 (R, C1): the layer-1 gradient per packed row (plain stores; sum it per source point with sa_dy_segsum) -- the
-    deterministic path; dY (B*P, C1) zero-filled: the same sums by fp32 atomics (run-dependent last bits; kept for A/B)."""
+    deterministic path; dY (B*P, C1) zero-filled: the same sums by fp32 atomics (run-dependent last bits; kept for A/B).
+    zero_pad_cols: a level without input features -- columns 3.. of dw1 are padding and are zeroed by the reduction launch."""
     _req(Y, w1, w3, packed, pooled, arg, dpooled, dw1, dw2, dw3, dY, dz1)
     if dz1 is not None:
         _f32c(dz1, "dz1")
@@ -894,8 +914,8 @@ def sa_bwd_packed(plan, Y, w1, b1, b2, w3, packed, dims, pooled, arg, dpooled, d
                                        _ptr(plan.tiles), _ptr(plan.totals), _ptr(w1), _rows(w1, "w1"), _ptr(b1), _ptr(b2),
                                        _ptr(w3), _ptr(packed), C1, C2, C3, _ptr(pooled), _rows(pooled, "pooled"), _ptr(arg),
                                        _ptr(dpooled), _rows(dpooled, "dpooled"), _ptr(dw1), _rows(dw1, "dw1"), _ptr(db1),
-                                       _ptr(dw2), _ptr(db2), _ptr(dw3), _ptr(db3), _ptr(dY), _ptr(dz1), _ptr(h2_saved), _ptr(w),
-                                       w.numel(), _stream()), "pm_sa_bwd_packed_f32")
+                                       _ptr(dw2), _ptr(db2), _ptr(dw3), _ptr(db3), _ptr(dY), _ptr(dz1), dw1.shape[1] if zero_pad_cols else 0,
+                                       _ptr(h2_saved), _ptr(w), w.numel(), _stream()), "pm_sa_bwd_packed_f32")
 
 
 # ----------------------------------------------------------------------------- sparse-voxel U-Net blocks

@@ -55,6 +55,36 @@ def test_library_exports_every_declared_symbol_and_ctypes_table_matches():
     assert so.pm_version() == want == _lib.ABI_VERSION
 
 
+def test_ctypes_table_matches_the_header_parameter_types_position_by_position():
+    """Round 6: a binding with the right NUMBER of parameters but an int where the header has a pointer (one slot off) is a memory
+    fault on the GPU box, not an error here -- so every position's C type is compared with its ctypes class: any `*` -> c_void_p,
+    int -> c_int, long -> c_long, size_t -> c_size_t, float -> c_float, double -> c_double, unsigned -> c_uint."""
+    from partmanip_amd import _lib
+    src = open(os.path.join(ROOT, "include", "partmanip_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    kinds = {"int": ctypes.c_int, "long": ctypes.c_long, "size_t": ctypes.c_size_t, "float": ctypes.c_float, "double": ctypes.c_double,
+             "unsigned": ctypes.c_uint, "int32_t": ctypes.c_int, "uint32_t": ctypes.c_uint}
+    checked = 0
+    for m in re.finditer(r"\b(int|size_t)\s+(pm_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        name, args = m.group(2), m.group(3).strip()
+        if args in ("", "void"):
+            continue
+        want = []
+        for a in args.split(","):
+            a = a.strip()
+            if "*" in a:
+                want.append(ctypes.c_void_p)
+            else:
+                toks = [t_ for t_ in a.replace("const", " ").split() if t_]
+                want.append(kinds[toks[0]])
+        got = _lib.SIGNATURES[name][1]
+        assert len(got) == len(want), name
+        for i, (g_, w_) in enumerate(zip(got, want)):
+            assert g_ is w_, f"{name}: parameter {i} is {w_.__name__} in the header, {g_.__name__} in the ctypes table"
+            checked += 1
+    assert checked > 1000
+
+
 def test_argument_validation_without_gpu():
     """Null pointers / bad sizes are rejected before any launch (safe on a GPU-less host)."""
     from partmanip_amd._lib import lib

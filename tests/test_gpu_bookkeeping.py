@@ -141,3 +141,52 @@ def test_col_blocks_copies_permuted_blocks_and_zero_fills():
     o.col_blocks(view, view, [(0, 8, 20)], zero_other=False, col0=16)  # in place, reading below col0: legal
     before[:, 4 + 20:4 + 28] = before[:, 4:12]
     assert torch.equal(big, before)
+
+
+def test_gather_copy_and_the_pointnet2_weight_arena_equal_the_per_copy_entry_points():
+    """pm_gather_copy_f32 (dst[q] = src[table[q]], 0 where table[q] < 0) and its use: every weight-derived operand copy of a
+    PointNet2 network (two pm_sa_pack_weights_f32 outputs, the aligned W1 feature block, the consumer's operand copy, the group-all
+    pack, the K-step-padded first group-all layer) refreshed by ONE gather whose table was recorded by running those entry points on
+    index-valued weights.  Outputs, arg-max tables and every parameter gradient of a forward + backward must be BIT-identical to the
+    per-copy path (`weight_arena: False`), before and after the parameters change in place (an optimiser step), and the arena must
+    hold exactly what the entry points write."""
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    src = torch.randn(1000, device=DEV, generator=g)
+    table = torch.randint(-1, 1000, (5000,), device=DEV, generator=g, dtype=torch.int32)
+    dst = torch.full((5000,), 9.0, device=DEV)
+    o.gather_copy(dst, src, table)
+    want = torch.where(table >= 0, src[table.clamp(min=0).long()], torch.zeros(()).to(DEV))
+    assert torch.equal(dst, want)
+
+    from partmanip_amd.algo_utils import ActorCritic
+    from tests.golden import cases
+    from tests.helpers import t
+    B, P, A = 24, 1024, 6
+    x = (torch.rand(B, P, 3, device=DEV, generator=g) * 2 - 1).reshape(B, 3 * P)
+    dy = torch.randn(B, A, device=DEV, generator=g)
+    res = {}
+    for arena in (True, False):
+        net = dict(name="PointNet2", activation="tanh", weight_arena=arena)
+        sd = cases.actor_critic_state(net, 3 * P, A, 0.5, 21)
+        ac = ActorCritic(3 * P, A, dict(action_std=0.5, action_activate="tanh", clipAction=1.0, network=net)).to(DEV)
+        ac.load_state_dict({k: t(v.copy()) for k, v in sd.items()})
+        f = ac.flat()
+        outs = []
+        for step in range(2):
+            out = ac.actor.hip_forward(x)
+            assert (ac.actor._arena_views is not None) == arena
+            ac.actor.hip_backward(dy)
+            outs.append((out.clone(), [s_[1].clone() for s_ in ac.actor._saved], f["grad_actor"][:f["n_actor"]].clone()))
+            if arena:                                          # the arena holds exactly what the entry points write
+                views = ac.actor._arena_views
+                assert {k[0] for k in views} == {"sa_packed", "w1f", "dyc", "ga_packed", "ga_w0p"}
+                ref = {k: torch.full_like(v, float("nan")) for k, v in views.items()}
+                ac.actor._arena_fill_by_entry_points(ref)
+                for k in views:
+                    assert torch.equal(views[k], ref[k]), k
+            f["actor"][:f["n_actor"]].add_(0.01 * torch.sin(torch.arange(f["n_actor"], device=DEV, dtype=torch.float32)))   # "an optimiser step"
+        res[arena] = outs
+    for (o1, a1, g1), (o2, a2, g2) in zip(res[True], res[False]):
+        assert torch.equal(o1, o2) and all(torch.equal(p_, q_) for p_, q_ in zip(a1, a2)) and torch.equal(g1, g2)
+    assert not torch.equal(res[True][0][0], res[True][1][0])               # the second forward did see the changed parameters
