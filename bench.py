@@ -46,6 +46,10 @@ WORKLOADS = {
                   net=dict(name="MLP", hid_dim=[512, 512, 512], activation="tanh")),
 }
 SA_LEVELS = {"64x64x128": (64, 64, 128, 256), "128x128x256": (128, 128, 256, 64)}     # C1, C2, C3, groups per cloud
+# the Linear launches left around the fused PointNet++ kernels at a 2048-cloud mini-batch (ops.py brackets them by shape): the
+# per-source-point layer-1 rows of level 2 (Y = feat W1f^T), the group-all level's first layer and its two gradients
+PN2_GLUE_GEMMS = {"linear_fwd_524288x128x128": 2.0 * 524288 * 128 * 128, "linear_fwd_131072x288x256": 2.0 * 131072 * 288 * 256,
+                  "linear_bwd_data_131072x256x256": 2.0 * 131072 * 256 * 256, "linear_bwd_weight_131072x256x288": 2.0 * 131072 * 256 * 288}
 
 DAGGER = dict(name="dagger_pointnet_student_4096env_x_16buf_x_{P}pt", N=4096, buf=16, O_t=53, A=10)
 
@@ -625,7 +629,8 @@ def run_ppo(args, device, rank, world):
         # they run on two and share the chip, which stretches every launch), outside the timed region
         ov = run.overlap
         run.overlap = False
-        ops.TIMER.add(*[f"sa_{d}_{k}" for d in ("fwd", "bwd") for k in SA_LEVELS], "sa_groupall_fwd", "sa_groupall_bwd", "sa_dy_consume")
+        ops.TIMER.add(*[f"sa_{d}_{k}" for d in ("fwd", "bwd") for k in SA_LEVELS], "sa_groupall_fwd", "sa_groupall_bwd", "sa_dy_consume",
+                      *PN2_GLUE_GEMMS)
         step()
         torch.cuda.synchronize()
         ops.TIMER.disable()
@@ -772,6 +777,17 @@ def run_ppo(args, device, rank, world):
                                                  deterministic=True,
                                                  note="dY = per-source-point sums of the packed rows' gradient in ascending row order (the plan's "
                                                       "inverse table): no floating-point atomics, dY never written to HBM")
+        glue = {}
+        for n_, fl_ in PN2_GLUE_GEMMS.items():
+            tg = ops.TIMER.mean_ms(n_)
+            if tg:
+                glue[n_] = dict(mean_call_ms=tg[0], calls=tg[1], tflops=fl_ / (tg[0] * 1e-3) / 1e12, frac=fl_ / (tg[0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)
+        if glue:
+            tot_ms, tot_fl = sum(v["mean_call_ms"] for v in glue.values()), sum(PN2_GLUE_GEMMS[k_] for k_ in glue)
+            glue["all"] = dict(ms_per_network_step=tot_ms, tflops=tot_fl / (tot_ms * 1e-3) / 1e12, frac=tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                               note="gemm2_dma_kernel (128 x 64 tiles) on K = 128 / 256 / 288: 4-9 K-steps per tile, i.e. prologue + epilogue per tile "
+                                    "weigh as much as the loop; 32 FLOP per HBM byte at K = N = 128 -- these launches sit ON the roofline's ridge "
+                                    "(0.10 ms of HBM time against 0.11 ms of MFMA time for the first one)")
         # group-all level: its last layer (256 -> 512 over 64 rows per cloud) fused with the max over the cloud; the backward call
         # = dH (sorted winners, one running sum per column) + dW gather + finish: 3 x 2048 x 512 x 256 multiply-adds instead of
         # the two dense GEMMs (2 x 34.4 GFLOP) on the one-non-zero-per-(cloud, channel) gradient (csrc/sa_groupall.hip)
@@ -792,7 +808,7 @@ def run_ppo(args, device, rank, world):
                                  frac_of_hbm=by / (gb[0] * 1e-3) / 1e9 / PEAK_HBM_GBS, dense_gemm_flops_not_executed=2 * 2.0 * rows_ga * 256 * 512)
         if kern:
             name = max(kern, key=lambda n: kern[n]["mean_launch_ms"] * kern[n]["launches"])
-            out["roofline"] = dict(group_all=ga, bound="mfma", kernel=name, achieved=kern[name]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
+            out["roofline"] = dict(group_all=ga, glue_gemms=glue, bound="mfma", kernel=name, achieved=kern[name]["tflops"], peak=PEAK_F32_MFMA_TFLOPS,
                                    unit="TFLOP/s", frac=kern[name]["tflops"] / PEAK_F32_MFMA_TFLOPS, traffic=kern[name]["traffic"],
                                    algorithmic_bytes=kern[name]["algorithmic_bytes"],
                                    launches=kern[name]["launches"], mean_launch_ms=kern[name]["mean_launch_ms"], kernels=kern,
@@ -986,7 +1002,7 @@ def _brief(line):
     """The part of a workload's line that the default line carries as a `secondary` entry."""
     r = line.get("roofline") or {}
     keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "fwd_mean_ms", "bwd_mean_ms",
-            "level_rows", "flops_per_env_step", "mean_launch_ms", "kernels", "levels", "latency", "traffic_note")
+            "level_rows", "flops_per_env_step", "mean_launch_ms", "kernels", "levels", "latency", "traffic_note", "glue_gemms")
     out = dict(metric=line["metric"], value=line["value"], unit=line["unit"], steps=line["steps"], warmup=line["warmup"],
                ms_per_step=line["ms_per_step"], dtype=line["dtype"], workload=line["config"]["workload"],
                roofline={k: r[k] for k in keep if k in r})

@@ -158,17 +158,19 @@ def linear_fwd(x, w, b, y, act):
     _req(x, w, b, y)
     M, K = x.shape
     N = w.shape[0]
-    check(lib.pm_linear_fwd_f32(_ptr(x), _rows(x, "x"), _ptr(w), _rows(w, "w"), _ptr(b), _ptr(y), _rows(y, "y"),
-                                M, N, K, act, _stream()), "pm_linear_fwd_f32")
+    with (TIMER.bracket(f"linear_fwd_{M}x{K}x{N}") if TIMER.enabled else _NULL):     # (bench.py names the glue GEMMs it wants timed by shape)
+        check(lib.pm_linear_fwd_f32(_ptr(x), _rows(x, "x"), _ptr(w), _rows(w, "w"), _ptr(b), _ptr(y), _rows(y, "y"),
+                                    M, N, K, act, _stream()), "pm_linear_fwd_f32")
 
 
 def linear_bwd_data(dy, w, h, dx, act):
     _req(dy, w, h, dx)
     M, N = dy.shape
     K = w.shape[1]
-    check(lib.pm_linear_bwd_data_f32(_ptr(dy), _rows(dy, "dy"), _ptr(w), _rows(w, "w"), _ptr(h),
-                                     _rows(h, "h") if h is not None else 0, _ptr(dx), _rows(dx, "dx"), M, N, K, act,
-                                     _stream()), "pm_linear_bwd_data_f32")
+    with (TIMER.bracket(f"linear_bwd_data_{M}x{N}x{K}") if TIMER.enabled else _NULL):
+        check(lib.pm_linear_bwd_data_f32(_ptr(dy), _rows(dy, "dy"), _ptr(w), _rows(w, "w"), _ptr(h),
+                                         _rows(h, "h") if h is not None else 0, _ptr(dx), _rows(dx, "dx"), M, N, K, act,
+                                         _stream()), "pm_linear_bwd_data_f32")
     return dx
 
 
@@ -177,8 +179,9 @@ def linear_bwd_weight(dy, x, dw, db, ws):
     M, N = dy.shape
     K = x.shape[1]
     w = ws.get(lib.pm_linear_bwd_weight_workspace_bytes(M, N, K))
-    check(lib.pm_linear_bwd_weight_f32(_ptr(dy), _rows(dy, "dy"), _ptr(x), _rows(x, "x"), _ptr(dw), _rows(dw, "dw"),
-                                       _ptr(db), M, N, K, _ptr(w), w.numel(), _stream()), "pm_linear_bwd_weight_f32")
+    with (TIMER.bracket(f"linear_bwd_weight_{M}x{N}x{K}") if TIMER.enabled else _NULL):
+        check(lib.pm_linear_bwd_weight_f32(_ptr(dy), _rows(dy, "dy"), _ptr(x), _rows(x, "x"), _ptr(dw), _rows(dw, "dw"),
+                                           _ptr(db), M, N, K, _ptr(w), w.numel(), _stream()), "pm_linear_bwd_weight_f32")
 
 
 # ---- grouped forms: several independent problems of one kind in ONE launch (the actor's and the critic's layer l; all
