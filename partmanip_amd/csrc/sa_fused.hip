@@ -719,6 +719,12 @@ extern "C" int pm_sa_bwd_f32(const float* xyz, const float* centers, const int32
 #ifndef SA_PK_ABLATE
 #define SA_PK_ABLATE 0   // timing probes (wrong results): bwd 1 = no dW3, 2 = no dH2 MFMA, 4 = no layer-1 recompute, 8 = no P7, 16 = no dW2 / dH1 MFMA; fwd 32 = no pooling pass, 64 = no layer 2 / 3 MFMA
 #endif
+#ifndef SA_A_PK_BWD_WPE
+#define SA_A_PK_BWD_WPE 3     // work-groups per CU of the SA1-shaped packed backward (49.6 KB of LDS each; A/B: 2)
+#endif
+#ifndef SA_B_PK_BWD_NW
+#define SA_B_PK_BWD_NW 16     // waves of the SA2-shaped packed backward's work-group (one per CU); 8: two row blocks per wave (A/B)
+#endif
 #ifndef SA_PK_DZ3_LDS
 #define SA_PK_DZ3_LDS 1   // 1: the layer-3 gradient rows of a channel window are BUILT ONCE PER TILE in LDS (zero-fill + one store per
                           // (group, channel)) and the dH2 product streams its A operand from there; 0: every lane builds its operand
@@ -1551,14 +1557,15 @@ extern "C" int pm_sa_bwd_packed_f32(const float* Y, int B, int P, int S, const i
     SaPk k = {grow, (const int2*)rowmap, (const float4*)relxyz, (const int4*)tiles, totals};
     const int ncu = sa_cu_count();
     if (SA_CFG_A(C1, C2, C3)) {
-        const long grid = sa_pk_grid(a.G, ncu, 3, SA_BWD_MAXGRID);
-        hipLaunchKernelGGL((sa_bwd_pk_kernel<64, 64, 128, 64, 4, 3, 20>), dim3((unsigned)grid), dim3(256), 0, pm_stream(stream), a, k);
+        const long grid = sa_pk_grid(a.G, ncu, SA_A_PK_BWD_WPE, SA_BWD_MAXGRID);
+        hipLaunchKernelGGL((sa_bwd_pk_kernel<64, 64, 128, 64, 4, SA_A_PK_BWD_WPE, 20>), dim3((unsigned)grid), dim3(256), 0, pm_stream(stream), a, k);
         constexpr int n = SaPart<64, 64, 128>::N;
         hipLaunchKernelGGL((sa_bwd_reduce_kernel<64, 64, 128>), dim3((n + 63) / 64), dim3(64 * SA_RED_G), 0, pm_stream(stream), a.parts,
                            (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3, dw1_zero_end);
     } else {
         const long grid = sa_pk_grid(a.G, ncu, 1, SA_BWD_MAXGRID);
-        hipLaunchKernelGGL((sa_bwd_pk_kernel<128, 128, 256, 128, 16, 4, 28>), dim3((unsigned)grid), dim3(1024), 0, pm_stream(stream), a, k);
+        hipLaunchKernelGGL((sa_bwd_pk_kernel<128, 128, 256, 128, SA_B_PK_BWD_NW, SA_B_PK_BWD_NW / 4, 28>), dim3((unsigned)grid),
+                           dim3(SA_B_PK_BWD_NW * 64), 0, pm_stream(stream), a, k);
         constexpr int n = SaPart<128, 128, 256>::N;
         hipLaunchKernelGGL((sa_bwd_reduce_kernel<128, 128, 256>), dim3((n + 63) / 64), dim3(64 * SA_RED_G), 0, pm_stream(stream), a.parts,
                            (int)grid, dW1, lddw1, db1, dW2, db2, dW3, db3, dw1_zero_end);
