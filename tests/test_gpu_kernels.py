@@ -805,7 +805,8 @@ def test_sa_kernels_are_invariant_to_neighbour_order_at_bench_size(dims, P, S, c
 
 
 @pytest.mark.parametrize("dims,P,S,cf,radius", [((64, 64, 128), 1024, 256, 0, 0.2), ((128, 128, 256), 256, 64, 128, 0.4),
-                                                 ((64, 64, 128), 300, 40, 0, 5.0), ((128, 128, 256), 200, 24, 128, 0.05)])
+                                                 ((64, 64, 128), 300, 40, 0, 5.0), ((128, 128, 256), 200, 24, 128, 0.05),
+                                                 ((128, 128, 256), 96, 48, 128, 5.0)])
 def test_sa_packed_rows_equal_the_dense_level(dims, P, S, cf, radius):
     """The duplicate-free form of the fused level (pm_sa_plan_i32 + pm_sa_*_packed_f32) against the dense kernels on the
     same neighbourhood table: the plan's tables against a numpy restatement (distinct rows per group = entries that

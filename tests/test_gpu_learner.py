@@ -13,6 +13,8 @@ Stated tolerances (fp32 everywhere; differences come only from summation order):
 """
 import tempfile
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -990,3 +992,15 @@ def test_rms_kernels_against_restatement(N, D):
         np.testing.assert_allclose(norm.running_ms.mean.cpu().numpy(), ref.mean.numpy(), rtol=2e-6, atol=2e-6)
         np.testing.assert_allclose(norm.running_ms.S.cpu().numpy(), ref.S.numpy(), rtol=5e-6, atol=2e-7)
         np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_pointnet2_forward_backward_is_bit_reproducible():
+    """VERDICT r5 next #1 in the suite (the long form: tools/stress_pointnet2.py --reps 1000 --noise): the same PointNet++ forward +
+    backward repeated under a noise stream -- output and every parameter gradient hashed -- must not change a bit (round 6: the
+    level-1 dY sums run in a fixed order, no floating-point atomics)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "tools/stress_pointnet2.py", "--reps", "60", "--B", "256", "--noise"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "repetitions that differed: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
