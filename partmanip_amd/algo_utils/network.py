@@ -1178,6 +1178,14 @@ class SparseUNet(_HipNet):
         e = lambda r, c: torch.empty(r, c, device=dev)
         N = B * c0
         u0, um0, rank0 = ops.rows_uniq(s["arg"], c0, R0, row_base=P)
+        if _os.environ.get("PARTMANIP_DEBUG_COMPACT") == "1":
+            # this backward sums a coarse row's children through `parent` (every row has one), the dense form through `child`
+            # (canonical rows only) -- equal because a duplicate-coordinate row never wins the max-pool.  Debug check of exactly that
+            # (a host read): every winner is the canonical row of its cell.
+            win = u0[u0 < R0].long()
+            pc = g["l1"]["parent_canon"].view(-1)[win]
+            if bool((pc < 0).any()):
+                raise RuntimeError("SparseUNet compact decoder backward: a duplicate-coordinate row won the max-pool")
         u1, um1, rank1 = ops.rows_uniq(u0, c0, R1, table=g["l1"]["parent"].view(-1), pad_in=R0)
         u2, um2, rank2 = ops.rows_uniq(u1, c0, R2, table=g["l2"]["parent"].view(-1), pad_in=R1)
         sel = lambda t, um: ops.rows_gather(t, um.view(N, 1), t.shape[1], e(N, t.shape[1]))      # padding slots: zero rows

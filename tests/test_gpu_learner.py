@@ -11,9 +11,8 @@ Stated tolerances (fp32 everywhere; differences come only from summation order):
   encoder features .................. 3e-6 relative to feature scale; argmax equal wherever the
                                        top-2 gap exceeds 1e-5
 """
-import tempfile
-
 import os
+import tempfile
 
 import numpy as np
 import pytest

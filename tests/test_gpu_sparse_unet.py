@@ -187,13 +187,14 @@ def test_fused_and_materialised_gathers_agree_bit_for_bit():
 
 
 @pytest.mark.parametrize("net", [NET, NET_WIDE])
-def test_compact_decoder_backward_equals_the_dense_one(net):
+def test_compact_decoder_backward_equals_the_dense_one(net, monkeypatch):
     """`sparse_top`: the cloud-wide max-pool leaves one non-zero per (cloud, channel), so max-pool, up0, up1 and conv2's weight
     gradient run over the winners' rows and their ancestors only (network.py::_decoder_backward_compact).  Same gradients as the
     dense form up to summation order -- on clouds with duplicate voxels and padding tails (several winners share a row / a parent)."""
     from partmanip_amd.algo_utils import ActorCritic
     from partmanip_amd.autograd import backbone_apply
     P, Rg, A, B = net["point_num"], net["grid"], 4, 9
+    monkeypatch.setenv("PARTMANIP_DEBUG_COMPACT", "1")    # (also run the debug check: no duplicate-coordinate row wins the max-pool)
     sd = cases.actor_critic_state(net, 4 * P, A, 0.5, 45)
     x = t(cases.sparse_clouds(B, P, Rg, 15, n_distinct=75, pad_tail=4)).to(DEV)
     w = torch.randn(B, A, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
