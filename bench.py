@@ -70,6 +70,11 @@ def _pick_threads(trial, ncpu):
         log[n] = round(dt, 3)
         if dt < tbest:
             best, tbest = n, dt
+        elif dt > 2.0 * tbest:
+            # past the knee the curve only gets worse (round 5's line: 0.33 s at 16 threads, 0.71 at 64, 2.4 at 128, 21.6 at 256):
+            # the larger counts are not tried -- they cost the default run a minute of wall time for nothing
+            log["stopped_after"] = n
+            break
     torch.set_num_threads(best)
     return best, log
 
@@ -112,7 +117,7 @@ def cpu_baseline_ppo(w, rollout_cpu, sd_cpu, cfg):
                 threads_tried_s=tried,
                 sample=f"oracle/ref_cpu.py ppo_update, warmed, {n_mb} actor + {n_mb} critic mini-batch steps of {mb} samples "
                        f"({t_upd:.1f} s) + full GAE ({t_gae * 1e3:.1f} ms), extrapolated to {cfg['n_updates']} epochs x "
-                       f"{T * N} samples per loop; {used} torch threads (fastest of {sorted(tried)} on {ncpu} host CPUs)")
+                       f"{T * N} samples per loop; {used} torch threads (fastest of {sorted(k_ for k_ in tried if isinstance(k_, int))} on {ncpu} host CPUs)")
 
 
 def cpu_baseline_dagger(d, net, ring_obs, ring_tea, stu_sd, tea_sd, tea_net, rows_total, proprio, mb=128):
@@ -137,7 +142,7 @@ def cpu_baseline_dagger(d, net, ring_obs, ring_tea, stu_sd, tea_sd, tea_net, row
     t_upd = per_row * rows_total
     return dict(value=d["N"] / t_upd, unit="env-steps/s", cores=used, kind="port", host_cpus=ncpu, threads_tried_s=tried,
                 sample=f"oracle/ref_cpu.py dagger_update, warmed, 3 mini-batch steps of {mb} ring rows ({t:.1f} s), extrapolated to "
-                       f"{rows_total} rows per update; {used} torch threads (fastest of {sorted(tried)} on {ncpu} host CPUs)")
+                       f"{rows_total} rows per update; {used} torch threads (fastest of {sorted(k_ for k_ in tried if isinstance(k_, int))} on {ncpu} host CPUs)")
 
 
 # ------------------------------------------------------------------------------------------------ DAgger
