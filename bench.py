@@ -60,7 +60,7 @@ def _pick_threads(trial, ncpu):
     the intra-op pool (round 1 measured 2.6x SLOWER per sample with 256 threads than the survey's 8-thread probe).
     Time a small warm-up pass at a few thread counts and keep the fastest; the passes double as the warm-up."""
     cand = sorted({n for n in (8, 16, 32, 64, 96, 128, ncpu // 2, ncpu) if 1 <= n <= ncpu})
-    best, tbest, log = cand[0], float("inf"), {}
+    best, tbest, log, worse = cand[0], float("inf"), {}, 0
     for n in cand:
         torch.set_num_threads(n)
         trial()                                        # first touch at this thread count (allocator, thread pool)
@@ -69,12 +69,15 @@ def _pick_threads(trial, ncpu):
         dt = time.perf_counter() - t0
         log[n] = round(dt, 3)
         if dt < tbest:
-            best, tbest = n, dt
-        elif dt > 2.0 * tbest:
-            # past the knee the curve only gets worse (round 5's line: 0.33 s at 16 threads, 0.71 at 64, 2.4 at 128, 21.6 at 256):
-            # the larger counts are not tried -- they cost the default run a minute of wall time for nothing
-            log["stopped_after"] = n
-            break
+            best, tbest, worse = n, dt, 0
+        else:
+            # past the knee the curve only gets worse (round 5's lines: 0.33 s at 16 threads, 0.71 at 64, 2.4 at 128, 21.6 at 256;
+            # SparseUNet 2.26 at 16, 2.56 at 64, 31.9 at 256): after two counts in a row that do not improve, or one that is 2 x
+            # slower, the larger counts are not tried -- they cost the default run two minutes of wall time for nothing
+            worse += 1
+            if worse >= 2 or dt > 2.0 * tbest:
+                log["stopped_after"] = n
+                break
     torch.set_num_threads(best)
     return best, log
 
