@@ -711,6 +711,12 @@ def run_ppo(args, device, rank, world):
             mfma_and_barriers_measured=4.58, operand_issue=0.28, valu_stages=0.57,
             valu_stage_parts=dict(layer1=0.095, layer2_tanh=0.087, saved_h2_copy=0.17, pooling=0.0, only_removable_together=0.22),
             sum_of_parts=4.58 + 0.28 + 0.57, measured_same_run=5.43, this_run=mean_ms,
+            counters=dict(source="tools/pmc_issue.sh over tools/time_enc.py, profiles/round6_c_pmc_issue_encoder.json (per SIMD, per launch)",
+                          launch_cycles=12.94e6, valu_mfma_coexec_cycles=0, mfma_busy_cycles=10.49e6, non_mfma_valu_insts=309e3,
+                          vmem_read_insts=24.3e3, lds_insts=42.3e3, sum_of_issue_cycles=12.64e6,
+                          note="SQ_VALU_MFMA_COEXEC_CYCLES = 0: VALU and MFMA work never overlapped on a SIMD; 10.49 M MFMA cycles + 309 k VALU "
+                               "instructions x 4 + 24.3 k VMEM reads x 27 + 42.3 k LDS instructions x 5 = 12.64 M of the launch's 12.94 M "
+                               "cycles -- the counters and the ablation builds give the same sum; pn_bwd16_kernel likewise (5.81 M of 5.79 M)"),
             note="MFMAs + the five barriers per tile alone: 4.58 ms (= the 4.37 ms of 5120 MFMAs per 64-point tile at 2.4 GHz, at the "
                  "~2.29 GHz the chip sustains under this load, barriers included); streaming the operands (ds_read_b128 + "
                  "global_load_dwordx4 per 16 MFMAs) +0.28; layer 1, the two tanh epilogues and the saved-layer-2 copy +0.57 "
