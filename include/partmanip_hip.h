@@ -358,6 +358,9 @@ int pm_ball_query_f32(const float* xyz, const float* centers, int B, int P, int 
                       int32_t* idx_out, void* stream);
 int pm_group_points_f32(const float* feat, const int32_t* idx, int B, int P, int C, int S, int nsample,
                         float* out, void* stream);
+/* (the gradient of the gather: per source point the sum of its rows of dout in ASCENDING row order -- one work-group per cloud inverts
+ * the index table in LDS, no floating-point atomics, every element of dfeat written -- when 2 P + S nsample <= ~15.7 k; larger
+ * tables: fp32 atomics into the zero-filled dfeat, summation order not fixed.  pm_group_concat_bwd_f32 alike.) */
 int pm_group_points_bwd_f32(const float* dout, const int32_t* idx, int B, int P, int C, int S, int nsample,
                             float* dfeat, void* stream);
 
@@ -365,7 +368,7 @@ int pm_group_points_bwd_f32(const float* dout, const int32_t* idx, int B, int P,
  * (absent from the reference; north-star mandated; parity unpinned, own oracle).
  * group_concat: out[b,s,j,:] = [xyz[b,idx]-centers[b,s] (3) | feat[b,idx,:] (Cf) | zero pad to ldo]
  * (the rows the shared per-point MLP consumes); its backward scatter-adds the feature columns
- * (dfeat zero-filled by the caller; fp32 atomics).  maxpool_rows: max over the nsample axis of
+ * (fixed-order sums like pm_group_points_bwd_f32; fp32 atomics into the zero-filled dfeat only beyond its size limit).  maxpool_rows: max over the nsample axis of
  * (G, nsample, C) with the lowest arg-max index; its backward writes every element of dx. */
 int pm_group_concat_f32(const float* xyz, const float* feat, const float* centers, const int32_t* idx, int B, int P,
                         int Cf, int S, int nsample, int ldo, float* out, void* stream);

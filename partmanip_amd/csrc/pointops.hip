@@ -304,6 +304,77 @@ __global__ __launch_bounds__(256) void group_points_kernel(const float* __restri
     }
 }
 
+// ---- the gradient of a row gather WITHOUT floating-point atomics ----------------------------------------------------------
+// dfeat[b, p, :] = sum over the cloud's rows r with idx[r] == p, in ASCENDING r, of dout[r, col0 : col0 + C].  One work-group per
+// cloud builds the inverse of its index table in LDS -- integer counts (LDS atomics: order-free), prefix, cursor fill, insertion sort
+// of every point's short list -- and then every (point, channel) is ONE sequential chain: bit-reproducible, every element of dfeat
+// written (no zero-fill needed).  Used when 2 P + rows-per-cloud ints fit 64 KB of LDS; beyond that the atomic kernels below run.
+#define SCAT_LDS_INTS (16000)
+__global__ __launch_bounds__(256) void scatter_rows_det_kernel(const float* __restrict__ dout, long ldo, int col0,
+                                                                const int32_t* __restrict__ idx, int P, int C, int rows_per_b,
+                                                                float* __restrict__ dfeat) {
+    extern __shared__ int sh[];                          // cnt[P + 1] | cur[P] | part[256] | list[rows_per_b]
+    int* cnt = sh;
+    int* cur = sh + P + 1;
+    int* part = cur + P;
+    int* list = part + 256;
+    const long b = blockIdx.x;
+    const int32_t* ib = idx + b * rows_per_b;
+    for (int p = threadIdx.x; p <= P; p += 256) cnt[p] = 0;
+    __syncthreads();
+    for (int r = threadIdx.x; r < rows_per_b; r += 256) atomicAdd(&cnt[ib[r]], 1);
+    __syncthreads();
+    const int per = (P + 255) / 256, lo = threadIdx.x * per, hi = lo + per < P ? lo + per : P;
+    int sum = 0;
+    for (int p = lo; p < hi; ++p) sum += cnt[p];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int p = lo; p < hi; ++p) {
+        cur[p] = run;
+        run += cnt[p];
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < rows_per_b; r += 256) list[atomicAdd(&cur[ib[r]], 1)] = r;
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += 256) {           // cur[p] is now the END of p's list
+        const int e = cur[p], s0 = e - cnt[p];
+        for (int i = s0 + 1; i < e; ++i) {
+            const int v = list[i];
+            int j = i - 1;
+            while (j >= s0 && list[j] > v) {
+                list[j + 1] = list[j];
+                --j;
+            }
+            list[j + 1] = v;
+        }
+    }
+    __syncthreads();
+    const float* db = dout + b * rows_per_b * ldo + col0;
+    float* fb = dfeat + b * (long)P * C;
+    for (long e = threadIdx.x; e < (long)P * C; e += 256) {
+        const int p = (int)(e / C), c = (int)(e - (long)p * C);
+        const int en = cur[p], s0 = en - cnt[p];
+        float acc = 0.f;
+        for (int j = s0; j < en; ++j) acc += db[(long)list[j] * ldo + c];
+        fb[e] = acc;
+    }
+}
+static bool scatter_rows_det(const float* dout, long ldo, int col0, const int32_t* idx, int B, int P, int C, int rows_per_b,
+                             float* dfeat, void* stream) {
+    const long ints = 2L * P + 1 + 256 + rows_per_b;
+    if (ints > SCAT_LDS_INTS) return false;
+    hipLaunchKernelGGL(scatter_rows_det_kernel, dim3(B), dim3(256), (size_t)ints * sizeof(int), pm_stream(stream), dout, ldo, col0, idx, P,
+                       C, rows_per_b, dfeat);
+    return true;
+}
+
 __global__ __launch_bounds__(256) void group_points_bwd_kernel(const float* __restrict__ dout,
                                                                 const int32_t* __restrict__ idx, int B, int P, int C,
                                                                 long n_rows, int rows_per_b,
@@ -329,10 +400,15 @@ extern "C" int pm_group_points_f32(const float* feat, const int32_t* idx, int B,
     return PM_OK;
 }
 
-// dfeat must be zero-filled by the caller; fp32 atomics (summation order is not fixed).
+// Deterministic (fixed ascending-row order per source point, scatter_rows_det_kernel) when 2 P + S nsample <= ~15.7 k; beyond that:
+// fp32 atomics into a dfeat the caller zero-filled (summation order not fixed).  Callers zero-fill either way.
 extern "C" int pm_group_points_bwd_f32(const float* dout, const int32_t* idx, int B, int P, int C, int S,
                                        int nsample, float* dfeat, void* stream) {
     PM_REQUIRE(dout && idx && dfeat && B > 0 && P > 0 && C > 0 && S > 0 && nsample > 0);
+    if (scatter_rows_det(dout, C, 0, idx, B, P, C, S * nsample, dfeat, stream)) {
+        PM_CHECK_LAUNCH();
+        return PM_OK;
+    }
     const long n_rows = (long)B * S * nsample;
     long nb = (n_rows * C + 255) / 256;
     if (nb > 4096) nb = 4096;
@@ -378,7 +454,7 @@ extern "C" int pm_group_concat_f32(const float* xyz, const float* feat, const fl
     return PM_OK;
 }
 
-// d feat[b, idx, :] += d out[row, 3:3+Cf]   (dfeat zero-filled by the caller; fp32 atomics)
+// d feat[b, idx, :] += d out[row, 3:3+Cf]   (dfeat zero-filled by the caller; fp32 atomics -- only for sizes beyond scatter_rows_det)
 __global__ __launch_bounds__(256) void group_concat_bwd_kernel(const float* __restrict__ dout,
                                                                 const int32_t* __restrict__ idx, int P, int Cf, int S,
                                                                 int ns, long n_rows, int ldo, float* __restrict__ dfeat) {
@@ -394,6 +470,10 @@ __global__ __launch_bounds__(256) void group_concat_bwd_kernel(const float* __re
 extern "C" int pm_group_concat_bwd_f32(const float* dout, const int32_t* idx, int B, int P, int Cf, int S, int nsample,
                                        int ldo, float* dfeat, void* stream) {
     PM_REQUIRE(dout && idx && dfeat && B > 0 && P > 0 && Cf > 0 && S > 0 && nsample > 0 && ldo >= 3 + Cf);
+    if (scatter_rows_det(dout, ldo, 3, idx, B, P, Cf, S * nsample, dfeat, stream)) {     // (as pm_group_points_bwd_f32)
+        PM_CHECK_LAUNCH();
+        return PM_OK;
+    }
     const long n_rows = (long)B * S * nsample;
     long nb = (n_rows * Cf + 255) / 256;
     if (nb > 8192) nb = 8192;

@@ -495,6 +495,26 @@ def test_ball_query_and_group_bit_exact(B, P, S, r, ns):
     for b in range(B):
         dref[b].index_add_(0, torch.from_numpy(ref[b].reshape(-1).astype(np.int64)), dout[b].reshape(-1, 7).double())
     assert rel_err(dfeat, dref) < 1e-5
+    # round 6: the gradient of the row gather runs in a fixed order (every source point's rows ascending: scatter_rows_det_kernel),
+    # not through fp32 atomics -- bit-reproducible, every element written (a NaN-filled destination comes back finite), and equal
+    # to the SEQUENTIAL fp32 sum in ascending row order; the same for the [xyz | feat | pad] rows of an unfused level (columns 3..)
+    seq = torch.zeros(B, P, 7)
+    for b in range(B):
+        rows, d_ = ref[b].reshape(-1), dout[b].reshape(-1, 7)
+        for r_ in range(rows.shape[0]):
+            seq[b, rows[r_]] += d_[r_]
+    assert torch.equal(dfeat.cpu(), seq)
+    for _ in range(3):
+        assert torch.equal(o.group_points_bwd(dout.to(DEV), idx, P), dfeat)
+    ldo = 12
+    drows = torch.randn(B * S * ns, ldo, generator=g)
+    dc = o.group_concat_bwd(drows.to(DEV), idx, B, P, 7, ldo)
+    seq2 = torch.zeros(B, P, 7)
+    for b in range(B):
+        rows = ref[b].reshape(-1)
+        for r_ in range(rows.shape[0]):
+            seq2[b, rows[r_]] += drows[b * S * ns + r_, 3:10]
+    assert torch.equal(dc.cpu(), seq2) and torch.equal(o.group_concat_bwd(drows.to(DEV), idx, B, P, 7, ldo), dc)
 
 
 def test_fast_tanh_accuracy():
